@@ -1,0 +1,267 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own functions.
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg /opt/conda/bin/python3.9 oracle/capture_goldens.py [G1 G2 ...]
+
+/opt/conda python3.9 has NumPy 1.26.4, SciPy 1.7.1, scikit-image 0.18.3, astropy
+4.3.1 -- everything the reference imports except cv2, FreeSimpleGUI and
+lsq-ellipse, which are stubbed as empty modules.
+Reference functions that never touch those modules run UNMODIFIED ("pinned").
+For functions that call cv2.blur / cv2.createCLAHE / cv2.circle / LsqEllipse the
+stub module is given this repo's own restatement of that primitive ("shim
+mode"): the logic around the primitive is then pinned byte for byte, the
+primitive itself is not (it is marked UNPINNED in oracle/shg_oracle.py).
+
+Only inputs and expected outputs are stored; no reference source is copied.
+"""
+import io
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+GOLD = os.path.join(REPO, 'tests', 'golden')
+REF = '/root/reference'
+
+for _n in ('cv2', 'FreeSimpleGUI', 'ellipse', 'skimage.data._fetchers'):
+    sys.modules[_n] = types.ModuleType(_n)
+sys.modules['ellipse'].LsqEllipse = object
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+
+import shg_oracle as orc                                  # noqa: E402  (shim primitives only)
+from solex_ser_recon_en_amd import synth                  # noqa: E402  (input generator only)
+
+import cv2                                                # noqa: E402  (the stub)
+import video_reader as ref_vr                             # noqa: E402
+import solex_util as ref_su                               # noqa: E402
+import ellipse_to_circle as ref_e2c                       # noqa: E402
+import Solex_recon as ref_sr                              # noqa: E402
+import CLI_handler as ref_cli                             # noqa: E402
+
+QUIET = {'output_dir': '', '_nolog': True, 'flag_display': False, 'clahe_only': True,
+         'protus_only': False, 'save_fit': False}
+
+
+def save(name, **arrays):
+    path = os.path.join(GOLD, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print('wrote', path, os.path.getsize(path), 'bytes')
+
+
+def tmp_ser(frames):
+    fd, path = tempfile.mkstemp(suffix='.ser')
+    os.close(fd)
+    synth.write_ser(path, frames)
+    return path
+
+
+def install_blur_shim():
+    def blur(img, ksize):
+        kw, kh = ksize
+        if img.dtype == np.uint16:
+            return orc.box_blur_u16(img, kw, kh)
+        return orc.box_blur_f64(img, kw, kh)
+    cv2.blur = blur
+
+
+# --------------------------------------------------------------------------
+def g1_mean_max():
+    """Reference compute_mean_max + video_reader, unmodified (pinned)."""
+    out = {}
+    cases = [('u16_rot', 24, 64, 20, 16), ('u16_norot', 24, 20, 64, 16),
+             ('u8_rot', 24, 64, 20, 8), ('u8_norot', 24, 20, 64, 8),
+             ('u16_odd', 7, 37, 11, 16)]       # odd sizes: exercises the non-vector path
+    for tag, n, w, h, bits in cases:
+        frames = synth.synth_frames_numpy(n, w, h, bits, seed=11)
+        path = tmp_ser(frames)
+        rdr = ref_vr.video_reader(path)
+        mean, mx = ref_su.compute_mean_max(rdr, QUIET, path[:-4])
+        os.remove(path)
+        out[tag + '_frames'] = frames
+        out[tag + '_mean'] = mean
+        out[tag + '_max'] = mx
+        out[tag + '_dims'] = np.array([rdr.ih, rdr.iw, rdr.FrameCount, int(rdr.flag_rotate)])
+    save('g1_mean_max', **out)
+
+
+def g2_extract():
+    """Reference read_video_improved, unmodified (pinned), incl. clamped columns and S=21."""
+    out = {}
+    for tag, n, w, h, bits in [('u16_rot', 20, 96, 40, 16), ('u16_norot', 20, 40, 96, 16),
+                               ('u8_rot', 20, 96, 40, 8), ('u16_odd', 9, 37, 29, 16)]:
+        frames = synth.synth_frames_numpy(n, w, h, bits, seed=5)
+        path = tmp_ser(frames)
+        rdr = ref_vr.video_reader(path)
+        ih, iw = rdr.ih, rdr.iw
+        # a curve that runs off both spectral edges so that the index clamps engage
+        curve = np.linspace(-6.3, iw + 4.7, ih) + 0.37 * np.sin(np.arange(ih))
+        fit = np.array([[np.floor(c), c - np.floor(c), y, c] for y, c in enumerate(curve)])
+        for stag, shifts in [('s2', [10, 0]), ('s21', list(dict.fromkeys([10, 0] + list(range(-10, 11))))),
+                             ('s3', [10, 0, -25])]:
+            opts = dict(QUIET, shift=shifts)
+            disks, _, _, _ = ref_su.read_video_improved(ref_vr.video_reader(path), fit, opts)
+            out[tag + '_' + stag + '_disks'] = np.stack(disks)
+            out[tag + '_' + stag + '_shifts'] = np.array(shifts)
+        os.remove(path)
+        out[tag + '_frames'] = frames
+        out[tag + '_fit'] = fit
+    save('g2_extract', **out)
+
+
+def _disk_image(h, w, seed, ratio=0.8, tilt=0.0):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    cx, cy = w / 2 + 1.5, h / 2 - 0.7
+    u = (xx - cx) + tilt * (yy - cy)
+    r2 = (u / (0.40 * w)) ** 2 + ((yy - cy) / (0.40 * w * ratio)) ** 2
+    img = np.where(r2 < 1, 0.35 + 0.65 * np.sqrt(np.clip(1 - r2, 0, 1)), 0.02)
+    img = img * (1 + 0.05 * rng.standard_normal((h, w)))
+    return np.clip(np.rint(img * 0.8 * 65535), 1, 65535).astype(np.uint16)
+
+
+def g3_warp():
+    """Reference correct_image (skimage 0.18.3 warp), unmodified (pinned)."""
+    out = {}
+    cases = [(0.0, 1.0), (0.0, 0.83), (0.05, 0.9), (-0.08, 1.12), (0.2, 0.75), (0.0, 1.25)]
+    img = _disk_image(60, 84, 3)
+    out['image_u16'] = img
+    for i, (phi, ratio) in enumerate(cases):
+        center = np.array([43.5, 29.3])
+        fixed, circle, mat3 = ref_e2c.correct_image(img / 65536, phi, ratio, center, 24.0, dict(QUIET), print_log=False)
+        out['c%d_params' % i] = np.array([phi, ratio, center[0], center[1], 24.0])
+        out['c%d_out' % i] = fixed
+        out['c%d_circle' % i] = np.array(circle)
+        out['c%d_mat3' % i] = mat3
+    # the no-ellipse call form of Solex_recon.py:123
+    fixed, circle, mat3 = ref_e2c.correct_image(img / 65536, 0.0, 1.0, np.array([-1.0, -1.0]), -1.0, dict(QUIET))
+    out['noellipse_out'] = fixed
+    out['noellipse_circle'] = np.array(circle)
+    save('g3_warp', **out)
+
+
+def g4_transversalium():
+    """Reference correct_transversalium2 (non-stubborn), unmodified (pinned)."""
+    out = {}
+    rng = np.random.default_rng(8)
+    img = _disk_image(150, 160, 4, ratio=1.0)
+    gain = 1 + 0.02 * rng.standard_normal(150)
+    img = np.clip(img * gain[:, None], 1, 65535).astype(np.uint16)
+    out['image'] = img
+    circle = (81.5, 74.3, 62.0)
+    borders = [18.2, 12.7, 143.9, 136.1]
+    for tag, ts in [('a', 301), ('b', 21)]:
+        opts = dict(QUIET, trans_strength=ts, stubborn_transversalium=False)
+        res = ref_su.correct_transversalium2(img, circle, borders, opts, 0, '/tmp/x')
+        out[tag + '_out'] = res
+        out[tag + '_c'] = opts['_transversalium_cache']
+        out[tag + '_strength'] = np.array(ts)
+    out['circle'] = np.array(circle)
+    out['borders'] = np.array(borders)
+    # backup-bounds call form, Solex_recon.py:146
+    opts = dict(QUIET, trans_strength=301, stubborn_transversalium=False)
+    bb = [0, 20 + 20, img.shape[1] - 1, 130 - 20]
+    res = ref_su.correct_transversalium2(img, (0, 0, 99999), bb, opts, 0, '/tmp/x')
+    out['bb_out'] = res
+    out['bb_c'] = opts['_transversalium_cache']
+    out['bb_borders'] = np.array(bb)
+    save('g4_transversalium', **out)
+
+
+def g5_rescale():
+    """Reference rescale_brightness + np.percentile (pinned)."""
+    out = {}
+    img = _disk_image(70, 90, 6)
+    out['image'] = img
+    bright = np.percentile(img, 99.9999)
+    out['bright'] = np.array(bright)
+    out['p10'] = np.array(np.percentile(img, 10))
+    out['hc'] = ref_su.rescale_brightness(img, bright * 0.25, bright)
+    out['protus'] = ref_su.rescale_brightness(img, 0, bright * 0.18)
+    out['alpha'] = ref_su.rescale_brightness(img, 1000.0, 50000.0, alpha=0.8)
+    img8 = (img >> 8).astype(np.uint8)
+    out['image8'] = img8
+    out['u8'] = ref_su.rescale_brightness(img8, 10.0, 200.0)
+    save('g5_rescale', **out)
+
+
+def g7_matrix():
+    """Reference get_correction_matrix table (pinned)."""
+    params = [(0.0, 1.0), (0.0, 0.8), (0.1, 0.9), (-0.2, 1.1), (0.7, 0.6), (-0.78, 1.4), (0.3, 1.0)]
+    mats = np.array([ref_e2c.get_correction_matrix(p, r)[0] for p, r in params])
+    thetas = np.array([ref_e2c.get_correction_matrix(p, r)[1] for p, r in params])
+    save('g7_matrix', params=np.array(params), mats=mats, thetas=thetas)
+
+
+def g8_fit_shim():
+    """Reference compute_mean_return_fit UNMODIFIED with cv2.blur := orc.box_blur (shim mode)."""
+    install_blur_shim()
+    out = {}
+    for tag, n, w, h, bits in [('u16_rot', 16, 180, 48, 16), ('u8_norot', 16, 48, 180, 8)]:
+        frames = synth.synth_frames_numpy(n, w, h, bits, seed=2, tilt=0.031, curv=2e-4)
+        path = tmp_ser(frames)
+        rdr = ref_vr.video_reader(path)
+        hdr = ref_su.make_header(rdr)
+        mean, fit, y1, y2 = ref_su.compute_mean_return_fit(ref_vr.video_reader(path), dict(QUIET), hdr,
+                                                           rdr.iw, rdr.ih, path[:-4])
+        _, mx = ref_su.compute_mean_max(ref_vr.video_reader(path), dict(QUIET), path[:-4])
+        os.remove(path)
+        out[tag + '_frames'] = frames
+        out[tag + '_mean'] = mean
+        out[tag + '_max'] = mx
+        out[tag + '_fit'] = fit
+        out[tag + '_y'] = np.array([y1, y2])
+    save('g8_fit_shim', **out)
+
+
+def g9_fits():
+    """astropy FITS bytes for a uint16 array with the reference's make_header cards."""
+    from astropy.io import fits
+
+    class R:
+        iw, ih = 7, 5
+    hdr = ref_su.make_header(R)
+    hdr['NAXIS1'] = 9                                     # Solex_recon.py:65
+    arr = (np.arange(45, dtype=np.uint16).reshape(5, 9) * 1500 + 7).astype(np.uint16)
+    buf = io.BytesIO()
+    fits.PrimaryHDU(arr, header=hdr).writeto(buf)
+    save('g9_fits', array=arr, fits_bytes=np.frombuffer(buf.getvalue(), dtype=np.uint8))
+
+
+def g10_cli():
+    """Reference CLI_handler.treat_flag_at_cli: argv -> options table (pinned)."""
+    import json
+    base = {'shift': [0], 'flag_display': False, 'ratio_fixe': None, 'slant_fix': None, 'save_fit': False,
+            'clahe_only': False, 'protus_only': False, 'disk_display': True, 'delta_radius': 0,
+            'crop_width_square': False, 'transversalium': True, 'flip_x': False, 'fixed_width': None}
+    cases = ['-w5', '-w-10:10:1', '-w1,2,-3', '-w-3:3', '-dcf', '-x', '-t', '-p', '-s', '-m', '-r1200',
+             '-cfw3,4', '-r800s', '-fw-2:2:2t', '-mw7']
+    table = {}
+    stdout = sys.stdout
+    for arg in cases:
+        opts = dict(base)
+        sys.stdout = io.StringIO()
+        try:
+            ref_cli.treat_flag_at_cli(opts, arg)
+        finally:
+            sys.stdout = stdout
+        table[arg] = opts
+    with open(os.path.join(GOLD, 'g10_cli.json'), 'w') as f:
+        json.dump(table, f, indent=1, sort_keys=True)
+    print('wrote g10_cli.json')
+
+
+ALL = dict(G1=g1_mean_max, G2=g2_extract, G3=g3_warp, G4=g4_transversalium, G5=g5_rescale,
+           G7=g7_matrix, G8=g8_fit_shim, G9=g9_fits, G10=g10_cli)
+
+if __name__ == '__main__':
+    os.makedirs(GOLD, exist_ok=True)
+    todo = sys.argv[1:] or list(ALL)
+    for key in todo:
+        ALL[key]()

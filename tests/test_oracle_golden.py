@@ -1,0 +1,151 @@
+"""The oracle (oracle/shg_oracle.py) against vectors produced by the reference's
+own functions (oracle/capture_goldens.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import shg_oracle as orc
+
+
+@pytest.mark.parametrize('tag', ['u16_rot', 'u16_norot', 'u8_rot', 'u8_norot', 'u16_odd'])
+def test_mean_max_bit_exact(golden, tag):
+    g = golden('g1_mean_max')
+    rdr = orc.SerReader(g[tag + '_frames'])
+    ih, iw, n, rot = g[tag + '_dims']
+    assert (rdr.ih, rdr.iw, rdr.FrameCount, int(rdr.flag_rotate)) == (ih, iw, n, rot)
+    mean, mx = orc.compute_mean_max(rdr)
+    assert mean.dtype == np.uint16 and mx.dtype == np.uint16
+    np.testing.assert_array_equal(mean, g[tag + '_mean'])
+    np.testing.assert_array_equal(mx, g[tag + '_max'])
+
+
+@pytest.mark.parametrize('tag', ['u16_rot', 'u16_norot', 'u8_rot', 'u16_odd'])
+@pytest.mark.parametrize('stag', ['s2', 's21', 's3'])
+def test_extract_bit_exact(golden, tag, stag):
+    g = golden('g2_extract')
+    shifts = [int(s) for s in g[tag + '_' + stag + '_shifts']]
+    disks = orc.extract_columns(orc.SerReader(g[tag + '_frames']), g[tag + '_fit'], shifts)
+    np.testing.assert_array_equal(np.stack(disks), g[tag + '_' + stag + '_disks'])
+
+
+def test_shift_list_order():
+    # Solex_recon.py:55
+    assert orc.shift_list(10, [0]) == [10, 0]
+    assert orc.shift_list(10, list(range(-10, 11))) == [10, 0] + [s for s in range(-10, 11) if s not in (10, 0)]
+    assert orc.shift_list(10, [10]) == [10, 0]
+    assert orc.shift_list(0, [3]) == [0, 3]
+
+
+def test_correction_matrix(golden):
+    g = golden('g7_matrix')
+    for (phi, r), mat, theta in zip(g['params'], g['mats'], g['thetas']):
+        m, t = orc.correction_matrix(phi, r)
+        np.testing.assert_allclose(m, mat, rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(t, theta, rtol=1e-13, atol=1e-15)
+        assert m[1, 0] == 0 and m[1, 1] == 1
+
+
+def test_warp_bit_exact(golden):
+    g = golden('g3_warp')
+    img = g['image_u16'] / 65536
+    for i in range(6):
+        phi, ratio, cx, cy, height = g['c%d_params' % i]
+        out, circle, mat3 = orc.correct_image(img, phi, ratio, np.array([cx, cy]), height)
+        assert out.shape == g['c%d_out' % i].shape
+        np.testing.assert_array_equal(out, g['c%d_out' % i])
+        np.testing.assert_allclose(circle, g['c%d_circle' % i], rtol=1e-12)
+        np.testing.assert_allclose(mat3, g['c%d_mat3' % i], rtol=1e-12, atol=1e-14)
+    out, circle, _ = orc.correct_image(img, 0.0, 1.0, np.array([-1.0, -1.0]), -1.0)
+    np.testing.assert_array_equal(out, g['noellipse_out'])
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_transversalium(golden, tag):
+    g = golden('g4_transversalium')
+    out, c = orc.correct_transversalium2(g['image'], tuple(g['circle']), list(g['borders']), int(g[tag + '_strength']))
+    np.testing.assert_allclose(c, g[tag + '_c'], rtol=1e-12)
+    # the factors agree to ~1e-15 across SciPy versions; a truncation flip needs img*c within that of an integer
+    assert np.count_nonzero(out != g[tag + '_out']) == 0
+
+
+def test_transversalium_backup_bounds(golden):
+    g = golden('g4_transversalium')
+    out, c = orc.correct_transversalium2(g['image'], (0, 0, 99999), list(g['bb_borders']), 301)
+    np.testing.assert_allclose(c, g['bb_c'], rtol=1e-12)
+    np.testing.assert_array_equal(out, g['bb_out'])
+
+
+def test_rescale_and_percentile(golden):
+    g = golden('g5_rescale')
+    img = g['image']
+    bright = np.percentile(img, 99.9999)
+    assert bright == float(g['bright'])
+    assert np.percentile(img, 10) == float(g['p10'])
+    np.testing.assert_array_equal(orc.rescale_brightness(img, bright * 0.25, bright), g['hc'])
+    np.testing.assert_array_equal(orc.rescale_brightness(img, 0, bright * 0.18), g['protus'])
+    np.testing.assert_array_equal(orc.rescale_brightness(img, 1000.0, 50000.0, alpha=0.8), g['alpha'])
+    np.testing.assert_array_equal(orc.rescale_brightness(g['image8'], 10.0, 200.0), g['u8'])
+
+
+@pytest.mark.parametrize('tag', ['u16_rot', 'u8_norot'])
+def test_line_fit_shim_mode(golden, tag):
+    """Reference compute_mean_return_fit ran unmodified with cv2.blur := orc.box_blur_u16."""
+    g = golden('g8_fit_shim')
+    mean, mx = orc.compute_mean_max(orc.SerReader(g[tag + '_frames']))
+    np.testing.assert_array_equal(mean, g[tag + '_mean'])
+    np.testing.assert_array_equal(mx, g[tag + '_max'])
+    fit, y1, y2, p, _ = orc.line_fit(mean, mx)
+    assert (y1, y2) == tuple(g[tag + '_y'])
+    ref = g[tag + '_fit']
+    away = np.abs(ref[:, 3] - np.rint(ref[:, 3])) > 1e-9      # floor() is only stable away from integers
+    np.testing.assert_array_equal(fit[away, 0], ref[away, 0])
+    np.testing.assert_array_equal(fit[:, 2], ref[:, 2])
+    # np.polyfit differs by ~1e-13 between NumPy builds (LAPACK); curve values agree to that level
+    np.testing.assert_allclose(fit[:, 3], ref[:, 3], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(fit[away, 1], ref[away, 1], rtol=0, atol=1e-9)
+
+
+# ---- known-answer tests for the UNPINNED third-party primitives ------------
+def test_box_blur_known_answers():
+    img = np.zeros((9, 16), np.uint16)
+    img[4, 8] = 900
+    b = orc.box_blur_u16(img, 3, 3)
+    assert b[3:6, 7:10].tolist() == [[100] * 3] * 3 and b.sum() == 900
+    const = np.full((12, 24), 1234, np.uint16)
+    assert (orc.box_blur_u16(const, 25, 7) == 1234).all()         # reflect-101 borders keep a constant
+    ramp = np.tile(np.arange(32, dtype=np.uint16) * 10, (6, 1))
+    b = orc.box_blur_u16(ramp, 5, 1)
+    assert (b[:, 2:-2] == ramp[:, 2:-2]).all()                    # symmetric window on a ramp
+    assert b[0, 0] == round((0 + 10 + 20 + 10 + 20) / 5)          # reflect-101: cols -2,-1 -> 2,1
+    # even kernel: anchor k//2 -> window [-2, 1]
+    b = orc.box_blur_u16(ramp, 4, 1)
+    assert b[0, 10] == round((80 + 90 + 100 + 110) / 4)
+
+
+def test_clahe_known_answers():
+    const = np.full((40, 60), 30000, np.uint16)
+    out = orc.clahe(const, 0.8, 2)
+    assert len(np.unique(out)) == 1
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 65536, (64, 64)).astype(np.uint16)
+    out = orc.clahe(img, 0.8, 2)
+    assert out.dtype == np.uint16 and out.shape == img.shape
+    # with clip = 1 every bin is <= 1 + redistribution: the LUT is ~the identity ramp
+    assert np.abs(out.astype(int) - img.astype(int)).max() < 4000
+    img8 = rng.integers(0, 256, (31, 45)).astype(np.uint8)       # ragged: padded tiles
+    out8 = orc.clahe(img8, 0.8, 3)
+    assert out8.dtype == np.uint8 and out8.shape == img8.shape
+    # monotone: CLAHE LUTs are non-decreasing, and so is the blend of them at one pixel position
+    a = np.full((32, 32), 100, np.uint16); b = a.copy(); b[5, 5] = 200
+    assert orc.clahe(b, 0.8, 2)[5, 5] >= orc.clahe(a, 0.8, 2)[5, 5]
+
+
+def test_filled_circle_known_answers():
+    img = np.zeros((21, 21), np.uint16)
+    orc.filled_circle(img, 10, 10, 5, 80)
+    assert img[10, 5] == 80 and img[10, 15] == 80 and img[10, 4] == 0 and img[5, 10] == 80 and img[4, 10] == 0
+    assert (img == img.T).all() and (img == img[::-1]).all()
+    area = int((img == 80).sum())
+    assert abs(area - np.pi * 25) < 12
+    img = np.zeros((10, 10), np.uint16)
+    orc.filled_circle(img, 0, 0, 4, 7)       # clipped at the image corner
+    assert img[0, 0] == 7 and img[0, 4] == 7 and img[0, 5] == 0
