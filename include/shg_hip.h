@@ -1,0 +1,156 @@
+/*
+ * shg_hip.h -- C ABI of libshg_hip.so, the MI355X (gfx950) implementation of the
+ * SHG reconstruction hot path of thelondonsmiths/Solex_ser_recon_EN.
+ *
+ * The reference is pure Python and has no FFI; the seam is its set of Python
+ * functions.  Each entry point below replaces the NumPy /
+ * OpenCV / scikit-image call sites named in its comment (reference file:line).
+ * The only consumer is a ctypes binding (solex_ser_recon_en_amd/_lib.py); the
+ * binding a reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its name starts with host_;
+ *  - the caller owns every buffer; the library allocates nothing;
+ *  - `stream` is a hipStream_t (0 = default stream); all calls are asynchronous
+ *    with respect to that stream and re-entrant;
+ *  - return value: 0 = OK, >0 = hipError_t, <0 = SHG_E_* argument error; the
+ *    message is available per thread from shg_last_error_string();
+ *  - "file layout" = the SER frame as stored: [Height][Width], little-endian,
+ *    1 or 2 bytes per pixel.  When Width > Height the reference rotates every
+ *    frame (video_reader.py:119-120): img[y][x] = raw[x][Width-1-y], ih = Width,
+ *    iw = Height.  The kernels never materialise that rotation for the stack.
+ */
+#ifndef SHG_HIP_H
+#define SHG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHG_ABI_VERSION 1
+
+#define SHG_E_ARG        (-1)   /* bad argument (null pointer, non-positive size, ...) */
+#define SHG_E_WORKSPACE  (-2)   /* workspace too small                                 */
+#define SHG_E_UNSUPPORTED (-3)  /* size outside what the kernel supports               */
+
+typedef void* shg_stream_t;
+
+int         shg_abi_version(void);
+const char* shg_last_error_string(void);
+
+/* ---- pass A: sum and max over frames -------- solex_util.py:174-188 (compute_mean_max)
+ * stack: n_frames frames in file layout.  sum_out[H*W] (file layout) receives the
+ * integer sum of the raw samples, max_out[H*W] their maximum (raw sample units;
+ * the 8-bit x256 scaling of video_reader.py:121-122 is applied in
+ * shg_finalize_mean_max).  Integer sums are order independent, so the result is
+ * bit-identical for any sharding of the frames (RCCL SUM / MAX all-reduce). */
+size_t shg_accumulate_workspace_bytes(int64_t n_frames, int64_t height, int64_t width, int bytes_per_px);
+int shg_accumulate_sum_max(const void* stack, int64_t n_frames, int64_t height, int64_t width,
+                           int bytes_per_px, uint64_t* sum_out, uint16_t* max_out,
+                           void* workspace, size_t workspace_bytes, shg_stream_t stream);
+
+/* mean = trunc(sum / n_total) as uint16 (solex_util.py:188), 8-bit samples scaled by
+ * 256, both images rotated into the reference's [ih][iw] orientation. */
+int shg_finalize_mean_max(const uint64_t* sum, const uint16_t* max_raw, int64_t n_total,
+                          int64_t height, int64_t width, int bytes_per_px,
+                          uint16_t* mean_out, uint16_t* max_out, shg_stream_t stream);
+
+/* ---- cv2.blur(img_u16, (kw, kh)) ------------- solex_util.py:166, 230
+ * Normalised box filter, anchor (kw/2, kh/2), BORDER_REFLECT_101, round half even.
+ * tmp: uint32 scratch of h*w elements. */
+int shg_box_blur_u16(const uint16_t* src, int64_t h, int64_t w, int kw, int kh,
+                     uint16_t* dst, uint32_t* tmp, shg_stream_t stream);
+
+/* first-occurrence argmin over columns [x0, x1) of every row: np.argmin(img[:, x0:x1], axis=1)
+ * (solex_util.py:231, 242).  out[h] int32, relative to x0. */
+int shg_row_argmin_u16(const uint16_t* img, int64_t h, int64_t w, int64_t x0, int64_t x1,
+                       int32_t* out, shg_stream_t stream);
+
+/* np.mean(img, axis=1) in float64 (solex_util.py:167). out[h]. */
+int shg_row_mean_u16(const uint16_t* img, int64_t h, int64_t w, double* out, shg_stream_t stream);
+
+/* ---- pass B: per-frame column extraction ----- solex_util.py:93-144 (read_video_improved)
+ * For every frame k, shift s and slit row y:
+ *     v = img[y][ind_l[s][y]] * lw[y] + img[y][ind_l[s][y] + 1] * rw[y]     (float64,
+ *         two rounded products and one rounded add, no FMA; solex_util.py:131-133)
+ *     disks[s][y][col(k)] = (uint16) v                                        (truncation, :134)
+ * with col(k) = k_offset + k, or n_cols - 1 - (k_offset + k) when flip_x != 0
+ * (np.flip(axis=1), Solex_recon.py:74-76).  ind_l is [n_shifts][ih] int32, already
+ * clamped to [0, iw-2] (solex_util.py:114-119); lw, rw are [ih] float64, NOT adjusted
+ * for the clamp (solex_util.py:122-123).  disks: n_shifts planes of plane_stride
+ * elements, rows of row_pitch elements (row_pitch >= n_cols). */
+int shg_extract_columns(const void* stack, int64_t n_frames, int64_t height, int64_t width,
+                        int bytes_per_px, const int32_t* ind_l, const double* lw, const double* rw,
+                        int n_shifts, uint16_t* disks, int64_t row_pitch, int64_t plane_stride,
+                        int64_t n_cols, int64_t k_offset, int flip_x, shg_stream_t stream);
+
+/* ---- the warp ---------------------------------- ellipse_to_circle.py:112-118
+ * skimage.transform.warp(order=1, mode='constant', cval=image[0,0], clip) for a
+ * transform that never moves rows: out[r][c] samples input row r at
+ * x = h00*c + h01*r + h02 (float64), bilinear, then clip to [min, max] of the input
+ * and (uint16)(65536 * v).  The input is the uint16 disk, interpreted as
+ * value/65536 (Solex_recon.py:123, ellipse_to_circle.py:299).  minmax: 2 uint32
+ * device scratch words (written by the call). */
+int shg_warp_rows_u16(const uint16_t* src, int64_t h, int64_t w, int64_t src_pitch,
+                      double h00, double h01, double h02,
+                      uint16_t* dst, int64_t out_h, int64_t out_w, int64_t dst_pitch,
+                      uint32_t* minmax, shg_stream_t stream);
+
+/* ---- transversalium ---------------------------- solex_util.py:383-395, 76-86
+ * Per row y in (y1, y2): the mean of the 2-MAD inliers of log(img[y][a:b] / img[y-1][a:b])
+ * with a, b the chord of `circle` clipped to `borders` (float64).  out[y2 - y1]
+ * (out[0] = 0 as solex_util.py:386).  xa, xb: int32 [y2-y1] column bounds computed on the
+ * host (solex_util.py:389-391).  Rows longer than SHG_TRANSV_MAX_COLS are rejected. */
+#define SHG_TRANSV_MAX_COLS 8192
+int shg_rowpair_logratio_stats(const uint16_t* img, int64_t h, int64_t w, int64_t pitch,
+                               int64_t y1, int64_t y2, const int32_t* xa, const int32_t* xb,
+                               double* out, shg_stream_t stream);
+
+/* ret = min(img * c[y], 65535) truncated to uint16 (solex_util.py:489, 515-516). */
+int shg_scale_rows_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, const double* c,
+                       uint16_t* dst, int64_t dst_pitch, shg_stream_t stream);
+
+/* ---- crop / pad -------------------------------- Solex_recon.py:155-171
+ * dst[h][nw] = fill everywhere, then dst[:, dx0:dx0+n] = src[:, sx0:sx0+n]. */
+int shg_crop_pad_u16(const uint16_t* src, int64_t h, int64_t w, int64_t pitch,
+                     uint16_t* dst, int64_t nw, int64_t dst_pitch,
+                     int64_t sx0, int64_t dx0, int64_t n, uint16_t fill, shg_stream_t stream);
+
+/* ---- CLAHE -------------------------------------- solex_util.py:532-533, clahe_apply.py:247
+ * cv2.createCLAHE(clipLimit, (tiles, tiles)).apply(img) for uint16 (hist_size 65536)
+ * or uint8 (hist_size 256) images.  workspace: tiles*tiles*hist_size uint32 histograms
+ * followed by tiles*tiles*hist_size LUT entries (uint16); query the size first. */
+size_t shg_clahe_workspace_bytes(int tiles, int bytes_per_px);
+int shg_clahe(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_per_px,
+              double clip_limit, int tiles, void* dst, int64_t dst_pitch,
+              void* workspace, size_t workspace_bytes, shg_stream_t stream);
+
+/* 65536-bin (or 256-bin) histogram of an image; hist is zeroed by the call.  Feeds
+ * np.percentile / np.max on the host (solex_util.py:535-537). */
+int shg_hist(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_per_px,
+             uint32_t* hist, shg_stream_t stream);
+
+/* rescale_brightness: trunc(clamp((sat*alpha)*(v-lo)/(hi-lo), 0, sat)), float64, sat = 65535
+ * (solex_util.py:519-525). */
+int shg_rescale_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch,
+                    double lo, double hi, double alpha, uint16_t* dst, int64_t dst_pitch,
+                    shg_stream_t stream);
+
+/* cv2.circle(img, (x0, y0), r, value, -1): filled integer midpoint circle, clipped to the
+ * image (solex_util.py:542-547).  scratch: r + 1 int32 words. */
+int shg_fill_disc_u16(uint16_t* img, int64_t h, int64_t w, int64_t pitch,
+                      int64_t x0, int64_t y0, int64_t r, uint16_t value, int32_t* scratch,
+                      shg_stream_t stream);
+
+/* skimage.transform.downscale_local_mean(img/65536, (f, f)) (ellipse_to_circle.py:299-302):
+ * zero-padded block mean, float64 out [ceil(h/f)][ceil(w/f)]. */
+int shg_downscale_mean_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, int factor,
+                           double* dst, shg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHG_HIP_H */

@@ -1,0 +1,67 @@
+"""ctypes binding of libshg_hip.so (C ABI declared in include/shg_hip.h).
+
+There is deliberately NO fallback: if the HIP library has not been built the
+import raises, and every entry point raises RuntimeError on a non-zero status
+(message from shg_last_error_string), which propagates out of solex_do_work
+exactly like an exception inside the reference's pool worker does
+(Solex_recon.py:42).
+"""
+import ctypes
+import os
+from ctypes import c_double, c_int, c_int32, c_int64, c_size_t, c_uint16, c_void_p
+
+import torch  # noqa: F401  -- loads torch's own libamdhip64.so first so that ours binds to the same HIP runtime
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libshg_hip.so')
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        'libshg_hip.so is missing (%s). Build it with `python -c "import __graft_entry__ as g; g.build()"` or '
+        '`make -C solex_ser_recon_en_amd/csrc`. There is no CPU fallback for the SHG hot path.' % LIB_PATH)
+
+lib = ctypes.CDLL(LIB_PATH)
+
+P = c_void_p
+SIGNATURES = {
+    'shg_abi_version': (c_int, []),
+    'shg_last_error_string': (ctypes.c_char_p, []),
+    'shg_accumulate_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int64, c_int]),
+    'shg_accumulate_sum_max': (c_int, [P, c_int64, c_int64, c_int64, c_int, P, P, P, c_size_t, P]),
+    'shg_finalize_mean_max': (c_int, [P, P, c_int64, c_int64, c_int64, c_int, P, P, P]),
+    'shg_box_blur_u16': (c_int, [P, c_int64, c_int64, c_int, c_int, P, P, P]),
+    'shg_row_argmin_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int64, P, P]),
+    'shg_row_mean_u16': (c_int, [P, c_int64, c_int64, P, P]),
+    'shg_extract_columns': (c_int, [P, c_int64, c_int64, c_int64, c_int, P, P, P, c_int, P, c_int64, c_int64,
+                                    c_int64, c_int64, c_int, P]),
+    'shg_warp_rows_u16': (c_int, [P, c_int64, c_int64, c_int64, c_double, c_double, c_double, P, c_int64, c_int64,
+                                  c_int64, P, P]),
+    'shg_rowpair_logratio_stats': (c_int, [P, c_int64, c_int64, c_int64, c_int64, c_int64, P, P, P, P]),
+    'shg_scale_rows_u16': (c_int, [P, c_int64, c_int64, c_int64, P, P, c_int64, P]),
+    'shg_crop_pad_u16': (c_int, [P, c_int64, c_int64, c_int64, P, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                 c_uint16, P]),
+    'shg_clahe_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'shg_clahe': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_double, c_int, P, c_int64, P, c_size_t, P]),
+    'shg_hist': (c_int, [P, c_int64, c_int64, c_int64, c_int, P, P]),
+    'shg_rescale_u16': (c_int, [P, c_int64, c_int64, c_int64, c_double, c_double, c_double, P, c_int64, P]),
+    'shg_fill_disc_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_uint16, P, P]),
+    'shg_downscale_mean_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int, P, P]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)      # AttributeError here = the library does not match include/shg_hip.h
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+ABI_VERSION = 1
+if lib.shg_abi_version() != ABI_VERSION:
+    raise ImportError('libshg_hip.so ABI %d != expected %d: rebuild it' % (lib.shg_abi_version(), ABI_VERSION))
+
+
+def last_error():
+    return lib.shg_last_error_string().decode('utf-8', 'replace')
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError('%s failed (status %d): %s' % (what, status, last_error()))

@@ -1,0 +1,270 @@
+// Pass A: sum and max of every pixel over the frame stack.
+// Replaces the frame loop of compute_mean_max (reference solex_util.py:174-188).
+//
+// HBM-bound streaming read: N*H*W*B bytes in, 6..10 bytes per pixel out.  Layout:
+// the stack stays in file layout [N][H*W]; a lane owns 16 contiguous bytes of the
+// frame (8 u16 / 16 u8 pixels) and walks the frame axis, so every wave-instruction
+// is one fully coalesced 1 KiB global_load_dwordx4.  The frame axis is cut into
+// `nsplit` ranges so that the grid has >= ~16 waves per CU; each range writes a
+// partial (u32 sum, u16 max) slab that k_reduce_partials folds (integer, order
+// independent, so any split / any rank sharding gives identical bits).
+#include <stdlib.h>
+#include "shg_common.h"
+
+namespace {
+
+typedef unsigned short __attribute__((ext_vector_type(2))) ushort2_t;
+typedef unsigned int __attribute__((ext_vector_type(4))) u32x4;   // native vector: nontemporal-loadable
+
+struct Plan {
+    int64_t npix, frame_bytes, vecs;   // vecs = 16-byte vectors per frame (vector path only)
+    int nsplit, frames_per_split, unroll;
+    bool vector_path;
+};
+
+int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+Plan make_plan(const void* stack, int64_t n, int64_t h, int64_t w, int bpp) {
+    Plan p;
+    p.npix = h * w;
+    p.frame_bytes = p.npix * bpp;
+    // the alignment of `stack` is only known at call time; hipMalloc/torch give >= 256 B,
+    // so the workspace query (stack == nullptr) assumes an aligned base
+    p.vector_path = (p.frame_bytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(stack) & 15) == 0);
+    p.vecs = p.frame_bytes / 16;
+    const int64_t blocks_x = p.vector_path ? (p.vecs + 255) / 256 : (p.npix + 255) / 256;
+    const int target_blocks = env_int("SHG_ACC_TARGET_BLOCKS", 1024);   // 4096 waves = 16 per CU
+    int64_t nsplit = (target_blocks + blocks_x - 1) / blocks_x;
+    if (nsplit > n) nsplit = n;
+    if (nsplit > 64) nsplit = 64;
+    if (nsplit < 1) nsplit = 1;
+    const int forced = env_int("SHG_ACC_NSPLIT", 0);
+    if (forced > 0) nsplit = forced > n ? n : forced;
+    p.nsplit = (int)nsplit;
+    p.frames_per_split = (int)((n + nsplit - 1) / nsplit);
+    p.unroll = env_int("SHG_ACC_UNROLL", 8);
+    return p;
+}
+
+template <int BPP>
+struct Acc;
+
+template <>
+struct Acc<2> {
+    static constexpr int PX = 8;
+    uint32_t sum[8];
+    uint32_t mx[4];   // packed u16 pairs
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sum[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mx[i] = 0;
+    }
+    __device__ __forceinline__ void add_dword(int i, uint32_t d) {
+        sum[2 * i] += d & 0xffffu;
+        sum[2 * i + 1] += d >> 16;
+        ushort2_t a = __builtin_bit_cast(ushort2_t, mx[i]);
+        ushort2_t b = __builtin_bit_cast(ushort2_t, d);
+        mx[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(a, b));   // v_pk_max_u16
+    }
+    __device__ __forceinline__ void add(const u32x4& r) {
+        add_dword(0, r.x); add_dword(1, r.y); add_dword(2, r.z); add_dword(3, r.w);
+    }
+    __device__ __forceinline__ void store(uint32_t* ps, uint16_t* pm) const {
+        uint4* s4 = reinterpret_cast<uint4*>(ps);
+        s4[0] = make_uint4(sum[0], sum[1], sum[2], sum[3]);
+        s4[1] = make_uint4(sum[4], sum[5], sum[6], sum[7]);
+        *reinterpret_cast<uint4*>(pm) = make_uint4(mx[0], mx[1], mx[2], mx[3]);
+    }
+};
+
+template <>
+struct Acc<1> {
+    static constexpr int PX = 16;
+    uint32_t sum[16];
+    uint32_t mx[16];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sum[i] = 0; mx[i] = 0; }
+    }
+    __device__ __forceinline__ void add_dword(int i, uint32_t d) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t v = (d >> (8 * b)) & 0xffu;
+            sum[4 * i + b] += v;
+            mx[4 * i + b] = mx[4 * i + b] > v ? mx[4 * i + b] : v;
+        }
+    }
+    __device__ __forceinline__ void add(const u32x4& r) {
+        add_dword(0, r.x); add_dword(1, r.y); add_dword(2, r.z); add_dword(3, r.w);
+    }
+    __device__ __forceinline__ void store(uint32_t* ps, uint16_t* pm) const {
+        uint4* s4 = reinterpret_cast<uint4*>(ps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s4[i] = make_uint4(sum[4 * i], sum[4 * i + 1], sum[4 * i + 2], sum[4 * i + 3]);
+        uint4* m4 = reinterpret_cast<uint4*>(pm);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            m4[i] = make_uint4(mx[8 * i] | (mx[8 * i + 1] << 16), mx[8 * i + 2] | (mx[8 * i + 3] << 16),
+                               mx[8 * i + 4] | (mx[8 * i + 5] << 16), mx[8 * i + 6] | (mx[8 * i + 7] << 16));
+    }
+};
+
+// grid: (ceil(vecs/256), nsplit).  One lane = 16 bytes of the frame, all frames of its split.
+template <int BPP, int UNROLL>
+__global__ __launch_bounds__(256) void k_accumulate_vec(const u32x4* __restrict__ stack, int64_t vecs,
+                                                        int n_frames, int frames_per_split,
+                                                        uint32_t* __restrict__ psum, uint16_t* __restrict__ pmax,
+                                                        int64_t npix) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= vecs) return;
+    const int split = blockIdx.y;
+    const int k0 = split * frames_per_split;
+    const int k1 = min(n_frames, k0 + frames_per_split);
+    Acc<BPP> acc;
+    acc.init();
+    const u32x4* p = stack + (int64_t)k0 * vecs + v;
+    int k = k0;
+    for (; k + UNROLL <= k1; k += UNROLL) {
+        u32x4 r[UNROLL];
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) r[j] = __builtin_nontemporal_load(p + (int64_t)j * vecs);
+        p += (int64_t)UNROLL * vecs;
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) acc.add(r[j]);
+    }
+    for (; k < k1; ++k) {
+        acc.add(__builtin_nontemporal_load(p));
+        p += vecs;
+    }
+    const int64_t pix = v * Acc<BPP>::PX;
+    acc.store(psum + (int64_t)split * npix + pix, pmax + (int64_t)split * npix + pix);
+}
+
+// Generic path (frame size not a multiple of 16 bytes, or unaligned base): one lane per pixel.
+template <typename T>
+__global__ __launch_bounds__(256) void k_accumulate_scalar(const T* __restrict__ stack, int64_t npix, int n_frames,
+                                                           int frames_per_split, uint32_t* __restrict__ psum,
+                                                           uint16_t* __restrict__ pmax) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const int split = blockIdx.y;
+    const int k0 = split * frames_per_split;
+    const int k1 = min(n_frames, k0 + frames_per_split);
+    uint32_t s = 0, m = 0;
+    for (int k = k0; k < k1; ++k) {
+        const uint32_t v = stack[(int64_t)k * npix + i];
+        s += v;
+        m = m > v ? m : v;
+    }
+    psum[(int64_t)split * npix + i] = s;
+    pmax[(int64_t)split * npix + i] = (uint16_t)m;
+}
+
+__global__ __launch_bounds__(256) void k_reduce_partials(const uint32_t* __restrict__ psum, const uint16_t* __restrict__ pmax,
+                                                         int nsplit, int64_t npix, uint64_t* __restrict__ sum_out,
+                                                         uint16_t* __restrict__ max_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    uint64_t s = 0;
+    uint32_t m = 0;
+    for (int j = 0; j < nsplit; ++j) {
+        s += psum[(int64_t)j * npix + i];
+        const uint32_t v = pmax[(int64_t)j * npix + i];
+        m = m > v ? m : v;
+    }
+    sum_out[i] = s;
+    max_out[i] = (uint16_t)m;
+}
+
+// mean = sum // n (== trunc(float64(sum)/n) for sums < 2^53, solex_util.py:188), x256 for 8-bit
+// (video_reader.py:121-122), rotated: out[y][x] = in[x][W-1-y] when W > H (video_reader.py:119-120).
+__global__ __launch_bounds__(256) void k_finalize(const uint64_t* __restrict__ sum, const uint16_t* __restrict__ mx,
+                                                  uint64_t n_total, int64_t height, int64_t width, int scale,
+                                                  uint16_t* __restrict__ mean_out, uint16_t* __restrict__ max_out) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= height * width) return;
+    int64_t src;
+    if (width > height) {
+        const int64_t iw = height;
+        const int64_t y = o / iw, x = o - y * iw;
+        src = x * width + (width - 1 - y);
+    } else {
+        src = o;
+    }
+    mean_out[o] = (uint16_t)((sum[src] * (uint64_t)scale) / n_total);
+    max_out[o] = (uint16_t)(mx[src] * scale);
+}
+
+template <int BPP>
+void launch_vec(const Plan& p, const void* stack, int n, uint32_t* psum, uint16_t* pmax, hipStream_t st) {
+    dim3 grid((unsigned)((p.vecs + 255) / 256), (unsigned)p.nsplit);
+    const u32x4* s = static_cast<const u32x4*>(stack);
+    switch (p.unroll) {
+        case 2: k_accumulate_vec<BPP, 2><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); break;
+        case 4: k_accumulate_vec<BPP, 4><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); break;
+        case 16: k_accumulate_vec<BPP, 16><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); break;
+        default: k_accumulate_vec<BPP, 8><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); break;
+    }
+}
+
+size_t slab_bytes(const Plan& p) {
+    // u32 sums then u16 maxima; npix*4*nsplit is 16-byte aligned on the vector path
+    return (size_t)p.nsplit * (size_t)p.npix * 6 + 64;
+}
+
+}  // namespace
+
+extern "C" size_t shg_accumulate_workspace_bytes(int64_t n_frames, int64_t height, int64_t width, int bytes_per_px) {
+    if (n_frames <= 0 || height <= 0 || width <= 0 || (bytes_per_px != 1 && bytes_per_px != 2)) return 0;
+    return slab_bytes(make_plan(nullptr, n_frames, height, width, bytes_per_px));
+}
+
+extern "C" int shg_accumulate_sum_max(const void* stack, int64_t n_frames, int64_t height, int64_t width,
+                                      int bytes_per_px, uint64_t* sum_out, uint16_t* max_out,
+                                      void* workspace, size_t workspace_bytes, shg_stream_t stream) {
+    SHG_REQUIRE(stack && sum_out && max_out && workspace, SHG_E_ARG, "shg_accumulate_sum_max: null pointer");
+    SHG_REQUIRE(n_frames > 0 && height > 0 && width > 0, SHG_E_ARG, "shg_accumulate_sum_max: empty stack (%lld x %lld x %lld)",
+                (long long)n_frames, (long long)height, (long long)width);
+    SHG_REQUIRE(bytes_per_px == 1 || bytes_per_px == 2, SHG_E_ARG, "shg_accumulate_sum_max: bytes_per_px must be 1 or 2");
+    SHG_REQUIRE(n_frames < (1ll << 31), SHG_E_UNSUPPORTED, "shg_accumulate_sum_max: too many frames");
+    Plan p = make_plan(stack, n_frames, height, width, bytes_per_px);
+    // a u32 partial holds 65537 frames of 16-bit samples
+    SHG_REQUIRE(p.frames_per_split <= 65537, SHG_E_UNSUPPORTED, "shg_accumulate_sum_max: %d frames per split overflow u32",
+                p.frames_per_split);
+    SHG_REQUIRE(workspace_bytes >= slab_bytes(p), SHG_E_WORKSPACE, "shg_accumulate_sum_max: workspace %zu < %zu bytes",
+                workspace_bytes, slab_bytes(p));
+    SHG_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, SHG_E_ARG, "shg_accumulate_sum_max: workspace not 16-byte aligned");
+    hipStream_t st = shg::as_stream(stream);
+    uint32_t* psum = static_cast<uint32_t*>(workspace);
+    uint16_t* pmax = reinterpret_cast<uint16_t*>(psum + (size_t)p.nsplit * p.npix);
+    const int n = (int)n_frames;
+    if (p.vector_path) {
+        if (bytes_per_px == 2) launch_vec<2>(p, stack, n, psum, pmax, st);
+        else launch_vec<1>(p, stack, n, psum, pmax, st);
+    } else {
+        dim3 grid((unsigned)((p.npix + 255) / 256), (unsigned)p.nsplit);
+        if (bytes_per_px == 2)
+            k_accumulate_scalar<uint16_t><<<grid, 256, 0, st>>>(static_cast<const uint16_t*>(stack), p.npix, n, p.frames_per_split, psum, pmax);
+        else
+            k_accumulate_scalar<uint8_t><<<grid, 256, 0, st>>>(static_cast<const uint8_t*>(stack), p.npix, n, p.frames_per_split, psum, pmax);
+    }
+    if (int e = shg::check_launch("k_accumulate")) return e;
+    k_reduce_partials<<<(unsigned)((p.npix + 255) / 256), 256, 0, st>>>(psum, pmax, p.nsplit, p.npix, sum_out, max_out);
+    return shg::check_launch("k_reduce_partials");
+}
+
+extern "C" int shg_finalize_mean_max(const uint64_t* sum, const uint16_t* max_raw, int64_t n_total,
+                                     int64_t height, int64_t width, int bytes_per_px,
+                                     uint16_t* mean_out, uint16_t* max_out, shg_stream_t stream) {
+    SHG_REQUIRE(sum && max_raw && mean_out && max_out, SHG_E_ARG, "shg_finalize_mean_max: null pointer");
+    SHG_REQUIRE(n_total > 0 && height > 0 && width > 0, SHG_E_ARG, "shg_finalize_mean_max: bad size");
+    SHG_REQUIRE(bytes_per_px == 1 || bytes_per_px == 2, SHG_E_ARG, "shg_finalize_mean_max: bytes_per_px must be 1 or 2");
+    const int64_t npix = height * width;
+    k_finalize<<<(unsigned)((npix + 255) / 256), 256, 0, shg::as_stream(stream)>>>(
+        sum, max_raw, (uint64_t)n_total, height, width, bytes_per_px == 1 ? 256 : 1, mean_out, max_out);
+    return shg::check_launch("k_finalize");
+}

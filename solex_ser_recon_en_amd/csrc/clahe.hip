@@ -1,0 +1,307 @@
+// CLAHE and image histograms.
+// Replaces cv2.createCLAHE(clipLimit, (t, t)).apply() (reference solex_util.py:532-533,
+// clahe_apply.py:247) and feeds np.percentile / np.max (solex_util.py:535-537).
+// Restated from OpenCV 4.x imgproc/clahe.cpp: per-tile histogram -> clip ->
+// redistribute -> cumulative LUT (float32 scale, round half even) -> per-pixel
+// bilinear blend of the four neighbouring tile LUTs in float32, unfused.
+//
+// The image is a few MB, so the stage is bound by the 65536-bin histogram scatter
+// and by launch latency, not by HBM streaming.  Histogram: every workgroup owns a
+// private 65536 x u16 LDS histogram (128 KiB) for a slice of <= 65535 pixels of one
+// tile and flushes only its non-zero bins with global atomics.
+#include "shg_common.h"
+
+namespace {
+
+constexpr int HIST16 = 65536;
+constexpr int SLICE_PX = 32768;        // pixels per workgroup (< 65536 so that u16 counters cannot wrap)
+
+// pixel (ty, tx, i) -> source coordinates with the bottom/right REFLECT_101 extension
+template <typename T>
+__device__ __forceinline__ uint32_t ext_pixel(const T* img, int64_t h, int64_t w, int64_t pitch, int64_t y, int64_t x) {
+    if (y >= h) y = shg::reflect101(y, h);
+    if (x >= w) x = shg::reflect101(x, w);
+    return img[y * pitch + x];
+}
+
+// grid: (slices_per_tile, tiles*tiles).  16-bit images: LDS-private u16 histogram.
+__global__ __launch_bounds__(1024) void k_tile_hist16(const uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch,
+                                                      int tiles, int64_t th, int64_t tw, uint32_t* __restrict__ hist) {
+    extern __shared__ uint32_t lh[];   // HIST16/2 dwords, two u16 counters each
+    const int tile = blockIdx.y;
+    const int64_t ty = tile / tiles, tx = tile % tiles;
+    const int64_t area = th * tw;
+    const int64_t p0 = (int64_t)blockIdx.x * SLICE_PX;
+    const int64_t p1 = p0 + SLICE_PX < area ? p0 + SLICE_PX : area;
+    for (int i = threadIdx.x; i < HIST16 / 2; i += 1024) lh[i] = 0;
+    __syncthreads();
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += 1024) {
+        const int64_t yy = p / tw, xx = p - yy * tw;
+        const uint32_t v = ext_pixel(img, h, w, pitch, ty * th + yy, tx * tw + xx);
+        atomicAdd(&lh[v >> 1], (v & 1) ? 0x10000u : 1u);
+    }
+    __syncthreads();
+    uint32_t* gh = hist + (int64_t)tile * HIST16;
+    for (int i = threadIdx.x; i < HIST16 / 2; i += 1024) {
+        const uint32_t c = lh[i];
+        if (c & 0xffffu) atomicAdd(&gh[2 * i], c & 0xffffu);
+        if (c >> 16) atomicAdd(&gh[2 * i + 1], c >> 16);
+    }
+}
+
+// 8-bit images: 256 bins, LDS-private u32 histogram
+__global__ __launch_bounds__(256) void k_tile_hist8(const uint8_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch,
+                                                    int tiles, int64_t th, int64_t tw, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[256];
+    const int tile = blockIdx.y;
+    const int64_t ty = tile / tiles, tx = tile % tiles;
+    const int64_t area = th * tw;
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < area; p += (int64_t)gridDim.x * 256) {
+        const int64_t yy = p / tw, xx = p - yy * tw;
+        atomicAdd(&lh[ext_pixel(img, h, w, pitch, ty * th + yy, tx * tw + xx)], 1u);
+    }
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&hist[(int64_t)tile * 256 + threadIdx.x], lh[threadIdx.x]);
+}
+
+// One workgroup per tile: clip, redistribute, prefix-sum, scale.  1024 lanes x (hist/1024) bins.
+template <int HIST>
+__global__ __launch_bounds__(1024) void k_tile_lut(const uint32_t* __restrict__ hist, int clip, float lut_scale,
+                                                   uint16_t* __restrict__ lut) {
+    constexpr int PER = HIST >= 1024 ? HIST / 1024 : 1;
+    constexpr int ACTIVE = HIST >= 1024 ? 1024 : HIST;
+    __shared__ int wsum[16];
+    __shared__ int total_clipped;
+    const int tile = blockIdx.x;
+    const uint32_t* hin = hist + (int64_t)tile * HIST;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const bool active = tid < ACTIVE;
+    int bins[PER];
+    int clipped = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        int c = active ? (int)hin[tid * PER + j] : 0;
+        if (clip > 0 && c > clip) { clipped += c - clip; c = clip; }
+        bins[j] = c;
+    }
+    // workgroup total of the clipped excess
+    int v = clipped;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if (lane == 0) wsum[wave] = v;
+    __syncthreads();
+    if (tid == 0) {
+        int s = 0;
+        for (int i = 0; i < 16; ++i) s += wsum[i];
+        total_clipped = s;
+    }
+    __syncthreads();
+    const int excess = total_clipped;
+    int local = 0;
+    if (clip > 0) {
+        const int batch = excess / HIST;
+        const int residual = excess - batch * HIST;
+        const int step = residual != 0 ? max(HIST / residual, 1) : 1;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int i = tid * PER + j;
+            int c = bins[j] + batch;
+            // for (i = 0; i < histSize && residual > 0; i += step, residual--) hist[i]++
+            if (residual != 0 && (i % step) == 0 && (i / step) < residual) c += 1;
+            bins[j] = c;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) local += bins[j];
+    // exclusive scan of `local` across the workgroup
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < wave; ++i) base += wsum[i];
+    int run = base + incl - local;
+    if (active) {
+        uint16_t* lout = lut + (int64_t)tile * HIST;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            run += bins[j];
+            int r = __float2int_rn(__int2float_rn(run) * lut_scale);     // saturate_cast<T>(sum * lutScale)
+            r = r < 0 ? 0 : (r > HIST - 1 ? HIST - 1 : r);
+            lout[tid * PER + j] = (uint16_t)r;
+        }
+    }
+}
+
+template <typename T, int HIST>
+__global__ __launch_bounds__(256) void k_clahe_interp(const T* __restrict__ img, int64_t h, int64_t w, int64_t pitch,
+                                                      int tiles, float inv_tw, float inv_th,
+                                                      const uint16_t* __restrict__ lut, T* __restrict__ dst, int64_t dst_pitch) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t y = blockIdx.y;
+    if (x >= w) return;
+    const float txf = (float)(int)x * inv_tw - 0.5f;
+    int tx1 = (int)floorf(txf);
+    int tx2 = tx1 + 1;
+    const float xa = txf - (float)tx1;
+    const float xa1 = 1.0f - xa;
+    tx1 = max(tx1, 0);
+    tx2 = min(tx2, tiles - 1);
+    const float tyf = (float)(int)y * inv_th - 0.5f;
+    int ty1 = (int)floorf(tyf);
+    int ty2 = ty1 + 1;
+    const float ya = tyf - (float)ty1;
+    const float ya1 = 1.0f - ya;
+    ty1 = max(ty1, 0);
+    ty2 = min(ty2, tiles - 1);
+    const int v = img[y * pitch + x];
+    const uint16_t* p1 = lut + (int64_t)(ty1 * tiles) * HIST + v;
+    const uint16_t* p2 = lut + (int64_t)(ty2 * tiles) * HIST + v;
+    const float l11 = (float)(int)p1[(int64_t)tx1 * HIST], l12 = (float)(int)p1[(int64_t)tx2 * HIST];
+    const float l21 = (float)(int)p2[(int64_t)tx1 * HIST], l22 = (float)(int)p2[(int64_t)tx2 * HIST];
+    const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+    int r = __float2int_rn(res);
+    r = r < 0 ? 0 : (r > HIST - 1 ? HIST - 1 : r);
+    dst[y * dst_pitch + x] = (T)r;
+}
+
+// whole-image histogram (65536 or 256 bins) with the same LDS privatisation
+__global__ __launch_bounds__(1024) void k_image_hist16(const uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch,
+                                                       uint32_t* __restrict__ hist) {
+    extern __shared__ uint32_t lh[];
+    const int64_t n = h * w;
+    const int64_t p0 = (int64_t)blockIdx.x * SLICE_PX;
+    const int64_t p1 = p0 + SLICE_PX < n ? p0 + SLICE_PX : n;
+    for (int i = threadIdx.x; i < HIST16 / 2; i += 1024) lh[i] = 0;
+    __syncthreads();
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += 1024) {
+        const int64_t y = p / w, x = p - y * w;
+        const uint32_t v = img[y * pitch + x];
+        atomicAdd(&lh[v >> 1], (v & 1) ? 0x10000u : 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HIST16 / 2; i += 1024) {
+        const uint32_t c = lh[i];
+        if (c & 0xffffu) atomicAdd(&hist[2 * i], c & 0xffffu);
+        if (c >> 16) atomicAdd(&hist[2 * i + 1], c >> 16);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_image_hist8(const uint8_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch,
+                                                     uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[256];
+    const int64_t n = h * w;
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (int64_t)gridDim.x * 256) {
+        const int64_t y = p / w, x = p - y * w;
+        atomicAdd(&lh[img[y * pitch + x]], 1u);
+    }
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+}
+
+void ensure_lds_attr() {
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_image_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
+        done = true;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t shg_clahe_workspace_bytes(int tiles, int bytes_per_px) {
+    if (tiles < 1 || tiles > 16 || (bytes_per_px != 1 && bytes_per_px != 2)) return 0;
+    const size_t hist = bytes_per_px == 1 ? 256 : HIST16;
+    return (size_t)tiles * tiles * hist * (sizeof(uint32_t) + sizeof(uint16_t));
+}
+
+extern "C" int shg_clahe(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_per_px, double clip_limit, int tiles,
+                         void* dst, int64_t dst_pitch, void* workspace, size_t workspace_bytes, shg_stream_t stream) {
+    SHG_REQUIRE(img && dst && workspace, SHG_E_ARG, "shg_clahe: null pointer");
+    SHG_REQUIRE(h > 0 && w > 0 && pitch >= w && dst_pitch >= w, SHG_E_ARG, "shg_clahe: bad image size");
+    SHG_REQUIRE(bytes_per_px == 1 || bytes_per_px == 2, SHG_E_ARG, "shg_clahe: bytes_per_px must be 1 or 2");
+    SHG_REQUIRE(tiles >= 1 && tiles <= 16, SHG_E_UNSUPPORTED, "shg_clahe: tiles must be in 1..16");
+    SHG_REQUIRE(h < 65536, SHG_E_UNSUPPORTED, "shg_clahe: more than 65535 rows");
+    SHG_REQUIRE(workspace_bytes >= shg_clahe_workspace_bytes(tiles, bytes_per_px), SHG_E_WORKSPACE, "shg_clahe: workspace too small");
+    // a reflect-101 extension needs at least `tiles` + 1 pixels along an extended axis
+    SHG_REQUIRE((h % tiles == 0 && w % tiles == 0) || (h > tiles && w > tiles), SHG_E_UNSUPPORTED, "shg_clahe: image smaller than the tile grid");
+    hipStream_t st = shg::as_stream(stream);
+    const int hist_size = bytes_per_px == 1 ? 256 : HIST16;
+    const int ntiles = tiles * tiles;
+    int64_t he = h, we = w;
+    if (!(w % tiles == 0 && h % tiles == 0)) {   // copyMakeBorder(0, t - h%t, 0, t - w%t, REFLECT_101), clahe.cpp
+        he = h + (tiles - h % tiles);
+        we = w + (tiles - w % tiles);
+    }
+    const int64_t th = he / tiles, tw = we / tiles;
+    const int64_t area = th * tw;
+    SHG_REQUIRE(area < (1ll << 31), SHG_E_UNSUPPORTED, "shg_clahe: tile too large");
+    const float lut_scale = (float)(hist_size - 1) / (float)area;
+    int clip = 0;
+    if (clip_limit > 0.0) {
+        clip = (int)(clip_limit * (double)area / hist_size);
+        clip = clip > 1 ? clip : 1;
+    }
+    uint32_t* hist = static_cast<uint32_t*>(workspace);
+    uint16_t* lut = reinterpret_cast<uint16_t*>(hist + (size_t)ntiles * hist_size);
+    if (hipError_t e = hipMemsetAsync(hist, 0, (size_t)ntiles * hist_size * sizeof(uint32_t), st)) {
+        shg::set_error("shg_clahe: memset: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    const float inv_tw = 1.0f / (float)tw, inv_th = 1.0f / (float)th;
+    dim3 igrid((unsigned)((w + 255) / 256), (unsigned)h);
+    if (bytes_per_px == 2) {
+        ensure_lds_attr();
+        dim3 hgrid((unsigned)((area + SLICE_PX - 1) / SLICE_PX), (unsigned)ntiles);
+        k_tile_hist16<<<hgrid, 1024, HIST16 * 2, st>>>(static_cast<const uint16_t*>(img), h, w, pitch, tiles, th, tw, hist);
+        if (int e = shg::check_launch("k_tile_hist16")) return e;
+        k_tile_lut<HIST16><<<ntiles, 1024, 0, st>>>(hist, clip, lut_scale, lut);
+        if (int e = shg::check_launch("k_tile_lut")) return e;
+        k_clahe_interp<uint16_t, HIST16><<<igrid, 256, 0, st>>>(static_cast<const uint16_t*>(img), h, w, pitch, tiles, inv_tw, inv_th,
+                                                                lut, static_cast<uint16_t*>(dst), dst_pitch);
+    } else {
+        int64_t hb = (area + 4095) / 4096;
+        if (hb > 256) hb = 256;
+        dim3 hgrid((unsigned)hb, (unsigned)ntiles);
+        k_tile_hist8<<<hgrid, 256, 0, st>>>(static_cast<const uint8_t*>(img), h, w, pitch, tiles, th, tw, hist);
+        if (int e = shg::check_launch("k_tile_hist8")) return e;
+        k_tile_lut<256><<<ntiles, 1024, 0, st>>>(hist, clip, lut_scale, lut);
+        if (int e = shg::check_launch("k_tile_lut")) return e;
+        k_clahe_interp<uint8_t, 256><<<igrid, 256, 0, st>>>(static_cast<const uint8_t*>(img), h, w, pitch, tiles, inv_tw, inv_th, lut,
+                                                            static_cast<uint8_t*>(dst), dst_pitch);
+    }
+    return shg::check_launch("k_clahe_interp");
+}
+
+extern "C" int shg_hist(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_per_px, uint32_t* hist, shg_stream_t stream) {
+    SHG_REQUIRE(img && hist, SHG_E_ARG, "shg_hist: null pointer");
+    SHG_REQUIRE(h > 0 && w > 0 && pitch >= w, SHG_E_ARG, "shg_hist: bad image size");
+    SHG_REQUIRE(bytes_per_px == 1 || bytes_per_px == 2, SHG_E_ARG, "shg_hist: bytes_per_px must be 1 or 2");
+    hipStream_t st = shg::as_stream(stream);
+    const int hist_size = bytes_per_px == 1 ? 256 : HIST16;
+    if (hipError_t e = hipMemsetAsync(hist, 0, (size_t)hist_size * sizeof(uint32_t), st)) {
+        shg::set_error("shg_hist: memset: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    const int64_t n = h * w;
+    if (bytes_per_px == 2) {
+        ensure_lds_attr();
+        k_image_hist16<<<(unsigned)((n + SLICE_PX - 1) / SLICE_PX), 1024, HIST16 * 2, st>>>(static_cast<const uint16_t*>(img), h, w, pitch, hist);
+    } else {
+        int64_t hb = (n + 4095) / 4096;
+        if (hb > 256) hb = 256;
+        k_image_hist8<<<(unsigned)hb, 256, 0, st>>>(static_cast<const uint8_t*>(img), h, w, pitch, hist);
+    }
+    return shg::check_launch("k_image_hist");
+}

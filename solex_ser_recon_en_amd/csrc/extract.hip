@@ -1,0 +1,137 @@
+// Pass B: per-frame column extraction along the fitted line -> raw disks.
+// Replaces the frame loop of read_video_improved (reference solex_util.py:93-144).
+//
+// Algorithmic traffic is tiny (2 samples in, 1 sample out per frame, shift and slit
+// row) and the access pattern is a gather, so the design goal is sector efficiency:
+//  * a lane owns one slit row y; consecutive lanes are consecutive y.  For rotated
+//    files (Width > Height, the usual SER) y runs along the file's column axis, so
+//    the 64 lanes of a wave read one contiguous 128-byte run of a file row;
+//  * a workgroup builds a [shift][64 rows][64 frames] tile in LDS (row stride padded to
+//    66 elements -> conflict-free 2-byte column writes) and writes it out as 128-byte
+//    row segments, 16 bytes per lane, instead of 2-byte scattered stores.
+// Arithmetic is float64 with separately rounded products (compile with
+// -ffp-contract=off) and a truncating store, to be bit-exact with NumPy.
+#include "shg_common.h"
+
+namespace {
+
+constexpr int TY = 64;        // slit rows per workgroup (= lanes of a wave)
+constexpr int TK = 64;        // output columns (frames) per workgroup
+constexpr int TKP = TK + 2;   // padded LDS row stride (33 dwords: odd)
+constexpr int SC = 4;         // shifts per workgroup
+
+template <typename T, bool ROT>
+__global__ __launch_bounds__(256) void k_extract(const T* __restrict__ stack, int n_frames, int64_t height, int64_t width,
+                                                 const int32_t* __restrict__ ind_l, const double* __restrict__ lw,
+                                                 const double* __restrict__ rw, int n_shifts,
+                                                 uint16_t* __restrict__ disks, int64_t row_pitch, int64_t plane_stride,
+                                                 int64_t n_cols, int64_t k_offset, int flip_x, int vec_store) {
+    __shared__ uint16_t tile[SC][TY][TKP];
+    const int64_t ih = ROT ? width : height;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t c0 = (int64_t)blockIdx.x * TK;           // first output column of this workgroup
+    const int64_t y = (int64_t)blockIdx.y * TY + lane;
+    const int s0 = blockIdx.z * SC;
+    const int ns = min(SC, n_shifts - s0);
+    const bool y_ok = y < ih;
+    const int64_t npix = height * width;
+    constexpr int scale = sizeof(T) == 1 ? 256 : 1;        // video_reader.py:121-122
+
+    int il[SC];
+    double wl = 0.0, wr = 0.0;
+    if (y_ok) {
+        wl = lw[y];
+        wr = rw[y];
+    }
+#pragma unroll
+    for (int s = 0; s < SC; ++s) il[s] = (y_ok && s < ns) ? ind_l[(int64_t)(s0 + s) * ih + y] : 0;
+
+    // element offset of the left sample inside a frame, and the distance to the right one
+    int64_t off[SC];
+    const int64_t step = ROT ? width : 1;
+#pragma unroll
+    for (int s = 0; s < SC; ++s) off[s] = ROT ? (int64_t)il[s] * width + (width - 1 - y) : y * width + il[s];
+
+#pragma unroll 2
+    for (int cc = wave; cc < TK; cc += 4) {
+        const int64_t col = c0 + cc;
+        const int64_t k = (flip_x ? (n_cols - 1 - col) : col) - k_offset;   // wave-uniform
+        if (col >= n_cols || k < 0 || k >= n_frames) continue;
+        if (!y_ok) continue;
+        const T* f = stack + k * npix;
+#pragma unroll
+        for (int s = 0; s < SC; ++s) {
+            if (s < ns) {
+                const double l = (double)((int)f[off[s]] * scale);
+                const double r = (double)((int)f[off[s] + step] * scale);
+                const double v = l * wl + r * wr;
+                tile[s][lane][cc] = (uint16_t)(int)v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // write-out: one 16-byte segment (8 columns) per lane, 8 lanes per row
+    const int seg = threadIdx.x & 7;
+    const int r0 = threadIdx.x >> 3;      // 0..31
+    for (int s = 0; s < ns; ++s) {
+        uint16_t* plane = disks + (int64_t)(s0 + s) * plane_stride;
+        for (int r = r0; r < TY; r += 32) {
+            const int64_t yy = (int64_t)blockIdx.y * TY + r;
+            if (yy >= ih) break;
+            const int64_t col = c0 + seg * 8;
+            uint16_t* dst = plane + yy * row_pitch + col;
+            const uint16_t* src = &tile[s][r][seg * 8];
+            if (vec_store && col + 8 <= n_cols) {
+                // the tile only holds columns whose frame this rank owns
+                const int64_t ka = (flip_x ? (n_cols - 1 - col) : col) - k_offset;
+                const int64_t kb = (flip_x ? (n_cols - 1 - (col + 7)) : (col + 7)) - k_offset;
+                if (ka >= 0 && ka < n_frames && kb >= 0 && kb < n_frames) {
+                    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(s32[0], s32[1], s32[2], s32[3]);
+                    continue;
+                }
+            }
+            for (int j = 0; j < 8; ++j) {
+                const int64_t cj = col + j;
+                const int64_t kj = (flip_x ? (n_cols - 1 - cj) : cj) - k_offset;
+                if (cj < n_cols && kj >= 0 && kj < n_frames) dst[j] = src[j];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int shg_extract_columns(const void* stack, int64_t n_frames, int64_t height, int64_t width,
+                                   int bytes_per_px, const int32_t* ind_l, const double* lw, const double* rw,
+                                   int n_shifts, uint16_t* disks, int64_t row_pitch, int64_t plane_stride,
+                                   int64_t n_cols, int64_t k_offset, int flip_x, shg_stream_t stream) {
+    SHG_REQUIRE(stack && ind_l && lw && rw && disks, SHG_E_ARG, "shg_extract_columns: null pointer");
+    SHG_REQUIRE(n_frames > 0 && height > 0 && width > 0 && n_shifts > 0, SHG_E_ARG, "shg_extract_columns: empty input");
+    SHG_REQUIRE(bytes_per_px == 1 || bytes_per_px == 2, SHG_E_ARG, "shg_extract_columns: bytes_per_px must be 1 or 2");
+    SHG_REQUIRE(n_frames < (1ll << 31), SHG_E_UNSUPPORTED, "shg_extract_columns: too many frames");
+    SHG_REQUIRE(n_cols >= n_frames && k_offset >= 0 && k_offset + n_frames <= n_cols, SHG_E_ARG,
+                "shg_extract_columns: frames [%lld, %lld) do not fit %lld columns", (long long)k_offset,
+                (long long)(k_offset + n_frames), (long long)n_cols);
+    SHG_REQUIRE(row_pitch >= n_cols, SHG_E_ARG, "shg_extract_columns: row_pitch < n_cols");
+    SHG_REQUIRE((height < width ? height : width) >= 2, SHG_E_ARG, "shg_extract_columns: spectral axis needs >= 2 pixels");
+    const bool rot = width > height;
+    const int64_t ih = rot ? width : height;
+    // the tile's 16-byte row segments land on 16-byte boundaries when every row does
+    const int vec_store = ((reinterpret_cast<uintptr_t>(disks) & 15) == 0) && (row_pitch % 8 == 0) && (plane_stride % 8 == 0);
+    dim3 grid((unsigned)((n_cols + TK - 1) / TK), (unsigned)((ih + TY - 1) / TY), (unsigned)((n_shifts + SC - 1) / SC));
+    hipStream_t st = shg::as_stream(stream);
+    const int n = (int)n_frames;
+#define SHG_LAUNCH(T, ROT)                                                                                              \
+    k_extract<T, ROT><<<grid, 256, 0, st>>>(static_cast<const T*>(stack), n, height, width, ind_l, lw, rw, n_shifts, \
+                                            disks, row_pitch, plane_stride, n_cols, k_offset, flip_x, vec_store)
+    if (bytes_per_px == 2) {
+        if (rot) SHG_LAUNCH(uint16_t, true); else SHG_LAUNCH(uint16_t, false);
+    } else {
+        if (rot) SHG_LAUNCH(uint8_t, true); else SHG_LAUNCH(uint8_t, false);
+    }
+#undef SHG_LAUNCH
+    return shg::check_launch("k_extract");
+}

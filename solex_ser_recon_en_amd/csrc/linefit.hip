@@ -1,0 +1,111 @@
+// Device parts of the spectral-line detection on the mean / max image:
+// box blur (cv2.blur), row arg-minimum, row mean.  Reference call sites:
+// solex_util.py:165-172 (detect_bord), 228-231, 242 (compute_mean_return_fit).
+// The images are one frame in size (<= ~1 MB): these kernels are latency-, not
+// bandwidth-bound; they exist so that the mean/max images never leave HBM.
+#include "shg_common.h"
+
+namespace {
+
+// horizontal window sums with BORDER_REFLECT_101, anchor kw/2
+__global__ __launch_bounds__(256) void k_box_rows(const uint16_t* __restrict__ src, int64_t h, int64_t w, int kw,
+                                                  uint32_t* __restrict__ tmp) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= h * w) return;
+    const int64_t y = i / w, x = i - y * w;
+    const uint16_t* row = src + y * w;
+    const int64_t xa = x - kw / 2;
+    uint32_t s = 0;
+    if (xa >= 0 && xa + kw <= w) {
+        for (int j = 0; j < kw; ++j) s += row[xa + j];
+    } else {
+        for (int j = 0; j < kw; ++j) s += row[shg::reflect101(xa + j, w)];
+    }
+    tmp[i] = s;
+}
+
+// vertical window sums, then the OpenCV ColumnSum<int, ushort> scaling: float32 multiply for
+// the SIMD lanes (columns below the last multiple of 8), double for the scalar tail; both
+// round half to even and saturate.
+__global__ __launch_bounds__(256) void k_box_cols(const uint32_t* __restrict__ tmp, int64_t h, int64_t w, int kh,
+                                                  double scale, uint16_t* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= h * w) return;
+    const int64_t y = i / w, x = i - y * w;
+    const int64_t ya = y - kh / 2;
+    uint32_t s = 0;
+    for (int j = 0; j < kh; ++j) s += tmp[shg::reflect101(ya + j, h) * w + x];
+    int r;
+    if (x < (w / 8) * 8) r = __float2int_rn(__int2float_rn((int)s) * (float)scale);
+    else r = __double2int_rn((double)(int)s * scale);
+    dst[i] = (uint16_t)(r < 0 ? 0 : (r > 65535 ? 65535 : r));
+}
+
+// one wave per row; first occurrence of the minimum over [x0, x1)
+__global__ __launch_bounds__(256) void k_row_argmin(const uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t x0,
+                                                    int64_t x1, int32_t* __restrict__ out) {
+    const int64_t y = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (y >= h) return;
+    const int lane = threadIdx.x & 63;
+    const uint16_t* row = img + y * w;
+    uint32_t best = 0xffffffffu;           // (value << 16 | index-in-chunk) does not fit: keep key = value, idx separate
+    int32_t best_i = 0x7fffffff;
+    for (int64_t x = x0 + lane; x < x1; x += 64) {
+        const uint32_t v = row[x];
+        if (v < best) { best = v; best_i = (int32_t)(x - x0); }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t ov = __shfl_xor(best, d);
+        const int32_t oi = __shfl_xor(best_i, d);
+        if (ov < best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+    }
+    if (lane == 0) out[y] = best_i;
+}
+
+// np.mean(axis=1): exact integer row sum, one correctly rounded float64 division
+__global__ __launch_bounds__(256) void k_row_mean(const uint16_t* __restrict__ img, int64_t h, int64_t w,
+                                                  double* __restrict__ out) {
+    const int64_t y = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (y >= h) return;
+    const int lane = threadIdx.x & 63;
+    const uint16_t* row = img + y * w;
+    uint64_t s = 0;
+    for (int64_t x = lane; x < w; x += 64) s += row[x];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) out[y] = (double)s / (double)w;
+}
+
+}  // namespace
+
+extern "C" int shg_box_blur_u16(const uint16_t* src, int64_t h, int64_t w, int kw, int kh, uint16_t* dst, uint32_t* tmp,
+                                shg_stream_t stream) {
+    SHG_REQUIRE(src && dst && tmp, SHG_E_ARG, "shg_box_blur_u16: null pointer");
+    SHG_REQUIRE(h > 0 && w > 0, SHG_E_ARG, "shg_box_blur_u16: empty image");
+    // cv2.blur raises for a zero-sized kernel (the reference's hidden precondition at solex_util.py:229-230)
+    SHG_REQUIRE(kw > 0 && kh > 0, SHG_E_ARG, "shg_box_blur_u16: kernel %d x %d must be positive", kw, kh);
+    SHG_REQUIRE((int64_t)kw * kh <= 32768, SHG_E_UNSUPPORTED, "shg_box_blur_u16: window %d x %d overflows int32 sums", kw, kh);
+    hipStream_t st = shg::as_stream(stream);
+    const unsigned blocks = (unsigned)((h * w + 255) / 256);
+    k_box_rows<<<blocks, 256, 0, st>>>(src, h, w, kw, tmp);
+    if (int e = shg::check_launch("k_box_rows")) return e;
+    k_box_cols<<<blocks, 256, 0, st>>>(tmp, h, w, kh, 1.0 / ((double)kw * (double)kh), dst);
+    return shg::check_launch("k_box_cols");
+}
+
+extern "C" int shg_row_argmin_u16(const uint16_t* img, int64_t h, int64_t w, int64_t x0, int64_t x1, int32_t* out,
+                                  shg_stream_t stream) {
+    SHG_REQUIRE(img && out, SHG_E_ARG, "shg_row_argmin_u16: null pointer");
+    SHG_REQUIRE(h > 0 && w > 0 && x0 >= 0 && x1 <= w && x0 < x1, SHG_E_ARG,
+                "shg_row_argmin_u16: empty column range [%lld, %lld) of %lld", (long long)x0, (long long)x1, (long long)w);
+    k_row_argmin<<<(unsigned)((h + 3) / 4), 256, 0, shg::as_stream(stream)>>>(img, h, w, x0, x1, out);
+    return shg::check_launch("k_row_argmin");
+}
+
+extern "C" int shg_row_mean_u16(const uint16_t* img, int64_t h, int64_t w, double* out, shg_stream_t stream) {
+    SHG_REQUIRE(img && out, SHG_E_ARG, "shg_row_mean_u16: null pointer");
+    SHG_REQUIRE(h > 0 && w > 0, SHG_E_ARG, "shg_row_mean_u16: empty image");
+    k_row_mean<<<(unsigned)((h + 3) / 4), 256, 0, shg::as_stream(stream)>>>(img, h, w, out);
+    return shg::check_launch("k_row_mean");
+}

@@ -1,0 +1,121 @@
+// Small per-disk image passes: crop/pad, brightness rescale, protuberance disc,
+// 4x4 block mean.  Reference: Solex_recon.py:155-171 (crop), solex_util.py:519-525
+// (rescale_brightness), solex_util.py:542-547 (cv2.circle), ellipse_to_circle.py:299-302
+// (downscale_local_mean).  All are single streaming passes over a few-MB image.
+#include "shg_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_crop_pad(const uint16_t* __restrict__ src, int64_t pitch, uint16_t* __restrict__ dst,
+                                                  int64_t nw, int64_t dst_pitch, int64_t sx0, int64_t dx0, int64_t n,
+                                                  uint16_t fill) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t y = blockIdx.y;
+    if (x >= nw) return;
+    const int64_t j = x - dx0;
+    dst[y * dst_pitch + x] = (j >= 0 && j < n) ? src[y * pitch + sx0 + j] : fill;
+}
+
+__global__ __launch_bounds__(256) void k_rescale(const uint16_t* __restrict__ img, int64_t w, int64_t pitch, double a,
+                                                 double lo, double span, uint16_t* __restrict__ dst, int64_t dst_pitch) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t y = blockIdx.y;
+    if (x >= w) return;
+    // (float(sat) * alpha * (img - lo)) / (hi - lo): left to right, float64
+    double v = a * ((double)img[y * pitch + x] - lo) / span;
+    v = v < 0.0 ? 0.0 : v;
+    v = v > 65535.0 ? 65535.0 : v;
+    dst[y * dst_pitch + x] = (uint16_t)(int)v;
+}
+
+// OpenCV drawing.cpp Circle(): integer midpoint circle; half[dy] = widest half-span drawn on rows y0 +- dy
+__global__ void k_disc_spans(int r, int32_t* __restrict__ half) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int i = 0; i <= r; ++i) half[i] = -1;
+    int err = 0, dx = r, dy = 0, plus = 1, minus = (r << 1) - 1;
+    while (dx >= dy) {
+        half[dy] = max(half[dy], dx);
+        half[dx] = max(half[dx], dy);
+        dy++;
+        err += plus;
+        plus += 2;
+        const int mask = (err <= 0) - 1;
+        err -= minus & mask;
+        dx += mask;
+        minus -= mask & 2;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill_disc(uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch, int64_t x0,
+                                                   int64_t y0, int r, uint16_t value, const int32_t* __restrict__ half) {
+    const int64_t x = x0 - r + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t y = y0 - r + blockIdx.y;
+    if (x < 0 || x >= w || y < 0 || y >= h || x > x0 + r) return;
+    const int64_t ady = y > y0 ? y - y0 : y0 - y;
+    const int64_t adx = x > x0 ? x - x0 : x0 - x;
+    if (adx <= half[ady]) img[y * pitch + x] = value;
+}
+
+__global__ __launch_bounds__(256) void k_downscale_mean(const uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch,
+                                                        int f, int64_t oh, int64_t ow, double* __restrict__ dst) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= oh * ow) return;
+    const int64_t oy = o / ow, ox = o - oy * ow;
+    uint64_t s = 0;                     // zero padded blocks (block_reduce cval=0); the integer sum is exact
+    for (int j = 0; j < f; ++j) {
+        const int64_t y = oy * f + j;
+        if (y >= h) break;
+        for (int i = 0; i < f; ++i) {
+            const int64_t x = ox * f + i;
+            if (x < w) s += img[y * pitch + x];
+        }
+    }
+    // mean of f*f float64 values k/65536: every partial sum is exactly representable
+    dst[o] = ((double)s / 65536.0) / (double)(f * f);
+}
+
+}  // namespace
+
+extern "C" int shg_crop_pad_u16(const uint16_t* src, int64_t h, int64_t w, int64_t pitch, uint16_t* dst, int64_t nw,
+                                int64_t dst_pitch, int64_t sx0, int64_t dx0, int64_t n, uint16_t fill, shg_stream_t stream) {
+    SHG_REQUIRE(src && dst, SHG_E_ARG, "shg_crop_pad_u16: null pointer");
+    SHG_REQUIRE(h > 0 && w > 0 && nw > 0 && pitch >= w && dst_pitch >= nw, SHG_E_ARG, "shg_crop_pad_u16: bad image size");
+    SHG_REQUIRE(n >= 0 && sx0 >= 0 && sx0 + n <= w && dx0 >= 0 && dx0 + n <= nw, SHG_E_ARG, "shg_crop_pad_u16: copy window outside the images");
+    SHG_REQUIRE(h < 65536, SHG_E_UNSUPPORTED, "shg_crop_pad_u16: more than 65535 rows");
+    dim3 grid((unsigned)((nw + 255) / 256), (unsigned)h);
+    k_crop_pad<<<grid, 256, 0, shg::as_stream(stream)>>>(src, pitch, dst, nw, dst_pitch, sx0, dx0, n, fill);
+    return shg::check_launch("k_crop_pad");
+}
+
+extern "C" int shg_rescale_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, double lo, double hi, double alpha,
+                               uint16_t* dst, int64_t dst_pitch, shg_stream_t stream) {
+    SHG_REQUIRE(img && dst, SHG_E_ARG, "shg_rescale_u16: null pointer");
+    SHG_REQUIRE(h > 0 && w > 0 && pitch >= w && dst_pitch >= w, SHG_E_ARG, "shg_rescale_u16: bad image size");
+    SHG_REQUIRE(65535.0 >= hi && hi > lo, SHG_E_ARG, "shg_rescale_u16: need sat >= hi > lo (got lo=%g hi=%g)", lo, hi);   // assert, solex_util.py:521
+    SHG_REQUIRE(h < 65536, SHG_E_UNSUPPORTED, "shg_rescale_u16: more than 65535 rows");
+    dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
+    k_rescale<<<grid, 256, 0, shg::as_stream(stream)>>>(img, w, pitch, 65535.0 * alpha, lo, hi - lo, dst, dst_pitch);
+    return shg::check_launch("k_rescale");
+}
+
+extern "C" int shg_fill_disc_u16(uint16_t* img, int64_t h, int64_t w, int64_t pitch, int64_t x0, int64_t y0, int64_t r,
+                                 uint16_t value, int32_t* scratch, shg_stream_t stream) {
+    SHG_REQUIRE(img && scratch, SHG_E_ARG, "shg_fill_disc_u16: null pointer");
+    SHG_REQUIRE(h > 0 && w > 0 && pitch >= w, SHG_E_ARG, "shg_fill_disc_u16: bad image size");
+    SHG_REQUIRE(r >= 0 && r < 32768, SHG_E_UNSUPPORTED, "shg_fill_disc_u16: radius %lld out of range", (long long)r);
+    hipStream_t st = shg::as_stream(stream);
+    k_disc_spans<<<1, 64, 0, st>>>((int)r, scratch);
+    if (int e = shg::check_launch("k_disc_spans")) return e;
+    dim3 grid((unsigned)((2 * r + 1 + 255) / 256), (unsigned)(2 * r + 1));
+    k_fill_disc<<<grid, 256, 0, st>>>(img, h, w, pitch, x0, y0, (int)r, value, scratch);
+    return shg::check_launch("k_fill_disc");
+}
+
+extern "C" int shg_downscale_mean_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, int factor, double* dst,
+                                      shg_stream_t stream) {
+    SHG_REQUIRE(img && dst, SHG_E_ARG, "shg_downscale_mean_u16: null pointer");
+    SHG_REQUIRE(h > 0 && w > 0 && pitch >= w && factor >= 1 && factor <= 64, SHG_E_ARG, "shg_downscale_mean_u16: bad size");
+    const int64_t oh = (h + factor - 1) / factor, ow = (w + factor - 1) / factor;
+    k_downscale_mean<<<(unsigned)((oh * ow + 255) / 256), 256, 0, shg::as_stream(stream)>>>(img, h, w, pitch, factor, oh, ow, dst);
+    return shg::check_launch("k_downscale_mean");
+}

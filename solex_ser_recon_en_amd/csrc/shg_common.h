@@ -1,0 +1,45 @@
+// Shared helpers for the libshg_hip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/shg_hip.h"
+
+namespace shg {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+#define SHG_REQUIRE(cond, code, ...)            \
+    do {                                        \
+        if (!(cond)) {                          \
+            shg::set_error(__VA_ARGS__);        \
+            return (code);                      \
+        }                                       \
+    } while (0)
+
+inline hipStream_t as_stream(shg_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kCUs = 256;          // MI355X
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+// BORDER_REFLECT_101 index (gfedcb|abcdefgh|gfedcba), valid for any i
+__host__ __device__ __forceinline__ int64_t reflect101(int64_t i, int64_t n) {
+    if (n == 1) return 0;
+    const int64_t period = 2 * n - 2;
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - i;
+}
+
+}  // namespace shg

@@ -1,0 +1,82 @@
+// The ellipse -> circle warp.  Replaces skimage.transform.warp in correct_image
+// (reference ellipse_to_circle.py:112-118).  The correction matrix is upper
+// triangular with [1][1] = 1 (ellipse_to_circle.py:48-49), so every output row is a
+// 1-D linear resample of the same input row: 2 reads + 1 write per output pixel,
+// HBM/L2-bound.  Arithmetic follows scikit-image 0.18.3 (_warp_fast,
+// bilinear_interpolation, _clip_warp_output) in float64, unfused.
+#include "shg_common.h"
+
+namespace {
+
+__global__ void k_minmax_init(uint32_t* mm) {
+    mm[0] = 0xffffffffu;
+    mm[1] = 0u;
+}
+
+__global__ __launch_bounds__(256) void k_minmax(const uint16_t* __restrict__ src, int64_t h, int64_t w, int64_t pitch,
+                                                uint32_t* __restrict__ mm) {
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    const int64_t n = h * w;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t y = i / w, x = i - y * w;
+        const uint32_t v = src[y * pitch + x];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t ol = __shfl_xor(lo, d), oh = __shfl_xor(hi, d);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&mm[0], lo);
+        atomicMax(&mm[1], hi);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_warp_rows(const uint16_t* __restrict__ src, int64_t h, int64_t w, int64_t pitch,
+                                                   double h00, double h01, double h02, uint16_t* __restrict__ dst,
+                                                   int64_t out_h, int64_t out_w, int64_t dst_pitch,
+                                                   const uint32_t* __restrict__ mm) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = blockIdx.y;
+    if (c >= out_w) return;
+    constexpr double inv = 1.0 / 65536.0;
+    const double cval = (double)src[0] * inv;                 // cval = image[0, 0]
+    const double x = h00 * (double)c + h01 * (double)r + h02;
+    const double x0 = floor(x), x1 = ceil(x);
+    const double dc = x - x0;
+    const int64_t i0 = (int64_t)x0, i1 = (int64_t)x1;
+    double left = cval, right = cval;
+    if (r < h) {
+        const uint16_t* row = src + r * pitch;
+        if (i0 >= 0 && i0 < w) left = (double)row[i0] * inv;
+        if (i1 >= 0 && i1 < w) right = (double)row[i1] * inv;
+    }
+    double v = (1.0 - dc) * left + dc * right;
+    const double lo = (double)mm[0] * inv, hi = (double)mm[1] * inv;
+    v = v < lo ? lo : v;                                       // np.clip(warped, image.min(), image.max())
+    v = v > hi ? hi : v;
+    dst[r * dst_pitch + c] = (uint16_t)(int)(65536.0 * v);     // (2**16 * img).astype(uint16)
+}
+
+}  // namespace
+
+extern "C" int shg_warp_rows_u16(const uint16_t* src, int64_t h, int64_t w, int64_t src_pitch, double h00, double h01,
+                                 double h02, uint16_t* dst, int64_t out_h, int64_t out_w, int64_t dst_pitch,
+                                 uint32_t* minmax, shg_stream_t stream) {
+    SHG_REQUIRE(src && dst && minmax, SHG_E_ARG, "shg_warp_rows_u16: null pointer");
+    SHG_REQUIRE(h > 0 && w > 0 && out_h > 0 && out_w > 0, SHG_E_ARG, "shg_warp_rows_u16: empty image");
+    SHG_REQUIRE(src_pitch >= w && dst_pitch >= out_w, SHG_E_ARG, "shg_warp_rows_u16: pitch smaller than width");
+    SHG_REQUIRE(out_h < 65536, SHG_E_UNSUPPORTED, "shg_warp_rows_u16: more than 65535 rows");
+    hipStream_t st = shg::as_stream(stream);
+    k_minmax_init<<<1, 1, 0, st>>>(minmax);
+    int64_t blocks = (h * w + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    k_minmax<<<(unsigned)blocks, 256, 0, st>>>(src, h, w, src_pitch, minmax);
+    if (int e = shg::check_launch("k_minmax")) return e;
+    dim3 grid((unsigned)((out_w + 255) / 256), (unsigned)out_h);
+    k_warp_rows<<<grid, 256, 0, st>>>(src, h, w, src_pitch, h00, h01, h02, dst, out_h, out_w, dst_pitch, minmax);
+    return shg::check_launch("k_warp_rows");
+}

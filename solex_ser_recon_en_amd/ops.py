@@ -1,0 +1,238 @@
+"""Thin tensor-level wrappers over the C ABI (include/shg_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every
+computation below happens in libshg_hip.so.  All tensors must live on the GPU; a
+CPU tensor raises (there is no CPU path).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, what):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError('%s must be a GPU tensor: the SHG hot path has no CPU fallback' % what)
+    return t
+
+
+def _img(t, what, dtype=None):
+    """(ptr, h, w, pitch) of a 2-D image view with unit column stride."""
+    _dev(t, what)
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError('%s must be a 2-D image with contiguous rows' % what)
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError('%s must be %s, got %s' % (what, dtype, t.dtype))
+    return t.data_ptr(), t.shape[0], t.shape[1], t.stride(0)
+
+
+def pitched_u16(h, w, device, align=64):
+    """uint16 image whose row pitch is a multiple of `align` elements (128 B rows)."""
+    pitch = (w + align - 1) // align * align
+    return torch.empty((h, pitch), dtype=torch.uint16, device=device)[:, :w]
+
+
+def stack_geometry(stack):
+    """(n, H, W, bytes_per_px) of a frame stack in file layout."""
+    _dev(stack, 'stack')
+    if stack.dim() != 3 or not stack.is_contiguous():
+        raise ValueError('stack must be a contiguous [N, Height, Width] tensor')
+    if stack.dtype == torch.uint8:
+        bpp = 1
+    elif stack.dtype in (torch.uint16, torch.int16):
+        bpp = 2
+    else:
+        raise TypeError('stack must be uint8 or uint16, got %s' % stack.dtype)
+    n, h, w = stack.shape
+    return n, h, w, bpp
+
+
+# ---- pass A ---------------------------------------------------------------
+def accumulate_sum_max(stack, workspace=None):
+    """-> (sum int64 [H*W], max uint16 [H*W]) in file layout, raw sample units."""
+    n, h, w, bpp = stack_geometry(stack)
+    dev = stack.device
+    need = lib.shg_accumulate_workspace_bytes(n, h, w, bpp)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    total = torch.empty(h * w, dtype=torch.int64, device=dev)
+    mx = torch.empty(h * w, dtype=torch.uint16, device=dev)
+    _lib.check(lib.shg_accumulate_sum_max(stack.data_ptr(), n, h, w, bpp, total.data_ptr(), mx.data_ptr(),
+                                          workspace.data_ptr(), workspace.numel(), _stream()),
+               'shg_accumulate_sum_max')
+    return total, mx
+
+
+def finalize_mean_max(total, mx, n_total, height, width, bpp):
+    """-> (mean uint16 [ih, iw], max uint16 [ih, iw]) in the reference's orientation."""
+    _dev(total, 'sum')
+    ih, iw = (width, height) if width > height else (height, width)
+    mean = torch.empty((ih, iw), dtype=torch.uint16, device=total.device)
+    mout = torch.empty((ih, iw), dtype=torch.uint16, device=total.device)
+    _lib.check(lib.shg_finalize_mean_max(total.data_ptr(), mx.data_ptr(), int(n_total), height, width, bpp,
+                                         mean.data_ptr(), mout.data_ptr(), _stream()), 'shg_finalize_mean_max')
+    return mean, mout
+
+
+# ---- line detection helpers -------------------------------------------------
+def box_blur_u16(img, kw, kh):
+    ptr, h, w, pitch = _img(img, 'img', torch.uint16)
+    if pitch != w:
+        raise ValueError('box_blur_u16 needs a dense image')
+    out = torch.empty_like(img)
+    tmp = torch.empty(h * w, dtype=torch.int32, device=img.device)
+    _lib.check(lib.shg_box_blur_u16(ptr, h, w, int(kw), int(kh), out.data_ptr(), tmp.data_ptr(), _stream()),
+               'shg_box_blur_u16')
+    return out
+
+
+def row_argmin_u16(img, x0, x1):
+    ptr, h, w, pitch = _img(img, 'img', torch.uint16)
+    if pitch != w:
+        raise ValueError('row_argmin_u16 needs a dense image')
+    out = torch.empty(h, dtype=torch.int32, device=img.device)
+    _lib.check(lib.shg_row_argmin_u16(ptr, h, w, int(x0), int(x1), out.data_ptr(), _stream()), 'shg_row_argmin_u16')
+    return out
+
+
+def row_mean_u16(img):
+    ptr, h, w, pitch = _img(img, 'img', torch.uint16)
+    if pitch != w:
+        raise ValueError('row_mean_u16 needs a dense image')
+    out = torch.empty(h, dtype=torch.float64, device=img.device)
+    _lib.check(lib.shg_row_mean_u16(ptr, h, w, out.data_ptr(), _stream()), 'shg_row_mean_u16')
+    return out
+
+
+# ---- pass B ---------------------------------------------------------------
+def extract_columns(stack, ind_l, lw, rw, n_cols=None, k_offset=0, flip_x=False, out=None):
+    """-> disks uint16 [S, ih, n_cols] (a view of a row-pitched buffer).
+
+    ind_l int32 [S, ih] (clamped), lw/rw float64 [ih]: host arrays or GPU tensors."""
+    n, h, w, bpp = stack_geometry(stack)
+    dev = stack.device
+    ih = max(h, w)
+    ind_l = torch.as_tensor(np.ascontiguousarray(ind_l, dtype=np.int32) if not isinstance(ind_l, torch.Tensor) else ind_l).to(dev)
+    lw = torch.as_tensor(np.ascontiguousarray(lw, dtype=np.float64) if not isinstance(lw, torch.Tensor) else lw).to(dev)
+    rw = torch.as_tensor(np.ascontiguousarray(rw, dtype=np.float64) if not isinstance(rw, torch.Tensor) else rw).to(dev)
+    if ind_l.dim() != 2 or ind_l.shape[1] != ih or lw.shape != (ih,) or rw.shape != (ih,):
+        raise ValueError('ind_l must be [S, %d] and lw, rw [%d]' % (ih, ih))
+    if ind_l.dtype != torch.int32 or lw.dtype != torch.float64 or rw.dtype != torch.float64:
+        raise TypeError('ind_l must be int32 and lw, rw float64')
+    s = ind_l.shape[0]
+    n_cols = n if n_cols is None else int(n_cols)
+    if out is None:
+        pitch = (n_cols + 63) // 64 * 64
+        out = torch.zeros((s, ih, pitch), dtype=torch.uint16, device=dev)[:, :, :n_cols]
+    if out.shape != (s, ih, n_cols) or out.stride(2) != 1:
+        raise ValueError('out must be a [S, ih, n_cols] view with unit column stride')
+    _lib.check(lib.shg_extract_columns(stack.data_ptr(), n, h, w, bpp, ind_l.contiguous().data_ptr(),
+                                       lw.contiguous().data_ptr(), rw.contiguous().data_ptr(), s, out.data_ptr(),
+                                       out.stride(1), out.stride(0), n_cols, int(k_offset), int(bool(flip_x)),
+                                       _stream()), 'shg_extract_columns')
+    return out
+
+
+# ---- post-processing ----------------------------------------------------------
+def warp_rows_u16(img, h00, h01, h02, out_h, out_w):
+    ptr, h, w, pitch = _img(img, 'img', torch.uint16)
+    out = pitched_u16(out_h, out_w, img.device)
+    mm = torch.empty(2, dtype=torch.int32, device=img.device)
+    _lib.check(lib.shg_warp_rows_u16(ptr, h, w, pitch, float(h00), float(h01), float(h02), out.data_ptr(),
+                                     int(out_h), int(out_w), out.stride(0), mm.data_ptr(), _stream()),
+               'shg_warp_rows_u16')
+    return out
+
+
+def rowpair_logratio_stats(img, y1, y2, xa, xb):
+    """xa, xb: int32 host arrays [y2-y1] of NumPy-normalised slice bounds. -> float64 tensor [y2-y1]."""
+    ptr, h, w, pitch = _img(img, 'img', torch.uint16)
+    xa = torch.as_tensor(np.ascontiguousarray(xa, dtype=np.int32)).to(img.device)
+    xb = torch.as_tensor(np.ascontiguousarray(xb, dtype=np.int32)).to(img.device)
+    if xa.numel() != y2 - y1 or xb.numel() != y2 - y1:
+        raise ValueError('xa, xb must have y2 - y1 entries')
+    out = torch.empty(y2 - y1, dtype=torch.float64, device=img.device)
+    _lib.check(lib.shg_rowpair_logratio_stats(ptr, h, w, pitch, int(y1), int(y2), xa.data_ptr(), xb.data_ptr(),
+                                              out.data_ptr(), _stream()), 'shg_rowpair_logratio_stats')
+    return out
+
+
+def scale_rows_u16(img, c):
+    ptr, h, w, pitch = _img(img, 'img', torch.uint16)
+    c = torch.as_tensor(np.ascontiguousarray(c, dtype=np.float64)).to(img.device) if not isinstance(c, torch.Tensor) else c
+    if c.shape != (h,) or c.dtype != torch.float64:
+        raise ValueError('c must be float64 [h]')
+    out = pitched_u16(h, w, img.device)
+    _lib.check(lib.shg_scale_rows_u16(ptr, h, w, pitch, c.contiguous().data_ptr(), out.data_ptr(), out.stride(0),
+                                      _stream()), 'shg_scale_rows_u16')
+    return out
+
+
+def crop_pad_u16(img, nw, sx0, dx0, n, fill):
+    ptr, h, w, pitch = _img(img, 'img', torch.uint16)
+    out = pitched_u16(h, nw, img.device)
+    _lib.check(lib.shg_crop_pad_u16(ptr, h, w, pitch, out.data_ptr(), int(nw), out.stride(0), int(sx0), int(dx0),
+                                    int(n), int(fill), _stream()), 'shg_crop_pad_u16')
+    return out
+
+
+def clahe(img, clip_limit=0.8, tiles=2):
+    _dev(img, 'img')
+    if img.dtype == torch.uint16:
+        bpp = 2
+    elif img.dtype == torch.uint8:
+        bpp = 1
+    else:
+        raise TypeError('clahe needs uint8 or uint16')
+    ptr, h, w, pitch = _img(img, 'img')
+    need = lib.shg_clahe_workspace_bytes(int(tiles), bpp)
+    if need == 0:
+        raise ValueError('clahe: unsupported tile count %r' % (tiles,))
+    ws = torch.empty(need, dtype=torch.uint8, device=img.device)
+    out = pitched_u16(h, w, img.device) if bpp == 2 else torch.empty((h, w), dtype=torch.uint8, device=img.device)
+    _lib.check(lib.shg_clahe(ptr, h, w, pitch, bpp, float(clip_limit), int(tiles), out.data_ptr(), out.stride(0),
+                             ws.data_ptr(), need, _stream()), 'shg_clahe')
+    return out
+
+
+def histogram(img):
+    """-> int32 tensor [65536] (uint16 images) or [256] (uint8)."""
+    _dev(img, 'img')
+    bpp = 2 if img.dtype == torch.uint16 else 1
+    if img.dtype not in (torch.uint16, torch.uint8):
+        raise TypeError('histogram needs uint8 or uint16')
+    ptr, h, w, pitch = _img(img, 'img')
+    hist = torch.empty(65536 if bpp == 2 else 256, dtype=torch.int32, device=img.device)
+    _lib.check(lib.shg_hist(ptr, h, w, pitch, bpp, hist.data_ptr(), _stream()), 'shg_hist')
+    return hist
+
+
+def rescale_u16(img, lo, hi, alpha=1.0):
+    ptr, h, w, pitch = _img(img, 'img', torch.uint16)
+    out = pitched_u16(h, w, img.device)
+    _lib.check(lib.shg_rescale_u16(ptr, h, w, pitch, float(lo), float(hi), float(alpha), out.data_ptr(),
+                                   out.stride(0), _stream()), 'shg_rescale_u16')
+    return out
+
+
+def fill_disc_u16(img, x0, y0, r, value):
+    """In place (cv2.circle returns its argument too)."""
+    ptr, h, w, pitch = _img(img, 'img', torch.uint16)
+    scratch = torch.empty(int(r) + 1, dtype=torch.int32, device=img.device)
+    _lib.check(lib.shg_fill_disc_u16(ptr, h, w, pitch, int(x0), int(y0), int(r), int(value), scratch.data_ptr(),
+                                     _stream()), 'shg_fill_disc_u16')
+    return img
+
+
+def downscale_mean_u16(img, factor=4):
+    ptr, h, w, pitch = _img(img, 'img', torch.uint16)
+    oh, ow = -(-h // factor), -(-w // factor)
+    out = torch.empty((oh, ow), dtype=torch.float64, device=img.device)
+    _lib.check(lib.shg_downscale_mean_u16(ptr, h, w, pitch, int(factor), out.data_ptr(), _stream()),
+               'shg_downscale_mean_u16')
+    return out

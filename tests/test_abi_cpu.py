@@ -1,0 +1,60 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports exactly
+the symbols include/shg_hip.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, 'include', 'shg_hip.h')
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(shg_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from solex_ser_recon_en_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 19
+    for name in names:
+        assert hasattr(_lib.lib, name), 'libshg_hip.so does not export %s' % name
+        assert name in _lib.SIGNATURES, 'no ctypes signature for %s' % name
+    assert sorted(_lib.SIGNATURES) == names
+    assert _lib.lib.shg_abi_version() == 1
+    assert isinstance(_lib.last_error(), str)
+
+
+def test_workspace_queries_need_no_gpu():
+    from solex_ser_recon_en_amd._lib import lib
+    assert lib.shg_accumulate_workspace_bytes(2000, 200, 2000, 2) >= 400000 * 6
+    assert lib.shg_accumulate_workspace_bytes(0, 200, 2000, 2) == 0
+    assert lib.shg_accumulate_workspace_bytes(10, 200, 2000, 3) == 0
+    assert lib.shg_clahe_workspace_bytes(2, 2) == 4 * 65536 * 6
+    assert lib.shg_clahe_workspace_bytes(3, 1) == 9 * 256 * 6
+    assert lib.shg_clahe_workspace_bytes(0, 2) == 0
+
+
+def test_argument_errors_are_reported_not_thrown():
+    """Bad arguments are rejected before any HIP call, so this runs without a GPU."""
+    from solex_ser_recon_en_amd import _lib
+    lib = _lib.lib
+    assert lib.shg_accumulate_sum_max(None, 1, 1, 1, 2, None, None, None, 0, None) == -1
+    assert 'null pointer' in _lib.last_error()
+    one = ctypes.c_void_p(16)
+    assert lib.shg_extract_columns(one, 0, 4, 4, 2, one, one, one, 1, one, 4, 16, 4, 0, 0, None) == -1
+    assert lib.shg_box_blur_u16(one, 10, 10, 25, 0, one, one, None) == -1      # cv2.blur rejects a zero kernel too
+    assert 'must be positive' in _lib.last_error()
+    assert lib.shg_rescale_u16(one, 4, 4, 4, 5.0, 5.0, 1.0, one, 4, None) == -1   # assert(sat >= hi > lo)
+    with pytest.raises(RuntimeError):
+        _lib.check(-1, 'unit test')
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from solex_ser_recon_en_amd import ops
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.accumulate_sum_max(torch.zeros((2, 4, 4), dtype=torch.uint8))

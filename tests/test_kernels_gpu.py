@@ -1,0 +1,225 @@
+"""HIP kernels (through the C ABI) against the golden vectors and the CPU oracle.
+Bit-exact for integer / index work; tolerances stated where floating point is involved."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from solex_ser_recon_en_amd import ops as _ops
+    return _ops
+
+
+@pytest.fixture(scope='module')
+def orc():
+    from oracle import shg_oracle
+    return shg_oracle
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def frames_geometry(frames):
+    n, h, w = frames.shape
+    return n, h, w, frames.dtype.itemsize
+
+
+# ---- pass A -----------------------------------------------------------------
+@pytest.mark.parametrize('tag', ['u16_rot', 'u16_norot', 'u8_rot', 'u8_norot', 'u16_odd'])
+def test_mean_max_golden(ops, golden, tag):
+    g = golden('g1_mean_max')
+    frames = g[tag + '_frames']
+    n, h, w, bpp = frames_geometry(frames)
+    total, mx = ops.accumulate_sum_max(dev(frames))
+    mean, mxo = ops.finalize_mean_max(total, mx, n, h, w, bpp)
+    np.testing.assert_array_equal(host(mean), g[tag + '_mean'])
+    np.testing.assert_array_equal(host(mxo), g[tag + '_max'])
+    np.testing.assert_array_equal(host(total), frames.astype(np.int64).sum(0).ravel())
+
+
+@pytest.mark.parametrize('shape,dtype', [((300, 24, 160), np.uint16), ((257, 160, 24), np.uint16),
+                                         ((130, 16, 128), np.uint8), ((3, 5, 7), np.uint16), ((1, 8, 16), np.uint8)])
+def test_mean_max_oracle_random(ops, orc, shape, dtype):
+    rng = np.random.default_rng(42)
+    hi = 256 if dtype == np.uint8 else 65536
+    frames = rng.integers(0, hi, shape).astype(dtype)
+    frames[rng.integers(0, shape[0])] = hi - 1                   # saturated frame: the max path sees full scale
+    n, h, w, bpp = frames_geometry(frames)
+    total, mx = ops.accumulate_sum_max(dev(frames))
+    mean, mxo = ops.finalize_mean_max(total, mx, n, h, w, bpp)
+    ref_mean, ref_max = orc.compute_mean_max(orc.SerReader(frames))
+    np.testing.assert_array_equal(host(mean), ref_mean)
+    np.testing.assert_array_equal(host(mxo), ref_max)
+
+
+def test_mean_max_sharding_is_bit_identical(ops):
+    """Integer sum / max partials of frame shards add up to the unsharded result (what RCCL SUM/MAX does)."""
+    rng = np.random.default_rng(1)
+    frames = rng.integers(0, 65536, (96, 16, 64)).astype(np.uint16)
+    t_all, m_all = ops.accumulate_sum_max(dev(frames))
+    parts = [ops.accumulate_sum_max(dev(frames[a:b])) for a, b in [(0, 31), (31, 64), (64, 96)]]
+    t_sum = sum(host(p[0]) for p in parts)
+    m_max = np.maximum.reduce([host(p[1]) for p in parts])
+    np.testing.assert_array_equal(host(t_all), t_sum)
+    np.testing.assert_array_equal(host(m_all), m_max)
+
+
+# ---- line detection helpers ---------------------------------------------------
+@pytest.mark.parametrize('h,w,kw,kh', [(180, 48, 25, 1), (180, 48, 5, 5), (64, 203, 25, 7), (33, 31, 4, 6), (12, 9, 25, 3)])
+def test_box_blur_matches_oracle(ops, orc, h, w, kw, kh):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 65536, (h, w)).astype(np.uint16)
+    np.testing.assert_array_equal(host(ops.box_blur_u16(dev(img), kw, kh)), orc.box_blur_u16(img, kw, kh))
+
+
+def test_row_argmin_and_mean(ops):
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 300, (211, 157)).astype(np.uint16)     # many ties: first occurrence matters
+    np.testing.assert_array_equal(host(ops.row_argmin_u16(dev(img), 12, 157 - 13)), np.argmin(img[:, 12:-13], axis=1))
+    np.testing.assert_array_equal(host(ops.row_argmin_u16(dev(img), 0, 157)), np.argmin(img, axis=1))
+    np.testing.assert_array_equal(host(ops.row_mean_u16(dev(img))), np.mean(img, axis=1))
+
+
+# ---- pass B -----------------------------------------------------------------
+@pytest.mark.parametrize('tag', ['u16_rot', 'u16_norot', 'u8_rot', 'u16_odd'])
+@pytest.mark.parametrize('stag', ['s2', 's21', 's3'])
+def test_extract_golden(ops, orc, golden, tag, stag):
+    g = golden('g2_extract')
+    frames = g[tag + '_frames']
+    shifts = [int(s) for s in g[tag + '_' + stag + '_shifts']]
+    iw = min(frames.shape[1:])
+    cols, lw, rw = orc.column_indices(g[tag + '_fit'], shifts, iw)
+    ind_l = np.stack([c[0] for c in cols]).astype(np.int32)
+    disks = ops.extract_columns(dev(frames), ind_l, lw, rw)
+    np.testing.assert_array_equal(host(disks), g[tag + '_' + stag + '_disks'])
+
+
+def test_extract_flip_and_column_blocks(ops, orc, golden):
+    """flip_x (Solex_recon.py:74-76) and per-rank column blocks assemble to the unsharded disks."""
+    g = golden('g2_extract')
+    frames = g['u16_rot_frames']
+    shifts = [10, 0]
+    cols, lw, rw = orc.column_indices(g['u16_rot_fit'], shifts, min(frames.shape[1:]))
+    ind_l = np.stack([c[0] for c in cols]).astype(np.int32)
+    want = g['u16_rot_s2_disks']
+    n = frames.shape[0]
+    flipped = ops.extract_columns(dev(frames), ind_l, lw, rw, flip_x=True)
+    np.testing.assert_array_equal(host(flipped), want[:, :, ::-1])
+    for flip in (False, True):
+        out = None
+        for a, b in [(0, 7), (7, 13), (13, n)]:
+            out = ops.extract_columns(dev(frames[a:b]), ind_l, lw, rw, n_cols=n, k_offset=a, flip_x=flip, out=out)
+        np.testing.assert_array_equal(host(out), want[:, :, ::-1] if flip else want)
+
+
+@pytest.mark.parametrize('n,h,w,dtype', [(150, 24, 200, np.uint16), (70, 200, 24, np.uint16), (130, 24, 200, np.uint8)])
+def test_extract_oracle_random(ops, orc, n, h, w, dtype):
+    rng = np.random.default_rng(9)
+    frames = rng.integers(0, 256 if dtype == np.uint8 else 65536, (n, h, w)).astype(dtype)
+    ih, iw = max(h, w), min(h, w)
+    curve = iw / 2 + 3 * np.sin(np.arange(ih) / 17.0) + rng.random(ih)
+    fit = np.stack([np.floor(curve), curve - np.floor(curve), np.arange(ih), curve], axis=1)
+    shifts = orc.shift_list(10, list(range(-4, 5, 2)))
+    cols, lw, rw = orc.column_indices(fit, shifts, iw)
+    disks = ops.extract_columns(dev(frames), np.stack([c[0] for c in cols]).astype(np.int32), lw, rw)
+    want = orc.extract_columns(orc.SerReader(frames), fit, shifts)
+    np.testing.assert_array_equal(host(disks), np.stack(want))
+
+
+# ---- warp ---------------------------------------------------------------------
+def test_warp_golden_bit_exact(ops, golden):
+    g = golden('g3_warp')
+    img = g['image_u16']
+    for i in range(6):
+        mat3 = g['c%d_mat3' % i]
+        want = g['c%d_out' % i]
+        out = ops.warp_rows_u16(dev(img), mat3[0, 0], mat3[0, 1], mat3[0, 2], want.shape[0], want.shape[1])
+        np.testing.assert_array_equal(host(out), want)
+
+
+# ---- transversalium -------------------------------------------------------------
+def test_transversalium_stats_and_scale(ops, orc, golden):
+    import math
+    g = golden('g4_transversalium')
+    img = g['image']
+    circle, borders = tuple(g['circle']), list(g['borders'])
+    y1, y2, want = orc.transversalium_row_stats(img, circle, borders)
+    xa = np.zeros(y2 - y1, np.int32)
+    xb = np.zeros(y2 - y1, np.int32)
+    for y in range(y1 + 1, y2):
+        dx = math.floor((circle[2] ** 2 - (y - circle[1]) ** 2) ** 0.5)
+        a, b, _ = slice(math.ceil(max(circle[0] - dx, borders[0])), math.floor(min(circle[0] + dx, borders[2]))).indices(img.shape[1])
+        xa[y - y1], xb[y - y1] = a, max(a, b)
+    got = host(ops.rowpair_logratio_stats(dev(img), y1, y2, xa, xb))
+    # float64 log + a different summation order: a few ulp of values ~1e-2
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-15)
+    for tag in ('a', 'b'):
+        out = host(ops.scale_rows_u16(dev(img), g[tag + '_c']))
+        np.testing.assert_array_equal(out, g[tag + '_out'])
+
+
+# ---- crop, rescale, disc, downscale, hist ---------------------------------------
+def test_crop_pad(ops):
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 65536, (37, 91)).astype(np.uint16)
+    out = host(ops.crop_pad_u16(dev(img), 50, 20, 5, 40, 777))
+    want = np.full((37, 50), 777, np.uint16)
+    want[:, 5:45] = img[:, 20:60]
+    np.testing.assert_array_equal(out, want)
+
+
+def test_rescale_golden(ops, golden):
+    g = golden('g5_rescale')
+    img = g['image']
+    bright = float(g['bright'])
+    np.testing.assert_array_equal(host(ops.rescale_u16(dev(img), bright * 0.25, bright)), g['hc'])
+    np.testing.assert_array_equal(host(ops.rescale_u16(dev(img), 0, bright * 0.18)), g['protus'])
+    np.testing.assert_array_equal(host(ops.rescale_u16(dev(img), 1000.0, 50000.0, 0.8)), g['alpha'])
+    with pytest.raises(RuntimeError):
+        ops.rescale_u16(dev(img), 10.0, 10.0)
+
+
+@pytest.mark.parametrize('x0,y0,r', [(40, 30, 17), (3, 4, 9), (79, 59, 30), (40, 30, 1), (200, 30, 5)])
+def test_fill_disc_matches_oracle(ops, orc, x0, y0, r):
+    img = np.full((60, 80), 1000, np.uint16)
+    want = orc.filled_circle(img.copy(), x0, y0, r, 80)
+    np.testing.assert_array_equal(host(ops.fill_disc_u16(dev(img), x0, y0, r, 80)), want)
+
+
+def test_downscale_and_hist(ops):
+    rng = np.random.default_rng(6)
+    img = rng.integers(0, 65536, (51, 70)).astype(np.uint16)
+    got = host(ops.downscale_mean_u16(dev(img), 4))
+    pad = np.zeros((52, 72))
+    pad[:51, :70] = img / 65536
+    want = pad.reshape(13, 4, 18, 4).mean(axis=(1, 3))
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(host(ops.histogram(dev(img))), np.bincount(img.ravel(), minlength=65536))
+    img8 = (img >> 8).astype(np.uint8)
+    np.testing.assert_array_equal(host(ops.histogram(dev(img8))), np.bincount(img8.ravel(), minlength=256))
+
+
+# ---- CLAHE ------------------------------------------------------------------------
+@pytest.mark.parametrize('h,w,tiles,dtype', [(64, 64, 2, np.uint16), (150, 161, 2, np.uint16), (90, 120, 3, np.uint16),
+                                             (77, 50, 4, np.uint8), (40, 40, 1, np.uint16), (300, 340, 2, np.uint16)])
+def test_clahe_matches_oracle(ops, orc, h, w, tiles, dtype):
+    rng = np.random.default_rng(7)
+    yy, xx = np.mgrid[0:h, 0:w]
+    full = 255 if dtype == np.uint8 else 65535
+    smooth = 0.5 + 0.4 * np.sin(xx / 13.0) * np.cos(yy / 11.0)
+    img = np.clip((smooth + 0.05 * rng.standard_normal((h, w))) * full, 0, full).astype(dtype)
+    got = host(ops.clahe(dev(img), 0.8, tiles))
+    want = orc.clahe(img, 0.8, tiles)
+    # float32 arithmetic restated operation by operation: identical bits expected
+    np.testing.assert_array_equal(got, want)
