@@ -36,6 +36,8 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, HERE)
 
 import shg_oracle as orc                                  # noqa: E402  (shim primitives only)
+import limb_oracle as limb                                # noqa: E402  (LsqEllipse shim only)
+sys.modules['ellipse'].LsqEllipse = limb.LsqEllipse       # bound by `from ellipse import LsqEllipse`
 from solex_ser_recon_en_amd import synth                  # noqa: E402  (input generator only)
 
 import cv2                                                # noqa: E402  (the stub)
@@ -257,7 +259,99 @@ def g10_cli():
     print('wrote g10_cli.json')
 
 
-ALL = dict(G1=g1_mean_max, G2=g2_extract, G3=g3_warp, G4=g4_transversalium, G5=g5_rescale,
+def g13_limb():
+    """Real scikit-image 0.18.3: downscale_local_mean and canny on a flooded disk (pinned)."""
+    import skimage.feature
+    from skimage.transform import downscale_local_mean
+    out = {}
+    disk = _disk_image(811, 920, 12, ratio=0.9)
+    out['disk_crop'] = disk[:41, :53]
+    out['small_crop'] = downscale_local_mean(disk[:41, :53] / 65536, (4, 4))
+    small = downscale_local_mean(disk / 65536, (4, 4))
+    out['small'] = small
+    install_blur_shim()
+    flooded = limb.get_flood_image(small.copy())
+    out['flooded'] = flooded
+    for i, (sigma, lo, hi) in enumerate([(2, 0.03, 0.045), (1.5, 0.03, 0.045), (2, 20000.0, 40000.0)]):
+        out['canny%d' % i] = skimage.feature.canny(image=flooded, sigma=sigma, low_threshold=lo, high_threshold=hi)
+        out['canny%d_params' % i] = np.array([sigma, lo, hi])
+    rng = np.random.default_rng(3)
+    noisy = np.clip(small + 0.05 * rng.standard_normal(small.shape), 0, 1)
+    out['noisy'] = noisy
+    out['canny_noisy'] = skimage.feature.canny(image=noisy, sigma=1.0, low_threshold=0.05, high_threshold=0.12)
+    save('g13_limb', **out)
+
+
+def g14_pipeline():
+    """The reference's solex_read + solex_process run END TO END, unmodified, in shim mode:
+    cv2.blur / createCLAHE / circle and ellipse.LsqEllipse are this repo's restatements,
+    cv2.imwrite captures the arrays.  Pins the orchestration (shift list, geometry state,
+    stage order, crop, flip, percentiles, rescale) around the unpinned primitives."""
+    import hashlib
+    import shutil
+    install_blur_shim()
+    captured = {}
+
+    class _Clahe:
+        def __init__(self, clipLimit, tileGridSize):
+            self.clip, self.tiles = clipLimit, tileGridSize[0]
+
+        def apply(self, img):
+            return orc.clahe(img, self.clip, self.tiles)
+
+    cv2.createCLAHE = lambda clipLimit, tileGridSize: _Clahe(clipLimit, tileGridSize)
+    cv2.circle = lambda img, center, r, color, thickness: orc.filled_circle(img, center[0], center[1], r, color)
+    cv2.IMWRITE_PNG_COMPRESSION = 16
+
+    def imwrite(path, img, params=None):
+        captured[os.path.basename(path)] = np.array(img)
+        return True
+    cv2.imwrite = imwrite
+    cv2.destroyAllWindows = lambda: None
+
+    base = {'shift': [0], 'flag_display': False, 'ratio_fixe': None, 'slant_fix': None, 'save_fit': False,
+            'clahe_only': False, 'protus_only': False, 'disk_display': True, 'delta_radius': 0,
+            'crop_width_square': False, 'transversalium': True, 'stubborn_transversalium': False,
+            'trans_strength': 301, 'img_rotate': 0, 'flip_x': False, 'fixed_width': None, 'output_dir': '',
+            'ellipse_fit_shift': 10, 'de-vignette': False}
+    params = dict(n=400, w=400, h=32, bits=16, seed=3, tilt=0.01, curv=5e-5)
+    row_gain = 1 + 0.01 * np.random.default_rng(77).standard_normal(400)
+    frames = synth.synth_frames_numpy(params['n'], params['w'], params['h'], params['bits'], seed=params['seed'],
+                                      tilt=params['tilt'], curv=params['curv'], row_gain=row_gain)
+    out = {'row_gain': row_gain, 'frames_sha256': np.frombuffer(hashlib.sha256(frames.tobytes()).digest(), np.uint8)}
+    out.update({'param_' + k: np.array(v) for k, v in params.items()})
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, 'scan.ser')
+    synth.write_ser(path, frames)
+    scenarios = {'A': {}, 'B': {'shift': [-2, 0, 3], 'flip_x': True, 'crop_width_square': True},
+                 'C': {'ratio_fixe': 1, 'fixed_width': 300, 'disk_display': False, 'img_rotate': 90}}
+    keep = {'A': ['clahe', 'protus', 'uncontrasted', 'high_contrast'], 'B': ['uncontrasted', 'clahe'], 'C': ['clahe', 'protus']}
+    for tag, extra in scenarios.items():
+        captured.clear()
+        opts = dict(base, **extra)
+        disk_list, bounds, hdr = ref_sr.solex_read(path, opts)
+        ref_sr.solex_process(opts, disk_list, bounds, hdr)
+        out[tag + '_shifts'] = np.array(opts['shift'])
+        out[tag + '_bounds'] = np.array(bounds)
+        out[tag + '_geometry'] = np.array([np.nan if opts['ratio_fixe'] is None else opts['ratio_fixe'],
+                                           np.nan if opts['slant_fix'] is None else opts['slant_fix']])
+        out[tag + '_disk_sha256'] = np.stack([np.frombuffer(hashlib.sha256(np.ascontiguousarray(d).tobytes()).digest(), np.uint8)
+                                              for d in disk_list])
+        for name, img in sorted(captured.items()):
+            # scan_shift=<s>_<product>.png
+            stem = name[len('scan_'):-len('.png')]
+            shift_s, product = stem.split('_', 1)
+            key = '%s_%s_%s' % (tag, shift_s.replace('shift=', 's'), product)
+            out[key + '_sha256'] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(img).tobytes()).digest(), np.uint8)
+            out[key + '_shape'] = np.array(img.shape)
+            if product in keep[tag] and (tag != 'B' or (product == 'uncontrasted' and shift_s == 'shift=-2')
+                                         or (product == 'clahe' and shift_s == 'shift=3')):
+                out[key] = img
+    shutil.rmtree(tmp)
+    save('g14_pipeline', **out)
+
+
+ALL = dict(G13=g13_limb, G14=g14_pipeline, G1=g1_mean_max, G2=g2_extract, G3=g3_warp, G4=g4_transversalium, G5=g5_rescale,
            G7=g7_matrix, G8=g8_fit_shim, G9=g9_fits, G10=g10_cli)
 
 if __name__ == '__main__':

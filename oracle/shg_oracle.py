@@ -250,10 +250,8 @@ def warp_rows(image, mat3, out_shape, cval):
         x0 = np.floor(x)
         x1 = np.ceil(x)
         dc = x - x0
-        if r >= rows_in:
-            out[r] = cval
-            continue
-        row = image[r]
+        # rows past the input sample cval on both sides; the blend below is still evaluated
+        row = image[r] if r < rows_in else np.full(cols_in, cval)
         i0 = x0.astype(np.int64)
         i1 = x1.astype(np.int64)
         left = np.where((i0 >= 0) & (i0 < cols_in), row[np.clip(i0, 0, cols_in - 1)], cval)

@@ -1,0 +1,108 @@
+"""Front door: `python -m solex_ser_recon_en_amd.SHG_MAIN [-flags] files...`.
+
+The command-line branch of the reference's SHG_MAIN.py (:218-223, :248) with its option
+schema (:41-68), task list (precheck_files :98-132), folder glob (:154-159) and error
+handling (handle_files :134-143: print the traceback, never re-raise).  The GUI, the ini
+file and the language packs are out of scope.  Under `torchrun` (one process per GPU) a
+single file is frame-sharded over the ranks, several files are dealt one per rank.
+"""
+import glob
+import os
+import sys
+import traceback
+
+from . import CLI_handler, Solex_recon
+
+options = {
+    'language': 'English',
+    'shift': [0],
+    'flag_display': False,
+    'ratio_fixe': None,
+    'slant_fix': None,
+    'save_fit': False,
+    'clahe_only': False,
+    'protus_only': False,
+    'disk_display': True,
+    'delta_radius': 0,
+    'crop_width_square': False,
+    'transversalium': True,
+    'stubborn_transversalium': False,
+    'trans_strength': 301,
+    'img_rotate': 0,
+    'flip_x': False,
+    'workDir': '',
+    'fixed_width': None,
+    'output_dir': '',
+    'input_dir': '',
+    'specDir': '',
+    'selected_mode': 'File input mode',
+    'continuous_detect_mode': False,
+    'dispersion': 0.05,
+    'ellipse_fit_shift': 10,
+    'de-vignette': False,
+}
+
+
+def default_options():
+    return {k: (list(v) if isinstance(v, list) else v) for k, v in options.items()}
+
+
+def precheck_files(serfiles, options):
+    options['tempo'] = 30000 if len(serfiles) == 1 else 5000
+    good_tasks = []
+    for serfile in serfiles:
+        print(serfile)
+        if serfile == '':
+            print("ERROR filename empty")
+            continue
+        if os.path.basename(serfile) == '':
+            print('filename ERROR : ', serfile)
+            continue
+        try:
+            with open(serfile, "rb"):
+                pass
+        except Exception:
+            traceback.print_exc()
+            print('ERROR opening file : ', serfile)
+            continue
+        good_tasks.append((serfile, options.copy()))
+    return good_tasks
+
+
+def handle_files(files, options, flag_command_line=False):
+    good_tasks = precheck_files(files, options)
+    try:
+        Solex_recon.solex_do_work(good_tasks, flag_command_line)
+        return True
+    except Exception:
+        print('ERROR ENCOUNTERED')
+        traceback.print_exc()
+        return False
+
+
+def handle_folder(options):
+    files = glob.glob(os.path.join(options['input_dir'], '*.ser')) + glob.glob(os.path.join(options['input_dir'], '*.SER'))
+    return handle_files(sorted(set(files)), options, True)
+
+
+def _init_distributed():
+    if int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+        return
+    import torch
+    import torch.distributed as td
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    td.init_process_group('nccl')
+
+
+def main(argv=None):
+    opts = default_options()
+    serfiles = CLI_handler.handle_CLI(opts, argv)
+    if not serfiles:
+        print(CLI_handler.usage())
+        return 1
+    _init_distributed()
+    return 0 if handle_files(serfiles, opts, flag_command_line=True) else 1
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -1,0 +1,172 @@
+"""Orchestration of the SHG reconstruction on MI355X.
+
+Keeps the reference's call surface (Solex_recon.py:26-174): solex_do_work(tasks,
+flag_command_line), solex_read(file, options), solex_process(options, disk_list,
+backup_bounds, hdr), single_image_process(...), including the `options` keys they
+mutate (basefich0, shift_requested, shift, ratio_fixe, slant_fix) and the output files.
+
+What changed underneath:
+  * the SER file is decoded ONCE into HBM (the reference reads it twice, :61-63) and
+    both frame passes are HIP kernels on the resident stack;
+  * disks stay in HBM from extraction to the final contrast products (DeviceImage);
+    the reference pickles them into a multiprocessing.Pool worker (:38);
+  * file encoders and the matplotlib diagnostics run on a background thread
+    (outputs.py), which is where the reference's Pool(4) overlap came from;
+  * with torch.distributed initialised (one process per GPU) the frames of ONE scan are
+    sharded across ranks: all-reduce after the mean/max pass, all-gather of the disk
+    columns after extraction, post-processing on the mosaic (rank 0 writes the files).
+    Several files (folder mode) are dealt round-robin to ranks instead: no collective.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import dist, ops, outputs
+from .device import DeviceImage, to_device_u16
+from .ellipse_to_circle import correct_image, ellipse_to_circle
+from .fits_io import write_fits
+from .solex_util import (clearlog, compute_mean_return_fit, correct_transversalium2, extract_disks, image_process,
+                         logme, make_header, output_path, write_complete)
+from .video_reader import video_reader
+
+
+def solex_do_work(tasks, flag_command_line=False):
+    """tasks: list of (file, options).  Raises on failure (the front door catches, SHG_MAIN.py:136-143)."""
+    tasks = list(tasks)
+    shard_frames = dist.active() and len(tasks) == 1
+    try:
+        for i, (file, options) in enumerate(tasks):
+            if dist.active() and not shard_frames and i % dist.world_size() != dist.rank():
+                continue                                    # folder mode: file i belongs to rank i mod G
+            print('file %s is processing' % file)
+            options['_shard_frames'] = shard_frames
+            disk_list, backup_bounds, hdr = solex_read(file, options)
+            if shard_frames and dist.rank() != 0:
+                continue                                    # the mosaic is post-processed and written once
+            solex_process(options, disk_list, backup_bounds, hdr)
+    finally:
+        outputs.flush()
+
+
+def _writes_files(options):
+    return not (options.get('_shard_frames') and dist.rank() != 0)
+
+
+def solex_read(file, options):
+    """Read one scan; return (disk_list, (backup_y1, backup_y2), hdr).  disk_list[i] is the raw
+    uint16 disk [ih, FrameCount] for options['shift'][i], in HBM."""
+    rdr = file if hasattr(file, 'device_stack') else video_reader(file)
+    basefich0 = os.path.splitext(str(rdr.file))[0]
+    options['basefich0'] = basefich0
+    # ranks other than 0 of a frame-sharded scan compute the same mosaic but write nothing
+    wopts = options if _writes_files(options) else dict(options, _nolog=True, save_fit=False)
+    clearlog(basefich0 + '_log.txt', wopts)
+    logme(basefich0 + '_log.txt', wopts, 'Pixel shift : ' + str(options['shift']))
+    options['shift_requested'] = options['shift']
+    # ellipse_fit_shift and 0 are "fake" shifts; if requested they are not double counted (:55)
+    options['shift'] = list(dict.fromkeys([options['ellipse_fit_shift'], 0] + options['shift']))
+    if options.get('_shard_frames'):
+        rdr.frame_range = dist.frame_block(int(rdr.FrameCount))
+    hdr = make_header(rdr)
+    ih, iw = rdr.ih, rdr.iw
+
+    mean_img, fit, backup_y1, backup_y2 = compute_mean_return_fit(rdr, wopts, hdr, iw, ih, basefich0)
+    disks = extract_disks(rdr, fit, options['shift'], flip_x=bool(options['flip_x']))     # flip fused (:74-76)
+    hdr['NAXIS1'] = iw          # as the reference (:65); the FITS writer takes NAXIS* from the data anyway
+
+    disk_list = [DeviceImage(disks[i]) for i in range(disks.shape[0])]
+    for i, disk in enumerate(disk_list):
+        basefich = basefich0 + '_shift=' + str(options['shift'][i])
+        flag_requested = options['shift'][i] in options['shift_requested']
+        if wopts['save_fit'] and flag_requested:
+            outputs.submit(write_fits, output_path(basefich + '_raw.fits', options), disk, hdr)
+    return disk_list, (backup_y1, backup_y2), hdr
+
+
+def solex_process(options, disk_list, backup_bounds, hdr):
+    """Circularise, de-transversalium, crop and contrast every requested disk."""
+    basefich0 = options['basefich0']
+    if options['transversalium']:
+        logme(basefich0 + '_log.txt', options, 'Transversalium correction : ' + str(options['trans_strength']))
+    else:
+        logme(basefich0 + '_log.txt', options, 'Transversalium disabled')
+    logme(basefich0 + '_log.txt', options, 'Mirror X : ' + str(options['flip_x']))
+    logme(basefich0 + '_log.txt', options, 'Post-rotation : ' + str(options['img_rotate']) + ' degrees')
+    logme(basefich0 + '_log.txt', options, f'Protus adjustment : {options["delta_radius"]}')
+    logme(basefich0 + '_log.txt', options, f'de-vignette : {options["de-vignette"]}')
+    borders = [0, 0, 0, 0]
+    cercle0 = (-1, -1, -1)
+    results = []
+    for i in range(len(disk_list)):
+        flag_requested = options['shift'][i] in options['shift_requested']
+        basefich = basefich0 + '_shift=' + str(options['shift'][i])
+        # disk_list[0] is always the ellipse-fit shift (more limb contrast)
+        if options['ratio_fixe'] is None and options['slant_fix'] is None:
+            frame_circularized, cercle0, options['ratio_fixe'], phi, borders = ellipse_to_circle(
+                disk_list[i], options, basefich)
+            options['slant_fix'] = math.degrees(phi)          # stored in degrees (:117)
+        else:
+            ratio = options['ratio_fixe'] if options['ratio_fixe'] is not None else 1.0
+            phi = math.radians(options['slant_fix']) if options['slant_fix'] is not None else 0.0
+            if flag_requested:
+                frame_circularized = correct_image(disk_list[i], phi, ratio, np.array([-1.0, -1.0]), -1.0, options,
+                                                   print_log=i == 0)[0]
+                if options['de-vignette']:
+                    if cercle0 == (-1, -1, -1):
+                        print("WARNING: cannot de-vignette without ellipse fit")
+                    else:
+                        raise NotImplementedError('de-vignette (removeVignette, solex_util.py:590-654) is not part '
+                                                  'of the MI355X hot path yet')
+        if not flag_requested:
+            continue
+        results.append(single_image_process(frame_circularized, hdr, options, cercle0, borders, basefich, backup_bounds))
+        write_complete(basefich0 + '_log.txt', options)
+    return results
+
+
+def single_image_process(frame_circularized, hdr, options, cercle0, borders, basefich, backup_bounds):
+    if options['save_fit']:
+        outputs.submit(write_fits, output_path(basefich + '_circular.fits', options),
+                       _as_image(frame_circularized), hdr)
+
+    if options['transversalium']:
+        if not cercle0 == (-1, -1, -1):
+            detransversaliumed = correct_transversalium2(frame_circularized, cercle0, borders, options, 0, basefich)
+        else:
+            detransversaliumed = correct_transversalium2(
+                frame_circularized, (0, 0, 99999),
+                [0, backup_bounds[0] + 20, frame_circularized.shape[1] - 1, backup_bounds[1] - 20], options, 0, basefich)
+    else:
+        detransversaliumed = frame_circularized
+
+    if options['save_fit'] and options['transversalium']:
+        outputs.submit(write_fits, output_path(basefich + '_detransversaliumed.fits', options),
+                       _as_image(detransversaliumed), hdr)
+
+    cercle = cercle0
+    if options['fixed_width'] is not None or options['crop_width_square']:
+        src = to_device_u16(detransversaliumed)
+        h, w = src.shape
+        nw = h if options['fixed_width'] is None else options['fixed_width']
+        nw2 = nw // 2
+        cx = w // 2 if cercle == (-1, -1, -1) else int(cercle[0])
+        tx = nw2 - cx
+        lo, hi = max(0, cx - nw2), min(cx + nw2, w)
+        # new_img[:, :hi-lo] = img[:, lo:hi]; then np.roll by tx when tx > 0 and refill the first tx columns (:161-167).
+        # The rolled-in tail is fill colour whenever the copied span fits, which it does: hi - lo <= nw - tx.
+        n = max(hi - lo, 0)
+        fill = int(src.view(torch.int16)[0, 0].item()) & 0xffff      # img[0, 0]
+        dx0 = tx if tx > 0 else 0
+        if dx0 + n > nw:
+            n = nw - dx0            # np.roll would wrap these columns round and the refill overwrite them
+        detransversaliumed = DeviceImage(ops.crop_pad_u16(src, nw, lo, dx0, n, fill))
+        if not cercle == (-1, -1, -1):
+            cercle = (nw2, cercle[1], cercle[2])
+
+    return image_process(detransversaliumed, cercle, options, hdr, basefich)
+
+
+def _as_image(x):
+    return x if isinstance(x, DeviceImage) else DeviceImage(to_device_u16(x))

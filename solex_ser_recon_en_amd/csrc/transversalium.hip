@@ -73,30 +73,43 @@ __global__ __launch_bounds__(NT) void k_rowpair_stats(const uint16_t* __restrict
     __syncthreads();
     const uint16_t* r1 = img + y * pitch + a;
     const uint16_t* r0 = img + (y - 1) * pitch + a;
+    // Zero pixels give -inf / +inf / NaN ratios.  NumPy keeps infinities as ordinary (sortable) values and
+    // lets any NaN poison the row statistic (np.median -> nan -> empty inlier set -> nan); same here.
     for (int i = threadIdx.x; i < n2; i += NT) {
         double x = __builtin_inf();
         if (i < n) {
             x = log((double)r1[i] / (double)r0[i]);        // np.log(strip1 / strip0)
-            if (!(x == x) || x == __builtin_inf() || x == -__builtin_inf()) bad = 1;
+            if (x != x) bad = 1;
         }
         v[i] = x;
     }
     __syncthreads();
-    if (bad) {                           // a zero pixel: NumPy propagates nan/inf into the row statistic
+    if (bad) {
         if (threadIdx.x == 0) out[t] = __builtin_nan("");
         return;
     }
     bitonic_sort(v, n2);
     const double med = median_sorted(v, n);
-    for (int i = threadIdx.x; i < n2; i += NT) d[i] = i < n ? fabs(v[i] - med) : __builtin_inf();
+    for (int i = threadIdx.x; i < n2; i += NT) {
+        double dv = __builtin_inf();
+        if (i < n) {
+            dv = fabs(v[i] - med);                         // inf - inf or a NaN median -> NaN
+            if (dv != dv) bad = 1;
+        }
+        d[i] = dv;
+    }
     __syncthreads();
+    if (bad) {
+        if (threadIdx.x == 0) out[t] = __builtin_nan("");
+        return;
+    }
     bitonic_sort(d, n2);
     const double mdev = median_sorted(d, n);
     double s = 0.0, cnt = 0.0;
     for (int i = threadIdx.x; i < n; i += NT) {
         const double x = v[i];
         const double dev = fabs(x - med);
-        const bool keep = (mdev != 0.0) ? (dev / mdev < 2.0) : true;   // s = d/mdev if mdev else zeros; data[s < m]
+        const bool keep = (mdev != 0.0) ? (dev / mdev < 2.0) : true;   // s = d/mdev if mdev else zeros; data[s < m] (NaN < 2 is false)
         if (keep) { s += x; cnt += 1.0; }
     }
     s = block_sum(s, red);

@@ -1,0 +1,108 @@
+"""Output encoders and diagnostics, kept off the critical path.
+
+The reference writes PNG/FITS products and three matplotlib diagnostics inline
+(solex_util.py:263-273, 482-488, 556-587; ellipse_to_circle.py:316-341); each 400-dpi
+plot costs seconds.  Here every file write is a task on a single background thread
+(device -> host copy + encode + write), so the GPU pipeline of the next disk / next file
+proceeds meanwhile.  flush() re-raises the first failure, so a failed write still
+stops the batch the way an exception in the reference's worker does (Solex_recon.py:42).
+"""
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import png_io
+
+_lock = threading.Lock()
+_pool = None
+_pending = []
+synchronous = False          # tests can force inline execution
+
+
+def submit(fn, *args):
+    global _pool
+    if synchronous:
+        fn(*args)
+        return
+    with _lock:
+        if _pool is None:
+            _pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='shg-output')
+        _pending.append(_pool.submit(fn, *args))
+
+
+def flush():
+    with _lock:
+        todo = list(_pending)
+        del _pending[:]
+    err = None
+    for fut in todo:
+        try:
+            fut.result()
+        except Exception as e:      # noqa: BLE001 -- keep draining, report the first
+            err = err or e
+    if err is not None:
+        raise err
+
+
+def write_png16(path, img):
+    png_io.write_png(path, np.asarray(img), 0)
+
+
+# ---- diagnostics (matplotlib Agg figures; same content as the reference's plots) ----------
+def _figure():
+    import matplotlib
+    matplotlib.use('Agg', force=False)
+    import matplotlib.figure
+    return matplotlib.figure.Figure()
+
+
+def plot_spectral_line(path, mean_img, xs, ys, curve, ih, stride):
+    import matplotlib.pyplot
+    fig = _figure()
+    ax = fig.add_subplot(1, 1, 1)
+    ax.imshow(np.asarray(mean_img), cmap=matplotlib.pyplot.cm.gray)
+    ax.plot(xs[::stride], ys[::stride], 'rx', label='line detection')
+    ax.plot(curve, np.arange(ih), label='polynomial fit')
+    ax.legend(loc='center left', bbox_to_anchor=(1, 0.5))
+    ax.set_aspect(0.1)
+    fig.tight_layout()
+    fig.savefig(path, dpi=400)
+
+
+def plot_transversalium(path, c):
+    fig = _figure()
+    ax = fig.add_subplot(1, 1, 1)
+    ax.plot(c)
+    ax.set_xlabel('y')
+    ax.set_ylabel('transversalium correction factor')
+    fig.savefig(path, dpi=300)
+
+
+def plot_ellipse_fit(path, image, fix_img, raw_X, X_f, ellipse_points, borders):
+    import matplotlib.pyplot
+    gray = matplotlib.pyplot.cm.gray
+    image = np.asarray(image)
+    fig = _figure()
+    ax = [[fig.add_subplot(2, 2, 1), fig.add_subplot(2, 2, 2)], [fig.add_subplot(2, 2, 3), fig.add_subplot(2, 2, 4)]]
+    fig.tight_layout()
+    ax[0][0].imshow(image, cmap=gray)
+    ax[0][0].set_title('uncorrected image', fontsize=11)
+    ax[0][0].set_aspect('equal')
+    ax[0][1].set_aspect('equal')
+    ax[0][1].imshow(image, cmap=gray)
+    ax[0][1].plot(raw_X[:, 1], raw_X[:, 0], 'ro', label='edge detection')
+    ax[0][1].legend(prop={'size': 6})
+    ax[1][1].set_aspect('equal')
+    ax[1][1].plot(X_f[:, 1], X_f[:, 0], 'ro', label='filtered edges')
+    ax[1][1].plot(ellipse_points[:, 1], ellipse_points[:, 0], color='b', label='ellipse fit')
+    ax[1][1].set_ylim([image.shape[0], 0])
+    ax[1][1].legend(prop={'size': 6})
+    ax[1][0].set_aspect('equal')
+    ax[1][0].imshow(np.asarray(fix_img), cmap=gray)
+    ax[1][0].axhline(y=borders[1])
+    ax[1][0].axhline(y=borders[3])
+    ax[1][0].axvline(x=borders[0])
+    ax[1][0].axvline(x=borders[2])
+    ax[1][0].set_title('geometrically corrected image', fontsize=11)
+    fig.savefig(path, dpi=300)

@@ -1,0 +1,301 @@
+"""Stage functions of the SHG pipeline on MI355X.
+
+Same names, argument order and return tuples as the reference's solex_util.py
+(SURVEY.md section 8b); the per-pixel / per-frame arithmetic runs in libshg_hip.so
+(see ops.py), the 1-D control plane (polynomial fits, Savitzky-Golay trend, percentiles
+from histograms) stays on the host with NumPy/SciPy exactly as the reference computes it.
+Images are DeviceImage handles: they stay in HBM between stages.
+"""
+import datetime
+import math
+import os
+import traceback
+
+import numpy as np
+import torch
+from numpy.polynomial.polynomial import polyval
+
+from . import dist, ops, outputs
+from .device import DeviceImage, to_device_u16
+from .fits_io import make_header, write_fits  # noqa: F401  (make_header is part of the surface)
+
+
+# ---- log / path helpers (reference solex_util.py:29-63) ------------------------
+def output_path(path, options):
+    if options['output_dir'].strip() == '':
+        return path
+    return os.path.join(options['output_dir'], os.path.basename(path))
+
+
+def _append(path, options, text, mode):
+    try:
+        with open(output_path(path, options), mode) as f:
+            f.write(text)
+    except Exception:
+        traceback.print_exc()
+        print('ERROR: failed to log file: ' + path)
+
+
+def clearlog(path, options):
+    if '_nolog' in options:
+        return      # the reference only guards logme; a file-less mode should not create an empty log either
+    _append(path, options, 'start time: ' + str(datetime.datetime.now()) + '\n', 'w')
+
+
+def write_complete(path, options):
+    if '_nolog' in options:
+        return
+    _append(path, options, 'end time: ' + str(datetime.datetime.now()) + '\n', 'a')
+
+
+def logme(path, options, s):
+    if '_nolog' in options:
+        return
+    _append(path, options, s + '\n', 'a')
+
+
+def _plots_enabled(options):
+    return not options['clahe_only'] and not options['protus_only'] and '_nolog' not in options
+
+
+# ---- a2: mean and max frames (reference solex_util.py:174-188) -----------------------
+def compute_mean_max(rdr, options, basefich0):
+    logme(basefich0 + '_log.txt', options, 'Width, Height : ' + str(rdr.Width) + ' ' + str(rdr.Height))
+    logme(basefich0 + '_log.txt', options, 'Number of frames : ' + str(rdr.FrameCount))
+    stack = rdr.device_stack()
+    n, h, w, bpp = ops.stack_geometry(stack)
+    total, mx = ops.accumulate_sum_max(stack)
+    if dist.is_sharded(rdr):
+        total, mx = dist.allreduce_sum_max(total, mx)          # integer SUM / MAX: bit-identical to one rank
+    mean, mxo = ops.finalize_mean_max(total, mx, int(rdr.FrameCount), h, w, bpp)
+    return DeviceImage(mean), DeviceImage(mxo)
+
+
+# ---- a3: sunlit row range (reference solex_util.py:165-172) --------------------------
+def detect_bord(img, axis):
+    t = to_device_u16(img)
+    if axis == 0:
+        t = t.view(torch.int16).t().contiguous().view(torch.uint16)
+    elif t.stride(0) != t.shape[1]:
+        t = t.contiguous()
+    ymean = ops.row_mean_u16(ops.box_blur_u16(t, 5, 5)).cpu().numpy()
+    where_sun = ymean > np.median(ymean) / 5
+    lb = np.argmax(where_sun)
+    ub = ymean.shape[0] - 1 - np.argmax(np.flip(where_sun))
+    return lb, ub
+
+
+# ---- a4: spectral line detection + cubic fit (reference solex_util.py:191-274) -------
+def compute_mean_return_fit(vid_rdr, options, hdr, iw, ih, basefich0):
+    mean_img, max_img = compute_mean_max(vid_rdr, options, basefich0)
+    if options['save_fit']:
+        outputs.submit(write_fits, output_path(basefich0 + '_mean.fits', options), mean_img, hdr)
+
+    y1, y2 = detect_bord(max_img, axis=1)
+    clip = int((y2 - y1) * 0.05)
+    y1 = min(max_img.shape[0] - 1, y1 + clip)
+    y2 = max(0, y2 - clip)
+    logme(basefich0 + '_log.txt', options, 'Vertical limits y1, y2 : ' + str(y1) + ' ' + str(y2))
+    blur_width_x = 25
+    blur_width_y = int((y2 - y1) * 0.01)
+    # a zero blur height (sunlit span <= 100 rows) raises here, as cv2.blur does in the reference (:229-230)
+    blur = ops.box_blur_u16(mean_img.t, blur_width_x, blur_width_y)
+    lo, hi = blur_width_x // 2, iw + (-blur_width_x // 2)            # blur[:, 12:-13]
+    traces = torch.stack([ops.row_argmin_u16(blur, lo, hi), ops.row_argmin_u16(mean_img.t, 0, iw)]).cpu().numpy()
+    min_intensity = blur_width_x // 2 + traces[0].astype(np.int64)
+    min_intensity_sharp = traces[1].astype(np.int64)
+
+    rows = np.arange(y1, y2)
+    rows_d = np.asarray(rows, dtype='d')
+    p = np.flip(np.asarray(np.polyfit(rows, min_intensity[y1:y2], 3), dtype='d'))
+    delta = polyval(rows_d, p) - min_intensity[y1:y2]
+    stdv = np.std(delta)
+    keep = np.abs(delta / stdv) < 3
+    p = np.flip(np.asarray(np.polyfit(rows[keep], min_intensity[y1:y2][keep], 3), dtype='d'))
+
+    delta_sharp = polyval(rows_d, p) - min_intensity_sharp[y1:y2]
+    values, counts = np.unique(np.around(delta_sharp, 1), return_counts=True)
+    ind = np.argpartition(-counts, kth=2)[:2]                         # needs >= 3 distinct values (:246)
+    shift = values[ind[0]]
+    mask_good = np.abs(delta_sharp - shift) < 5
+    p = np.flip(np.asarray(np.polyfit(rows[mask_good], min_intensity_sharp[y1:y2][mask_good], 3), dtype='d'))
+    logme(basefich0 + '_log.txt', options, 'Spectral line polynomial fit: ' + str(p))
+
+    curve = polyval(np.asarray(np.arange(ih), dtype='d'), p)
+    floor = np.floor(curve)
+    fit = np.stack([floor, curve - floor, np.arange(ih, dtype='d'), curve], axis=1)
+
+    if _plots_enabled(options):
+        outputs.submit(outputs.plot_spectral_line, output_path(basefich0 + '_spectral_line_data.png', options),
+                       mean_img, min_intensity_sharp[y1:y2][mask_good], rows[mask_good], curve, ih, (y2 - y1) // 20 + 1)
+    return mean_img, fit, y1, y2
+
+
+# ---- a5: per-frame column extraction (reference solex_util.py:93-144) ---------------------
+def column_plan(fit, shifts, ih, iw):
+    """Clamped left sample column per shift and the (unclamped) bilinear weights, :113-123."""
+    fit = np.asarray(fit)
+    ind_l = np.empty((len(shifts), ih), dtype=np.int32)
+    for i, shift in enumerate(shifts):
+        col = (fit[:, 0] + np.ones(ih) * shift).astype(int)
+        col[col < 0] = 0
+        col[col > iw - 2] = iw - 2
+        ind_l[i] = col
+    left_weights = np.ones(ih) - fit[:, 1]
+    right_weights = np.ones(ih) - left_weights
+    return ind_l, left_weights, right_weights
+
+
+def extract_disks(rdr, fit, shifts, flip_x=False):
+    """-> uint16 GPU tensor [S, ih, FrameCount]; all ranks hold the full mosaic when sharded."""
+    ih, iw = int(rdr.ih), int(rdr.iw)
+    ind_l, lw, rw = column_plan(fit, shifts, ih, iw)
+    stack = rdr.device_stack()
+    n_total = int(rdr.FrameCount)
+    if dist.is_sharded(rdr):
+        local = ops.extract_columns(stack, ind_l, lw, rw)
+        return dist.gather_columns(local, rdr.frame_range, n_total, flip_x)
+    return ops.extract_columns(stack, ind_l, lw, rw, n_cols=n_total, k_offset=0, flip_x=flip_x)
+
+
+def read_video_improved(rdr, fit, options):
+    disks = extract_disks(rdr, fit, options['shift'])
+    return [DeviceImage(disks[i]) for i in range(disks.shape[0])], rdr.ih, rdr.iw, rdr.FrameCount
+
+
+# ---- a9: transversalium (reference solex_util.py:76-86, 383-516) ---------------------------
+def reject_outliers(data, m=2):
+    median_value = np.median(data)
+    d = np.abs(data - median_value)
+    mdev = np.median(d)
+    s = d / mdev if mdev else np.zeros(len(d))
+    return data[s < m]
+
+
+def _tukey(n, a=0.05):
+    def t(x):
+        if 0 <= x < a * n / 2:
+            return 1 / 2 * (1 - math.cos(2 * math.pi * x / (a * n)))
+        elif a * n / 2 <= x <= n / 2:
+            return 1
+        elif n / 2 <= x <= n:
+            return t(n - x)
+        print('error: weird input for taper function: ' + str(x))
+        return 1
+    return np.array([t(x) for x in range(n)])
+
+
+def correct_transversalium2(img, circle, borders, options, reqFlag, basefich):
+    from scipy.signal import savgol_filter
+    if options.get('stubborn_transversalium'):
+        raise NotImplementedError('stubborn transversalium (cv2.filter2D path, solex_util.py:415-423) is out of scope')
+    t = to_device_u16(img)
+    h, w = t.shape
+    y1 = math.ceil(max(circle[1] - circle[2], borders[1]))
+    y2 = math.floor(min(circle[1] + circle[2], borders[3]))
+    count = max(y2 - y1, 1)
+    xa = np.zeros(count, dtype=np.int32)
+    xb = np.zeros(count, dtype=np.int32)
+    for y in range(y1 + 1, y2):
+        dx = math.floor((circle[2] ** 2 - (y - circle[1]) ** 2) ** 0.5)
+        a, b, _ = slice(math.ceil(max(circle[0] - dx, borders[0])),
+                        math.floor(min(circle[0] + dx, borders[2]))).indices(w)      # NumPy slice semantics
+        xa[y - y1], xb[y - y1] = a, max(a, b)
+    if y2 - y1 >= 1:
+        y_ratios_r = ops.rowpair_logratio_stats(t, y1, y2, xa, xb).cpu().numpy()
+    else:
+        y_ratios_r = np.array([0.0])                                                  # y_ratios_r = [0], :386
+    trend = savgol_filter(y_ratios_r, min(options['trans_strength'], len(y_ratios_r) // 2 * 2 - 1), 3)
+    detrended = y_ratios_r - trend
+    detrended -= np.mean(detrended)
+    correction = np.exp(-np.cumsum(detrended))
+    n = correction.shape[0]
+    correction_t = np.ones(n) + (correction - np.ones(n)) * _tukey(n)
+    c = np.ones(h)
+    c[y1:y2] = correction_t
+    options['_transversalium_cache'] = c
+    if (not reqFlag) and _plots_enabled(options):
+        outputs.submit(outputs.plot_transversalium, output_path(basefich + '_transversalium_correction.png', options), c)
+    return DeviceImage(ops.scale_rows_u16(t, c))
+
+
+# ---- a12: rescale_brightness (reference solex_util.py:519-525) ------------------------------
+def rescale_brightness(img, lo, hi, alpha=1.0):
+    if isinstance(img, np.ndarray) and img.dtype == np.uint8:
+        # 8-bit images only reach this function from clahe_apply.py; a few hundred KB -> host float64, as the reference
+        sat = 255
+        assert sat >= hi > lo
+        rescaled = float(sat) * alpha * (img - lo) / (hi - lo)
+        rescaled[rescaled < 0] = 0
+        rescaled[rescaled > sat] = sat
+        return rescaled.astype(img.dtype)
+    assert 65535 >= hi > lo                                                            # :521
+    return DeviceImage(ops.rescale_u16(to_device_u16(img), lo, hi, alpha))
+
+
+def percentile_from_hist(hist, q):
+    """np.percentile(values, q) (method 'linear') from the exact histogram of integer values.
+    Follows NumPy's _quantile: virtual index (n-1)*(q/100), neighbours by order statistic, _lerp."""
+    hist = np.asarray(hist, dtype=np.int64)
+    n = int(hist.sum())
+    if n == 0:
+        raise ValueError('percentile of an empty image')
+    cum = np.cumsum(hist)
+    quantile = np.true_divide(q, 100)
+    virtual = (n - 1) * quantile
+    prev = math.floor(virtual)
+    gamma = virtual - prev
+    prev = min(max(prev, 0), n - 1)
+    nxt = min(prev + 1, n - 1)
+    a = float(np.searchsorted(cum, prev + 1))            # value of the prev-th order statistic (0-based)
+    b = float(np.searchsorted(cum, nxt + 1))
+    diff = b - a
+    return b - diff * (1 - gamma) if gamma >= 0.5 else a + diff * gamma
+
+
+def max_from_hist(hist):
+    return int(np.flatnonzero(np.asarray(hist))[-1])
+
+
+def _rot90(t, k):
+    k %= 4
+    if k == 0:
+        return t
+    return torch.rot90(t.view(torch.int16), k, dims=(0, 1)).contiguous().view(torch.uint16)
+
+
+# ---- a11: CLAHE + contrast products + writers (reference solex_util.py:527-588) ---------------
+def image_process(frame, cercle, options, header, basefich):
+    frame_t = to_device_u16(frame)
+    cl1 = ops.clahe(frame_t, 0.8, 2)
+    hists = torch.stack([ops.histogram(frame_t), ops.histogram(cl1)]).cpu().numpy()
+    bright = percentile_from_hist(hists[0], 99.9999)                # basically the same as max
+    dark_clahe = percentile_from_hist(hists[1], 10)
+    bright_clahe = max_from_hist(hists[1])
+    frame_raw = frame_t
+    assert 65535 >= bright > bright * 0.25 and 65535 >= bright * 0.18 > 0 and 65535 >= bright_clahe > dark_clahe
+    frame_HC = ops.rescale_u16(frame_t, bright * 0.25, bright)
+    frame_protus = ops.rescale_u16(frame_t, 0, bright * 0.18)
+    cc = ops.rescale_u16(cl1, dark_clahe, bright_clahe)
+    if not cercle == (-1, -1, -1) and options['disk_display']:
+        x0 = int(cercle[0])
+        y0 = int(cercle[1])
+        r = int(cercle[2]) + options['delta_radius']
+        if r > 0:
+            ops.fill_disc_u16(frame_protus, x0, y0, r, 80)
+
+    k = options['img_rotate'] // 90
+    frame_raw, frame_HC, frame_protus, cc = (_rot90(x, k) for x in (frame_raw, frame_HC, frame_protus, cc))
+
+    if '_nolog' not in options:
+        if options['clahe_only'] or not options['protus_only']:
+            print('saving image to:' + basefich + '_clahe.png')
+            outputs.submit(outputs.write_png16, output_path(basefich + '_clahe.png', options), cc)
+        if options['protus_only'] or not options['clahe_only']:
+            outputs.submit(outputs.write_png16, output_path(basefich + '_protus.png', options), frame_protus)
+        if not options['clahe_only'] and not options['protus_only']:
+            outputs.submit(outputs.write_png16, output_path(basefich + '_uncontrasted.png', options), frame_raw)
+            outputs.submit(outputs.write_png16, output_path(basefich + '_high_contrast.png', options), frame_HC)
+    if options['save_fit']:
+        outputs.submit(write_fits, output_path(basefich + '_clahe.fits', options), DeviceImage(cl1), header)
+    return (DeviceImage(cc), DeviceImage(frame_protus))

@@ -1,0 +1,152 @@
+"""Host-side logic of the product (no GPU): limb fit vs the oracle, percentile from
+histograms, FITS / PNG encoders, CLI flag table, SER header parsing."""
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import limb_oracle as limb
+from oracle import shg_oracle as orc
+from solex_ser_recon_en_amd import CLI_handler, fits_io, limb_fit, png_io, synth
+from solex_ser_recon_en_amd.ellipse_to_circle import get_correction_matrix
+from solex_ser_recon_en_amd.solex_util import column_plan, max_from_hist, percentile_from_hist
+
+
+def test_limb_fit_matches_oracle_and_skimage(golden):
+    g = golden('g13_limb')
+    for i in range(3):
+        sigma, lo, hi = g['canny%d_params' % i]
+        np.testing.assert_array_equal(limb_fit.canny_edges(g['flooded'], sigma, lo, hi), g['canny%d' % i])
+    np.testing.assert_array_equal(limb_fit.canny_edges(g['noisy'], 1.0, 0.05, 0.12), g['canny_noisy'])
+    np.testing.assert_array_equal(limb_fit.flood_image(g['small']), g['flooded'])
+    X, raw = limb_fit.edge_points(g['small'])
+    Xo, rawo = limb.get_edge_list(g['small'].copy())
+    np.testing.assert_array_equal(X, Xo)
+    np.testing.assert_array_equal(raw, rawo)
+    got = limb_fit.two_step(X * 4, get_correction_matrix)
+    want = limb.two_step(Xo * 4)
+    for a, b in zip(got[:4], want[:4]):
+        np.testing.assert_allclose(a, b, rtol=1e-12)
+    np.testing.assert_array_equal(got[4], want[4])
+
+
+def test_correction_matrix_golden(golden):
+    g = golden('g7_matrix')
+    for (phi, r), mat, theta in zip(g['params'], g['mats'], g['thetas']):
+        m, t = get_correction_matrix(phi, r)
+        np.testing.assert_allclose(m, mat, rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(t, theta, rtol=1e-13, atol=1e-15)
+
+
+@pytest.mark.parametrize('q', [0, 10, 50, 99, 99.9999, 100, 33.3])
+def test_percentile_from_hist_is_np_percentile(q):
+    rng = np.random.default_rng(int(q * 10))
+    for n in (1, 2, 7, 1000, 54321):
+        img = rng.integers(0, 65536, n).astype(np.uint16)
+        if n > 100:
+            img[: n // 3] = 40000          # heavy ties
+        hist = np.bincount(img, minlength=65536)
+        assert percentile_from_hist(hist, q) == np.percentile(img, q)
+        assert max_from_hist(hist) == img.max()
+
+
+def test_percentile_golden(golden):
+    g = golden('g5_rescale')
+    hist = np.bincount(g['image'].ravel(), minlength=65536)
+    assert percentile_from_hist(hist, 99.9999) == float(g['bright'])
+    assert percentile_from_hist(hist, 10) == float(g['p10'])
+
+
+def test_column_plan_matches_oracle(golden):
+    g = golden('g2_extract')
+    fit = g['u16_rot_fit']
+    shifts = [10, 0, -25, 7]
+    ind_l, lw, rw = column_plan(fit, shifts, fit.shape[0], 40)
+    cols, olw, orw = orc.column_indices(fit, shifts, 40)
+    np.testing.assert_array_equal(ind_l, np.stack([c[0] for c in cols]))
+    np.testing.assert_array_equal(lw, olw)
+    np.testing.assert_array_equal(rw, orw)
+
+
+def test_fits_writer_matches_astropy_bytes(golden):
+    g = golden('g9_fits')
+
+    class R:
+        iw, ih = 7, 5
+    hdr = fits_io.make_header(R)
+    hdr['NAXIS1'] = 9
+    assert fits_io.fits_bytes(g['array'], hdr) == g['fits_bytes'].tobytes()
+
+
+def test_fits_round_trip(tmp_path):
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 65536, (33, 47)).astype(np.uint16)
+    path = str(tmp_path / 'x.fits')
+    fits_io.write_fits(path, img, {'BIN1': 1})
+    back, cards = fits_io.read_fits_u16(path)
+    np.testing.assert_array_equal(back, img)
+    assert cards['BITPIX'] == '16' and cards['BZERO'] == '32768' and os.path.getsize(path) % 2880 == 0
+
+
+@pytest.mark.parametrize('dtype', [np.uint8, np.uint16])
+def test_png_round_trip(tmp_path, dtype):
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, np.iinfo(dtype).max + 1, (19, 23)).astype(dtype)
+    path = str(tmp_path / 'x.png')
+    png_io.write_png(path, img, 0)
+    np.testing.assert_array_equal(png_io.read_png_gray(path), img)
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    np.testing.assert_array_equal(np.array(Image.open(path)), img)          # an independent decoder agrees
+    Image.fromarray(img).save(path)                                          # filtered rows from an independent encoder
+    np.testing.assert_array_equal(png_io.read_png_gray(path), img)
+
+
+def test_cli_flag_table_matches_reference(golden, capsys):
+    table = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'g10_cli.json')))
+    base = {'shift': [0], 'flag_display': False, 'ratio_fixe': None, 'slant_fix': None, 'save_fit': False,
+            'clahe_only': False, 'protus_only': False, 'disk_display': True, 'delta_radius': 0,
+            'crop_width_square': False, 'transversalium': True, 'flip_x': False, 'fixed_width': None}
+    for arg, want in table.items():
+        opts = dict(base)
+        CLI_handler.treat_flag_at_cli(opts, arg)
+        assert opts == want, arg
+    capsys.readouterr()
+
+
+def test_cli_detached_values_and_files(capsys):
+    opts = {'shift': [0], 'fixed_width': None}
+    files = CLI_handler.handle_CLI(opts, ['-w', '-10:10:1', '-r', '900', 'a.ser', 'b.SER', 'notes.txt', '-cf'])
+    assert files == ['a.ser', 'b.SER']
+    assert opts['shift'] == list(range(-10, 11)) and opts['fixed_width'] == 900
+    assert opts['clahe_only'] is True and opts['save_fit'] is True
+    with pytest.raises(ValueError):
+        CLI_handler.handle_CLI({'shift': [0]}, ['-w'])
+    capsys.readouterr()
+
+
+def test_ser_header_parse(tmp_path):
+    from solex_ser_recon_en_amd.video_reader import video_reader
+    frames = synth.synth_frames_numpy(5, 40, 12, 8, seed=0)
+    path = str(tmp_path / 'a.ser')
+    synth.write_ser(path, frames)
+    rdr = video_reader(path)
+    assert (rdr.Width, rdr.Height, rdr.FrameCount, rdr.infilebytes) == (40, 12, 5, 1)
+    assert rdr.flag_rotate and (rdr.ih, rdr.iw) == (40, 12) and rdr.count == 480
+    ref = orc.SerReader(path)
+    k = 0
+    while rdr.has_frames():
+        np.testing.assert_array_equal(rdr.next_frame(), ref.next_frame())
+        k += 1
+    assert k == 5
+    with pytest.raises(Exception, match='neither is SER nor AVI'):
+        video_reader(str(tmp_path / 'a.txt'))
+    with pytest.raises(Exception, match='AVI'):
+        video_reader(str(tmp_path / 'a.avi'))
+    open(str(tmp_path / 'short.ser'), 'wb').write(b'LUCAM')
+    with pytest.raises(Exception, match='truncated'):
+        video_reader(str(tmp_path / 'short.ser'))
