@@ -87,6 +87,7 @@ def detect_bord(img, axis):
 
 # ---- a4: spectral line detection + cubic fit (reference solex_util.py:191-274) -------
 def compute_mean_return_fit(vid_rdr, options, hdr, iw, ih, basefich0):
+    iw, ih = int(iw), int(ih)             # the reader exposes np.uint32 like the reference's
     mean_img, max_img = compute_mean_max(vid_rdr, options, basefich0)
     if options['save_fit']:
         outputs.submit(write_fits, output_path(basefich0 + '_mean.fits', options), mean_img, hdr)
@@ -290,12 +291,12 @@ def image_process(frame, cercle, options, header, basefich):
     if '_nolog' not in options:
         if options['clahe_only'] or not options['protus_only']:
             print('saving image to:' + basefich + '_clahe.png')
-            outputs.submit(outputs.write_png16, output_path(basefich + '_clahe.png', options), cc)
+            outputs.submit(outputs.write_png16, output_path(basefich + '_clahe.png', options), DeviceImage(cc))
         if options['protus_only'] or not options['clahe_only']:
-            outputs.submit(outputs.write_png16, output_path(basefich + '_protus.png', options), frame_protus)
+            outputs.submit(outputs.write_png16, output_path(basefich + '_protus.png', options), DeviceImage(frame_protus))
         if not options['clahe_only'] and not options['protus_only']:
-            outputs.submit(outputs.write_png16, output_path(basefich + '_uncontrasted.png', options), frame_raw)
-            outputs.submit(outputs.write_png16, output_path(basefich + '_high_contrast.png', options), frame_HC)
+            outputs.submit(outputs.write_png16, output_path(basefich + '_uncontrasted.png', options), DeviceImage(frame_raw))
+            outputs.submit(outputs.write_png16, output_path(basefich + '_high_contrast.png', options), DeviceImage(frame_HC))
     if options['save_fit']:
         outputs.submit(write_fits, output_path(basefich + '_clahe.fits', options), DeviceImage(cl1), header)
     return (DeviceImage(cc), DeviceImage(frame_protus))
