@@ -41,6 +41,14 @@ typedef void* shg_stream_t;
 int         shg_abi_version(void);
 const char* shg_last_error_string(void);
 
+/* Optional per-kernel timing (bench.py roofline leg): HIP events recorded on the launch stream
+ * directly around each kernel launch, keyed by kernel tag ("accumulate", "reduce_partials",
+ * "extract", "warp", "rowpair_stats", "scale_rows", "clahe_hist", "clahe_lut", "clahe_interp",
+ * "hist", "rescale", ...).  Off by default.  shg_profile_get waits for the events of `tag`. */
+int shg_profile_enable(int on);
+int shg_profile_reset(void);
+int shg_profile_get(const char* tag, double* total_ms, int64_t* launches);
+
 /* ---- pass A: sum and max over frames -------- solex_util.py:174-188 (compute_mean_max)
  * stack: n_frames frames in file layout.  sum_out[H*W] (file layout) receives the
  * integer sum of the raw samples, max_out[H*W] their maximum (raw sample units;

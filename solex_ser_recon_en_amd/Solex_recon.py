@@ -23,7 +23,7 @@ import os
 import numpy as np
 import torch
 
-from . import dist, ops, outputs
+from . import dist, ops, outputs, timing
 from .device import DeviceImage, to_device_u16
 from .ellipse_to_circle import correct_image, ellipse_to_circle
 from .fits_io import write_fits
@@ -72,8 +72,10 @@ def solex_read(file, options):
     hdr = make_header(rdr)
     ih, iw = rdr.ih, rdr.iw
 
-    mean_img, fit, backup_y1, backup_y2 = compute_mean_return_fit(rdr, wopts, hdr, iw, ih, basefich0)
-    disks = extract_disks(rdr, fit, options['shift'], flip_x=bool(options['flip_x']))     # flip fused (:74-76)
+    with timing.stage('mean_max+line_fit'):
+        mean_img, fit, backup_y1, backup_y2 = compute_mean_return_fit(rdr, wopts, hdr, iw, ih, basefich0)
+    with timing.stage('extract'):
+        disks = extract_disks(rdr, fit, options['shift'], flip_x=bool(options['flip_x']))     # flip fused (:74-76)
     hdr['NAXIS1'] = iw          # as the reference (:65); the FITS writer takes NAXIS* from the data anyway
 
     disk_list = [DeviceImage(disks[i]) for i in range(disks.shape[0])]
@@ -104,15 +106,17 @@ def solex_process(options, disk_list, backup_bounds, hdr):
         basefich = basefich0 + '_shift=' + str(options['shift'][i])
         # disk_list[0] is always the ellipse-fit shift (more limb contrast)
         if options['ratio_fixe'] is None and options['slant_fix'] is None:
-            frame_circularized, cercle0, options['ratio_fixe'], phi, borders = ellipse_to_circle(
-                disk_list[i], options, basefich)
+            with timing.stage('ellipse_fit+warp'):
+                frame_circularized, cercle0, options['ratio_fixe'], phi, borders = ellipse_to_circle(
+                    disk_list[i], options, basefich)
             options['slant_fix'] = math.degrees(phi)          # stored in degrees (:117)
         else:
             ratio = options['ratio_fixe'] if options['ratio_fixe'] is not None else 1.0
             phi = math.radians(options['slant_fix']) if options['slant_fix'] is not None else 0.0
             if flag_requested:
-                frame_circularized = correct_image(disk_list[i], phi, ratio, np.array([-1.0, -1.0]), -1.0, options,
-                                                   print_log=i == 0)[0]
+                with timing.stage('warp'):
+                    frame_circularized = correct_image(disk_list[i], phi, ratio, np.array([-1.0, -1.0]), -1.0, options,
+                                                       print_log=i == 0)[0]
                 if options['de-vignette']:
                     if cercle0 == (-1, -1, -1):
                         print("WARNING: cannot de-vignette without ellipse fit")
@@ -131,15 +135,16 @@ def single_image_process(frame_circularized, hdr, options, cercle0, borders, bas
         outputs.submit(write_fits, output_path(basefich + '_circular.fits', options),
                        _as_image(frame_circularized), hdr)
 
-    if options['transversalium']:
-        if not cercle0 == (-1, -1, -1):
-            detransversaliumed = correct_transversalium2(frame_circularized, cercle0, borders, options, 0, basefich)
+    with timing.stage('transversalium'):
+        if options['transversalium']:
+            if not cercle0 == (-1, -1, -1):
+                detransversaliumed = correct_transversalium2(frame_circularized, cercle0, borders, options, 0, basefich)
+            else:
+                detransversaliumed = correct_transversalium2(
+                    frame_circularized, (0, 0, 99999),
+                    [0, backup_bounds[0] + 20, frame_circularized.shape[1] - 1, backup_bounds[1] - 20], options, 0, basefich)
         else:
-            detransversaliumed = correct_transversalium2(
-                frame_circularized, (0, 0, 99999),
-                [0, backup_bounds[0] + 20, frame_circularized.shape[1] - 1, backup_bounds[1] - 20], options, 0, basefich)
-    else:
-        detransversaliumed = frame_circularized
+            detransversaliumed = frame_circularized
 
     if options['save_fit'] and options['transversalium']:
         outputs.submit(write_fits, output_path(basefich + '_detransversaliumed.fits', options),
@@ -165,7 +170,8 @@ def single_image_process(frame_circularized, hdr, options, cercle0, borders, bas
         if not cercle == (-1, -1, -1):
             cercle = (nw2, cercle[1], cercle[2])
 
-    return image_process(detransversaliumed, cercle, options, hdr, basefich)
+    with timing.stage('clahe+contrast'):
+        return image_process(detransversaliumed, cercle, options, hdr, basefich)
 
 
 def _as_image(x):

@@ -26,6 +26,9 @@ P = c_void_p
 SIGNATURES = {
     'shg_abi_version': (c_int, []),
     'shg_last_error_string': (ctypes.c_char_p, []),
+    'shg_profile_enable': (c_int, [c_int]),
+    'shg_profile_reset': (c_int, []),
+    'shg_profile_get': (c_int, [ctypes.c_char_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int64)]),
     'shg_accumulate_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int64, c_int]),
     'shg_accumulate_sum_max': (c_int, [P, c_int64, c_int64, c_int64, c_int, P, P, P, c_size_t, P]),
     'shg_finalize_mean_max': (c_int, [P, P, c_int64, c_int64, c_int64, c_int, P, P, P]),
@@ -65,3 +68,18 @@ def last_error():
 def check(status, what):
     if status != 0:
         raise RuntimeError('%s failed (status %d): %s' % (what, status, last_error()))
+
+
+def profile_enable(on=True):
+    lib.shg_profile_enable(1 if on else 0)
+
+
+def profile_reset():
+    lib.shg_profile_reset()
+
+
+def profile_get(tag):
+    """-> (total milliseconds, launches) of the kernel `tag` since the last reset."""
+    ms, n = c_double(0.0), c_int64(0)
+    check(lib.shg_profile_get(tag.encode(), ctypes.byref(ms), ctypes.byref(n)), 'shg_profile_get')
+    return ms.value, n.value

@@ -204,10 +204,10 @@ void launch_vec(const Plan& p, const void* stack, int n, uint32_t* psum, uint16_
     dim3 grid((unsigned)((p.vecs + 255) / 256), (unsigned)p.nsplit);
     const u32x4* s = static_cast<const u32x4*>(stack);
     switch (p.unroll) {
-        case 2: k_accumulate_vec<BPP, 2><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); break;
-        case 4: k_accumulate_vec<BPP, 4><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); break;
-        case 16: k_accumulate_vec<BPP, 16><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); break;
-        default: k_accumulate_vec<BPP, 8><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); break;
+        case 2: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 2><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
+        case 4: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 4><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
+        case 16: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 16><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
+        default: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 8><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
     }
 }
 
@@ -248,12 +248,12 @@ extern "C" int shg_accumulate_sum_max(const void* stack, int64_t n_frames, int64
     } else {
         dim3 grid((unsigned)((p.npix + 255) / 256), (unsigned)p.nsplit);
         if (bytes_per_px == 2)
-            k_accumulate_scalar<uint16_t><<<grid, 256, 0, st>>>(static_cast<const uint16_t*>(stack), p.npix, n, p.frames_per_split, psum, pmax);
+            { SHG_PROF("accumulate", st); k_accumulate_scalar<uint16_t><<<grid, 256, 0, st>>>(static_cast<const uint16_t*>(stack), p.npix, n, p.frames_per_split, psum, pmax); }
         else
-            k_accumulate_scalar<uint8_t><<<grid, 256, 0, st>>>(static_cast<const uint8_t*>(stack), p.npix, n, p.frames_per_split, psum, pmax);
+            { SHG_PROF("accumulate", st); k_accumulate_scalar<uint8_t><<<grid, 256, 0, st>>>(static_cast<const uint8_t*>(stack), p.npix, n, p.frames_per_split, psum, pmax); }
     }
     if (int e = shg::check_launch("k_accumulate")) return e;
-    k_reduce_partials<<<(unsigned)((p.npix + 255) / 256), 256, 0, st>>>(psum, pmax, p.nsplit, p.npix, sum_out, max_out);
+    { SHG_PROF("reduce_partials", st); k_reduce_partials<<<(unsigned)((p.npix + 255) / 256), 256, 0, st>>>(psum, pmax, p.nsplit, p.npix, sum_out, max_out); }
     return shg::check_launch("k_reduce_partials");
 }
 
@@ -264,7 +264,7 @@ extern "C" int shg_finalize_mean_max(const uint64_t* sum, const uint16_t* max_ra
     SHG_REQUIRE(n_total > 0 && height > 0 && width > 0, SHG_E_ARG, "shg_finalize_mean_max: bad size");
     SHG_REQUIRE(bytes_per_px == 1 || bytes_per_px == 2, SHG_E_ARG, "shg_finalize_mean_max: bytes_per_px must be 1 or 2");
     const int64_t npix = height * width;
-    k_finalize<<<(unsigned)((npix + 255) / 256), 256, 0, shg::as_stream(stream)>>>(
-        sum, max_raw, (uint64_t)n_total, height, width, bytes_per_px == 1 ? 256 : 1, mean_out, max_out);
+    { SHG_PROF("finalize", shg::as_stream(stream)); k_finalize<<<(unsigned)((npix + 255) / 256), 256, 0, shg::as_stream(stream)>>>(
+        sum, max_raw, (uint64_t)n_total, height, width, bytes_per_px == 1 ? 256 : 1, mean_out, max_out); }
     return shg::check_launch("k_finalize");
 }

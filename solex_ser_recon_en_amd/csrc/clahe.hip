@@ -264,22 +264,22 @@ extern "C" int shg_clahe(const void* img, int64_t h, int64_t w, int64_t pitch, i
     if (bytes_per_px == 2) {
         ensure_lds_attr();
         dim3 hgrid((unsigned)((area + SLICE_PX - 1) / SLICE_PX), (unsigned)ntiles);
-        k_tile_hist16<<<hgrid, 1024, HIST16 * 2, st>>>(static_cast<const uint16_t*>(img), h, w, pitch, tiles, th, tw, hist);
+        { SHG_PROF("clahe_hist", st); k_tile_hist16<<<hgrid, 1024, HIST16 * 2, st>>>(static_cast<const uint16_t*>(img), h, w, pitch, tiles, th, tw, hist); }
         if (int e = shg::check_launch("k_tile_hist16")) return e;
-        k_tile_lut<HIST16><<<ntiles, 1024, 0, st>>>(hist, clip, lut_scale, lut);
+        { SHG_PROF("clahe_lut", st); k_tile_lut<HIST16><<<ntiles, 1024, 0, st>>>(hist, clip, lut_scale, lut); }
         if (int e = shg::check_launch("k_tile_lut")) return e;
-        k_clahe_interp<uint16_t, HIST16><<<igrid, 256, 0, st>>>(static_cast<const uint16_t*>(img), h, w, pitch, tiles, inv_tw, inv_th,
-                                                                lut, static_cast<uint16_t*>(dst), dst_pitch);
+        { SHG_PROF("clahe_interp", st); k_clahe_interp<uint16_t, HIST16><<<igrid, 256, 0, st>>>(static_cast<const uint16_t*>(img), h, w, pitch, tiles, inv_tw, inv_th,
+                                                                lut, static_cast<uint16_t*>(dst), dst_pitch); }
     } else {
         int64_t hb = (area + 4095) / 4096;
         if (hb > 256) hb = 256;
         dim3 hgrid((unsigned)hb, (unsigned)ntiles);
-        k_tile_hist8<<<hgrid, 256, 0, st>>>(static_cast<const uint8_t*>(img), h, w, pitch, tiles, th, tw, hist);
+        { SHG_PROF("clahe_hist", st); k_tile_hist8<<<hgrid, 256, 0, st>>>(static_cast<const uint8_t*>(img), h, w, pitch, tiles, th, tw, hist); }
         if (int e = shg::check_launch("k_tile_hist8")) return e;
-        k_tile_lut<256><<<ntiles, 1024, 0, st>>>(hist, clip, lut_scale, lut);
+        { SHG_PROF("clahe_lut", st); k_tile_lut<256><<<ntiles, 1024, 0, st>>>(hist, clip, lut_scale, lut); }
         if (int e = shg::check_launch("k_tile_lut")) return e;
-        k_clahe_interp<uint8_t, 256><<<igrid, 256, 0, st>>>(static_cast<const uint8_t*>(img), h, w, pitch, tiles, inv_tw, inv_th, lut,
-                                                            static_cast<uint8_t*>(dst), dst_pitch);
+        { SHG_PROF("clahe_interp", st); k_clahe_interp<uint8_t, 256><<<igrid, 256, 0, st>>>(static_cast<const uint8_t*>(img), h, w, pitch, tiles, inv_tw, inv_th, lut,
+                                                            static_cast<uint8_t*>(dst), dst_pitch); }
     }
     return shg::check_launch("k_clahe_interp");
 }
@@ -297,11 +297,11 @@ extern "C" int shg_hist(const void* img, int64_t h, int64_t w, int64_t pitch, in
     const int64_t n = h * w;
     if (bytes_per_px == 2) {
         ensure_lds_attr();
-        k_image_hist16<<<(unsigned)((n + SLICE_PX - 1) / SLICE_PX), 1024, HIST16 * 2, st>>>(static_cast<const uint16_t*>(img), h, w, pitch, hist);
+        { SHG_PROF("hist", st); k_image_hist16<<<(unsigned)((n + SLICE_PX - 1) / SLICE_PX), 1024, HIST16 * 2, st>>>(static_cast<const uint16_t*>(img), h, w, pitch, hist); }
     } else {
         int64_t hb = (n + 4095) / 4096;
         if (hb > 256) hb = 256;
-        k_image_hist8<<<(unsigned)hb, 256, 0, st>>>(static_cast<const uint8_t*>(img), h, w, pitch, hist);
+        { SHG_PROF("hist", st); k_image_hist8<<<(unsigned)hb, 256, 0, st>>>(static_cast<const uint8_t*>(img), h, w, pitch, hist); }
     }
     return shg::check_launch("k_image_hist");
 }

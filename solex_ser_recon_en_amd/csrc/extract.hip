@@ -127,6 +127,7 @@ extern "C" int shg_extract_columns(const void* stack, int64_t n_frames, int64_t 
 #define SHG_LAUNCH(T, ROT)                                                                                              \
     k_extract<T, ROT><<<grid, 256, 0, st>>>(static_cast<const T*>(stack), n, height, width, ind_l, lw, rw, n_shifts, \
                                             disks, row_pitch, plane_stride, n_cols, k_offset, flip_x, vec_store)
+    SHG_PROF("extract", st);
     if (bytes_per_px == 2) {
         if (rot) SHG_LAUNCH(uint16_t, true); else SHG_LAUNCH(uint16_t, false);
     } else {

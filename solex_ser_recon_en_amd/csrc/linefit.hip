@@ -88,9 +88,9 @@ extern "C" int shg_box_blur_u16(const uint16_t* src, int64_t h, int64_t w, int k
     SHG_REQUIRE((int64_t)kw * kh <= 32768, SHG_E_UNSUPPORTED, "shg_box_blur_u16: window %d x %d overflows int32 sums", kw, kh);
     hipStream_t st = shg::as_stream(stream);
     const unsigned blocks = (unsigned)((h * w + 255) / 256);
-    k_box_rows<<<blocks, 256, 0, st>>>(src, h, w, kw, tmp);
+    { SHG_PROF("box_blur", st); k_box_rows<<<blocks, 256, 0, st>>>(src, h, w, kw, tmp); }
     if (int e = shg::check_launch("k_box_rows")) return e;
-    k_box_cols<<<blocks, 256, 0, st>>>(tmp, h, w, kh, 1.0 / ((double)kw * (double)kh), dst);
+    { SHG_PROF("box_blur", st); k_box_cols<<<blocks, 256, 0, st>>>(tmp, h, w, kh, 1.0 / ((double)kw * (double)kh), dst); }
     return shg::check_launch("k_box_cols");
 }
 
@@ -99,13 +99,13 @@ extern "C" int shg_row_argmin_u16(const uint16_t* img, int64_t h, int64_t w, int
     SHG_REQUIRE(img && out, SHG_E_ARG, "shg_row_argmin_u16: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && x0 >= 0 && x1 <= w && x0 < x1, SHG_E_ARG,
                 "shg_row_argmin_u16: empty column range [%lld, %lld) of %lld", (long long)x0, (long long)x1, (long long)w);
-    k_row_argmin<<<(unsigned)((h + 3) / 4), 256, 0, shg::as_stream(stream)>>>(img, h, w, x0, x1, out);
+    { SHG_PROF("row_argmin", shg::as_stream(stream)); k_row_argmin<<<(unsigned)((h + 3) / 4), 256, 0, shg::as_stream(stream)>>>(img, h, w, x0, x1, out); }
     return shg::check_launch("k_row_argmin");
 }
 
 extern "C" int shg_row_mean_u16(const uint16_t* img, int64_t h, int64_t w, double* out, shg_stream_t stream) {
     SHG_REQUIRE(img && out, SHG_E_ARG, "shg_row_mean_u16: null pointer");
     SHG_REQUIRE(h > 0 && w > 0, SHG_E_ARG, "shg_row_mean_u16: empty image");
-    k_row_mean<<<(unsigned)((h + 3) / 4), 256, 0, shg::as_stream(stream)>>>(img, h, w, out);
+    { SHG_PROF("row_mean", shg::as_stream(stream)); k_row_mean<<<(unsigned)((h + 3) / 4), 256, 0, shg::as_stream(stream)>>>(img, h, w, out); }
     return shg::check_launch("k_row_mean");
 }

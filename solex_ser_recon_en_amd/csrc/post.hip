@@ -83,7 +83,7 @@ extern "C" int shg_crop_pad_u16(const uint16_t* src, int64_t h, int64_t w, int64
     SHG_REQUIRE(n >= 0 && sx0 >= 0 && sx0 + n <= w && dx0 >= 0 && dx0 + n <= nw, SHG_E_ARG, "shg_crop_pad_u16: copy window outside the images");
     SHG_REQUIRE(h < 65536, SHG_E_UNSUPPORTED, "shg_crop_pad_u16: more than 65535 rows");
     dim3 grid((unsigned)((nw + 255) / 256), (unsigned)h);
-    k_crop_pad<<<grid, 256, 0, shg::as_stream(stream)>>>(src, pitch, dst, nw, dst_pitch, sx0, dx0, n, fill);
+    { SHG_PROF("crop_pad", shg::as_stream(stream)); k_crop_pad<<<grid, 256, 0, shg::as_stream(stream)>>>(src, pitch, dst, nw, dst_pitch, sx0, dx0, n, fill); }
     return shg::check_launch("k_crop_pad");
 }
 
@@ -94,7 +94,7 @@ extern "C" int shg_rescale_u16(const uint16_t* img, int64_t h, int64_t w, int64_
     SHG_REQUIRE(65535.0 >= hi && hi > lo, SHG_E_ARG, "shg_rescale_u16: need sat >= hi > lo (got lo=%g hi=%g)", lo, hi);   // assert, solex_util.py:521
     SHG_REQUIRE(h < 65536, SHG_E_UNSUPPORTED, "shg_rescale_u16: more than 65535 rows");
     dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
-    k_rescale<<<grid, 256, 0, shg::as_stream(stream)>>>(img, w, pitch, 65535.0 * alpha, lo, hi - lo, dst, dst_pitch);
+    { SHG_PROF("rescale", shg::as_stream(stream)); k_rescale<<<grid, 256, 0, shg::as_stream(stream)>>>(img, w, pitch, 65535.0 * alpha, lo, hi - lo, dst, dst_pitch); }
     return shg::check_launch("k_rescale");
 }
 
@@ -104,10 +104,10 @@ extern "C" int shg_fill_disc_u16(uint16_t* img, int64_t h, int64_t w, int64_t pi
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w, SHG_E_ARG, "shg_fill_disc_u16: bad image size");
     SHG_REQUIRE(r >= 0 && r < 32768, SHG_E_UNSUPPORTED, "shg_fill_disc_u16: radius %lld out of range", (long long)r);
     hipStream_t st = shg::as_stream(stream);
-    k_disc_spans<<<1, 64, 0, st>>>((int)r, scratch);
+    { SHG_PROF("fill_disc", st); k_disc_spans<<<1, 64, 0, st>>>((int)r, scratch); }
     if (int e = shg::check_launch("k_disc_spans")) return e;
     dim3 grid((unsigned)((2 * r + 1 + 255) / 256), (unsigned)(2 * r + 1));
-    k_fill_disc<<<grid, 256, 0, st>>>(img, h, w, pitch, x0, y0, (int)r, value, scratch);
+    { SHG_PROF("fill_disc", st); k_fill_disc<<<grid, 256, 0, st>>>(img, h, w, pitch, x0, y0, (int)r, value, scratch); }
     return shg::check_launch("k_fill_disc");
 }
 
@@ -116,6 +116,6 @@ extern "C" int shg_downscale_mean_u16(const uint16_t* img, int64_t h, int64_t w,
     SHG_REQUIRE(img && dst, SHG_E_ARG, "shg_downscale_mean_u16: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w && factor >= 1 && factor <= 64, SHG_E_ARG, "shg_downscale_mean_u16: bad size");
     const int64_t oh = (h + factor - 1) / factor, ow = (w + factor - 1) / factor;
-    k_downscale_mean<<<(unsigned)((oh * ow + 255) / 256), 256, 0, shg::as_stream(stream)>>>(img, h, w, pitch, factor, oh, ow, dst);
+    { SHG_PROF("downscale", shg::as_stream(stream)); k_downscale_mean<<<(unsigned)((oh * ow + 255) / 256), 256, 0, shg::as_stream(stream)>>>(img, h, w, pitch, factor, oh, ow, dst); }
     return shg::check_launch("k_downscale_mean");
 }

@@ -28,6 +28,16 @@ inline int check_launch(const char* what) {
 
 inline hipStream_t as_stream(shg_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Optional per-kernel timing with HIP events recorded on the launch stream, right around
+// the launch (bench.py's roofline leg).  Disabled by default: no events, no overhead.
+struct ProfScope {
+    ProfScope(const char* tag, hipStream_t st);
+    ~ProfScope();
+    int slot;
+    hipStream_t stream;
+};
+#define SHG_PROF(tag, st) shg::ProfScope shg_prof_scope_(tag, st)
+
 constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kCUs = 256;          // MI355X
 

@@ -152,7 +152,7 @@ extern "C" int shg_rowpair_logratio_stats(const uint16_t* img, int64_t h, int64_
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowpair_stats), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MAXN * 8);
         attr_set = true;
     }
-    k_rowpair_stats<<<(unsigned)rows, NT, lds_bytes, st>>>(img, pitch, y1, xa, xb, out);
+    { SHG_PROF("rowpair_stats", st); k_rowpair_stats<<<(unsigned)rows, NT, lds_bytes, st>>>(img, pitch, y1, xa, xb, out); }
     return shg::check_launch("k_rowpair_stats");
 }
 
@@ -162,6 +162,6 @@ extern "C" int shg_scale_rows_u16(const uint16_t* img, int64_t h, int64_t w, int
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w && dst_pitch >= w, SHG_E_ARG, "shg_scale_rows_u16: bad image size");
     SHG_REQUIRE(h < 65536, SHG_E_UNSUPPORTED, "shg_scale_rows_u16: more than 65535 rows");
     dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
-    k_scale_rows<<<grid, 256, 0, shg::as_stream(stream)>>>(img, w, pitch, c, dst, dst_pitch);
+    { SHG_PROF("scale_rows", shg::as_stream(stream)); k_scale_rows<<<grid, 256, 0, shg::as_stream(stream)>>>(img, w, pitch, c, dst, dst_pitch); }
     return shg::check_launch("k_scale_rows");
 }

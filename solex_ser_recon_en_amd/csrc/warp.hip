@@ -71,12 +71,12 @@ extern "C" int shg_warp_rows_u16(const uint16_t* src, int64_t h, int64_t w, int6
     SHG_REQUIRE(src_pitch >= w && dst_pitch >= out_w, SHG_E_ARG, "shg_warp_rows_u16: pitch smaller than width");
     SHG_REQUIRE(out_h < 65536, SHG_E_UNSUPPORTED, "shg_warp_rows_u16: more than 65535 rows");
     hipStream_t st = shg::as_stream(stream);
-    k_minmax_init<<<1, 1, 0, st>>>(minmax);
+    { SHG_PROF("minmax", st); k_minmax_init<<<1, 1, 0, st>>>(minmax); }
     int64_t blocks = (h * w + 256 * 8 - 1) / (256 * 8);
     if (blocks > 2048) blocks = 2048;
-    k_minmax<<<(unsigned)blocks, 256, 0, st>>>(src, h, w, src_pitch, minmax);
+    { SHG_PROF("minmax", st); k_minmax<<<(unsigned)blocks, 256, 0, st>>>(src, h, w, src_pitch, minmax); }
     if (int e = shg::check_launch("k_minmax")) return e;
     dim3 grid((unsigned)((out_w + 255) / 256), (unsigned)out_h);
-    k_warp_rows<<<grid, 256, 0, st>>>(src, h, w, src_pitch, h00, h01, h02, dst, out_h, out_w, dst_pitch, minmax);
+    { SHG_PROF("warp", st); k_warp_rows<<<grid, 256, 0, st>>>(src, h, w, src_pitch, h00, h01, h02, dst, out_h, out_w, dst_pitch, minmax); }
     return shg::check_launch("k_warp_rows");
 }

@@ -9,7 +9,7 @@ import math
 
 import numpy as np
 
-from . import limb_fit, ops, outputs
+from . import limb_fit, ops, outputs, timing
 from .device import DeviceImage, to_device_u16, u16_from_unit_float
 from .solex_util import logme, output_path
 
@@ -68,10 +68,13 @@ def ellipse_to_circle(image, options, basefich):
     """image: the uint16 raw disk.  Returns (fix_img, (cx, cy, r), ratio, phi, borders)."""
     src = to_device_u16(image)
     factor = 4
-    small = ops.downscale_mean_u16(src, factor).cpu().numpy()          # downscale_local_mean(image / 65536, (4, 4))
-    X, raw_X = limb_fit.edge_points(small)
+    with timing.stage('  limb: downscale+D2H'):
+        small = ops.downscale_mean_u16(src, factor).cpu().numpy()      # downscale_local_mean(image / 65536, (4, 4))
+    with timing.stage('  limb: edges (host)'):
+        X, raw_X = limb_fit.edge_points(small)
     X, raw_X = X * factor, raw_X * factor                              # down-scaled, then upscaled back (:301-302)
-    center, height, phi, ratio, X_f, ellipse_points = limb_fit.two_step(X, get_correction_matrix)
+    with timing.stage('  limb: ellipse lsq (host)'):
+        center, height, phi, ratio, X_f, ellipse_points = limb_fit.two_step(X, get_correction_matrix)
     center = np.array([center[1], center[0]])
     fix_img, new_circle, mat3 = correct_image(src, phi, ratio, center, height, options, print_log=True)
 
