@@ -61,8 +61,11 @@ def gather_columns(local, frame_range, n_total, flip_x=False):
     n_max = max(b - a for a, b in blocks)
     send = torch.zeros((s, ih, n_max), dtype=torch.int16, device=local.device)
     send[:, :, :n_local] = local.view(torch.int16)
-    recv = [torch.empty_like(send) for _ in range(w)]
-    td.all_gather(recv, send)
+    # neither RCCL nor gloo moves 16-bit integers: gather the bytes
+    send8 = send.view(torch.uint8)
+    recv8 = [torch.empty_like(send8) for _ in range(w)]
+    td.all_gather(recv8, send8)
+    recv = [r.view(torch.int16) for r in recv8]
     full = torch.cat([recv[r][:, :, :blocks[r][1] - blocks[r][0]] for r in range(w)], dim=2)
     if flip_x:
         full = torch.flip(full, dims=(2,))

@@ -1,0 +1,82 @@
+"""The multi-GPU exchange steps (dist.py) on CPU tensors with the gloo backend, world size 2:
+integer all-reduce of the sum/max frames and all-gather of the disk column blocks reproduce
+the unsharded oracle result bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as td
+import torch.multiprocessing as mp
+
+from oracle import shg_oracle as orc
+from solex_ser_recon_en_amd import dist, synth
+
+
+def test_frame_block_partitions_the_scan():
+    for n in (1, 7, 2000, 4001):
+        for w in (1, 2, 3, 8):
+            blocks = [dist.frame_block(n, r, w) for r in range(w)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, frames, fit, shifts, flip, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    td.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        n = frames.shape[0]
+        k0, k1 = dist.frame_block(n)
+        local = frames[k0:k1]
+        # what pass A produces on this rank: integer sum and max of its frames, file layout
+        total = torch.from_numpy(local.astype(np.int64).sum(0).ravel())
+        mx = torch.from_numpy(local.max(0).ravel().copy())
+
+        class R:
+            FrameCount = n
+            frame_range = (k0, k1)
+        assert dist.is_sharded(R)
+        total, mx = dist.allreduce_sum_max(total, mx)
+        # what pass B produces on this rank: the columns of its own frames
+        rdr = orc.SerReader(frames, k0, k1)
+        disks = orc.extract_columns(rdr, fit, shifts)
+        local_disks = torch.from_numpy(np.stack(disks)[:, :, k0:k1].copy())
+        full = dist.gather_columns(local_disks, (k0, k1), n, flip_x=flip)
+        np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), total=total.numpy(), mx=mx.numpy(),
+                 full=full.contiguous().numpy())
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize('flip', [False, True])
+def test_sharded_exchange_matches_unsharded_oracle(tmp_path, flip):
+    frames = synth.synth_frames_numpy(21, 96, 40, 16, seed=4)       # 21 frames over 2 ranks: uneven blocks
+    frames[5] = 65535                                                # full-scale maxima must survive the widened MAX
+    ih, iw = 96, 40
+    curve = np.linspace(3.2, iw - 5.1, ih)
+    fit = np.stack([np.floor(curve), curve - np.floor(curve), np.arange(ih), curve], axis=1)
+    shifts = [10, 0, -3]
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), frames, fit, shifts, flip, str(tmp_path)), nprocs=world, join=True)
+    want_sum = frames.astype(np.int64).sum(0).ravel()
+    want_max = frames.max(0).ravel()
+    want_disks = np.stack(orc.extract_columns(orc.SerReader(frames), fit, shifts))
+    if flip:
+        want_disks = want_disks[:, :, ::-1]
+    for r in range(world):
+        got = np.load(str(tmp_path / ('rank%d.npz' % r)))
+        np.testing.assert_array_equal(got['total'], want_sum)
+        np.testing.assert_array_equal(got['mx'], want_max)
+        np.testing.assert_array_equal(got['full'], want_disks)
