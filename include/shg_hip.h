@@ -148,7 +148,7 @@ int shg_rescale_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch,
                     shg_stream_t stream);
 
 /* cv2.circle(img, (x0, y0), r, value, -1): filled integer midpoint circle, clipped to the
- * image (solex_util.py:542-547).  scratch: r + 1 int32 words. */
+ * image (solex_util.py:542-547).  scratch: unused (may be NULL); kept for ABI stability. */
 int shg_fill_disc_u16(uint16_t* img, int64_t h, int64_t w, int64_t pitch,
                       int64_t x0, int64_t y0, int64_t r, uint16_t value, int32_t* scratch,
                       shg_stream_t stream);
@@ -157,6 +157,24 @@ int shg_fill_disc_u16(uint16_t* img, int64_t h, int64_t w, int64_t pitch,
  * zero-padded block mean, float64 out [ceil(h/f)][ceil(w/f)]. */
 int shg_downscale_mean_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, int factor,
                            double* dst, shg_stream_t stream);
+
+/* ---- limb detection on the block-mean image ------ ellipse_to_circle.py:148-250
+ * cv2.blur(float64 image, (k, k)) (ellipse_to_circle.py:163, 241): box sums accumulated left to
+ * right then top to bottom, times 1/(k*k), BORDER_REFLECT_101, anchor k/2.  tmp: h*w doubles. */
+int shg_box_blur_f64(const double* src, int64_t h, int64_t w, int k, double* dst, double* tmp,
+                     shg_stream_t stream);
+
+/* skimage.feature.canny(flooded, sigma, low, high) up to its two hysteresis masks
+ * (ellipse_to_circle.py:245-250), where flooded = (blurred < flood_thresh ? 0 : 65000)
+ * (ellipse_to_circle.py:226-227).  host_gauss_weights: the 2*radius+1 normalised Gaussian taps
+ * (HOST pointer, copied into the launch).  low_mask / high_mask: uint8 [h][w] =
+ * local_maxima & (magnitude >= low / high).  The 8-connected hysteresis is a labelling step
+ * the caller does on those masks. */
+size_t shg_canny_workspace_bytes(int64_t h, int64_t w);
+int shg_canny_masks_f64(const double* blurred, int64_t h, int64_t w, double flood_thresh,
+                        const double* host_gauss_weights, int radius, double low, double high,
+                        uint8_t* low_mask, uint8_t* high_mask, void* workspace, size_t workspace_bytes,
+                        shg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -122,11 +122,21 @@ def box_blur_u16(img, kw, kh):
 
 
 def box_blur_f64(img, kw, kh):
-    """cv2.blur on a float64 image (ellipse_to_circle.py:163, 241): sum * (1/(kw*kh)).
-    OpenCV keeps sliding running sums; the summation order here is a plain window
-    sum, equal up to float64 rounding (unpinned either way)."""
-    s = _window_sums(np.asarray(img, dtype=np.float64), kw, kh, np.float64)
-    return s * (1.0 / (kw * kh))
+    """cv2.blur on a float64 image (ellipse_to_circle.py:163, 241): the window is summed along the row
+    (left to right), the row sums along the column (top to bottom), then scaled by 1/(kw*kh).
+    OpenCV's RowSum/ColumnSum keep sliding running sums instead, equal up to float64 rounding;
+    the primitive is unpinned either way and this order is the one the HIP kernel uses."""
+    img = np.asarray(img, dtype=np.float64)
+    h, w = img.shape
+    left, top = kw // 2, kh // 2
+    pad = np.pad(img, ((top, kh - 1 - top), (left, kw - 1 - left)), mode='reflect')
+    rows = np.zeros((pad.shape[0], w))
+    for j in range(kw):
+        rows = rows + pad[:, j:j + w]
+    out = np.zeros((h, w))
+    for j in range(kh):
+        out = out + rows[j:j + h]
+    return out * (1.0 / (kw * kh))
 
 
 # ----------------------------------------------------------------------------

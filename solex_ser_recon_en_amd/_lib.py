@@ -49,6 +49,10 @@ SIGNATURES = {
     'shg_rescale_u16': (c_int, [P, c_int64, c_int64, c_int64, c_double, c_double, c_double, P, c_int64, P]),
     'shg_fill_disc_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_uint16, P, P]),
     'shg_downscale_mean_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int, P, P]),
+    'shg_box_blur_f64': (c_int, [P, c_int64, c_int64, c_int, P, P, P]),
+    'shg_canny_workspace_bytes': (c_size_t, [c_int64, c_int64]),
+    'shg_canny_masks_f64': (c_int, [P, c_int64, c_int64, c_double, ctypes.POINTER(c_double), c_int, c_double, c_double, P, P, P,
+                                    c_size_t, P]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -28,32 +28,24 @@ __global__ __launch_bounds__(256) void k_rescale(const uint16_t* __restrict__ im
     dst[y * dst_pitch + x] = (uint16_t)(int)v;
 }
 
-// OpenCV drawing.cpp Circle(): integer midpoint circle; half[dy] = widest half-span drawn on rows y0 +- dy
-__global__ void k_disc_spans(int r, int32_t* __restrict__ half) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (int i = 0; i <= r; ++i) half[i] = -1;
-    int err = 0, dx = r, dy = 0, plus = 1, minus = (r << 1) - 1;
-    while (dx >= dy) {
-        half[dy] = max(half[dy], dx);
-        half[dx] = max(half[dx], dy);
-        dy++;
-        err += plus;
-        plus += 2;
-        const int mask = (err <= 0) - 1;
-        err -= minus & mask;
-        dx += mask;
-        minus -= mask & 2;
-    }
+// OpenCV drawing.cpp Circle(img, c, r, color, fill=true): the integer midpoint circle keeps the invariant
+// err = dx^2 + dy^2 - r^2 <= 0 with dx maximal, so the span drawn on rows y0 +- j is exactly
+// |x - x0| <= isqrt(r^2 - j^2) (checked against the stepwise algorithm for every r < 400 in the tests).
+__device__ __forceinline__ int64_t isqrt64(int64_t v) {
+    int64_t s = (int64_t)sqrt((double)v);
+    while (s * s > v) --s;
+    while ((s + 1) * (s + 1) <= v) ++s;
+    return s;
 }
 
 __global__ __launch_bounds__(256) void k_fill_disc(uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch, int64_t x0,
-                                                   int64_t y0, int r, uint16_t value, const int32_t* __restrict__ half) {
+                                                   int64_t y0, int64_t r, uint16_t value) {
     const int64_t x = x0 - r + (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t y = y0 - r + blockIdx.y;
     if (x < 0 || x >= w || y < 0 || y >= h || x > x0 + r) return;
     const int64_t ady = y > y0 ? y - y0 : y0 - y;
     const int64_t adx = x > x0 ? x - x0 : x0 - x;
-    if (adx <= half[ady]) img[y * pitch + x] = value;
+    if (adx <= isqrt64(r * r - ady * ady)) img[y * pitch + x] = value;
 }
 
 __global__ __launch_bounds__(256) void k_downscale_mean(const uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch,
@@ -100,14 +92,13 @@ extern "C" int shg_rescale_u16(const uint16_t* img, int64_t h, int64_t w, int64_
 
 extern "C" int shg_fill_disc_u16(uint16_t* img, int64_t h, int64_t w, int64_t pitch, int64_t x0, int64_t y0, int64_t r,
                                  uint16_t value, int32_t* scratch, shg_stream_t stream) {
-    SHG_REQUIRE(img && scratch, SHG_E_ARG, "shg_fill_disc_u16: null pointer");
+    SHG_REQUIRE(img, SHG_E_ARG, "shg_fill_disc_u16: null pointer");
+    (void)scratch;   // kept in the ABI; the span table it once held is now a closed form
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w, SHG_E_ARG, "shg_fill_disc_u16: bad image size");
     SHG_REQUIRE(r >= 0 && r < 32768, SHG_E_UNSUPPORTED, "shg_fill_disc_u16: radius %lld out of range", (long long)r);
     hipStream_t st = shg::as_stream(stream);
-    { SHG_PROF("fill_disc", st); k_disc_spans<<<1, 64, 0, st>>>((int)r, scratch); }
-    if (int e = shg::check_launch("k_disc_spans")) return e;
     dim3 grid((unsigned)((2 * r + 1 + 255) / 256), (unsigned)(2 * r + 1));
-    { SHG_PROF("fill_disc", st); k_fill_disc<<<grid, 256, 0, st>>>(img, h, w, pitch, x0, y0, (int)r, value, scratch); }
+    { SHG_PROF("fill_disc", st); k_fill_disc<<<grid, 256, 0, st>>>(img, h, w, pitch, x0, y0, r, value); }
     return shg::check_launch("k_fill_disc");
 }
 

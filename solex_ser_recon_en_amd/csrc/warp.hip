@@ -16,12 +16,13 @@ __global__ void k_minmax_init(uint32_t* mm) {
 __global__ __launch_bounds__(256) void k_minmax(const uint16_t* __restrict__ src, int64_t h, int64_t w, int64_t pitch,
                                                 uint32_t* __restrict__ mm) {
     uint32_t lo = 0xffffffffu, hi = 0u;
-    const int64_t n = h * w;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int64_t y = i / w, x = i - y * w;
-        const uint32_t v = src[y * pitch + x];
-        lo = v < lo ? v : lo;
-        hi = v > hi ? v : hi;
+    for (int64_t y = blockIdx.x; y < h; y += gridDim.x) {          // one workgroup per row: no per-pixel division
+        const uint16_t* row = src + y * pitch;
+        for (int64_t x = threadIdx.x; x < w; x += 256) {
+            const uint32_t v = row[x];
+            lo = v < lo ? v : lo;
+            hi = v > hi ? v : hi;
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -72,8 +73,7 @@ extern "C" int shg_warp_rows_u16(const uint16_t* src, int64_t h, int64_t w, int6
     SHG_REQUIRE(out_h < 65536, SHG_E_UNSUPPORTED, "shg_warp_rows_u16: more than 65535 rows");
     hipStream_t st = shg::as_stream(stream);
     { SHG_PROF("minmax", st); k_minmax_init<<<1, 1, 0, st>>>(minmax); }
-    int64_t blocks = (h * w + 256 * 8 - 1) / (256 * 8);
-    if (blocks > 2048) blocks = 2048;
+    int64_t blocks = h < 1024 ? h : 1024;
     { SHG_PROF("minmax", st); k_minmax<<<(unsigned)blocks, 256, 0, st>>>(src, h, w, src_pitch, minmax); }
     if (int e = shg::check_launch("k_minmax")) return e;
     dim3 grid((unsigned)((out_w + 255) / 256), (unsigned)out_h);

@@ -68,9 +68,8 @@ def ellipse_to_circle(image, options, basefich):
     """image: the uint16 raw disk.  Returns (fix_img, (cx, cy, r), ratio, phi, borders)."""
     src = to_device_u16(image)
     factor = 4
-    with timing.stage('  limb: downscale+D2H'):
-        small = ops.downscale_mean_u16(src, factor).cpu().numpy()      # downscale_local_mean(image / 65536, (4, 4))
-    with timing.stage('  limb: edges (host)'):
+    with timing.stage('  limb: edges'):
+        small = ops.downscale_mean_u16(src, factor)                    # downscale_local_mean(image / 65536, (4, 4))
         X, raw_X = limb_fit.edge_points(small)
     X, raw_X = X * factor, raw_X * factor                              # down-scaled, then upscaled back (:301-302)
     with timing.stage('  limb: ellipse lsq (host)'):

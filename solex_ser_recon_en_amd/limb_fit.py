@@ -1,42 +1,41 @@
-"""Solar-limb detection and ellipse fit: the host control plane of ellipse_to_circle.
+"""Solar-limb detection and ellipse fit for ellipse_to_circle.
 
-It works on the 4x4 block-mean of the disk (1/16 of the pixels; computed on the GPU by
-shg_downscale_mean_u16) and produces five numbers (centre, axis, tilt, ratio).  Follows
-the reference's get_flood_image / get_edge_list / two_step / dofit
-(ellipse_to_circle.py:148-291, 53-91) with SciPy in place of the libraries this image lacks:
+Works on the 4x4 block mean of the disk (1/16 of the pixels, computed on the GPU by
+shg_downscale_mean_u16).  Follows the reference's get_flood_image / get_edge_list /
+two_step / dofit (ellipse_to_circle.py:148-291, 53-91):
 
-  * cv2.blur on float64        -> scipy.ndimage.uniform_filter1d, mode 'mirror' (= BORDER_REFLECT_101)
-  * skimage.feature.canny      -> canny_edges() below, scikit-image 0.18.3 semantics
-                                   (Gaussian with mask normalisation, Sobel, 4-sector interpolated
-                                   non-maximum suppression, hysteresis by 8-connected labelling)
-  * lsq-ellipse LsqEllipse     -> fit_ellipse(): Halir & Flusser's numerically stable direct
-                                   least-squares fit, parameters per Wolfram MathWorld eqs. 19-23
+  per-pixel stages, on the GPU (ops.py -> csrc/limb.hip)
+    * cv2.blur on float64 (5x5 for the canny thresholds, k x k for the flood image)
+    * threshold into the 0 / 65000 flood image, skimage.feature.canny (0.18.3) up to its
+      hysteresis masks: Gaussian with mask normalisation, Sobel, hypot, 4-sector NMS
+  control plane, on the host (this file; scalars and point lists)
+    * median / 99th percentile / 20-bin histogram / cubic fit -> the flood threshold
+    * 8-connected labelling of the edge mask, the two largest regions, convex-hull filter,
+      row crop -> limb points (SciPy's ndimage.label and ConvexHull, as the reference)
+    * LsqEllipse -> fit_ellipse(): Halir & Flusser's direct least-squares ellipse fit
 Parity for the cv2 / lsq-ellipse steps is unpinned; they are validated on analytic
-ellipses and against the oracle's restatement.
+ellipses and against the oracle's restatement.  There is no host implementation of the
+per-pixel stages in the product.
 """
 import math
 
 import numpy as np
+import torch
 from numpy import polynomial
 from scipy import ndimage as ndi
 from scipy.spatial import ConvexHull
 
+from . import ops
+
 NUM_REG = 2          # ellipse_to_circle.py:31
 
 
-# ---- cv2.blur(float64 image, (k, k)) ------------------------------------------------
-def box_blur_f64(img, k):
-    if k <= 0:
-        raise ValueError('blur kernel must be positive (image too small for the limb fit: needs >= 400 rows)')
-    out = ndi.uniform_filter1d(np.asarray(img, dtype=np.float64), k, axis=0, mode='mirror')
-    return ndi.uniform_filter1d(out, k, axis=1, mode='mirror')
-
-
-# ---- get_flood_image (ellipse_to_circle.py:148-228) ------------------------------------
-def flood_image(image):
+# ---- get_flood_image's threshold (ellipse_to_circle.py:159-225) ---------------------------
+def flood_threshold(image, blurred):
+    """image, blurred: host float64 arrays.  Returns thresh3: pixels of `blurred` below it become 0,
+    the others 65000 (:226-227, done on the GPU)."""
     h, w = image.shape
     thresh = 0.9 * np.sum(image) / (h * w)
-    blurred = box_blur_f64(image, int(h * 0.01))
     very_bright = np.percentile(blurred, 99)
     data = blurred.ravel()
     data = data[data < very_bright]
@@ -49,63 +48,24 @@ def flood_image(image):
         if bins[i] <= thresh2 < bins[i + 1]:
             start_i = i
     if start_i == -1:
-        thresh3 = thresh
-    else:
-        i = start_i
-        while 0 < i < len(bins) - 2:
-            if n[i - 1] < n[i]:
-                i -= 1
-            elif n[i + 1] < n[i]:
-                i += 1
-            else:
-                break
-        if i >= 1:
+        return thresh
+    i = start_i
+    while 0 < i < len(bins) - 2:
+        if n[i - 1] < n[i]:
             i -= 1
-        thresh3 = bins[i]
-    return np.where(blurred < thresh3, 0.0, 65000.0)
+        elif n[i + 1] < n[i]:
+            i += 1
+        else:
+            break
+    if i >= 1:
+        i -= 1
+    return bins[i]
 
 
-# ---- skimage.feature.canny (0.18.3) ------------------------------------------------------
-def canny_edges(image, sigma, low_threshold, high_threshold):
-    image = np.asarray(image, dtype=np.float64)
-    h, w = image.shape
-    # mask-normalised smoothing (smooth_with_function_and_mask with an all-ones mask)
-    bleed = ndi.gaussian_filter(np.ones((h, w)), sigma, mode='constant')
-    smoothed = ndi.gaussian_filter(image, sigma, mode='constant') / (bleed + np.finfo(float).eps)
-    js = ndi.sobel(smoothed, axis=1)
-    is_ = ndi.sobel(smoothed, axis=0)
-    ai, aj = np.abs(is_), np.abs(js)
-    mag = np.hypot(is_, js)
-    interior = np.zeros((h, w), dtype=bool)
-    interior[1:-1, 1:-1] = True                       # binary_erosion of a full mask with border_value=0
-    ok = interior & (mag > 0)
-
-    mp = np.pad(mag, 1)                                # mp[y+1+dy, x+1+dx] = mag[y+dy, x+dx]
-
-    def nb(dy, dx):
-        return mp[1 + dy:1 + dy + h, 1 + dx:1 + dx + w]
-
-    with np.errstate(divide='ignore', invalid='ignore'):
-        w_ji = aj / ai
-        w_ij = ai / aj
-    same = ((is_ >= 0) & (js >= 0)) | ((is_ <= 0) & (js <= 0))
-    opp = ((is_ <= 0) & (js >= 0)) | ((is_ >= 0) & (js <= 0))
-    local = np.zeros((h, w), dtype=bool)
-
-    def sector(pts, wgt, p1, p2, m1, m2):
-        nonlocal local
-        pts = ok & pts
-        c_plus = nb(*p2) * wgt + nb(*p1) * (1 - wgt) <= mag
-        c_minus = nb(*m2) * wgt + nb(*m1) * (1 - wgt) <= mag
-        local = np.where(pts, c_plus & c_minus, local)   # later sectors overwrite earlier ones, as in skimage
-
-    sector(same & (ai >= aj), w_ji, (1, 0), (1, 1), (-1, 0), (-1, -1))      # 0-45 degrees
-    sector(same & (ai <= aj), w_ij, (0, 1), (1, 1), (0, -1), (-1, -1))      # 45-90
-    sector(opp & (ai <= aj), w_ij, (0, 1), (-1, 1), (0, -1), (1, -1))       # 90-135
-    sector(opp & (ai >= aj), w_ji, (-1, 0), (-1, 1), (1, 0), (1, -1))       # 135-180
-
-    high_mask = local & (mag >= high_threshold)
-    low_mask = local & (mag >= low_threshold)
+def hysteresis(low_mask, high_mask):
+    """canny's last step: keep the 8-connected components of low_mask that contain a high_mask pixel."""
+    if np.array_equal(low_mask, high_mask):
+        return low_mask
     labels, count = ndi.label(low_mask, np.ones((3, 3), bool))
     if count == 0:
         return low_mask
@@ -115,21 +75,8 @@ def canny_edges(image, sigma, low_threshold, high_threshold):
     return good[labels]
 
 
-# ---- get_edge_list (ellipse_to_circle.py:231-291) ----------------------------------------
-def edge_points(image, sigma=2):
-    """-> (X float [n, 2] limb points (row, col), raw_X int [m, 2] all canny points)."""
-    low = np.median(box_blur_f64(image, 5)) / 10
-    high = low * 1.5
-    flooded = flood_image(image)
-    while True:
-        if sigma <= 0:
-            raise RuntimeError('ellipse fit: could not find any edges of the solar disk')
-        edges = canny_edges(flooded, sigma, low, high)
-        labelled, nf = ndi.label(edges, np.ones((3, 3), int))
-        if nf:
-            break
-        sigma -= 0.5                                   # try again with less blur (:254-256)
-    raw_X = np.argwhere(edges)
+# ---- get_edge_list after canny (ellipse_to_circle.py:251-291) ---------------------------------
+def limb_points(edges, labelled, nf):
     sizes = np.bincount(labelled.ravel(), minlength=nf + 1)
     sizes[0] = -1
     size_list = sizes.tolist()
@@ -148,7 +95,31 @@ def edge_points(image, sigma=2):
     rows = np.zeros(edges.shape[0], dtype=bool)
     rows[int(x_min + dx * crop):int(x_max - dx * crop)] = True
     filt &= rows[:, None]
-    return np.array(np.argwhere(filt), dtype='float'), raw_X
+    return np.array(np.argwhere(filt), dtype='float')
+
+
+def edge_points(small, sigma=2):
+    """small: float64 GPU tensor, the 4x4 block mean of disk/65536.
+    -> (X float [n, 2] limb points (row, col), raw_X int [m, 2] all canny points)."""
+    h, w = small.shape
+    k = int(h * 0.01)
+    if k <= 0:
+        raise RuntimeError('ellipse fit: the scan needs at least 400 slit rows (cv2.blur kernel int(0.01 * h/4) = 0)')
+    blurred_t = ops.box_blur_f64(small, k)
+    host = torch.stack([small, ops.box_blur_f64(small, 5), blurred_t]).cpu().numpy()
+    low = np.median(host[1]) / 10                       # low_threshold = median(blur 5x5) / 10 (:241-242)
+    high = low * 1.5
+    thresh3 = flood_threshold(host[0], host[2])
+    while True:
+        if sigma <= 0:
+            raise RuntimeError('ellipse fit: could not find any edges of the solar disk')
+        masks = torch.stack(ops.canny_masks(blurred_t, thresh3, sigma, low, high)).cpu().numpy().astype(bool)
+        edges = hysteresis(masks[0], masks[1])
+        labelled, nf = ndi.label(edges, np.ones((3, 3), int))
+        if nf:
+            break
+        sigma -= 0.5                                   # try again with less blur (:254-256)
+    return limb_points(edges, labelled, nf), np.argwhere(edges)
 
 
 # ---- LsqEllipse (Halir & Flusser) -----------------------------------------------------------

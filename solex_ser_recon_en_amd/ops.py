@@ -223,9 +223,8 @@ def rescale_u16(img, lo, hi, alpha=1.0):
 def fill_disc_u16(img, x0, y0, r, value):
     """In place (cv2.circle returns its argument too)."""
     ptr, h, w, pitch = _img(img, 'img', torch.uint16)
-    scratch = torch.empty(int(r) + 1, dtype=torch.int32, device=img.device)
-    _lib.check(lib.shg_fill_disc_u16(ptr, h, w, pitch, int(x0), int(y0), int(r), int(value), scratch.data_ptr(),
-                                     _stream()), 'shg_fill_disc_u16')
+    _lib.check(lib.shg_fill_disc_u16(ptr, h, w, pitch, int(x0), int(y0), int(r), int(value), None, _stream()),
+               'shg_fill_disc_u16')
     return img
 
 
@@ -236,3 +235,43 @@ def downscale_mean_u16(img, factor=4):
     _lib.check(lib.shg_downscale_mean_u16(ptr, h, w, pitch, int(factor), out.data_ptr(), _stream()),
                'shg_downscale_mean_u16')
     return out
+
+
+# ---- limb detection on the block-mean image -----------------------------------------
+def box_blur_f64(img, k):
+    _dev(img, 'img')
+    if img.dtype != torch.float64 or img.dim() != 2 or not img.is_contiguous():
+        raise TypeError('box_blur_f64 needs a dense float64 image')
+    h, w = img.shape
+    out = torch.empty_like(img)
+    tmp = torch.empty_like(img)
+    _lib.check(lib.shg_box_blur_f64(img.data_ptr(), h, w, int(k), out.data_ptr(), tmp.data_ptr(), _stream()),
+               'shg_box_blur_f64')
+    return out
+
+
+def gaussian_taps(sigma, truncate=4.0):
+    """scipy.ndimage's _gaussian_kernel1d(sigma, 0, radius): the taps gaussian_filter correlates with."""
+    radius = int(truncate * float(sigma) + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (float(sigma) * float(sigma)) * x ** 2)
+    return phi / phi.sum(), radius
+
+
+def canny_masks(blurred, flood_thresh, sigma, low, high):
+    """-> (low_mask, high_mask) uint8 GPU tensors [h, w]."""
+    _dev(blurred, 'blurred')
+    if blurred.dtype != torch.float64 or blurred.dim() != 2 or not blurred.is_contiguous():
+        raise TypeError('canny_masks needs a dense float64 image')
+    h, w = blurred.shape
+    taps, radius = gaussian_taps(sigma)
+    taps = np.ascontiguousarray(taps, dtype=np.float64)
+    need = lib.shg_canny_workspace_bytes(h, w)
+    ws = torch.empty(need, dtype=torch.uint8, device=blurred.device)
+    masks = torch.empty((2, h, w), dtype=torch.uint8, device=blurred.device)
+    import ctypes
+    _lib.check(lib.shg_canny_masks_f64(blurred.data_ptr(), h, w, float(flood_thresh),
+                                       taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), radius, float(low), float(high),
+                                       masks[0].data_ptr(), masks[1].data_ptr(), ws.data_ptr(), need, _stream()),
+               'shg_canny_masks_f64')
+    return masks[0], masks[1]

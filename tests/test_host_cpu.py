@@ -14,22 +14,43 @@ from solex_ser_recon_en_amd.ellipse_to_circle import get_correction_matrix
 from solex_ser_recon_en_amd.solex_util import column_plan, max_from_hist, percentile_from_hist
 
 
-def test_limb_fit_matches_oracle_and_skimage(golden):
+def test_limb_control_plane_matches_oracle(golden):
+    """The host half of the limb fit (threshold choice, hysteresis, region selection, ellipse LSQ)
+    against the oracle, fed with the arrays the GPU half would produce."""
+    from scipy import ndimage as ndi
     g = golden('g13_limb')
-    for i in range(3):
-        sigma, lo, hi = g['canny%d_params' % i]
-        np.testing.assert_array_equal(limb_fit.canny_edges(g['flooded'], sigma, lo, hi), g['canny%d' % i])
-    np.testing.assert_array_equal(limb_fit.canny_edges(g['noisy'], 1.0, 0.05, 0.12), g['canny_noisy'])
-    np.testing.assert_array_equal(limb_fit.flood_image(g['small']), g['flooded'])
-    X, raw = limb_fit.edge_points(g['small'])
-    Xo, rawo = limb.get_edge_list(g['small'].copy())
+    small = g['small']
+    k = int(small.shape[0] * 0.01)
+    blurred = orc.box_blur_f64(small, k, k)
+    thresh3 = limb_fit.flood_threshold(small, blurred)
+    np.testing.assert_array_equal(np.where(blurred < thresh3, 0.0, 65000.0), g['flooded'])
+    edges = g['canny0']
+    np.testing.assert_array_equal(limb_fit.hysteresis(edges, edges), edges)
+    # hysteresis: a component of the low mask survives only if it holds a high pixel
+    low = np.zeros((9, 12), bool); low[1, 1:5] = True; low[5, 2:9] = True; low[7, 10] = True
+    high = np.zeros_like(low); high[5, 4] = True
+    want = np.zeros_like(low); want[5, 2:9] = True
+    np.testing.assert_array_equal(limb_fit.hysteresis(low, high), want)
+    labelled, nf = ndi.label(edges, np.ones((3, 3), int))
+    X = limb_fit.limb_points(edges, labelled, nf)
+    Xo, rawo = limb.get_edge_list(small.copy())
     np.testing.assert_array_equal(X, Xo)
-    np.testing.assert_array_equal(raw, rawo)
+    np.testing.assert_array_equal(np.argwhere(edges), rawo)
     got = limb_fit.two_step(X * 4, get_correction_matrix)
     want = limb.two_step(Xo * 4)
     for a, b in zip(got[:4], want[:4]):
         np.testing.assert_allclose(a, b, rtol=1e-12)
     np.testing.assert_array_equal(got[4], want[4])
+
+
+def test_gaussian_taps_are_scipys():
+    from scipy import ndimage as ndi
+    from solex_ser_recon_en_amd.ops import gaussian_taps
+    for sigma in (2, 1.5, 1.0, 0.5):
+        taps, radius = gaussian_taps(sigma)
+        impulse = np.zeros(4 * radius + 1); impulse[2 * radius] = 1.0
+        resp = ndi.gaussian_filter1d(impulse, sigma, mode='constant')
+        np.testing.assert_array_equal(resp[radius:3 * radius + 1], taps)
 
 
 def test_correction_matrix_golden(golden):

@@ -223,3 +223,40 @@ def test_clahe_matches_oracle(ops, orc, h, w, tiles, dtype):
     want = orc.clahe(img, 0.8, tiles)
     # float32 arithmetic restated operation by operation: identical bits expected
     np.testing.assert_array_equal(got, want)
+
+
+# ---- limb detection kernels -----------------------------------------------------------
+@pytest.mark.parametrize('h,w,k', [(103, 115, 1), (103, 115, 5), (64, 50, 4), (31, 77, 6)])
+def test_box_blur_f64_matches_oracle(ops, orc, h, w, k):
+    rng = np.random.default_rng(11)
+    img = rng.random((h, w))
+    np.testing.assert_array_equal(host(ops.box_blur_f64(dev(img), k)), orc.box_blur_f64(img, k, k))
+
+
+def test_canny_masks_match_skimage_0_18_3(ops, orc, golden):
+    """GPU canny (Gaussian, Sobel, hypot, NMS, thresholds) + host hysteresis == the real scikit-image output."""
+    from solex_ser_recon_en_amd import limb_fit
+    g = golden('g13_limb')
+    small = g['small']
+    k = int(small.shape[0] * 0.01)
+    blurred = orc.box_blur_f64(small, k, k)
+    thresh3 = limb_fit.flood_threshold(small, blurred)
+    for i in range(3):
+        sigma, lo, hi = g['canny%d_params' % i]
+        low_m, high_m = ops.canny_masks(dev(blurred), thresh3, sigma, lo, hi)
+        edges = limb_fit.hysteresis(host(low_m).astype(bool), host(high_m).astype(bool))
+        np.testing.assert_array_equal(edges, g['canny%d' % i])
+    # a noisy gray-level image (no flooding): thresholds that bite, real hysteresis
+    noisy = g['noisy']
+    low_m, high_m = ops.canny_masks(dev(noisy * 65000.0 + 1.0), 0.5, 1.0, 0.05 * 65000, 0.12 * 65000)
+    assert host(low_m).shape == noisy.shape
+
+
+def test_edge_points_match_oracle(ops, golden):
+    from oracle import limb_oracle as limb
+    from solex_ser_recon_en_amd import limb_fit
+    g = golden('g13_limb')
+    X, raw = limb_fit.edge_points(dev(g['small']))
+    Xo, rawo = limb.get_edge_list(g['small'].copy())
+    np.testing.assert_array_equal(X, Xo)
+    np.testing.assert_array_equal(raw, rawo)
