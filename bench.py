@@ -103,7 +103,7 @@ def main():
     for _ in range(args.warmup):
         step()
     _lib.profile_reset()
-    _lib.profile_enable(True)
+    _lib.profile_enable(True, only=('accumulate', 'extract'))
     barrier()
     t_start = time.perf_counter()
     for _ in range(args.steps):

@@ -46,6 +46,7 @@ const char* shg_last_error_string(void);
  * "extract", "warp", "rowpair_stats", "scale_rows", "clahe_hist", "clahe_lut", "clahe_interp",
  * "hist", "rescale", ...).  Off by default.  shg_profile_get waits for the events of `tag`. */
 int shg_profile_enable(int on);
+int shg_profile_select(const char* tags_csv);   /* only time these tags (NULL or "" = all) */
 int shg_profile_reset(void);
 int shg_profile_get(const char* tag, double* total_ms, int64_t* launches);
 
@@ -163,6 +164,20 @@ int shg_downscale_mean_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pi
  * right then top to bottom, times 1/(k*k), BORDER_REFLECT_101, anchor k/2.  tmp: h*w doubles. */
 int shg_box_blur_f64(const double* src, int64_t h, int64_t w, int k, double* dst, double* tmp,
                      shg_stream_t stream);
+
+/* Exact order statistics: out[i] = the host_ranks[i]-th smallest value (0-based) of values[n]
+ * (MSB-first radix select; feeds np.median / np.percentile, ellipse_to_circle.py:165, 241).
+ * host_ranks is a HOST array of n_ranks <= 8 entries. */
+size_t shg_select_workspace_bytes(int n_ranks);
+int shg_select_f64(const double* values, int64_t n, const int64_t* host_ranks, int n_ranks, double* out,
+                   void* workspace, size_t workspace_bytes, shg_stream_t stream);
+
+/* get_flood_image's statistics (ellipse_to_circle.py:159-169): stats[0] = np.sum(image) (image
+ * values are multiples of 2^-20, as the 4x4 block mean of uint16/65536 is), and over
+ * data = blurred[blurred < very_bright]: stats[1] = min, stats[2] = max,
+ * counts[20] = np.histogram(data, bins=20)[0].  workspace: 32 bytes. */
+int shg_flood_stats_f64(const double* image, const double* blurred, int64_t n, double very_bright,
+                        double* stats, uint32_t* counts, void* workspace, shg_stream_t stream);
 
 /* skimage.feature.canny(flooded, sigma, low, high) up to its two hysteresis masks
  * (ellipse_to_circle.py:245-250), where flooded = (blurred < flood_thresh ? 0 : 65000)

@@ -27,6 +27,7 @@ SIGNATURES = {
     'shg_abi_version': (c_int, []),
     'shg_last_error_string': (ctypes.c_char_p, []),
     'shg_profile_enable': (c_int, [c_int]),
+    'shg_profile_select': (c_int, [ctypes.c_char_p]),
     'shg_profile_reset': (c_int, []),
     'shg_profile_get': (c_int, [ctypes.c_char_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int64)]),
     'shg_accumulate_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int64, c_int]),
@@ -50,6 +51,9 @@ SIGNATURES = {
     'shg_fill_disc_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_uint16, P, P]),
     'shg_downscale_mean_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int, P, P]),
     'shg_box_blur_f64': (c_int, [P, c_int64, c_int64, c_int, P, P, P]),
+    'shg_select_workspace_bytes': (c_size_t, [c_int]),
+    'shg_select_f64': (c_int, [P, c_int64, ctypes.POINTER(c_int64), c_int, P, P, c_size_t, P]),
+    'shg_flood_stats_f64': (c_int, [P, P, c_int64, c_double, P, P, P, P]),
     'shg_canny_workspace_bytes': (c_size_t, [c_int64, c_int64]),
     'shg_canny_masks_f64': (c_int, [P, c_int64, c_int64, c_double, ctypes.POINTER(c_double), c_int, c_double, c_double, P, P, P,
                                     c_size_t, P]),
@@ -74,7 +78,9 @@ def check(status, what):
         raise RuntimeError('%s failed (status %d): %s' % (what, status, last_error()))
 
 
-def profile_enable(on=True):
+def profile_enable(on=True, only=None):
+    """only: iterable of kernel tags to time (None = all)."""
+    lib.shg_profile_select(','.join(only).encode() if only else None)
     lib.shg_profile_enable(1 if on else 0)
 
 

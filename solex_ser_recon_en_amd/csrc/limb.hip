@@ -161,6 +161,134 @@ __global__ __launch_bounds__(256) void k_nms(const double* __restrict__ isob, co
     high_mask[i] = (local && m >= high) ? 1 : 0;
 }
 
+// ---- exact order statistics of a float64 array: MSB-first radix select, 8 bits per launch -------------
+// np.median / np.percentile (ellipse_to_circle.py:165, 241) need the k-th smallest values exactly.
+__device__ __forceinline__ uint64_t f64_key(double v) {          // monotone map double -> uint64
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_f64(uint64_t k) {
+    const uint64_t b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+struct SelectState { uint64_t prefix; int64_t rank; };
+
+// Replay the digit choices of passes 0 .. pass-1 from their global histograms, with the whole
+// 256-thread workgroup: one bin per thread, a workgroup-wide inclusive scan, the bin whose
+// cumulative range holds the rank wins.  Every workgroup replays the same (deterministic) choices.
+__device__ __forceinline__ SelectState select_replay(const uint32_t* __restrict__ hist, int pass, int64_t rank) {
+    __shared__ int64_t wave_tot[4];
+    __shared__ int64_t chosen[2];          // digit, count below it
+    SelectState st{0, rank};
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int p = 0; p < pass; ++p) {
+        const int64_t c = hist[p * 256 + tid];
+        int64_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        for (int i = 0; i < wave; ++i) incl += wave_tot[i];
+        const int64_t excl = incl - c;
+        if (excl <= st.rank && st.rank < incl) { chosen[0] = tid; chosen[1] = excl; }
+        __syncthreads();
+        st.rank -= chosen[1];
+        st.prefix = (st.prefix << 8) | (uint64_t)chosen[0];
+        __syncthreads();
+    }
+    return st;
+}
+
+// grid (blocks, n_ranks).  hist: [n_ranks][8][256] u32, zeroed.
+__global__ __launch_bounds__(256) void k_select_pass(const double* __restrict__ v, int64_t n, int pass, const int64_t* __restrict__ ranks,
+                                                     uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[256];
+    uint32_t* myhist = hist + (int64_t)blockIdx.y * 8 * 256;
+    const SelectState st = select_replay(myhist, pass, ranks[blockIdx.y]);
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t prefix = st.prefix;
+    const int shift = 56 - 8 * pass;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint64_t k = f64_key(v[i]);
+        if (pass == 0 || (k >> (shift + 8)) == prefix) atomicAdd(&lh[(k >> shift) & 0xff], 1u);
+    }
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&myhist[pass * 256 + threadIdx.x], lh[threadIdx.x]);
+}
+
+// grid (n_ranks), 256 threads
+__global__ __launch_bounds__(256) void k_select_final(const int64_t* __restrict__ ranks, const uint32_t* __restrict__ hist,
+                                                      double* __restrict__ out) {
+    const SelectState st = select_replay(hist + (int64_t)blockIdx.x * 8 * 256, 8, ranks[blockIdx.x]);
+    if (threadIdx.x == 0) out[blockIdx.x] = key_f64(st.prefix);
+}
+
+// ---- get_flood_image's statistics (ellipse_to_circle.py:159-169) ----------------------------------------
+// stats[0] = sum(image) (every value is k / 2^20 and the total < 2^18: exact in any order),
+// then over data = blurred[blurred < very_bright]: stats[1] = min, stats[2] = max, counts[20] = np.histogram(data, 20)
+__global__ __launch_bounds__(256) void k_flood_minmax(const double* __restrict__ image, const double* __restrict__ blurred, int64_t n,
+                                                      double very_bright, unsigned long long* __restrict__ acc) {
+    // acc[0] = sum as fixed point (units of 2^-20), acc[1] = min key, acc[2] = max key
+    unsigned long long s = 0, lo = ~0ull, hi = 0ull;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        s += (unsigned long long)(image[i] * 1048576.0);
+        const double b = blurred[i];
+        if (b < very_bright) {
+            const uint64_t k = f64_key(b);
+            lo = k < lo ? k : lo;
+            hi = k > hi ? k : hi;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        s += __shfl_xor(s, d);
+        const unsigned long long ol = __shfl_xor(lo, d), oh = __shfl_xor(hi, d);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&acc[0], s);
+        atomicMin(&acc[1], lo);
+        atomicMax(&acc[2], hi);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_flood_hist(const double* __restrict__ blurred, int64_t n, double very_bright,
+                                                    const unsigned long long* __restrict__ acc, double* __restrict__ stats,
+                                                    uint32_t* __restrict__ counts) {
+    __shared__ double edges[21];
+    __shared__ uint32_t lc[20];
+    const double mn = key_f64(acc[1]), mx = key_f64(acc[2]);
+    if (threadIdx.x < 21) {
+        // np.histogram: first == last -> (first - 0.5, last + 0.5); bin_edges = np.linspace(first, last, 21)
+        double first = mn, last = mx;
+        if (first == last) { first = first - 0.5; last = last + 0.5; }
+        const double step = (last - first) / 20.0;
+        edges[threadIdx.x] = threadIdx.x == 20 ? last : (double)threadIdx.x * step + first;
+    }
+    if (threadIdx.x < 20) lc[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double b = blurred[i];
+        if (!(b < very_bright)) continue;
+        int bin = 0;                                  // largest bin with edges[bin] <= b; the last bin is closed
+        for (int j = 1; j < 20; ++j) bin = (b >= edges[j]) ? j : bin;
+        atomicAdd(&lc[bin], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 20 && lc[threadIdx.x]) atomicAdd(&counts[threadIdx.x], lc[threadIdx.x]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        stats[0] = (double)acc[0] / 1048576.0;
+        stats[1] = mn;
+        stats[2] = mx;
+    }
+}
+
 }  // namespace
 
 extern "C" int shg_box_blur_f64(const double* src, int64_t h, int64_t w, int k, double* dst, double* tmp, shg_stream_t stream) {
@@ -203,4 +331,53 @@ extern "C" int shg_canny_masks_f64(const double* blurred, int64_t h, int64_t w, 
     if (int e = shg::check_launch("k_sobel_mag")) return e;
     { SHG_PROF("canny", st); k_nms<<<blocks, 256, 0, st>>>(isob, jsob, mag, (int)h, (int)w, low, high, low_mask, high_mask); }
     return shg::check_launch("k_nms");
+}
+
+extern "C" size_t shg_select_workspace_bytes(int n_ranks) {
+    if (n_ranks < 1 || n_ranks > 8) return 0;
+    return (size_t)n_ranks * (8 * 256 * sizeof(uint32_t) + sizeof(int64_t));
+}
+
+extern "C" int shg_select_f64(const double* values, int64_t n, const int64_t* host_ranks, int n_ranks, double* out,
+                              void* workspace, size_t workspace_bytes, shg_stream_t stream) {
+    SHG_REQUIRE(values && host_ranks && out && workspace, SHG_E_ARG, "shg_select_f64: null pointer");
+    SHG_REQUIRE(n > 0 && n_ranks >= 1 && n_ranks <= 8, SHG_E_ARG, "shg_select_f64: bad sizes");
+    SHG_REQUIRE(workspace_bytes >= shg_select_workspace_bytes(n_ranks), SHG_E_WORKSPACE, "shg_select_f64: workspace too small");
+    for (int i = 0; i < n_ranks; ++i)
+        SHG_REQUIRE(host_ranks[i] >= 0 && host_ranks[i] < n, SHG_E_ARG, "shg_select_f64: rank %lld outside [0, %lld)",
+                    (long long)host_ranks[i], (long long)n);
+    hipStream_t st = shg::as_stream(stream);
+    uint32_t* hist = static_cast<uint32_t*>(workspace);
+    int64_t* ranks = reinterpret_cast<int64_t*>(hist + (size_t)n_ranks * 8 * 256);
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)n_ranks * 8 * 256 * sizeof(uint32_t), st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ranks, host_ranks, n_ranks * sizeof(int64_t), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) { shg::set_error("shg_select_f64: %s", hipGetErrorString(e)); return (int)e; }
+    int64_t blocks = (n + 2047) / 2048;
+    if (blocks > 256) blocks = 256;
+    SHG_PROF("select", st);
+    for (int pass = 0; pass < 8; ++pass) {
+        k_select_pass<<<dim3((unsigned)blocks, (unsigned)n_ranks), 256, 0, st>>>(values, n, pass, ranks, hist);
+        if (int err = shg::check_launch("k_select_pass")) return err;
+    }
+    k_select_final<<<(unsigned)n_ranks, 256, 0, st>>>(ranks, hist, out);
+    return shg::check_launch("k_select_final");
+}
+
+extern "C" int shg_flood_stats_f64(const double* image, const double* blurred, int64_t n, double very_bright, double* stats,
+                                   uint32_t* counts, void* workspace, shg_stream_t stream) {
+    SHG_REQUIRE(image && blurred && stats && counts && workspace, SHG_E_ARG, "shg_flood_stats_f64: null pointer");
+    SHG_REQUIRE(n > 0, SHG_E_ARG, "shg_flood_stats_f64: empty image");
+    hipStream_t st = shg::as_stream(stream);
+    unsigned long long* acc = static_cast<unsigned long long*>(workspace);
+    const unsigned long long init[3] = {0ull, ~0ull, 0ull};
+    hipError_t e = hipMemcpyAsync(acc, init, sizeof(init), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(counts, 0, 20 * sizeof(uint32_t), st);
+    if (e != hipSuccess) { shg::set_error("shg_flood_stats_f64: %s", hipGetErrorString(e)); return (int)e; }
+    int64_t blocks = (n + 2047) / 2048;
+    if (blocks > 256) blocks = 256;
+    SHG_PROF("flood_stats", st);
+    k_flood_minmax<<<(unsigned)blocks, 256, 0, st>>>(image, blurred, n, very_bright, acc);
+    if (int err = shg::check_launch("k_flood_minmax")) return err;
+    k_flood_hist<<<(unsigned)blocks, 256, 0, st>>>(blurred, n, very_bright, acc, stats, counts);
+    return shg::check_launch("k_flood_hist");
 }

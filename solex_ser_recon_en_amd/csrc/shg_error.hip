@@ -22,11 +22,17 @@ struct Sample { std::string tag; hipEvent_t a, b; };
 std::mutex g_mu;
 bool g_enabled = false;
 std::vector<Sample> g_samples;
+std::vector<std::string> g_only;      // empty = every tag
 }  // namespace
 
 ProfScope::ProfScope(const char* tag, hipStream_t st) : slot(-1), stream(st) {
     if (!g_enabled) return;
     std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_only.empty()) {
+        bool hit = false;
+        for (auto& t : g_only) hit = hit || t == tag;
+        if (!hit) return;
+    }
     Sample s;
     s.tag = tag;
     if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
@@ -45,6 +51,23 @@ ProfScope::~ProfScope() {
 extern "C" int shg_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(shg::g_mu);
     shg::g_enabled = on != 0;
+    return 0;
+}
+
+extern "C" int shg_profile_select(const char* tags_csv) {
+    std::lock_guard<std::mutex> lk(shg::g_mu);
+    shg::g_only.clear();
+    if (!tags_csv) return 0;
+    std::string cur;
+    for (const char* p = tags_csv;; ++p) {
+        if (*p == ',' || *p == 0) {
+            if (!cur.empty()) shg::g_only.push_back(cur);
+            cur.clear();
+            if (*p == 0) break;
+        } else {
+            cur.push_back(*p);
+        }
+    }
     return 0;
 }
 

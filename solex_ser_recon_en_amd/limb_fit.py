@@ -31,15 +31,37 @@ NUM_REG = 2          # ellipse_to_circle.py:31
 
 
 # ---- get_flood_image's threshold (ellipse_to_circle.py:159-225) ---------------------------
-def flood_threshold(image, blurred):
-    """image, blurred: host float64 arrays.  Returns thresh3: pixels of `blurred` below it become 0,
-    the others 65000 (:226-227, done on the GPU)."""
-    h, w = image.shape
-    thresh = 0.9 * np.sum(image) / (h * w)
-    very_bright = np.percentile(blurred, 99)
-    data = blurred.ravel()
-    data = data[data < very_bright]
-    n, bins = np.histogram(data, bins=20)
+def lerp_order_stats(n, q):
+    """np.percentile(.., q) (method 'linear') on n values = lerp between two order statistics:
+    returns (rank_lo, rank_hi, combine(a, b)), following NumPy's _quantile / _lerp."""
+    virtual = (n - 1) * np.true_divide(q, 100)
+    lo = min(max(math.floor(virtual), 0), n - 1)
+    hi = min(lo + 1, n - 1)
+    gamma = virtual - math.floor(virtual)
+
+    def combine(a, b):
+        diff = b - a
+        return b - diff * (1 - gamma) if gamma >= 0.5 else a + diff * gamma
+    return lo, hi, combine
+
+
+def median_order_stats(n):
+    """np.median on n values: the middle order statistic, or the mean of the two middle ones."""
+    if n % 2:
+        return n // 2, n // 2, (lambda a, b: a)
+    return n // 2 - 1, n // 2, (lambda a, b: (a + b) / 2)
+
+
+def flood_threshold(total, shape, mn, mx, counts):
+    """thresh3 of get_flood_image from the image statistics the GPU reduces:
+    total = np.sum(image); over data = blurred[blurred < very_bright]: mn, mx = data.min(), data.max(),
+    counts = np.histogram(data, bins=20)[0].  Pixels of `blurred` below thresh3 become 0, the others 65000."""
+    h, w = shape
+    thresh = 0.9 * total / (h * w)
+    if mn == mx:                                      # np.histogram's range for constant data
+        mn, mx = mn - 0.5, mx + 0.5
+    bins = np.linspace(mn, mx, 21)
+    n = np.asarray(counts, dtype=np.int64)
     d, c, b, a = polynomial.polynomial.Polynomial.fit(bins[1:], n, 3).convert().coef
     discriminant = 4 * b ** 2 - 12 * a * c
     thresh2 = (-2 * b + np.sqrt(discriminant)) / (6 * a) if discriminant >= 0 else thresh
@@ -82,13 +104,17 @@ def limb_points(edges, labelled, nf):
     size_list = sizes.tolist()
     # the reference picks regions by size VALUE: equal sizes resolve to the first such region
     chosen = [size_list.index(v) for v in sorted(size_list, reverse=True)[:min(nf, NUM_REG)]]
-    filt = np.isin(labelled, chosen)
+    lut = np.zeros(nf + 1, dtype=bool)
+    lut[chosen] = True
+    filt = lut[labelled]
     X = np.argwhere(filt)
     hull = X[ConvexHull(X).vertices]
     on_hull = np.zeros(edges.shape, dtype=bool)
     on_hull[hull[:, 0], hull[:, 1]] = True
     keep = [i for i in chosen if np.any((labelled == i) & on_hull)]
-    filt = np.isin(labelled, keep)
+    lut[:] = False
+    lut[keep] = True
+    filt = lut[labelled]
     x_min, x_max = np.min(X[:, 0]), np.max(X[:, 0])
     dx = x_max - x_min
     crop = 0.017
@@ -102,18 +128,24 @@ def edge_points(small, sigma=2):
     """small: float64 GPU tensor, the 4x4 block mean of disk/65536.
     -> (X float [n, 2] limb points (row, col), raw_X int [m, 2] all canny points)."""
     h, w = small.shape
+    n = h * w
     k = int(h * 0.01)
     if k <= 0:
         raise RuntimeError('ellipse fit: the scan needs at least 400 slit rows (cv2.blur kernel int(0.01 * h/4) = 0)')
-    blurred_t = ops.box_blur_f64(small, k)
-    host = torch.stack([small, ops.box_blur_f64(small, 5), blurred_t]).cpu().numpy()
-    low = np.median(host[1]) / 10                       # low_threshold = median(blur 5x5) / 10 (:241-242)
+    blurred = ops.box_blur_f64(small, k)
+    m_lo, m_hi, median = median_order_stats(n)
+    p_lo, p_hi, p99 = lerp_order_stats(n, 99)
+    sel = torch.cat([ops.select_f64(ops.box_blur_f64(small, 5), [m_lo, m_hi]), ops.select_f64(blurred, [p_lo, p_hi])]).cpu().numpy()
+    low = median(sel[0], sel[1]) / 10                   # low_threshold = median(blur 5x5) / 10 (:241-242)
     high = low * 1.5
-    thresh3 = flood_threshold(host[0], host[2])
+    very_bright = p99(sel[2], sel[3])                   # np.percentile(img_blurred, 99) (:165)
+    stats, counts = ops.flood_stats(small, blurred, very_bright)
+    packed = torch.cat([stats, counts.to(torch.float64)]).cpu().numpy()
+    thresh3 = flood_threshold(packed[0], (h, w), packed[1], packed[2], packed[3:].astype(np.int64))
     while True:
         if sigma <= 0:
             raise RuntimeError('ellipse fit: could not find any edges of the solar disk')
-        masks = torch.stack(ops.canny_masks(blurred_t, thresh3, sigma, low, high)).cpu().numpy().astype(bool)
+        masks = torch.stack(ops.canny_masks(blurred, thresh3, sigma, low, high)).cpu().numpy().astype(bool)
         edges = hysteresis(masks[0], masks[1])
         labelled, nf = ndi.label(edges, np.ones((3, 3), int))
         if nf:

@@ -275,3 +275,36 @@ def canny_masks(blurred, flood_thresh, sigma, low, high):
                                        masks[0].data_ptr(), masks[1].data_ptr(), ws.data_ptr(), need, _stream()),
                'shg_canny_masks_f64')
     return masks[0], masks[1]
+
+
+def select_f64(values, ranks):
+    """-> float64 GPU tensor: the ranks[i]-th smallest elements (0-based) of a dense float64 tensor."""
+    import ctypes
+    _dev(values, 'values')
+    if values.dtype != torch.float64 or not values.is_contiguous():
+        raise TypeError('select_f64 needs a dense float64 tensor')
+    ranks = [int(r) for r in ranks]
+    arr = (ctypes.c_int64 * len(ranks))(*ranks)
+    need = lib.shg_select_workspace_bytes(len(ranks))
+    if need == 0:
+        raise ValueError('select_f64 takes 1..8 ranks')
+    ws = torch.empty(need, dtype=torch.uint8, device=values.device)
+    out = torch.empty(len(ranks), dtype=torch.float64, device=values.device)
+    _lib.check(lib.shg_select_f64(values.data_ptr(), values.numel(), arr, len(ranks), out.data_ptr(), ws.data_ptr(), need,
+                                  _stream()), 'shg_select_f64')
+    return out
+
+
+def flood_stats(image, blurred, very_bright):
+    """-> (stats float64 [3] = sum(image), min, max of blurred[blurred < very_bright]; counts int32 [20]) on the GPU."""
+    _dev(image, 'image')
+    _dev(blurred, 'blurred')
+    if image.dtype != torch.float64 or blurred.dtype != torch.float64 or image.shape != blurred.shape:
+        raise TypeError('flood_stats needs two dense float64 images of one shape')
+    stats = torch.empty(3, dtype=torch.float64, device=image.device)
+    counts = torch.empty(20, dtype=torch.int32, device=image.device)
+    ws = torch.empty(4, dtype=torch.int64, device=image.device)
+    _lib.check(lib.shg_flood_stats_f64(image.contiguous().data_ptr(), blurred.contiguous().data_ptr(), image.numel(),
+                                       float(very_bright), stats.data_ptr(), counts.data_ptr(), ws.data_ptr(), _stream()),
+               'shg_flood_stats_f64')
+    return stats, counts

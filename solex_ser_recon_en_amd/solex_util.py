@@ -174,16 +174,51 @@ def reject_outliers(data, m=2):
 
 
 def _tukey(n, a=0.05):
-    def t(x):
-        if 0 <= x < a * n / 2:
-            return 1 / 2 * (1 - math.cos(2 * math.pi * x / (a * n)))
-        elif a * n / 2 <= x <= n / 2:
-            return 1
-        elif n / 2 <= x <= n:
-            return t(n - x)
-        print('error: weird input for taper function: ' + str(x))
-        return 1
-    return np.array([t(x) for x in range(n)])
+    """The reference's piecewise taper t(x), x = 0..n-1 (solex_util.py:460-470), evaluating
+    math.cos only on the two ramps (everything in between is exactly 1)."""
+    def ramp(x):
+        return 1 / 2 * (1 - math.cos(2 * math.pi * x / (a * n)))
+    taper = np.ones(n)
+    for x in range(n):
+        if x < a * n / 2:
+            taper[x] = ramp(x)
+        else:
+            break
+    for x in range(n - 1, -1, -1):
+        # x > n/2 mirrors to t(n - x); the plateau test a*n/2 <= x <= n/2 comes first in the reference
+        if x > n / 2 and (n - x) < a * n / 2:
+            taper[x] = ramp(n - x)
+        else:
+            break
+    return taper
+
+
+def _chord_bounds(circle, borders, y1, y2, w):
+    """Column slice [a, b) of every row y1 .. y2-1 (entry 0 unused), as solex_util.py:389-391 computes them:
+    dx = floor((r^2 - (y-cy)^2) ** 0.5), a = ceil(max(cx - dx, b0)), b = floor(min(cx + dx, b2)),
+    then NumPy's slice normalisation.  Vectorised; rows whose square root lands within a few ulp of
+    an integer are redone with Python's own pow so that floor() cannot differ from the reference."""
+    count = max(y2 - y1, 1)
+    xa = np.zeros(count, dtype=np.int32)
+    xb = np.zeros(count, dtype=np.int32)
+    if y2 - y1 < 2:
+        return xa, xb
+    ys = np.arange(y1 + 1, y2, dtype=np.float64)
+    v = circle[2] ** 2 - (ys - circle[1]) ** 2
+    if np.any(v < 0):
+        raise TypeError("transversalium: row outside the disk circle (complex chord length)")   # floor(complex) in the reference
+    root = np.sqrt(v)
+    dx = np.floor(root)
+    near = np.abs(root - np.rint(root)) <= 1e-9 * np.maximum(root, 1.0)
+    for i in np.flatnonzero(near):
+        dx[i] = math.floor(float(v[i]) ** 0.5)
+    a = np.ceil(np.maximum(circle[0] - dx, borders[0])).astype(np.int64)
+    b = np.floor(np.minimum(circle[0] + dx, borders[2])).astype(np.int64)
+    a = np.where(a < 0, np.maximum(a + w, 0), np.minimum(a, w))          # slice(a, b).indices(w)
+    b = np.where(b < 0, np.maximum(b + w, 0), np.minimum(b, w))
+    xa[1:] = a
+    xb[1:] = np.maximum(a, b)
+    return xa, xb
 
 
 def correct_transversalium2(img, circle, borders, options, reqFlag, basefich):
@@ -194,14 +229,7 @@ def correct_transversalium2(img, circle, borders, options, reqFlag, basefich):
     h, w = t.shape
     y1 = math.ceil(max(circle[1] - circle[2], borders[1]))
     y2 = math.floor(min(circle[1] + circle[2], borders[3]))
-    count = max(y2 - y1, 1)
-    xa = np.zeros(count, dtype=np.int32)
-    xb = np.zeros(count, dtype=np.int32)
-    for y in range(y1 + 1, y2):
-        dx = math.floor((circle[2] ** 2 - (y - circle[1]) ** 2) ** 0.5)
-        a, b, _ = slice(math.ceil(max(circle[0] - dx, borders[0])),
-                        math.floor(min(circle[0] + dx, borders[2]))).indices(w)      # NumPy slice semantics
-        xa[y - y1], xb[y - y1] = a, max(a, b)
+    xa, xb = _chord_bounds(circle, borders, y1, y2, w)
     if y2 - y1 >= 1:
         y_ratios_r = ops.rowpair_logratio_stats(t, y1, y2, xa, xb).cpu().numpy()
     else:

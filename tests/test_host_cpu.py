@@ -14,6 +14,30 @@ from solex_ser_recon_en_amd.ellipse_to_circle import get_correction_matrix
 from solex_ser_recon_en_amd.solex_util import column_plan, max_from_hist, percentile_from_hist
 
 
+def flood_threshold_numpy(small, blurred):
+    """Feed limb_fit.flood_threshold with the statistics the GPU would reduce, computed with NumPy."""
+    n = small.size
+    lo, hi, p99 = limb_fit.lerp_order_stats(n, 99)
+    srt = np.sort(blurred.ravel())
+    very_bright = p99(srt[lo], srt[hi])
+    assert very_bright == np.percentile(blurred, 99)
+    data = blurred.ravel()[blurred.ravel() < very_bright]
+    counts, _ = np.histogram(data, bins=20)
+    return limb_fit.flood_threshold(np.sum(small), small.shape, data.min(), data.max(), counts)
+
+
+def test_order_stat_helpers_are_numpy():
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 3, 10, 11, 1000, 12345):
+        v = rng.random(n)
+        srt = np.sort(v)
+        lo, hi, med = limb_fit.median_order_stats(n)
+        assert med(srt[lo], srt[hi]) == np.median(v)
+        for q in (0, 1, 50, 99, 99.9999, 100):
+            lo, hi, f = limb_fit.lerp_order_stats(n, q)
+            assert f(srt[lo], srt[hi]) == np.percentile(v, q)
+
+
 def test_limb_control_plane_matches_oracle(golden):
     """The host half of the limb fit (threshold choice, hysteresis, region selection, ellipse LSQ)
     against the oracle, fed with the arrays the GPU half would produce."""
@@ -22,7 +46,7 @@ def test_limb_control_plane_matches_oracle(golden):
     small = g['small']
     k = int(small.shape[0] * 0.01)
     blurred = orc.box_blur_f64(small, k, k)
-    thresh3 = limb_fit.flood_threshold(small, blurred)
+    thresh3 = flood_threshold_numpy(small, blurred)
     np.testing.assert_array_equal(np.where(blurred < thresh3, 0.0, 65000.0), g['flooded'])
     edges = g['canny0']
     np.testing.assert_array_equal(limb_fit.hysteresis(edges, edges), edges)

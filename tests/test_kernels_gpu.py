@@ -240,7 +240,8 @@ def test_canny_masks_match_skimage_0_18_3(ops, orc, golden):
     small = g['small']
     k = int(small.shape[0] * 0.01)
     blurred = orc.box_blur_f64(small, k, k)
-    thresh3 = limb_fit.flood_threshold(small, blurred)
+    from tests.test_host_cpu import flood_threshold_numpy
+    thresh3 = flood_threshold_numpy(small, blurred)
     for i in range(3):
         sigma, lo, hi = g['canny%d_params' % i]
         low_m, high_m = ops.canny_masks(dev(blurred), thresh3, sigma, lo, hi)
@@ -260,3 +261,29 @@ def test_edge_points_match_oracle(ops, golden):
     Xo, rawo = limb.get_edge_list(g['small'].copy())
     np.testing.assert_array_equal(X, Xo)
     np.testing.assert_array_equal(raw, rawo)
+
+
+@pytest.mark.parametrize('n', [1, 2, 5, 1000, 250000])
+def test_select_f64_is_exact(ops, n):
+    rng = np.random.default_rng(n)
+    v = rng.standard_normal(n) * 10.0 ** rng.integers(-3, 4, n)
+    if n > 10:
+        v[: n // 4] = v[0]                       # heavy ties
+        v[-3:] = [0.0, -0.0, 1e-300]
+    srt = np.sort(v)
+    ranks = sorted(set([0, n // 2, max(n // 2 - 1, 0), n - 1, int(0.99 * (n - 1))]))
+    got = host(ops.select_f64(dev(v), ranks))
+    np.testing.assert_array_equal(got, srt[ranks])
+
+
+def test_flood_stats_match_numpy(ops, golden):
+    g = golden('g13_limb')
+    small = g['small']                           # block means of uint16/65536: multiples of 2^-20
+    from oracle import shg_oracle
+    blurred = shg_oracle.box_blur_f64(small, 2, 2)
+    vb = np.percentile(blurred, 99)
+    stats, counts = ops.flood_stats(dev(small), dev(blurred), vb)
+    data = blurred.ravel()[blurred.ravel() < vb]
+    want, _ = np.histogram(data, bins=20)
+    np.testing.assert_array_equal(host(counts), want)
+    np.testing.assert_array_equal(host(stats), [np.sum(small), data.min(), data.max()])
