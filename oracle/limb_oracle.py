@@ -186,10 +186,15 @@ def get_edge_list(image, sigma=2):                                  # ellipse_to
     high_threshold = low_threshold * 1.5
     image_flooded = get_flood_image(image)
     edges = canny(image_flooded, sigma, low_threshold, high_threshold)
-    raw_X = np.argwhere(edges)
     labelled, nf = ndi.label(edges, structure=[[1, 1, 1], [1, 1, 1], [1, 1, 1]])
     if nf == 0:
         return get_edge_list(image, sigma=sigma - 0.5)
+    return points_from_edges(edges)
+
+
+def points_from_edges(edges):                                       # ellipse_to_circle.py:251-291
+    raw_X = np.argwhere(edges)
+    labelled, nf = ndi.label(edges, structure=[[1, 1, 1], [1, 1, 1], [1, 1, 1]])
     region_sizes = [-1] + [int(np.sum(labelled == i)) for i in range(1, nf + 1)]
     top = sorted(region_sizes, reverse=True)[:min(nf, NUM_REG)]
     filt = np.zeros(edges.shape)

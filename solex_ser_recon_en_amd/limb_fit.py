@@ -99,29 +99,27 @@ def hysteresis(low_mask, high_mask):
 
 # ---- get_edge_list after canny (ellipse_to_circle.py:251-291) ---------------------------------
 def limb_points(edges, labelled, nf):
-    sizes = np.bincount(labelled.ravel(), minlength=nf + 1)
+    """The reference builds full-size masks per region; the same selections on the list of edge
+    points (np.argwhere order is kept, so the result equals np.argwhere(filt) of the reference)."""
+    pts = np.argwhere(edges)                          # row-major order, as every np.argwhere of a sub-mask
+    lab = labelled[pts[:, 0], pts[:, 1]]
+    sizes = np.bincount(lab, minlength=nf + 1)
     sizes[0] = -1
     size_list = sizes.tolist()
-    # the reference picks regions by size VALUE: equal sizes resolve to the first such region
+    # regions are picked by size VALUE: equal sizes resolve to the first such region (list.index)
     chosen = [size_list.index(v) for v in sorted(size_list, reverse=True)[:min(nf, NUM_REG)]]
-    lut = np.zeros(nf + 1, dtype=bool)
-    lut[chosen] = True
-    filt = lut[labelled]
-    X = np.argwhere(filt)
-    hull = X[ConvexHull(X).vertices]
-    on_hull = np.zeros(edges.shape, dtype=bool)
-    on_hull[hull[:, 0], hull[:, 1]] = True
-    keep = [i for i in chosen if np.any((labelled == i) & on_hull)]
-    lut[:] = False
-    lut[keep] = True
-    filt = lut[labelled]
+    in_chosen = np.isin(lab, chosen)
+    X = pts[in_chosen]
+    hull_labels = set(lab[in_chosen][ConvexHull(X).vertices].tolist())
+    keep = [i for i in chosen if i in hull_labels]    # regions that own a convex-hull vertex
     x_min, x_max = np.min(X[:, 0]), np.max(X[:, 0])
     dx = x_max - x_min
     crop = 0.017
+    r0, r1 = int(x_min + dx * crop), int(x_max - dx * crop)
     rows = np.zeros(edges.shape[0], dtype=bool)
-    rows[int(x_min + dx * crop):int(x_max - dx * crop)] = True
-    filt &= rows[:, None]
-    return np.array(np.argwhere(filt), dtype='float')
+    rows[r0:r1] = True                                # slice semantics of mask[int(..):int(..), :] = 1
+    sel = np.isin(lab, keep) & rows[pts[:, 0]]
+    return np.array(pts[sel], dtype='float'), pts
 
 
 def edge_points(small, sigma=2):
@@ -151,7 +149,7 @@ def edge_points(small, sigma=2):
         if nf:
             break
         sigma -= 0.5                                   # try again with less blur (:254-256)
-    return limb_points(edges, labelled, nf), np.argwhere(edges)
+    return limb_points(edges, labelled, nf)
 
 
 # ---- LsqEllipse (Halir & Flusser) -----------------------------------------------------------

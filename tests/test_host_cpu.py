@@ -56,7 +56,8 @@ def test_limb_control_plane_matches_oracle(golden):
     want = np.zeros_like(low); want[5, 2:9] = True
     np.testing.assert_array_equal(limb_fit.hysteresis(low, high), want)
     labelled, nf = ndi.label(edges, np.ones((3, 3), int))
-    X = limb_fit.limb_points(edges, labelled, nf)
+    X, raw = limb_fit.limb_points(edges, labelled, nf)
+    np.testing.assert_array_equal(raw, np.argwhere(edges))
     Xo, rawo = limb.get_edge_list(small.copy())
     np.testing.assert_array_equal(X, Xo)
     np.testing.assert_array_equal(np.argwhere(edges), rawo)
@@ -65,6 +66,35 @@ def test_limb_control_plane_matches_oracle(golden):
     for a, b in zip(got[:4], want[:4]):
         np.testing.assert_allclose(a, b, rtol=1e-12)
     np.testing.assert_array_equal(got[4], want[4])
+
+
+def test_limb_region_selection_cases():
+    """Two largest regions by size value (ties -> first), hull filter, 1.7 % row crop: mask form vs point form."""
+    from scipy import ndimage as ndi
+    rng = np.random.default_rng(9)
+
+    def ring(shape, cy, cx, r, arc=(0, 2 * np.pi)):
+        m = np.zeros(shape, bool)
+        t = np.linspace(arc[0], arc[1], 2000)
+        m[np.clip(np.rint(cy + r * np.sin(t)).astype(int), 0, shape[0] - 1), np.clip(np.rint(cx + r * np.cos(t)).astype(int), 0, shape[1] - 1)] = True
+        return m
+    cases = []
+    a = ring((120, 140), 60, 70, 50)                                  # one closed limb
+    cases.append(a)
+    b = ring((120, 140), 60, 70, 50, (0.2, 3.0)) | ring((120, 140), 60, 70, 50, (3.4, 6.1))   # limb in two arcs
+    b[60, 70] = True; b[61, 71] = True                                # a small blob inside: third region, dropped
+    cases.append(b)
+    c = ring((120, 140), 60, 70, 50, (0.1, 6.2)) | ring((120, 140), 60, 70, 20)               # inner ring: 2nd largest, off the hull
+    cases.append(c)
+    d = np.zeros((90, 90), bool)                                      # equal sizes: list.index picks the first twice
+    d[10, 10:30] = True; d[11:15, 10] = True; d[40, 10:34] = True; d[70, 10:34] = True; d[80, 50:60] = True
+    cases.append(d)
+    for edges in cases:
+        labelled, nf = ndi.label(edges, np.ones((3, 3), int))
+        X, raw = limb_fit.limb_points(edges, labelled, nf)
+        Xo, rawo = limb.points_from_edges(edges)
+        np.testing.assert_array_equal(X, Xo)
+        np.testing.assert_array_equal(raw, rawo)
 
 
 def test_gaussian_taps_are_scipys():
