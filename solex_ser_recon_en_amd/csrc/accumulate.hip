@@ -8,6 +8,7 @@
 // `nsplit` ranges so that the grid has >= ~16 waves per CU; each range writes a
 // partial (u32 sum, u16 max) slab that k_reduce_partials folds (integer, order
 // independent, so any split / any rank sharding gives identical bits).
+#include <math.h>
 #include <stdlib.h>
 #include "shg_common.h"
 
@@ -35,17 +36,32 @@ Plan make_plan(const void* stack, int64_t n, int64_t h, int64_t w, int bpp) {
     // so the workspace query (stack == nullptr) assumes an aligned base
     p.vector_path = (p.frame_bytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(stack) & 15) == 0);
     p.vecs = p.frame_bytes / 16;
-    const int64_t blocks_x = p.vector_path ? (p.vecs + 255) / 256 : (p.npix + 255) / 256;
-    const int target_blocks = env_int("SHG_ACC_TARGET_BLOCKS", 1024);   // 4096 waves = 16 per CU
-    int64_t nsplit = (target_blocks + blocks_x - 1) / blocks_x;
-    if (nsplit > n) nsplit = n;
-    if (nsplit > 64) nsplit = 64;
-    if (nsplit < 1) nsplit = 1;
+    // Launch shape.  Measured on MI355X (tools/sweep_acc*.sh): the read rate peaks when about 7 MiB of loads are
+    // in flight chip-wide (waves x unroll x 1 KiB) -- 6.7 TB/s at C2 -- and drops on either side (fewer: latency
+    // bound; more: 5.5-6.2 TB/s, the extra concurrent frame streams cost DRAM locality).  So choose
+    // (nsplit, unroll) for that footprint instead of for maximum occupancy.
+    const int64_t wave_cols = p.vector_path ? (p.vecs + 63) / 64 : (p.npix + 63) / 64;
+    const double target_kib = (double)env_int("SHG_ACC_INFLIGHT_KIB", 7168);
+    int64_t min_split = (n + 65536) / 65537;                    // a u32 partial holds 65537 full-scale frames
+    if (min_split < 1) min_split = 1;
+    double best = 1e30;
+    int best_split = (int)min_split, best_unroll = 4;
+    const int unrolls[3] = {4, 2, 8};
+    const double unroll_penalty[3] = {0.0, 0.03, 0.05};
+    for (int ui = 0; ui < 3; ++ui) {
+        for (int64_t sp = min_split; sp <= 64 && sp <= n; ++sp) {
+            const double kib = (double)wave_cols * (double)sp * unrolls[ui];
+            double score = kib > target_kib ? kib / target_kib : target_kib / kib;
+            score = log(score) + 0.01 * (double)sp + unroll_penalty[ui];
+            if (score < best) { best = score; best_split = (int)sp; best_unroll = unrolls[ui]; }
+        }
+    }
+    int64_t nsplit = best_split;
     const int forced = env_int("SHG_ACC_NSPLIT", 0);
     if (forced > 0) nsplit = forced > n ? n : forced;
     p.nsplit = (int)nsplit;
     p.frames_per_split = (int)((n + nsplit - 1) / nsplit);
-    p.unroll = env_int("SHG_ACC_UNROLL", 8);
+    p.unroll = env_int("SHG_ACC_UNROLL", best_unroll);
     return p;
 }
 
@@ -114,7 +130,7 @@ struct Acc<1> {
 };
 
 // grid: (ceil(vecs/256), nsplit).  One lane = 16 bytes of the frame, all frames of its split.
-template <int BPP, int UNROLL>
+template <int BPP, int UNROLL, bool NT>
 __global__ __launch_bounds__(256) void k_accumulate_vec(const u32x4* __restrict__ stack, int64_t vecs,
                                                         int n_frames, int frames_per_split,
                                                         uint32_t* __restrict__ psum, uint16_t* __restrict__ pmax,
@@ -131,13 +147,13 @@ __global__ __launch_bounds__(256) void k_accumulate_vec(const u32x4* __restrict_
     for (; k + UNROLL <= k1; k += UNROLL) {
         u32x4 r[UNROLL];
 #pragma unroll
-        for (int j = 0; j < UNROLL; ++j) r[j] = __builtin_nontemporal_load(p + (int64_t)j * vecs);
+        for (int j = 0; j < UNROLL; ++j) r[j] = NT ? __builtin_nontemporal_load(p + (int64_t)j * vecs) : p[(int64_t)j * vecs];
         p += (int64_t)UNROLL * vecs;
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) acc.add(r[j]);
     }
     for (; k < k1; ++k) {
-        acc.add(__builtin_nontemporal_load(p));
+        acc.add(NT ? __builtin_nontemporal_load(p) : *p);
         p += vecs;
     }
     const int64_t pix = v * Acc<BPP>::PX;
@@ -199,15 +215,15 @@ __global__ __launch_bounds__(256) void k_finalize(const uint64_t* __restrict__ s
     max_out[o] = (uint16_t)(mx[src] * scale);
 }
 
-template <int BPP>
+template <int BPP, bool NT>
 void launch_vec(const Plan& p, const void* stack, int n, uint32_t* psum, uint16_t* pmax, hipStream_t st) {
     dim3 grid((unsigned)((p.vecs + 255) / 256), (unsigned)p.nsplit);
     const u32x4* s = static_cast<const u32x4*>(stack);
     switch (p.unroll) {
-        case 2: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 2><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
-        case 4: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 4><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
-        case 16: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 16><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
-        default: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 8><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
+        case 2: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 2, NT><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
+        case 4: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 4, NT><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
+        case 16: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 16, NT><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
+        default: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 8, NT><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
     }
 }
 
@@ -243,8 +259,9 @@ extern "C" int shg_accumulate_sum_max(const void* stack, int64_t n_frames, int64
     uint16_t* pmax = reinterpret_cast<uint16_t*>(psum + (size_t)p.nsplit * p.npix);
     const int n = (int)n_frames;
     if (p.vector_path) {
-        if (bytes_per_px == 2) launch_vec<2>(p, stack, n, psum, pmax, st);
-        else launch_vec<1>(p, stack, n, psum, pmax, st);
+        const bool nt = env_int("SHG_ACC_NT", 1) != 0;
+        if (bytes_per_px == 2) { if (nt) launch_vec<2, true>(p, stack, n, psum, pmax, st); else launch_vec<2, false>(p, stack, n, psum, pmax, st); }
+        else { if (nt) launch_vec<1, true>(p, stack, n, psum, pmax, st); else launch_vec<1, false>(p, stack, n, psum, pmax, st); }
     } else {
         dim3 grid((unsigned)((p.npix + 255) / 256), (unsigned)p.nsplit);
         if (bytes_per_px == 2)
