@@ -2,9 +2,10 @@
 // Reference: correct_transversalium2 (solex_util.py:383-395, 489, 515-516) and
 // reject_outliers (solex_util.py:76-86).
 //
-// k_rowpair_stats: one workgroup per row pair.  The log-ratios of the chord are held
-// in LDS, sorted with a bitonic network to read the median, their absolute deviations
-// are sorted the same way for the MAD, and the 2-MAD inliers are averaged.  All float64.
+// k_rowpair_stats: one workgroup per row pair.  The log-ratios of the chord are held in LDS as
+// order-preserving 64-bit keys; the median and the MAD are read by an MSB-first radix select
+// (8 bits per pass, both middle order statistics in the same passes), then the 2-MAD inliers are
+// averaged.  All float64.  (A select moves ~16x less LDS data than sorting the row.)
 // The reference sums the inliers in image order with NumPy's pairwise scheme; here they
 // are summed by a fixed-shape tree, so the mean can differ in the last bits (as NumPy's
 // own log already does between CPUs); the correction factors agree to ~1e-15 relative.
@@ -15,31 +16,90 @@
 
 namespace {
 
-constexpr int MAXN = SHG_TRANSV_MAX_COLS;   // 8192 doubles = 64 KiB per array
+constexpr int MAXN = SHG_TRANSV_MAX_COLS;   // 8192 keys = 64 KiB of LDS
 constexpr int NT = 256;
 
-__device__ __forceinline__ void bitonic_sort(double* a, int n2) {
-    // n2 = power of two >= element count; padding holds +inf
-    for (int k = 2; k <= n2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n2; i += NT) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const double x = a[i], y = a[ixj];
-                    const bool up = (i & k) == 0;
-                    // NaN never compares: rows holding a NaN are detected before sorting
-                    if ((x > y) == up) { a[i] = y; a[ixj] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    }
+__device__ __forceinline__ uint64_t f64_key(double v) {          // monotone map double -> uint64 (no NaN)
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_f64(uint64_t k) {
+    const uint64_t b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
 }
 
-__device__ __forceinline__ double median_sorted(const double* a, int n) {
-    // np.median: mean of the two middle order statistics for even n
-    if (n & 1) return a[n >> 1];
-    return (a[(n >> 1) - 1] + a[n >> 1]) / 2.0;
+struct Scratch {
+    uint32_t hist[2][256];
+    int64_t wave_tot[2][4];
+    int64_t pick[2][2];          // [which rank][digit, count below]
+    double red[4];
+    int bad;
+};
+
+// one histogram increment with wave-level aggregation of the most common digit
+__device__ __forceinline__ void hist_add(uint32_t* hist, bool valid, uint32_t digit) {
+    const unsigned long long act = __ballot(valid);
+    if (act == 0) return;
+    const int leader = __ffsll((long long)act) - 1;
+    const uint32_t d0 = __shfl(digit, leader);
+    const unsigned long long same = __ballot(valid && digit == d0);
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[d0], (uint32_t)__popcll(same));
+    if (valid && digit != d0) atomicAdd(&hist[digit], 1u);
+}
+
+// The two order statistics rank_lo <= rank_hi (0-based) of key(i), i < n, for the whole workgroup.
+template <typename KeyFn>
+__device__ __forceinline__ void select2(KeyFn key, int n, int64_t rank_lo, int64_t rank_hi, Scratch& sc, uint64_t& out_lo,
+                                        uint64_t& out_hi) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t pref[2] = {0, 0};
+    int64_t rank[2] = {rank_lo, rank_hi};
+    bool same = true;                                  // both ranks still follow the same prefix
+    for (int p = 0; p < 8; ++p) {
+        const int shift = 56 - 8 * p;
+        sc.hist[0][tid] = 0;
+        sc.hist[1][tid] = 0;
+        __syncthreads();
+        for (int i0 = 0; i0 < n; i0 += NT) {
+            const int i = i0 + tid;
+            const bool in = i < n;
+            const uint64_t k = in ? key(i) : 0;
+            const uint64_t top = p == 0 ? 0 : (k >> (shift + 8));
+            const uint32_t digit = (uint32_t)(k >> shift) & 0xffu;
+            hist_add(sc.hist[0], in && (p == 0 || top == pref[0]), digit);
+            if (!same) hist_add(sc.hist[1], in && top == pref[1], digit);
+        }
+        __syncthreads();
+        // workgroup-wide inclusive scan of both histograms, one bin per thread
+        int64_t c[2], incl[2];
+        c[0] = sc.hist[0][tid];
+        c[1] = same ? c[0] : sc.hist[1][tid];
+        incl[0] = c[0];
+        incl[1] = c[1];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t o0 = __shfl_up(incl[0], d), o1 = __shfl_up(incl[1], d);
+            if (lane >= d) { incl[0] += o0; incl[1] += o1; }
+        }
+        if (lane == 63) { sc.wave_tot[0][wave] = incl[0]; sc.wave_tot[1][wave] = incl[1]; }
+        __syncthreads();
+        for (int i = 0; i < wave; ++i) { incl[0] += sc.wave_tot[0][i]; incl[1] += sc.wave_tot[1][i]; }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int64_t excl = incl[r] - c[r];
+            if (excl <= rank[r] && rank[r] < incl[r]) { sc.pick[r][0] = tid; sc.pick[r][1] = excl; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            rank[r] -= sc.pick[r][1];
+            pref[r] = (pref[r] << 8) | (uint64_t)sc.pick[r][0];
+        }
+        same = same && (pref[0] == pref[1]);
+        __syncthreads();
+    }
+    out_lo = pref[0];
+    out_hi = pref[1];
 }
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
@@ -54,9 +114,8 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 __global__ __launch_bounds__(NT) void k_rowpair_stats(const uint16_t* __restrict__ img, int64_t pitch, int64_t y1,
                                                       const int32_t* __restrict__ xa, const int32_t* __restrict__ xb,
                                                       double* __restrict__ out) {
-    extern __shared__ double lds[];      // [2][n2]
-    __shared__ double red[4];
-    __shared__ int bad;
+    extern __shared__ uint64_t keys[];   // [n]
+    __shared__ Scratch sc;
     const int t = blockIdx.x + 1;        // out[0] stays 0 (solex_util.py:386)
     const int64_t y = y1 + t;
     const int a = xa[t], b = xb[t];
@@ -65,55 +124,48 @@ __global__ __launch_bounds__(NT) void k_rowpair_stats(const uint16_t* __restrict
         if (threadIdx.x == 0) out[t] = __builtin_nan("");
         return;
     }
-    int n2 = 1;
-    while (n2 < n) n2 <<= 1;
-    double* v = lds;
-    double* d = lds + n2;
-    if (threadIdx.x == 0) bad = 0;
+    if (threadIdx.x == 0) sc.bad = 0;
     __syncthreads();
     const uint16_t* r1 = img + y * pitch + a;
     const uint16_t* r0 = img + (y - 1) * pitch + a;
     // Zero pixels give -inf / +inf / NaN ratios.  NumPy keeps infinities as ordinary (sortable) values and
     // lets any NaN poison the row statistic (np.median -> nan -> empty inlier set -> nan); same here.
-    for (int i = threadIdx.x; i < n2; i += NT) {
-        double x = __builtin_inf();
-        if (i < n) {
-            x = log((double)r1[i] / (double)r0[i]);        // np.log(strip1 / strip0)
-            if (x != x) bad = 1;
-        }
-        v[i] = x;
+    for (int i = threadIdx.x; i < n; i += NT) {
+        const double x = log((double)r1[i] / (double)r0[i]);        // np.log(strip1 / strip0)
+        if (x != x) sc.bad = 1;
+        keys[i] = f64_key(x);
     }
     __syncthreads();
-    if (bad) {
+    if (sc.bad) {
         if (threadIdx.x == 0) out[t] = __builtin_nan("");
         return;
     }
-    bitonic_sort(v, n2);
-    const double med = median_sorted(v, n);
-    for (int i = threadIdx.x; i < n2; i += NT) {
-        double dv = __builtin_inf();
-        if (i < n) {
-            dv = fabs(v[i] - med);                         // inf - inf or a NaN median -> NaN
-            if (dv != dv) bad = 1;
-        }
-        d[i] = dv;
+    // np.median: the middle order statistic, or the mean of the two middle ones
+    const int64_t lo = (n & 1) ? (n >> 1) : (n >> 1) - 1, hi = n >> 1;
+    uint64_t ka, kb;
+    select2([&](int i) { return keys[i]; }, n, lo, hi, sc, ka, kb);
+    const double med = (n & 1) ? key_f64(ka) : (key_f64(ka) + key_f64(kb)) / 2.0;
+    for (int i = threadIdx.x; i < n; i += NT) {
+        const double dv = fabs(key_f64(keys[i]) - med);             // inf - inf or a NaN median -> NaN
+        if (dv != dv) sc.bad = 1;
     }
     __syncthreads();
-    if (bad) {
+    if (sc.bad) {
         if (threadIdx.x == 0) out[t] = __builtin_nan("");
         return;
     }
-    bitonic_sort(d, n2);
-    const double mdev = median_sorted(d, n);
+    // |x - med| >= 0: its bit pattern is already order preserving
+    select2([&](int i) { return f64_key(fabs(key_f64(keys[i]) - med)); }, n, lo, hi, sc, ka, kb);
+    const double mdev = (n & 1) ? key_f64(ka) : (key_f64(ka) + key_f64(kb)) / 2.0;
     double s = 0.0, cnt = 0.0;
     for (int i = threadIdx.x; i < n; i += NT) {
-        const double x = v[i];
+        const double x = key_f64(keys[i]);
         const double dev = fabs(x - med);
         const bool keep = (mdev != 0.0) ? (dev / mdev < 2.0) : true;   // s = d/mdev if mdev else zeros; data[s < m] (NaN < 2 is false)
         if (keep) { s += x; cnt += 1.0; }
     }
-    s = block_sum(s, red);
-    cnt = block_sum(cnt, red);
+    s = block_sum(s, sc.red);
+    cnt = block_sum(cnt, sc.red);
     if (threadIdx.x == 0) out[t] = s / cnt;
 }
 
@@ -144,12 +196,10 @@ extern "C" int shg_rowpair_logratio_stats(const uint16_t* img, int64_t h, int64_
     }
     const int64_t rows = y2 - y1 - 1;
     if (rows <= 0) return 0;
-    int n2 = 1;
-    while (n2 < w) n2 <<= 1;
-    const size_t lds_bytes = (size_t)2 * n2 * sizeof(double);
+    const size_t lds_bytes = (size_t)w * sizeof(uint64_t);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowpair_stats), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MAXN * 8);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowpair_stats), hipFuncAttributeMaxDynamicSharedMemorySize, MAXN * 8);
         attr_set = true;
     }
     { SHG_PROF("rowpair_stats", st); k_rowpair_stats<<<(unsigned)rows, NT, lds_bytes, st>>>(img, pitch, y1, xa, xb, out); }
