@@ -1,0 +1,145 @@
+"""BASELINE.json's full-size configurations through size-independent properties (the oracle only
+runs where it finishes in seconds).  All on the GPU."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from solex_ser_recon_en_amd import ops, synth
+    return ops, synth
+
+
+def chunked_sum_max(stack, chunk=100):
+    total = torch.zeros(stack.shape[1:], dtype=torch.int64, device=stack.device)
+    mx = torch.zeros(stack.shape[1:], dtype=torch.int32, device=stack.device)
+    for k in range(0, stack.shape[0], chunk):
+        blk = stack[k:k + chunk].to(torch.int32)
+        total += blk.sum(0, dtype=torch.int64)
+        mx = torch.maximum(mx, blk.amax(0))
+    return total.ravel(), mx.ravel()
+
+
+def integer_fit(ih, iw, amplitude=6.0):
+    """A curve with zero fractional part: the bilinear weights are exactly (1, 0), so a disk is a pure gather."""
+    curve = np.floor(iw / 2 + amplitude * np.sin(np.arange(ih) / 97.0))
+    return np.stack([curve, np.zeros(ih), np.arange(ih, dtype=float), curve], axis=1)
+
+
+def gather_reference(stack, curve, shift, rotated):
+    """disk[y, k] = img_k[y, curve[y] + shift] straight from the file layout (torch indexing as an independent reference)."""
+    n, h, w = stack.shape
+    ih, iw = (w, h) if rotated else (h, w)
+    x = torch.as_tensor(np.clip(curve + shift, 0, iw - 2).astype(np.int64), device=stack.device)
+    y = torch.arange(ih, device=stack.device)
+    s32 = stack.view(torch.int16) if stack.dtype == torch.uint16 else stack
+    if rotated:      # img[y, x] = raw[x, W-1-y]
+        out = s32[:, x, w - 1 - y]
+    else:
+        out = s32[:, y, x]
+    return out.t().contiguous()
+
+
+@pytest.mark.parametrize('n,w,h,bits,shifts', [
+    (2000, 2000, 200, 16, [10, 0]),                                   # C2
+    (2000, 2000, 200, 16, [10, 0] + [s for s in range(-10, 11) if s not in (10, 0)]),   # C4: -w -10:10:1 -> 21 disks
+    (1000, 2560, 256, 16, [10, 0]),                                   # C5 frame shape
+    (2000, 200, 2000, 16, [10, 0]),                                   # un-rotated file
+    (200, 120, 800, 8, [10, 0]),                                      # C1 (8-bit, Width < Height)
+    (200, 800, 120, 8, [10, 0]),                                      # C1 shape stored rotated
+])
+def test_frame_passes_at_full_size(env, n, w, h, bits, shifts):
+    ops, synth = env
+    stack = synth.synth_frames_torch(n, w, h, bits, seed=3)
+    rotated = w > h
+    ih, iw = max(w, h), min(w, h)
+    # pass A against an independent chunked torch reduction (exact integers)
+    total, mx = ops.accumulate_sum_max(stack)
+    want_total, want_max = chunked_sum_max(stack)
+    assert torch.equal(total, want_total)
+    assert torch.equal(mx.view(torch.int16).to(torch.int32) & 0xffff, want_max)
+    mean, mxo = ops.finalize_mean_max(total, mx, n, h, w, bits // 8)
+    scale = 256 if bits == 8 else 1
+    want_mean = (want_total * scale // n).reshape(h, w)
+    if rotated:
+        want_mean = torch.rot90(want_mean, 1, dims=(0, 1))
+    assert torch.equal(mean.view(torch.int16).to(torch.int64) & 0xffff, want_mean)
+    # pass B: integer curve => pure gather, for every shift (incl. the clamped ones)
+    fit = integer_fit(ih, iw)
+    from solex_ser_recon_en_amd.solex_util import column_plan
+    ind_l, lw, rw = column_plan(fit, shifts, ih, iw)
+    disks = ops.extract_columns(stack, ind_l, lw, rw)
+    assert disks.shape == (len(shifts), ih, n)
+    for i, s in enumerate(shifts):
+        ref = gather_reference(stack, fit[:, 0], s, rotated)
+        got = disks[i].view(torch.int16)
+        if bits == 8:
+            ref = (ref.to(torch.int32) * 256).to(torch.int16)
+        assert torch.equal(got, ref.view(torch.int16) if ref.dtype != torch.int16 else ref), 'shift %d' % s
+    # shift linearity: the disk of shift s on curve c equals the disk of shift 0 on curve c + s
+    fit2 = fit.copy()
+    fit2[:, 0] += 3
+    fit2[:, 3] += 3
+    ind2, lw2, rw2 = column_plan(fit2, [0], ih, iw)
+    ind3, lw3, rw3 = column_plan(fit, [3], ih, iw)
+    assert torch.equal(ops.extract_columns(stack, ind2, lw2, rw2).view(torch.int16),
+                       ops.extract_columns(stack, ind3, lw3, rw3).view(torch.int16))
+    # half-way weights: disk = trunc((L + R) / 2) exactly
+    fit_h = fit.copy()
+    fit_h[:, 1] = 0.5
+    ind_h, lw_h, rw_h = column_plan(fit_h, [0], ih, iw)
+    half = ops.extract_columns(stack, ind_h, lw_h, rw_h)[0].view(torch.int16).to(torch.int32) & 0xffff
+    left = gather_reference(stack, fit[:, 0], 0, rotated).to(torch.int32) & (0xffff if bits == 16 else 0xff)
+    right = gather_reference(stack, fit[:, 0] + 1, 0, rotated).to(torch.int32) & (0xffff if bits == 16 else 0xff)
+    assert torch.equal(half, ((left + right) * scale) // 2)
+
+
+def test_whole_path_c2_against_the_oracle(env):
+    """BASELINE configs[1] end to end on the GPU vs the CPU oracle (about 15 s of NumPy)."""
+    ops, synth = env
+    from oracle import pipeline_oracle as po
+    from solex_ser_recon_en_amd import SHG_MAIN, Solex_recon
+    from solex_ser_recon_en_amd.video_reader import array_reader
+    stack = synth.synth_frames_torch(2000, 2000, 200, 16, seed=0)
+    opts = SHG_MAIN.default_options()
+    opts['_nolog'] = True
+    disk_list, bounds, hdr = Solex_recon.solex_read(array_reader(stack), opts)
+    (cc, protus), = Solex_recon.solex_process(opts, disk_list, bounds, hdr)
+    with np.errstate(all='ignore'):
+        want = po.run(stack.cpu().numpy(), {})
+    for got, ref in zip(disk_list, want['read']['disks']):
+        np.testing.assert_array_equal(np.asarray(got), ref)                      # raw disks: bit exact
+    np.testing.assert_allclose(opts['ratio_fixe'], want['geometry']['ratio'], rtol=1e-9)
+    for got, ref in ((cc, want['results'][0]['cc']), (protus, want['results'][0]['protus'])):
+        d = np.abs(np.asarray(got).astype(np.int64) - ref.astype(np.int64))
+        assert d.max() <= 1 and np.count_nonzero(d) <= 8, (d.max(), np.count_nonzero(d))
+
+
+def test_multishift_c4_post_processing(env):
+    """-w -10:10:1: 21 requested disks through warp / transversalium / CLAHE; each product is internally
+    consistent (shape, geometry state reused) and the shift-0 product equals the single-shift run."""
+    ops, synth = env
+    from solex_ser_recon_en_amd import SHG_MAIN, Solex_recon
+    from solex_ser_recon_en_amd.video_reader import array_reader
+    stack = synth.synth_frames_torch(600, 1200, 120, 16, seed=1)
+
+    def run(shifts):
+        opts = SHG_MAIN.default_options()
+        opts.update(_nolog=True, shift=list(shifts))
+        disk_list, bounds, hdr = Solex_recon.solex_read(array_reader(stack), opts)
+        return opts, Solex_recon.solex_process(opts, disk_list, bounds, hdr)
+    o21, r21 = run(range(-10, 11))
+    o1, r1 = run([0])
+    assert o21['shift'] == [10, 0] + [s for s in range(-10, 11) if s not in (10, 0)]
+    assert len(r21) == 21 and len(r1) == 1
+    assert o21['ratio_fixe'] == o1['ratio_fixe'] and o21['slant_fix'] == o1['slant_fix']
+    shapes = {np.asarray(cc).shape for cc, _ in r21}
+    assert len(shapes) == 1
+    idx0 = [s for s in o21['shift'] if s in o21['shift_requested']].index(0)
+    np.testing.assert_array_equal(np.asarray(r21[idx0][0]), np.asarray(r1[0][0]))
+    np.testing.assert_array_equal(np.asarray(r21[idx0][1]), np.asarray(r1[0][1]))
