@@ -14,10 +14,12 @@ One "step" = one pass of the hot path over one synthetic scan:
   the timed region (inputs are resident in HBM; the PNG/FITS encoders are off the path).
 
 N = 1: BASELINE.json configs[1] -- 2000 frames of 2000x200 16-bit, single H-alpha shift,
-transversalium + ellipse fit on.  N > 1 (default --mode sharded): ONE scan of N x 2000 frames
-whose frames are sharded over the ranks (weak scaling, configs[2]'s layout): RCCL all-reduce of
-the integer sum/max frames, all-gather of the disk columns, mosaic post-processed on rank 0.
---mode folder: one 2000-frame scan per rank, no collective (configs[4]'s layout).
+transversalium + ellipse fit on.  N > 1, default --mode folder (configs[4]'s layout, the reference's own
+batch parallelism: SHG_MAIN.handle_folder + Pool over files): one such scan per rank, the files are
+independent, so there is no data-path collective (weak scaling).  --mode sharded (configs[2]'s layout):
+ONE scan of N x 2000 frames whose frames are sharded over the ranks -- RCCL all-reduce of the integer
+sum/max frames, all-gather of the disk columns, mosaic post-processed on rank 0; its serial per-file tail
+(limb fit, one requested disk) does not shard, see DESIGN.md section 6.
 """
 import argparse
 import contextlib
@@ -43,7 +45,7 @@ def parse():
     ap.add_argument('--width', type=int, default=2000)
     ap.add_argument('--height', type=int, default=200)
     ap.add_argument('--bits', type=int, default=16)
-    ap.add_argument('--mode', choices=['sharded', 'folder'], default='sharded')
+    ap.add_argument('--mode', choices=['folder', 'sharded'], default='folder')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=0, help='frames of the CPU-baseline sample (0 = the whole scan)')
     ap.add_argument('--stages', action='store_true', help='print a per-stage wall-clock table to stderr')

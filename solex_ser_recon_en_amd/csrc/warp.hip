@@ -30,7 +30,12 @@ __global__ __launch_bounds__(256) void k_minmax(const uint16_t* __restrict__ src
         lo = ol < lo ? ol : lo;
         hi = oh > hi ? oh : hi;
     }
-    if ((threadIdx.x & 63) == 0) {
+    // one atomic pair per workgroup: same-address atomics serialise chip-wide
+    __shared__ uint32_t wlo[4], whi[4];
+    if ((threadIdx.x & 63) == 0) { wlo[threadIdx.x >> 6] = lo; whi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) { lo = wlo[i] < lo ? wlo[i] : lo; hi = whi[i] > hi ? whi[i] : hi; }
         atomicMin(&mm[0], lo);
         atomicMax(&mm[1], hi);
     }
@@ -73,7 +78,7 @@ extern "C" int shg_warp_rows_u16(const uint16_t* src, int64_t h, int64_t w, int6
     SHG_REQUIRE(out_h < 65536, SHG_E_UNSUPPORTED, "shg_warp_rows_u16: more than 65535 rows");
     hipStream_t st = shg::as_stream(stream);
     { SHG_PROF("minmax", st); k_minmax_init<<<1, 1, 0, st>>>(minmax); }
-    int64_t blocks = h < 1024 ? h : 1024;
+    int64_t blocks = h < 256 ? h : 256;
     { SHG_PROF("minmax", st); k_minmax<<<(unsigned)blocks, 256, 0, st>>>(src, h, w, src_pitch, minmax); }
     if (int e = shg::check_launch("k_minmax")) return e;
     dim3 grid((unsigned)((out_w + 255) / 256), (unsigned)out_h);

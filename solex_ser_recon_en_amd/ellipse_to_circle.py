@@ -38,7 +38,8 @@ def correct_image(image, phi, ratio, center, height, options, print_log=False):
     mat3[:2, :2] = mat
     mat3[2, 2] = 1
     corners = np.array([[0, 0], [0, h], [w, 0], [w, h]])
-    new_corners = (np.linalg.inv(mat) @ corners.T).T
+    inv_mat = np.linalg.inv(mat)              # the reference re-inverts at each use; same input, same result
+    new_corners = (inv_mat @ corners.T).T
     new_h = np.max(new_corners[:, 1]) - np.min(new_corners[:, 1])
     new_w = np.max(new_corners[:, 0]) - np.min(new_corners[:, 0])
     mat3 = mat3 @ np.array([[1, 0, np.min(new_corners[:, 0])], [0, 1, np.min(new_corners[:, 1])], [0, 0, 1]])
@@ -47,9 +48,9 @@ def correct_image(image, phi, ratio, center, height, options, print_log=False):
         raise RuntimeError('correct_image: the correction never moves rows (ellipse_to_circle.py:48-49); got\n%s' % mat3)
     fixed = ops.warp_rows_u16(src, mat3[0, 0], mat3[0, 1], mat3[0, 2], int(np.ceil(new_h)), int(np.ceil(new_w)))
     center = np.asarray(center)
-    new_center = (np.linalg.inv(mat) @ center.T).T - np.array([np.min(new_corners[:, 0]), np.min(new_corners[:, 1])])
+    new_center = (inv_mat @ center.T).T - np.array([np.min(new_corners[:, 0]), np.min(new_corners[:, 1])])
     new_radius = height * np.sqrt(np.abs(ratio / np.linalg.det(mat)))
-    if print_log:
+    if print_log and '_nolog' not in options:
         basefich0 = options['basefich0']
         print('unrotation angle theta = ' + "{:.3f}".format(math.degrees(theta)) + " degrees")
         np.set_printoptions(suppress=True)

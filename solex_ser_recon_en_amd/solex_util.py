@@ -49,9 +49,10 @@ def write_complete(path, options):
 
 
 def logme(path, options, s):
+    """s may be a callable building the line: formatting arrays costs more than the kernels it reports on."""
     if '_nolog' in options:
         return
-    _append(path, options, s + '\n', 'a')
+    _append(path, options, (s() if callable(s) else s) + '\n', 'a')
 
 
 def _plots_enabled(options):
@@ -120,7 +121,7 @@ def compute_mean_return_fit(vid_rdr, options, hdr, iw, ih, basefich0):
     shift = values[ind[0]]
     mask_good = np.abs(delta_sharp - shift) < 5
     p = np.flip(np.asarray(np.polyfit(rows[mask_good], min_intensity_sharp[y1:y2][mask_good], 3), dtype='d'))
-    logme(basefich0 + '_log.txt', options, 'Spectral line polynomial fit: ' + str(p))
+    logme(basefich0 + '_log.txt', options, lambda: 'Spectral line polynomial fit: ' + str(p))
 
     curve = polyval(np.asarray(np.arange(ih), dtype='d'), p)
     floor = np.floor(curve)
