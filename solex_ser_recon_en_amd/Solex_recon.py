@@ -19,6 +19,7 @@ What changed underneath:
 """
 import math
 import os
+import threading
 
 import numpy as np
 import torch
@@ -32,17 +33,54 @@ from .solex_util import (clearlog, compute_mean_return_fit, correct_transversali
 from .video_reader import video_reader
 
 
+class _Prefetch:
+    """Decode file k+1 into HBM (reader threads + copy streams) while file k is being processed:
+    the overlap the reference gets from reading in the parent while Pool workers post-process
+    (Solex_recon.py:30-42)."""
+
+    def __init__(self, file, frame_range=None):
+        self.file, self.frame_range = file, frame_range
+        self.rdr, self.err = None, None
+        self.thread = threading.Thread(target=self._run, name='shg-prefetch')
+        self.thread.start()
+
+    def _run(self):
+        try:
+            rdr = video_reader(self.file)
+            if self.frame_range is not None:
+                rdr.frame_range = self.frame_range(int(rdr.FrameCount))
+            rdr.device_stack()
+            self.rdr = rdr
+        except BaseException as e:      # noqa: BLE001 -- re-raised when this file's turn comes
+            self.err = e
+
+    def get(self):
+        self.thread.join()
+        if self.err is not None:
+            raise self.err
+        return self.rdr
+
+
 def solex_do_work(tasks, flag_command_line=False):
     """tasks: list of (file, options).  Raises on failure (the front door catches, SHG_MAIN.py:136-143)."""
     tasks = list(tasks)
     shard_frames = dist.active() and len(tasks) == 1
+    if dist.active() and not shard_frames:
+        tasks = tasks[dist.rank()::dist.world_size()]       # folder mode: file i belongs to rank i mod G
+    block = dist.frame_block if shard_frames else None
+
+    def start(i):
+        file = tasks[i][0]
+        return file if hasattr(file, 'device_stack') else _Prefetch(file, block)
     try:
+        nxt = start(0) if tasks else None
         for i, (file, options) in enumerate(tasks):
-            if dist.active() and not shard_frames and i % dist.world_size() != dist.rank():
-                continue                                    # folder mode: file i belongs to rank i mod G
+            cur, nxt = nxt, (start(i + 1) if i + 1 < len(tasks) else None)
             print('file %s is processing' % file)
             options['_shard_frames'] = shard_frames
-            disk_list, backup_bounds, hdr = solex_read(file, options)
+            rdr = cur.get() if isinstance(cur, _Prefetch) else cur
+            disk_list, backup_bounds, hdr = solex_read(rdr, options)
+            rdr._stack = None                               # release the frame stack before the next file's lands
             if shard_frames and dist.rank() != 0:
                 continue                                    # the mosaic is post-processed and written once
             solex_process(options, disk_list, backup_bounds, hdr)
@@ -67,7 +105,7 @@ def solex_read(file, options):
     options['shift_requested'] = options['shift']
     # ellipse_fit_shift and 0 are "fake" shifts; if requested they are not double counted (:55)
     options['shift'] = list(dict.fromkeys([options['ellipse_fit_shift'], 0] + options['shift']))
-    if options.get('_shard_frames'):
+    if options.get('_shard_frames') and getattr(rdr, '_stack', None) is None:
         rdr.frame_range = dist.frame_block(int(rdr.FrameCount))
     hdr = make_header(rdr)
     ih, iw = rdr.ih, rdr.iw

@@ -138,3 +138,28 @@ def test_apply_clahe_tool(pkg, tmp_path):
     np.testing.assert_array_equal(clahe_apply.apply_clahe(path, o, write_file=False), want)
     img8 = (img >> 8).astype(np.uint8)
     np.testing.assert_array_equal(clahe_apply.apply_clahe(img8, dict(clahe_apply.options), write_file=False), orc.clahe(img8, 0.8, 2))
+
+
+def test_folder_of_files_with_prefetch(pkg, scan, tmp_path):
+    """Several files through solex_do_work: file k+1 is decoded into HBM while file k is processed;
+    every file gets the same products as when processed alone."""
+    SHG_MAIN, Solex_recon, outputs = pkg
+    g, frames, path = scan
+    from solex_ser_recon_en_amd import png_io
+    files = []
+    for i in range(3):
+        f = str(tmp_path / ('scan%d.ser' % i))
+        synth.write_ser(f, frames if i != 1 else frames[::-1].copy())          # file 1: the scan reversed
+        files.append(f)
+    opts = SHG_MAIN.default_options()
+    opts['clahe_only'] = True
+    Solex_recon.solex_do_work(SHG_MAIN.precheck_files(files, opts), True)
+    a = png_io.read_png_gray(files[0][:-4] + '_shift=0_clahe.png')
+    b = png_io.read_png_gray(files[1][:-4] + '_shift=0_clahe.png')
+    c = png_io.read_png_gray(files[2][:-4] + '_shift=0_clahe.png')
+    close_u16(a, g['A_s0_clahe'])
+    np.testing.assert_array_equal(a, c)
+    assert a.shape[0] == b.shape[0] and not np.array_equal(a, b)
+    # a missing file in the middle stops the batch when its turn comes (README: "will halt if a file is unsuitable")
+    with pytest.raises(Exception):
+        Solex_recon.solex_do_work([(files[0], SHG_MAIN.default_options()), (str(tmp_path / 'nope.ser'), SHG_MAIN.default_options())], True)
