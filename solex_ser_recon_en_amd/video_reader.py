@@ -21,19 +21,24 @@ from .device import default_device
 
 SER_HEADER_BYTES = 178
 
-_pinned = {}
+_pinned_free = []
 _pinned_lock = threading.Lock()
 
 
-def _pinned_pair(tid, nbytes):
-    """Two pinned staging buffers per reader thread, kept for the life of the process
-    (pinning 64 MB costs more than copying it)."""
+def _lease_pinned_pair(nbytes):
+    """Two pinned staging buffers for one reader thread, leased from a process-wide pool and
+    returned afterwards (pinning 64 MB costs more than copying it; concurrent decodes must
+    not share a buffer)."""
     with _pinned_lock:
-        pair = _pinned.get(tid)
-        if pair is None or pair[0].numel() < nbytes:
-            pair = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
-            _pinned[tid] = pair
-        return pair
+        for i, pair in enumerate(_pinned_free):
+            if pair[0].numel() >= nbytes:
+                return _pinned_free.pop(i)
+    return [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
+
+
+def _return_pinned_pair(pair):
+    with _pinned_lock:
+        _pinned_free.append(pair)
 
 
 class video_reader:
@@ -129,7 +134,7 @@ class video_reader:
         def work(tid):
             try:
                 torch.cuda.set_device(device)
-                bufs = _pinned_pair(tid, chunk_bytes)
+                bufs = _lease_pinned_pair(chunk_bytes)
                 events = [None, None]
                 fd = os.open(self.file, os.O_RDONLY)
                 try:
@@ -161,6 +166,10 @@ class video_reader:
                             ev.synchronize()
                 finally:
                     os.close(fd)
+                    for ev in events:
+                        if ev is not None:
+                            ev.synchronize()
+                    _return_pinned_pair(bufs)
             except BaseException as e:      # noqa: BLE001 -- re-raised on the caller's thread
                 errors.append(e)
 
