@@ -191,6 +191,16 @@ int shg_canny_masks_f64(const double* blurred, int64_t h, int64_t w, double floo
                         uint8_t* low_mask, uint8_t* high_mask, void* workspace, size_t workspace_bytes,
                         shg_stream_t stream);
 
+/* canny's hysteresis and the labelling of its result (ellipse_to_circle.py:245-252): the pixels of
+ * the 8-connected components of low_mask that contain a high_mask pixel, in raster order:
+ * out_idx[i] = y*w + x, out_root[i] = smallest linear index of the pixel's component (sorting the
+ * distinct roots gives scipy.ndimage.label's numbering), out_count[0] = number of pixels.
+ * out_idx / out_root: h*w int32 each. */
+size_t shg_edge_components_workspace_bytes(int64_t h, int64_t w);
+int shg_edge_components(const uint8_t* low_mask, const uint8_t* high_mask, int64_t h, int64_t w,
+                        int32_t* out_idx, int32_t* out_root, int32_t* out_count,
+                        void* workspace, size_t workspace_bytes, shg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

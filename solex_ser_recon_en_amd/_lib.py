@@ -54,6 +54,8 @@ SIGNATURES = {
     'shg_select_workspace_bytes': (c_size_t, [c_int]),
     'shg_select_f64': (c_int, [P, c_int64, ctypes.POINTER(c_int64), c_int, P, P, c_size_t, P]),
     'shg_flood_stats_f64': (c_int, [P, P, c_int64, c_double, P, P, P, P]),
+    'shg_edge_components_workspace_bytes': (c_size_t, [c_int64, c_int64]),
+    'shg_edge_components': (c_int, [P, P, c_int64, c_int64, P, P, P, P, c_size_t, P]),
     'shg_canny_workspace_bytes': (c_size_t, [c_int64, c_int64]),
     'shg_canny_masks_f64': (c_int, [P, c_int64, c_int64, c_double, ctypes.POINTER(c_double), c_int, c_double, c_double, P, P, P,
                                     c_size_t, P]),

@@ -289,6 +289,128 @@ __global__ __launch_bounds__(256) void k_flood_hist(const double* __restrict__ b
     }
 }
 
+// ---- canny's hysteresis + the labelling of its result (ellipse_to_circle.py:245-252) ------------------------
+// 8-connected components of low_mask by union-find on the pixel grid (each pixel links to its W, NW, N, NE
+// neighbours; roots are the smallest linear index of a component, so sorting roots = scipy.ndimage.label's
+// raster numbering).  Components holding a high_mask pixel survive (skimage's hysteresis); their pixels
+// are emitted in raster order with their root.
+__device__ __forceinline__ int ccl_find(const int* L, int x) {
+    // agent-scope relaxed loads: parents are rewritten by other workgroups (other XCDs) during the merge,
+    // and a CU's L1 / an XCD's L2 is not refreshed by them.  A stale parent would still be a valid older
+    // ancestor (parents only ever decrease, and every link is validated by the atomicMin), but fresh reads
+    // keep the chains short.
+    int p = __hip_atomic_load(&L[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != x) { x = p; p = __hip_atomic_load(&L[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    return x;
+}
+
+__device__ __forceinline__ void ccl_union(int* L, int a, int b) {
+    while (true) {
+        a = ccl_find(L, a);
+        b = ccl_find(L, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }      // link the larger root under the smaller
+        const int old = atomicMin(&L[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ccl_init(const uint8_t* __restrict__ low, int n, int* __restrict__ L, int* __restrict__ flag) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    L[i] = low[i] ? i : -1;
+    flag[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_ccl_merge(const uint8_t* __restrict__ low, int h, int w, int* __restrict__ L) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= h * w || !low[i]) return;
+    const int y = i / w, x = i - y * w;
+    if (x > 0 && low[i - 1]) ccl_union(L, i, i - 1);
+    if (y > 0) {
+        const int up = i - w;
+        if (x > 0 && low[up - 1]) ccl_union(L, i, up - 1);
+        if (low[up]) ccl_union(L, i, up);
+        if (x < w - 1 && low[up + 1]) ccl_union(L, i, up + 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ccl_flatten(const uint8_t* __restrict__ low, const uint8_t* __restrict__ high, int n,
+                                                     int* __restrict__ L, int* __restrict__ flag) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !low[i]) return;
+    const int r = ccl_find(L, i);
+    L[i] = r;            // benign race: every writer stores a value on the path to the same root
+    if (high[i]) flag[r] = 1;
+}
+
+// grid = h rows, 256 threads.  counts[y] = kept pixels of the row (pass 0) or emit them at offsets[y] (pass 1)
+__global__ __launch_bounds__(256) void k_ccl_emit(const int* __restrict__ L, const int* __restrict__ flag, int w, int pass,
+                                                  int* __restrict__ counts, const int* __restrict__ offsets,
+                                                  int* __restrict__ out_idx, int* __restrict__ out_root) {
+    __shared__ int wave_cnt[4];
+    __shared__ int base;
+    const int y = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base = pass ? offsets[y] : 0;
+    __syncthreads();
+    for (int x0 = 0; x0 < w; x0 += 256) {
+        const int x = x0 + threadIdx.x;
+        int root = -1;
+        if (x < w) {
+            const int l = L[y * w + x];
+            if (l >= 0) {
+                const int r = L[l] == l ? l : ccl_find(L, l);
+                if (flag[r]) root = r;
+            }
+        }
+        const unsigned long long m = __ballot(root >= 0);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int i = 0; i < wave; ++i) off += wave_cnt[i];
+        if (pass && root >= 0) {
+            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            out_idx[pos] = y * w + x;
+            out_root[pos] = root;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    if (!pass && threadIdx.x == 0) counts[y] = base;
+}
+
+// exclusive scan of the h row counts by one workgroup; total -> out_count[0]
+__global__ __launch_bounds__(256) void k_ccl_scan(const int* __restrict__ counts, int h, int* __restrict__ offsets,
+                                                  int* __restrict__ out_count) {
+    __shared__ int wave_tot[4];
+    __shared__ int carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int y0 = 0; y0 < h; y0 += 256) {
+        const int y = y0 + threadIdx.x;
+        const int c = y < h ? counts[y] : 0;
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int off = carry;
+        for (int i = 0; i < wave; ++i) off += wave_tot[i];
+        if (y < h) offsets[y] = off + incl - c;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out_count[0] = carry;
+}
+
 }  // namespace
 
 extern "C" int shg_box_blur_f64(const double* src, int64_t h, int64_t w, int k, double* dst, double* tmp, shg_stream_t stream) {
@@ -380,4 +502,32 @@ extern "C" int shg_flood_stats_f64(const double* image, const double* blurred, i
     if (int err = shg::check_launch("k_flood_minmax")) return err;
     k_flood_hist<<<(unsigned)blocks, 256, 0, st>>>(blurred, n, very_bright, acc, stats, counts);
     return shg::check_launch("k_flood_hist");
+}
+
+extern "C" size_t shg_edge_components_workspace_bytes(int64_t h, int64_t w) {
+    if (h <= 0 || w <= 0) return 0;
+    return ((size_t)2 * h * w + 2 * (size_t)h) * sizeof(int32_t);
+}
+
+extern "C" int shg_edge_components(const uint8_t* low_mask, const uint8_t* high_mask, int64_t h, int64_t w, int32_t* out_idx,
+                                   int32_t* out_root, int32_t* out_count, void* workspace, size_t workspace_bytes,
+                                   shg_stream_t stream) {
+    SHG_REQUIRE(low_mask && high_mask && out_idx && out_root && out_count && workspace, SHG_E_ARG, "shg_edge_components: null pointer");
+    SHG_REQUIRE(h > 0 && w > 0 && h * w < (1ll << 30), SHG_E_ARG, "shg_edge_components: bad image size");
+    SHG_REQUIRE(workspace_bytes >= shg_edge_components_workspace_bytes(h, w), SHG_E_WORKSPACE, "shg_edge_components: workspace too small");
+    hipStream_t st = shg::as_stream(stream);
+    const int n = (int)(h * w);
+    int* L = static_cast<int*>(workspace);
+    int* flag = L + n;
+    int* counts = flag + n;
+    int* offsets = counts + h;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    SHG_PROF("edge_components", st);
+    k_ccl_init<<<blocks, 256, 0, st>>>(low_mask, n, L, flag);
+    k_ccl_merge<<<blocks, 256, 0, st>>>(low_mask, (int)h, (int)w, L);
+    k_ccl_flatten<<<blocks, 256, 0, st>>>(low_mask, high_mask, n, L, flag);
+    k_ccl_emit<<<(unsigned)h, 256, 0, st>>>(L, flag, (int)w, 0, counts, offsets, out_idx, out_root);
+    k_ccl_scan<<<1, 256, 0, st>>>(counts, (int)h, offsets, out_count);
+    k_ccl_emit<<<(unsigned)h, 256, 0, st>>>(L, flag, (int)w, 1, counts, offsets, out_idx, out_root);
+    return shg::check_launch("k_ccl");
 }

@@ -22,7 +22,6 @@ import math
 import numpy as np
 import torch
 from numpy import polynomial
-from scipy import ndimage as ndi
 from scipy.spatial import ConvexHull
 
 from . import ops
@@ -84,25 +83,11 @@ def flood_threshold(total, shape, mn, mx, counts):
     return bins[i]
 
 
-def hysteresis(low_mask, high_mask):
-    """canny's last step: keep the 8-connected components of low_mask that contain a high_mask pixel."""
-    if np.array_equal(low_mask, high_mask):
-        return low_mask
-    labels, count = ndi.label(low_mask, np.ones((3, 3), bool))
-    if count == 0:
-        return low_mask
-    good = np.zeros(count + 1, dtype=bool)
-    good[np.unique(labels[high_mask])] = True
-    good[0] = False
-    return good[labels]
-
-
 # ---- get_edge_list after canny (ellipse_to_circle.py:251-291) ---------------------------------
-def limb_points(edges, labelled, nf):
-    """The reference builds full-size masks per region; the same selections on the list of edge
-    points (np.argwhere order is kept, so the result equals np.argwhere(filt) of the reference)."""
-    pts = np.argwhere(edges)                          # row-major order, as every np.argwhere of a sub-mask
-    lab = labelled[pts[:, 0], pts[:, 1]]
+def limb_points(pts, lab, nf, n_rows):
+    """pts: int [m, 2] edge pixels (row, col) in raster order; lab: their component labels 1..nf
+    (scipy.ndimage.label numbering).  The reference builds full-size masks per region; these are the
+    same selections on the point list (raster order is what np.argwhere of any sub-mask returns)."""
     sizes = np.bincount(lab, minlength=nf + 1)
     sizes[0] = -1
     size_list = sizes.tolist()
@@ -115,11 +100,17 @@ def limb_points(edges, labelled, nf):
     x_min, x_max = np.min(X[:, 0]), np.max(X[:, 0])
     dx = x_max - x_min
     crop = 0.017
-    r0, r1 = int(x_min + dx * crop), int(x_max - dx * crop)
-    rows = np.zeros(edges.shape[0], dtype=bool)
-    rows[r0:r1] = True                                # slice semantics of mask[int(..):int(..), :] = 1
+    rows = np.zeros(n_rows, dtype=bool)
+    rows[int(x_min + dx * crop):int(x_max - dx * crop)] = True     # slice semantics of mask[int(..):int(..), :] = 1
     sel = np.isin(lab, keep) & rows[pts[:, 0]]
     return np.array(pts[sel], dtype='float'), pts
+
+
+def labels_from_roots(root):
+    """Component roots (smallest linear index of each component) -> scipy.ndimage.label numbering:
+    label k is the k-th component met in raster order, i.e. the k-th smallest root."""
+    uniq, inverse = np.unique(root, return_inverse=True)
+    return inverse.astype(np.int64) + 1, len(uniq)
 
 
 def edge_points(small, sigma=2):
@@ -143,13 +134,14 @@ def edge_points(small, sigma=2):
     while True:
         if sigma <= 0:
             raise RuntimeError('ellipse fit: could not find any edges of the solar disk')
-        masks = torch.stack(ops.canny_masks(blurred, thresh3, sigma, low, high)).cpu().numpy().astype(bool)
-        edges = hysteresis(masks[0], masks[1])
-        labelled, nf = ndi.label(edges, np.ones((3, 3), int))
-        if nf:
+        low_mask, high_mask = ops.canny_masks(blurred, thresh3, sigma, low, high)
+        idx, root = ops.edge_components(low_mask, high_mask)          # hysteresis + labelling, on the GPU
+        if idx.size:
             break
         sigma -= 0.5                                   # try again with less blur (:254-256)
-    return limb_points(edges, labelled, nf)
+    pts = np.stack([idx // w, idx % w], axis=1).astype(np.int64)
+    lab, nf = labels_from_roots(root)
+    return limb_points(pts, lab, nf, h)
 
 
 # ---- LsqEllipse (Halir & Flusser) -----------------------------------------------------------

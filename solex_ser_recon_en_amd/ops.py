@@ -309,3 +309,25 @@ def flood_stats(image, blurred, very_bright):
                                        float(very_bright), stats.data_ptr(), counts.data_ptr(), ws.data_ptr(), _stream()),
                'shg_flood_stats_f64')
     return stats, counts
+
+
+def edge_components(low_mask, high_mask, prefetch=16384):
+    """Hysteresis + labelling on the GPU.  -> (idx int32 [m], root int32 [m]) HOST arrays: the surviving edge
+    pixels in raster order (idx = y*w + x) and the root (smallest linear index) of each pixel's component."""
+    _dev(low_mask, 'low_mask')
+    if low_mask.dtype != torch.uint8 or high_mask.dtype != torch.uint8 or low_mask.shape != high_mask.shape:
+        raise TypeError('edge_components needs two uint8 masks of one shape')
+    h, w = low_mask.shape
+    n = h * w
+    need = lib.shg_edge_components_workspace_bytes(h, w)
+    ws = torch.empty(need, dtype=torch.uint8, device=low_mask.device)
+    out = torch.empty(2 * n + 1, dtype=torch.int32, device=low_mask.device)      # [count | idx[n] | root[n]]
+    _lib.check(lib.shg_edge_components(low_mask.contiguous().data_ptr(), high_mask.contiguous().data_ptr(), h, w,
+                                       out[1:].data_ptr(), out[1 + n:].data_ptr(), out.data_ptr(), ws.data_ptr(), need,
+                                       _stream()), 'shg_edge_components')
+    k = min(prefetch, n)
+    head = torch.cat([out[:1 + k], out[1 + n:1 + n + k]]).cpu().numpy()          # one read covers the usual ~1500 points
+    m = int(head[0])
+    if m <= k:
+        return head[1:1 + m], head[1 + k:1 + k + m]
+    return out[1:1 + m].cpu().numpy(), out[1 + n:1 + n + m].cpu().numpy()

@@ -14,6 +14,20 @@ from solex_ser_recon_en_amd.ellipse_to_circle import get_correction_matrix
 from solex_ser_recon_en_amd.solex_util import column_plan, max_from_hist, percentile_from_hist
 
 
+def points_via_scipy_label(edges):
+    """limb_fit.limb_points fed the way the GPU labelling feeds it: raster-ordered points + component roots."""
+    from scipy import ndimage as ndi
+    labelled, nf = ndi.label(edges, np.ones((3, 3), int))
+    pts = np.argwhere(edges)
+    lab_img = labelled[pts[:, 0], pts[:, 1]]
+    lin = pts[:, 0] * edges.shape[1] + pts[:, 1]
+    first = np.full(nf + 1, np.iinfo(np.int64).max)
+    np.minimum.at(first, lab_img, lin)                       # root = smallest linear index of the component
+    lab, n = limb_fit.labels_from_roots(first[lab_img])
+    assert n == nf and np.array_equal(lab, lab_img)          # root order == scipy's raster numbering
+    return limb_fit.limb_points(pts, lab, nf, edges.shape[0])
+
+
 def flood_threshold_numpy(small, blurred):
     """Feed limb_fit.flood_threshold with the statistics the GPU would reduce, computed with NumPy."""
     n = small.size
@@ -49,14 +63,7 @@ def test_limb_control_plane_matches_oracle(golden):
     thresh3 = flood_threshold_numpy(small, blurred)
     np.testing.assert_array_equal(np.where(blurred < thresh3, 0.0, 65000.0), g['flooded'])
     edges = g['canny0']
-    np.testing.assert_array_equal(limb_fit.hysteresis(edges, edges), edges)
-    # hysteresis: a component of the low mask survives only if it holds a high pixel
-    low = np.zeros((9, 12), bool); low[1, 1:5] = True; low[5, 2:9] = True; low[7, 10] = True
-    high = np.zeros_like(low); high[5, 4] = True
-    want = np.zeros_like(low); want[5, 2:9] = True
-    np.testing.assert_array_equal(limb_fit.hysteresis(low, high), want)
-    labelled, nf = ndi.label(edges, np.ones((3, 3), int))
-    X, raw = limb_fit.limb_points(edges, labelled, nf)
+    X, raw = points_via_scipy_label(edges)
     np.testing.assert_array_equal(raw, np.argwhere(edges))
     Xo, rawo = limb.get_edge_list(small.copy())
     np.testing.assert_array_equal(X, Xo)
@@ -90,8 +97,7 @@ def test_limb_region_selection_cases():
     d[10, 10:30] = True; d[11:15, 10] = True; d[40, 10:34] = True; d[70, 10:34] = True; d[80, 50:60] = True
     cases.append(d)
     for edges in cases:
-        labelled, nf = ndi.label(edges, np.ones((3, 3), int))
-        X, raw = limb_fit.limb_points(edges, labelled, nf)
+        X, raw = points_via_scipy_label(edges)
         Xo, rawo = limb.points_from_edges(edges)
         np.testing.assert_array_equal(X, Xo)
         np.testing.assert_array_equal(raw, rawo)

@@ -233,6 +233,41 @@ def test_box_blur_f64_matches_oracle(ops, orc, h, w, k):
     np.testing.assert_array_equal(host(ops.box_blur_f64(dev(img), k)), orc.box_blur_f64(img, k, k))
 
 
+def host_hysteresis(low_mask, high_mask):
+    """skimage canny's last step with scipy.ndimage.label (reference for the GPU labelling)."""
+    from scipy import ndimage as ndi
+    labels, count = ndi.label(low_mask, np.ones((3, 3), bool))
+    good = np.zeros(count + 1, dtype=bool)
+    good[np.unique(labels[high_mask])] = True
+    good[0] = False
+    return good[labels]
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_edge_components_match_scipy_label(ops, seed):
+    """Random blobs, spirals and long thin chains: components, hysteresis and raster numbering vs scipy."""
+    from scipy import ndimage as ndi
+    from solex_ser_recon_en_amd import limb_fit
+    rng = np.random.default_rng(seed)
+    h, w = [(97, 131), (256, 256), (500, 500), (33, 700)][seed]
+    low = rng.random((h, w)) < [0.3, 0.45, 0.05, 0.5][seed]
+    t = np.linspace(0, 12 * np.pi, 20000)
+    yy = np.clip((h / 2 + (h / 2.2) * t / t.max() * np.sin(t)).astype(int), 0, h - 1)
+    xx = np.clip((w / 2 + (w / 2.2) * t / t.max() * np.cos(t)).astype(int), 0, w - 1)
+    low[yy, xx] = True                                       # a long spiral: deep union-find chains
+    high = low & (rng.random((h, w)) < 0.02)
+    idx, root = ops.edge_components(dev(low.astype(np.uint8)), dev(high.astype(np.uint8)), prefetch=1000)
+    want = host_hysteresis(low, high)
+    np.testing.assert_array_equal(idx, np.flatnonzero(want))
+    labelled, nf = ndi.label(want, np.ones((3, 3), int))
+    lab, n = limb_fit.labels_from_roots(root)
+    assert n == nf
+    np.testing.assert_array_equal(lab, labelled.ravel()[idx])
+    # nothing survives without a high pixel
+    idx0, _ = ops.edge_components(dev(low.astype(np.uint8)), dev(np.zeros((h, w), np.uint8)))
+    assert idx0.size == 0
+
+
 def test_canny_masks_match_skimage_0_18_3(ops, orc, golden):
     """GPU canny (Gaussian, Sobel, hypot, NMS, thresholds) + host hysteresis == the real scikit-image output."""
     from solex_ser_recon_en_amd import limb_fit
@@ -245,8 +280,10 @@ def test_canny_masks_match_skimage_0_18_3(ops, orc, golden):
     for i in range(3):
         sigma, lo, hi = g['canny%d_params' % i]
         low_m, high_m = ops.canny_masks(dev(blurred), thresh3, sigma, lo, hi)
-        edges = limb_fit.hysteresis(host(low_m).astype(bool), host(high_m).astype(bool))
+        edges = host_hysteresis(host(low_m).astype(bool), host(high_m).astype(bool))
         np.testing.assert_array_equal(edges, g['canny%d' % i])
+        idx, root = ops.edge_components(low_m, high_m)                 # the same on the GPU
+        np.testing.assert_array_equal(idx, np.flatnonzero(edges))
     # a noisy gray-level image (no flooding): thresholds that bite, real hysteresis
     noisy = g['noisy']
     low_m, high_m = ops.canny_masks(dev(noisy * 65000.0 + 1.0), 0.5, 1.0, 0.05 * 65000, 0.12 * 65000)

@@ -27,3 +27,33 @@ try:
     assert torch.equal(dev.view(torch.int16), stack.view(torch.int16))
 finally:
     os.remove(path)
+
+# ---- PCIe-inclusive throughput of a folder of files on one GPU (decode of file k+1 overlaps file k) ----
+import contextlib
+import io
+
+from solex_ser_recon_en_amd import SHG_MAIN, Solex_recon  # noqa: E402
+
+files = []
+for i in range(5):
+    f = path.replace('.ser', '_%d.ser' % i)
+    synth.write_ser(f, stack.cpu().numpy())
+    files.append(f)
+try:
+    for rep in range(2):
+        tasks = []
+        for f in files:
+            o = SHG_MAIN.default_options()
+            o['_nolog'] = True
+            tasks.append((f, o))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            Solex_recon.solex_do_work(tasks, True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print('solex_do_work on %d files from %s: %.1f ms per file -> %.0f frames/s PCIe-inclusive' % (
+            len(files), os.path.dirname(path), dt / len(files) * 1e3, n * len(files) / dt))
+finally:
+    for f in files:
+        os.remove(f)
