@@ -8,7 +8,7 @@ exactly like an exception inside the reference's pool worker does
 """
 import ctypes
 import os
-from ctypes import c_double, c_int, c_int32, c_int64, c_size_t, c_uint16, c_void_p
+from ctypes import c_double, c_int, c_int64, c_size_t, c_uint16, c_void_p
 
 import torch  # noqa: F401  -- loads torch's own libamdhip64.so first so that ours binds to the same HIP runtime
 

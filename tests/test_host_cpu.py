@@ -1,6 +1,5 @@
 """Host-side logic of the product (no GPU): limb fit vs the oracle, percentile from
 histograms, FITS / PNG encoders, CLI flag table, SER header parsing."""
-import io
 import json
 import os
 
