@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SHG_ABI_VERSION 1
+#define SHG_ABI_VERSION 2
 
 #define SHG_E_ARG        (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SHG_E_WORKSPACE  (-2)   /* workspace too small                                 */
@@ -112,15 +112,23 @@ int shg_warp_rows_u16(const uint16_t* src, int64_t h, int64_t w, int64_t src_pit
  * Per row y in (y1, y2): the mean of the 2-MAD inliers of log(img[y][a:b] / img[y-1][a:b])
  * with a, b the chord of `circle` clipped to `borders` (float64).  out[y2 - y1]
  * (out[0] = 0 as solex_util.py:386).  xa, xb: int32 [y2-y1] column bounds computed on the
- * host (solex_util.py:389-391).  Rows longer than SHG_TRANSV_MAX_COLS are rejected. */
+ * host (solex_util.py:389-391).  Rows longer than SHG_TRANSV_MAX_COLS are rejected.
+ * row_factor (may be NULL): float64 [h]; when given the image is the float64 frame
+ * img[y][x] * row_factor[y] that removeVignette returns (solex_util.py:654). */
 #define SHG_TRANSV_MAX_COLS 8192
 int shg_rowpair_logratio_stats(const uint16_t* img, int64_t h, int64_t w, int64_t pitch,
                                int64_t y1, int64_t y2, const int32_t* xa, const int32_t* xb,
-                               double* out, shg_stream_t stream);
+                               const double* row_factor, double* out, shg_stream_t stream);
 
 /* ret = min(img * c[y], 65535) truncated to uint16 (solex_util.py:489, 515-516). */
 int shg_scale_rows_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, const double* c,
-                       uint16_t* dst, int64_t dst_pitch, shg_stream_t stream);
+                       const double* row_factor, uint16_t* dst, int64_t dst_pitch, shg_stream_t stream);
+
+/* np.percentile(img, q, axis) building block (removeVignette, solex_util.py:591-592): for every
+ * column (axis 0) or row (axis 1) the rank_lo-th and rank_hi-th smallest values (0-based). */
+int shg_line_order_stats_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, int axis,
+                             int64_t rank_lo, int64_t rank_hi, uint16_t* out_lo, uint16_t* out_hi,
+                             shg_stream_t stream);
 
 /* ---- crop / pad -------------------------------- Solex_recon.py:155-171
  * dst[h][nw] = fill everywhere, then dst[:, dx0:dx0+n] = src[:, sx0:sx0+n]. */

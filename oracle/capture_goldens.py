@@ -259,6 +259,28 @@ def g10_cli():
     print('wrote g10_cli.json')
 
 
+def g6_vignette():
+    """Reference removeVignette, unmodified (pinned)."""
+    out = {}
+    rng = np.random.default_rng(21)
+    for tag, (h, w, cx, cy, r) in {'a': (300, 330, 160.4, 148.9, 120.3), 'b': (260, 420, 230.0, 120.0, 110.0)}.items():
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        r2 = ((xx - cx) ** 2 + (yy - cy) ** 2) / r ** 2
+        img = np.where(r2 < 1, 0.35 + 0.65 * np.sqrt(np.clip(1 - r2, 0, 1)), 0.02) * (1 + 0.15 * (yy - cy) / h)
+        img = np.clip(img * 0.7 * 65535 * (1 + 0.02 * rng.standard_normal((h, w))), 1, 65535).astype(np.uint16)
+        res = ref_su.removeVignette(img, (cx, cy, r))
+        out[tag + '_image'] = img
+        out[tag + '_circle'] = np.array([cx, cy, r])
+        out[tag + '_factor'] = res[:, 0] / img[:, 0]
+        out[tag + '_out_sha256_shape'] = np.array(res.shape)
+        out[tag + '_row_sample'] = res[::17, ::13]
+        out[tag + '_p85_cols'] = np.percentile(img, 85, axis=0)
+        out[tag + '_p85_rows'] = np.percentile(img, 85, axis=1)
+    small = np.full((90, 90), 1000, np.uint16)
+    assert ref_su.removeVignette(small, (45.0, 45.0, 40.0)) is small        # not enough data: returned unchanged
+    save('g6_vignette', **out)
+
+
 def g13_limb():
     """Real scikit-image 0.18.3: downscale_local_mean and canny on a flooded disk (pinned)."""
     import skimage.feature
@@ -324,8 +346,10 @@ def g14_pipeline():
     path = os.path.join(tmp, 'scan.ser')
     synth.write_ser(path, frames)
     scenarios = {'A': {}, 'B': {'shift': [-2, 0, 3], 'flip_x': True, 'crop_width_square': True},
-                 'C': {'ratio_fixe': 1, 'fixed_width': 300, 'disk_display': False, 'img_rotate': 90}}
-    keep = {'A': ['clahe', 'protus', 'uncontrasted', 'high_contrast'], 'B': ['uncontrasted', 'clahe'], 'C': ['clahe', 'protus']}
+                 'C': {'ratio_fixe': 1, 'fixed_width': 300, 'disk_display': False, 'img_rotate': 90},
+                 'D': {'de-vignette': True, 'shift': [0, 4]}, 'E': {'de-vignette': True, 'transversalium': False, 'crop_width_square': True}}
+    keep = {'A': ['clahe', 'protus', 'uncontrasted', 'high_contrast'], 'B': ['uncontrasted', 'clahe'], 'C': ['clahe', 'protus'],
+            'D': ['clahe', 'uncontrasted'], 'E': ['clahe', 'protus']}
     for tag, extra in scenarios.items():
         captured.clear()
         opts = dict(base, **extra)
@@ -344,6 +368,8 @@ def g14_pipeline():
             key = '%s_%s_%s' % (tag, shift_s.replace('shift=', 's'), product)
             out[key + '_sha256'] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(img).tobytes()).digest(), np.uint8)
             out[key + '_shape'] = np.array(img.shape)
+            if tag == 'D' and not (shift_s == 'shift=4' or product == 'clahe'):
+                continue
             if product in keep[tag] and (tag != 'B' or (product == 'uncontrasted' and shift_s == 'shift=-2')
                                          or (product == 'clahe' and shift_s == 'shift=3')):
                 out[key] = img
@@ -351,7 +377,7 @@ def g14_pipeline():
     save('g14_pipeline', **out)
 
 
-ALL = dict(G13=g13_limb, G14=g14_pipeline, G1=g1_mean_max, G2=g2_extract, G3=g3_warp, G4=g4_transversalium, G5=g5_rescale,
+ALL = dict(G6=g6_vignette, G13=g13_limb, G14=g14_pipeline, G1=g1_mean_max, G2=g2_extract, G3=g3_warp, G4=g4_transversalium, G5=g5_rescale,
            G7=g7_matrix, G8=g8_fit_shim, G9=g9_fits, G10=g10_cli)
 
 if __name__ == '__main__':

@@ -19,7 +19,7 @@ except ImportError:
 
 DEFAULTS = dict(shift=[0], ratio_fixe=None, slant_fix=None, disk_display=True, delta_radius=0,
                 crop_width_square=False, transversalium=True, trans_strength=301, img_rotate=0,
-                flip_x=False, fixed_width=None, ellipse_fit_shift=10)
+                flip_x=False, fixed_width=None, ellipse_fit_shift=10, **{'de-vignette': False})
 
 
 def solex_read(frames, options):
@@ -75,6 +75,8 @@ def solex_process(read, options):
             phi = math.radians(slant_fix) if slant_fix is not None else 0.0
             if flag_requested:
                 frame = orc.correct_image(disk / 65536, phi, ratio, np.array([-1.0, -1.0]), -1.0)[0]
+                if opts['de-vignette'] and not cercle0 == (-1, -1, -1):      # Solex_recon.py:124-128
+                    frame = orc.remove_vignette(frame, cercle0)
         if not flag_requested:
             continue
         results[shift] = single_image_process(frame, opts, cercle0, borders, (read['y1'], read['y2']))

@@ -351,6 +351,54 @@ def correct_transversalium2(img, circle, borders, trans_strength=301):
 
 
 # ----------------------------------------------------------------------------
+# removeVignette                                             solex_util.py:590-654
+# ----------------------------------------------------------------------------
+def remove_vignette(frame, cercle0):
+    """Returns the float64 image frame * correction_factor[:, None] (or `frame` itself when there is
+    not enough data), exactly as the reference: 85th percentiles per column / row, Savitzky-Golay
+    trends inside the disk, ratio of the two axes as the row correction, NaN fill, Gaussian smoothing."""
+    from scipy.ndimage import gaussian_filter1d
+    from scipy.signal import savgol_filter
+    y_arr = np.percentile(frame, 85, axis=0)
+    y_arr2 = np.percentile(frame, 85, axis=1)
+    shrink = 65
+    start1 = max(0, int(cercle0[0] - cercle0[2] + shrink))
+    end1 = min(y_arr.shape[0], int(cercle0[0] + cercle0[2] + 1 - shrink))
+    start2 = max(0, int(cercle0[1] - cercle0[2] + shrink))
+    end2 = min(y_arr2.shape[0], int(cercle0[1] + cercle0[2] + 1 - shrink))
+    y1 = y_arr[start1:end1]
+    y2 = y_arr2[start2:end2]
+    x1 = np.arange(y1.shape[0]) + start1 - int(cercle0[0])
+    x2 = np.arange(y2.shape[0]) + start2 - int(cercle0[1])
+    if y1.shape[0] < 20 or y2.shape[0] < 20:
+        return frame
+    scale_pix = int(min(y1.shape[0] // 2.75, y2.shape[0] // 2.75)) // 2 * 2 - 1
+    trend1 = savgol_filter(y1, min(801, scale_pix), 3)
+    trend2 = savgol_filter(y2, min(801, scale_pix), 3)
+    mm = min(np.min(x1), np.min(x2))
+    dest = np.zeros((3, int(max(np.max(x1), np.max(x2)) - mm + 1)))
+    dest.fill(np.nan)
+    dest[0, :] = np.arange(dest.shape[1]) + mm
+    dest[1, int(x1[0] - mm): int(x1[-1] - mm + 1)] = trend1
+    dest[2, int(x2[0] - mm): int(x2[-1] - mm + 1)] = trend2
+    with np.errstate(divide='ignore', invalid='ignore'):
+        ratio_axes = dest[1, :] / dest[2, :]
+    ratio_axes[dest[1, :] == 0] = np.nan
+    ratio_axes[dest[2, :] == 0] = np.nan
+    correction_factor = np.zeros(frame.shape[0])
+    correction_factor.fill(np.nan)
+    correction_factor[dest[0, :].astype(int) + int(cercle0[1])] = ratio_axes
+    for i in range(1, len(correction_factor)):
+        if np.isnan(correction_factor[i]):
+            correction_factor[i] = correction_factor[i - 1]
+    for i in range(len(correction_factor) - 2, -1, -1):
+        if np.isnan(correction_factor[i]):
+            correction_factor[i] = correction_factor[i + 1]
+    correction_factor = gaussian_filter1d(correction_factor, max(2, min(150, scale_pix // 4)))
+    return frame * correction_factor.reshape((-1, 1))
+
+
+# ----------------------------------------------------------------------------
 # a10  crop / pad                                        Solex_recon.py:155-171
 # ----------------------------------------------------------------------------
 def crop_center(img, cercle, fixed_width, crop_width_square):

@@ -28,8 +28,8 @@ from . import dist, ops, outputs, timing
 from .device import DeviceImage, to_device_u16
 from .ellipse_to_circle import correct_image, ellipse_to_circle
 from .fits_io import write_fits
-from .solex_util import (clearlog, compute_mean_return_fit, correct_transversalium2, extract_disks, image_process,
-                         logme, make_header, output_path, write_complete)
+from .solex_util import (as_uint16_image, clearlog, compute_mean_return_fit, correct_transversalium2, extract_disks,
+                         image_process, logme, make_header, output_path, removeVignette, write_complete)
 from .video_reader import video_reader
 
 
@@ -159,8 +159,7 @@ def solex_process(options, disk_list, backup_bounds, hdr):
                     if cercle0 == (-1, -1, -1):
                         print("WARNING: cannot de-vignette without ellipse fit")
                     else:
-                        raise NotImplementedError('de-vignette (removeVignette, solex_util.py:590-654) is not part '
-                                                  'of the MI355X hot path yet')
+                        frame_circularized = removeVignette(frame_circularized, cercle0)
         if not flag_requested:
             continue
         results.append(single_image_process(frame_circularized, hdr, options, cercle0, borders, basefich, backup_bounds))
@@ -189,6 +188,10 @@ def single_image_process(frame_circularized, hdr, options, cercle0, borders, bas
                        _as_image(detransversaliumed), hdr)
 
     cercle = cercle0
+    # A de-vignetted frame that skipped the transversalium stage is still float64 here; the reference crops
+    # the float image and truncates in image_process (solex_util.py:528).  Cropping is a pure copy, so
+    # truncating first gives the same pixels (and the same fill value img[0, 0]).
+    detransversaliumed = as_uint16_image(detransversaliumed)
     if options['fixed_width'] is not None or options['crop_width_square']:
         src = to_device_u16(detransversaliumed)
         h, w = src.shape

@@ -113,7 +113,7 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 
 __global__ __launch_bounds__(NT) void k_rowpair_stats(const uint16_t* __restrict__ img, int64_t pitch, int64_t y1,
                                                       const int32_t* __restrict__ xa, const int32_t* __restrict__ xb,
-                                                      double* __restrict__ out) {
+                                                      const double* __restrict__ row_factor, double* __restrict__ out) {
     extern __shared__ uint64_t keys[];   // [n]
     __shared__ Scratch sc;
     const int t = blockIdx.x + 1;        // out[0] stays 0 (solex_util.py:386)
@@ -130,8 +130,10 @@ __global__ __launch_bounds__(NT) void k_rowpair_stats(const uint16_t* __restrict
     const uint16_t* r0 = img + (y - 1) * pitch + a;
     // Zero pixels give -inf / +inf / NaN ratios.  NumPy keeps infinities as ordinary (sortable) values and
     // lets any NaN poison the row statistic (np.median -> nan -> empty inlier set -> nan); same here.
+    // a de-vignetted frame is the float64 image img * row_factor[y] (removeVignette, solex_util.py:654)
+    const double f1 = row_factor ? row_factor[y] : 1.0, f0 = row_factor ? row_factor[y - 1] : 1.0;
     for (int i = threadIdx.x; i < n; i += NT) {
-        const double x = log((double)r1[i] / (double)r0[i]);        // np.log(strip1 / strip0)
+        const double x = log(((double)r1[i] * f1) / ((double)r0[i] * f0));        // np.log(strip1 / strip0)
         if (x != x) sc.bad = 1;
         keys[i] = f64_key(x);
     }
@@ -170,20 +172,89 @@ __global__ __launch_bounds__(NT) void k_rowpair_stats(const uint16_t* __restrict
 }
 
 __global__ __launch_bounds__(256) void k_scale_rows(const uint16_t* __restrict__ img, int64_t w, int64_t pitch,
-                                                    const double* __restrict__ c, uint16_t* __restrict__ dst,
-                                                    int64_t dst_pitch) {
+                                                    const double* __restrict__ c, const double* __restrict__ row_factor,
+                                                    uint16_t* __restrict__ dst, int64_t dst_pitch) {
     const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t y = blockIdx.y;
     if (x >= w) return;
-    double v = (double)img[y * pitch + x] * c[y];
+    double v = (double)img[y * pitch + x];
+    if (row_factor) v = v * row_factor[y];              // the float64 de-vignetted pixel, rounded as NumPy stores it
+    v = v * c[y];
     v = v > 65535.0 ? 65535.0 : v;
     dst[y * dst_pitch + x] = (uint16_t)(int)v;
 }
 
+// Two order statistics of every row (axis 1) or column (axis 0) of a uint16 image: np.percentile(img, q, axis)
+// (removeVignette, solex_util.py:591-592).  One workgroup per line, 16-bit keys, two 8-bit radix passes.
+__global__ __launch_bounds__(NT) void k_line_order_stats(const uint16_t* __restrict__ img, int64_t pitch, int n, int64_t line_stride,
+                                                         int64_t elem_stride, int rank_lo, int rank_hi,
+                                                         uint16_t* __restrict__ out_lo, uint16_t* __restrict__ out_hi) {
+    __shared__ uint32_t hist[256];
+    __shared__ int pick[2][2];
+    const uint16_t* line = img + (int64_t)blockIdx.x * line_stride;
+    int rank[2] = {rank_lo, rank_hi};
+    int hi_digit[2] = {0, 0};
+    int result[2] = {0, 0};
+    // pass 0: high byte, one histogram serves both ranks; pass 1: low byte within the chosen high byte (per rank)
+    for (int pass = 0; pass < 3; ++pass) {
+        if (pass == 2 && hi_digit[0] == hi_digit[1]) break;        // both ranks share the high byte: pass 1 served both
+        const int which = pass == 2 ? 1 : 0;
+        hist[threadIdx.x] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += NT) {
+            const uint32_t v = line[(int64_t)i * elem_stride];
+            if (pass == 0) atomicAdd(&hist[v >> 8], 1u);
+            else if ((int)(v >> 8) == hi_digit[which]) atomicAdd(&hist[v & 0xff], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {                                    // 256 bins: a serial scan is a few hundred cycles
+            for (int r = 0; r < 2; ++r) {
+                if (pass == 2 && r == 0) continue;
+                if (pass == 1 && r == 1 && hi_digit[1] != hi_digit[0]) continue;
+                int below = 0, d = 0;
+                for (; d < 256; ++d) {
+                    const int c = (int)hist[d];
+                    if (below + c > rank[r]) break;
+                    below += c;
+                }
+                pick[r][0] = d;
+                pick[r][1] = below;
+            }
+        }
+        __syncthreads();
+        for (int r = 0; r < 2; ++r) {
+            if (pass == 2 && r == 0) continue;
+            if (pass == 1 && r == 1 && hi_digit[1] != hi_digit[0]) continue;
+            if (pass == 0) { hi_digit[r] = pick[r][0]; rank[r] -= pick[r][1]; }
+            else result[r] = (hi_digit[r] << 8) | pick[r][0];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out_lo[blockIdx.x] = (uint16_t)result[0];
+        out_hi[blockIdx.x] = (uint16_t)result[1];
+    }
+}
+
 }  // namespace
 
+extern "C" int shg_line_order_stats_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, int axis, int64_t rank_lo,
+                                        int64_t rank_hi, uint16_t* out_lo, uint16_t* out_hi, shg_stream_t stream) {
+    SHG_REQUIRE(img && out_lo && out_hi, SHG_E_ARG, "shg_line_order_stats_u16: null pointer");
+    SHG_REQUIRE(h > 0 && w > 0 && pitch >= w && (axis == 0 || axis == 1), SHG_E_ARG, "shg_line_order_stats_u16: bad arguments");
+    const int64_t n = axis == 0 ? h : w, lines = axis == 0 ? w : h;
+    SHG_REQUIRE(n < (1ll << 31) && rank_lo >= 0 && rank_lo <= rank_hi && rank_hi < n, SHG_E_ARG,
+                "shg_line_order_stats_u16: ranks [%lld, %lld] outside a line of %lld", (long long)rank_lo, (long long)rank_hi, (long long)n);
+    hipStream_t st = shg::as_stream(stream);
+    SHG_PROF("line_order_stats", st);
+    k_line_order_stats<<<(unsigned)lines, NT, 0, st>>>(img, pitch, (int)n, axis == 0 ? 1 : pitch, axis == 0 ? pitch : 1, (int)rank_lo,
+                                                      (int)rank_hi, out_lo, out_hi);
+    return shg::check_launch("k_line_order_stats");
+}
+
 extern "C" int shg_rowpair_logratio_stats(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, int64_t y1, int64_t y2,
-                                          const int32_t* xa, const int32_t* xb, double* out, shg_stream_t stream) {
+                                          const int32_t* xa, const int32_t* xb, const double* row_factor, double* out,
+                                          shg_stream_t stream) {
     SHG_REQUIRE(img && xa && xb && out, SHG_E_ARG, "shg_rowpair_logratio_stats: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w, SHG_E_ARG, "shg_rowpair_logratio_stats: bad image size");
     SHG_REQUIRE(y1 >= 0 && y2 <= h && y2 > y1, SHG_E_ARG, "shg_rowpair_logratio_stats: rows [%lld, %lld) outside the image",
@@ -202,16 +273,16 @@ extern "C" int shg_rowpair_logratio_stats(const uint16_t* img, int64_t h, int64_
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowpair_stats), hipFuncAttributeMaxDynamicSharedMemorySize, MAXN * 8);
         attr_set = true;
     }
-    { SHG_PROF("rowpair_stats", st); k_rowpair_stats<<<(unsigned)rows, NT, lds_bytes, st>>>(img, pitch, y1, xa, xb, out); }
+    { SHG_PROF("rowpair_stats", st); k_rowpair_stats<<<(unsigned)rows, NT, lds_bytes, st>>>(img, pitch, y1, xa, xb, row_factor, out); }
     return shg::check_launch("k_rowpair_stats");
 }
 
-extern "C" int shg_scale_rows_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, const double* c, uint16_t* dst,
-                                  int64_t dst_pitch, shg_stream_t stream) {
+extern "C" int shg_scale_rows_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, const double* c,
+                                  const double* row_factor, uint16_t* dst, int64_t dst_pitch, shg_stream_t stream) {
     SHG_REQUIRE(img && c && dst, SHG_E_ARG, "shg_scale_rows_u16: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w && dst_pitch >= w, SHG_E_ARG, "shg_scale_rows_u16: bad image size");
     SHG_REQUIRE(h < 65536, SHG_E_UNSUPPORTED, "shg_scale_rows_u16: more than 65535 rows");
     dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
-    { SHG_PROF("scale_rows", shg::as_stream(stream)); k_scale_rows<<<grid, 256, 0, shg::as_stream(stream)>>>(img, w, pitch, c, dst, dst_pitch); }
+    { SHG_PROF("scale_rows", shg::as_stream(stream)); k_scale_rows<<<grid, 256, 0, shg::as_stream(stream)>>>(img, w, pitch, c, row_factor, dst, dst_pitch); }
     return shg::check_launch("k_scale_rows");
 }

@@ -18,10 +18,14 @@ def default_device():
 class DeviceImage:
     __array_priority__ = 100
 
-    def __init__(self, tensor):
+    def __init__(self, tensor, row_factor=None):
+        """row_factor (float64 GPU tensor [h], optional): the image is then the float64 array
+        tensor[y, x] * row_factor[y] -- what the reference's removeVignette returns (solex_util.py:654) --
+        kept factored so that it never has to be materialised in HBM."""
         if not isinstance(tensor, torch.Tensor) or not tensor.is_cuda:
             raise TypeError('DeviceImage wraps a GPU tensor')
         self.t = tensor
+        self.row_factor = row_factor
         self._host = None
 
     # ndarray surface -------------------------------------------------------
@@ -35,11 +39,16 @@ class DeviceImage:
 
     @property
     def dtype(self):
+        if self.row_factor is not None:
+            return np.dtype(np.float64)
         return np.dtype(str(self.t.dtype).replace('torch.', ''))
 
     def numpy(self):
         if self._host is None:
-            self._host = self.t.cpu().numpy()
+            host = self.t.cpu().numpy()
+            if self.row_factor is not None:
+                host = host * self.row_factor.cpu().numpy().reshape((-1, 1))
+            self._host = host
         return self._host
 
     def __array__(self, dtype=None, copy=None):
@@ -68,6 +77,8 @@ class DeviceImage:
 def to_device_u16(img, device=None):
     """GPU uint16 tensor (2-D, unit column stride) from a DeviceImage, tensor or ndarray."""
     if isinstance(img, DeviceImage):
+        if img.row_factor is not None:
+            raise TypeError('this stage needs a uint16 image, got a factored float64 one')
         return img.t
     if isinstance(img, torch.Tensor):
         if not img.is_cuda:

@@ -54,8 +54,21 @@ def _card(key, value, comment=''):
 
 def fits_bytes(array, header=None):
     array = np.asarray(array)
+    if array.dtype == np.float64 and array.ndim == 2:
+        # a de-vignetted frame is float64 in the reference (solex_util.py:654): BITPIX = -64, no scaling
+        cards = [_card('SIMPLE', True, 'conforms to FITS standard'), _card('BITPIX', -64, 'array data type'),
+                 _card('NAXIS', 2, 'number of array dimensions'), _card('NAXIS1', array.shape[1]),
+                 _card('NAXIS2', array.shape[0])]
+        for key, value in (header or {}).items():
+            if key.upper() not in _STRUCTURAL:
+                cards.append(_card(key.upper(), value))
+        cards.append('END'.ljust(80))
+        head = ''.join(cards).encode('ascii')
+        head += b' ' * (-len(head) % BLOCK)
+        data = array.astype('>f8').tobytes()
+        return head + data + b'\0' * (-len(data) % BLOCK)
     if array.dtype != np.uint16 or array.ndim != 2:
-        raise TypeError('fits_bytes writes 2-D uint16 images, got %s %s' % (array.dtype, array.shape))
+        raise TypeError('fits_bytes writes 2-D uint16 (or float64) images, got %s %s' % (array.dtype, array.shape))
     cards = [_card('SIMPLE', True, 'conforms to FITS standard'), _card('BITPIX', 16, 'array data type'),
              _card('NAXIS', 2, 'number of array dimensions'), _card('NAXIS1', array.shape[1]),
              _card('NAXIS2', array.shape[0])]

@@ -150,28 +150,50 @@ def warp_rows_u16(img, h00, h01, h02, out_h, out_w):
     return out
 
 
-def rowpair_logratio_stats(img, y1, y2, xa, xb):
+def _row_factor_ptr(row_factor, h, device):
+    if row_factor is None:
+        return None, None
+    rf = row_factor if isinstance(row_factor, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(row_factor, dtype=np.float64))
+    rf = rf.to(device).contiguous()
+    if rf.shape != (h,) or rf.dtype != torch.float64:
+        raise ValueError('row_factor must be float64 [h]')
+    return rf, rf.data_ptr()
+
+
+def rowpair_logratio_stats(img, y1, y2, xa, xb, row_factor=None):
     """xa, xb: int32 host arrays [y2-y1] of NumPy-normalised slice bounds. -> float64 tensor [y2-y1]."""
     ptr, h, w, pitch = _img(img, 'img', torch.uint16)
     xa = torch.as_tensor(np.ascontiguousarray(xa, dtype=np.int32)).to(img.device)
     xb = torch.as_tensor(np.ascontiguousarray(xb, dtype=np.int32)).to(img.device)
     if xa.numel() != y2 - y1 or xb.numel() != y2 - y1:
         raise ValueError('xa, xb must have y2 - y1 entries')
+    rf, rf_ptr = _row_factor_ptr(row_factor, h, img.device)
     out = torch.empty(y2 - y1, dtype=torch.float64, device=img.device)
-    _lib.check(lib.shg_rowpair_logratio_stats(ptr, h, w, pitch, int(y1), int(y2), xa.data_ptr(), xb.data_ptr(),
+    _lib.check(lib.shg_rowpair_logratio_stats(ptr, h, w, pitch, int(y1), int(y2), xa.data_ptr(), xb.data_ptr(), rf_ptr,
                                               out.data_ptr(), _stream()), 'shg_rowpair_logratio_stats')
     return out
 
 
-def scale_rows_u16(img, c):
+def scale_rows_u16(img, c, row_factor=None):
     ptr, h, w, pitch = _img(img, 'img', torch.uint16)
     c = torch.as_tensor(np.ascontiguousarray(c, dtype=np.float64)).to(img.device) if not isinstance(c, torch.Tensor) else c
     if c.shape != (h,) or c.dtype != torch.float64:
         raise ValueError('c must be float64 [h]')
+    rf, rf_ptr = _row_factor_ptr(row_factor, h, img.device)
     out = pitched_u16(h, w, img.device)
-    _lib.check(lib.shg_scale_rows_u16(ptr, h, w, pitch, c.contiguous().data_ptr(), out.data_ptr(), out.stride(0),
+    _lib.check(lib.shg_scale_rows_u16(ptr, h, w, pitch, c.contiguous().data_ptr(), rf_ptr, out.data_ptr(), out.stride(0),
                                       _stream()), 'shg_scale_rows_u16')
     return out
+
+
+def line_order_stats_u16(img, axis, rank_lo, rank_hi):
+    """-> (lo, hi) uint16 GPU tensors: per column (axis 0) / row (axis 1) order statistics."""
+    ptr, h, w, pitch = _img(img, 'img', torch.uint16)
+    lines = w if axis == 0 else h
+    out = torch.empty((2, lines), dtype=torch.uint16, device=img.device)
+    _lib.check(lib.shg_line_order_stats_u16(ptr, h, w, pitch, int(axis), int(rank_lo), int(rank_hi), out[0].data_ptr(),
+                                            out[1].data_ptr(), _stream()), 'shg_line_order_stats_u16')
+    return out[0], out[1]
 
 
 def crop_pad_u16(img, nw, sx0, dx0, n, fill):

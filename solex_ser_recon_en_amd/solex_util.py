@@ -226,13 +226,14 @@ def correct_transversalium2(img, circle, borders, options, reqFlag, basefich):
     from scipy.signal import savgol_filter
     if options.get('stubborn_transversalium'):
         raise NotImplementedError('stubborn transversalium (cv2.filter2D path, solex_util.py:415-423) is out of scope')
-    t = to_device_u16(img)
+    row_factor = img.row_factor if isinstance(img, DeviceImage) else None     # a de-vignetted (float64) frame
+    t = img.t if row_factor is not None else to_device_u16(img)
     h, w = t.shape
     y1 = math.ceil(max(circle[1] - circle[2], borders[1]))
     y2 = math.floor(min(circle[1] + circle[2], borders[3]))
     xa, xb = _chord_bounds(circle, borders, y1, y2, w)
     if y2 - y1 >= 1:
-        y_ratios_r = ops.rowpair_logratio_stats(t, y1, y2, xa, xb).cpu().numpy()
+        y_ratios_r = ops.rowpair_logratio_stats(t, y1, y2, xa, xb, row_factor).cpu().numpy()
     else:
         y_ratios_r = np.array([0.0])                                                  # y_ratios_r = [0], :386
     trend = savgol_filter(y_ratios_r, min(options['trans_strength'], len(y_ratios_r) // 2 * 2 - 1), 3)
@@ -246,7 +247,67 @@ def correct_transversalium2(img, circle, borders, options, reqFlag, basefich):
     options['_transversalium_cache'] = c
     if (not reqFlag) and _plots_enabled(options):
         outputs.submit(outputs.plot_transversalium, output_path(basefich + '_transversalium_correction.png', options), c)
-    return DeviceImage(ops.scale_rows_u16(t, c))
+    return DeviceImage(ops.scale_rows_u16(t, c, row_factor))
+
+
+# ---- removeVignette (reference solex_util.py:590-654) ----------------------------------------------
+def removeVignette(frame_circularized, cercle0):
+    """Returns the de-vignetted frame: the reference's float64 image frame * correction_factor[:, None],
+    held as (uint16 image, float64 row factor) on the GPU; or the input itself when there is too little data."""
+    from scipy.ndimage import gaussian_filter1d
+    from scipy.signal import savgol_filter
+    from .limb_fit import lerp_order_stats
+    t = to_device_u16(frame_circularized)
+    h, w = t.shape
+    # np.percentile(frame, 85, axis): two order statistics per line on the GPU, NumPy's lerp on the host
+    lo0, hi0, mix0 = lerp_order_stats(h, 85)
+    lo1, hi1, mix1 = lerp_order_stats(w, 85)
+    cols = torch.stack(ops.line_order_stats_u16(t, 0, lo0, hi0)).view(torch.int16).cpu().numpy().view(np.uint16).astype(np.float64)
+    rows = torch.stack(ops.line_order_stats_u16(t, 1, lo1, hi1)).view(torch.int16).cpu().numpy().view(np.uint16).astype(np.float64)
+    y_arr, y_arr2 = mix0(cols[0], cols[1]), mix1(rows[0], rows[1])          # _lerp is elementwise
+    shrink = 65
+    start1 = max(0, int(cercle0[0] - cercle0[2] + shrink))
+    end1 = min(y_arr.shape[0], int(cercle0[0] + cercle0[2] + 1 - shrink))
+    start2 = max(0, int(cercle0[1] - cercle0[2] + shrink))
+    end2 = min(y_arr2.shape[0], int(cercle0[1] + cercle0[2] + 1 - shrink))
+    y1 = y_arr[start1:end1]
+    y2 = y_arr2[start2:end2]
+    x1 = np.arange(y1.shape[0]) + start1 - int(cercle0[0])
+    x2 = np.arange(y2.shape[0]) + start2 - int(cercle0[1])
+    if y1.shape[0] < 20 or y2.shape[0] < 20:
+        print("no de-vignette, due to not enough data")
+        return frame_circularized
+    print("vignette shapes:", y1.shape, y2.shape)
+    scale_pix = int(min(y1.shape[0] // 2.75, y2.shape[0] // 2.75)) // 2 * 2 - 1
+    trend1 = savgol_filter(y1, min(801, scale_pix), 3)
+    trend2 = savgol_filter(y2, min(801, scale_pix), 3)
+    mm = min(np.min(x1), np.min(x2))
+    dest = np.full((3, int(max(np.max(x1), np.max(x2)) - mm + 1)), np.nan)
+    dest[0, :] = np.arange(dest.shape[1]) + mm
+    dest[1, int(x1[0] - mm): int(x1[-1] - mm + 1)] = trend1
+    dest[2, int(x2[0] - mm): int(x2[-1] - mm + 1)] = trend2
+    with np.errstate(divide='ignore', invalid='ignore'):
+        ratio_axes = dest[1, :] / dest[2, :]
+    ratio_axes[dest[1, :] == 0] = np.nan
+    ratio_axes[dest[2, :] == 0] = np.nan
+    correction_factor = np.full(h, np.nan)
+    correction_factor[dest[0, :].astype(int) + int(cercle0[1])] = ratio_axes
+    for i in range(1, len(correction_factor)):                 # forward fill, then backward fill
+        if np.isnan(correction_factor[i]):
+            correction_factor[i] = correction_factor[i - 1]
+    for i in range(len(correction_factor) - 2, -1, -1):
+        if np.isnan(correction_factor[i]):
+            correction_factor[i] = correction_factor[i + 1]
+    correction_factor = gaussian_filter1d(correction_factor, max(2, min(150, scale_pix // 4)))
+    return DeviceImage(t, row_factor=torch.from_numpy(np.ascontiguousarray(correction_factor)).to(t.device))
+
+
+def as_uint16_image(img):
+    """frame.astype(np.uint16) (solex_util.py:528) for a factored float64 frame: trunc(img * row_factor)."""
+    if isinstance(img, DeviceImage) and img.row_factor is not None:
+        ones = torch.ones(img.t.shape[0], dtype=torch.float64, device=img.t.device)
+        return DeviceImage(ops.scale_rows_u16(img.t, ones, img.row_factor))
+    return img
 
 
 # ---- a12: rescale_brightness (reference solex_util.py:519-525) ------------------------------
@@ -296,7 +357,7 @@ def _rot90(t, k):
 
 # ---- a11: CLAHE + contrast products + writers (reference solex_util.py:527-588) ---------------
 def image_process(frame, cercle, options, header, basefich):
-    frame_t = to_device_u16(frame)
+    frame_t = to_device_u16(as_uint16_image(frame))               # frame.astype(np.uint16), :528
     cl1 = ops.clahe(frame_t, 0.8, 2)
     hists = torch.stack([ops.histogram(frame_t), ops.histogram(cl1)]).cpu().numpy()
     bright = percentile_from_hist(hists[0], 99.9999)                # basically the same as max

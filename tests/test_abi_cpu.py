@@ -19,12 +19,12 @@ def declared_symbols():
 def test_library_loads_and_exports_every_declared_symbol():
     from solex_ser_recon_en_amd import _lib
     names = declared_symbols()
-    assert len(names) >= 19
+    assert len(names) >= 30
     for name in names:
         assert hasattr(_lib.lib, name), 'libshg_hip.so does not export %s' % name
         assert name in _lib.SIGNATURES, 'no ctypes signature for %s' % name
     assert sorted(_lib.SIGNATURES) == names
-    assert _lib.lib.shg_abi_version() == 1
+    assert _lib.lib.shg_abi_version() == _lib.ABI_VERSION == 2
     assert isinstance(_lib.last_error(), str)
 
 

@@ -324,3 +324,54 @@ def test_flood_stats_match_numpy(ops, golden):
     want, _ = np.histogram(data, bins=20)
     np.testing.assert_array_equal(host(counts), want)
     np.testing.assert_array_equal(host(stats), [np.sum(small), data.min(), data.max()])
+
+
+@pytest.mark.parametrize('h,w', [(300, 330), (57, 1025), (1, 9), (260, 3)])
+def test_line_order_stats_and_percentile(ops, h, w):
+    from solex_ser_recon_en_amd.limb_fit import lerp_order_stats
+    rng = np.random.default_rng(h * w)
+    img = rng.integers(0, 65536, (h, w)).astype(np.uint16)
+    img[:, : w // 3] = 513                                  # ties, and one high byte shared by both ranks
+    for axis in (0, 1):
+        n = img.shape[axis]
+        lo, hi, mix = lerp_order_stats(n, 85)
+        a, b = ops.line_order_stats_u16(dev(img), axis, lo, hi)
+        srt = np.sort(img, axis=axis)
+        np.testing.assert_array_equal(host(a), np.take(srt, lo, axis=axis))
+        np.testing.assert_array_equal(host(b), np.take(srt, hi, axis=axis))
+        got = mix(host(a).astype(np.float64), host(b).astype(np.float64))
+        np.testing.assert_array_equal(got, np.percentile(img, 85, axis=axis))
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_remove_vignette_golden(ops, golden, tag):
+    from solex_ser_recon_en_amd import solex_util
+    g = golden('g6_vignette')
+    img = g[tag + '_image']
+    out = solex_util.removeVignette(dev(img), tuple(g[tag + '_circle']))
+    assert out.dtype == np.float64 and out.shape == img.shape
+    np.testing.assert_allclose(out.row_factor.cpu().numpy(), g[tag + '_factor'], rtol=1e-12)
+    np.testing.assert_allclose(np.asarray(out)[::17, ::13], g[tag + '_row_sample'], rtol=1e-12)
+    small = dev(np.full((90, 90), 1000, np.uint16))
+    assert solex_util.removeVignette(small, (45.0, 45.0, 40.0)) is small
+
+
+def test_row_factor_paths_match_float_image(ops, orc, golden):
+    """rowpair statistics / row scaling on the factored float64 frame == the oracle on the materialised one."""
+    import math
+    g = golden('g4_transversalium')
+    img = g['image']
+    rng = np.random.default_rng(3)
+    rf = 1.0 + 0.05 * rng.standard_normal(img.shape[0])
+    fimg = img * rf.reshape((-1, 1))
+    circle, borders = tuple(g['circle']), list(g['borders'])
+    y1, y2, want = orc.transversalium_row_stats(fimg, circle, borders)
+    from solex_ser_recon_en_amd.solex_util import _chord_bounds
+    xa, xb = _chord_bounds(circle, borders, y1, y2, img.shape[1])
+    got = host(ops.rowpair_logratio_stats(dev(img), y1, y2, xa, xb, rf))
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-15)
+    c = g['a_c']
+    ret = (fimg.T * c).T
+    ret[ret > 65535] = 65535
+    np.testing.assert_array_equal(host(ops.scale_rows_u16(dev(img), c, rf)), ret.astype(np.uint16))
+    np.testing.assert_array_equal(host(ops.scale_rows_u16(dev(img), np.ones(img.shape[0]), rf)), np.minimum(fimg, 65535).astype(np.uint16))

@@ -149,3 +149,17 @@ def test_filled_circle_known_answers():
     img = np.zeros((10, 10), np.uint16)
     orc.filled_circle(img, 0, 0, 4, 7)       # clipped at the image corner
     assert img[0, 0] == 7 and img[0, 4] == 7 and img[0, 5] == 0
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_remove_vignette_pinned(golden, tag):
+    g = golden('g6_vignette')
+    img = g[tag + '_image']
+    out = orc.remove_vignette(img, tuple(g[tag + '_circle']))
+    assert out.dtype == np.float64 and out.shape == tuple(g[tag + '_out_sha256_shape'])
+    # savgol / gaussian_filter1d agree to ~1e-15 across SciPy versions
+    np.testing.assert_allclose(out[:, 0] / img[:, 0], g[tag + '_factor'], rtol=1e-12)
+    np.testing.assert_allclose(out[::17, ::13], g[tag + '_row_sample'], rtol=1e-12)
+    np.testing.assert_array_equal(np.percentile(img, 85, axis=0), g[tag + '_p85_cols'])
+    small = np.full((90, 90), 1000, np.uint16)
+    assert orc.remove_vignette(small, (45.0, 45.0, 40.0)) is small

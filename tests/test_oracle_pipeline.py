@@ -66,11 +66,13 @@ def g14_frames(golden):
 
 
 SCENARIOS = {'A': {}, 'B': {'shift': [-2, 0, 3], 'flip_x': True, 'crop_width_square': True},
-             'C': {'ratio_fixe': 1, 'fixed_width': 300, 'disk_display': False, 'img_rotate': 90}}
+             'C': {'ratio_fixe': 1, 'fixed_width': 300, 'disk_display': False, 'img_rotate': 90},
+             'D': {'de-vignette': True, 'shift': [0, 4]},
+             'E': {'de-vignette': True, 'transversalium': False, 'crop_width_square': True}}
 PRODUCT_KEY = {'clahe': 'cc', 'protus': 'protus', 'uncontrasted': 'raw', 'high_contrast': 'hc'}
 
 
-@pytest.mark.parametrize('tag', ['A', 'B', 'C'])
+@pytest.mark.parametrize('tag', ['A', 'B', 'C', 'D', 'E'])
 def test_pipeline_oracle_matches_reference_shim_run(g14_frames, tag):
     g, frames = g14_frames
     run = po.run(frames, SCENARIOS[tag])

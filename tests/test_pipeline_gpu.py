@@ -12,7 +12,9 @@ from oracle import pipeline_oracle as po          # noqa: E402
 from solex_ser_recon_en_amd import synth          # noqa: E402
 
 SCENARIOS = {'A': {}, 'B': {'shift': [-2, 0, 3], 'flip_x': True, 'crop_width_square': True},
-             'C': {'ratio_fixe': 1, 'fixed_width': 300, 'disk_display': False, 'img_rotate': 90}}
+             'C': {'ratio_fixe': 1, 'fixed_width': 300, 'disk_display': False, 'img_rotate': 90},
+             'D': {'de-vignette': True, 'shift': [0, 4]},
+             'E': {'de-vignette': True, 'transversalium': False, 'crop_width_square': True}}
 PRODUCT_KEY = {'clahe': 'cc', 'protus': 'protus', 'uncontrasted': 'raw', 'high_contrast': 'hc'}
 
 
@@ -41,7 +43,7 @@ def close_u16(got, want, max_flips=4):
     assert diff.max() <= 1 and np.count_nonzero(diff) <= max_flips, (diff.max(), np.count_nonzero(diff))
 
 
-@pytest.mark.parametrize('tag', ['A', 'B', 'C'])
+@pytest.mark.parametrize('tag', ['A', 'B', 'C', 'D', 'E'])
 def test_solex_read_process_vs_oracle_and_reference(pkg, scan, tag):
     SHG_MAIN, Solex_recon, outputs = pkg
     g, frames, path = scan
@@ -68,6 +70,7 @@ def test_solex_read_process_vs_oracle_and_reference(pkg, scan, tag):
         close_u16(protus, ref['protus'])
         for product in ('clahe', 'protus'):
             key = '%s_s%d_%s' % (tag, shift, product)
+            # (float stages of a de-vignetted frame: the row factors agree to ~1e-15, same 1-LSB allowance)
             if key in g.files:                          # the reference's own output for this product
                 close_u16({'clahe': cc, 'protus': protus}[product], g[key])
 
