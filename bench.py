@@ -49,6 +49,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=0, help='frames of the CPU-baseline sample (0 = the whole scan)')
     ap.add_argument('--stages', action='store_true', help='print a per-stage wall-clock table to stderr')
+    ap.add_argument('--shifts', default='0', help="requested pixel shifts, CLI syntax of -w: '0', 'a,b,c' or 'x:y:w' (C4 = -10:10:1)")
     return ap.parse_args()
 
 
@@ -76,6 +77,9 @@ def main():
     from solex_ser_recon_en_amd import SHG_MAIN, Solex_recon, _lib, synth, timing
     from solex_ser_recon_en_amd.video_reader import array_reader
 
+    from solex_ser_recon_en_amd.CLI_handler import parse_shift
+    requested_shifts = parse_shift(args.shifts)
+    n_disks = len(dict.fromkeys([10, 0] + requested_shifts))
     sharded = world > 1 and args.mode == 'sharded'
     n_local = args.frames
     n_scan = n_local * world if sharded else n_local
@@ -89,6 +93,7 @@ def main():
     def step():
         opts = SHG_MAIN.default_options()
         opts['_nolog'] = True
+        opts['shift'] = list(requested_shifts)
         opts['_shard_frames'] = sharded
         rdr = array_reader(stack, frame_count=n_scan, frame_range=(k0, k0 + n_local) if sharded else None)
         with contextlib.redirect_stdout(io.StringIO()):
@@ -124,8 +129,9 @@ def main():
     ih, iw = max(args.width, args.height), min(args.width, args.height)
     bpp = args.bits // 8
     bytes_a = n_local * ih * iw * bpp                                   # algorithmic: every sample read once
-    n_shifts = 2
-    u = 4                                                               # distinct samples per row: c, c+1, c+10, c+11
+    n_shifts = n_disks
+    distinct = sorted(set(s + d for s in dict.fromkeys([10, 0] + requested_shifts) for d in (0, 1)))
+    u = len(distinct)                                                   # distinct samples per row (4 for S=2: c, c+1, c+10, c+11)
     bytes_b = n_local * ih * (u * bpp + 2 * n_shifts)
     ach = bytes_a / (acc_ms / acc_n * 1e-3) / 1e9 if acc_n else 0.0
     traffic = None
@@ -184,9 +190,10 @@ def main():
             'value': round(total_frames / elapsed, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u16' if bpp == 2 else 'u8', 'data': 'synthetic',
-            'config': {'workload': '%d-frame %d-bit SER, %dx%d frames, single H-alpha shift (S=2 disks), '
+            'config': {'workload': '%d-frame %d-bit SER, %dx%d frames, %s (S=%d disks), '
                                    'transversalium+ellipse on%s' % (
                                        n_scan, args.bits, args.width, args.height,
+                                       'single H-alpha shift' if requested_shifts == [0] else 'shifts -w %s' % args.shifts, n_disks,
                                        '' if world == 1 else (', frames sharded over %d GPUs (RCCL all-reduce + all-gather)' % world
                                                               if sharded else ', folder mode: one scan per GPU, no collective')),
                        'frames_per_gpu': n_local, 'mode': 'single' if world == 1 else args.mode},

@@ -150,6 +150,12 @@ int shg_clahe(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_pe
 int shg_hist(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_per_px,
              uint32_t* hist, shg_stream_t stream);
 
+/* Exact order statistics of a uint16 image: out[i] (as double) = the host_ranks[i]-th smallest pixel
+ * (0-based; rank h*w-1 = np.max).  Feeds np.percentile without moving a histogram to the host. */
+size_t shg_select_u16_workspace_bytes(int n_ranks);
+int shg_select_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, const int64_t* host_ranks,
+                   int n_ranks, double* out, void* workspace, size_t workspace_bytes, shg_stream_t stream);
+
 /* rescale_brightness: trunc(clamp((sat*alpha)*(v-lo)/(hi-lo), 0, sat)), float64, sat = 65535
  * (solex_util.py:519-525). */
 int shg_rescale_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch,

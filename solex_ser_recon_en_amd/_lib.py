@@ -48,6 +48,8 @@ SIGNATURES = {
     'shg_clahe_workspace_bytes': (c_size_t, [c_int, c_int]),
     'shg_clahe': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_double, c_int, P, c_int64, P, c_size_t, P]),
     'shg_hist': (c_int, [P, c_int64, c_int64, c_int64, c_int, P, P]),
+    'shg_select_u16_workspace_bytes': (c_size_t, [c_int]),
+    'shg_select_u16': (c_int, [P, c_int64, c_int64, c_int64, ctypes.POINTER(c_int64), c_int, P, P, c_size_t, P]),
     'shg_rescale_u16': (c_int, [P, c_int64, c_int64, c_int64, c_double, c_double, c_double, P, c_int64, P]),
     'shg_fill_disc_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_uint16, P, P]),
     'shg_downscale_mean_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int, P, P]),

@@ -209,6 +209,64 @@ __global__ __launch_bounds__(256) void k_image_hist8(const uint8_t* __restrict__
     if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
 }
 
+// ---- exact order statistics of a uint16 image (np.percentile / np.max, solex_util.py:535-537) ---------------
+// MSB-first radix select on the 16-bit values: pass 0 histograms the high byte, pass 1 the low byte of the
+// pixels whose high byte was chosen.  hist: [n_ranks][2][256] u32, zeroed.  Every workgroup replays pass 0's
+// choice with a workgroup-wide scan (one bin per thread).
+__device__ __forceinline__ void pick_digit(const uint32_t* __restrict__ hist, int64_t rank, int& digit, int64_t& below) {
+    __shared__ int64_t wave_tot[4];
+    __shared__ int64_t chosen[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t c = hist[tid];
+    int64_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    for (int i = 0; i < wave; ++i) incl += wave_tot[i];
+    const int64_t excl = incl - c;
+    if (excl <= rank && rank < incl) { chosen[0] = tid; chosen[1] = excl; }
+    __syncthreads();
+    digit = (int)chosen[0];
+    below = chosen[1];
+    __syncthreads();
+}
+
+// grid (row blocks, n_ranks), 256 threads
+__global__ __launch_bounds__(256) void k_select16_pass(const uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch, int pass,
+                                                       const int64_t* __restrict__ ranks, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[256];
+    uint32_t* myhist = hist + (int64_t)blockIdx.y * 512;
+    int hi = 0;
+    int64_t below = 0;
+    if (pass == 1) pick_digit(myhist, ranks[blockIdx.y], hi, below);
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t y = blockIdx.x; y < h; y += gridDim.x) {
+        const uint16_t* row = img + y * pitch;
+        for (int64_t x = threadIdx.x; x < w; x += 256) {
+            const uint32_t v = row[x];
+            if (pass == 0) atomicAdd(&lh[v >> 8], 1u);
+            else if ((int)(v >> 8) == hi) atomicAdd(&lh[v & 0xff], 1u);
+        }
+    }
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&myhist[pass * 256 + threadIdx.x], lh[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_select16_final(const int64_t* __restrict__ ranks, const uint32_t* __restrict__ hist,
+                                                        double* __restrict__ out) {
+    const uint32_t* myhist = hist + (int64_t)blockIdx.x * 512;
+    int hi, lo;
+    int64_t below, below2;
+    pick_digit(myhist, ranks[blockIdx.x], hi, below);
+    pick_digit(myhist + 256, ranks[blockIdx.x] - below, lo, below2);
+    if (threadIdx.x == 0) out[blockIdx.x] = (double)((hi << 8) | lo);
+}
+
 void ensure_lds_attr() {
     static bool done = false;
     if (!done) {
@@ -304,4 +362,32 @@ extern "C" int shg_hist(const void* img, int64_t h, int64_t w, int64_t pitch, in
         { SHG_PROF("hist", st); k_image_hist8<<<(unsigned)hb, 256, 0, st>>>(static_cast<const uint8_t*>(img), h, w, pitch, hist); }
     }
     return shg::check_launch("k_image_hist");
+}
+
+extern "C" size_t shg_select_u16_workspace_bytes(int n_ranks) {
+    if (n_ranks < 1 || n_ranks > 8) return 0;
+    return (size_t)n_ranks * (512 * sizeof(uint32_t) + sizeof(int64_t));
+}
+
+extern "C" int shg_select_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, const int64_t* host_ranks, int n_ranks,
+                              double* out, void* workspace, size_t workspace_bytes, shg_stream_t stream) {
+    SHG_REQUIRE(img && host_ranks && out && workspace, SHG_E_ARG, "shg_select_u16: null pointer");
+    SHG_REQUIRE(h > 0 && w > 0 && pitch >= w && n_ranks >= 1 && n_ranks <= 8, SHG_E_ARG, "shg_select_u16: bad sizes");
+    SHG_REQUIRE(workspace_bytes >= shg_select_u16_workspace_bytes(n_ranks), SHG_E_WORKSPACE, "shg_select_u16: workspace too small");
+    for (int i = 0; i < n_ranks; ++i)
+        SHG_REQUIRE(host_ranks[i] >= 0 && host_ranks[i] < h * w, SHG_E_ARG, "shg_select_u16: rank %lld outside the image", (long long)host_ranks[i]);
+    hipStream_t st = shg::as_stream(stream);
+    uint32_t* hist = static_cast<uint32_t*>(workspace);
+    int64_t* ranks = reinterpret_cast<int64_t*>(hist + (size_t)n_ranks * 512);
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)n_ranks * 512 * sizeof(uint32_t), st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ranks, host_ranks, n_ranks * sizeof(int64_t), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) { shg::set_error("shg_select_u16: %s", hipGetErrorString(e)); return (int)e; }
+    const unsigned blocks = (unsigned)(h < 256 ? h : 256);
+    SHG_PROF("select_u16", st);
+    for (int pass = 0; pass < 2; ++pass) {
+        k_select16_pass<<<dim3(blocks, (unsigned)n_ranks), 256, 0, st>>>(img, h, w, pitch, pass, ranks, hist);
+        if (int err = shg::check_launch("k_select16_pass")) return err;
+    }
+    k_select16_final<<<(unsigned)n_ranks, 256, 0, st>>>(ranks, hist, out);
+    return shg::check_launch("k_select16_final");
 }

@@ -353,3 +353,20 @@ def edge_components(low_mask, high_mask, prefetch=16384):
     if m <= k:
         return head[1:1 + m], head[1 + k:1 + k + m]
     return out[1:1 + m].cpu().numpy(), out[1 + n:1 + n + m].cpu().numpy()
+
+
+def select_u16(img, ranks, out=None):
+    """-> float64 GPU tensor: the ranks[i]-th smallest pixels (0-based) of a uint16 image."""
+    import ctypes
+    ptr, h, w, pitch = _img(img, 'img', torch.uint16)
+    ranks = [int(r) for r in ranks]
+    arr = (ctypes.c_int64 * len(ranks))(*ranks)
+    need = lib.shg_select_u16_workspace_bytes(len(ranks))
+    if need == 0:
+        raise ValueError('select_u16 takes 1..8 ranks')
+    ws = torch.empty(need, dtype=torch.uint8, device=img.device)
+    if out is None:
+        out = torch.empty(len(ranks), dtype=torch.float64, device=img.device)
+    _lib.check(lib.shg_select_u16(ptr, h, w, pitch, arr, len(ranks), out.data_ptr(), ws.data_ptr(), need, _stream()),
+               'shg_select_u16')
+    return out

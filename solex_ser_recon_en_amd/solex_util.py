@@ -358,11 +358,18 @@ def _rot90(t, k):
 # ---- a11: CLAHE + contrast products + writers (reference solex_util.py:527-588) ---------------
 def image_process(frame, cercle, options, header, basefich):
     frame_t = to_device_u16(as_uint16_image(frame))               # frame.astype(np.uint16), :528
+    from .limb_fit import lerp_order_stats
     cl1 = ops.clahe(frame_t, 0.8, 2)
-    hists = torch.stack([ops.histogram(frame_t), ops.histogram(cl1)]).cpu().numpy()
-    bright = percentile_from_hist(hists[0], 99.9999)                # basically the same as max
-    dark_clahe = percentile_from_hist(hists[1], 10)
-    bright_clahe = max_from_hist(hists[1])
+    n_px = frame_t.shape[0] * frame_t.shape[1]
+    b_lo, b_hi, b_mix = lerp_order_stats(n_px, 99.9999)
+    d_lo, d_hi, d_mix = lerp_order_stats(n_px, 10)
+    stats = torch.empty(5, dtype=torch.float64, device=frame_t.device)
+    ops.select_u16(frame_t, [b_lo, b_hi], out=stats[0:2])           # np.percentile needs two order statistics
+    ops.select_u16(cl1, [d_lo, d_hi, n_px - 1], out=stats[2:5])     # ... and np.max is the last one
+    stats = stats.cpu().numpy()
+    bright = b_mix(stats[0], stats[1])                              # basically the same as max
+    dark_clahe = d_mix(stats[2], stats[3])
+    bright_clahe = int(stats[4])
     frame_raw = frame_t
     assert 65535 >= bright > bright * 0.25 and 65535 >= bright * 0.18 > 0 and 65535 >= bright_clahe > dark_clahe
     frame_HC = ops.rescale_u16(frame_t, bright * 0.25, bright)

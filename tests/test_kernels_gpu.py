@@ -375,3 +375,23 @@ def test_row_factor_paths_match_float_image(ops, orc, golden):
     ret[ret > 65535] = 65535
     np.testing.assert_array_equal(host(ops.scale_rows_u16(dev(img), c, rf)), ret.astype(np.uint16))
     np.testing.assert_array_equal(host(ops.scale_rows_u16(dev(img), np.ones(img.shape[0]), rf)), np.minimum(fimg, 65535).astype(np.uint16))
+
+
+@pytest.mark.parametrize('h,w', [(70, 90), (1, 1), (333, 1027), (2000, 64)])
+def test_select_u16_is_exact(ops, h, w):
+    rng = np.random.default_rng(h + w)
+    img = rng.integers(0, 65536, (h, w)).astype(np.uint16)
+    if h * w > 100:
+        img[: h // 2] = 40000
+    n = h * w
+    srt = np.sort(img.ravel())
+    ranks = sorted(set([0, n // 10, n // 2, int(0.999999 * (n - 1)), n - 1]))
+    padded = torch.zeros((h, w + 5), dtype=torch.int16, device='cuda').view(torch.uint16)
+    padded[:, :w] = dev(img)                              # a pitched view: the padding must not be counted
+    got = host(ops.select_u16(padded[:, :w], ranks))
+    np.testing.assert_array_equal(got, srt[ranks].astype(np.float64))
+    from solex_ser_recon_en_amd.limb_fit import lerp_order_stats
+    for q in (10, 99.9999):
+        lo, hi, mix = lerp_order_stats(n, q)
+        a, b = host(ops.select_u16(dev(img), [lo, hi]))
+        assert mix(a, b) == np.percentile(img, q)

@@ -166,3 +166,46 @@ def test_folder_of_files_with_prefetch(pkg, scan, tmp_path):
     # a missing file in the middle stops the batch when its turn comes (README: "will halt if a file is unsuitable")
     with pytest.raises(Exception):
         Solex_recon.solex_do_work([(files[0], SHG_MAIN.default_options()), (str(tmp_path / 'nope.ser'), SHG_MAIN.default_options())], True)
+
+
+def test_stage_functions_keep_the_reference_call_surface(pkg, scan):
+    """The second caller of the stage functions (spectralAnalyserUI.py:155-175, 345-359): all_video_reader ->
+    compute_mean_return_fit -> read_video_improved -> ellipse_to_circle -> correct_image(disk / 65536) ->
+    single_image_process, with options['_nolog'] (no files)."""
+    SHG_MAIN, Solex_recon, outputs = pkg
+    from oracle import shg_oracle as orc
+    from solex_ser_recon_en_amd import ellipse_to_circle as e2c
+    from solex_ser_recon_en_amd import solex_util
+    from solex_ser_recon_en_amd.video_reader import all_video_reader
+    g, frames, path = scan
+    rdr = all_video_reader(path)
+    assert rdr.frames.shape == (400, 400, 32) and rdr.means.shape == (400,)
+    options = SHG_MAIN.default_options()
+    options.update(_nolog=True, shift=[options['ellipse_fit_shift']], basefich0=path[:-4])
+    hdr = solex_util.make_header(rdr)
+    mean_img, fit, y1, y2 = solex_util.compute_mean_return_fit(rdr, options, hdr, rdr.iw, rdr.ih, path[:-4])
+    ref_mean, ref_max = orc.compute_mean_max(orc.SerReader(frames))
+    np.testing.assert_array_equal(np.asarray(mean_img), ref_mean)
+    ref_fit, ry1, ry2, _, _ = orc.line_fit(ref_mean, ref_max)
+    assert (y1, y2) == (ry1, ry2) and fit.shape == (400, 4)
+    np.testing.assert_allclose(fit, ref_fit, rtol=0, atol=1e-9)
+    assert solex_util.detect_bord(mean_img, axis=1) == orc.detect_bord(ref_mean, axis=1)
+    assert solex_util.detect_bord(mean_img, axis=0) == orc.detect_bord(ref_mean, axis=0)
+    rdr.reset()
+    disk_list, ih, iw, n = solex_util.read_video_improved(rdr, fit, options)
+    assert (ih, iw, n, len(disk_list)) == (400, 32, 400, 1) and disk_list[0].dtype == np.uint16
+    want = orc.extract_columns(orc.SerReader(frames), fit, options['shift'])
+    np.testing.assert_array_equal(np.asarray(disk_list[0]), want[0])
+    fix_img, circle, ratio, phi, borders = e2c.ellipse_to_circle(disk_list[0], options, path[:-4])
+    again, circle2, mat3 = e2c.correct_image(np.asarray(disk_list[0]) / 65536, phi, ratio, np.array([-1.0, -1.0]), -1.0, options)
+    np.testing.assert_array_equal(np.asarray(again), np.asarray(fix_img))          # float disk/65536 input, as the reference passes it
+    with pytest.raises(ValueError):
+        e2c.correct_image(np.random.default_rng(0).random((8, 8)), 0.0, 1.0, np.array([-1.0, -1.0]), -1.0, options)
+    cc, protus = Solex_recon.single_image_process(fix_img, hdr, options, circle, borders, path[:-4] + '_x', (y1, y2))
+    assert np.asarray(cc).shape == np.asarray(fix_img).shape and np.asarray(cc).dtype == np.uint16
+    # rescale_brightness keeps its signature, including the 8-bit form clahe_apply uses
+    img8 = (np.asarray(fix_img) >> 8).astype(np.uint8)
+    np.testing.assert_array_equal(solex_util.rescale_brightness(img8, 10.0, 200.0), orc.rescale_brightness(img8, 10.0, 200.0))
+    np.testing.assert_array_equal(np.asarray(solex_util.rescale_brightness(fix_img, 100.0, 50000.0, alpha=0.9)),
+                                  orc.rescale_brightness(np.asarray(fix_img), 100.0, 50000.0, alpha=0.9))
+    np.testing.assert_array_equal(solex_util.reject_outliers(np.array([1.0, 1.1, 0.9, 50.0])), orc.reject_outliers(np.array([1.0, 1.1, 0.9, 50.0])))
