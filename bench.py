@@ -70,9 +70,14 @@ def main():
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the SHG hot path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
+    backend = os.environ.get('SHG_DIST_BACKEND', 'nccl')           # 'gloo' lets two ranks share one GPU (functional tests)
+    device_index = local_rank % max(torch.cuda.device_count(), 1) if backend != 'nccl' else local_rank
+    torch.cuda.set_device(device_index)
     if world > 1:
-        td.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            td.init_process_group('nccl', device_id=torch.device('cuda', device_index))
+        else:
+            td.init_process_group(backend)
 
     from solex_ser_recon_en_amd import SHG_MAIN, Solex_recon, _lib, synth, timing
     from solex_ser_recon_en_amd.video_reader import array_reader
@@ -162,7 +167,7 @@ def main():
 
     # ---- CPU baseline: the NumPy oracle of the same path on this box's host cores -------------------
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the CPU baseline is an N=1 figure
         from oracle import pipeline_oracle as po
         n_cpu = args.cpu_frames or n_local
         if sharded:

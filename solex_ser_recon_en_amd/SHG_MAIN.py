@@ -90,8 +90,10 @@ def _init_distributed():
         return
     import torch
     import torch.distributed as td
-    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-    td.init_process_group('nccl')
+    backend = os.environ.get('SHG_DIST_BACKEND', 'nccl')     # 'gloo': functional runs with several ranks on one GPU
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank if backend == 'nccl' else local_rank % max(torch.cuda.device_count(), 1))
+    td.init_process_group(backend)
 
 
 def main(argv=None):

@@ -42,11 +42,24 @@ def is_sharded(rdr):
     return active() and rng is not None and tuple(rng) != (0, int(rdr.FrameCount))
 
 
+def _staged(t):
+    """gloo moves host memory only: stage GPU tensors through the host (functional tests with several
+    ranks on one GPU).  RCCL (backend "nccl") works on the device buffers directly."""
+    return t.is_cuda and td.get_backend() == 'gloo'
+
+
 def allreduce_sum_max(total, mx):
     """total: int64 [P] partial sums; mx: uint16 [P] partial maxima (raw sample units)."""
-    td.all_reduce(total, op=td.ReduceOp.SUM)
     wide = mx.view(torch.int16).to(torch.int32) & 0xffff          # RCCL has no uint16 MAX; widen losslessly
-    td.all_reduce(wide, op=td.ReduceOp.MAX)
+    if _staged(total):
+        dev = total.device
+        total, wide = total.cpu(), wide.cpu()
+        td.all_reduce(total, op=td.ReduceOp.SUM)
+        td.all_reduce(wide, op=td.ReduceOp.MAX)
+        total, wide = total.to(dev), wide.to(dev)
+    else:
+        td.all_reduce(total, op=td.ReduceOp.SUM)
+        td.all_reduce(wide, op=td.ReduceOp.MAX)
     return total, wide.to(torch.int16).view(torch.uint16)
 
 
@@ -63,8 +76,14 @@ def gather_columns(local, frame_range, n_total, flip_x=False):
     send[:, :, :n_local] = local.view(torch.int16)
     # neither RCCL nor gloo moves 16-bit integers: gather the bytes
     send8 = send.view(torch.uint8)
-    recv8 = [torch.empty_like(send8) for _ in range(w)]
-    td.all_gather(recv8, send8)
+    if _staged(send8):
+        host = send8.cpu()
+        recv_h = [torch.empty_like(host) for _ in range(w)]
+        td.all_gather(recv_h, host)
+        recv8 = [r.to(local.device) for r in recv_h]
+    else:
+        recv8 = [torch.empty_like(send8) for _ in range(w)]
+        td.all_gather(recv8, send8)
     recv = [r.view(torch.int16) for r in recv8]
     full = torch.cat([recv[r][:, :, :blocks[r][1] - blocks[r][0]] for r in range(w)], dim=2)
     if flip_x:

@@ -209,3 +209,37 @@ def test_stage_functions_keep_the_reference_call_surface(pkg, scan):
     np.testing.assert_array_equal(np.asarray(solex_util.rescale_brightness(fix_img, 100.0, 50000.0, alpha=0.9)),
                                   orc.rescale_brightness(np.asarray(fix_img), 100.0, 50000.0, alpha=0.9))
     np.testing.assert_array_equal(solex_util.reject_outliers(np.array([1.0, 1.1, 0.9, 50.0])), orc.reject_outliers(np.array([1.0, 1.1, 0.9, 50.0])))
+
+
+def test_two_ranks_sharded_scan_equals_one_rank(pkg, scan, tmp_path):
+    """The sharded orchestration end to end: two processes (gloo, both on this GPU) each decode and reduce half
+    of the frames of ONE file, exchange sum/max and disk columns, rank 0 post-processes and writes.  Every
+    product must equal the single-process run bit for bit (integer reductions are order independent)."""
+    import subprocess
+    import sys
+    SHG_MAIN, Solex_recon, outputs = pkg
+    g, frames, path = scan
+    from solex_ser_recon_en_amd import fits_io, png_io
+    one = tmp_path / 'one'
+    two = tmp_path / 'two'
+    one.mkdir(); two.mkdir()
+    for d in (one, two):
+        synth.write_ser(str(d / 'scan.ser'), frames)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=repo, SHG_DIST_BACKEND='gloo', MPLBACKEND='Agg')
+    args = ['-cf', '-w-2,0', str(one / 'scan.ser')]
+    subprocess.run([sys.executable, '-m', 'solex_ser_recon_en_amd.SHG_MAIN'] + args, check=True, env=env, cwd=repo,
+                   stdout=subprocess.DEVNULL, timeout=600)
+    args2 = ['-cf', '-w-2,0', str(two / 'scan.ser')]
+    subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                    '--master-port', '29671', '-m', 'solex_ser_recon_en_amd.SHG_MAIN'] + args2, check=True, env=env, cwd=repo,
+                   stdout=subprocess.DEVNULL, timeout=600)
+    names = sorted(os.listdir(str(one)))
+    assert names == sorted(os.listdir(str(two))), 'rank 1 must not write anything, rank 0 everything'
+    assert 'scan_shift=-2_clahe.png' in names and 'scan_shift=0_raw.fits' in names and 'scan_mean.fits' in names
+    for name in names:
+        a, b = str(one / name), str(two / name)
+        if name.endswith('.png'):
+            np.testing.assert_array_equal(png_io.read_png_gray(a), png_io.read_png_gray(b), err_msg=name)
+        elif name.endswith('.fits'):
+            np.testing.assert_array_equal(fits_io.read_fits_u16(a)[0], fits_io.read_fits_u16(b)[0], err_msg=name)
