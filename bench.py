@@ -99,13 +99,12 @@ def main():
         opts = SHG_MAIN.default_options()
         opts['_nolog'] = True
         opts['shift'] = list(requested_shifts)
-        opts['_shard_frames'] = sharded
         rdr = array_reader(stack, frame_count=n_scan, frame_range=(k0, k0 + n_local) if sharded else None)
         with contextlib.redirect_stdout(io.StringIO()):
-            disk_list, bounds, hdr = Solex_recon.solex_read(rdr, opts)
-            if sharded and rank != 0:
-                return None
-            return Solex_recon.solex_process(opts, disk_list, bounds, hdr)
+            # the production entry point: sharded = collectives per scan (and the disks of a Doppler stack dealt to
+            # the ranks); folder = every rank processes its own scan
+            return Solex_recon.solex_do_work([(rdr, opts)], True, distribute='frames' if sharded else 'none',
+                                             return_results=True)
 
     def barrier():
         if world > 1:
@@ -175,14 +174,14 @@ def main():
         sample = stack[:n_cpu].cpu().numpy()
         t0 = time.perf_counter()
         with contextlib.redirect_stdout(io.StringIO()), np.errstate(all='ignore'):
-            ref = po.run(sample, {})
+            ref = po.run(sample, {'shift': list(requested_shifts)})
         t_cpu = time.perf_counter() - t0
         cpu = {'value': round(n_cpu / t_cpu, 1), 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
                'sample': 'the first %d frames of rank 0\'s stack through the whole path (oracle/pipeline_oracle.py, '
                          'NumPy, single thread like the reference\'s frame loops), %.1f s' % (n_cpu, t_cpu),
                'host_cpus': os.cpu_count()}
-        if out is not None and not sharded and n_cpu == n_local:
-            cc = np.asarray(out[0][0])
+        if out and not sharded and n_cpu == n_local and requested_shifts == [0]:
+            cc = np.asarray(out[0][0][0])
             want = ref['results'][0]['cc']
             d = np.abs(cc.astype(np.int64) - want.astype(np.int64)) if cc.shape == want.shape else None
             cpu['parity_vs_gpu'] = 'shape mismatch' if d is None else 'max |diff| %d LSB, %d of %d px differ' % (

@@ -61,17 +61,26 @@ class _Prefetch:
         return self.rdr
 
 
-def solex_do_work(tasks, flag_command_line=False):
-    """tasks: list of (file, options).  Raises on failure (the front door catches, SHG_MAIN.py:136-143)."""
+def solex_do_work(tasks, flag_command_line=False, distribute='auto', return_results=False):
+    """tasks: list of (file, options).  Raises on failure (the front door catches, SHG_MAIN.py:136-143).
+
+    distribute (only matters under torch.distributed with more than one rank):
+      'auto'   one file -> its frames are sharded over the ranks; several files -> file i goes to rank i mod G
+      'frames' shard the frames of every file over the ranks (collectives per file)
+      'none'   this rank processes exactly the tasks it was given (the caller already dealt the files)
+    return_results: also return the list of solex_process results (one list of (cc, protus) per processed file)."""
     tasks = list(tasks)
-    shard_frames = dist.active() and len(tasks) == 1
-    if dist.active() and not shard_frames:
+    if distribute not in ('auto', 'frames', 'none'):
+        raise ValueError("distribute must be 'auto', 'frames' or 'none'")
+    shard_frames = dist.active() and (distribute == 'frames' or (distribute == 'auto' and len(tasks) == 1))
+    if dist.active() and distribute == 'auto' and not shard_frames:
         tasks = tasks[dist.rank()::dist.world_size()]       # folder mode: file i belongs to rank i mod G
     block = dist.frame_block if shard_frames else None
 
     def start(i):
         file = tasks[i][0]
         return file if hasattr(file, 'device_stack') else _Prefetch(file, block)
+    collected = []
     try:
         nxt = start(0) if tasks else None
         for i, (file, options) in enumerate(tasks):
@@ -81,11 +90,18 @@ def solex_do_work(tasks, flag_command_line=False):
             rdr = cur.get() if isinstance(cur, _Prefetch) else cur
             disk_list, backup_bounds, hdr = solex_read(rdr, options)
             rdr._stack = None                               # release the frame stack before the next file's lands
-            if shard_frames and dist.rank() != 0:
-                continue                                    # the mosaic is post-processed and written once
-            solex_process(options, disk_list, backup_bounds, hdr)
+            if shard_frames:
+                n_requested = sum(1 for s in options['shift'] if s in options['shift_requested'])
+                if n_requested > 1:
+                    options['_deal_disks'] = True           # Doppler stack: every rank post-processes its share of the disks
+                elif dist.rank() != 0:
+                    continue                                # one disk: the mosaic is post-processed and written once
+            res = solex_process(options, disk_list, backup_bounds, hdr)
+            if return_results:
+                collected.append(res)
     finally:
         outputs.flush()
+    return collected if return_results else None
 
 
 def _writes_files(options):
@@ -128,6 +144,8 @@ def solex_read(file, options):
 def solex_process(options, disk_list, backup_bounds, hdr):
     """Circularise, de-transversalium, crop and contrast every requested disk."""
     basefich0 = options['basefich0']
+    if options.get('_deal_disks') and dist.active() and dist.rank() != 0:
+        options = _no_log(options)                            # products yes, shared log file no
     if options['transversalium']:
         logme(basefich0 + '_log.txt', options, 'Transversalium correction : ' + str(options['trans_strength']))
     else:
@@ -139,19 +157,35 @@ def solex_process(options, disk_list, backup_bounds, hdr):
     borders = [0, 0, 0, 0]
     cercle0 = (-1, -1, -1)
     results = []
+    # Frame-sharded Doppler stack: all ranks hold every raw disk after the gather; rank 0 fits the limb once and
+    # broadcasts the geometry, then the requested disks are dealt round-robin (rank 0 keeps the log file).
+    deal = bool(options.get('_deal_disks')) and dist.active()
+    turn = 0
     for i in range(len(disk_list)):
         flag_requested = options['shift'][i] in options['shift_requested']
         basefich = basefich0 + '_shift=' + str(options['shift'][i])
+        mine = True
+        if deal and flag_requested:
+            mine = turn % dist.world_size() == dist.rank()
+            turn += 1
         # disk_list[0] is always the ellipse-fit shift (more limb contrast)
         if options['ratio_fixe'] is None and options['slant_fix'] is None:
-            with timing.stage('ellipse_fit+warp'):
-                frame_circularized, cercle0, options['ratio_fixe'], phi, borders = ellipse_to_circle(
-                    disk_list[i], options, basefich)
+            if not deal or dist.rank() == 0:
+                with timing.stage('ellipse_fit+warp'):
+                    frame_circularized, cercle0, options['ratio_fixe'], phi, borders = ellipse_to_circle(
+                        disk_list[i], options, basefich)
+            if deal:
+                geometry = dist.broadcast_object((cercle0, options['ratio_fixe'], phi, borders) if dist.rank() == 0 else None)
+                cercle0, options['ratio_fixe'], phi, borders = geometry
+                if dist.rank() != 0 and flag_requested and mine:
+                    # the same warp the fit ran on rank 0 (centre / height only feed the returned circle)
+                    frame_circularized = correct_image(disk_list[i], phi, options['ratio_fixe'], np.array([-1.0, -1.0]),
+                                                       -1.0, dict(options, _nolog=True))[0]
             options['slant_fix'] = math.degrees(phi)          # stored in degrees (:117)
         else:
             ratio = options['ratio_fixe'] if options['ratio_fixe'] is not None else 1.0
             phi = math.radians(options['slant_fix']) if options['slant_fix'] is not None else 0.0
-            if flag_requested:
+            if flag_requested and mine:
                 with timing.stage('warp'):
                     frame_circularized = correct_image(disk_list[i], phi, ratio, np.array([-1.0, -1.0]), -1.0, options,
                                                        print_log=i == 0)[0]
@@ -160,11 +194,21 @@ def solex_process(options, disk_list, backup_bounds, hdr):
                         print("WARNING: cannot de-vignette without ellipse fit")
                     else:
                         frame_circularized = removeVignette(frame_circularized, cercle0)
-        if not flag_requested:
+        if not flag_requested or not mine:
             continue
-        results.append(single_image_process(frame_circularized, hdr, options, cercle0, borders, basefich, backup_bounds))
-        write_complete(basefich0 + '_log.txt', options)
+        popts = options if (not deal or dist.rank() == 0) else _no_log(options)
+        results.append(single_image_process(frame_circularized, hdr, popts, cercle0, borders, basefich, backup_bounds))
+        write_complete(basefich0 + '_log.txt', popts)
     return results
+
+
+class _no_log(dict):
+    """options of a rank that writes products but leaves the shared log file to rank 0:
+    logme / clearlog / write_complete look for the '_log_off' key."""
+
+    def __init__(self, options):
+        super().__init__(options)
+        self['_log_off'] = True
 
 
 def single_image_process(frame_circularized, hdr, options, cercle0, borders, basefich, backup_bounds):

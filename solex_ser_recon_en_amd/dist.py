@@ -92,3 +92,10 @@ def gather_columns(local, frame_range, n_total, flip_x=False):
     out = torch.zeros((s, ih, pitch), dtype=torch.int16, device=local.device)
     out[:, :, :n_total] = full
     return out.view(torch.uint16)[:, :, :n_total]
+
+
+def broadcast_object(obj, src=0):
+    """A small picklable object (the limb geometry: a dozen floats) from rank src to every rank."""
+    box = [obj]
+    td.broadcast_object_list(box, src=src)
+    return box[0]

@@ -37,20 +37,20 @@ def _append(path, options, text, mode):
 
 
 def clearlog(path, options):
-    if '_nolog' in options:
+    if '_nolog' in options or '_log_off' in options:
         return      # the reference only guards logme; a file-less mode should not create an empty log either
     _append(path, options, 'start time: ' + str(datetime.datetime.now()) + '\n', 'w')
 
 
 def write_complete(path, options):
-    if '_nolog' in options:
+    if '_nolog' in options or '_log_off' in options:
         return
     _append(path, options, 'end time: ' + str(datetime.datetime.now()) + '\n', 'a')
 
 
 def logme(path, options, s):
     """s may be a callable building the line: formatting arrays costs more than the kernels it reports on."""
-    if '_nolog' in options:
+    if '_nolog' in options or '_log_off' in options:
         return
     _append(path, options, (s() if callable(s) else s) + '\n', 'a')
 

@@ -211,6 +211,38 @@ def test_stage_functions_keep_the_reference_call_surface(pkg, scan):
     np.testing.assert_array_equal(solex_util.reject_outliers(np.array([1.0, 1.1, 0.9, 50.0])), orc.reject_outliers(np.array([1.0, 1.1, 0.9, 50.0])))
 
 
+@pytest.mark.parametrize('flags', ['-cf', '-f'])
+def test_two_ranks_doppler_stack_is_dealt_and_identical(pkg, scan, tmp_path, flags):
+    """Frame-sharded Doppler stack (-w-3:3:1, 7 requested disks): after the gather rank 0 fits the limb and
+    broadcasts the geometry, the disks are dealt round-robin, each rank writes its own products; the union of the
+    files equals the single-process run bit for bit."""
+    import subprocess
+    import sys
+    g, frames, path = scan
+    from solex_ser_recon_en_amd import fits_io, png_io
+    one = tmp_path / 'one'
+    two = tmp_path / 'two'
+    one.mkdir(); two.mkdir()
+    for d in (one, two):
+        synth.write_ser(str(d / 'scan.ser'), frames)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=repo, SHG_DIST_BACKEND='gloo', MPLBACKEND='Agg')
+    subprocess.run([sys.executable, '-m', 'solex_ser_recon_en_amd.SHG_MAIN', flags, '-w-3:3:1', str(one / 'scan.ser')], check=True,
+                   env=env, cwd=repo, stdout=subprocess.DEVNULL, timeout=900)
+    subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                    '--master-port', '29673', '-m', 'solex_ser_recon_en_amd.SHG_MAIN', flags, '-w-3:3:1', str(two / 'scan.ser')],
+                   check=True, env=env, cwd=repo, stdout=subprocess.DEVNULL, timeout=900)
+    names = sorted(os.listdir(str(one)))
+    assert names == sorted(os.listdir(str(two)))
+    assert sum(n.endswith('_clahe.png') for n in names) == 7
+    for name in names:
+        a, b = str(one / name), str(two / name)
+        if name.endswith('_clahe.png') or name.endswith('_protus.png') or name.endswith('contrast.png') or name.endswith('contrasted.png'):
+            np.testing.assert_array_equal(png_io.read_png_gray(a), png_io.read_png_gray(b), err_msg=name)
+        elif name.endswith('.fits'):
+            np.testing.assert_array_equal(fits_io.read_fits_u16(a)[0], fits_io.read_fits_u16(b)[0], err_msg=name)
+
+
 def test_two_ranks_sharded_scan_equals_one_rank(pkg, scan, tmp_path):
     """The sharded orchestration end to end: two processes (gloo, both on this GPU) each decode and reduce half
     of the frames of ONE file, exchange sum/max and disk columns, rank 0 post-processes and writes.  Every
