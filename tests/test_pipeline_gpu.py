@@ -275,3 +275,48 @@ def test_two_ranks_sharded_scan_equals_one_rank(pkg, scan, tmp_path):
             np.testing.assert_array_equal(png_io.read_png_gray(a), png_io.read_png_gray(b), err_msg=name)
         elif name.endswith('.fits'):
             np.testing.assert_array_equal(fits_io.read_fits_u16(a)[0], fits_io.read_fits_u16(b)[0], err_msg=name)
+
+
+@pytest.mark.parametrize('n,w,h,bits,extra', [
+    (220, 800, 120, 8, {}),                                            # BASELINE configs[0] shape, stored rotated
+    (220, 120, 800, 8, {'shift': [0, 5]}),                             # the same shape stored un-rotated (Width < Height)
+    (330, 640, 64, 16, {'flip_x': True, 'fixed_width': 500, 'delta_radius': 7}),
+    (260, 720, 96, 16, {'transversalium': False, 'img_rotate': 270, 'disk_display': False}),
+])
+def test_whole_flow_other_shapes_vs_oracle(pkg, n, w, h, bits, extra):
+    SHG_MAIN, Solex_recon, outputs = pkg
+    from solex_ser_recon_en_amd.video_reader import array_reader
+    frames = synth.synth_frames_numpy(n, w, h, bits, seed=n, tilt=0.004, curv=3e-5)
+    opts = SHG_MAIN.default_options()
+    opts.update(extra, _nolog=True)
+    disk_list, bounds, hdr = Solex_recon.solex_read(array_reader(torch.from_numpy(frames).cuda()), opts)
+    results = Solex_recon.solex_process(opts, disk_list, bounds, hdr)
+    with np.errstate(all='ignore'):
+        want = po.run(frames, extra)
+    for got, ref in zip(disk_list, want['read']['disks']):
+        np.testing.assert_array_equal(np.asarray(got), ref)
+    requested = [s for s in opts['shift'] if s in opts['shift_requested']]
+    for shift, (cc, protus) in zip(requested, results):
+        close_u16(cc, want['results'][shift]['cc'])
+        close_u16(protus, want['results'][shift]['protus'])
+
+
+def test_bad_files_raise_like_the_reference(pkg, tmp_path):
+    SHG_MAIN, Solex_recon, outputs = pkg
+    from solex_ser_recon_en_amd.video_reader import video_reader
+    frames = synth.synth_frames_numpy(6, 64, 16, 16, seed=0)
+    good = str(tmp_path / 'good.ser')
+    synth.write_ser(good, frames)
+    raw = open(good, 'rb').read()
+    cut = str(tmp_path / 'cut.ser')
+    open(cut, 'wb').write(raw[:-100])                                  # shorter than its header says
+    with pytest.raises(Exception, match='shorter than its header'):
+        video_reader(cut).device_stack()
+    empty = str(tmp_path / 'empty.ser')
+    open(empty, 'wb').write(synth.ser_header(64, 16, 16, 0))           # FrameCount = 0
+    with pytest.raises(Exception, match='no frames'):
+        video_reader(empty).device_stack()
+    stack = video_reader(good).device_stack()
+    np.testing.assert_array_equal(stack.cpu().numpy(), frames)
+    part = video_reader(good, frame_range=(2, 5)).device_stack()      # a rank's block of a sharded scan
+    np.testing.assert_array_equal(part.cpu().numpy(), frames[2:5])
