@@ -146,9 +146,14 @@ def main():
             traffic = rec['accumulate_bytes_per_launch'] if rec else None
         except Exception:      # noqa: BLE001
             traffic = None
+    from solex_ser_recon_en_amd import ops as _ops
+    ceiling, ceiling_shape = _ops.stream_read_ceiling(stack)
     roofline = {'kernel': 'k_accumulate_vec (pass A: sum+max over frames)', 'bound': 'hbm',
                 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
                 'traffic': traffic, 'algorithmic_bytes_per_launch': bytes_a,
+                'measured_read_ceiling': {'value': round(ceiling, 1), 'unit': 'GB/s', 'frac_of_it': round(ach / ceiling, 4) if ceiling else None,
+                                          'how': 'best of %d launch shapes of a trivial read-only kernel (shg_stream_read_probe) over the same stack, '
+                                                 'blocks x unroll = %s' % (8, ceiling_shape)},
                 'avg_launch_ms': round(acc_ms / acc_n, 5) if acc_n else None, 'launches': acc_n,
                 'secondary': {'kernel': 'k_extract (pass B)', 'algorithmic_bytes_per_launch': bytes_b,
                               'avg_launch_ms': round(ext_ms / ext_n, 5) if ext_n else None,

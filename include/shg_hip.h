@@ -50,6 +50,12 @@ int shg_profile_select(const char* tags_csv);   /* only time these tags (NULL or
 int shg_profile_reset(void);
 int shg_profile_get(const char* tag, double* total_ms, int64_t* launches);
 
+/* Measurement aid: a trivial grid-strided streaming read of `bytes` bytes (16 B/lane non-temporal loads,
+ * XOR-folded; out1024: 1024 uint32 words).  bench.py times it to quote a MEASURED read ceiling beside the
+ * spec peak. */
+int shg_stream_read_probe(const void* buf, int64_t bytes, int blocks, int unroll, uint32_t* out1024,
+                          shg_stream_t stream);
+
 /* ---- pass A: sum and max over frames -------- solex_util.py:174-188 (compute_mean_max)
  * stack: n_frames frames in file layout.  sum_out[H*W] (file layout) receives the
  * integer sum of the raw samples, max_out[H*W] their maximum (raw sample units;

@@ -370,3 +370,26 @@ def select_u16(img, ranks, out=None):
     _lib.check(lib.shg_select_u16(ptr, h, w, pitch, arr, len(ranks), out.data_ptr(), ws.data_ptr(), need, _stream()),
                'shg_select_u16')
     return out
+
+
+def stream_read_ceiling(buf, shapes=((384, 4), (512, 4), (768, 4), (1024, 4), (1536, 2), (2048, 2), (1024, 8), (4096, 1)), reps=5):
+    """Measured HBM read ceiling in GB/s: best of a few launch shapes of a trivial read-only kernel over `buf`
+    (a dense GPU tensor, ideally the frame stack itself).  Returns (GB/s, (blocks, unroll))."""
+    _dev(buf, 'buf')
+    nbytes = buf.numel() * buf.element_size()
+    out = torch.zeros(1024, dtype=torch.int32, device=buf.device)
+    best = (0.0, None)
+    for blocks, unroll in shapes:
+        times = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            _lib.check(lib.shg_stream_read_probe(buf.data_ptr(), nbytes, blocks, unroll, out.data_ptr(), _stream()),
+                       'shg_stream_read_probe')
+            b.record()
+            b.synchronize()
+            times.append(a.elapsed_time(b))
+        rate = nbytes / (min(times[1:]) * 1e-3) / 1e9
+        if rate > best[0]:
+            best = (rate, (blocks, unroll))
+    return best
