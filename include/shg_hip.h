@@ -191,6 +191,10 @@ int shg_box_blur_f64(const double* src, int64_t h, int64_t w, int k, double* dst
 size_t shg_select_workspace_bytes(int n_ranks);
 int shg_select_f64(const double* values, int64_t n, const int64_t* host_ranks, int n_ranks, double* out,
                    void* workspace, size_t workspace_bytes, shg_stream_t stream);
+/* the same for several arrays of one length in one launch sequence: out[i] = the host_ranks[i]-th smallest value of
+ * host_arrays[i] (HOST array of device pointers). */
+int shg_select_multi_f64(const double* const* host_arrays, int64_t n, const int64_t* host_ranks, int n_ranks,
+                         double* out, void* workspace, size_t workspace_bytes, shg_stream_t stream);
 
 /* get_flood_image's statistics (ellipse_to_circle.py:159-169): stats[0] = np.sum(image) (image
  * values are multiples of 2^-20, as the 4x4 block mean of uint16/65536 is), and over

@@ -57,6 +57,7 @@ SIGNATURES = {
     'shg_box_blur_f64': (c_int, [P, c_int64, c_int64, c_int, P, P, P]),
     'shg_select_workspace_bytes': (c_size_t, [c_int]),
     'shg_select_f64': (c_int, [P, c_int64, ctypes.POINTER(c_int64), c_int, P, P, c_size_t, P]),
+    'shg_select_multi_f64': (c_int, [ctypes.POINTER(c_void_p), c_int64, ctypes.POINTER(c_int64), c_int, P, P, c_size_t, P]),
     'shg_flood_stats_f64': (c_int, [P, P, c_int64, c_double, P, P, P, P]),
     'shg_edge_components_workspace_bytes': (c_size_t, [c_int64, c_int64]),
     'shg_edge_components': (c_int, [P, P, c_int64, c_int64, P, P, P, P, c_size_t, P]),

@@ -235,35 +235,48 @@ __device__ __forceinline__ void pick_digit(const uint32_t* __restrict__ hist, in
     __syncthreads();
 }
 
-// grid (row blocks, n_ranks), 256 threads
+// grid (row blocks), 256 threads.  hist layout: [0][256] = high-byte histogram shared by all ranks,
+// [1 + r][256] = low-byte histogram of rank r.  The image is read once per pass, whatever the number of ranks.
 __global__ __launch_bounds__(256) void k_select16_pass(const uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch, int pass,
-                                                       const int64_t* __restrict__ ranks, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t lh[256];
-    uint32_t* myhist = hist + (int64_t)blockIdx.y * 512;
-    int hi = 0;
-    int64_t below = 0;
-    if (pass == 1) pick_digit(myhist, ranks[blockIdx.y], hi, below);
-    lh[threadIdx.x] = 0;
+                                                       const int64_t* __restrict__ ranks, int n_ranks, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[8][256];
+    __shared__ int his[8];
+    const int nh = pass == 0 ? 1 : n_ranks;
+    if (pass == 1) {
+        for (int r = 0; r < n_ranks; ++r) {
+            int hi;
+            int64_t below;
+            pick_digit(hist, ranks[r], hi, below);
+            if (threadIdx.x == 0) his[r] = hi;
+        }
+    }
+    for (int r = 0; r < nh; ++r) lh[r][threadIdx.x] = 0;
     __syncthreads();
     for (int64_t y = blockIdx.x; y < h; y += gridDim.x) {
         const uint16_t* row = img + y * pitch;
         for (int64_t x = threadIdx.x; x < w; x += 256) {
             const uint32_t v = row[x];
-            if (pass == 0) atomicAdd(&lh[v >> 8], 1u);
-            else if ((int)(v >> 8) == hi) atomicAdd(&lh[v & 0xff], 1u);
+            if (pass == 0) {
+                atomicAdd(&lh[0][v >> 8], 1u);
+            } else {
+                const int hi = (int)(v >> 8);
+                for (int r = 0; r < n_ranks; ++r)
+                    if (hi == his[r]) atomicAdd(&lh[r][v & 0xff], 1u);
+            }
         }
     }
     __syncthreads();
-    if (lh[threadIdx.x]) atomicAdd(&myhist[pass * 256 + threadIdx.x], lh[threadIdx.x]);
+    for (int r = 0; r < nh; ++r)
+        if (lh[r][threadIdx.x]) atomicAdd(&hist[(pass == 0 ? 0 : 1 + r) * 256 + threadIdx.x], lh[r][threadIdx.x]);
 }
 
+// grid (n_ranks), 256 threads
 __global__ __launch_bounds__(256) void k_select16_final(const int64_t* __restrict__ ranks, const uint32_t* __restrict__ hist,
                                                         double* __restrict__ out) {
-    const uint32_t* myhist = hist + (int64_t)blockIdx.x * 512;
     int hi, lo;
     int64_t below, below2;
-    pick_digit(myhist, ranks[blockIdx.x], hi, below);
-    pick_digit(myhist + 256, ranks[blockIdx.x] - below, lo, below2);
+    pick_digit(hist, ranks[blockIdx.x], hi, below);
+    pick_digit(hist + (1 + blockIdx.x) * 256, ranks[blockIdx.x] - below, lo, below2);
     if (threadIdx.x == 0) out[blockIdx.x] = (double)((hi << 8) | lo);
 }
 
@@ -366,7 +379,7 @@ extern "C" int shg_hist(const void* img, int64_t h, int64_t w, int64_t pitch, in
 
 extern "C" size_t shg_select_u16_workspace_bytes(int n_ranks) {
     if (n_ranks < 1 || n_ranks > 8) return 0;
-    return (size_t)n_ranks * (512 * sizeof(uint32_t) + sizeof(int64_t));
+    return (size_t)(1 + n_ranks) * 256 * sizeof(uint32_t) + (size_t)n_ranks * sizeof(int64_t);
 }
 
 extern "C" int shg_select_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, const int64_t* host_ranks, int n_ranks,
@@ -378,14 +391,14 @@ extern "C" int shg_select_u16(const uint16_t* img, int64_t h, int64_t w, int64_t
         SHG_REQUIRE(host_ranks[i] >= 0 && host_ranks[i] < h * w, SHG_E_ARG, "shg_select_u16: rank %lld outside the image", (long long)host_ranks[i]);
     hipStream_t st = shg::as_stream(stream);
     uint32_t* hist = static_cast<uint32_t*>(workspace);
-    int64_t* ranks = reinterpret_cast<int64_t*>(hist + (size_t)n_ranks * 512);
-    hipError_t e = hipMemsetAsync(hist, 0, (size_t)n_ranks * 512 * sizeof(uint32_t), st);
+    int64_t* ranks = reinterpret_cast<int64_t*>(hist + (size_t)(1 + n_ranks) * 256);
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)(1 + n_ranks) * 256 * sizeof(uint32_t), st);
     if (e == hipSuccess) e = hipMemcpyAsync(ranks, host_ranks, n_ranks * sizeof(int64_t), hipMemcpyHostToDevice, st);
     if (e != hipSuccess) { shg::set_error("shg_select_u16: %s", hipGetErrorString(e)); return (int)e; }
     const unsigned blocks = (unsigned)(h < 256 ? h : 256);
     SHG_PROF("select_u16", st);
     for (int pass = 0; pass < 2; ++pass) {
-        k_select16_pass<<<dim3(blocks, (unsigned)n_ranks), 256, 0, st>>>(img, h, w, pitch, pass, ranks, hist);
+        k_select16_pass<<<blocks, 256, 0, st>>>(img, h, w, pitch, pass, ranks, n_ranks, hist);
         if (int err = shg::check_launch("k_select16_pass")) return err;
     }
     k_select16_final<<<(unsigned)n_ranks, 256, 0, st>>>(ranks, hist, out);

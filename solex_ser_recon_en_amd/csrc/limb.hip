@@ -204,9 +204,10 @@ __device__ __forceinline__ SelectState select_replay(const uint32_t* __restrict_
 }
 
 // grid (blocks, n_ranks).  hist: [n_ranks][8][256] u32, zeroed.
-__global__ __launch_bounds__(256) void k_select_pass(const double* __restrict__ v, int64_t n, int pass, const int64_t* __restrict__ ranks,
-                                                     uint32_t* __restrict__ hist) {
+__global__ __launch_bounds__(256) void k_select_pass(const double* const* __restrict__ arrays, int64_t n, int pass,
+                                                     const int64_t* __restrict__ ranks, uint32_t* __restrict__ hist) {
     __shared__ uint32_t lh[256];
+    const double* __restrict__ v = arrays[blockIdx.y];
     uint32_t* myhist = hist + (int64_t)blockIdx.y * 8 * 256;
     const SelectState st = select_replay(myhist, pass, ranks[blockIdx.y]);
     lh[threadIdx.x] = 0;
@@ -457,12 +458,20 @@ extern "C" int shg_canny_masks_f64(const double* blurred, int64_t h, int64_t w, 
 
 extern "C" size_t shg_select_workspace_bytes(int n_ranks) {
     if (n_ranks < 1 || n_ranks > 8) return 0;
-    return (size_t)n_ranks * (8 * 256 * sizeof(uint32_t) + sizeof(int64_t));
+    return (size_t)n_ranks * (8 * 256 * sizeof(uint32_t) + sizeof(int64_t) + sizeof(void*));
 }
 
 extern "C" int shg_select_f64(const double* values, int64_t n, const int64_t* host_ranks, int n_ranks, double* out,
                               void* workspace, size_t workspace_bytes, shg_stream_t stream) {
-    SHG_REQUIRE(values && host_ranks && out && workspace, SHG_E_ARG, "shg_select_f64: null pointer");
+    SHG_REQUIRE(values && n_ranks >= 1 && n_ranks <= 8, SHG_E_ARG, "shg_select_f64: bad arguments");
+    const double* same[8];
+    for (int i = 0; i < n_ranks; ++i) same[i] = values;
+    return shg_select_multi_f64(same, n, host_ranks, n_ranks, out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int shg_select_multi_f64(const double* const* host_arrays, int64_t n, const int64_t* host_ranks, int n_ranks, double* out,
+                                    void* workspace, size_t workspace_bytes, shg_stream_t stream) {
+    SHG_REQUIRE(host_arrays && host_ranks && out && workspace, SHG_E_ARG, "shg_select_f64: null pointer");
     SHG_REQUIRE(n > 0 && n_ranks >= 1 && n_ranks <= 8, SHG_E_ARG, "shg_select_f64: bad sizes");
     SHG_REQUIRE(workspace_bytes >= shg_select_workspace_bytes(n_ranks), SHG_E_WORKSPACE, "shg_select_f64: workspace too small");
     for (int i = 0; i < n_ranks; ++i)
@@ -471,14 +480,17 @@ extern "C" int shg_select_f64(const double* values, int64_t n, const int64_t* ho
     hipStream_t st = shg::as_stream(stream);
     uint32_t* hist = static_cast<uint32_t*>(workspace);
     int64_t* ranks = reinterpret_cast<int64_t*>(hist + (size_t)n_ranks * 8 * 256);
+    const double** arrays = reinterpret_cast<const double**>(ranks + n_ranks);
+    for (int i = 0; i < n_ranks; ++i) SHG_REQUIRE(host_arrays[i], SHG_E_ARG, "shg_select_f64: null array");
     hipError_t e = hipMemsetAsync(hist, 0, (size_t)n_ranks * 8 * 256 * sizeof(uint32_t), st);
     if (e == hipSuccess) e = hipMemcpyAsync(ranks, host_ranks, n_ranks * sizeof(int64_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(arrays, host_arrays, n_ranks * sizeof(void*), hipMemcpyHostToDevice, st);
     if (e != hipSuccess) { shg::set_error("shg_select_f64: %s", hipGetErrorString(e)); return (int)e; }
     int64_t blocks = (n + 2047) / 2048;
     if (blocks > 256) blocks = 256;
     SHG_PROF("select", st);
     for (int pass = 0; pass < 8; ++pass) {
-        k_select_pass<<<dim3((unsigned)blocks, (unsigned)n_ranks), 256, 0, st>>>(values, n, pass, ranks, hist);
+        k_select_pass<<<dim3((unsigned)blocks, (unsigned)n_ranks), 256, 0, st>>>(arrays, n, pass, ranks, hist);
         if (int err = shg::check_launch("k_select_pass")) return err;
     }
     k_select_final<<<(unsigned)n_ranks, 256, 0, st>>>(ranks, hist, out);

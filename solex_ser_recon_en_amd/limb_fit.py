@@ -124,7 +124,8 @@ def edge_points(small, sigma=2):
     blurred = ops.box_blur_f64(small, k)
     m_lo, m_hi, median = median_order_stats(n)
     p_lo, p_hi, p99 = lerp_order_stats(n, 99)
-    sel = torch.cat([ops.select_f64(ops.box_blur_f64(small, 5), [m_lo, m_hi]), ops.select_f64(blurred, [p_lo, p_hi])]).cpu().numpy()
+    blur5 = ops.box_blur_f64(small, 5)
+    sel = ops.select_multi_f64([blur5, blur5, blurred, blurred], [m_lo, m_hi, p_lo, p_hi]).cpu().numpy()
     low = median(sel[0], sel[1]) / 10                   # low_threshold = median(blur 5x5) / 10 (:241-242)
     high = low * 1.5
     very_bright = p99(sel[2], sel[3])                   # np.percentile(img_blurred, 99) (:165)

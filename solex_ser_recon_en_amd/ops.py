@@ -318,6 +318,26 @@ def select_f64(values, ranks):
     return out
 
 
+def select_multi_f64(arrays, ranks):
+    """out[i] = the ranks[i]-th smallest element of arrays[i] (dense float64 GPU tensors of one size), one launch sequence."""
+    import ctypes
+    if len(arrays) != len(ranks) or not 1 <= len(ranks) <= 8:
+        raise ValueError('select_multi_f64 takes 1..8 (array, rank) pairs')
+    n = arrays[0].numel()
+    for a in arrays:
+        _dev(a, 'array')
+        if a.dtype != torch.float64 or not a.is_contiguous() or a.numel() != n:
+            raise TypeError('select_multi_f64 needs dense float64 tensors of one size')
+    ptrs = (ctypes.c_void_p * len(arrays))(*[a.data_ptr() for a in arrays])
+    rk = (ctypes.c_int64 * len(ranks))(*[int(r) for r in ranks])
+    need = lib.shg_select_workspace_bytes(len(ranks))
+    ws = torch.empty(need, dtype=torch.uint8, device=arrays[0].device)
+    out = torch.empty(len(ranks), dtype=torch.float64, device=arrays[0].device)
+    _lib.check(lib.shg_select_multi_f64(ptrs, n, rk, len(ranks), out.data_ptr(), ws.data_ptr(), need, _stream()),
+               'shg_select_multi_f64')
+    return out
+
+
 def flood_stats(image, blurred, very_bright):
     """-> (stats float64 [3] = sum(image), min, max of blurred[blurred < very_bright]; counts int32 [20]) on the GPU."""
     _dev(image, 'image')
