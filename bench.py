@@ -148,12 +148,17 @@ def main():
             traffic = None
     from solex_ser_recon_en_amd import ops as _ops
     ceiling, ceiling_shape = _ops.stream_read_ceiling(stack)
+    frame_bytes = ih * iw * bpp
+    walk, walk_shape = _ops.stream_read_ceiling(stack, mode=2, vecs_per_frame=frame_bytes // 16) if frame_bytes % 16 == 0 else (0.0, None)
     roofline = {'kernel': 'k_accumulate_vec (pass A: sum+max over frames)', 'bound': 'hbm',
                 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
                 'traffic': traffic, 'algorithmic_bytes_per_launch': bytes_a,
                 'measured_read_ceiling': {'value': round(ceiling, 1), 'unit': 'GB/s', 'frac_of_it': round(ach / ceiling, 4) if ceiling else None,
                                           'how': 'best of %d launch shapes of a trivial read-only kernel (shg_stream_read_probe) over the same stack, '
                                                  'blocks x unroll = %s' % (8, ceiling_shape)},
+                'frame_walk_ceiling': {'value': round(walk, 1), 'unit': 'GB/s', 'frac_of_it': round(ach / walk, 4) if walk else None,
+                                       'how': 'the same XOR-only kernel with pass A\'s addresses (a lane walks the frame axis), best of 8 '
+                                              '(splits x unroll) = %s' % (walk_shape,)},
                 'avg_launch_ms': round(acc_ms / acc_n, 5) if acc_n else None, 'launches': acc_n,
                 'secondary': {'kernel': 'k_extract (pass B)', 'algorithmic_bytes_per_launch': bytes_b,
                               'avg_launch_ms': round(ext_ms / ext_n, 5) if ext_n else None,

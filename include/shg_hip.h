@@ -50,11 +50,13 @@ int shg_profile_select(const char* tags_csv);   /* only time these tags (NULL or
 int shg_profile_reset(void);
 int shg_profile_get(const char* tag, double* total_ms, int64_t* launches);
 
-/* Measurement aid: a trivial grid-strided streaming read of `bytes` bytes (16 B/lane non-temporal loads,
- * XOR-folded; out1024: 1024 uint32 words).  bench.py times it to quote a MEASURED read ceiling beside the
- * spec peak. */
-int shg_stream_read_probe(const void* buf, int64_t bytes, int blocks, int unroll, uint32_t* out1024,
-                          shg_stream_t stream);
+/* Measurement aid: trivial read-only kernels over `bytes` bytes (16 B/lane non-temporal loads, XOR-folded;
+ * out1024: 1024 uint32 words) that bench.py times to quote MEASURED read ceilings beside the spec peak
+ * (SURVEY.md section 8d).  mode 0: grid-strided contiguous sweep with `blocks` workgroups; mode 1: the same with
+ * pass A's arithmetic; mode 2: pass A's address pattern for frames of vecs_per_frame 16-byte vectors, `blocks`
+ * = frame-axis splits.  unroll: 1, 2, 4 or 8 loads in flight per lane. */
+int shg_stream_read_probe(const void* buf, int64_t bytes, int mode, int blocks, int unroll,
+                          int64_t vecs_per_frame, uint32_t* out1024, shg_stream_t stream);
 
 /* ---- pass A: sum and max over frames -------- solex_util.py:174-188 (compute_mean_max)
  * stack: n_frames frames in file layout.  sum_out[H*W] (file layout) receives the

@@ -30,7 +30,7 @@ SIGNATURES = {
     'shg_profile_select': (c_int, [ctypes.c_char_p]),
     'shg_profile_reset': (c_int, []),
     'shg_profile_get': (c_int, [ctypes.c_char_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int64)]),
-    'shg_stream_read_probe': (c_int, [P, c_int64, c_int, c_int, P, P]),
+    'shg_stream_read_probe': (c_int, [P, c_int64, c_int, c_int, c_int, c_int64, P, P]),
     'shg_accumulate_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int64, c_int]),
     'shg_accumulate_sum_max': (c_int, [P, c_int64, c_int64, c_int64, c_int, P, P, P, c_size_t, P]),
     'shg_finalize_mean_max': (c_int, [P, P, c_int64, c_int64, c_int64, c_int, P, P, P]),

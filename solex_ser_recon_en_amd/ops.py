@@ -392,10 +392,14 @@ def select_u16(img, ranks, out=None):
     return out
 
 
-def stream_read_ceiling(buf, shapes=((384, 4), (512, 4), (768, 4), (1024, 4), (1536, 2), (2048, 2), (1024, 8), (4096, 1)), reps=5):
+def stream_read_ceiling(buf, mode=0, vecs_per_frame=0, shapes=None, reps=5):
     """Measured HBM read ceiling in GB/s: best of a few launch shapes of a trivial read-only kernel over `buf`
-    (a dense GPU tensor, ideally the frame stack itself).  Returns (GB/s, (blocks, unroll))."""
+    (a dense GPU tensor, ideally the frame stack itself).  mode 0: contiguous sweep (shapes = (workgroups, unroll));
+    mode 2: pass A's frame-walking addresses (shapes = (frame splits, unroll)).  Returns (GB/s, best shape)."""
     _dev(buf, 'buf')
+    if shapes is None:
+        shapes = (((384, 4), (512, 4), (768, 4), (1024, 4), (768, 2), (1536, 2), (2048, 2), (512, 8)) if mode != 2
+                  else ((1, 8), (2, 4), (1, 4), (2, 2), (3, 2), (4, 2), (2, 8), (3, 4)))
     nbytes = buf.numel() * buf.element_size()
     out = torch.zeros(1024, dtype=torch.int32, device=buf.device)
     best = (0.0, None)
@@ -404,8 +408,8 @@ def stream_read_ceiling(buf, shapes=((384, 4), (512, 4), (768, 4), (1024, 4), (1
         for _ in range(reps):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            _lib.check(lib.shg_stream_read_probe(buf.data_ptr(), nbytes, blocks, unroll, out.data_ptr(), _stream()),
-                       'shg_stream_read_probe')
+            _lib.check(lib.shg_stream_read_probe(buf.data_ptr(), nbytes, int(mode), int(blocks), int(unroll), int(vecs_per_frame),
+                                                 out.data_ptr(), _stream()), 'shg_stream_read_probe')
             b.record()
             b.synchronize()
             times.append(a.elapsed_time(b))
