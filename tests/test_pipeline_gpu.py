@@ -37,6 +37,13 @@ def scan(golden, tmp_path_factory):
     return g, frames, path
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
 def close_u16(got, want, max_flips=4):
     assert got.shape == want.shape
     diff = np.abs(np.asarray(got).astype(np.int64) - np.asarray(want).astype(np.int64))
@@ -230,7 +237,7 @@ def test_two_ranks_doppler_stack_is_dealt_and_identical(pkg, scan, tmp_path, fla
     subprocess.run([sys.executable, '-m', 'solex_ser_recon_en_amd.SHG_MAIN', flags, '-w-3:3:1', str(one / 'scan.ser')], check=True,
                    env=env, cwd=repo, stdout=subprocess.DEVNULL, timeout=900)
     subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
-                    '--master-port', '29673', '-m', 'solex_ser_recon_en_amd.SHG_MAIN', flags, '-w-3:3:1', str(two / 'scan.ser')],
+                    '--master-port', str(free_port()), '-m', 'solex_ser_recon_en_amd.SHG_MAIN', flags, '-w-3:3:1', str(two / 'scan.ser')],
                    check=True, env=env, cwd=repo, stdout=subprocess.DEVNULL, timeout=900)
     names = sorted(os.listdir(str(one)))
     assert names == sorted(os.listdir(str(two)))
@@ -264,7 +271,7 @@ def test_two_ranks_sharded_scan_equals_one_rank(pkg, scan, tmp_path):
                    stdout=subprocess.DEVNULL, timeout=600)
     args2 = ['-cf', '-w-2,0', str(two / 'scan.ser')]
     subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
-                    '--master-port', '29671', '-m', 'solex_ser_recon_en_amd.SHG_MAIN'] + args2, check=True, env=env, cwd=repo,
+                    '--master-port', str(free_port()), '-m', 'solex_ser_recon_en_amd.SHG_MAIN'] + args2, check=True, env=env, cwd=repo,
                    stdout=subprocess.DEVNULL, timeout=600)
     names = sorted(os.listdir(str(one)))
     assert names == sorted(os.listdir(str(two))), 'rank 1 must not write anything, rank 0 everything'
