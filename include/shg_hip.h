@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SHG_ABI_VERSION 2
+#define SHG_ABI_VERSION 3
 
 #define SHG_E_ARG        (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SHG_E_WORKSPACE  (-2)   /* workspace too small                                 */
@@ -139,10 +139,11 @@ int shg_line_order_stats_u16(const uint16_t* img, int64_t h, int64_t w, int64_t 
                              shg_stream_t stream);
 
 /* ---- crop / pad -------------------------------- Solex_recon.py:155-171
- * dst[h][nw] = fill everywhere, then dst[:, dx0:dx0+n] = src[:, sx0:sx0+n]. */
+ * dst[h][nw] = fill everywhere, then dst[:, dx0:dx0+n] = src[:, sx0:sx0+n].
+ * fill: 0..65535, or negative = src[0][0] read on the device (np.full(.., img[0, 0]), :161). */
 int shg_crop_pad_u16(const uint16_t* src, int64_t h, int64_t w, int64_t pitch,
                      uint16_t* dst, int64_t nw, int64_t dst_pitch,
-                     int64_t sx0, int64_t dx0, int64_t n, uint16_t fill, shg_stream_t stream);
+                     int64_t sx0, int64_t dx0, int64_t n, int32_t fill, shg_stream_t stream);
 
 /* ---- CLAHE -------------------------------------- solex_util.py:532-533, clahe_apply.py:247
  * cv2.createCLAHE(clipLimit, (tiles, tiles)).apply(img) for uint16 (hist_size 65536)

@@ -28,8 +28,8 @@ from . import dist, ops, outputs, timing
 from .device import DeviceImage, to_device_u16
 from .ellipse_to_circle import correct_image, ellipse_to_circle
 from .fits_io import write_fits
-from .solex_util import (as_uint16_image, clearlog, compute_mean_return_fit, correct_transversalium2, extract_disks,
-                         image_process, logme, make_header, output_path, removeVignette, write_complete)
+from .solex_util import (as_uint16_image, clearlog, compute_mean_return_fit, correct_transversalium2_batch, extract_disks,
+                         image_process_batch, logme, make_header, output_path, removeVignette, write_complete)
 from .video_reader import video_reader
 
 
@@ -157,6 +157,7 @@ def solex_process(options, disk_list, backup_bounds, hdr):
     borders = [0, 0, 0, 0]
     cercle0 = (-1, -1, -1)
     results = []
+    pending = []
     # Frame-sharded Doppler stack: all ranks hold every raw disk after the gather; rank 0 fits the limb once and
     # broadcasts the geometry, then the requested disks are dealt round-robin (rank 0 keeps the log file).
     deal = bool(options.get('_deal_disks')) and dist.active()
@@ -196,9 +197,14 @@ def solex_process(options, disk_list, backup_bounds, hdr):
                         frame_circularized = removeVignette(frame_circularized, cercle0)
         if not flag_requested or not mine:
             continue
-        popts = options if (not deal or dist.rank() == 0) else _no_log(options)
-        results.append(single_image_process(frame_circularized, hdr, popts, cercle0, borders, basefich, backup_bounds))
-        write_complete(basefich0 + '_log.txt', popts)
+        pending.append((frame_circularized, basefich))
+    # every requested disk of the file shares the geometry (cercle0 / borders are those of the one limb fit), so
+    # the per-disk stages run as a batch: all kernels of a stage are launched before its single device->host read
+    popts = options if (not deal or dist.rank() == 0) else _no_log(options)
+    if pending:
+        results = process_images([f for f, _ in pending], hdr, popts, cercle0, borders, [b for _, b in pending], backup_bounds)
+        for _ in pending:
+            write_complete(basefich0 + '_log.txt', popts)
     return results
 
 
@@ -212,33 +218,38 @@ class _no_log(dict):
 
 
 def single_image_process(frame_circularized, hdr, options, cercle0, borders, basefich, backup_bounds):
+    return process_images([frame_circularized], hdr, options, cercle0, borders, [basefich], backup_bounds)[0]
+
+
+def process_images(frames, hdr, options, cercle0, borders, basefichs, backup_bounds):
+    """single_image_process (Solex_recon.py:136-174) for a list of circularised frames of one file:
+    transversalium, crop, CLAHE + contrast products.  Returns [(cc, frame_protus), ...]."""
     if options['save_fit']:
-        outputs.submit(write_fits, output_path(basefich + '_circular.fits', options),
-                       _as_image(frame_circularized), hdr)
+        for frame, basefich in zip(frames, basefichs):
+            outputs.submit(write_fits, output_path(basefich + '_circular.fits', options), _as_image(frame), hdr)
 
     with timing.stage('transversalium'):
         if options['transversalium']:
             if not cercle0 == (-1, -1, -1):
-                detransversaliumed = correct_transversalium2(frame_circularized, cercle0, borders, options, 0, basefich)
+                detrans = correct_transversalium2_batch(frames, cercle0, borders, options, 0, basefichs)
             else:
-                detransversaliumed = correct_transversalium2(
-                    frame_circularized, (0, 0, 99999),
-                    [0, backup_bounds[0] + 20, frame_circularized.shape[1] - 1, backup_bounds[1] - 20], options, 0, basefich)
+                detrans = correct_transversalium2_batch(
+                    frames, (0, 0, 99999),
+                    [0, backup_bounds[0] + 20, frames[0].shape[1] - 1, backup_bounds[1] - 20], options, 0, basefichs)
         else:
-            detransversaliumed = frame_circularized
+            detrans = list(frames)
 
     if options['save_fit'] and options['transversalium']:
-        outputs.submit(write_fits, output_path(basefich + '_detransversaliumed.fits', options),
-                       _as_image(detransversaliumed), hdr)
+        for img, basefich in zip(detrans, basefichs):
+            outputs.submit(write_fits, output_path(basefich + '_detransversaliumed.fits', options), _as_image(img), hdr)
 
     cercle = cercle0
     # A de-vignetted frame that skipped the transversalium stage is still float64 here; the reference crops
     # the float image and truncates in image_process (solex_util.py:528).  Cropping is a pure copy, so
     # truncating first gives the same pixels (and the same fill value img[0, 0]).
-    detransversaliumed = as_uint16_image(detransversaliumed)
+    detrans = [as_uint16_image(img) for img in detrans]
     if options['fixed_width'] is not None or options['crop_width_square']:
-        src = to_device_u16(detransversaliumed)
-        h, w = src.shape
+        h, w = detrans[0].shape
         nw = h if options['fixed_width'] is None else options['fixed_width']
         nw2 = nw // 2
         cx = w // 2 if cercle == (-1, -1, -1) else int(cercle[0])
@@ -247,16 +258,16 @@ def single_image_process(frame_circularized, hdr, options, cercle0, borders, bas
         # new_img[:, :hi-lo] = img[:, lo:hi]; then np.roll by tx when tx > 0 and refill the first tx columns (:161-167).
         # The rolled-in tail is fill colour whenever the copied span fits, which it does: hi - lo <= nw - tx.
         n = max(hi - lo, 0)
-        fill = int(src.view(torch.int16)[0, 0].item()) & 0xffff      # img[0, 0]
         dx0 = tx if tx > 0 else 0
         if dx0 + n > nw:
             n = nw - dx0            # np.roll would wrap these columns round and the refill overwrite them
-        detransversaliumed = DeviceImage(ops.crop_pad_u16(src, nw, lo, dx0, n, fill))
+        # the fill colour img[0, 0] is read on the device (no host round trip per image)
+        detrans = [DeviceImage(ops.crop_pad_u16(to_device_u16(img), nw, lo, dx0, n, None)) for img in detrans]
         if not cercle == (-1, -1, -1):
             cercle = (nw2, cercle[1], cercle[2])
 
     with timing.stage('clahe+contrast'):
-        return image_process(detransversaliumed, cercle, options, hdr, basefich)
+        return image_process_batch(detrans, cercle, options, hdr, basefichs)
 
 
 def _as_image(x):

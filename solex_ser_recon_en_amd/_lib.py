@@ -45,7 +45,7 @@ SIGNATURES = {
     'shg_line_order_stats_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int64, c_int64, P, P, P]),
     'shg_scale_rows_u16': (c_int, [P, c_int64, c_int64, c_int64, P, P, P, c_int64, P]),
     'shg_crop_pad_u16': (c_int, [P, c_int64, c_int64, c_int64, P, c_int64, c_int64, c_int64, c_int64, c_int64,
-                                 c_uint16, P]),
+                                 c_int, P]),
     'shg_clahe_workspace_bytes': (c_size_t, [c_int, c_int]),
     'shg_clahe': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_double, c_int, P, c_int64, P, c_size_t, P]),
     'shg_hist': (c_int, [P, c_int64, c_int64, c_int64, c_int, P, P]),
@@ -71,7 +71,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 if lib.shg_abi_version() != ABI_VERSION:
     raise ImportError('libshg_hip.so ABI %d != expected %d: rebuild it' % (lib.shg_abi_version(), ABI_VERSION))
 

@@ -8,10 +8,11 @@ namespace {
 
 __global__ __launch_bounds__(256) void k_crop_pad(const uint16_t* __restrict__ src, int64_t pitch, uint16_t* __restrict__ dst,
                                                   int64_t nw, int64_t dst_pitch, int64_t sx0, int64_t dx0, int64_t n,
-                                                  uint16_t fill) {
+                                                  uint16_t fill, int fill_is_src00) {
     const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t y = blockIdx.y;
     if (x >= nw) return;
+    if (fill_is_src00) fill = src[0];                   // np.full(..., img[0, 0]) without a host round trip
     const int64_t j = x - dx0;
     dst[y * dst_pitch + x] = (j >= 0 && j < n) ? src[y * pitch + sx0 + j] : fill;
 }
@@ -69,13 +70,14 @@ __global__ __launch_bounds__(256) void k_downscale_mean(const uint16_t* __restri
 }  // namespace
 
 extern "C" int shg_crop_pad_u16(const uint16_t* src, int64_t h, int64_t w, int64_t pitch, uint16_t* dst, int64_t nw,
-                                int64_t dst_pitch, int64_t sx0, int64_t dx0, int64_t n, uint16_t fill, shg_stream_t stream) {
+                                int64_t dst_pitch, int64_t sx0, int64_t dx0, int64_t n, int32_t fill, shg_stream_t stream) {
     SHG_REQUIRE(src && dst, SHG_E_ARG, "shg_crop_pad_u16: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && nw > 0 && pitch >= w && dst_pitch >= nw, SHG_E_ARG, "shg_crop_pad_u16: bad image size");
     SHG_REQUIRE(n >= 0 && sx0 >= 0 && sx0 + n <= w && dx0 >= 0 && dx0 + n <= nw, SHG_E_ARG, "shg_crop_pad_u16: copy window outside the images");
     SHG_REQUIRE(h < 65536, SHG_E_UNSUPPORTED, "shg_crop_pad_u16: more than 65535 rows");
+    SHG_REQUIRE(fill <= 65535, SHG_E_ARG, "shg_crop_pad_u16: fill must be 0..65535, or negative for src[0][0]");
     dim3 grid((unsigned)((nw + 255) / 256), (unsigned)h);
-    { SHG_PROF("crop_pad", shg::as_stream(stream)); k_crop_pad<<<grid, 256, 0, shg::as_stream(stream)>>>(src, pitch, dst, nw, dst_pitch, sx0, dx0, n, fill); }
+    { SHG_PROF("crop_pad", shg::as_stream(stream)); k_crop_pad<<<grid, 256, 0, shg::as_stream(stream)>>>(src, pitch, dst, nw, dst_pitch, sx0, dx0, n, (uint16_t)(fill < 0 ? 0 : fill), fill < 0 ? 1 : 0); }
     return shg::check_launch("k_crop_pad");
 }
 

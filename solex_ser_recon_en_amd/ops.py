@@ -163,10 +163,12 @@ def _row_factor_ptr(row_factor, h, device):
 def rowpair_logratio_stats(img, y1, y2, xa, xb, row_factor=None):
     """xa, xb: int32 host arrays [y2-y1] of NumPy-normalised slice bounds. -> float64 tensor [y2-y1]."""
     ptr, h, w, pitch = _img(img, 'img', torch.uint16)
-    xa = torch.as_tensor(np.ascontiguousarray(xa, dtype=np.int32)).to(img.device)
-    xb = torch.as_tensor(np.ascontiguousarray(xb, dtype=np.int32)).to(img.device)
-    if xa.numel() != y2 - y1 or xb.numel() != y2 - y1:
-        raise ValueError('xa, xb must have y2 - y1 entries')
+    if not isinstance(xa, torch.Tensor):
+        xa = torch.as_tensor(np.ascontiguousarray(xa, dtype=np.int32)).to(img.device)
+    if not isinstance(xb, torch.Tensor):
+        xb = torch.as_tensor(np.ascontiguousarray(xb, dtype=np.int32)).to(img.device)
+    if xa.numel() != y2 - y1 or xb.numel() != y2 - y1 or xa.dtype != torch.int32 or xb.dtype != torch.int32:
+        raise ValueError('xa, xb must be int32 with y2 - y1 entries')
     rf, rf_ptr = _row_factor_ptr(row_factor, h, img.device)
     out = torch.empty(y2 - y1, dtype=torch.float64, device=img.device)
     _lib.check(lib.shg_rowpair_logratio_stats(ptr, h, w, pitch, int(y1), int(y2), xa.data_ptr(), xb.data_ptr(), rf_ptr,
@@ -197,10 +199,11 @@ def line_order_stats_u16(img, axis, rank_lo, rank_hi):
 
 
 def crop_pad_u16(img, nw, sx0, dx0, n, fill):
+    """fill: 0..65535, or None for img[0, 0] (read on the device)."""
     ptr, h, w, pitch = _img(img, 'img', torch.uint16)
     out = pitched_u16(h, nw, img.device)
     _lib.check(lib.shg_crop_pad_u16(ptr, h, w, pitch, out.data_ptr(), int(nw), out.stride(0), int(sx0), int(dx0),
-                                    int(n), int(fill), _stream()), 'shg_crop_pad_u16')
+                                    int(n), -1 if fill is None else int(fill), _stream()), 'shg_crop_pad_u16')
     return out
 
 

@@ -222,32 +222,78 @@ def _chord_bounds(circle, borders, y1, y2, w):
     return xa, xb
 
 
-def correct_transversalium2(img, circle, borders, options, reqFlag, basefich):
-    from scipy.signal import savgol_filter
+def _savgol_rows(y, window):
+    """scipy.signal.savgol_filter(row, window, 3) (mode 'interp') for every row of y [k, n], bit-identical to k
+    separate calls: the interior is one correlate1d along the rows (row-independent arithmetic), the two edges
+    are the same np.polyfit / np.polyval per row that SciPy's _fit_edge performs (a multi-right-hand-side
+    lstsq would depend on k in the last bits)."""
+    from scipy.ndimage import convolve1d
+    from scipy.signal import savgol_coeffs
+    if y.shape[0] == 1:
+        from scipy.signal import savgol_filter
+        return savgol_filter(y, window, 3, axis=-1)
+    n = y.shape[-1]
+    if window > n:
+        raise ValueError("If mode is 'interp', window_length must be less than or equal to the size of x.")
+    out = convolve1d(y, savgol_coeffs(window, 3), axis=-1, mode='constant')
+    half = window // 2
+    for row_in, row_out in zip(y, out):
+        head = np.polyfit(np.arange(0, window), row_in[:window], 3)
+        row_out[:half] = np.polyval(head, np.arange(0, half))
+        tail = np.polyfit(np.arange(0, window), row_in[n - window:], 3)
+        row_out[n - half:] = np.polyval(tail, np.arange(window - half, window))
+    return out
+
+
+def transversalium_factors(y_ratios_r, trans_strength):
+    """Row correction factors from the robust row-pair log-ratios (solex_util.py:400-404, 456-472).
+    y_ratios_r: [n] or [k, n] (k disks of one Doppler stack, same geometry).  Every row is processed exactly as
+    a separate call would, so a disk's result does not depend on which other disks share the batch."""
+    y = np.atleast_2d(np.asarray(y_ratios_r, dtype=np.float64))
+    n = y.shape[-1]
+    trend = _savgol_rows(y, min(trans_strength, n // 2 * 2 - 1))
+    detrended = y - trend
+    for row in detrended:
+        row -= np.mean(row)
+    correction = np.exp(-np.cumsum(detrended, axis=-1))
+    out = np.ones(n) + (correction - np.ones(n)) * _tukey(n)
+    return out if np.ndim(y_ratios_r) == 2 else out[0]
+
+
+def correct_transversalium2_batch(imgs, circle, borders, options, reqFlag, basefichs):
+    """correct_transversalium2 for several frames that share circle / borders / shape (the disks of a Doppler
+    stack): all row statistics are launched before the single device->host read, and the 1-D control plane runs
+    once on the [k, n] matrix."""
     if options.get('stubborn_transversalium'):
         raise NotImplementedError('stubborn transversalium (cv2.filter2D path, solex_util.py:415-423) is out of scope')
-    row_factor = img.row_factor if isinstance(img, DeviceImage) else None     # a de-vignetted (float64) frame
-    t = img.t if row_factor is not None else to_device_u16(img)
-    h, w = t.shape
+    factors = [img.row_factor if isinstance(img, DeviceImage) else None for img in imgs]       # de-vignetted (float64) frames
+    tensors = [img.t if rf is not None else to_device_u16(img) for img, rf in zip(imgs, factors)]
+    h, w = tensors[0].shape
+    if any(t.shape != (h, w) for t in tensors):
+        raise ValueError('correct_transversalium2_batch: the frames must share one shape')
     y1 = math.ceil(max(circle[1] - circle[2], borders[1]))
     y2 = math.floor(min(circle[1] + circle[2], borders[3]))
-    xa, xb = _chord_bounds(circle, borders, y1, y2, w)
     if y2 - y1 >= 1:
-        y_ratios_r = ops.rowpair_logratio_stats(t, y1, y2, xa, xb, row_factor).cpu().numpy()
+        xa, xb = _chord_bounds(circle, borders, y1, y2, w)
+        xa_d = torch.from_numpy(xa).to(tensors[0].device)
+        xb_d = torch.from_numpy(xb).to(tensors[0].device)
+        ratios = torch.stack([ops.rowpair_logratio_stats(t, y1, y2, xa_d, xb_d, rf) for t, rf in zip(tensors, factors)]).cpu().numpy()
     else:
-        y_ratios_r = np.array([0.0])                                                  # y_ratios_r = [0], :386
-    trend = savgol_filter(y_ratios_r, min(options['trans_strength'], len(y_ratios_r) // 2 * 2 - 1), 3)
-    detrended = y_ratios_r - trend
-    detrended -= np.mean(detrended)
-    correction = np.exp(-np.cumsum(detrended))
-    n = correction.shape[0]
-    correction_t = np.ones(n) + (correction - np.ones(n)) * _tukey(n)
-    c = np.ones(h)
-    c[y1:y2] = correction_t
-    options['_transversalium_cache'] = c
-    if (not reqFlag) and _plots_enabled(options):
-        outputs.submit(outputs.plot_transversalium, output_path(basefich + '_transversalium_correction.png', options), c)
-    return DeviceImage(ops.scale_rows_u16(t, c, row_factor))
+        ratios = np.zeros((len(tensors), 1))                                          # y_ratios_r = [0], :386
+    correction_t = transversalium_factors(ratios, options['trans_strength'])
+    out = []
+    for i, (t, rf) in enumerate(zip(tensors, factors)):
+        c = np.ones(h)
+        c[y1:y2] = correction_t[i]
+        options['_transversalium_cache'] = c
+        if (not reqFlag) and _plots_enabled(options):
+            outputs.submit(outputs.plot_transversalium, output_path(basefichs[i] + '_transversalium_correction.png', options), c)
+        out.append(DeviceImage(ops.scale_rows_u16(t, c, rf)))
+    return out
+
+
+def correct_transversalium2(img, circle, borders, options, reqFlag, basefich):
+    return correct_transversalium2_batch([img], circle, borders, options, reqFlag, [basefich])[0]
 
 
 # ---- removeVignette (reference solex_util.py:590-654) ----------------------------------------------
@@ -356,44 +402,57 @@ def _rot90(t, k):
 
 
 # ---- a11: CLAHE + contrast products + writers (reference solex_util.py:527-588) ---------------
-def image_process(frame, cercle, options, header, basefich):
-    frame_t = to_device_u16(as_uint16_image(frame))               # frame.astype(np.uint16), :528
+def image_process_batch(frames, cercle, options, header, basefichs):
+    """image_process for several frames of one shape: CLAHE and the order statistics of every frame are launched
+    before the single device->host read of their 5 scalars each."""
     from .limb_fit import lerp_order_stats
-    cl1 = ops.clahe(frame_t, 0.8, 2)
-    n_px = frame_t.shape[0] * frame_t.shape[1]
-    b_lo, b_hi, b_mix = lerp_order_stats(n_px, 99.9999)
-    d_lo, d_hi, d_mix = lerp_order_stats(n_px, 10)
-    stats = torch.empty(5, dtype=torch.float64, device=frame_t.device)
-    ops.select_u16(frame_t, [b_lo, b_hi], out=stats[0:2])           # np.percentile needs two order statistics
-    ops.select_u16(cl1, [d_lo, d_hi, n_px - 1], out=stats[2:5])     # ... and np.max is the last one
+    tensors = [to_device_u16(as_uint16_image(f)) for f in frames]                       # frame.astype(np.uint16), :528
+    stats = torch.empty((len(tensors), 5), dtype=torch.float64, device=tensors[0].device)
+    cl1s = []
+    for i, frame_t in enumerate(tensors):
+        cl1 = ops.clahe(frame_t, 0.8, 2)
+        n_px = frame_t.shape[0] * frame_t.shape[1]
+        b_lo, b_hi, b_mix = lerp_order_stats(n_px, 99.9999)
+        d_lo, d_hi, d_mix = lerp_order_stats(n_px, 10)
+        ops.select_u16(frame_t, [b_lo, b_hi], out=stats[i, 0:2])        # np.percentile needs two order statistics
+        ops.select_u16(cl1, [d_lo, d_hi, n_px - 1], out=stats[i, 2:5])  # ... and np.max is the last one
+        cl1s.append((cl1, b_mix, d_mix))
     stats = stats.cpu().numpy()
-    bright = b_mix(stats[0], stats[1])                              # basically the same as max
-    dark_clahe = d_mix(stats[2], stats[3])
-    bright_clahe = int(stats[4])
-    frame_raw = frame_t
-    assert 65535 >= bright > bright * 0.25 and 65535 >= bright * 0.18 > 0 and 65535 >= bright_clahe > dark_clahe
-    frame_HC = ops.rescale_u16(frame_t, bright * 0.25, bright)
-    frame_protus = ops.rescale_u16(frame_t, 0, bright * 0.18)
-    cc = ops.rescale_u16(cl1, dark_clahe, bright_clahe)
-    if not cercle == (-1, -1, -1) and options['disk_display']:
-        x0 = int(cercle[0])
-        y0 = int(cercle[1])
-        r = int(cercle[2]) + options['delta_radius']
-        if r > 0:
-            ops.fill_disc_u16(frame_protus, x0, y0, r, 80)
+    results = []
+    for i, (frame_t, (cl1, b_mix, d_mix)) in enumerate(zip(tensors, cl1s)):
+        basefich = basefichs[i]
+        bright = b_mix(stats[i, 0], stats[i, 1])                        # basically the same as max
+        dark_clahe = d_mix(stats[i, 2], stats[i, 3])
+        bright_clahe = int(stats[i, 4])
+        frame_raw = frame_t
+        assert 65535 >= bright > bright * 0.25 and 65535 >= bright * 0.18 > 0 and 65535 >= bright_clahe > dark_clahe
+        frame_HC = ops.rescale_u16(frame_t, bright * 0.25, bright)
+        frame_protus = ops.rescale_u16(frame_t, 0, bright * 0.18)
+        cc = ops.rescale_u16(cl1, dark_clahe, bright_clahe)
+        if not cercle == (-1, -1, -1) and options['disk_display']:
+            x0 = int(cercle[0])
+            y0 = int(cercle[1])
+            r = int(cercle[2]) + options['delta_radius']
+            if r > 0:
+                ops.fill_disc_u16(frame_protus, x0, y0, r, 80)
 
-    k = options['img_rotate'] // 90
-    frame_raw, frame_HC, frame_protus, cc = (_rot90(x, k) for x in (frame_raw, frame_HC, frame_protus, cc))
+        k = options['img_rotate'] // 90
+        frame_raw, frame_HC, frame_protus, cc = (_rot90(x, k) for x in (frame_raw, frame_HC, frame_protus, cc))
 
-    if '_nolog' not in options:
-        if options['clahe_only'] or not options['protus_only']:
-            print('saving image to:' + basefich + '_clahe.png')
-            outputs.submit(outputs.write_png16, output_path(basefich + '_clahe.png', options), DeviceImage(cc))
-        if options['protus_only'] or not options['clahe_only']:
-            outputs.submit(outputs.write_png16, output_path(basefich + '_protus.png', options), DeviceImage(frame_protus))
-        if not options['clahe_only'] and not options['protus_only']:
-            outputs.submit(outputs.write_png16, output_path(basefich + '_uncontrasted.png', options), DeviceImage(frame_raw))
-            outputs.submit(outputs.write_png16, output_path(basefich + '_high_contrast.png', options), DeviceImage(frame_HC))
-    if options['save_fit']:
-        outputs.submit(write_fits, output_path(basefich + '_clahe.fits', options), DeviceImage(cl1), header)
-    return (DeviceImage(cc), DeviceImage(frame_protus))
+        if '_nolog' not in options:
+            if options['clahe_only'] or not options['protus_only']:
+                print('saving image to:' + basefich + '_clahe.png')
+                outputs.submit(outputs.write_png16, output_path(basefich + '_clahe.png', options), DeviceImage(cc))
+            if options['protus_only'] or not options['clahe_only']:
+                outputs.submit(outputs.write_png16, output_path(basefich + '_protus.png', options), DeviceImage(frame_protus))
+            if not options['clahe_only'] and not options['protus_only']:
+                outputs.submit(outputs.write_png16, output_path(basefich + '_uncontrasted.png', options), DeviceImage(frame_raw))
+                outputs.submit(outputs.write_png16, output_path(basefich + '_high_contrast.png', options), DeviceImage(frame_HC))
+        if options['save_fit']:
+            outputs.submit(write_fits, output_path(basefich + '_clahe.fits', options), DeviceImage(cl1), header)
+        results.append((DeviceImage(cc), DeviceImage(frame_protus)))
+    return results
+
+
+def image_process(frame, cercle, options, header, basefich):
+    return image_process_batch([frame], cercle, options, header, [basefich])[0]

@@ -177,6 +177,8 @@ def test_crop_pad(ops):
     want = np.full((37, 50), 777, np.uint16)
     want[:, 5:45] = img[:, 20:60]
     np.testing.assert_array_equal(out, want)
+    want[:, :5] = img[0, 0]; want[:, 45:] = img[0, 0]
+    np.testing.assert_array_equal(host(ops.crop_pad_u16(dev(img), 50, 20, 5, 40, None)), want)     # fill = img[0, 0] on the device
 
 
 def test_rescale_golden(ops, golden):
