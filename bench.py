@@ -91,7 +91,7 @@ def main():
     k0 = rank * n_local if sharded else 0
     t0 = time.time()
     stack = synth.synth_frames_torch(n_scan, args.width, args.height, args.bits, seed=rank if not sharded else 0,
-                                     k0=k0, k1=k0 + n_local, n_total=n_scan)
+                                     k0=k0, k1=k0 + n_local, n_total=n_scan, padded=True)
     torch.cuda.synchronize()
     log('[rank %d] synthetic stack %s %s built in %.1f s' % (rank, tuple(stack.shape), stack.dtype, time.time() - t0))
 
@@ -147,12 +147,14 @@ def main():
         except Exception:      # noqa: BLE001
             traffic = None
     from solex_ser_recon_en_amd import ops as _ops
-    ceiling, ceiling_shape = _ops.stream_read_ceiling(stack)
     frame_bytes = ih * iw * bpp
-    walk, walk_shape = _ops.stream_read_ceiling(stack, mode=2, vecs_per_frame=frame_bytes // 16) if frame_bytes % 16 == 0 else (0.0, None)
+    pitch_bytes = _ops.frame_stride(stack) * bpp
+    flat = torch.as_strided(stack, (stack.shape[0] * pitch_bytes // bpp,), (1,)) if stack.shape[0] > 1 else stack.reshape(-1)
+    ceiling, ceiling_shape = _ops.stream_read_ceiling(flat)
+    walk, walk_shape = _ops.stream_read_ceiling(flat, mode=2, vecs_per_frame=pitch_bytes // 16) if pitch_bytes % 16 == 0 else (0.0, None)
     roofline = {'kernel': 'k_accumulate_vec (pass A: sum+max over frames)', 'bound': 'hbm',
                 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                'traffic': traffic, 'algorithmic_bytes_per_launch': bytes_a,
+                'traffic': traffic, 'algorithmic_bytes_per_launch': bytes_a, 'frame_pitch_bytes': pitch_bytes,
                 'measured_read_ceiling': {'value': round(ceiling, 1), 'unit': 'GB/s', 'frac_of_it': round(ach / ceiling, 4) if ceiling else None,
                                           'how': 'best of %d launch shapes of a trivial read-only kernel (shg_stream_read_probe) over the same stack, '
                                                  'blocks x unroll = %s' % (8, ceiling_shape)},
@@ -181,7 +183,7 @@ def main():
         n_cpu = args.cpu_frames or n_local
         if sharded:
             n_cpu = min(n_cpu, n_local)
-        sample = stack[:n_cpu].cpu().numpy()
+        sample = _ops.stack_to_host(stack[:n_cpu])
         t0 = time.perf_counter()
         with contextlib.redirect_stdout(io.StringIO()), np.errstate(all='ignore'):
             ref = po.run(sample, {'shift': list(requested_shifts)})

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SHG_ABI_VERSION 3
+#define SHG_ABI_VERSION 4
 
 #define SHG_E_ARG        (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SHG_E_WORKSPACE  (-2)   /* workspace too small                                 */
@@ -66,8 +66,17 @@ int shg_stream_read_probe(const void* buf, int64_t bytes, int mode, int blocks, 
  * bit-identical for any sharding of the frames (RCCL SUM / MAX all-reduce). */
 size_t shg_accumulate_workspace_bytes(int64_t n_frames, int64_t height, int64_t width, int bytes_per_px);
 int shg_accumulate_sum_max(const void* stack, int64_t n_frames, int64_t height, int64_t width,
-                           int bytes_per_px, uint64_t* sum_out, uint16_t* max_out,
+                           int bytes_per_px, int64_t frame_stride_px, uint64_t* sum_out, uint16_t* max_out,
                            void* workspace, size_t workspace_bytes, shg_stream_t stream);
+
+/* ---- decode: frames into HBM ---------------------- video_reader.py:94-123
+ * The stack may keep a padded frame pitch: frame k starts frame_stride_px samples after frame k-1
+ * (0 = dense, height*width).  shg_frame_pitch_bytes gives the pitch the frame-walking kernels read fastest
+ * (the frame size rounded up to 8 KiB); shg_upload_frames copies n_frames dense frames from PINNED host
+ * memory into such a stack with one asynchronous 2-D hipMemcpy on `stream`. */
+int64_t shg_frame_pitch_bytes(int64_t frame_bytes);
+int shg_upload_frames(void* dst, int64_t dst_pitch_bytes, const void* host_src, int64_t frame_bytes,
+                      int64_t n_frames, shg_stream_t stream);
 
 /* mean = trunc(sum / n_total) as uint16 (solex_util.py:188), 8-bit samples scaled by
  * 256, both images rotated into the reference's [ih][iw] orientation. */
@@ -100,7 +109,7 @@ int shg_row_mean_u16(const uint16_t* img, int64_t h, int64_t w, double* out, shg
  * for the clamp (solex_util.py:122-123).  disks: n_shifts planes of plane_stride
  * elements, rows of row_pitch elements (row_pitch >= n_cols). */
 int shg_extract_columns(const void* stack, int64_t n_frames, int64_t height, int64_t width,
-                        int bytes_per_px, const int32_t* ind_l, const double* lw, const double* rw,
+                        int bytes_per_px, int64_t frame_stride_px, const int32_t* ind_l, const double* lw, const double* rw,
                         int n_shifts, uint16_t* disks, int64_t row_pitch, int64_t plane_stride,
                         int64_t n_cols, int64_t k_offset, int flip_x, shg_stream_t stream);
 

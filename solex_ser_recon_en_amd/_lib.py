@@ -32,12 +32,14 @@ SIGNATURES = {
     'shg_profile_get': (c_int, [ctypes.c_char_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int64)]),
     'shg_stream_read_probe': (c_int, [P, c_int64, c_int, c_int, c_int, c_int64, P, P]),
     'shg_accumulate_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int64, c_int]),
-    'shg_accumulate_sum_max': (c_int, [P, c_int64, c_int64, c_int64, c_int, P, P, P, c_size_t, P]),
+    'shg_accumulate_sum_max': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int64, P, P, P, c_size_t, P]),
+    'shg_frame_pitch_bytes': (c_int64, [c_int64]),
+    'shg_upload_frames': (c_int, [P, c_int64, P, c_int64, c_int64, P]),
     'shg_finalize_mean_max': (c_int, [P, P, c_int64, c_int64, c_int64, c_int, P, P, P]),
     'shg_box_blur_u16': (c_int, [P, c_int64, c_int64, c_int, c_int, P, P, P]),
     'shg_row_argmin_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int64, P, P]),
     'shg_row_mean_u16': (c_int, [P, c_int64, c_int64, P, P]),
-    'shg_extract_columns': (c_int, [P, c_int64, c_int64, c_int64, c_int, P, P, P, c_int, P, c_int64, c_int64,
+    'shg_extract_columns': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int64, P, P, P, c_int, P, c_int64, c_int64,
                                     c_int64, c_int64, c_int, P]),
     'shg_warp_rows_u16': (c_int, [P, c_int64, c_int64, c_int64, c_double, c_double, c_double, P, c_int64, c_int64,
                                   c_int64, P, P]),
@@ -71,7 +73,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 if lib.shg_abi_version() != ABI_VERSION:
     raise ImportError('libshg_hip.so ABI %d != expected %d: rebuild it' % (lib.shg_abi_version(), ABI_VERSION))
 

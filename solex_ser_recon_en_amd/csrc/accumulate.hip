@@ -19,6 +19,7 @@ typedef unsigned int __attribute__((ext_vector_type(4))) u32x4;   // native vect
 
 struct Plan {
     int64_t npix, frame_bytes, vecs;   // vecs = 16-byte vectors per frame (vector path only)
+    int64_t stride_px, stride_vecs;    // distance between consecutive frames (>= npix: a padded frame pitch)
     int nsplit, frames_per_split, unroll;
     bool vector_path;
 };
@@ -28,13 +29,15 @@ int env_int(const char* name, int dflt) {
     return (s && *s) ? atoi(s) : dflt;
 }
 
-Plan make_plan(const void* stack, int64_t n, int64_t h, int64_t w, int bpp) {
+Plan make_plan(const void* stack, int64_t n, int64_t h, int64_t w, int bpp, int64_t frame_stride_px) {
     Plan p;
     p.npix = h * w;
     p.frame_bytes = p.npix * bpp;
+    p.stride_px = frame_stride_px > 0 ? frame_stride_px : p.npix;
+    p.stride_vecs = p.stride_px * bpp / 16;
     // the alignment of `stack` is only known at call time; hipMalloc/torch give >= 256 B,
     // so the workspace query (stack == nullptr) assumes an aligned base
-    p.vector_path = (p.frame_bytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(stack) & 15) == 0);
+    p.vector_path = (p.frame_bytes % 16 == 0) && ((p.stride_px * bpp) % 16 == 0) && ((reinterpret_cast<uintptr_t>(stack) & 15) == 0);
     p.vecs = p.frame_bytes / 16;
     // Launch shape.  Measured on MI355X (tools/sweep_acc*.sh): the read rate peaks when about 7 MiB of loads are
     // in flight chip-wide (waves x unroll x 1 KiB) -- 6.7 TB/s at C2 -- and drops on either side (fewer: latency
@@ -131,7 +134,7 @@ struct Acc<1> {
 
 // grid: (ceil(vecs/256), nsplit).  One lane = 16 bytes of the frame, all frames of its split.
 template <int BPP, int UNROLL, bool NT>
-__global__ __launch_bounds__(256) void k_accumulate_vec(const u32x4* __restrict__ stack, int64_t vecs,
+__global__ __launch_bounds__(256) void k_accumulate_vec(const u32x4* __restrict__ stack, int64_t vecs, int64_t fstride,
                                                         int n_frames, int frames_per_split,
                                                         uint32_t* __restrict__ psum, uint16_t* __restrict__ pmax,
                                                         int64_t npix) {
@@ -142,19 +145,19 @@ __global__ __launch_bounds__(256) void k_accumulate_vec(const u32x4* __restrict_
     const int k1 = min(n_frames, k0 + frames_per_split);
     Acc<BPP> acc;
     acc.init();
-    const u32x4* p = stack + (int64_t)k0 * vecs + v;
+    const u32x4* p = stack + (int64_t)k0 * fstride + v;
     int k = k0;
     for (; k + UNROLL <= k1; k += UNROLL) {
         u32x4 r[UNROLL];
 #pragma unroll
-        for (int j = 0; j < UNROLL; ++j) r[j] = NT ? __builtin_nontemporal_load(p + (int64_t)j * vecs) : p[(int64_t)j * vecs];
-        p += (int64_t)UNROLL * vecs;
+        for (int j = 0; j < UNROLL; ++j) r[j] = NT ? __builtin_nontemporal_load(p + (int64_t)j * fstride) : p[(int64_t)j * fstride];
+        p += (int64_t)UNROLL * fstride;
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) acc.add(r[j]);
     }
     for (; k < k1; ++k) {
         acc.add(NT ? __builtin_nontemporal_load(p) : *p);
-        p += vecs;
+        p += fstride;
     }
     const int64_t pix = v * Acc<BPP>::PX;
     acc.store(psum + (int64_t)split * npix + pix, pmax + (int64_t)split * npix + pix);
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256) void k_accumulate_vec(const u32x4* __restrict_
 
 // Generic path (frame size not a multiple of 16 bytes, or unaligned base): one lane per pixel.
 template <typename T>
-__global__ __launch_bounds__(256) void k_accumulate_scalar(const T* __restrict__ stack, int64_t npix, int n_frames,
+__global__ __launch_bounds__(256) void k_accumulate_scalar(const T* __restrict__ stack, int64_t npix, int64_t fstride, int n_frames,
                                                            int frames_per_split, uint32_t* __restrict__ psum,
                                                            uint16_t* __restrict__ pmax) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void k_accumulate_scalar(const T* __restrict__
     const int k1 = min(n_frames, k0 + frames_per_split);
     uint32_t s = 0, m = 0;
     for (int k = k0; k < k1; ++k) {
-        const uint32_t v = stack[(int64_t)k * npix + i];
+        const uint32_t v = stack[(int64_t)k * fstride + i];
         s += v;
         m = m > v ? m : v;
     }
@@ -220,10 +223,10 @@ void launch_vec(const Plan& p, const void* stack, int n, uint32_t* psum, uint16_
     dim3 grid((unsigned)((p.vecs + 255) / 256), (unsigned)p.nsplit);
     const u32x4* s = static_cast<const u32x4*>(stack);
     switch (p.unroll) {
-        case 2: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 2, NT><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
-        case 4: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 4, NT><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
-        case 16: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 16, NT><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
-        default: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 8, NT><<<grid, 256, 0, st>>>(s, p.vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
+        case 2: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 2, NT><<<grid, 256, 0, st>>>(s, p.vecs, p.stride_vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
+        case 4: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 4, NT><<<grid, 256, 0, st>>>(s, p.vecs, p.stride_vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
+        case 16: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 16, NT><<<grid, 256, 0, st>>>(s, p.vecs, p.stride_vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
+        default: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 8, NT><<<grid, 256, 0, st>>>(s, p.vecs, p.stride_vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
     }
 }
 
@@ -236,18 +239,19 @@ size_t slab_bytes(const Plan& p) {
 
 extern "C" size_t shg_accumulate_workspace_bytes(int64_t n_frames, int64_t height, int64_t width, int bytes_per_px) {
     if (n_frames <= 0 || height <= 0 || width <= 0 || (bytes_per_px != 1 && bytes_per_px != 2)) return 0;
-    return slab_bytes(make_plan(nullptr, n_frames, height, width, bytes_per_px));
+    return slab_bytes(make_plan(nullptr, n_frames, height, width, bytes_per_px, 0));
 }
 
 extern "C" int shg_accumulate_sum_max(const void* stack, int64_t n_frames, int64_t height, int64_t width,
-                                      int bytes_per_px, uint64_t* sum_out, uint16_t* max_out,
+                                      int bytes_per_px, int64_t frame_stride_px, uint64_t* sum_out, uint16_t* max_out,
                                       void* workspace, size_t workspace_bytes, shg_stream_t stream) {
     SHG_REQUIRE(stack && sum_out && max_out && workspace, SHG_E_ARG, "shg_accumulate_sum_max: null pointer");
     SHG_REQUIRE(n_frames > 0 && height > 0 && width > 0, SHG_E_ARG, "shg_accumulate_sum_max: empty stack (%lld x %lld x %lld)",
                 (long long)n_frames, (long long)height, (long long)width);
     SHG_REQUIRE(bytes_per_px == 1 || bytes_per_px == 2, SHG_E_ARG, "shg_accumulate_sum_max: bytes_per_px must be 1 or 2");
     SHG_REQUIRE(n_frames < (1ll << 31), SHG_E_UNSUPPORTED, "shg_accumulate_sum_max: too many frames");
-    Plan p = make_plan(stack, n_frames, height, width, bytes_per_px);
+    SHG_REQUIRE(frame_stride_px == 0 || frame_stride_px >= height * width, SHG_E_ARG, "shg_accumulate_sum_max: frame stride smaller than a frame");
+    Plan p = make_plan(stack, n_frames, height, width, bytes_per_px, frame_stride_px);
     // a u32 partial holds 65537 frames of 16-bit samples
     SHG_REQUIRE(p.frames_per_split <= 65537, SHG_E_UNSUPPORTED, "shg_accumulate_sum_max: %d frames per split overflow u32",
                 p.frames_per_split);
@@ -265,9 +269,9 @@ extern "C" int shg_accumulate_sum_max(const void* stack, int64_t n_frames, int64
     } else {
         dim3 grid((unsigned)((p.npix + 255) / 256), (unsigned)p.nsplit);
         if (bytes_per_px == 2)
-            { SHG_PROF("accumulate", st); k_accumulate_scalar<uint16_t><<<grid, 256, 0, st>>>(static_cast<const uint16_t*>(stack), p.npix, n, p.frames_per_split, psum, pmax); }
+            { SHG_PROF("accumulate", st); k_accumulate_scalar<uint16_t><<<grid, 256, 0, st>>>(static_cast<const uint16_t*>(stack), p.npix, p.stride_px, n, p.frames_per_split, psum, pmax); }
         else
-            { SHG_PROF("accumulate", st); k_accumulate_scalar<uint8_t><<<grid, 256, 0, st>>>(static_cast<const uint8_t*>(stack), p.npix, n, p.frames_per_split, psum, pmax); }
+            { SHG_PROF("accumulate", st); k_accumulate_scalar<uint8_t><<<grid, 256, 0, st>>>(static_cast<const uint8_t*>(stack), p.npix, p.stride_px, n, p.frames_per_split, psum, pmax); }
     }
     if (int e = shg::check_launch("k_accumulate")) return e;
     { SHG_PROF("reduce_partials", st); k_reduce_partials<<<(unsigned)((p.npix + 255) / 256), 256, 0, st>>>(psum, pmax, p.nsplit, p.npix, sum_out, max_out); }

@@ -21,7 +21,7 @@ constexpr int TKP = TK + 2;   // padded LDS row stride (33 dwords: odd)
 constexpr int SC = 4;         // shifts per workgroup
 
 template <typename T, bool ROT>
-__global__ __launch_bounds__(256) void k_extract(const T* __restrict__ stack, int n_frames, int64_t height, int64_t width,
+__global__ __launch_bounds__(256) void k_extract(const T* __restrict__ stack, int n_frames, int64_t height, int64_t width, int64_t fstride,
                                                  const int32_t* __restrict__ ind_l, const double* __restrict__ lw,
                                                  const double* __restrict__ rw, int n_shifts,
                                                  uint16_t* __restrict__ disks, int64_t row_pitch, int64_t plane_stride,
@@ -35,7 +35,6 @@ __global__ __launch_bounds__(256) void k_extract(const T* __restrict__ stack, in
     const int s0 = blockIdx.z * SC;
     const int ns = min(SC, n_shifts - s0);
     const bool y_ok = y < ih;
-    const int64_t npix = height * width;
     constexpr int scale = sizeof(T) == 1 ? 256 : 1;        // video_reader.py:121-122
 
     int il[SC];
@@ -59,7 +58,7 @@ __global__ __launch_bounds__(256) void k_extract(const T* __restrict__ stack, in
         const int64_t k = (flip_x ? (n_cols - 1 - col) : col) - k_offset;   // wave-uniform
         if (col >= n_cols || k < 0 || k >= n_frames) continue;
         if (!y_ok) continue;
-        const T* f = stack + k * npix;
+        const T* f = stack + k * fstride;
 #pragma unroll
         for (int s = 0; s < SC; ++s) {
             if (s < ns) {
@@ -105,7 +104,7 @@ __global__ __launch_bounds__(256) void k_extract(const T* __restrict__ stack, in
 }  // namespace
 
 extern "C" int shg_extract_columns(const void* stack, int64_t n_frames, int64_t height, int64_t width,
-                                   int bytes_per_px, const int32_t* ind_l, const double* lw, const double* rw,
+                                   int bytes_per_px, int64_t frame_stride_px, const int32_t* ind_l, const double* lw, const double* rw,
                                    int n_shifts, uint16_t* disks, int64_t row_pitch, int64_t plane_stride,
                                    int64_t n_cols, int64_t k_offset, int flip_x, shg_stream_t stream) {
     SHG_REQUIRE(stack && ind_l && lw && rw && disks, SHG_E_ARG, "shg_extract_columns: null pointer");
@@ -117,6 +116,8 @@ extern "C" int shg_extract_columns(const void* stack, int64_t n_frames, int64_t 
                 (long long)(k_offset + n_frames), (long long)n_cols);
     SHG_REQUIRE(row_pitch >= n_cols, SHG_E_ARG, "shg_extract_columns: row_pitch < n_cols");
     SHG_REQUIRE((height < width ? height : width) >= 2, SHG_E_ARG, "shg_extract_columns: spectral axis needs >= 2 pixels");
+    SHG_REQUIRE(frame_stride_px == 0 || frame_stride_px >= height * width, SHG_E_ARG, "shg_extract_columns: frame stride smaller than a frame");
+    const int64_t fstride = frame_stride_px > 0 ? frame_stride_px : height * width;
     const bool rot = width > height;
     const int64_t ih = rot ? width : height;
     // the tile's 16-byte row segments land on 16-byte boundaries when every row does
@@ -125,7 +126,7 @@ extern "C" int shg_extract_columns(const void* stack, int64_t n_frames, int64_t 
     hipStream_t st = shg::as_stream(stream);
     const int n = (int)n_frames;
 #define SHG_LAUNCH(T, ROT)                                                                                              \
-    k_extract<T, ROT><<<grid, 256, 0, st>>>(static_cast<const T*>(stack), n, height, width, ind_l, lw, rw, n_shifts, \
+    k_extract<T, ROT><<<grid, 256, 0, st>>>(static_cast<const T*>(stack), n, height, width, fstride, ind_l, lw, rw, n_shifts, \
                                             disks, row_pitch, plane_stride, n_cols, k_offset, flip_x, vec_store)
     SHG_PROF("extract", st);
     if (bytes_per_px == 2) {

@@ -38,11 +38,32 @@ def pitched_u16(h, w, device, align=64):
     return torch.empty((h, pitch), dtype=torch.uint16, device=device)[:, :w]
 
 
+def padded_stack(n, h, w, dtype, device):
+    """An [n, h, w] frame stack whose frame pitch is shg_frame_pitch_bytes (frame size rounded up to 8 KiB):
+    the layout video_reader.device_stack() uploads into and the frame-walking kernels read fastest."""
+    item = torch.empty((), dtype=dtype).element_size()
+    pitch = lib.shg_frame_pitch_bytes(h * w * item) // item
+    store = torch.empty(n * pitch, dtype=dtype, device=device)
+    return torch.as_strided(store, (n, h, w), (pitch, w, 1))
+
+
+def stack_to_host(stack):
+    """Dense NumPy copy [n, H, W] of a (possibly pitched) frame stack."""
+    if stack.dtype == torch.uint16:
+        return stack.view(torch.int16).contiguous().cpu().numpy().view(np.uint16)
+    return stack.contiguous().cpu().numpy()
+
+
+def frame_stride(stack):
+    return stack.stride(0) if stack.shape[0] > 1 else stack.shape[1] * stack.shape[2]
+
+
 def stack_geometry(stack):
-    """(n, H, W, bytes_per_px) of a frame stack in file layout."""
+    """(n, H, W, bytes_per_px) of a frame stack in file layout (frames dense, frame pitch >= H*W)."""
     _dev(stack, 'stack')
-    if stack.dim() != 3 or not stack.is_contiguous():
-        raise ValueError('stack must be a contiguous [N, Height, Width] tensor')
+    if stack.dim() != 3 or stack.stride(2) != 1 or stack.stride(1) != stack.shape[2] or (
+            stack.shape[0] > 1 and stack.stride(0) < stack.shape[1] * stack.shape[2]):
+        raise ValueError('stack must be an [N, Height, Width] tensor with dense frames')
     if stack.dtype == torch.uint8:
         bpp = 1
     elif stack.dtype in (torch.uint16, torch.int16):
@@ -63,7 +84,7 @@ def accumulate_sum_max(stack, workspace=None):
         workspace = torch.empty(need, dtype=torch.uint8, device=dev)
     total = torch.empty(h * w, dtype=torch.int64, device=dev)
     mx = torch.empty(h * w, dtype=torch.uint16, device=dev)
-    _lib.check(lib.shg_accumulate_sum_max(stack.data_ptr(), n, h, w, bpp, total.data_ptr(), mx.data_ptr(),
+    _lib.check(lib.shg_accumulate_sum_max(stack.data_ptr(), n, h, w, bpp, frame_stride(stack), total.data_ptr(), mx.data_ptr(),
                                           workspace.data_ptr(), workspace.numel(), _stream()),
                'shg_accumulate_sum_max')
     return total, mx
@@ -132,7 +153,7 @@ def extract_columns(stack, ind_l, lw, rw, n_cols=None, k_offset=0, flip_x=False,
         out = torch.zeros((s, ih, pitch), dtype=torch.uint16, device=dev)[:, :, :n_cols]
     if out.shape != (s, ih, n_cols) or out.stride(2) != 1:
         raise ValueError('out must be a [S, ih, n_cols] view with unit column stride')
-    _lib.check(lib.shg_extract_columns(stack.data_ptr(), n, h, w, bpp, ind_l.contiguous().data_ptr(),
+    _lib.check(lib.shg_extract_columns(stack.data_ptr(), n, h, w, bpp, frame_stride(stack), ind_l.contiguous().data_ptr(),
                                        lw.contiguous().data_ptr(), rw.contiguous().data_ptr(), s, out.data_ptr(),
                                        out.stride(1), out.stride(0), n_cols, int(k_offset), int(bool(flip_x)),
                                        _stream()), 'shg_extract_columns')

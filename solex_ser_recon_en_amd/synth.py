@@ -87,7 +87,7 @@ def write_ser(path, frames, depth_bits=None):
 
 
 def synth_frames_torch(n_frames, width, height, depth_bits=16, seed=0, device='cuda',
-                       k0=0, k1=None, n_total=None, chunk=250):
+                       k0=0, k1=None, n_total=None, chunk=250, padded=False):
     """Same scene built directly on `device` (bench workloads; torch RNG, so not
     bit-identical to the NumPy generator).  Returns uint8/uint16 [k1-k0, H, W]."""
     import torch
@@ -104,7 +104,11 @@ def synth_frames_torch(n_frames, width, height, depth_bits=16, seed=0, device='c
     curve = iw / 2.0 + 6e-6 * yc * yc + 0.002 * yc
     line = 1.0 - sp['depth'] * torch.exp(-0.5 * ((x[None, :] - curve[:, None]) / sp['sigma']) ** 2)
     lit = ((y > sp['y_lo']) & (y < sp['y_hi'])).float()
-    out = torch.empty((k1 - k0, height, width), dtype=dt, device=device)
+    if padded:          # the frame pitch video_reader.device_stack() uploads into (rounded up to 8 KiB)
+        from . import ops
+        out = ops.padded_stack(k1 - k0, height, width, dt, device)
+    else:
+        out = torch.empty((k1 - k0, height, width), dtype=dt, device=device)
     gen = torch.Generator(device=device)
     for c0 in range(k0, k1, chunk):
         c1 = min(k1, c0 + chunk)
@@ -118,5 +122,6 @@ def synth_frames_torch(n_frames, width, height, depth_bits=16, seed=0, device='c
         img = torch.clamp(torch.round(img * full), 0, full)
         if rotate:
             img = torch.rot90(img, -1, dims=(1, 2))
-        out[c0 - k0:c1 - k0] = img.to(torch.int32).to(dt)
+        out.view(torch.int16 if depth_bits == 16 else torch.uint8)[c0 - k0:c1 - k0] = img.to(torch.int32).to(
+            torch.int16 if depth_bits == 16 else torch.uint8)
     return out

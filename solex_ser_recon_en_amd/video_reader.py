@@ -106,8 +106,8 @@ class video_reader:
         """Frames [k0:k1) of the file as one tensor [n, Height, Width] in HBM (file layout).
 
         `readers` threads (default min(8, cpus)) each own two pinned staging buffers and a copy
-        stream: preadv() into pinned memory (GIL released), asynchronous hipMemcpy to the slice of
-        the stack, next chunk.  One thread tops out at the page-cache memcpy rate (~12 GB/s
+        stream: preadv() of whole frames into pinned memory (GIL released), one asynchronous 2-D hipMemcpy
+        into the (8 KiB-pitched) frames of the stack, next chunk.  One thread tops out at the page-cache memcpy rate (~12 GB/s
         measured); several saturate the PCIe link."""
         if self._stack is not None:
             return self._stack
@@ -120,12 +120,14 @@ class video_reader:
         frame_bytes = h * w * b
         if os.path.getsize(self.file) < SER_HEADER_BYTES + int(self.FrameCount) * frame_bytes:
             raise Exception('error input file ' + str(self.file) + ': shorter than its header says')
+        from . import _lib, ops
         dt = torch.uint16 if b == 2 else torch.uint8
-        stack = torch.empty((n, h, w), dtype=dt, device=device)
-        flat = stack.view(-1).view(torch.uint8)
-        total = n * frame_bytes
+        stack = ops.padded_stack(n, h, w, dt, device)                  # frame pitch rounded up to 8 KiB
+        pitch_bytes = stack.stride(0) * b if n > 1 else frame_bytes
+        base_ptr = stack.data_ptr()
         base = SER_HEADER_BYTES + k0 * frame_bytes
-        n_chunks = (total + chunk_bytes - 1) // chunk_bytes
+        chunk_frames = max(1, chunk_bytes // frame_bytes)
+        n_chunks = (n + chunk_frames - 1) // chunk_frames
         readers = max(1, min(readers or min(8, os.cpu_count() or 1), n_chunks))
         counter = itertools.count()
         errors = []
@@ -134,7 +136,7 @@ class video_reader:
         def work(tid):
             try:
                 torch.cuda.set_device(device)
-                bufs = _lease_pinned_pair(chunk_bytes)
+                bufs = _lease_pinned_pair(chunk_frames * frame_bytes)
                 events = [None, None]
                 fd = os.open(self.file, os.O_RDONLY)
                 try:
@@ -143,22 +145,24 @@ class video_reader:
                         c = next(counter)
                         if c >= n_chunks:
                             break
-                        off = c * chunk_bytes
-                        m = min(chunk_bytes, total - off)
+                        f0 = c * chunk_frames
+                        m = min(chunk_frames, n - f0)
+                        nbytes = m * frame_bytes
                         if events[slot] is not None:
                             events[slot].synchronize()                  # this buffer's previous copy has landed
-                        view = bufs[slot][:m]
+                        view = bufs[slot][:nbytes]
                         mv = memoryview(view.numpy())
                         got = 0
-                        while got < m:
-                            r = os.preadv(fd, [mv[got:]], base + off + got)
+                        while got < nbytes:
+                            r = os.preadv(fd, [mv[got:]], base + f0 * frame_bytes + got)
                             if r <= 0:
                                 raise Exception('error input file ' + str(self.file) + ': short read')
                             got += r
-                        with torch.cuda.stream(streams[tid]):
-                            flat[off:off + m].copy_(view, non_blocking=True)
-                            ev = torch.cuda.Event()
-                            ev.record(streams[tid])
+                        # dense frames in pinned memory -> pitched frames in HBM: one asynchronous 2-D hipMemcpy
+                        _lib.check(_lib.lib.shg_upload_frames(base_ptr + f0 * pitch_bytes, pitch_bytes, view.data_ptr(), frame_bytes, m,
+                                                              streams[tid].cuda_stream), 'shg_upload_frames')
+                        ev = torch.cuda.Event()
+                        ev.record(streams[tid])
                         events[slot] = ev
                         slot ^= 1
                     for ev in events:

@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(_lib.lib, name), 'libshg_hip.so does not export %s' % name
         assert name in _lib.SIGNATURES, 'no ctypes signature for %s' % name
     assert sorted(_lib.SIGNATURES) == names
-    assert _lib.lib.shg_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.lib.shg_abi_version() == _lib.ABI_VERSION == 4
     assert isinstance(_lib.last_error(), str)
 
 
@@ -42,10 +42,11 @@ def test_argument_errors_are_reported_not_thrown():
     """Bad arguments are rejected before any HIP call, so this runs without a GPU."""
     from solex_ser_recon_en_amd import _lib
     lib = _lib.lib
-    assert lib.shg_accumulate_sum_max(None, 1, 1, 1, 2, None, None, None, 0, None) == -1
+    assert lib.shg_accumulate_sum_max(None, 1, 1, 1, 2, 0, None, None, None, 0, None) == -1
     assert 'null pointer' in _lib.last_error()
     one = ctypes.c_void_p(16)
-    assert lib.shg_extract_columns(one, 0, 4, 4, 2, one, one, one, 1, one, 4, 16, 4, 0, 0, None) == -1
+    assert lib.shg_extract_columns(one, 0, 4, 4, 2, 0, one, one, one, 1, one, 4, 16, 4, 0, 0, None) == -1
+    assert lib.shg_frame_pitch_bytes(800000) == 802816 and lib.shg_frame_pitch_bytes(1310720) == 1310720
     assert lib.shg_box_blur_u16(one, 10, 10, 25, 0, one, one, None) == -1      # cv2.blur rejects a zero kernel too
     assert 'must be positive' in _lib.last_error()
     assert lib.shg_rescale_u16(one, 4, 4, 4, 5.0, 5.0, 1.0, one, 4, None) == -1   # assert(sat >= hi > lo)

@@ -397,3 +397,28 @@ def test_select_u16_is_exact(ops, h, w):
         lo, hi, mix = lerp_order_stats(n, q)
         a, b = host(ops.select_u16(dev(img), [lo, hi]))
         assert mix(a, b) == np.percentile(img, q)
+
+
+@pytest.mark.parametrize('n,h,w,dtype', [(40, 24, 160, np.uint16), (33, 160, 24, np.uint16), (21, 16, 128, np.uint8), (9, 7, 5, np.uint16)])
+def test_frame_passes_on_a_pitched_stack(ops, orc, n, h, w, dtype):
+    """The stack video_reader.device_stack() builds has a padded frame pitch: both frame passes must ignore the padding."""
+    rng = np.random.default_rng(n)
+    frames = rng.integers(0, 256 if dtype == np.uint8 else 65536, (n, h, w)).astype(dtype)
+    tdt = torch.uint8 if dtype == np.uint8 else torch.uint16
+    stack = ops.padded_stack(n, h, w, tdt, 'cuda')
+    assert stack.stride(0) * frames.itemsize % 8192 == 0 and stack.stride(0) >= h * w
+    torch.as_strided(stack, (n * stack.stride(0),), (1,)).view(torch.uint8).fill_(255)      # poison the padding
+    stack.view(torch.int16 if dtype == np.uint16 else torch.uint8)[:] = dev(frames).view(torch.int16 if dtype == np.uint16 else torch.uint8)
+    np.testing.assert_array_equal(ops.stack_to_host(stack), frames)
+    total, mx = ops.accumulate_sum_max(stack)
+    mean, mxo = ops.finalize_mean_max(total, mx, n, h, w, frames.itemsize)
+    ref_mean, ref_max = orc.compute_mean_max(orc.SerReader(frames))
+    np.testing.assert_array_equal(host(mean), ref_mean)
+    np.testing.assert_array_equal(host(mxo), ref_max)
+    ih, iw = max(h, w), min(h, w)
+    curve = np.clip(iw / 2 + 2 * np.sin(np.arange(ih) / 5.0) + rng.random(ih), 0, iw - 1.5)
+    fit = np.stack([np.floor(curve), curve - np.floor(curve), np.arange(ih), curve], axis=1)
+    shifts = [1, 0, -1]
+    cols, lw, rw = orc.column_indices(fit, shifts, iw)
+    disks = ops.extract_columns(stack, np.stack([c[0] for c in cols]).astype(np.int32), lw, rw)
+    np.testing.assert_array_equal(host(disks), np.stack(orc.extract_columns(orc.SerReader(frames), fit, shifts)))
