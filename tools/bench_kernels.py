@@ -32,8 +32,9 @@ def main():
     ap.add_argument('--h', type=int, default=200)
     ap.add_argument('--bits', type=int, default=16)
     ap.add_argument('--shifts', type=int, default=2)
+    ap.add_argument('--dense', action='store_true', help='dense frames instead of the 8 KiB-rounded frame pitch')
     a = ap.parse_args()
-    stack = synth.synth_frames_torch(a.n, a.w, a.h, a.bits, seed=0)
+    stack = synth.synth_frames_torch(a.n, a.w, a.h, a.bits, seed=0, padded=not a.dense)
     n, h, w = stack.shape
     bpp = stack.element_size()
     ih, iw = max(h, w), min(h, w)
