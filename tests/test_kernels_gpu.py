@@ -422,3 +422,31 @@ def test_frame_passes_on_a_pitched_stack(ops, orc, n, h, w, dtype):
     cols, lw, rw = orc.column_indices(fit, shifts, iw)
     disks = ops.extract_columns(stack, np.stack([c[0] for c in cols]).astype(np.int32), lw, rw)
     np.testing.assert_array_equal(host(disks), np.stack(orc.extract_columns(orc.SerReader(frames), fit, shifts)))
+
+
+@pytest.mark.parametrize('h,w', [(2, 8), (3, 5)])
+def test_sum_does_not_overflow_at_70000_full_scale_frames(ops, h, w):
+    """More than 65 537 saturated 16-bit frames overflow a u32 sum: the frame axis must be split so that every
+    partial fits and the total is exact in u64 (the reference accumulates in uint64, solex_util.py:182)."""
+    n = 70000
+    stack = torch.full((n, h, w), -1, dtype=torch.int16, device='cuda').view(torch.uint16)      # 65535 everywhere
+    total, mx = ops.accumulate_sum_max(stack)
+    assert int(total.min()) == int(total.max()) == n * 65535 > 2 ** 32
+    mean, mxo = ops.finalize_mean_max(total, mx, n, h, w, 2)
+    assert int(mean.view(torch.int16).to(torch.int32).min()) & 0xffff == 65535
+    assert int(mxo.view(torch.int16).to(torch.int32).min()) & 0xffff == 65535
+
+
+def test_single_frame_and_single_pixel_edge_cases(ops, orc):
+    rng = np.random.default_rng(0)
+    frames = rng.integers(0, 65536, (1, 2, 16)).astype(np.uint16)        # one frame; iw = 2: the only legal column pair is (0, 1)
+    total, mx = ops.accumulate_sum_max(dev(frames))
+    mean, mxo = ops.finalize_mean_max(total, mx, 1, 2, 16, 2)
+    ref_mean, ref_max = orc.compute_mean_max(orc.SerReader(frames))
+    np.testing.assert_array_equal(host(mean), ref_mean)
+    fit = np.stack([np.full(16, 5.0), np.full(16, 0.25), np.arange(16.0), np.full(16, 5.25)], axis=1)   # far off the 2-px axis: clamps to 0
+    cols, lw, rw = orc.column_indices(fit, [10, 0], 2)
+    disks = ops.extract_columns(dev(frames), np.stack([c[0] for c in cols]).astype(np.int32), lw, rw)
+    np.testing.assert_array_equal(host(disks), np.stack(orc.extract_columns(orc.SerReader(frames), fit, [10, 0])))
+    with pytest.raises(RuntimeError):
+        ops.extract_columns(dev(rng.integers(0, 9, (2, 1, 8)).astype(np.uint16)), np.zeros((1, 8), np.int32), np.ones(8), np.zeros(8))   # 1-px spectral axis
