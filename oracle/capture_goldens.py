@@ -377,8 +377,73 @@ def g14_pipeline():
     save('g14_pipeline', **out)
 
 
+def g11_crop():
+    """single_image_process's crop / pad block (Solex_recon.py:155-171), run unmodified: transversalium and
+    FITS off, `image_process` replaced by a recorder so that the (frame, cercle) it is handed is the fixture."""
+    rng = np.random.default_rng(11)
+    seen = {}
+
+    def record(frame, cercle, options, header, basefich):
+        seen['frame'], seen['cercle'] = np.array(frame), tuple(cercle)
+        return frame, frame
+    ref_sr.image_process = record
+    out = {}
+    cases = [  # (h, w, cercle, fixed_width, crop_width_square)
+        (40, 90, (45.7, 20.0, 18.0), None, True),        # square crop, circle centred
+        (40, 90, (12.2, 20.0, 18.0), None, True),        # circle near the left edge: pad on the left (tx > 0)
+        (40, 90, (80.9, 20.0, 18.0), None, True),        # circle near the right edge: pad on the right
+        (40, 90, (-1, -1, -1), None, True),              # no circle: centre on w // 2
+        (40, 90, (45.0, 20.0, 18.0), 140, False),        # wider than the image: pad both sides
+        (40, 90, (45.0, 20.0, 18.0), 33, False),         # odd width
+        (41, 57, (30.3, 20.0, 18.0), 58, True),          # fixed_width wins over crop_width_square
+        (64, 37, (18.0, 30.0, 17.0), None, True),        # taller than wide: square crop pads
+        (40, 90, (-1, -1, -1), 21, False),
+        (40, 90, (0.4, 20.0, 18.0), 30, False),          # cx = 0
+    ]
+    for k, (h, w, cercle, fw, sq) in enumerate(cases):
+        img = rng.integers(0, 65536, (h, w)).astype(np.uint16)
+        opts = dict(QUIET, save_fit=False, transversalium=False, fixed_width=fw, crop_width_square=sq)
+        ref_sr.single_image_process(img, {}, opts, cercle, [0, 0, 0, 0], 'x', (0, h))
+        out['in_%d' % k] = img
+        out['args_%d' % k] = np.array([cercle[0], cercle[1], cercle[2], -1 if fw is None else fw, int(sq)], dtype=np.float64)
+        out['out_%d' % k] = seen['frame']
+        out['cercle_%d' % k] = np.array(seen['cercle'], dtype=np.float64)
+    out['n'] = np.array(len(cases))
+    save('g11_crop', **out)
+
+
+def g12_shift_order():
+    """options['shift'] / options['shift_requested'] after the reference's solex_read (Solex_recon.py:53-55) for
+    request lists that repeat, contain or omit the two implicit shifts; and the raw disks it returns for them."""
+    import hashlib
+    import shutil
+    install_blur_shim()
+    params = dict(n=120, w=160, h=40, bits=8, seed=12, tilt=0.02, curv=1e-4)
+    frames = synth.synth_frames_numpy(params['n'], params['w'], params['h'], params['bits'], seed=params['seed'],
+                                      tilt=params['tilt'], curv=params['curv'])
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, 'scan.ser')
+    synth.write_ser(path, frames)
+    cases = [(10, [0]), (10, [10]), (10, [10, 0]), (10, [0, 10]), (10, [-3, 5, 5]), (10, [2, -2, 0, 2]),
+             (0, [0, 1]), (5, [5]), (-4, [3, -4, 0]), (10, list(range(-10, 11)))]
+    out = {'frames_sha256': np.frombuffer(hashlib.sha256(frames.tobytes()).digest(), np.uint8), 'n': np.array(len(cases))}
+    out.update({'param_' + k: np.array(v) for k, v in params.items()})
+    for k, (efs, req) in enumerate(cases):
+        opts = dict(QUIET, shift=list(req), ellipse_fit_shift=efs, flip_x=False)
+        disks, bounds, hdr = ref_sr.solex_read(path, opts)
+        out['efs_%d' % k] = np.array(efs)
+        out['request_%d' % k] = np.array(req)
+        out['shift_%d' % k] = np.array(opts['shift'])
+        out['shift_requested_%d' % k] = np.array(opts['shift_requested'])
+        out['bounds_%d' % k] = np.array(bounds)
+        out['disk_sha256_%d' % k] = np.stack([np.frombuffer(hashlib.sha256(np.ascontiguousarray(d).tobytes()).digest(), np.uint8)
+                                              for d in disks])
+    shutil.rmtree(tmp)
+    save('g12_shift_order', **out)
+
+
 ALL = dict(G6=g6_vignette, G13=g13_limb, G14=g14_pipeline, G1=g1_mean_max, G2=g2_extract, G3=g3_warp, G4=g4_transversalium, G5=g5_rescale,
-           G7=g7_matrix, G8=g8_fit_shim, G9=g9_fits, G10=g10_cli)
+           G7=g7_matrix, G8=g8_fit_shim, G9=g9_fits, G10=g10_cli, G11=g11_crop, G12=g12_shift_order)
 
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)

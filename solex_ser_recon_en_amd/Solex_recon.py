@@ -221,6 +221,36 @@ def single_image_process(frame_circularized, hdr, options, cercle0, borders, bas
     return process_images([frame_circularized], hdr, options, cercle0, borders, [basefich], backup_bounds)[0]
 
 
+def crop_to_width(images, cercle, options):
+    """The crop / pad block of single_image_process (Solex_recon.py:155-171) for a list of same-shape images:
+    centre on int(cx) (w // 2 without a circle), crop or pad to `fixed_width` (or to the height for
+    `crop_width_square`), fill with img[0, 0].  Returns (images, cercle) with cx moved to the new centre."""
+    # A de-vignetted frame that skipped the transversalium stage is still float64 here; the reference crops
+    # the float image and truncates in image_process (solex_util.py:528).  Cropping is a pure copy, so
+    # truncating first gives the same pixels (and the same fill value img[0, 0]).
+    images = [as_uint16_image(img) for img in images]
+    if options['fixed_width'] is not None or options['crop_width_square']:
+        h, w = images[0].shape
+        nw = h if options['fixed_width'] is None else options['fixed_width']
+        nw2 = nw // 2
+        cx = w // 2 if cercle == (-1, -1, -1) else int(cercle[0])
+        tx = nw2 - cx
+        lo, hi = max(0, cx - nw2), min(cx + nw2, w)
+        if hi < lo:
+            raise ValueError('crop window [%d, %d) lies outside the %d px wide image' % (cx - nw2, cx + nw2, w))
+        # new_img[:, :hi-lo] = img[:, lo:hi]; then np.roll by tx when tx > 0 and refill the first tx columns (:161-167).
+        # The rolled-in tail is fill colour whenever the copied span fits, which it does: hi - lo <= nw - tx.
+        n = hi - lo
+        dx0 = tx if tx > 0 else 0
+        if dx0 + n > nw:
+            n = nw - dx0            # np.roll would wrap these columns round and the refill overwrite them
+        # the fill colour img[0, 0] is read on the device (no host round trip per image)
+        images = [DeviceImage(ops.crop_pad_u16(to_device_u16(img), nw, lo, dx0, n, None)) for img in images]
+        if not cercle == (-1, -1, -1):
+            cercle = (nw2, cercle[1], cercle[2])
+    return images, cercle
+
+
 def process_images(frames, hdr, options, cercle0, borders, basefichs, backup_bounds):
     """single_image_process (Solex_recon.py:136-174) for a list of circularised frames of one file:
     transversalium, crop, CLAHE + contrast products.  Returns [(cc, frame_protus), ...]."""
@@ -243,28 +273,7 @@ def process_images(frames, hdr, options, cercle0, borders, basefichs, backup_bou
         for img, basefich in zip(detrans, basefichs):
             outputs.submit(write_fits, output_path(basefich + '_detransversaliumed.fits', options), _as_image(img), hdr)
 
-    cercle = cercle0
-    # A de-vignetted frame that skipped the transversalium stage is still float64 here; the reference crops
-    # the float image and truncates in image_process (solex_util.py:528).  Cropping is a pure copy, so
-    # truncating first gives the same pixels (and the same fill value img[0, 0]).
-    detrans = [as_uint16_image(img) for img in detrans]
-    if options['fixed_width'] is not None or options['crop_width_square']:
-        h, w = detrans[0].shape
-        nw = h if options['fixed_width'] is None else options['fixed_width']
-        nw2 = nw // 2
-        cx = w // 2 if cercle == (-1, -1, -1) else int(cercle[0])
-        tx = nw2 - cx
-        lo, hi = max(0, cx - nw2), min(cx + nw2, w)
-        # new_img[:, :hi-lo] = img[:, lo:hi]; then np.roll by tx when tx > 0 and refill the first tx columns (:161-167).
-        # The rolled-in tail is fill colour whenever the copied span fits, which it does: hi - lo <= nw - tx.
-        n = max(hi - lo, 0)
-        dx0 = tx if tx > 0 else 0
-        if dx0 + n > nw:
-            n = nw - dx0            # np.roll would wrap these columns round and the refill overwrite them
-        # the fill colour img[0, 0] is read on the device (no host round trip per image)
-        detrans = [DeviceImage(ops.crop_pad_u16(to_device_u16(img), nw, lo, dx0, n, None)) for img in detrans]
-        if not cercle == (-1, -1, -1):
-            cercle = (nw2, cercle[1], cercle[2])
+    detrans, cercle = crop_to_width(detrans, cercle0, options)
 
     with timing.stage('clahe+contrast'):
         return image_process_batch(detrans, cercle, options, hdr, basefichs)

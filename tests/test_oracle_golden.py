@@ -163,3 +163,39 @@ def test_remove_vignette_pinned(golden, tag):
     np.testing.assert_array_equal(np.percentile(img, 85, axis=0), g[tag + '_p85_cols'])
     small = np.full((90, 90), 1000, np.uint16)
     assert orc.remove_vignette(small, (45.0, 45.0, 40.0)) is small
+
+
+def _crop_cases(g):
+    for k in range(int(g['n'])):
+        cx, cy, r, fw, sq = g['args_%d' % k]
+        cercle = (-1, -1, -1) if cx == -1 else (float(cx), float(cy), float(r))
+        yield k, g['in_%d' % k], cercle, (None if fw < 0 else int(fw)), bool(sq)
+
+
+def test_crop_center_vs_reference(golden):
+    """G11: the crop / pad block of single_image_process (Solex_recon.py:155-171), reference run unmodified."""
+    g = golden('g11_crop')
+    for k, img, cercle, fw, sq in _crop_cases(g):
+        out, c2 = orc.crop_center(img, cercle, fw, sq)
+        np.testing.assert_array_equal(out, g['out_%d' % k], err_msg='case %d' % k)
+        np.testing.assert_array_equal(np.array(c2, dtype=np.float64), g['cercle_%d' % k], err_msg='case %d' % k)
+
+
+def test_shift_order_and_raw_disks_vs_reference(golden):
+    """G12: options['shift'] after solex_read (Solex_recon.py:53-55) and the disks it returns, in that order."""
+    import hashlib
+    from solex_ser_recon_en_amd import synth
+    g = golden('g12_shift_order')
+    frames = synth.synth_frames_numpy(int(g['param_n']), int(g['param_w']), int(g['param_h']), int(g['param_bits']),
+                                      seed=int(g['param_seed']), tilt=float(g['param_tilt']), curv=float(g['param_curv']))
+    assert hashlib.sha256(frames.tobytes()).digest() == g['frames_sha256'].tobytes()
+    rdr = orc.SerReader(frames)
+    mean, mx = orc.compute_mean_max(rdr)
+    fit, y1, y2, _, _ = orc.line_fit(mean, mx)
+    for k in range(int(g['n'])):
+        shifts = orc.shift_list(int(g['efs_%d' % k]), [int(s) for s in g['request_%d' % k]])
+        assert shifts == [int(s) for s in g['shift_%d' % k]]
+        assert (y1, y2) == tuple(int(b) for b in g['bounds_%d' % k])
+        disks = orc.extract_columns(orc.SerReader(frames), fit, shifts)
+        got = np.stack([np.frombuffer(hashlib.sha256(np.ascontiguousarray(d).tobytes()).digest(), np.uint8) for d in disks])
+        np.testing.assert_array_equal(got, g['disk_sha256_%d' % k])

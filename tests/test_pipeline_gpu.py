@@ -327,3 +327,35 @@ def test_bad_files_raise_like_the_reference(pkg, tmp_path):
     np.testing.assert_array_equal(stack.cpu().numpy(), frames)
     part = video_reader(good, frame_range=(2, 5)).device_stack()      # a rank's block of a sharded scan
     np.testing.assert_array_equal(part.cpu().numpy(), frames[2:5])
+
+
+def test_crop_to_width_vs_reference(pkg, golden):
+    """G11 through the product: crop_to_width = the crop / pad block of single_image_process (Solex_recon.py:155-171)."""
+    from tests.test_oracle_golden import _crop_cases
+    _, Solex_recon, _ = pkg
+    g = golden('g11_crop')
+    for k, img, cercle, fw, sq in _crop_cases(g):
+        opts = {'fixed_width': fw, 'crop_width_square': sq}
+        (out,), c2 = Solex_recon.crop_to_width([img], cercle, opts)
+        np.testing.assert_array_equal(np.asarray(out), g['out_%d' % k], err_msg='case %d' % k)
+        np.testing.assert_array_equal(np.array(c2, dtype=np.float64), g['cercle_%d' % k], err_msg='case %d' % k)
+
+
+def test_solex_read_shift_order_vs_reference(pkg, golden, tmp_path):
+    """G12 through the product: options['shift'], options['shift_requested'], bounds and the raw disks of solex_read."""
+    import hashlib
+    SHG_MAIN, Solex_recon, _ = pkg
+    g = golden('g12_shift_order')
+    frames = synth.synth_frames_numpy(int(g['param_n']), int(g['param_w']), int(g['param_h']), int(g['param_bits']),
+                                      seed=int(g['param_seed']), tilt=float(g['param_tilt']), curv=float(g['param_curv']))
+    path = str(tmp_path / 'scan.ser')
+    synth.write_ser(path, frames)
+    for k in range(int(g['n'])):
+        opts = SHG_MAIN.default_options()
+        opts.update(shift=[int(s) for s in g['request_%d' % k]], ellipse_fit_shift=int(g['efs_%d' % k]), _nolog=True)
+        disks, bounds, hdr = Solex_recon.solex_read(path, opts)
+        assert opts['shift'] == [int(s) for s in g['shift_%d' % k]]
+        assert list(opts['shift_requested']) == [int(s) for s in g['shift_requested_%d' % k]]
+        assert tuple(int(b) for b in bounds) == tuple(int(b) for b in g['bounds_%d' % k])
+        got = np.stack([np.frombuffer(hashlib.sha256(np.ascontiguousarray(np.asarray(d)).tobytes()).digest(), np.uint8) for d in disks])
+        np.testing.assert_array_equal(got, g['disk_sha256_%d' % k])
