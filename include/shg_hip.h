@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SHG_ABI_VERSION 4
+#define SHG_ABI_VERSION 5
 
 #define SHG_E_ARG        (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SHG_E_WORKSPACE  (-2)   /* workspace too small                                 */
@@ -140,6 +140,31 @@ int shg_rowpair_logratio_stats(const uint16_t* img, int64_t h, int64_t w, int64_
 /* ret = min(img * c[y], 65535) truncated to uint16 (solex_util.py:489, 515-516). */
 int shg_scale_rows_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, const double* c,
                        const double* row_factor, uint16_t* dst, int64_t dst_pitch, shg_stream_t stream);
+
+/* ---- f4: "stubborn" transversalium, the line filter of apply_lin_filter + fix_edge_effect ----
+ * Replaces the three cv2.filter2D calls on log(img) (solex_util.py:277-353) and the limb clean-up
+ * (:356-375).  Exact BORDER_REFLECT_101 correlation: float64 sums in a fixed order, rounded once to
+ * float32 for a uint16 image (np.log(uint16) is float32) or kept in float64 for the float64 image
+ * img * row_factor[y] (row_factor non-NULL).
+ *
+ * shg_lin_filter_row_sums: hl[h][w] = sum of the `linlen` logs centred on x along row y; hf the same
+ * for the image whose flagged rows are replaced by (nearest unflagged row above)/2 + (… below)/2
+ * (up/dn: int32 [h], -1 = none; only read where flagged[y] != 0).  log_lut: float32 [65536], the
+ * log of every uint16 value as the caller's NumPy computes it (ignored when row_factor is given).
+ *
+ * shg_lin_filter_apply: delta = hl/linlen - (sum of hf over rows y-half_width..y+half_width except y)
+ * /(2*half_width*linlen); kept on columns [xa[y], xb[y]), copied from column xa+edge_half into
+ * [xa, xa+edge_half) when edge[y] & 1, from xb-edge_half-1 into [xb-edge_half, xb) when edge[y] & 2,
+ * zero elsewhere; dst = min(img * exp(-delta * taper[y]), 65535) truncated (solex_util.py:352, 423). */
+int shg_lin_filter_row_sums(const uint16_t* img, int64_t h, int64_t w, int64_t pitch,
+                            const double* row_factor, const float* log_lut, const uint8_t* flagged,
+                            const int32_t* up, const int32_t* dn, int linlen, double* hl, double* hf,
+                            shg_stream_t stream);
+int shg_lin_filter_apply(const uint16_t* img, int64_t h, int64_t w, int64_t pitch,
+                         const double* row_factor, const double* hl, const double* hf, int linlen,
+                         int half_width, const double* taper, const int32_t* xa, const int32_t* xb,
+                         const uint8_t* edge, int edge_half, uint16_t* dst, int64_t dst_pitch,
+                         shg_stream_t stream);
 
 /* np.percentile(img, q, axis) building block (removeVignette, solex_util.py:591-592): for every
  * column (axis 0) or row (axis 1) the rank_lo-th and rank_hi-th smallest values (0-based). */

@@ -308,7 +308,8 @@ def g14_pipeline():
     """The reference's solex_read + solex_process run END TO END, unmodified, in shim mode:
     cv2.blur / createCLAHE / circle and ellipse.LsqEllipse are this repo's restatements,
     cv2.imwrite captures the arrays.  Pins the orchestration (shift list, geometry state,
-    stage order, crop, flip, percentiles, rescale) around the unpinned primitives."""
+    stage order, crop, flip, percentiles, rescale) around the unpinned primitives.  Scenarios F and G take the
+    stubborn transversalium branch with cv2.filter2D := scipy.ndimage.correlate(mode='mirror')."""
     import hashlib
     import shutil
     install_blur_shim()
@@ -330,6 +331,8 @@ def g14_pipeline():
         return True
     cv2.imwrite = imwrite
     cv2.destroyAllWindows = lambda: None
+    from scipy import ndimage
+    cv2.filter2D = lambda src, ddepth, kernel: ndimage.correlate(src, kernel, mode='mirror')      # scenarios F, G (see g15_stubborn)
 
     base = {'shift': [0], 'flag_display': False, 'ratio_fixe': None, 'slant_fix': None, 'save_fit': False,
             'clahe_only': False, 'protus_only': False, 'disk_display': True, 'delta_radius': 0,
@@ -347,9 +350,11 @@ def g14_pipeline():
     synth.write_ser(path, frames)
     scenarios = {'A': {}, 'B': {'shift': [-2, 0, 3], 'flip_x': True, 'crop_width_square': True},
                  'C': {'ratio_fixe': 1, 'fixed_width': 300, 'disk_display': False, 'img_rotate': 90},
-                 'D': {'de-vignette': True, 'shift': [0, 4]}, 'E': {'de-vignette': True, 'transversalium': False, 'crop_width_square': True}}
+                 'D': {'de-vignette': True, 'shift': [0, 4]}, 'E': {'de-vignette': True, 'transversalium': False, 'crop_width_square': True},
+                 'F': {'stubborn_transversalium': True, 'trans_strength': 41},
+                 'G': {'stubborn_transversalium': True, 'de-vignette': True}}
     keep = {'A': ['clahe', 'protus', 'uncontrasted', 'high_contrast'], 'B': ['uncontrasted', 'clahe'], 'C': ['clahe', 'protus'],
-            'D': ['clahe', 'uncontrasted'], 'E': ['clahe', 'protus']}
+            'D': ['clahe', 'uncontrasted'], 'E': ['clahe', 'protus'], 'F': ['clahe', 'uncontrasted'], 'G': ['clahe', 'uncontrasted']}
     for tag, extra in scenarios.items():
         captured.clear()
         opts = dict(base, **extra)
@@ -442,8 +447,39 @@ def g12_shift_order():
     save('g12_shift_order', **out)
 
 
+def g15_stubborn():
+    """Reference correct_transversalium2 with `stubborn_transversalium`, unmodified, in shim mode: cv2.filter2D :=
+    scipy.ndimage.correlate(mode='mirror') (= BORDER_REFLECT_101, exact correlation accumulated in float64 and
+    stored in the source type).  Pins the spurious-row logic, the row replacement, fix_edge_effect and the taper;
+    cv2's own DFT rounding stays unpinned.  Two inputs: uint16 (float32 filters) and a float64 image."""
+    from scipy import ndimage
+    cv2.filter2D = lambda src, ddepth, kernel: ndimage.correlate(src, kernel, mode='mirror')
+    out = {}
+    rng = np.random.default_rng(15)
+    h, w = 300, 330
+    img = _disk_image(h, w, 15, ratio=1.0)
+    gain = 1 + 0.004 * rng.standard_normal(h)
+    for y in (97, 98, 160, 221):
+        gain[y] *= 1.25                                   # lines the smooth correction cannot follow
+    img = np.clip(img * gain[:, None], 1, 65535).astype(np.uint16)
+    circle = (w / 2 + 1.5, h / 2 - 0.7, 0.40 * w)
+    borders = [20.3, 14.2, 310.8, 287.6]
+    opts = dict(QUIET, trans_strength=301, stubborn_transversalium=True)
+    out['image'] = img
+    out['circle'] = np.array(circle)
+    out['borders'] = np.array(borders)
+    out['u16_out'] = ref_su.correct_transversalium2(img, circle, borders, opts, 0, '/tmp/x')
+    rowf = 1 + 0.1 * np.sin(np.arange(h) / 40.0)
+    out['row_factor'] = rowf
+    out['f64_out'] = ref_su.correct_transversalium2(img * rowf[:, None], circle, borders, dict(opts), 0, '/tmp/x')
+    bb = [0, 30 + 20, w - 1, 270 - 20]                    # backup-bounds call form, Solex_recon.py:146
+    out['bb_borders'] = np.array(bb)
+    out['bb_out'] = ref_su.correct_transversalium2(img, (0, 0, 99999), bb, dict(opts, trans_strength=41), 0, '/tmp/x')
+    save('g15_stubborn', **out)
+
+
 ALL = dict(G6=g6_vignette, G13=g13_limb, G14=g14_pipeline, G1=g1_mean_max, G2=g2_extract, G3=g3_warp, G4=g4_transversalium, G5=g5_rescale,
-           G7=g7_matrix, G8=g8_fit_shim, G9=g9_fits, G10=g10_cli, G11=g11_crop, G12=g12_shift_order)
+           G7=g7_matrix, G8=g8_fit_shim, G9=g9_fits, G10=g10_cli, G11=g11_crop, G12=g12_shift_order, G15=g15_stubborn)
 
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)

@@ -19,7 +19,8 @@ except ImportError:
 
 DEFAULTS = dict(shift=[0], ratio_fixe=None, slant_fix=None, disk_display=True, delta_radius=0,
                 crop_width_square=False, transversalium=True, trans_strength=301, img_rotate=0,
-                flip_x=False, fixed_width=None, ellipse_fit_shift=10, **{'de-vignette': False})
+                flip_x=False, fixed_width=None, ellipse_fit_shift=10, stubborn_transversalium=False,
+                **{'de-vignette': False})
 
 
 def solex_read(frames, options):
@@ -38,12 +39,13 @@ def single_image_process(frame, opts, cercle0, borders, backup_bounds):
     out = dict(circular=frame)
     if opts['transversalium']:
         if not cercle0 == (-1, -1, -1):
-            det, c = orc.correct_transversalium2(frame, cercle0, borders, opts['trans_strength'])
+            circle, borders_t = cercle0, borders
         else:
-            det, c = orc.correct_transversalium2(
-                frame, (0, 0, 99999), [0, backup_bounds[0] + 20, frame.shape[1] - 1, backup_bounds[1] - 20],
-                opts['trans_strength'])
-        out['c'] = c
+            circle, borders_t = (0, 0, 99999), [0, backup_bounds[0] + 20, frame.shape[1] - 1, backup_bounds[1] - 20]
+        if opts['stubborn_transversalium']:
+            det, out['spurious'] = orc.correct_transversalium2_stubborn(frame, circle, borders_t, opts['trans_strength'])
+        else:
+            det, out['c'] = orc.correct_transversalium2(frame, circle, borders_t, opts['trans_strength'])
     else:
         det = frame
     out['detrans'] = det

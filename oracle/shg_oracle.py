@@ -351,6 +351,134 @@ def correct_transversalium2(img, circle, borders, trans_strength=301):
 
 
 # ----------------------------------------------------------------------------
+# f4  stubborn transversalium                     solex_util.py:277-375, 415-423
+#     cv2.filter2D is restated (UNPINNED: opencv-python is absent here and unpinned upstream).  OpenCV runs
+#     kernels this large (11x101, 1x101) through a DFT whose rounding cannot be reproduced; the restatement
+#     is the exact correlation with BORDER_REFLECT_101, summed in float64 and rounded once to the image's
+#     float type -- the value the DFT approximates.
+# ----------------------------------------------------------------------------
+def row_box_sums_reflect101(a, k):
+    """S[y, x] = sum_{d = -(k//2) .. k//2} a[y, reflect101(x + d)], float64, added left to right."""
+    half = k // 2
+    w = a.shape[1]
+    p = np.pad(np.asarray(a, dtype=np.float64), ((0, 0), (half, half)), mode='reflect')
+    acc = p[:, 0:w].copy()
+    for d in range(1, k):
+        acc += p[:, d:d + w]
+    return acc
+
+
+def spurious_rows(correction, n_rows, y1, y2):
+    """Rows whose accumulated correction is an outlier, dilated by one row with wrap-around (:416-421)."""
+    lc = np.log(correction)
+    c = np.zeros(n_rows)
+    c[y1:y2] = lc
+    flag = np.abs(c) > np.std(lc) * 2.5
+    return np.logical_or(flag, np.logical_or(np.roll(flag, -1), np.roll(flag, 1)))
+
+
+def neighbour_rows(flag):
+    """For every row the nearest unflagged row above and below (-1: none), the two passes of :306-317."""
+    n = len(flag)
+    up = np.full(n, -1, dtype=np.int32)
+    dn = np.full(n, -1, dtype=np.int32)
+    last = -1
+    for i in range(n):
+        if flag[i]:
+            up[i] = last
+        else:
+            last = i
+    last = -1
+    for i in range(n - 1, -1, -1):
+        if flag[i]:
+            dn[i] = last
+        else:
+            last = i
+    return up, dn
+
+
+def edge_plan(circle, h, w, linlen):
+    """fix_edge_effect (:356-375) as per-row data: delta is kept on [xa, xb), copied from column xa+half into
+    [xa, xa+half) when left[y], from column xb-half-1 into [xb-half, xb) when right[y], zero elsewhere."""
+    y1 = math.ceil(max(circle[1] - circle[2], 0))
+    y2 = math.floor(min(circle[1] + circle[2], h - 1))
+    half = linlen // 2
+    xa = np.zeros(h, dtype=np.int32)
+    xb = np.zeros(h, dtype=np.int32)
+    left = np.zeros(h, dtype=bool)
+    right = np.zeros(h, dtype=bool)
+    for y in range(max(y1, 0), y2):
+        dx = math.floor((circle[2] ** 2 - (y - circle[1]) ** 2) ** 0.5)
+        x2 = math.floor(min(circle[0] + dx, w - 1))
+        x1 = math.ceil(max(circle[0] - dx, 0))
+        xa[y], xb[y] = x1, max(x2, x1)
+        if x2 - x1 < linlen:
+            continue
+        left[y] = x1 > 0
+        right[y] = x2 < w - 1
+    if 0 <= y2 < h and y2 >= y1:
+        xa[y2], xb[y2] = 0, w                     # the loop stops before row y2 and only rows > y2 are cleared
+    return xa, xb, left, right, half
+
+
+def apply_lin_filter(img, flag, y1, y2, circle, linlen=101, half_width=5):
+    """img * exp(-delta * taper): delta = (1 x linlen mean of log img) - (mean over the 2*half_width neighbouring
+    rows x linlen columns of log img with the flagged rows replaced by the mean of their nearest unflagged
+    neighbours), cleaned at the limb by fix_edge_effect with linlen + 20 (:277-353).
+    np.log of a uint16 image is float32, of a float64 image float64: the filters keep that type."""
+    h, w = img.shape
+    with np.errstate(divide='ignore', invalid='ignore'):
+        L = np.log(img)
+    ftype = L.dtype
+    up, dn = neighbour_rows(flag)
+    filt2 = L.copy()
+    zero = np.zeros(w, dtype=ftype)
+    with np.errstate(invalid='ignore'):
+        for i in np.nonzero(flag)[0]:
+            a = L[up[i]] if up[i] >= 0 else zero
+            b = L[dn[i]] if dn[i] >= 0 else zero
+            filt2[i] = a / 2
+            filt2[i] += b / 2
+        hf = row_box_sums_reflect101(filt2, linlen)
+        hl = row_box_sums_reflect101(L, linlen)
+        pf = np.pad(hf, ((half_width, half_width), (0, 0)), mode='reflect')
+        acc = np.zeros((h, w))
+        for d in range(2 * half_width + 1):
+            if d != half_width:
+                acc += pf[d:d + h]
+        result3 = (acc * (1.0 / (2 * half_width * linlen))).astype(ftype)
+        result4 = (hl * (1.0 / linlen)).astype(ftype)
+        delta = result4 - result3
+        xa, xb, left, right, half = edge_plan(circle, h, w, linlen + 20)
+        fixed = np.zeros_like(delta)
+        for y in range(h):
+            a, b = int(xa[y]), int(xb[y])
+            fixed[y, a:b] = delta[y, a:b]
+            if left[y]:
+                fixed[y, a:a + half] = delta[y, a + half]
+            if right[y]:
+                fixed[y, b - half:b] = delta[y, b - half - 1]
+        n = y2 - y1
+        c = np.zeros(h)
+        c[y1:y2] = tukey_taper(n)
+        return img * np.exp(-fixed * c.reshape(-1, 1))
+
+
+def correct_transversalium2_stubborn(img, circle, borders, trans_strength=301):
+    """The `stubborn_transversalium` branch of correct_transversalium2 (:415-423)."""
+    from scipy.signal import savgol_filter
+    y1, y2, ratios = transversalium_row_stats(img, circle, borders)
+    trend = savgol_filter(ratios, min(trans_strength, len(ratios) // 2 * 2 - 1), 3)
+    detrended = ratios - trend
+    detrended -= np.mean(detrended)
+    correction = np.exp(-np.cumsum(detrended))
+    flag = spurious_rows(correction, img.shape[0], y1, y2)
+    with np.errstate(invalid='ignore'):
+        out = apply_lin_filter(img, flag, y1, y2, circle)
+        return np.minimum(out, 65535).astype('uint16'), flag
+
+
+# ----------------------------------------------------------------------------
 # removeVignette                                             solex_util.py:590-654
 # ----------------------------------------------------------------------------
 def remove_vignette(frame, cercle0):

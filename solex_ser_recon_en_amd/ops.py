@@ -209,6 +209,47 @@ def scale_rows_u16(img, c, row_factor=None):
     return out
 
 
+_LOG_LUT = {}
+
+
+def _log_lut(device):
+    """float32 log of every uint16 value exactly as NumPy computes np.log(uint16 image) on this host."""
+    key = str(device)
+    if key not in _LOG_LUT:
+        with np.errstate(divide='ignore'):
+            lut = np.log(np.arange(65536, dtype=np.uint16))
+        assert lut.dtype == np.float32
+        _LOG_LUT[key] = torch.from_numpy(lut).to(device)
+    return _LOG_LUT[key]
+
+
+def lin_filter_u16(img, flagged, up, dn, taper, xa, xb, edge, edge_half, linlen=101, half_width=5, row_factor=None):
+    """apply_lin_filter + fix_edge_effect (solex_util.py:277-375) -> uint16 image (saturated, truncated).
+    flagged / up / dn / taper / xa / xb / edge: per-row host arrays (see include/shg_hip.h)."""
+    ptr, h, w, pitch = _img(img, 'img', torch.uint16)
+    dev = img.device
+
+    def put(a, dtype):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        if a.shape != (h,):
+            raise ValueError('per-row arrays must have shape (%d,)' % h)
+        return torch.from_numpy(a).to(dev)
+    flagged_d, up_d, dn_d = put(flagged, np.uint8), put(up, np.int32), put(dn, np.int32)
+    taper_d, xa_d, xb_d, edge_d = put(taper, np.float64), put(xa, np.int32), put(xb, np.int32), put(edge, np.uint8)
+    rf, rf_ptr = _row_factor_ptr(row_factor, h, dev)
+    lut = _log_lut(dev)
+    hl = torch.empty((h, w), dtype=torch.float64, device=dev)
+    hf = torch.empty((h, w), dtype=torch.float64, device=dev)
+    _lib.check(lib.shg_lin_filter_row_sums(ptr, h, w, pitch, rf_ptr, lut.data_ptr(), flagged_d.data_ptr(), up_d.data_ptr(),
+                                           dn_d.data_ptr(), int(linlen), hl.data_ptr(), hf.data_ptr(), _stream()),
+               'shg_lin_filter_row_sums')
+    out = pitched_u16(h, w, dev)
+    _lib.check(lib.shg_lin_filter_apply(ptr, h, w, pitch, rf_ptr, hl.data_ptr(), hf.data_ptr(), int(linlen), int(half_width),
+                                        taper_d.data_ptr(), xa_d.data_ptr(), xb_d.data_ptr(), edge_d.data_ptr(), int(edge_half),
+                                        out.data_ptr(), out.stride(0), _stream()), 'shg_lin_filter_apply')
+    return out
+
+
 def line_order_stats_u16(img, axis, rank_lo, rank_hi):
     """-> (lo, hi) uint16 GPU tensors: per column (axis 0) / row (axis 1) order statistics."""
     ptr, h, w, pitch = _img(img, 'img', torch.uint16)

@@ -245,10 +245,11 @@ def _savgol_rows(y, window):
     return out
 
 
-def transversalium_factors(y_ratios_r, trans_strength):
+def transversalium_factors(y_ratios_r, trans_strength, tapered=True):
     """Row correction factors from the robust row-pair log-ratios (solex_util.py:400-404, 456-472).
     y_ratios_r: [n] or [k, n] (k disks of one Doppler stack, same geometry).  Every row is processed exactly as
-    a separate call would, so a disk's result does not depend on which other disks share the batch."""
+    a separate call would, so a disk's result does not depend on which other disks share the batch.
+    tapered=False returns `correction` itself (:404), which the stubborn branch thresholds (:416-420)."""
     y = np.atleast_2d(np.asarray(y_ratios_r, dtype=np.float64))
     n = y.shape[-1]
     trend = _savgol_rows(y, min(trans_strength, n // 2 * 2 - 1))
@@ -256,16 +257,67 @@ def transversalium_factors(y_ratios_r, trans_strength):
     for row in detrended:
         row -= np.mean(row)
     correction = np.exp(-np.cumsum(detrended, axis=-1))
-    out = np.ones(n) + (correction - np.ones(n)) * _tukey(n)
+    out = np.ones(n) + (correction - np.ones(n)) * _tukey(n) if tapered else correction
     return out if np.ndim(y_ratios_r) == 2 else out[0]
+
+
+# ---- stubborn transversalium: host control plane of solex_util.py:277-375, 415-423 ------------------
+LIN_LEN, LIN_HALF_WIDTH, LIN_EDGE_FUDGE = 101, 5, 20          # apply_lin_filter(img, 101, 5, ...), fix_edge_effect(..., linlen + 20)
+
+
+def _spurious_rows(correction, n_rows, y1, y2):
+    """Rows whose accumulated log-correction exceeds 2.5 sigma, plus their two neighbours (np.roll wraps), :416-421."""
+    log_corr = np.log(correction)
+    c = np.zeros(n_rows)
+    c[y1:y2] = log_corr
+    flag = np.abs(c) > np.std(log_corr) * 2.5
+    return flag | np.roll(flag, -1) | np.roll(flag, 1)
+
+
+def _nearest_unflagged(flag):
+    """(up, dn): for every row the index of the nearest unflagged row above / below, -1 where there is none --
+    the two sweeps of :306-317 (a flagged row becomes prev/2 + next/2) as index maps."""
+    n = flag.shape[0]
+    idx = np.arange(n)
+    up = np.maximum.accumulate(np.where(flag, -1, idx))
+    dn = np.minimum.accumulate(np.where(flag, n, idx)[::-1])[::-1]
+    return up.astype(np.int32), np.where(dn == n, -1, dn).astype(np.int32)
+
+
+def _limb_edge_plan(circle, h, w, linlen):
+    """fix_edge_effect (:356-375) as per-row data for shg_lin_filter_apply: keep delta on [xa, xb); edge bit 0 =
+    copy column xa + half over [xa, xa + half), bit 1 = copy column xb - half - 1 over [xb - half, xb)."""
+    y1 = math.ceil(max(circle[1] - circle[2], 0))
+    y2 = math.floor(min(circle[1] + circle[2], h - 1))
+    xa = np.zeros(h, dtype=np.int32)
+    xb = np.zeros(h, dtype=np.int32)
+    edge = np.zeros(h, dtype=np.uint8)
+    if y2 > y1:
+        ys = np.arange(y1, y2, dtype=np.float64)
+        v = circle[2] ** 2 - (ys - circle[1]) ** 2
+        if np.any(v < 0):
+            raise TypeError('stubborn transversalium: row outside the disk circle (complex chord length)')
+        root = np.sqrt(v)
+        dx = np.floor(root)
+        for i in np.flatnonzero(np.abs(root - np.rint(root)) <= 1e-9 * np.maximum(root, 1.0)):
+            dx[i] = math.floor(float(v[i]) ** 0.5)                # Python's own pow where floor() could differ
+        x2 = np.floor(np.minimum(circle[0] + dx, w - 1)).astype(np.int64)
+        x1 = np.ceil(np.maximum(circle[0] - dx, 0)).astype(np.int64)
+        if np.any(x1 < 0) or np.any(x2 < 0):
+            raise ValueError('stubborn transversalium: the circle lies outside the image')
+        wide = (x2 - x1) >= linlen
+        xa[y1:y2] = x1
+        xb[y1:y2] = np.maximum(x2, x1)
+        edge[y1:y2] = (wide & (x1 > 0)).astype(np.uint8) | ((wide & (x2 < w - 1)).astype(np.uint8) << 1)
+    if 0 <= y1 <= y2 < h:
+        xa[y2], xb[y2] = 0, w            # row y2 is neither in the loop nor in the cleared tail: it keeps its delta
+    return xa, xb, edge, linlen // 2
 
 
 def correct_transversalium2_batch(imgs, circle, borders, options, reqFlag, basefichs):
     """correct_transversalium2 for several frames that share circle / borders / shape (the disks of a Doppler
     stack): all row statistics are launched before the single device->host read, and the 1-D control plane runs
     once on the [k, n] matrix."""
-    if options.get('stubborn_transversalium'):
-        raise NotImplementedError('stubborn transversalium (cv2.filter2D path, solex_util.py:415-423) is out of scope')
     factors = [img.row_factor if isinstance(img, DeviceImage) else None for img in imgs]       # de-vignetted (float64) frames
     tensors = [img.t if rf is not None else to_device_u16(img) for img, rf in zip(imgs, factors)]
     h, w = tensors[0].shape
@@ -280,6 +332,20 @@ def correct_transversalium2_batch(imgs, circle, borders, options, reqFlag, basef
         ratios = torch.stack([ops.rowpair_logratio_stats(t, y1, y2, xa_d, xb_d, rf) for t, rf in zip(tensors, factors)]).cpu().numpy()
     else:
         ratios = np.zeros((len(tensors), 1))                                          # y_ratios_r = [0], :386
+    if options.get('stubborn_transversalium'):
+        # :415-423: rows the smooth correction cannot follow are rebuilt from their neighbours by a line filter;
+        # no correction plot and no '_transversalium_cache' on this branch
+        correction = transversalium_factors(ratios, options['trans_strength'], tapered=False)
+        taper = np.zeros(h)
+        taper[y1:y2] = _tukey(y2 - y1)
+        xa_e, xb_e, edge, edge_half = _limb_edge_plan(circle, h, w, LIN_LEN + LIN_EDGE_FUDGE)
+        out = []
+        for i, (t, rf) in enumerate(zip(tensors, factors)):
+            flag = _spurious_rows(correction[i], h, y1, y2)
+            up, dn = _nearest_unflagged(flag)
+            out.append(DeviceImage(ops.lin_filter_u16(t, flag, up, dn, taper, xa_e, xb_e, edge, edge_half, LIN_LEN,
+                                                      LIN_HALF_WIDTH, rf)))
+        return out
     correction_t = transversalium_factors(ratios, options['trans_strength'])
     out = []
     for i, (t, rf) in enumerate(zip(tensors, factors)):

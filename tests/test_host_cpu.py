@@ -230,3 +230,38 @@ def test_ser_header_parse(tmp_path):
     open(str(tmp_path / 'short.ser'), 'wb').write(b'LUCAM')
     with pytest.raises(Exception, match='truncated'):
         video_reader(str(tmp_path / 'short.ser'))
+
+
+def test_stubborn_control_plane_matches_oracle():
+    """Host side of the stubborn transversalium branch (solex_util.py:356-375, 416-421): vectorised row maps
+    against the oracle's loops, including wrap-around dilation, leading / trailing flagged runs and circles that
+    touch or leave the image."""
+    from solex_ser_recon_en_amd import solex_util as su
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 7, 64):
+        for _ in range(20):
+            flag = rng.random(n) < rng.choice([0.0, 0.2, 0.7, 1.0])
+            up, dn = su._nearest_unflagged(flag)
+            rup, rdn = orc.neighbour_rows(flag)
+            sel = flag                                         # only read where flagged
+            np.testing.assert_array_equal(up[sel], rup[sel])
+            np.testing.assert_array_equal(dn[sel], rdn[sel])
+    for trial in range(30):
+        n = int(rng.integers(5, 60))
+        y1 = int(rng.integers(0, 4))
+        y2 = n - int(rng.integers(0, 4))
+        corr = np.exp(0.01 * rng.standard_normal(y2 - y1))
+        corr[rng.integers(0, y2 - y1)] *= 1.5
+        if trial % 3 == 0:
+            corr[0] *= 2.0                                     # flags row y1: the dilation wraps when y1 == 0
+        np.testing.assert_array_equal(su._spurious_rows(corr, n, y1, y2), orc.spurious_rows(corr, n, y1, y2))
+    for circle, h, w in [((160.5, 149.3, 132.0), 300, 330), ((40.0, 30.0, 80.0), 200, 260), ((130.2, 100.0, 100.0), 201, 260),
+                         ((0, 0, 99999), 120, 300), ((50.0, 60.0, 20.0), 120, 130), ((100.0, 100.0, 60.5), 150, 200),
+                         ((65.0, 50.0, 50.0), 101, 131)]:
+        xa, xb, edge, half = su._limb_edge_plan(circle, h, w, 121)
+        rxa, rxb, left, right, rhalf = orc.edge_plan(circle, h, w, 121)
+        assert half == rhalf == 60
+        np.testing.assert_array_equal(xa, rxa)
+        np.testing.assert_array_equal(xb, rxb)
+        np.testing.assert_array_equal(edge & 1, left.astype(np.uint8))
+        np.testing.assert_array_equal(edge >> 1, right.astype(np.uint8))

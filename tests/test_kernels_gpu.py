@@ -450,3 +450,48 @@ def test_single_frame_and_single_pixel_edge_cases(ops, orc):
     np.testing.assert_array_equal(host(disks), np.stack(orc.extract_columns(orc.SerReader(frames), fit, [10, 0])))
     with pytest.raises(RuntimeError):
         ops.extract_columns(dev(rng.integers(0, 9, (2, 1, 8)).astype(np.uint16)), np.zeros((1, 8), np.int32), np.ones(8), np.zeros(8))   # 1-px spectral axis
+
+
+# ---- stubborn transversalium (line filter) ------------------------------------------------------------
+def _flips(got, want):
+    d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+    return int(d.max()), int(np.count_nonzero(d))
+
+
+@pytest.mark.parametrize('case', ['u16', 'f64', 'bb', 'edge_rows', 'zeros'])
+def test_lin_filter_vs_oracle_and_reference_shim(ops, orc, golden, case):
+    """shg_lin_filter_row_sums + shg_lin_filter_apply through the product's correct_transversalium2 (stubborn
+    branch) against the oracle and against the reference's own run (G15, shim mode).  Sums are float64 in one
+    fixed order on both sides; what can differ is the device's exp (and log for float64 frames) in the last
+    bit, i.e. a truncation flip: <= 1 LSB on <= 8 pixels."""
+    from solex_ser_recon_en_amd import solex_util as su
+    from solex_ser_recon_en_amd.device import DeviceImage
+    g = golden('g15_stubborn')
+    img, circle, borders = g['image'].copy(), tuple(g['circle']), list(g['borders'])
+    opts = {'stubborn_transversalium': True, 'trans_strength': 301, '_nolog': True, 'clahe_only': True, 'protus_only': False}
+    ref_key, rf = 'u16_out', None
+    if case == 'f64':
+        rf, ref_key = g['row_factor'], 'f64_out'
+    elif case == 'bb':
+        circle, borders, ref_key = (0, 0, 99999), list(g['bb_borders']), 'bb_out'
+        opts['trans_strength'] = 41
+    elif case == 'edge_rows':
+        ref_key = None
+        img[0:3] = (img[0:3] * 1.4).clip(1, 65535).astype(np.uint16)        # does not matter: outside the circle
+        circle, borders = (165.0, 149.0, 149.0), [0, 0, 329, 299]            # circle touches the top and bottom rows
+    elif case == 'zeros':
+        ref_key = None
+        img[150, 100:103] = 0                                                # log(0) = -inf inside the windows
+    frame = DeviceImage(dev(img), row_factor=dev(rf)) if rf is not None else dev(img)
+    got = np.asarray(su.correct_transversalium2(frame, circle, borders, opts, 0, 'x'))
+    cpu_img = img * rf[:, None] if rf is not None else img
+    with np.errstate(all='ignore'):
+        want, flag = orc.correct_transversalium2_stubborn(cpu_img, circle, borders, opts['trans_strength'])
+    assert got.dtype == np.uint16 and got.shape == want.shape
+    mx, n = _flips(got, want)
+    assert mx <= 1 and n <= 8, (mx, n)
+    if ref_key:
+        mx, n = _flips(got, g[ref_key])
+        assert mx <= 1 and n <= 8, (mx, n)
+    if case in ('u16', 'bb'):
+        assert flag.sum() >= 3 and '_transversalium_cache' not in opts

@@ -199,3 +199,33 @@ def test_shift_order_and_raw_disks_vs_reference(golden):
         disks = orc.extract_columns(orc.SerReader(frames), fit, shifts)
         got = np.stack([np.frombuffer(hashlib.sha256(np.ascontiguousarray(d).tobytes()).digest(), np.uint8) for d in disks])
         np.testing.assert_array_equal(got, g['disk_sha256_%d' % k])
+
+
+def close_u16(got, want, max_flips):
+    assert got.shape == want.shape and got.dtype == want.dtype
+    d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+    assert d.max() <= 1 and np.count_nonzero(d) <= max_flips, (d.max(), np.count_nonzero(d))
+
+
+def test_stubborn_transversalium_vs_reference_shim(golden):
+    """G15: the reference's stubborn branch run unmodified with cv2.filter2D := scipy.ndimage.correlate (mirror).
+    The restatement sums in float64 and rounds once; scipy rounds the products first: a last-bit difference of
+    delta can flip a truncation, hence <= 1 LSB on a handful of the 99 000 pixels."""
+    g = golden('g15_stubborn')
+    img, circle, borders = g['image'], tuple(g['circle']), list(g['borders'])
+    out, flag = orc.correct_transversalium2_stubborn(img, circle, borders, 301)
+    assert flag.sum() >= 3
+    close_u16(out, g['u16_out'], 8)
+    assert np.count_nonzero(out != orc.correct_transversalium2(img, circle, borders, 301)[0]) > 1000     # a different filter
+    out, flag = orc.correct_transversalium2_stubborn(img * g['row_factor'][:, None], circle, borders, 301)
+    close_u16(out, g['f64_out'], 8)
+    out, flag = orc.correct_transversalium2_stubborn(img, (0, 0, 99999), list(g['bb_borders']), 41)
+    assert flag.sum() >= 3
+    close_u16(out, g['bb_out'], 8)
+
+
+def test_row_box_sums_known_answers():
+    a = np.arange(12, dtype=np.float64).reshape(2, 6)
+    s = orc.row_box_sums_reflect101(a, 3)
+    np.testing.assert_array_equal(s[0], [1 + 0 + 1, 0 + 1 + 2, 1 + 2 + 3, 2 + 3 + 4, 3 + 4 + 5, 4 + 5 + 4])   # gfedcb|abcdefgh|gfedcba
+    np.testing.assert_array_equal(orc.row_box_sums_reflect101(np.ones((3, 9)), 7), np.full((3, 9), 7.0))

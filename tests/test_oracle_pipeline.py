@@ -68,11 +68,13 @@ def g14_frames(golden):
 SCENARIOS = {'A': {}, 'B': {'shift': [-2, 0, 3], 'flip_x': True, 'crop_width_square': True},
              'C': {'ratio_fixe': 1, 'fixed_width': 300, 'disk_display': False, 'img_rotate': 90},
              'D': {'de-vignette': True, 'shift': [0, 4]},
-             'E': {'de-vignette': True, 'transversalium': False, 'crop_width_square': True}}
+             'E': {'de-vignette': True, 'transversalium': False, 'crop_width_square': True},
+             'F': {'stubborn_transversalium': True, 'trans_strength': 41},
+             'G': {'stubborn_transversalium': True, 'de-vignette': True}}
 PRODUCT_KEY = {'clahe': 'cc', 'protus': 'protus', 'uncontrasted': 'raw', 'high_contrast': 'hc'}
 
 
-@pytest.mark.parametrize('tag', ['A', 'B', 'C', 'D', 'E'])
+@pytest.mark.parametrize('tag', ['A', 'B', 'C', 'D', 'E', 'F', 'G'])
 def test_pipeline_oracle_matches_reference_shim_run(g14_frames, tag):
     g, frames = g14_frames
     run = po.run(frames, SCENARIOS[tag])
@@ -93,8 +95,11 @@ def test_pipeline_oracle_matches_reference_shim_run(g14_frames, tag):
         want = g[key]
         assert got.shape == want.shape, key
         # the limb-fit floats may differ in the last bits between NumPy builds; a truncation flip is 1 LSB
+        # (stubborn scenarios F, G: NumPy's float32 log differs in the last bit between builds; a 1-LSB flip of
+        # the de-transversaliumed frame is stretched by the CLAHE / contrast slope, <= 4 LSB in `cc`)
         diff = np.abs(got.astype(np.int64) - want.astype(np.int64))
-        assert diff.max() <= 1 and np.count_nonzero(diff) <= 4, (key, diff.max(), np.count_nonzero(diff))
+        lsb = 4 if tag in 'FG' and product == 'clahe' else 1
+        assert diff.max() <= lsb and np.count_nonzero(diff) <= 4, (key, diff.max(), np.count_nonzero(diff))
         checked += 1
     assert checked >= 2
     # products stored only as hashes: shapes must agree, and so do the bits unless a 1-LSB flip occurred

@@ -14,7 +14,9 @@ from solex_ser_recon_en_amd import synth          # noqa: E402
 SCENARIOS = {'A': {}, 'B': {'shift': [-2, 0, 3], 'flip_x': True, 'crop_width_square': True},
              'C': {'ratio_fixe': 1, 'fixed_width': 300, 'disk_display': False, 'img_rotate': 90},
              'D': {'de-vignette': True, 'shift': [0, 4]},
-             'E': {'de-vignette': True, 'transversalium': False, 'crop_width_square': True}}
+             'E': {'de-vignette': True, 'transversalium': False, 'crop_width_square': True},
+             'F': {'stubborn_transversalium': True, 'trans_strength': 41},
+             'G': {'stubborn_transversalium': True, 'de-vignette': True}}
 PRODUCT_KEY = {'clahe': 'cc', 'protus': 'protus', 'uncontrasted': 'raw', 'high_contrast': 'hc'}
 
 
@@ -44,13 +46,13 @@ def free_port():
         return s.getsockname()[1]
 
 
-def close_u16(got, want, max_flips=4):
+def close_u16(got, want, max_flips=4, lsb=1):
     assert got.shape == want.shape
     diff = np.abs(np.asarray(got).astype(np.int64) - np.asarray(want).astype(np.int64))
-    assert diff.max() <= 1 and np.count_nonzero(diff) <= max_flips, (diff.max(), np.count_nonzero(diff))
+    assert diff.max() <= lsb and np.count_nonzero(diff) <= max_flips, (diff.max(), np.count_nonzero(diff))
 
 
-@pytest.mark.parametrize('tag', ['A', 'B', 'C', 'D', 'E'])
+@pytest.mark.parametrize('tag', ['A', 'B', 'C', 'D', 'E', 'F', 'G'])
 def test_solex_read_process_vs_oracle_and_reference(pkg, scan, tag):
     SHG_MAIN, Solex_recon, outputs = pkg
     g, frames, path = scan
@@ -73,13 +75,14 @@ def test_solex_read_process_vs_oracle_and_reference(pkg, scan, tag):
     for shift, (cc, protus) in zip(requested, results):
         ref = want['results'][shift]
         # float stages (warp f64, transversalium f64 + device log, CLAHE f32): <= 1 LSB on a handful of pixels
-        close_u16(cc, ref['cc'])
+        # stubborn scenarios: a 1-LSB flip of the filtered frame (device exp / log) is stretched by the CLAHE slope
+        close_u16(cc, ref['cc'], lsb=4 if tag in 'FG' else 1)
         close_u16(protus, ref['protus'])
         for product in ('clahe', 'protus'):
             key = '%s_s%d_%s' % (tag, shift, product)
             # (float stages of a de-vignetted frame: the row factors agree to ~1e-15, same 1-LSB allowance)
             if key in g.files:                          # the reference's own output for this product
-                close_u16({'clahe': cc, 'protus': protus}[product], g[key])
+                close_u16({'clahe': cc, 'protus': protus}[product], g[key], lsb=4 if tag in 'FG' and product == 'clahe' else 1)
 
 
 def test_cli_writes_the_reference_file_layout(pkg, scan, tmp_path):
