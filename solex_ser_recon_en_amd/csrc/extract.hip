@@ -20,7 +20,7 @@ constexpr int TK = 64;        // output columns (frames) per workgroup
 constexpr int TKP = TK + 2;   // padded LDS row stride (33 dwords: odd)
 constexpr int SC = 4;         // shifts per workgroup
 
-template <typename T, bool ROT>
+template <typename T, bool ROT, int BATCH>
 __global__ __launch_bounds__(256) void k_extract(const T* __restrict__ stack, int n_frames, int64_t height, int64_t width, int64_t fstride,
                                                  const int32_t* __restrict__ ind_l, const double* __restrict__ lw,
                                                  const double* __restrict__ rw, int n_shifts,
@@ -52,20 +52,38 @@ __global__ __launch_bounds__(256) void k_extract(const T* __restrict__ stack, in
 #pragma unroll
     for (int s = 0; s < SC; ++s) off[s] = ROT ? (int64_t)il[s] * width + (width - 1 - y) : y * width + il[s];
 
-#pragma unroll 2
-    for (int cc = wave; cc < TK; cc += 4) {
-        const int64_t col = c0 + cc;
-        const int64_t k = (flip_x ? (n_cols - 1 - col) : col) - k_offset;   // wave-uniform
-        if (col >= n_cols || k < 0 || k >= n_frames) continue;
-        if (!y_ok) continue;
-        const T* f = stack + k * fstride;
+    // Frames of this wave: cc = wave, wave + 4, ...  BATCH of them at a time: all loads of the batch are issued
+    // before the first use, so a wave keeps BATCH * 2 * ns 128-byte requests in flight instead of waiting for each
+    // frame in turn.  Two frames per batch is where it stops paying (deeper batches cost registers, tools/sweep_extract.sh).
+    for (int cb = wave; cb < TK; cb += 4 * BATCH) {
+        T lv[BATCH][SC], rv[BATCH][SC];
+        bool ok[BATCH];
 #pragma unroll
-        for (int s = 0; s < SC; ++s) {
-            if (s < ns) {
-                const double l = (double)((int)f[off[s]] * scale);
-                const double r = (double)((int)f[off[s] + step] * scale);
-                const double v = l * wl + r * wr;
-                tile[s][lane][cc] = (uint16_t)(int)v;
+        for (int i = 0; i < BATCH; ++i) {
+            const int cc = cb + 4 * i;
+            const int64_t col = c0 + cc;
+            const int64_t k = (flip_x ? (n_cols - 1 - col) : col) - k_offset;   // wave-uniform
+            ok[i] = y_ok && cc < TK && col < n_cols && k >= 0 && k < n_frames;
+            const T* f = stack + (ok[i] ? k : 0) * fstride;
+#pragma unroll
+            for (int s = 0; s < SC; ++s) {
+                const bool ld = ok[i] && s < ns;
+                lv[i][s] = ld ? f[off[s]] : (T)0;
+                rv[i][s] = ld ? f[off[s] + step] : (T)0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            const int cc = cb + 4 * i;
+            if (!ok[i]) continue;
+#pragma unroll
+            for (int s = 0; s < SC; ++s) {
+                if (s < ns) {
+                    const double l = (double)((int)lv[i][s] * scale);
+                    const double r = (double)((int)rv[i][s] * scale);
+                    const double v = l * wl + r * wr;
+                    tile[s][lane][cc] = (uint16_t)(int)v;
+                }
             }
         }
     }
@@ -125,15 +143,24 @@ extern "C" int shg_extract_columns(const void* stack, int64_t n_frames, int64_t 
     dim3 grid((unsigned)((n_cols + TK - 1) / TK), (unsigned)((ih + TY - 1) / TY), (unsigned)((n_shifts + SC - 1) / SC));
     hipStream_t st = shg::as_stream(stream);
     const int n = (int)n_frames;
-#define SHG_LAUNCH(T, ROT)                                                                                              \
-    k_extract<T, ROT><<<grid, 256, 0, st>>>(static_cast<const T*>(stack), n, height, width, fstride, ind_l, lw, rw, n_shifts, \
-                                            disks, row_pitch, plane_stride, n_cols, k_offset, flip_x, vec_store)
+#define SHG_LAUNCH_B(T, ROT, B)                                                                                         \
+    k_extract<T, ROT, B><<<grid, 256, 0, st>>>(static_cast<const T*>(stack), n, height, width, fstride, ind_l, lw, rw, n_shifts, \
+                                               disks, row_pitch, plane_stride, n_cols, k_offset, flip_x, vec_store)
+#define SHG_LAUNCH(T, ROT)                                                 \
+    switch (batch) {                                                       \
+        case 1: SHG_LAUNCH_B(T, ROT, 1); break;                            \
+        case 4: SHG_LAUNCH_B(T, ROT, 4); break;                            \
+        default: SHG_LAUNCH_B(T, ROT, 2); break;                           \
+    }
+    static const int batch_env = [] { const char* e = getenv("SHG_EXT_BATCH"); return e ? atoi(e) : 0; }();   // tuning override
+    const int batch = batch_env > 0 ? batch_env : 2;      // measured: 1 -> 30 us, 2 and 4 -> 22 us, 8 -> 35 us, 16 -> 64 us (C2, S=2)
     SHG_PROF("extract", st);
     if (bytes_per_px == 2) {
-        if (rot) SHG_LAUNCH(uint16_t, true); else SHG_LAUNCH(uint16_t, false);
+        if (rot) SHG_LAUNCH(uint16_t, true) else SHG_LAUNCH(uint16_t, false)
     } else {
-        if (rot) SHG_LAUNCH(uint8_t, true); else SHG_LAUNCH(uint8_t, false);
+        if (rot) SHG_LAUNCH(uint8_t, true) else SHG_LAUNCH(uint8_t, false)
     }
+#undef SHG_LAUNCH_B
 #undef SHG_LAUNCH
     return shg::check_launch("k_extract");
 }
