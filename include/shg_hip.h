@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SHG_ABI_VERSION 5
+#define SHG_ABI_VERSION 6
 
 #define SHG_E_ARG        (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SHG_E_WORKSPACE  (-2)   /* workspace too small                                 */
@@ -77,6 +77,16 @@ int shg_accumulate_sum_max(const void* stack, int64_t n_frames, int64_t height, 
 int64_t shg_frame_pitch_bytes(int64_t frame_bytes);
 int shg_upload_frames(void* dst, int64_t dst_pitch_bytes, const void* host_src, int64_t frame_bytes,
                       int64_t n_frames, shg_stream_t stream);
+
+/* Uncompressed AVI frames (cv2.VideoCapture + COLOR_BGR2GRAY, video_reader.py:68-80, 111-113) into the
+ * uint8 stack: raw holds n_frames chunk payloads raw_pitch_bytes apart, each `height` rows of row_bytes
+ * (bottom_up: last row first); bits 8 (optional 256-entry grey table for palettised frames, NULL =
+ * identity) or 24 (B, G, R; OpenCV 4's (B*3735 + G*19235 + R*9798 + 2^14) >> 15).  At most 65535
+ * frames per call. */
+int shg_unpack_dib_frames(const uint8_t* raw, int64_t n_frames, int64_t raw_pitch_bytes, int64_t height,
+                          int64_t width, int bits, int64_t row_bytes, int bottom_up,
+                          const uint8_t* gray_lut, uint8_t* stack, int64_t frame_stride_px,
+                          shg_stream_t stream);
 
 /* mean = trunc(sum / n_total) as uint16 (solex_util.py:188), 8-bit samples scaled by
  * 256, both images rotated into the reference's [ih][iw] orientation. */

@@ -75,6 +75,86 @@ class SerReader:
         return img
 
 
+class AviReader:
+    """The AVI branch of the reference's video_reader (video_reader.py:20-23, 68-80, 111-113):
+    cv2.VideoCapture(file).read() -> BGR frame -> cv2.cvtColor(COLOR_BGR2GRAY) -> rot90 / x256 as for SER.
+    UNPINNED: cv2 is absent.  Restated for UNCOMPRESSED streams only, from the AVI RIFF layout: the frames are
+    located through the file's 'idx1' index (the product walks the 'movi' chunks instead), decoded to the BGR
+    image VideoCapture would hand back, and converted with OpenCV 4's 8-bit BGR2GRAY
+    (B*3735 + G*19235 + R*9798 + 2^14) >> 15."""
+
+    def __init__(self, path):
+        import struct
+        data = open(path, 'rb').read()
+        assert data[:4] == b'RIFF' and data[8:12] == b'AVI '
+        # stream headers in file order; the first 'vids' stream is the one VideoCapture decodes
+        kinds, pos = [], 0
+        while True:
+            pos = data.find(b'strh', pos)
+            if pos < 0:
+                break
+            kinds.append(data[pos + 8:pos + 12])
+            pos += 4
+        vid = kinds.index(b'vids')
+        strf = data.find(b'strf', data.find(b'vids'))
+        strf_size = struct.unpack_from('<I', data, strf + 4)[0]
+        bi = strf + 8
+        bi_size, w, h, _, bits, comp = struct.unpack_from('<IiiHH4s', data, bi)
+        self.Width, self.Height = w, abs(h)
+        raw_rgb = comp == b'\0\0\0\0'
+        if not (raw_rgb and bits in (8, 24)) and not (comp in (b'Y800', b'Y8  ', b'GREY') and bits == 8):
+            raise Exception('compressed AVI')
+        flip = raw_rgb and h > 0                              # a DIB with positive height stores the bottom row first
+        row = (w * bits + 31) // 32 * 4 if raw_rgb else w
+        palette = None
+        if raw_rgb and bits == 8 and strf_size > bi_size:
+            palette = np.frombuffer(data, np.uint8, (strf_size - bi_size) // 4 * 4, bi + bi_size).reshape(-1, 4)[:, :3]
+        movi = data.find(b'movi')
+        idx = data.rfind(b'idx1')
+        n_idx = struct.unpack_from('<I', data, idx + 4)[0] // 16
+        self._bgr = []
+        for e in range(n_idx):
+            ckid, _flags, off, size = struct.unpack_from('<4sIII', data, idx + 8 + 16 * e)
+            if ckid[2:4] not in (b'db', b'dc') or int(ckid[:2]) != vid or size == 0:
+                continue
+            at = movi + off if data[movi + off:movi + off + 4] == ckid else off       # offsets from 'movi' (usual) or absolute
+            rows = np.frombuffer(data, np.uint8, row * self.Height, at + 8).reshape(self.Height, row)
+            if flip:
+                rows = rows[::-1]
+            if bits == 24:
+                bgr = rows[:, :3 * w].reshape(self.Height, w, 3)
+            else:
+                index = rows[:, :w]
+                bgr = palette[index] if palette is not None else np.stack([index] * 3, axis=-1)
+            self._bgr.append(bgr)
+        self.FrameCount = len(self._bgr)
+        self.infilebytes, self.infiledatatype = 1, 'uint8'      # video_reader.py:23, 77
+        self.count = self.Width * self.Height
+        self.flag_rotate = self.Width > self.Height
+        self.ih, self.iw = (self.Width, self.Height) if self.flag_rotate else (self.Height, self.Width)
+        self.FrameIndex = -1
+
+    def has_frames(self):
+        return self.FrameIndex + 1 < self.FrameCount
+
+    @staticmethod
+    def bgr2gray(bgr):
+        b, g, r = (bgr[..., i].astype(np.int64) for i in range(3))
+        return ((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15).astype(np.uint8)
+
+    def next_frame(self):
+        self.FrameIndex += 1
+        img = self.bgr2gray(self._bgr[self.FrameIndex])         # video_reader.py:112-113
+        img = np.reshape(img, (self.Height, self.Width))
+        if self.flag_rotate:
+            img = np.rot90(img)
+        return np.asarray(img, dtype='uint16') * 256            # video_reader.py:121-122
+
+    def raw_frames(self):
+        """[N, Height, Width] uint8 grey frames in file orientation (what the GPU stack holds)."""
+        return np.stack([self.bgr2gray(f) for f in self._bgr])
+
+
 # ----------------------------------------------------------------------------
 # a2  mean and max frames                                  solex_util.py:174-188
 # ----------------------------------------------------------------------------

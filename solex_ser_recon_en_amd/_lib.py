@@ -35,6 +35,7 @@ SIGNATURES = {
     'shg_accumulate_sum_max': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int64, P, P, P, c_size_t, P]),
     'shg_frame_pitch_bytes': (c_int64, [c_int64]),
     'shg_upload_frames': (c_int, [P, c_int64, P, c_int64, c_int64, P]),
+    'shg_unpack_dib_frames': (c_int, [P, c_int64, c_int64, c_int64, c_int64, c_int, c_int64, c_int, P, P, c_int64, P]),
     'shg_finalize_mean_max': (c_int, [P, P, c_int64, c_int64, c_int64, c_int, P, P, P]),
     'shg_box_blur_u16': (c_int, [P, c_int64, c_int64, c_int, c_int, P, P, P]),
     'shg_row_argmin_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int64, P, P]),
@@ -75,7 +76,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 if lib.shg_abi_version() != ABI_VERSION:
     raise ImportError('libshg_hip.so ABI %d != expected %d: rebuild it' % (lib.shg_abi_version(), ABI_VERSION))
 

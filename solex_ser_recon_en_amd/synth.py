@@ -86,6 +86,71 @@ def write_ser(path, frames, depth_bits=None):
     return path
 
 
+def write_avi(path, frames, layout='Y800', bottom_up=None, palette=None, audio_every=0, junk_bytes=0, rec_lists=False):
+    """Write frames as an uncompressed AVI 1.0 file (RIFF 'AVI ', hdrl / movi / idx1) -- test input for the AVI reader.
+    layout 'Y800': frames uint8 [N, H, W], 8-bit luma, top-down, no row padding;
+           'pal8': frames uint8 [N, H, W] of palette indices, BI_RGB 8 bit, rows padded to 4 bytes,
+                   bottom-up unless bottom_up=False (negative biHeight); palette uint8 [256, 3] B,G,R (default grey ramp);
+           'bgr24': frames uint8 [N, H, W, 3] (B, G, R), BI_RGB 24 bit, same row rules.
+    audio_every > 0 interleaves a dummy '01wb' chunk after every that many frames (uneven chunk spacing),
+    junk_bytes > 0 puts a JUNK chunk before 'movi', rec_lists wraps every frame in a LIST 'rec '."""
+    import struct
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    n, h, w = frames.shape[:3]
+    raw_rgb = layout in ('pal8', 'bgr24')
+    bits = 24 if layout == 'bgr24' else 8
+    if bottom_up is None:
+        bottom_up = raw_rgb
+    row = w if layout == 'Y800' else (w * bits + 31) // 32 * 4
+    payload = row * h
+
+    def chunk(cid, data):
+        return cid + struct.pack('<I', len(data)) + data + (b'\0' if len(data) & 1 else b'')
+
+    def lst(ltype, body):
+        return b'LIST' + struct.pack('<I', 4 + len(body)) + ltype + body
+
+    pal = b''
+    if layout == 'pal8':
+        p = np.stack([np.arange(256)] * 3, axis=1).astype(np.uint8) if palette is None else np.asarray(palette, dtype=np.uint8)
+        pal = np.concatenate([p, np.zeros((256, 1), np.uint8)], axis=1).tobytes()
+    fourcc = b'\0\0\0\0' if raw_rgb else b'Y800'
+    bih = struct.pack('<IiiHH4sIiiII', 40, w, h if (bottom_up or not raw_rgb) else -h, 1, bits, fourcc, payload, 0, 0,
+                      256 if layout == 'pal8' else 0, 0) + pal
+    strh = struct.pack('<4s4sIHHIIIIIIII4h', b'vids', b'DIB ' if raw_rgb else b'Y800', 0, 0, 0, 0, 1, 25, 0, n, payload, 0xffffffff, 0,
+                       0, 0, w, h)
+    avih = struct.pack('<14I', 40000, payload * 25, 0, 0x10, n, 0, 2 if audio_every else 1, payload, w, h, 0, 0, 0, 0)
+    streams = lst(b'strl', chunk(b'strh', strh) + chunk(b'strf', bih))
+    if audio_every:
+        wave = struct.pack('<HHIIHH', 1, 1, 8000, 8000, 1, 8)
+        strh_a = struct.pack('<4s4sIHHIIIIIIII4h', b'auds', b'\0\0\0\0', 0, 0, 0, 0, 1, 8000, 0, 0, 0, 0xffffffff, 1, 0, 0, 0, 0)
+        streams += lst(b'strl', chunk(b'strh', strh_a) + chunk(b'strf', wave))
+    hdrl = lst(b'hdrl', chunk(b'avih', avih) + streams)
+    pre = hdrl + (chunk(b'JUNK', b'\0' * junk_bytes) if junk_bytes else b'')
+    movi = bytearray()
+    index = bytearray()
+    for k in range(n):
+        img = frames[k].reshape(h, -1)
+        if bottom_up:
+            img = img[::-1]
+        rows = np.zeros((h, row), dtype=np.uint8)
+        rows[:, :img.shape[1]] = img
+        body = chunk(b'00db', rows.tobytes())
+        if rec_lists:
+            body = lst(b'rec ', body)
+            index += struct.pack('<4sIII', b'00db', 0x10, 4 + len(movi) + 12, payload)
+        else:
+            index += struct.pack('<4sIII', b'00db', 0x10, 4 + len(movi), payload)
+        movi += body
+        if audio_every and (k + 1) % audio_every == 0:
+            index += struct.pack('<4sIII', b'01wb', 0x10, 4 + len(movi), 40)
+            movi += chunk(b'01wb', bytes(40))
+    body = pre + lst(b'movi', bytes(movi)) + chunk(b'idx1', bytes(index))
+    with open(path, 'wb') as f:
+        f.write(b'RIFF' + struct.pack('<I', 4 + len(body)) + b'AVI ' + body)
+    return path
+
+
 def synth_frames_torch(n_frames, width, height, depth_bits=16, seed=0, device='cuda',
                        k0=0, k1=None, n_total=None, chunk=250, padded=False):
     """Same scene built directly on `device` (bench workloads; torch RNG, so not

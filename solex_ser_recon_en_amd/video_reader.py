@@ -8,7 +8,9 @@ stream (double-buffered, asynchronous hipMemcpy) -- the file is read ONCE and bo
 frame passes run on the resident stack (the reference decodes it twice,
 Solex_recon.py:61-63).  The rotation of wide frames (video_reader.py:119-120) and the
 8-bit x256 widening (:121-122) are never materialised for the stack: the kernels index
-the file layout directly.  AVI input needs a video codec and is out of scope.
+the file layout directly.  AVI: uncompressed streams (8-bit grey, 8-bit palettised, 24-bit DIB) are
+indexed by avi_io.AviIndex, uploaded as they lie in the file and re-laid into the same uint8 stack by
+shg_unpack_dib_frames; compressed AVI needs a codec and raises.
 """
 import itertools
 import os
@@ -46,8 +48,21 @@ class video_reader:
         self.file = file
         self.buffer_size = buffer_size
         upper = str(file).upper()
-        if upper.endswith('.AVI'):
-            raise Exception('error input file ' + file + ': AVI input is not supported by the MI355X path (SER only)')
+        self._mm = None
+        self._stack = None
+        if upper.endswith('.AVI'):                              # video_reader.py:20-23, 68-80
+            from .avi_io import AviIndex
+            self.SER_flag, self.AVI_flag = False, True
+            self._avi = AviIndex(file)
+            self.infiledatatype, self.infilebytes = 'uint8', 1
+            self.Width, self.Height = self._avi.width, self._avi.height
+            self.PixelDepthPerPlane = 8
+            self.FrameCount = self._avi.frame_count
+            self.count = self.Width * self.Height
+            self.FrameIndex = -1
+            self.offset = self.fileoffset = 0
+            self._set_orientation(frame_range)
+            return
         if not upper.endswith('.SER'):
             raise Exception('error input file ' + file + 'neither is SER nor AVI')        # video_reader.py:26
         with open(file, 'rb') as f:
@@ -68,14 +83,15 @@ class video_reader:
         self.count = self.Width * self.Height
         self.FrameIndex = -1
         self.offset = self.fileoffset = SER_HEADER_BYTES
+        self._set_orientation(frame_range)
+
+    def _set_orientation(self, frame_range):
         if self.Width > self.Height:                        # video_reader.py:84-91
             self.flag_rotate, self.ih, self.iw = True, self.Width, self.Height
         else:
             self.flag_rotate, self.iw, self.ih = False, self.Width, self.Height
         # frame block owned by this process (multi-GPU sharding); FrameCount stays the scan length
         self.frame_range = (0, int(self.FrameCount)) if frame_range is None else (int(frame_range[0]), int(frame_range[1]))
-        self._mm = None
-        self._stack = None
 
     # ---- host iterator (compatibility; not used by the GPU path) ------------
     def _memmap(self):
@@ -91,7 +107,7 @@ class video_reader:
     def next_frame(self):
         self.FrameIndex += 1
         self.offset = self.fileoffset + self.FrameIndex * int(self.count) * self.infilebytes
-        img = np.array(self._memmap()[self.FrameIndex])
+        img = self._avi.frame(self.FrameIndex) if self.AVI_flag else np.array(self._memmap()[self.FrameIndex])
         if self.flag_rotate:
             img = np.rot90(img)
         if self.infilebytes == 1:
@@ -112,6 +128,9 @@ class video_reader:
         if self._stack is not None:
             return self._stack
         device = device or default_device()
+        if self.AVI_flag:
+            self._stack = self._avi_device_stack(device, chunk_bytes)
+            return self._stack
         k0, k1 = self.frame_range
         n = k1 - k0
         h, w, b = int(self.Height), int(self.Width), self.infilebytes
@@ -188,6 +207,69 @@ class video_reader:
         for st in streams:
             cur.wait_stream(st)
         self._stack = stack
+        return stack
+
+
+    def _avi_device_stack(self, device, chunk_bytes):
+        """Frames [k0:k1) of an uncompressed AVI as the uint8 [n, Height, Width] stack: chunk payloads go to HBM as
+        they lie in the file (one contiguous read per block when the chunks are evenly spaced, which is what capture
+        programs write), then one re-layout kernel (row order, row padding, palette / BGR -> grey)."""
+        from . import _lib, ops
+        avi = self._avi
+        k0, k1 = self.frame_range
+        n = k1 - k0
+        if n <= 0:
+            raise Exception('error input file ' + str(self.file) + ': no frames')
+        pitch = avi.stride if avi.stride is not None else avi.payload_bytes
+        raw = torch.empty(n * pitch, dtype=torch.uint8, device=device)
+        chunk_frames = max(1, chunk_bytes // pitch)
+        bufs = _lease_pinned_pair(chunk_frames * pitch)
+        events = [None, None]
+        stream = torch.cuda.Stream(device=device)
+        fd = os.open(self.file, os.O_RDONLY)
+        try:
+            slot = 0
+            for f0 in range(0, n, chunk_frames):
+                m = min(chunk_frames, n - f0)
+                if events[slot] is not None:
+                    events[slot].synchronize()
+                view = bufs[slot][:m * pitch]
+                mv = memoryview(view.numpy())
+                if avi.stride is not None:               # payload k sits at offsets[k0] + k * stride: one read, chunk headers included
+                    spans = [(0, m * pitch - (pitch - avi.payload_bytes), int(avi.offsets[k0 + f0]))]
+                else:
+                    spans = [(i * pitch, avi.payload_bytes, int(avi.offsets[k0 + f0 + i])) for i in range(m)]
+                for dst0, nbytes, pos in spans:
+                    got = 0
+                    while got < nbytes:
+                        r = os.preadv(fd, [mv[dst0 + got:dst0 + nbytes]], pos + got)
+                        if r <= 0:
+                            raise Exception('error input file ' + str(self.file) + ': short read')
+                        got += r
+                _lib.check(_lib.lib.shg_upload_frames(raw.data_ptr() + f0 * pitch, m * pitch, view.data_ptr(), m * pitch, 1,
+                                                      stream.cuda_stream), 'shg_upload_frames')
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                events[slot] = ev
+                slot ^= 1
+        finally:
+            os.close(fd)
+            for ev in events:
+                if ev is not None:
+                    ev.synchronize()
+            _return_pinned_pair(bufs)
+        h, w = int(self.Height), int(self.Width)
+        stack = ops.padded_stack(n, h, w, torch.uint8, device)
+        cur = torch.cuda.current_stream(device)
+        cur.wait_stream(stream)
+        lut = torch.from_numpy(avi.gray_lut).to(device) if avi.gray_lut is not None else None
+        fstride = stack.stride(0) if n > 1 else h * w
+        for f0 in range(0, n, 32768):                          # grid limit: 65535 frames per launch
+            m = min(32768, n - f0)
+            _lib.check(_lib.lib.shg_unpack_dib_frames(raw.data_ptr() + f0 * pitch, m, pitch, h, w, avi.bit_count, avi.row_bytes,
+                                                      int(avi.bottom_up), lut.data_ptr() if lut is not None else None,
+                                                      stack.data_ptr() + f0 * fstride, fstride, cur.cuda_stream),
+                       'shg_unpack_dib_frames')
         return stack
 
 

@@ -265,3 +265,73 @@ def test_stubborn_control_plane_matches_oracle():
         np.testing.assert_array_equal(xb, rxb)
         np.testing.assert_array_equal(edge & 1, left.astype(np.uint8))
         np.testing.assert_array_equal(edge >> 1, right.astype(np.uint8))
+
+
+AVI_CASES = [('Y800', {}), ('pal8', {}), ('pal8', {'bottom_up': False}), ('pal8', {'audio_every': 3, 'junk_bytes': 37}),
+             ('Y800', {'rec_lists': True}), ('pal8', {'palette': 'random'}), ('bgr24', {}), ('bgr24', {'bottom_up': False})]
+
+
+def avi_case(path, layout, kw, n=7, h=9, w=14, seed=0):
+    rng = np.random.default_rng(seed)
+    kw = dict(kw)
+    if kw.get('palette') == 'random':
+        kw['palette'] = rng.integers(0, 256, (256, 3)).astype(np.uint8)
+    shape = (n, h, w, 3) if layout == 'bgr24' else (n, h, w)
+    frames = rng.integers(0, 256, shape).astype(np.uint8)
+    synth.write_avi(path, frames, layout, **kw)
+    return frames
+
+
+@pytest.mark.parametrize('layout,kw', AVI_CASES)
+@pytest.mark.parametrize('h,w', [(9, 14), (14, 9), (5, 5)])
+def test_avi_index_and_host_frames_match_oracle(tmp_path, layout, kw, h, w):
+    """Uncompressed AVI: the product walks the 'movi' chunks, the oracle follows 'idx1'; both must land on the same
+    pixels, in the reference's orientation (video_reader.py:111-122), for every row order / padding / palette."""
+    from solex_ser_recon_en_amd.video_reader import video_reader
+    path = str(tmp_path / 'scan.avi')
+    frames = avi_case(path, layout, kw, h=h, w=w)
+    rdr, ref = video_reader(path), orc.AviReader(path)
+    assert (rdr.Width, rdr.Height, rdr.FrameCount, rdr.ih, rdr.iw, rdr.flag_rotate) == \
+           (ref.Width, ref.Height, ref.FrameCount, ref.ih, ref.iw, ref.flag_rotate) == (w, h, 7, max(h, w), min(h, w), w > h)
+    assert rdr.infilebytes == 1 and rdr.infiledatatype == 'uint8' and rdr.AVI_flag and not rdr.SER_flag
+    if layout != 'bgr24' and 'palette' not in kw:
+        np.testing.assert_array_equal(ref.raw_frames(), frames)          # grey in, grey out: BGR2GRAY is the identity
+    k = 0
+    while rdr.has_frames():
+        assert ref.has_frames()
+        got, want = rdr.next_frame(), ref.next_frame()
+        assert got.dtype == np.uint16 and got.shape == (max(h, w), min(h, w))
+        np.testing.assert_array_equal(got, want)
+        k += 1
+    assert k == 7 and not ref.has_frames()
+
+
+def test_avi_compressed_or_broken_files_raise(tmp_path):
+    from solex_ser_recon_en_amd.video_reader import video_reader
+    path = str(tmp_path / 'scan.avi')
+    avi_case(path, 'Y800', {})
+    data = bytearray(open(path, 'rb').read())
+    at = data.find(b'strf') + 8 + 16
+    assert data[at:at + 4] == b'Y800'
+    data[at:at + 4] = b'MJPG'
+    open(path, 'wb').write(data)
+    with pytest.raises(Exception, match='codec'):
+        video_reader(path)
+    open(path, 'wb').write(b'RIFF\x04\x00\x00\x00WAVE')
+    with pytest.raises(Exception, match='not a RIFF AVI'):
+        video_reader(path)
+    avi_case(path, 'pal8', {})
+    data = open(path, 'rb').read()
+    open(path, 'wb').write(data[:len(data) // 2])                        # truncated inside 'movi'
+    with pytest.raises(Exception):
+        rdr = video_reader(path)
+        while rdr.has_frames():
+            rdr.next_frame()
+
+
+def test_bgr2gray_fixed_point():
+    from solex_ser_recon_en_amd.avi_io import bgr_to_gray_u8
+    v = np.arange(256, dtype=np.uint8)
+    np.testing.assert_array_equal(bgr_to_gray_u8(v, v, v), v)            # identity on grey
+    b, g, r = np.array([255, 0, 0], np.uint8), np.array([0, 255, 0], np.uint8), np.array([0, 0, 255], np.uint8)
+    np.testing.assert_array_equal(bgr_to_gray_u8(b, g, r), [29, 150, 76])   # OpenCV's well-known primaries

@@ -362,3 +362,49 @@ def test_solex_read_shift_order_vs_reference(pkg, golden, tmp_path):
         assert tuple(int(b) for b in bounds) == tuple(int(b) for b in g['bounds_%d' % k])
         got = np.stack([np.frombuffer(hashlib.sha256(np.ascontiguousarray(np.asarray(d)).tobytes()).digest(), np.uint8) for d in disks])
         np.testing.assert_array_equal(got, g['disk_sha256_%d' % k])
+
+
+# ---- uncompressed AVI input (video_reader.py:68-80, 111-113) -------------------------------------------------
+def test_avi_device_stack_matches_oracle(pkg, tmp_path):
+    """Every uncompressed layout through the raw upload + shg_unpack_dib_frames, against the oracle's idx1-based decode;
+    includes a sharded frame range and chunked uploads (chunk_bytes smaller than the file)."""
+    from oracle import shg_oracle as orc
+    from solex_ser_recon_en_amd import ops
+    from solex_ser_recon_en_amd.video_reader import video_reader
+    from tests.test_host_cpu import AVI_CASES, avi_case
+    path = str(tmp_path / 'scan.avi')
+    for layout, kw in AVI_CASES:
+        for h, w in [(9, 14), (37, 21)]:
+            avi_case(path, layout, kw, n=11, h=h, w=w, seed=h)
+            want = orc.AviReader(path).raw_frames()
+            got = ops.stack_to_host(video_reader(path).device_stack())
+            assert got.dtype == np.uint8
+            np.testing.assert_array_equal(got, want, err_msg='%s %s %dx%d' % (layout, kw, h, w))
+            rdr = video_reader(path, frame_range=(3, 9))
+            part = ops.stack_to_host(rdr.device_stack(chunk_bytes=2 * h * ((w * 3 + 3) // 4 * 4)))
+            np.testing.assert_array_equal(part, want[3:9])
+
+
+@pytest.mark.parametrize('layout', ['Y800', 'pal8'])
+def test_solex_read_from_avi_equals_ser(pkg, tmp_path, layout):
+    """The same 8-bit scan as SER and as uncompressed AVI: identical raw disks, bounds and products; both equal the oracle."""
+    SHG_MAIN, Solex_recon, outputs = pkg
+    frames = synth.synth_frames_numpy(400, 400, 32, 8, seed=5, tilt=0.01, curv=5e-5)
+    ser, avi = str(tmp_path / 'scan.ser'), str(tmp_path / 'scan.avi')
+    synth.write_ser(ser, frames)
+    synth.write_avi(avi, frames, layout)
+    want = po.run(frames, {})
+    results = {}
+    for path in (ser, avi):
+        opts = SHG_MAIN.default_options()
+        opts.update(_nolog=True)
+        disks, bounds, hdr = Solex_recon.solex_read(path, opts)
+        for got, ref in zip(disks, want['read']['disks']):
+            np.testing.assert_array_equal(np.asarray(got), ref)
+        assert tuple(int(b) for b in bounds) == (want['read']['y1'], want['read']['y2'])
+        out = Solex_recon.solex_process(opts, disks, bounds, hdr)
+        outputs.flush()
+        results[path] = [np.asarray(x) for x in out[0]]
+    for a, b in zip(results[ser], results[avi]):
+        np.testing.assert_array_equal(a, b)
+    close_u16(results[avi][0], want['results'][0]['cc'])
