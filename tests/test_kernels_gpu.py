@@ -495,3 +495,22 @@ def test_lin_filter_vs_oracle_and_reference_shim(ops, orc, golden, case):
         assert mx <= 1 and n <= 8, (mx, n)
     if case in ('u16', 'bb'):
         assert flag.sum() >= 3 and '_transversalium_cache' not in opts
+
+
+@pytest.mark.parametrize('n', [255, 256, 257, 513, 1300])
+@pytest.mark.parametrize('nsplit', ['1', '2', ''])
+def test_u8_sums_across_the_packed_u16_flush(ops, monkeypatch, n, nsplit):
+    """8-bit frames are summed in packed u16 pairs that are folded into u32 every 256 frames: saturated and random
+    stacks on either side of the fold, with the frame axis in one piece, two, or split by the heuristic."""
+    if nsplit:
+        monkeypatch.setenv('SHG_ACC_NSPLIT', nsplit)          # the library reads its tuning overrides per call
+    rng = np.random.default_rng(n)
+    h, w = 3, 32                                                        # 96 B frames: the 16-byte vector path
+    sat = torch.full((n, h, w), 255, dtype=torch.uint8, device='cuda')
+    total, mx = ops.accumulate_sum_max(sat)
+    assert int(total.min()) == int(total.max()) == 255 * n and int(mx.view(torch.int16).min()) == 255
+    frames = rng.integers(0, 256, (n, h, w)).astype(np.uint8)
+    frames[:, 0, :5] = 255
+    total, mx = ops.accumulate_sum_max(dev(frames))
+    np.testing.assert_array_equal(host(total).reshape(h, w), frames.sum(axis=0, dtype=np.uint64).astype(np.int64))
+    np.testing.assert_array_equal(host(mx.view(torch.int16)).reshape(h, w).astype(np.uint16), frames.max(axis=0))

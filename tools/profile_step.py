@@ -35,3 +35,4 @@ torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
 st.sort_stats('cumulative').print_stats(45)
+st.sort_stats('tottime').print_stats(40)
