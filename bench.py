@@ -147,7 +147,6 @@ def main():
         except Exception:      # noqa: BLE001
             traffic = None
     from solex_ser_recon_en_amd import ops as _ops
-    frame_bytes = ih * iw * bpp
     pitch_bytes = _ops.frame_stride(stack) * bpp
     flat = torch.as_strided(stack, (stack.shape[0] * pitch_bytes // bpp,), (1,)) if stack.shape[0] > 1 else stack.reshape(-1)
     ceiling, ceiling_shape = _ops.stream_read_ceiling(flat)

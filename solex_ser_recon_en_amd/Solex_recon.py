@@ -22,7 +22,6 @@ import os
 import threading
 
 import numpy as np
-import torch
 
 from . import dist, ops, outputs, timing
 from .device import DeviceImage, to_device_u16

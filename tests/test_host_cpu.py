@@ -54,7 +54,6 @@ def test_order_stat_helpers_are_numpy():
 def test_limb_control_plane_matches_oracle(golden):
     """The host half of the limb fit (threshold choice, hysteresis, region selection, ellipse LSQ)
     against the oracle, fed with the arrays the GPU half would produce."""
-    from scipy import ndimage as ndi
     g = golden('g13_limb')
     small = g['small']
     k = int(small.shape[0] * 0.01)
@@ -76,8 +75,6 @@ def test_limb_control_plane_matches_oracle(golden):
 
 def test_limb_region_selection_cases():
     """Two largest regions by size value (ties -> first), hull filter, 1.7 % row crop: mask form vs point form."""
-    from scipy import ndimage as ndi
-    rng = np.random.default_rng(9)
 
     def ring(shape, cy, cx, r, arc=(0, 2 * np.pi)):
         m = np.zeros(shape, bool)

@@ -272,7 +272,6 @@ def test_edge_components_match_scipy_label(ops, seed):
 
 def test_canny_masks_match_skimage_0_18_3(ops, orc, golden):
     """GPU canny (Gaussian, Sobel, hypot, NMS, thresholds) + host hysteresis == the real scikit-image output."""
-    from solex_ser_recon_en_amd import limb_fit
     g = golden('g13_limb')
     small = g['small']
     k = int(small.shape[0] * 0.01)
@@ -360,7 +359,6 @@ def test_remove_vignette_golden(ops, golden, tag):
 
 def test_row_factor_paths_match_float_image(ops, orc, golden):
     """rowpair statistics / row scaling on the factored float64 frame == the oracle on the materialised one."""
-    import math
     g = golden('g4_transversalium')
     img = g['image']
     rng = np.random.default_rng(3)

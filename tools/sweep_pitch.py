@@ -1,7 +1,6 @@
 """How the frame-walking read rate depends on the frame pitch (probe mode 2, XOR only)."""
 import sys
 sys.path.insert(0, '.')
-import torch
 from solex_ser_recon_en_amd import ops, synth
 stack = synth.synth_frames_torch(2100, 2000, 200, 16, seed=0)
 res = []

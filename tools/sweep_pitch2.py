@@ -1,6 +1,5 @@
 import sys
 sys.path.insert(0, '.')
-import torch
 from solex_ser_recon_en_amd import ops, synth
 stack = synth.synth_frames_torch(2100, 2000, 200, 16, seed=0)
 for rep in range(2):
