@@ -165,10 +165,20 @@ template <int BPP, int UNROLL, bool NT>
 __global__ __launch_bounds__(256) void k_accumulate_vec(const u32x4* __restrict__ stack, int64_t vecs, int64_t fstride,
                                                         int n_frames, int frames_per_split,
                                                         uint32_t* __restrict__ psum, uint16_t* __restrict__ pmax,
-                                                        int64_t npix) {
-    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                        int64_t npix, int nsplit, int xcd_per_split) {
+    // Column block and frame split of this workgroup.  Plain mapping: (blockIdx.x, blockIdx.y).  XCD-aware mapping
+    // (1-D grid): workgroups b and b + 8 share an XCD under round-robin dispatch, so giving the XCDs with
+    // (b % 8) / xcd_per_split == s split s keeps every XCD on one frame range (tried for TLB / DRAM-page locality).
+    int64_t cb = blockIdx.x;
+    int split = blockIdx.y;
+    if (xcd_per_split > 0) {
+        const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        split = (int)(xcd / (unsigned)xcd_per_split);
+        cb = (int64_t)slot * xcd_per_split + (xcd % (unsigned)xcd_per_split);
+        if (split >= nsplit) return;
+    }
+    const int64_t v = cb * 256 + threadIdx.x;
     if (v >= vecs) return;
-    const int split = blockIdx.y;
     const int k0 = split * frames_per_split;
     const int k1 = min(n_frames, k0 + frames_per_split);
     Acc<BPP> acc;
@@ -248,14 +258,22 @@ __global__ __launch_bounds__(256) void k_finalize(const uint64_t* __restrict__ s
 
 template <int BPP, bool NT>
 void launch_vec(const Plan& p, const void* stack, int n, uint32_t* psum, uint16_t* pmax, hipStream_t st) {
-    dim3 grid((unsigned)((p.vecs + 255) / 256), (unsigned)p.nsplit);
-    const u32x4* s = static_cast<const u32x4*>(stack);
-    switch (p.unroll) {
-        case 2: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 2, NT><<<grid, 256, 0, st>>>(s, p.vecs, p.stride_vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
-        case 4: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 4, NT><<<grid, 256, 0, st>>>(s, p.vecs, p.stride_vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
-        case 16: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 16, NT><<<grid, 256, 0, st>>>(s, p.vecs, p.stride_vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
-        default: { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, 8, NT><<<grid, 256, 0, st>>>(s, p.vecs, p.stride_vecs, n, p.frames_per_split, psum, pmax, p.npix); } break;
+    const int64_t nblk = (p.vecs + 255) / 256;
+    dim3 grid((unsigned)nblk, (unsigned)p.nsplit);
+    int xcd_per = 0;
+    if (env_int("SHG_ACC_XCD", 0) && p.nsplit <= 8 && 8 % p.nsplit == 0) {      // tuning experiment, off by default
+        xcd_per = 8 / p.nsplit;
+        grid = dim3((unsigned)(8 * ((nblk + xcd_per - 1) / xcd_per)), 1u);
     }
+    const u32x4* s = static_cast<const u32x4*>(stack);
+#define SHG_ACC_LAUNCH(U) { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, U, NT><<<grid, 256, 0, st>>>(s, p.vecs, p.stride_vecs, n, p.frames_per_split, psum, pmax, p.npix, p.nsplit, xcd_per); }
+    switch (p.unroll) {
+        case 2: SHG_ACC_LAUNCH(2) break;
+        case 4: SHG_ACC_LAUNCH(4) break;
+        case 16: SHG_ACC_LAUNCH(16) break;
+        default: SHG_ACC_LAUNCH(8) break;
+    }
+#undef SHG_ACC_LAUNCH
 }
 
 size_t slab_bytes(const Plan& p) {
