@@ -35,8 +35,11 @@ def scene_params(n_frames, ih, iw):
 
 
 def synth_frames_numpy(n_frames, width, height, depth_bits=16, seed=0, row_gain=None,
-                       k0=0, k1=None, n_total=None, tilt=0.002, curv=6e-6):
+                       k0=0, k1=None, n_total=None, tilt=0.002, curv=6e-6, scene=None):
     """Return frames [k1-k0, Height, Width] (file layout) as uint8/uint16.
+
+    scene overrides entries of scene_params() (disk centre / semi-axes, lit slit span, line depth / width, gain,
+    sky, noise) for scans that are off-centre, elongated, noisier ...
 
     n_total is the length of the whole scan (defaults to n_frames); k0:k1 selects
     a block of frames of that scan (used for sharded generation).  The noise of
@@ -46,7 +49,7 @@ def synth_frames_numpy(n_frames, width, height, depth_bits=16, seed=0, row_gain=
     k1 = n_total if k1 is None else k1
     rotate = width > height
     ih, iw = (width, height) if rotate else (height, width)
-    sp = scene_params(n_total, ih, iw)
+    sp = dict(scene_params(n_total, ih, iw), **(scene or {}))
     full = 255.0 if depth_bits == 8 else 65535.0
     y = np.arange(ih, dtype=np.float64)
     x = np.arange(iw, dtype=np.float64)

@@ -408,3 +408,41 @@ def test_solex_read_from_avi_equals_ser(pkg, tmp_path, layout):
     for a, b in zip(results[ser], results[avi]):
         np.testing.assert_array_equal(a, b)
     close_u16(results[avi][0], want['results'][0]['cc'])
+
+
+VARIANTS = {
+    'off_centre': dict(scene=dict(cx=230.0, cy=180.0, ax=150.0, ay=150.0)),
+    'elongated_scan': dict(scene=dict(ax=0.30 * 400, ay=0.44 * 400), options={'shift': [1]}),          # fast scan: ratio well below 1
+    'slow_scan': dict(n=520, scene=dict(ax=0.46 * 520, ay=0.36 * 400)),                               # ratio above 1
+    'noisy': dict(scene=dict(noise=0.012, depth=0.6), options={'crop_width_square': True}),
+    'faint_8bit': dict(bits=8, scene=dict(gain=0.5, sky=0.04)),
+    'tilted_line': dict(tilt=0.03, curv=-4e-5, options={'shift': [-3, 3]}),
+}
+
+
+@pytest.mark.parametrize('name', sorted(VARIANTS))
+def test_scene_variants_vs_oracle(pkg, name):
+    """Scans that differ from the golden scene (disk position / shape, noise, bit depth, line tilt): the whole
+    flow on the GPU against the CPU oracle.  Raw disks and bounds bit-exact, products <= 1 LSB on <= 4 pixels."""
+    SHG_MAIN, Solex_recon, outputs = pkg
+    from solex_ser_recon_en_amd.video_reader import array_reader
+    v = VARIANTS[name]
+    frames = synth.synth_frames_numpy(v.get('n', 400), 400, 32, v.get('bits', 16), seed=11, tilt=v.get('tilt', 0.01),
+                                      curv=v.get('curv', 5e-5), scene=v.get('scene'))
+    extra = v.get('options', {})
+    want = po.run(frames, extra)
+    opts = SHG_MAIN.default_options()
+    opts.update(extra, _nolog=True)
+    rdr = array_reader(torch.from_numpy(frames).cuda())
+    disks, bounds, hdr = Solex_recon.solex_read(rdr, opts)
+    assert opts['shift'] == want['read']['shifts']
+    assert tuple(int(b) for b in bounds) == (want['read']['y1'], want['read']['y2'])
+    for got, ref in zip(disks, want['read']['disks']):
+        np.testing.assert_array_equal(np.asarray(got), ref)
+    results = Solex_recon.solex_process(opts, disks, bounds, hdr)
+    outputs.flush()
+    np.testing.assert_allclose(opts['ratio_fixe'], want['geometry']['ratio'], rtol=1e-9)
+    requested = [s for s in opts['shift'] if s in opts['shift_requested']]
+    for shift, (cc, protus) in zip(requested, results):
+        close_u16(cc, want['results'][shift]['cc'])
+        close_u16(protus, want['results'][shift]['protus'])
