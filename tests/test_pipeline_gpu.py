@@ -446,3 +446,36 @@ def test_scene_variants_vs_oracle(pkg, name):
     for shift, (cc, protus) in zip(requested, results):
         close_u16(cc, want['results'][shift]['cc'])
         close_u16(protus, want['results'][shift]['protus'])
+
+
+@pytest.mark.parametrize('name', ['zeros', 'noise_only', 'ten_frames', 'half_scan', 'tiny_disk'])
+def test_pathological_scans_fail_like_the_reference(pkg, name):
+    """Scans the reference cannot process (solex_util.py:245-246 needs >= 3 distinct residuals, ellipse_to_circle.py:
+    245-263 needs a closed limb) must raise the same exception type here -- no hang, no garbage -- and a half
+    scan must still come out like the oracle's."""
+    SHG_MAIN, Solex_recon, outputs = pkg
+    from solex_ser_recon_en_amd.video_reader import array_reader
+    base = synth.synth_frames_numpy(400, 400, 32, 16, seed=1, tilt=0.01, curv=5e-5)
+    frames = {'zeros': np.zeros_like(base),
+              'noise_only': np.random.default_rng(0).integers(0, 3000, base.shape).astype(np.uint16),
+              'ten_frames': base[195:205].copy(), 'half_scan': base[:200].copy(),
+              'tiny_disk': synth.synth_frames_numpy(400, 400, 32, 16, seed=1, scene=dict(ax=20.0, ay=20.0))}[name]
+    opts = SHG_MAIN.default_options()
+    opts.update(_nolog=True)
+    try:
+        with np.errstate(all='ignore'):
+            want = po.run(frames, {})
+        expected = None
+    except Exception as e:          # noqa: BLE001
+        want, expected = None, type(e)
+    task = [(array_reader(torch.from_numpy(frames).cuda()), opts)]
+    if expected is not None:
+        with pytest.raises(expected):
+            Solex_recon.solex_do_work(task, True, return_results=True)
+        outputs.flush()
+        torch.cuda.synchronize()                                    # the device is still usable
+    else:
+        (results,) = Solex_recon.solex_do_work(task, True, return_results=True)
+        outputs.flush()
+        close_u16(results[0][0], want['results'][0]['cc'])
+    assert (expected is None) == (name == 'half_scan')
