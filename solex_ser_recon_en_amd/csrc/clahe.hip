@@ -9,6 +9,7 @@
 // and by launch latency, not by HBM streaming.  Histogram: every workgroup owns a
 // private 65536 x u16 LDS histogram (128 KiB) for a slice of <= 65535 pixels of one
 // tile and flushes only its non-zero bins with global atomics.
+#include <stdlib.h>
 #include "shg_common.h"
 
 namespace {
@@ -235,39 +236,94 @@ __device__ __forceinline__ void pick_digit(const uint32_t* __restrict__ hist, in
     __syncthreads();
 }
 
-// grid (row blocks), 256 threads.  hist layout: [0][256] = high-byte histogram shared by all ranks,
+// grid (row chunks), 256 threads.  hist layout: [0][256] = high-byte histogram shared by all ranks,
 // [1 + r][256] = low-byte histogram of rank r.  The image is read once per pass, whatever the number of ranks.
+// The pass is bound by the LDS atomic rate (about one lane-atomic per clock per CU): what helps is spreading the
+// work over every CU (~8192 pixels per workgroup) and keeping same-address collisions short -- a solar frame puts
+// most pixels of a wave into a handful of bins, so each bin is kept in interleaved copies ([bin][copy]: a bin's
+// copies sit in different LDS banks; 16 copies in pass 0, 4 per rank in pass 1).  Tried and dropped: merging runs
+// of equal keys inside a lane's eight pixels (the divergent bookkeeping costs more than the atomics it saves).
+constexpr int SEL_COPIES0 = 16, SEL_COPIES1 = 4;
+
 __global__ __launch_bounds__(256) void k_select16_pass(const uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch, int pass,
-                                                       const int64_t* __restrict__ ranks, int n_ranks, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t lh[8][256];
-    __shared__ int his[8];
-    const int nh = pass == 0 ? 1 : n_ranks;
+                                                       const int64_t* __restrict__ ranks, int n_ranks, uint32_t* __restrict__ hist,
+                                                       int vec_ok) {
+    __shared__ uint32_t lh[8 * 256 * SEL_COPIES1];        // pass 0: [bin][16 copies]; pass 1: [rank][bin][4 copies]
+    __shared__ int his_s[8];
     if (pass == 1) {
         for (int r = 0; r < n_ranks; ++r) {
             int hi;
             int64_t below;
             pick_digit(hist, ranks[r], hi, below);
-            if (threadIdx.x == 0) his[r] = hi;
+            if (threadIdx.x == 0) his_s[r] = hi;
         }
     }
-    for (int r = 0; r < nh; ++r) lh[r][threadIdx.x] = 0;
+    const int n_words = pass == 0 ? 256 * SEL_COPIES0 : n_ranks * 256 * SEL_COPIES1;
+    for (int i = threadIdx.x; i < n_words; i += 256) lh[i] = 0;
     __syncthreads();
-    for (int64_t y = blockIdx.x; y < h; y += gridDim.x) {
-        const uint16_t* row = img + y * pitch;
-        for (int64_t x = threadIdx.x; x < w; x += 256) {
-            const uint32_t v = row[x];
-            if (pass == 0) {
-                atomicAdd(&lh[0][v >> 8], 1u);
-            } else {
-                const int hi = (int)(v >> 8);
-                for (int r = 0; r < n_ranks; ++r)
-                    if (hi == his[r]) atomicAdd(&lh[r][v & 0xff], 1u);
+    int his[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) his[r] = (pass == 1 && r < n_ranks) ? his_s[r] : -1;
+    const int copy0 = threadIdx.x & (SEL_COPIES0 - 1), copy1 = threadIdx.x & (SEL_COPIES1 - 1);
+    auto count = [&](uint32_t v) {
+        if (pass == 0) {
+            atomicAdd(&lh[(v >> 8) * SEL_COPIES0 + copy0], 1u);
+        } else {
+            const int hi = (int)(v >> 8);
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (hi == his[r]) atomicAdd(&lh[(r * 256 + (v & 0xff)) * SEL_COPIES1 + copy1], 1u);
+        }
+    };
+    const int64_t rows_per_block = (h + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t nrows = min(h, r0 + rows_per_block) - r0;
+    if (nrows > 0) {
+        const int64_t vpr = vec_ok ? w / 8 : 0;           // 16-byte vectors per row
+        // four independent 16-byte loads per lane before the first use; out-of-range slots re-read vector 0 and are dropped
+        const int64_t nvec = nrows * vpr;
+        for (int64_t base = 0; base < nvec; base += 4 * 256) {
+            uint4 q[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = base + u * 256 + threadIdx.x;
+                ok[u] = i < nvec;
+                const int64_t ii = ok[u] ? i : 0;
+                const int64_t r = ii / vpr, vx = ii - r * vpr;
+                q[u] = *reinterpret_cast<const uint4*>(img + (r0 + r) * pitch + vx * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!ok[u]) continue;
+                const uint32_t d[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    count(d[j] & 0xffffu);
+                    count(d[j] >> 16);
+                }
             }
         }
+        const int64_t tail = w - vpr * 8;
+        for (int64_t i = threadIdx.x; i < nrows * tail; i += 256) {
+            const int64_t r = i / tail, x = vpr * 8 + (i - r * tail);
+            count(img[(r0 + r) * pitch + x]);
+        }
     }
     __syncthreads();
-    for (int r = 0; r < nh; ++r)
-        if (lh[r][threadIdx.x]) atomicAdd(&hist[(pass == 0 ? 0 : 1 + r) * 256 + threadIdx.x], lh[r][threadIdx.x]);
+    if (pass == 0) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < SEL_COPIES0; ++k) c += lh[threadIdx.x * SEL_COPIES0 + k];
+        if (c) atomicAdd(&hist[threadIdx.x], c);
+    } else {
+        for (int r = 0; r < n_ranks; ++r) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int k = 0; k < SEL_COPIES1; ++k) c += lh[(r * 256 + threadIdx.x) * SEL_COPIES1 + k];
+            if (c) atomicAdd(&hist[(1 + r) * 256 + threadIdx.x], c);
+        }
+    }
 }
 
 // grid (n_ranks), 256 threads
@@ -395,10 +451,14 @@ extern "C" int shg_select_u16(const uint16_t* img, int64_t h, int64_t w, int64_t
     hipError_t e = hipMemsetAsync(hist, 0, (size_t)(1 + n_ranks) * 256 * sizeof(uint32_t), st);
     if (e == hipSuccess) e = hipMemcpyAsync(ranks, host_ranks, n_ranks * sizeof(int64_t), hipMemcpyHostToDevice, st);
     if (e != hipSuccess) { shg::set_error("shg_select_u16: %s", hipGetErrorString(e)); return (int)e; }
-    const unsigned blocks = (unsigned)(h < 256 ? h : 256);
+    // ~8192 pixels per workgroup, at most 1024 workgroups, whole rows each
+    int64_t want = (h * w + 8191) / 8192;
+    want = want < 1 ? 1 : (want > 1024 ? 1024 : want);
+    const unsigned blocks = (unsigned)(h < want ? h : want);
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(img) & 15) == 0) && (pitch % 8 == 0);
     SHG_PROF("select_u16", st);
     for (int pass = 0; pass < 2; ++pass) {
-        k_select16_pass<<<blocks, 256, 0, st>>>(img, h, w, pitch, pass, ranks, n_ranks, hist);
+        k_select16_pass<<<blocks, 256, 0, st>>>(img, h, w, pitch, pass, ranks, n_ranks, hist, vec_ok);
         if (int err = shg::check_launch("k_select16_pass")) return err;
     }
     k_select16_final<<<(unsigned)n_ranks, 256, 0, st>>>(ranks, hist, out);

@@ -8,7 +8,10 @@
 //    the 64 lanes of a wave read one contiguous 128-byte run of a file row;
 //  * a workgroup builds a [shift][64 rows][64 frames] tile in LDS (row stride padded to
 //    66 elements -> conflict-free 2-byte column writes) and writes it out as 128-byte
-//    row segments, 16 bytes per lane, instead of 2-byte scattered stores.
+//    row segments, 16 bytes per lane, instead of 2-byte scattered stores;
+//  * the gather is latency bound, so what matters is how many requests a wave keeps in
+//    flight: all loads are branch-free (stand-in addresses instead of predicates) and are
+//    issued BATCH frames at a time before the first use (S=21 at C2: 211 -> 95 us).
 // Arithmetic is float64 with separately rounded products (compile with
 // -ffp-contract=off) and a truncating store, to be bit-exact with NumPy.
 #include "shg_common.h"
@@ -37,24 +40,22 @@ __global__ __launch_bounds__(256) void k_extract(const T* __restrict__ stack, in
     const bool y_ok = y < ih;
     constexpr int scale = sizeof(T) == 1 ? 256 : 1;        // video_reader.py:121-122
 
+    // Every load below is unconditional: out-of-range rows / shifts / frames read a valid stand-in address and the
+    // result is dropped.  A predicated load (`ok ? f[i] : 0`) becomes a branch with an s_waitcnt at its join, which
+    // left two requests in flight per wave; branch-free, a batch issues all its loads back to back and waits once.
+    const int64_t yc = y_ok ? y : ih - 1;
     int il[SC];
-    double wl = 0.0, wr = 0.0;
-    if (y_ok) {
-        wl = lw[y];
-        wr = rw[y];
-    }
+    const double wl = lw[yc], wr = rw[yc];
 #pragma unroll
-    for (int s = 0; s < SC; ++s) il[s] = (y_ok && s < ns) ? ind_l[(int64_t)(s0 + s) * ih + y] : 0;
+    for (int s = 0; s < SC; ++s) il[s] = ind_l[(int64_t)(s0 + min(s, ns - 1)) * ih + yc];
 
     // element offset of the left sample inside a frame, and the distance to the right one
     int64_t off[SC];
     const int64_t step = ROT ? width : 1;
 #pragma unroll
-    for (int s = 0; s < SC; ++s) off[s] = ROT ? (int64_t)il[s] * width + (width - 1 - y) : y * width + il[s];
+    for (int s = 0; s < SC; ++s) off[s] = ROT ? (int64_t)il[s] * width + (width - 1 - yc) : yc * width + il[s];
 
-    // Frames of this wave: cc = wave, wave + 4, ...  BATCH of them at a time: all loads of the batch are issued
-    // before the first use, so a wave keeps BATCH * 2 * ns 128-byte requests in flight instead of waiting for each
-    // frame in turn.  Two frames per batch is where it stops paying (deeper batches cost registers, tools/sweep_extract.sh).
+    // Frames of this wave: cc = wave, wave + 4, ...  BATCH of them at a time.
     for (int cb = wave; cb < TK; cb += 4 * BATCH) {
         T lv[BATCH][SC], rv[BATCH][SC];
         bool ok[BATCH];
@@ -63,19 +64,18 @@ __global__ __launch_bounds__(256) void k_extract(const T* __restrict__ stack, in
             const int cc = cb + 4 * i;
             const int64_t col = c0 + cc;
             const int64_t k = (flip_x ? (n_cols - 1 - col) : col) - k_offset;   // wave-uniform
-            ok[i] = y_ok && cc < TK && col < n_cols && k >= 0 && k < n_frames;
+            ok[i] = cc < TK && col < n_cols && k >= 0 && k < n_frames;
             const T* f = stack + (ok[i] ? k : 0) * fstride;
 #pragma unroll
             for (int s = 0; s < SC; ++s) {
-                const bool ld = ok[i] && s < ns;
-                lv[i][s] = ld ? f[off[s]] : (T)0;
-                rv[i][s] = ld ? f[off[s] + step] : (T)0;
+                lv[i][s] = f[off[s]];
+                rv[i][s] = f[off[s] + step];
             }
         }
 #pragma unroll
         for (int i = 0; i < BATCH; ++i) {
             const int cc = cb + 4 * i;
-            if (!ok[i]) continue;
+            if (!ok[i] || !y_ok) continue;
 #pragma unroll
             for (int s = 0; s < SC; ++s) {
                 if (s < ns) {
@@ -149,11 +149,14 @@ extern "C" int shg_extract_columns(const void* stack, int64_t n_frames, int64_t 
 #define SHG_LAUNCH(T, ROT)                                                 \
     switch (batch) {                                                       \
         case 1: SHG_LAUNCH_B(T, ROT, 1); break;                            \
-        case 4: SHG_LAUNCH_B(T, ROT, 4); break;                            \
-        default: SHG_LAUNCH_B(T, ROT, 2); break;                           \
+        case 2: SHG_LAUNCH_B(T, ROT, 2); break;                            \
+        case 8: SHG_LAUNCH_B(T, ROT, 8); break;                            \
+        case 16: SHG_LAUNCH_B(T, ROT, 16); break;                          \
+        default: SHG_LAUNCH_B(T, ROT, 4); break;                           \
     }
     static const int batch_env = [] { const char* e = getenv("SHG_EXT_BATCH"); return e ? atoi(e) : 0; }();   // tuning override
-    const int batch = batch_env > 0 ? batch_env : 2;      // measured: 1 -> 30 us, 2 and 4 -> 22 us, 8 -> 35 us, 16 -> 64 us (C2, S=2)
+    // measured at C2 (tools/sweep_extract.sh), batch 1 / 2 / 4 / 8 / 16: S=2 18 / 16 / 16 / 16 / 20 us, S=21 124 / 104 / 104 / 95 / 124 us
+    const int batch = batch_env > 0 ? batch_env : (n_shifts > SC ? 8 : 4);
     SHG_PROF("extract", st);
     if (bytes_per_px == 2) {
         if (rot) SHG_LAUNCH(uint16_t, true) else SHG_LAUNCH(uint16_t, false)

@@ -386,10 +386,11 @@ def test_select_u16_is_exact(ops, h, w):
     n = h * w
     srt = np.sort(img.ravel())
     ranks = sorted(set([0, n // 10, n // 2, int(0.999999 * (n - 1)), n - 1]))
-    padded = torch.zeros((h, w + 5), dtype=torch.int16, device='cuda').view(torch.uint16)
-    padded[:, :w] = dev(img)                              # a pitched view: the padding must not be counted
-    got = host(ops.select_u16(padded[:, :w], ranks))
-    np.testing.assert_array_equal(got, srt[ranks].astype(np.float64))
+    for pad in (5, (-w) % 8 + 8):                         # odd pitch: scalar reads; pitch % 8 == 0: 16-byte reads + row tail
+        padded = torch.full((h, w + pad), 7, dtype=torch.int16, device='cuda').view(torch.uint16)
+        padded[:, :w] = dev(img)                          # a pitched view: the padding must not be counted
+        got = host(ops.select_u16(padded[:, :w], ranks))
+        np.testing.assert_array_equal(got, srt[ranks].astype(np.float64))
     from solex_ser_recon_en_amd.limb_fit import lerp_order_stats
     for q in (10, 99.9999):
         lo, hi, mix = lerp_order_stats(n, q)

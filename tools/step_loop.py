@@ -1,0 +1,22 @@
+"""N bench steps on a resident C2 stack and nothing else (rocprofv3 target: per-kernel time of one step)."""
+import contextlib
+import io
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from solex_ser_recon_en_amd import SHG_MAIN, Solex_recon, synth  # noqa: E402
+from solex_ser_recon_en_amd.video_reader import array_reader  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+shifts = [int(s) for s in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0]
+stack = synth.synth_frames_torch(2000, 2000, 200, 16, seed=0, padded=True)
+torch.cuda.synchronize()
+for _ in range(steps):
+    opts = SHG_MAIN.default_options()
+    opts.update(_nolog=True, shift=list(shifts))
+    with contextlib.redirect_stdout(io.StringIO()):
+        Solex_recon.solex_do_work([(array_reader(stack), opts)], True, return_results=True)
+torch.cuda.synchronize()
