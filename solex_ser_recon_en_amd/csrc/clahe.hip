@@ -245,8 +245,10 @@ __device__ __forceinline__ void pick_digit(const uint32_t* __restrict__ hist, in
 // of equal keys inside a lane's eight pixels (the divergent bookkeeping costs more than the atomics it saves).
 constexpr int SEL_COPIES0 = 16, SEL_COPIES1 = 4;
 
+struct Ranks8 { int64_t v[8]; };            // the requested ranks travel as a kernel argument: no host-to-device copy per call
+
 __global__ __launch_bounds__(256) void k_select16_pass(const uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch, int pass,
-                                                       const int64_t* __restrict__ ranks, int n_ranks, uint32_t* __restrict__ hist,
+                                                       Ranks8 ranks, int n_ranks, uint32_t* __restrict__ hist,
                                                        int vec_ok) {
     __shared__ uint32_t lh[8 * 256 * SEL_COPIES1];        // pass 0: [bin][16 copies]; pass 1: [rank][bin][4 copies]
     __shared__ int his_s[8];
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256) void k_select16_pass(const uint16_t* __restric
         for (int r = 0; r < n_ranks; ++r) {
             int hi;
             int64_t below;
-            pick_digit(hist, ranks[r], hi, below);
+            pick_digit(hist, ranks.v[r], hi, below);
             if (threadIdx.x == 0) his_s[r] = hi;
         }
     }
@@ -327,12 +329,12 @@ __global__ __launch_bounds__(256) void k_select16_pass(const uint16_t* __restric
 }
 
 // grid (n_ranks), 256 threads
-__global__ __launch_bounds__(256) void k_select16_final(const int64_t* __restrict__ ranks, const uint32_t* __restrict__ hist,
+__global__ __launch_bounds__(256) void k_select16_final(Ranks8 ranks, const uint32_t* __restrict__ hist,
                                                         double* __restrict__ out) {
     int hi, lo;
     int64_t below, below2;
-    pick_digit(hist, ranks[blockIdx.x], hi, below);
-    pick_digit(hist + (1 + blockIdx.x) * 256, ranks[blockIdx.x] - below, lo, below2);
+    pick_digit(hist, ranks.v[blockIdx.x], hi, below);
+    pick_digit(hist + (1 + blockIdx.x) * 256, ranks.v[blockIdx.x] - below, lo, below2);
     if (threadIdx.x == 0) out[blockIdx.x] = (double)((hi << 8) | lo);
 }
 
@@ -447,9 +449,9 @@ extern "C" int shg_select_u16(const uint16_t* img, int64_t h, int64_t w, int64_t
         SHG_REQUIRE(host_ranks[i] >= 0 && host_ranks[i] < h * w, SHG_E_ARG, "shg_select_u16: rank %lld outside the image", (long long)host_ranks[i]);
     hipStream_t st = shg::as_stream(stream);
     uint32_t* hist = static_cast<uint32_t*>(workspace);
-    int64_t* ranks = reinterpret_cast<int64_t*>(hist + (size_t)(1 + n_ranks) * 256);
+    Ranks8 ranks = {};
+    for (int i = 0; i < n_ranks; ++i) ranks.v[i] = host_ranks[i];
     hipError_t e = hipMemsetAsync(hist, 0, (size_t)(1 + n_ranks) * 256 * sizeof(uint32_t), st);
-    if (e == hipSuccess) e = hipMemcpyAsync(ranks, host_ranks, n_ranks * sizeof(int64_t), hipMemcpyHostToDevice, st);
     if (e != hipSuccess) { shg::set_error("shg_select_u16: %s", hipGetErrorString(e)); return (int)e; }
     // ~8192 pixels per workgroup, at most 1024 workgroups, whole rows each
     int64_t want = (h * w + 8191) / 8192;

@@ -31,7 +31,8 @@ __device__ __forceinline__ double key_f64(uint64_t k) {
 struct Scratch {
     uint32_t hist[2][256];
     int64_t wave_tot[2][4];
-    int64_t pick[2][2];          // [which rank][digit, count below]
+    int64_t pick[2][3];          // [which rank][digit, count below, count in the digit's bin]
+    unsigned long long found[2]; // the key a singleton bin holds (early exit of select2)
     double red[4];
     int bad;
 };
@@ -87,7 +88,7 @@ __device__ __forceinline__ void select2(KeyFn key, int n, int64_t rank_lo, int64
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int64_t excl = incl[r] - c[r];
-            if (excl <= rank[r] && rank[r] < incl[r]) { sc.pick[r][0] = tid; sc.pick[r][1] = excl; }
+            if (excl <= rank[r] && rank[r] < incl[r]) { sc.pick[r][0] = tid; sc.pick[r][1] = excl; sc.pick[r][2] = c[r]; }
         }
         __syncthreads();
 #pragma unroll
@@ -96,7 +97,22 @@ __device__ __forceinline__ void select2(KeyFn key, int n, int64_t rank_lo, int64
             pref[r] = (pref[r] << 8) | (uint64_t)sc.pick[r][0];
         }
         same = same && (pref[0] == pref[1]);
+        const bool singletons = sc.pick[0][2] == 1 && sc.pick[1][2] == 1;
         __syncthreads();
+        // Both ranks alone in their bins: the remaining digits are those of the one key with that prefix.  For real
+        // data (distinct log-ratios) this happens after 2-3 of the 8 passes; rows with many equal keys run them all.
+        if (singletons && p < 7) {
+            for (int i = tid; i < n; i += NT) {
+                const uint64_t k = key(i);
+                if ((k >> shift) == pref[0]) sc.found[0] = k;
+                if ((k >> shift) == pref[1]) sc.found[1] = k;
+            }
+            __syncthreads();
+            out_lo = sc.found[0];
+            out_hi = sc.found[1];
+            __syncthreads();
+            return;
+        }
     }
     out_lo = pref[0];
     out_hi = pref[1];
