@@ -13,6 +13,8 @@ go, pr = os.path.join(root, 'gpurun_out'), os.path.join(root, 'profiles')
 shutil.copy(glob.glob(os.path.join(go, tag + '_trace', '*', '*_kernel_stats.csv'))[0], os.path.join(pr, tag + '_bench_kernel_stats.csv'))
 shutil.copy(os.path.join(go, tag + '_bench_under_rocprof.json'), os.path.join(pr, tag + '_bench_under_rocprof.json'))
 shutil.copy(os.path.join(go, tag + '_bench.json'), os.path.join(pr, tag + '_bench.json'))
+if os.path.exists(os.path.join(go, tag + '_step_kernel_table.txt')):
+    shutil.copy(os.path.join(go, tag + '_step_kernel_table.txt'), os.path.join(pr, tag + '_step_kernel_table.txt'))
 out = {}
 for which in ('fetch', 'write'):
     f = glob.glob(os.path.join(go, '%s_pmc_%s' % (tag, which), '*', '*_counter_collection.csv'))[0]
