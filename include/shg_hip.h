@@ -139,10 +139,11 @@ int shg_warp_rows_u16(const uint16_t* src, int64_t h, int64_t w, int64_t src_pit
  * Per row y in (y1, y2): the mean of the 2-MAD inliers of log(img[y][a:b] / img[y-1][a:b])
  * with a, b the chord of `circle` clipped to `borders` (float64).  out[y2 - y1]
  * (out[0] = 0 as solex_util.py:386).  xa, xb: int32 [y2-y1] column bounds computed on the
- * host (solex_util.py:389-391).  Rows longer than SHG_TRANSV_MAX_COLS are rejected.
+ * host (solex_util.py:389-391).  Images wider than SHG_TRANSV_MAX_COLS
+ * (19456 columns: the row's keys must fit the CU's 160 KiB of LDS) are rejected.
  * row_factor (may be NULL): float64 [h]; when given the image is the float64 frame
  * img[y][x] * row_factor[y] that removeVignette returns (solex_util.py:654). */
-#define SHG_TRANSV_MAX_COLS 8192
+#define SHG_TRANSV_MAX_COLS 19456
 int shg_rowpair_logratio_stats(const uint16_t* img, int64_t h, int64_t w, int64_t pitch,
                                int64_t y1, int64_t y2, const int32_t* xa, const int32_t* xb,
                                const double* row_factor, double* out, shg_stream_t stream);

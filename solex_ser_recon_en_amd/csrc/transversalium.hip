@@ -16,7 +16,7 @@
 
 namespace {
 
-constexpr int MAXN = SHG_TRANSV_MAX_COLS;   // 8192 keys = 64 KiB of LDS
+constexpr int MAXN = SHG_TRANSV_MAX_COLS;   // 19456 keys = 152 KiB of the CU's 160 KiB LDS (plus the static scratch)
 constexpr int NT = 256;
 
 __device__ __forceinline__ uint64_t f64_key(double v) {          // monotone map double -> uint64 (no NaN)

@@ -513,3 +513,26 @@ def test_u8_sums_across_the_packed_u16_flush(ops, monkeypatch, n, nsplit):
     total, mx = ops.accumulate_sum_max(dev(frames))
     np.testing.assert_array_equal(host(total).reshape(h, w), frames.sum(axis=0, dtype=np.uint64).astype(np.int64))
     np.testing.assert_array_equal(host(mx.view(torch.int16)).reshape(h, w).astype(np.uint16), frames.max(axis=0))
+
+
+def test_rowpair_stats_on_a_12000_column_disk(ops, orc):
+    """A slow scan (12 000 frames) gives disk rows far longer than 8192 px: the row's keys then take 94 KiB of LDS
+    (dynamic allocation above the 64 KiB default)."""
+    import math
+    rng = np.random.default_rng(12)
+    h, w = 12, 12000
+    img = rng.integers(20000, 40000, (h, w)).astype(np.uint16)
+    circle, borders = (6000.2, 5.5, 5990.0), [3.0, 0, 11990.0, 11]
+    y1, y2, want = orc.transversalium_row_stats(img, circle, borders)
+    xa = np.zeros(y2 - y1, np.int32)
+    xb = np.zeros(y2 - y1, np.int32)
+    for y in range(y1 + 1, y2):
+        dx = math.floor((circle[2] ** 2 - (y - circle[1]) ** 2) ** 0.5)
+        a, b, _ = slice(math.ceil(max(circle[0] - dx, borders[0])), math.floor(min(circle[0] + dx, borders[2]))).indices(w)
+        xa[y - y1], xb[y - y1] = a, max(a, b)
+    assert (xb - xa).max() > 11000
+    got = host(ops.rowpair_logratio_stats(dev(img), y1, y2, dev(xa), dev(xb)))
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-15)
+    with pytest.raises(RuntimeError, match='width'):
+        ops.rowpair_logratio_stats(torch.zeros((4, 20000), dtype=torch.int16, device='cuda').view(torch.uint16), 0, 4,
+                                   dev(np.zeros(4, np.int32)), dev(np.zeros(4, np.int32)))
