@@ -143,3 +143,26 @@ def test_multishift_c4_post_processing(env):
     idx0 = [s for s in o21['shift'] if s in o21['shift_requested']].index(0)
     np.testing.assert_array_equal(np.asarray(r21[idx0][0]), np.asarray(r1[0][0]))
     np.testing.assert_array_equal(np.asarray(r21[idx0][1]), np.asarray(r1[0][1]))
+
+
+def test_long_scan_12000_frames_against_the_oracle(env):
+    """A slow scan: 12 000 8-bit frames of 800 x 64.  The raw disks are 12 000 px wide and the limb is a 15:1 ellipse
+    that the warp squeezes back to a circle (ratio ~ 0.07)."""
+    ops, synth = env
+    from oracle import pipeline_oracle as po
+    from solex_ser_recon_en_amd import SHG_MAIN, Solex_recon
+    from solex_ser_recon_en_amd.video_reader import array_reader
+    stack = synth.synth_frames_torch(12000, 800, 64, 8, seed=4)
+    opts = SHG_MAIN.default_options()
+    opts['_nolog'] = True
+    disk_list, bounds, hdr = Solex_recon.solex_read(array_reader(stack), opts)
+    (cc, protus), = Solex_recon.solex_process(opts, disk_list, bounds, hdr)
+    with np.errstate(all='ignore'):
+        want = po.run(stack.cpu().numpy(), {})
+    for got, ref in zip(disk_list, want['read']['disks']):
+        np.testing.assert_array_equal(np.asarray(got), ref)
+    np.testing.assert_allclose(opts['ratio_fixe'], want['geometry']['ratio'], rtol=1e-9)
+    assert np.asarray(disk_list[0]).shape == (800, 12000) and opts['ratio_fixe'] < 0.1
+    for got, ref in ((cc, want['results'][0]['cc']), (protus, want['results'][0]['protus'])):
+        d = np.abs(np.asarray(got).astype(np.int64) - ref.astype(np.int64))
+        assert d.max() <= 1 and np.count_nonzero(d) <= 8, (d.max(), np.count_nonzero(d))
