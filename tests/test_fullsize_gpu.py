@@ -166,3 +166,25 @@ def test_long_scan_12000_frames_against_the_oracle(env):
     for got, ref in ((cc, want['results'][0]['cc']), (protus, want['results'][0]['protus'])):
         d = np.abs(np.asarray(got).astype(np.int64) - ref.astype(np.int64))
         assert d.max() <= 1 and np.count_nonzero(d) <= 8, (d.max(), np.count_nonzero(d))
+
+
+def test_large_sensor_scan_against_the_oracle(env):
+    """A 4096-row slit (large sensor), 3000 frames, 16 bit: 2.4 GB stack, 4096 x ~4300 px products."""
+    ops, synth = env
+    from oracle import pipeline_oracle as po
+    from solex_ser_recon_en_amd import SHG_MAIN, Solex_recon
+    from solex_ser_recon_en_amd.video_reader import array_reader
+    stack = synth.synth_frames_torch(3000, 4096, 96, 16, seed=6)
+    opts = SHG_MAIN.default_options()
+    opts['_nolog'] = True
+    disk_list, bounds, hdr = Solex_recon.solex_read(array_reader(stack), opts)
+    (cc, protus), = Solex_recon.solex_process(opts, disk_list, bounds, hdr)
+    with np.errstate(all='ignore'):
+        want = po.run(stack.cpu().numpy(), {})
+    for got, ref in zip(disk_list, want['read']['disks']):
+        np.testing.assert_array_equal(np.asarray(got), ref)
+    np.testing.assert_allclose(opts['ratio_fixe'], want['geometry']['ratio'], rtol=1e-9)
+    assert np.asarray(cc).shape[0] == 4096 and np.asarray(cc).shape == want['results'][0]['cc'].shape
+    for got, ref in ((cc, want['results'][0]['cc']), (protus, want['results'][0]['protus'])):
+        d = np.abs(np.asarray(got).astype(np.int64) - ref.astype(np.int64))
+        assert d.max() <= 1 and np.count_nonzero(d) <= 16, (d.max(), np.count_nonzero(d))
