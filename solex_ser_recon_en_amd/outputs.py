@@ -2,9 +2,11 @@
 
 The reference writes PNG/FITS products and three matplotlib diagnostics inline
 (solex_util.py:263-273, 482-488, 556-587; ellipse_to_circle.py:316-341); each 400-dpi
-plot costs seconds.  Here every file write is a task on a single background thread
-(device -> host copy + encode + write), so the GPU pipeline of the next disk / next file
-proceeds meanwhile.  flush() re-raises the first failure, so a failed write still
+plot costs seconds.  Here every file write is a background task (device -> host copy +
+encode + write), so the GPU pipeline of the next disk / next file proceeds meanwhile:
+image encoders run on a small pool (byte swaps, deflate, CRC and file writes release the
+GIL; four 8 MB PNGs per file would otherwise take longer than decoding the next file),
+the matplotlib diagnostics on one thread of their own.  flush() re-raises the first failure, so a failed write still
 stops the batch the way an exception in the reference's worker does (Solex_recon.py:42).
 """
 import threading
@@ -15,20 +17,22 @@ import numpy as np
 from . import png_io
 
 _lock = threading.Lock()
-_pool = None
+_pools = {}
 _pending = []
+ENCODER_THREADS = 4
 synchronous = False          # tests can force inline execution
 
 
 def submit(fn, *args):
-    global _pool
     if synchronous:
         fn(*args)
         return
+    kind = 'plot' if getattr(fn, '__name__', '').startswith('plot_') else 'encode'
     with _lock:
-        if _pool is None:
-            _pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='shg-output')
-        _pending.append(_pool.submit(fn, *args))
+        if kind not in _pools:
+            _pools[kind] = ThreadPoolExecutor(max_workers=1 if kind == 'plot' else ENCODER_THREADS,
+                                              thread_name_prefix='shg-' + kind)
+        _pending.append(_pools[kind].submit(fn, *args))
 
 
 def flush():

@@ -17,22 +17,32 @@ def _chunk(tag, payload):
     return struct.pack('>I', len(payload)) + tag + payload + struct.pack('>I', zlib.crc32(tag + payload) & 0xffffffff)
 
 
-def png_bytes(img, compression=0):
+def _pieces(img, compression=0):
+    """The PNG byte stream as a list of buffers (written one after the other: an 8 MB image is copied twice, for the
+    big-endian rows and by deflate, instead of once per concatenation)."""
     img = np.asarray(img)
     if img.ndim != 2 or img.dtype not in (np.uint8, np.uint16):
         raise TypeError('png_bytes writes 2-D uint8/uint16 images, got %s %s' % (img.dtype, img.shape))
     h, w = img.shape
     depth = 8 * img.dtype.itemsize
-    rows = np.zeros((h, 1 + w * img.dtype.itemsize), dtype=np.uint8)          # filter byte 0 + big-endian samples
-    rows[:, 1:] = img.astype('>u2' if depth == 16 else np.uint8).view(np.uint8).reshape(h, -1)
+    rows = np.empty((h, 1 + w * img.dtype.itemsize), dtype=np.uint8)          # filter byte 0 + big-endian samples
+    rows[:, 0] = 0
+    src = np.ascontiguousarray(img)
+    rows[:, 1:] = (src.byteswap() if depth == 16 else src).view(np.uint8).reshape(h, -1)
     ihdr = struct.pack('>IIBBBBB', w, h, depth, 0, 0, 0, 0)
-    idat = zlib.compress(rows.tobytes(), compression)
-    return _SIG + _chunk(b'IHDR', ihdr) + _chunk(b'IDAT', idat) + _chunk(b'IEND', b'')
+    idat = zlib.compress(rows, compression)
+    crc = zlib.crc32(idat, zlib.crc32(b'IDAT')) & 0xffffffff
+    return [_SIG, _chunk(b'IHDR', ihdr), struct.pack('>I', len(idat)), b'IDAT', idat, struct.pack('>I', crc), _chunk(b'IEND', b'')]
+
+
+def png_bytes(img, compression=0):
+    return b''.join(_pieces(img, compression))
 
 
 def write_png(path, img, compression=0):
     with open(path, 'wb') as f:
-        f.write(png_bytes(img, compression))
+        for piece in _pieces(img, compression):
+            f.write(piece)
 
 
 def read_png_gray(path):
