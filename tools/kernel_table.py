@@ -3,7 +3,9 @@ import csv
 import glob
 import sys
 
-path = sorted(glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True))[-1]
+import os
+
+path = max(glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True), key=os.path.getmtime)
 steps = int(sys.argv[2])
 rows = [r for r in csv.DictReader(open(path)) if 'anonymous namespace' in r['Name'] and int(r['Calls']) >= steps]
 tot = 0.0

@@ -10,14 +10,21 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go, pr = os.path.join(root, 'gpurun_out'), os.path.join(root, 'profiles')
-shutil.copy(glob.glob(os.path.join(go, tag + '_trace', '*', '*_kernel_stats.csv'))[0], os.path.join(pr, tag + '_bench_kernel_stats.csv'))
+
+
+def newest(pattern):
+    """gpurun merges every collection into the same directories: take the latest run's file."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+shutil.copy(newest(os.path.join(go, tag + '_trace', '*', '*_kernel_stats.csv')), os.path.join(pr, tag + '_bench_kernel_stats.csv'))
 shutil.copy(os.path.join(go, tag + '_bench_under_rocprof.json'), os.path.join(pr, tag + '_bench_under_rocprof.json'))
 shutil.copy(os.path.join(go, tag + '_bench.json'), os.path.join(pr, tag + '_bench.json'))
 if os.path.exists(os.path.join(go, tag + '_step_kernel_table.txt')):
     shutil.copy(os.path.join(go, tag + '_step_kernel_table.txt'), os.path.join(pr, tag + '_step_kernel_table.txt'))
 out = {}
 for which in ('fetch', 'write'):
-    f = glob.glob(os.path.join(go, '%s_pmc_%s' % (tag, which), '*', '*_counter_collection.csv'))[0]
+    f = newest(os.path.join(go, '%s_pmc_%s' % (tag, which), '*', '*_counter_collection.csv'))
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
