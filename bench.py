@@ -3,7 +3,7 @@
 contrast products in HBM), plus the HBM-roofline figure of the dominant kernel and a CPU
 baseline (the NumPy oracle of the same path on the host cores).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 50 --warmup 5      # the defaults
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -39,8 +39,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); m
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--frames', type=int, default=2000, help='frames per GPU')
     ap.add_argument('--width', type=int, default=2000)
     ap.add_argument('--height', type=int, default=200)
