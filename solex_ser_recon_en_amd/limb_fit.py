@@ -51,6 +51,28 @@ def median_order_stats(n):
     return n // 2 - 1, n // 2, (lambda a, b: (a + b) / 2)
 
 
+def cubic_fit_coef(x, y):
+    """== numpy.polynomial.Polynomial.fit(x, y, 3).convert().coef, bit for bit, without the Polynomial objects (the
+    class arithmetic costs 0.3 ms of as_series / trimseq bookkeeping per call).  Same steps: map x from its range to
+    [-1, 1], least squares there (the very polyfit Polynomial._fit is), then Horner's rule on coefficient arrays with
+    np.convolve for the products -- what Polynomial.__call__ does with the line off + scl*x (every convolution term
+    is a sum of at most two products, so there is no summation order to get wrong)."""
+    from numpy.polynomial import polyutils as pu
+    x = np.asarray(x, dtype=np.float64)
+    dom = pu.getdomain(x)
+    if dom[0] == dom[1]:
+        dom[0] -= 1
+        dom[1] += 1
+    off, scl = pu.mapparms(dom, np.array([-1.0, 1.0]))
+    coef = polynomial.polynomial.polyfit(off + scl * x, y, 3)
+    line = np.array([0.0 + off, 1.0 * scl])                      # off + scl * identity
+    acc = np.array([coef[3] + 0.0])
+    for k in (2, 1, 0):
+        acc = pu.trimseq(np.convolve(acc, line))
+        acc[0] += coef[k]
+    return pu.trimseq(acc)
+
+
 def flood_threshold(total, shape, mn, mx, counts):
     """thresh3 of get_flood_image from the image statistics the GPU reduces:
     total = np.sum(image); over data = blurred[blurred < very_bright]: mn, mx = data.min(), data.max(),
@@ -61,7 +83,7 @@ def flood_threshold(total, shape, mn, mx, counts):
         mn, mx = mn - 0.5, mx + 0.5
     bins = np.linspace(mn, mx, 21)
     n = np.asarray(counts, dtype=np.int64)
-    d, c, b, a = polynomial.polynomial.Polynomial.fit(bins[1:], n, 3).convert().coef
+    d, c, b, a = cubic_fit_coef(bins[1:], n)
     discriminant = 4 * b ** 2 - 12 * a * c
     thresh2 = (-2 * b + np.sqrt(discriminant)) / (6 * a) if discriminant >= 0 else thresh
     start_i = -1

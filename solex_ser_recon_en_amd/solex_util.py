@@ -7,6 +7,7 @@ from histograms) stays on the host with NumPy/SciPy exactly as the reference com
 Images are DeviceImage handles: they stay in HBM between stages.
 """
 import datetime
+import functools
 import math
 import os
 import traceback
@@ -174,7 +175,18 @@ def reject_outliers(data, m=2):
     return data[s < m]
 
 
+@functools.lru_cache(maxsize=64)
+def _tukey_cached(n, a):
+    t = _tukey_compute(n, a)
+    t.setflags(write=False)
+    return t
+
+
 def _tukey(n, a=0.05):
+    return _tukey_cached(int(n), float(a))
+
+
+def _tukey_compute(n, a=0.05):
     """The reference's piecewise taper t(x), x = 0..n-1 (solex_util.py:460-470), evaluating
     math.cos only on the two ramps (everything in between is exactly 1)."""
     def ramp(x):
@@ -222,20 +234,24 @@ def _chord_bounds(circle, borders, y1, y2, w):
     return xa, xb
 
 
+@functools.lru_cache(maxsize=32)
+def _savgol_taps(window):
+    from scipy.signal import savgol_coeffs
+    taps = savgol_coeffs(window, 3)
+    taps.setflags(write=False)
+    return taps
+
+
 def _savgol_rows(y, window):
     """scipy.signal.savgol_filter(row, window, 3) (mode 'interp') for every row of y [k, n], bit-identical to k
     separate calls: the interior is one correlate1d along the rows (row-independent arithmetic), the two edges
     are the same np.polyfit / np.polyval per row that SciPy's _fit_edge performs (a multi-right-hand-side
-    lstsq would depend on k in the last bits)."""
+    lstsq would depend on k in the last bits).  The taps depend on the window only and are cached."""
     from scipy.ndimage import convolve1d
-    from scipy.signal import savgol_coeffs
-    if y.shape[0] == 1:
-        from scipy.signal import savgol_filter
-        return savgol_filter(y, window, 3, axis=-1)
     n = y.shape[-1]
     if window > n:
         raise ValueError("If mode is 'interp', window_length must be less than or equal to the size of x.")
-    out = convolve1d(y, savgol_coeffs(window, 3), axis=-1, mode='constant')
+    out = convolve1d(y, _savgol_taps(window), axis=-1, mode='constant')
     half = window // 2
     for row_in, row_out in zip(y, out):
         head = np.polyfit(np.arange(0, window), row_in[:window], 3)

@@ -332,3 +332,25 @@ def test_bgr2gray_fixed_point():
     np.testing.assert_array_equal(bgr_to_gray_u8(v, v, v), v)            # identity on grey
     b, g, r = np.array([255, 0, 0], np.uint8), np.array([0, 255, 0], np.uint8), np.array([0, 0, 255], np.uint8)
     np.testing.assert_array_equal(bgr_to_gray_u8(b, g, r), [29, 150, 76])   # OpenCV's well-known primaries
+
+
+def test_cubic_fit_coef_is_polynomial_fit_convert():
+    """limb_fit.cubic_fit_coef == numpy.polynomial.Polynomial.fit(x, y, 3).convert().coef bit for bit (ellipse_to_circle.py:
+    177-179 uses the latter on the 20-bin histogram), and transversalium's Savitzky-Golay rows == scipy's filter."""
+    from numpy.polynomial import Polynomial
+    from scipy.signal import savgol_filter
+    from solex_ser_recon_en_amd import solex_util as su
+    rng = np.random.default_rng(0)
+    for t in range(3000):
+        lo = rng.normal() * rng.choice([1e-3, 1, 100])
+        hi = lo + abs(rng.normal()) * rng.choice([1e-3, 1, 50]) + 1e-9
+        x = np.linspace(lo, hi, 21)[1:]
+        y = rng.integers(0, 50000, 20).astype(np.int64) if t % 2 else rng.standard_normal(20)
+        np.testing.assert_array_equal(limb_fit.cubic_fit_coef(x, y), Polynomial.fit(x, y, 3).convert().coef)
+    x = np.full(20, 3.0)                                                   # constant abscissa: the domain is widened by +-1
+    np.testing.assert_array_equal(limb_fit.cubic_fit_coef(x, np.arange(20.0)), Polynomial.fit(x, np.arange(20.0), 3).convert().coef)
+    for n, win in [(280, 279), (1800, 301), (40, 21), (5, 5), (302, 301)]:
+        y = rng.standard_normal((1, n)) * 0.01
+        np.testing.assert_array_equal(su._savgol_rows(y, win), savgol_filter(y, win, 3, axis=-1))
+        y3 = rng.standard_normal((3, n)) * 0.01
+        np.testing.assert_array_equal(su._savgol_rows(y3, win), np.stack([savgol_filter(r, win, 3) for r in y3]))
