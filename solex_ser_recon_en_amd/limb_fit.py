@@ -115,7 +115,9 @@ def limb_points(pts, lab, nf, n_rows):
     size_list = sizes.tolist()
     # regions are picked by size VALUE: equal sizes resolve to the first such region (list.index)
     chosen = [size_list.index(v) for v in sorted(size_list, reverse=True)[:min(nf, NUM_REG)]]
-    in_chosen = np.isin(lab, chosen)
+    member = np.zeros(nf + 1, dtype=bool)               # label -> selected? (a table lookup instead of np.isin's sort)
+    member[np.asarray(chosen, dtype=np.int64)] = True
+    in_chosen = member[lab]
     X = pts[in_chosen]
     hull_labels = set(lab[in_chosen][ConvexHull(X).vertices].tolist())
     keep = [i for i in chosen if i in hull_labels]    # regions that own a convex-hull vertex
@@ -124,7 +126,9 @@ def limb_points(pts, lab, nf, n_rows):
     crop = 0.017
     rows = np.zeros(n_rows, dtype=bool)
     rows[int(x_min + dx * crop):int(x_max - dx * crop)] = True     # slice semantics of mask[int(..):int(..), :] = 1
-    sel = np.isin(lab, keep) & rows[pts[:, 0]]
+    member[:] = False
+    member[np.asarray(keep, dtype=np.int64)] = True
+    sel = member[lab] & rows[pts[:, 0]]
     return np.array(pts[sel], dtype='float'), pts
 
 
