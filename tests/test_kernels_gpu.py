@@ -536,3 +536,39 @@ def test_rowpair_stats_on_a_12000_column_disk(ops, orc):
     with pytest.raises(RuntimeError, match='width'):
         ops.rowpair_logratio_stats(torch.zeros((4, 20000), dtype=torch.int16, device='cuda').view(torch.uint16), 0, 4,
                                    dev(np.zeros(4, np.int32)), dev(np.zeros(4, np.int32)))
+
+
+@pytest.mark.parametrize('w', [5, 8, 13, 64, 77])
+def test_image_passes_respect_view_boundaries(ops, orc, w):
+    """rescale / scale_rows / warp on views inside larger images whose neighbouring columns hold sentinels: results
+    must equal those on dense copies and the neighbours must stay untouched (source and destination pitch > width)."""
+    rng = np.random.default_rng(w)
+    h, pitch = 9, 96                                                      # 192-byte rows: aligned, wider than every w
+    img = rng.integers(0, 65536, (h, w)).astype(np.uint16)
+    big = torch.full((h, pitch), 7, dtype=torch.int16, device='cuda').view(torch.uint16)
+    big[:, :w] = dev(img)
+    src = big[:, :w]
+    dense = dev(np.ascontiguousarray(img[:, :w]))                         # pitch = w
+    lo, hi = 1000.0, 60000.0
+    want = host(ops.rescale_u16(dense, lo, hi, 1.0))
+    np.testing.assert_array_equal(want, orc.rescale_brightness(img, lo, hi))
+    np.testing.assert_array_equal(host(ops.rescale_u16(src, lo, hi, 1.0)), want)
+    c = 1 + 0.3 * rng.standard_normal(h)
+    np.testing.assert_array_equal(host(ops.scale_rows_u16(src, c)), host(ops.scale_rows_u16(dense, c)))
+    rf = 1 + 0.1 * rng.standard_normal(h)
+    np.testing.assert_array_equal(host(ops.scale_rows_u16(src, c, rf)), host(ops.scale_rows_u16(dense, c, rf)))
+    a = host(ops.warp_rows_u16(src, 1.0, 0.0, 0.25, h, w))
+    b = host(ops.warp_rows_u16(dense, 1.0, 0.0, 0.25, h, w))
+    np.testing.assert_array_equal(a, b)
+    # destination views through the C ABI itself (ops always allocates a fresh pitched image)
+    from solex_ser_recon_en_amd import _lib
+    out_big = torch.full((h, pitch), 9, dtype=torch.int16, device='cuda').view(torch.uint16)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.lib.shg_rescale_u16(src.data_ptr(), h, w, pitch, lo, hi, 1.0, out_big.data_ptr(), pitch, st), 'shg_rescale_u16')
+    np.testing.assert_array_equal(host(out_big[:, :w]), want)
+    assert int((out_big[:, w:].view(torch.int16) != 9).sum()) == 0
+    cd = dev(c)
+    _lib.check(_lib.lib.shg_scale_rows_u16(src.data_ptr(), h, w, pitch, cd.data_ptr(), None, out_big.data_ptr(), pitch, st), 'shg_scale_rows_u16')
+    np.testing.assert_array_equal(host(out_big[:, :w]), host(ops.scale_rows_u16(dense, c)))
+    assert int((out_big[:, w:].view(torch.int16) != 9).sum()) == 0
+    assert int((big[:, w:].view(torch.int16) != 7).sum()) == 0            # nothing leaked out of the source view either
