@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SHG_ABI_VERSION 6
+#define SHG_ABI_VERSION 7
 
 #define SHG_E_ARG        (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SHG_E_WORKSPACE  (-2)   /* workspace too small                                 */
@@ -147,6 +147,14 @@ int shg_warp_rows_u16(const uint16_t* src, int64_t h, int64_t w, int64_t src_pit
 int shg_rowpair_logratio_stats(const uint16_t* img, int64_t h, int64_t w, int64_t pitch,
                                int64_t y1, int64_t y2, const int32_t* xa, const int32_t* xb,
                                const double* row_factor, double* out, shg_stream_t stream);
+
+/* scipy.ndimage.correlate1d(src, weights, axis=-1, mode='constant', cval=0) for k rows of n float64
+ * samples with 2*radius+1 float64 weights (device memory), in NI_Correlate1D's order of operations:
+ * the interior of scipy.signal.savgol_filter(y_ratios_r, window, 3) (solex_util.py:400).  `symmetric`
+ * non-zero selects SciPy's symmetric-filter form (pairs summed first, left half of the weights used),
+ * which SciPy takes when |w[R+i] - w[R-i]| <= DBL_EPSILON for every i. */
+int shg_correlate1d_rows_f64(const double* src, int64_t k, int64_t n, const double* weights, int radius,
+                             int symmetric, double* dst, shg_stream_t stream);
 
 /* ret = min(img * c[y], 65535) truncated to uint16 (solex_util.py:489, 515-516). */
 int shg_scale_rows_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, const double* c,

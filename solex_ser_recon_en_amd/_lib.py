@@ -47,6 +47,7 @@ SIGNATURES = {
     'shg_rowpair_logratio_stats': (c_int, [P, c_int64, c_int64, c_int64, c_int64, c_int64, P, P, P, P, P]),
     'shg_line_order_stats_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int64, c_int64, P, P, P]),
     'shg_scale_rows_u16': (c_int, [P, c_int64, c_int64, c_int64, P, P, P, c_int64, P]),
+    'shg_correlate1d_rows_f64': (c_int, [P, c_int64, c_int64, P, c_int, c_int, P, P]),
     'shg_lin_filter_row_sums': (c_int, [P, c_int64, c_int64, c_int64, P, P, P, P, P, c_int, P, P, P]),
     'shg_lin_filter_apply': (c_int, [P, c_int64, c_int64, c_int64, P, P, P, c_int, c_int, P, P, P, P, c_int, P, c_int64, P]),
     'shg_crop_pad_u16': (c_int, [P, c_int64, c_int64, c_int64, P, c_int64, c_int64, c_int64, c_int64, c_int64,
@@ -76,7 +77,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 if lib.shg_abi_version() != ABI_VERSION:
     raise ImportError('libshg_hip.so ABI %d != expected %d: rebuild it' % (lib.shg_abi_version(), ABI_VERSION))
 

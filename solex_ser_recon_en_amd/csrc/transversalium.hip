@@ -200,6 +200,31 @@ __global__ __launch_bounds__(256) void k_scale_rows(const uint16_t* __restrict__
     dst[y * dst_pitch + x] = (uint16_t)(int)v;
 }
 
+// scipy.ndimage.correlate1d(rows, weights, axis=-1, mode='constant', cval=0) for k rows of n float64 samples, in
+// NI_Correlate1D's own order of operations (the interior of scipy.signal.savgol_filter, solex_util.py:400):
+//   symmetric weights : t = x[0]*w[0]; for j = -R..-1: t += (x[j] + x[-j]) * w[j]      (w indexed from the centre)
+//   otherwise         : t = x[R]*w[R]; for j = -R..R-1: t += x[j] * w[j]
+// One lane per output sample; the 2R+1 weights are read by every lane (L1 broadcast).
+__global__ __launch_bounds__(256) void k_correlate1d_rows(const double* __restrict__ src, int64_t k, int64_t n,
+                                                          const double* __restrict__ weights, int radius, int symmetric,
+                                                          double* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= k * n) return;
+    const int64_t row = i / n, x = i - row * n;
+    const double* line = src + row * n;
+    const double* w = weights + radius;
+    auto at = [&](int64_t xx) -> double { return (xx < 0 || xx >= n) ? 0.0 : line[xx]; };
+    double t;
+    if (symmetric) {
+        t = at(x) * w[0];
+        for (int j = -radius; j < 0; ++j) t += (at(x + j) + at(x - j)) * w[j];
+    } else {
+        t = at(x + radius) * w[radius];
+        for (int j = -radius; j < radius; ++j) t += at(x + j) * w[j];
+    }
+    dst[i] = t;
+}
+
 // Two order statistics of every row (axis 1) or column (axis 0) of a uint16 image: np.percentile(img, q, axis)
 // (removeVignette, solex_util.py:591-592).  One workgroup per line, 16-bit keys, two 8-bit radix passes.
 __global__ __launch_bounds__(NT) void k_line_order_stats(const uint16_t* __restrict__ img, int64_t pitch, int n, int64_t line_stride,
@@ -291,6 +316,16 @@ extern "C" int shg_rowpair_logratio_stats(const uint16_t* img, int64_t h, int64_
     }
     { SHG_PROF("rowpair_stats", st); k_rowpair_stats<<<(unsigned)rows, NT, lds_bytes, st>>>(img, pitch, y1, xa, xb, row_factor, out); }
     return shg::check_launch("k_rowpair_stats");
+}
+
+extern "C" int shg_correlate1d_rows_f64(const double* src, int64_t k, int64_t n, const double* weights, int radius, int symmetric,
+                                        double* dst, shg_stream_t stream) {
+    SHG_REQUIRE(src && weights && dst, SHG_E_ARG, "shg_correlate1d_rows_f64: null pointer");
+    SHG_REQUIRE(k > 0 && n > 0 && radius >= 0 && k * n < (1ll << 40), SHG_E_ARG, "shg_correlate1d_rows_f64: bad sizes");
+    hipStream_t st = shg::as_stream(stream);
+    SHG_PROF("correlate1d_rows", st);
+    k_correlate1d_rows<<<(unsigned)((k * n + 255) / 256), 256, 0, st>>>(src, k, n, weights, radius, symmetric ? 1 : 0, dst);
+    return shg::check_launch("k_correlate1d_rows");
 }
 
 extern "C" int shg_scale_rows_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, const double* c,

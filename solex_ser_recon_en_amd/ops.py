@@ -209,6 +209,32 @@ def scale_rows_u16(img, c, row_factor=None):
     return out
 
 
+_TAPS = {}
+
+
+def correlate1d_rows_f64(rows, weights):
+    """scipy.ndimage.correlate1d(rows, weights, axis=-1, mode='constant') for a float64 GPU tensor [k, n]; `weights`
+    is a host array of odd length (as correlate1d takes them).  SciPy's symmetric-filter test is made here."""
+    _dev(rows, 'rows')
+    if rows.dim() != 2 or rows.dtype != torch.float64 or not rows.is_contiguous():
+        raise ValueError('rows must be a contiguous float64 [k, n] tensor')
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    if w.ndim != 1 or not w.size & 1:
+        raise ValueError('weights must be 1-D of odd length')
+    key = (str(rows.device), w.tobytes())
+    if key not in _TAPS:
+        r = w.size // 2
+        sym = all(abs(w[r + i] - w[r - i]) <= np.finfo(np.float64).eps for i in range(1, r + 1))     # NI_Correlate1D
+        if len(_TAPS) > 64:
+            _TAPS.clear()
+        _TAPS[key] = (torch.from_numpy(w).to(rows.device), r, int(sym))
+    wd, r, sym = _TAPS[key]
+    out = torch.empty_like(rows)
+    _lib.check(lib.shg_correlate1d_rows_f64(rows.data_ptr(), rows.shape[0], rows.shape[1], wd.data_ptr(), r, sym, out.data_ptr(),
+                                            _stream()), 'shg_correlate1d_rows_f64')
+    return out
+
+
 _LOG_LUT = {}
 
 

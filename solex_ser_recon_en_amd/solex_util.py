@@ -242,33 +242,60 @@ def _savgol_taps(window):
     return taps
 
 
-def _savgol_rows(y, window):
+@functools.lru_cache(maxsize=32)
+def _edge_fit_system(window):
+    """What np.polyfit(np.arange(window), y, 3) builds before its lstsq call: the column-scaled Vandermonde matrix,
+    the scale and rcond.  Cached: SciPy's _fit_edge fits the same abscissa for every row and every file."""
+    x = np.arange(0, window) + 0.0
+    lhs = np.vander(x, 4)
+    scale = np.sqrt((lhs * lhs).sum(axis=0))
+    lhs /= scale
+    lhs.setflags(write=False)
+    return lhs, scale, len(x) * np.finfo(x.dtype).eps
+
+
+def _edge_polyfit(window, y):
+    """== np.polyfit(np.arange(0, window), y, 3), bit for bit (same lstsq on the same matrices)."""
+    lhs, scale, rcond = _edge_fit_system(window)
+    c = np.linalg.lstsq(lhs, y + 0.0, rcond)[0]
+    return (c.T / scale).T
+
+
+def _savgol_rows(y, window, interior=None):
     """scipy.signal.savgol_filter(row, window, 3) (mode 'interp') for every row of y [k, n], bit-identical to k
     separate calls: the interior is one correlate1d along the rows (row-independent arithmetic), the two edges
     are the same np.polyfit / np.polyval per row that SciPy's _fit_edge performs (a multi-right-hand-side
-    lstsq would depend on k in the last bits).  The taps depend on the window only and are cached."""
-    from scipy.ndimage import convolve1d
+    lstsq would depend on k in the last bits).  The taps depend on the window only and are cached.
+    interior: that correlate1d already computed on the GPU (ops.correlate1d_rows_f64, same order of operations)."""
     n = y.shape[-1]
     if window > n:
         raise ValueError("If mode is 'interp', window_length must be less than or equal to the size of x.")
-    out = convolve1d(y, _savgol_taps(window), axis=-1, mode='constant')
+    if interior is None:
+        from scipy.ndimage import convolve1d
+        out = convolve1d(y, _savgol_taps(window), axis=-1, mode='constant')
+    else:
+        out = np.array(interior, dtype=np.float64)
     half = window // 2
     for row_in, row_out in zip(y, out):
-        head = np.polyfit(np.arange(0, window), row_in[:window], 3)
+        head = _edge_polyfit(window, row_in[:window])
         row_out[:half] = np.polyval(head, np.arange(0, half))
-        tail = np.polyfit(np.arange(0, window), row_in[n - window:], 3)
+        tail = _edge_polyfit(window, row_in[n - window:])
         row_out[n - half:] = np.polyval(tail, np.arange(window - half, window))
     return out
 
 
-def transversalium_factors(y_ratios_r, trans_strength, tapered=True):
+def savgol_window(n, trans_strength):
+    return min(trans_strength, n // 2 * 2 - 1)                    # solex_util.py:400
+
+
+def transversalium_factors(y_ratios_r, trans_strength, tapered=True, interior=None):
     """Row correction factors from the robust row-pair log-ratios (solex_util.py:400-404, 456-472).
     y_ratios_r: [n] or [k, n] (k disks of one Doppler stack, same geometry).  Every row is processed exactly as
     a separate call would, so a disk's result does not depend on which other disks share the batch.
     tapered=False returns `correction` itself (:404), which the stubborn branch thresholds (:416-420)."""
     y = np.atleast_2d(np.asarray(y_ratios_r, dtype=np.float64))
     n = y.shape[-1]
-    trend = _savgol_rows(y, min(trans_strength, n // 2 * 2 - 1))
+    trend = _savgol_rows(y, savgol_window(n, trans_strength), None if interior is None else np.atleast_2d(interior))
     detrended = y - trend
     for row in detrended:
         row -= np.mean(row)
@@ -345,13 +372,22 @@ def correct_transversalium2_batch(imgs, circle, borders, options, reqFlag, basef
         xa, xb = _chord_bounds(circle, borders, y1, y2, w)
         xa_d = torch.from_numpy(xa).to(tensors[0].device)
         xb_d = torch.from_numpy(xb).to(tensors[0].device)
-        ratios = torch.stack([ops.rowpair_logratio_stats(t, y1, y2, xa_d, xb_d, rf) for t, rf in zip(tensors, factors)]).cpu().numpy()
+        stats = torch.stack([ops.rowpair_logratio_stats(t, y1, y2, xa_d, xb_d, rf) for t, rf in zip(tensors, factors)])
+        window = savgol_window(stats.shape[1], options['trans_strength'])
+        interior = None
+        if 3 < window <= stats.shape[1]:
+            # the interior of the Savitzky-Golay trend while the statistics are still on the GPU (SciPy's own order of
+            # operations); its two edges are LAPACK fits and stay on the host
+            both = torch.stack([stats, ops.correlate1d_rows_f64(stats, _savgol_taps(window)[::-1])]).cpu().numpy()
+            ratios, interior = both[0], both[1]
+        else:
+            ratios = stats.cpu().numpy()
     else:
-        ratios = np.zeros((len(tensors), 1))                                          # y_ratios_r = [0], :386
+        ratios, interior = np.zeros((len(tensors), 1)), None                           # y_ratios_r = [0], :386
     if options.get('stubborn_transversalium'):
         # :415-423: rows the smooth correction cannot follow are rebuilt from their neighbours by a line filter;
         # no correction plot and no '_transversalium_cache' on this branch
-        correction = transversalium_factors(ratios, options['trans_strength'], tapered=False)
+        correction = transversalium_factors(ratios, options['trans_strength'], tapered=False, interior=interior)
         taper = np.zeros(h)
         taper[y1:y2] = _tukey(y2 - y1)
         xa_e, xb_e, edge, edge_half = _limb_edge_plan(circle, h, w, LIN_LEN + LIN_EDGE_FUDGE)
@@ -362,7 +398,7 @@ def correct_transversalium2_batch(imgs, circle, borders, options, reqFlag, basef
             out.append(DeviceImage(ops.lin_filter_u16(t, flag, up, dn, taper, xa_e, xb_e, edge, edge_half, LIN_LEN,
                                                       LIN_HALF_WIDTH, rf)))
         return out
-    correction_t = transversalium_factors(ratios, options['trans_strength'])
+    correction_t = transversalium_factors(ratios, options['trans_strength'], interior=interior)
     out = []
     for i, (t, rf) in enumerate(zip(tensors, factors)):
         c = np.ones(h)

@@ -572,3 +572,24 @@ def test_image_passes_respect_view_boundaries(ops, orc, w):
     np.testing.assert_array_equal(host(out_big[:, :w]), host(ops.scale_rows_u16(dense, c)))
     assert int((out_big[:, w:].view(torch.int16) != 9).sum()) == 0
     assert int((big[:, w:].view(torch.int16) != 7).sum()) == 0            # nothing leaked out of the source view either
+
+
+@pytest.mark.parametrize('k,n,window', [(1, 1800, 301), (21, 1800, 301), (3, 280, 279), (2, 40, 21), (1, 5, 5), (4, 302, 301)])
+def test_correlate1d_rows_is_scipys(ops, k, n, window):
+    """shg_correlate1d_rows_f64 == scipy.ndimage.convolve1d(rows, savgol taps, mode='constant') bit for bit (SciPy's
+    symmetric-filter order of operations), also for a non-symmetric filter and with NaN / inf samples."""
+    from scipy.ndimage import convolve1d, correlate1d
+    from scipy.signal import savgol_coeffs
+    rng = np.random.default_rng(n + window)
+    rows = rng.standard_normal((k, n)) * 0.01
+    taps = savgol_coeffs(window, 3)
+    got = host(ops.correlate1d_rows_f64(dev(rows), taps[::-1]))
+    np.testing.assert_array_equal(got, convolve1d(rows, taps, axis=-1, mode='constant'))
+    skew = rng.standard_normal(window)                                   # neither symmetric nor antisymmetric
+    np.testing.assert_array_equal(host(ops.correlate1d_rows_f64(dev(rows), skew)), correlate1d(rows, skew, axis=-1, mode='constant'))
+    if n > 20:
+        rows[0, 7] = np.nan
+        rows[-1, n - 3] = np.inf
+        with np.errstate(all='ignore'):
+            want = convolve1d(rows, taps, axis=-1, mode='constant')
+        np.testing.assert_array_equal(host(ops.correlate1d_rows_f64(dev(rows), taps[::-1])), want)
