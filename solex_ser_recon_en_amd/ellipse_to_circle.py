@@ -5,6 +5,7 @@ correct_image (:94-145) and ellipse_to_circle (:294-342).  The warp runs on the 
 (shg_warp_rows_u16); the limb fit works on the GPU-computed 4x4 block mean and is host
 control plane (limb_fit.py); the 2x2 matrix algebra stays NumPy as in the reference.
 """
+import functools
 import math
 
 import numpy as np
@@ -28,11 +29,10 @@ def get_correction_matrix(phi, r):
     return np.linalg.inv(correction_matrix), theta
 
 
-def correct_image(image, phi, ratio, center, height, options, print_log=False):
-    """image: the uint16 disk (DeviceImage / tensor / ndarray) or, as the reference passes it,
-    float64 disk/65536.  Returns (uint16 DeviceImage, (cx, cy, radius), mat3)."""
-    src = to_device_u16(u16_from_unit_float(image))
-    h, w = src.shape
+@functools.lru_cache(maxsize=64)
+def _warp_geometry(phi, ratio, h, w):
+    """Everything correct_image derives from (phi, ratio) and the image shape (ellipse_to_circle.py:100-114): the disks of
+    a Doppler stack share one geometry, so the 2x2 algebra runs once per file instead of once per disk."""
     mat, theta = get_correction_matrix(phi, ratio)
     mat3 = np.zeros((3, 3))
     mat3[:2, :2] = mat
@@ -42,14 +42,26 @@ def correct_image(image, phi, ratio, center, height, options, print_log=False):
     new_corners = (inv_mat @ corners.T).T
     new_h = np.max(new_corners[:, 1]) - np.min(new_corners[:, 1])
     new_w = np.max(new_corners[:, 0]) - np.min(new_corners[:, 0])
-    mat3 = mat3 @ np.array([[1, 0, np.min(new_corners[:, 0])], [0, 1, np.min(new_corners[:, 1])], [0, 0, 1]])
+    origin = np.array([np.min(new_corners[:, 0]), np.min(new_corners[:, 1])])
+    mat3 = mat3 @ np.array([[1, 0, origin[0]], [0, 1, origin[1]], [0, 0, 1]])
     if not (mat3[1, 0] == 0 and mat3[1, 1] == 1 and mat3[1, 2] == 0 and mat3[2, 0] == 0 and mat3[2, 1] == 0
             and mat3[2, 2] == 1):
         raise RuntimeError('correct_image: the correction never moves rows (ellipse_to_circle.py:48-49); got\n%s' % mat3)
-    fixed = ops.warp_rows_u16(src, mat3[0, 0], mat3[0, 1], mat3[0, 2], int(np.ceil(new_h)), int(np.ceil(new_w)))
+    for a in (mat, inv_mat, mat3, origin):
+        a.setflags(write=False)
+    return mat, theta, inv_mat, mat3, int(np.ceil(new_h)), int(np.ceil(new_w)), origin, np.linalg.det(mat)
+
+
+def correct_image(image, phi, ratio, center, height, options, print_log=False):
+    """image: the uint16 disk (DeviceImage / tensor / ndarray) or, as the reference passes it,
+    float64 disk/65536.  Returns (uint16 DeviceImage, (cx, cy, radius), mat3)."""
+    src = to_device_u16(u16_from_unit_float(image))
+    h, w = src.shape
+    mat, theta, inv_mat, mat3, out_h, out_w, origin, det = _warp_geometry(float(phi), float(ratio), int(h), int(w))
+    fixed = ops.warp_rows_u16(src, mat3[0, 0], mat3[0, 1], mat3[0, 2], out_h, out_w)
     center = np.asarray(center)
-    new_center = (inv_mat @ center.T).T - np.array([np.min(new_corners[:, 0]), np.min(new_corners[:, 1])])
-    new_radius = height * np.sqrt(np.abs(ratio / np.linalg.det(mat)))
+    new_center = (inv_mat @ center.T).T - origin
+    new_radius = height * np.sqrt(np.abs(ratio / det))
     if print_log and '_nolog' not in options:
         basefich0 = options['basefich0']
         print('unrotation angle theta = ' + "{:.3f}".format(math.degrees(theta)) + " degrees")
@@ -62,7 +74,7 @@ def correct_image(image, phi, ratio, center, height, options, print_log=False):
             (str(new_center) + ', ' + "{:.3f}".format(new_radius)) if not height == -1.0 else 'UNKNOWN'))
         logme(basefich0 + '_log.txt', options, 'Unrotation : ' + "{:.3f}".format(math.degrees(theta)) + " degrees")
         np.set_printoptions(suppress=False)
-    return DeviceImage(fixed), (new_center[0], new_center[1], new_radius), mat3
+    return DeviceImage(fixed), (new_center[0], new_center[1], new_radius), mat3.copy()
 
 
 def ellipse_to_circle(image, options, basefich):
