@@ -204,25 +204,37 @@ __global__ __launch_bounds__(256) void k_scale_rows(const uint16_t* __restrict__
 // NI_Correlate1D's own order of operations (the interior of scipy.signal.savgol_filter, solex_util.py:400):
 //   symmetric weights : t = x[0]*w[0]; for j = -R..-1: t += (x[j] + x[-j]) * w[j]      (w indexed from the centre)
 //   otherwise         : t = x[R]*w[R]; for j = -R..R-1: t += x[j] * w[j]
-// One lane per output sample; the 2R+1 weights are read by every lane (L1 broadcast).
-__global__ __launch_bounds__(256) void k_correlate1d_rows(const double* __restrict__ src, int64_t k, int64_t n,
-                                                          const double* __restrict__ weights, int radius, int symmetric,
-                                                          double* __restrict__ dst) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= k * n) return;
-    const int64_t row = i / n, x = i - row * n;
+// One workgroup per (row, 256 output samples): the samples it needs (256 + 2R, zero beyond the row's ends) and the
+// weights are staged in LDS first, so the inner loop has no bounds test and no global load to wait for (with
+// predicated global loads a single 1800-sample row took 30 us: one request in flight per lane).
+constexpr int CORR_MAXR = 1024;
+
+__global__ __launch_bounds__(256) void k_correlate1d_rows(const double* __restrict__ src, int64_t n, const double* __restrict__ weights,
+                                                          int radius, int symmetric, double* __restrict__ dst) {
+    extern __shared__ double corr_lds[];                 // [256 + 2R] samples, then [2R + 1] weights
+    double* xs = corr_lds;
+    double* ws = corr_lds + 256 + 2 * radius;
+    const int64_t row = blockIdx.y, x0 = (int64_t)blockIdx.x * 256;
     const double* line = src + row * n;
-    const double* w = weights + radius;
-    auto at = [&](int64_t xx) -> double { return (xx < 0 || xx >= n) ? 0.0 : line[xx]; };
+    for (int i = threadIdx.x; i < 256 + 2 * radius; i += 256) {
+        const int64_t xx = x0 - radius + i;
+        xs[i] = (xx >= 0 && xx < n) ? line[xx] : 0.0;
+    }
+    for (int i = threadIdx.x; i < 2 * radius + 1; i += 256) ws[i] = weights[i];
+    __syncthreads();
+    const int64_t x = x0 + threadIdx.x;
+    if (x >= n) return;
+    const double* c = xs + radius + threadIdx.x;         // this lane's sample
+    const double* w = ws + radius;
     double t;
     if (symmetric) {
-        t = at(x) * w[0];
-        for (int j = -radius; j < 0; ++j) t += (at(x + j) + at(x - j)) * w[j];
+        t = c[0] * w[0];
+        for (int j = -radius; j < 0; ++j) t += (c[j] + c[-j]) * w[j];
     } else {
-        t = at(x + radius) * w[radius];
-        for (int j = -radius; j < radius; ++j) t += at(x + j) * w[j];
+        t = c[radius] * w[radius];
+        for (int j = -radius; j < radius; ++j) t += c[j] * w[j];
     }
-    dst[i] = t;
+    dst[row * n + x] = t;
 }
 
 // Two order statistics of every row (axis 1) or column (axis 0) of a uint16 image: np.percentile(img, q, axis)
@@ -321,10 +333,12 @@ extern "C" int shg_rowpair_logratio_stats(const uint16_t* img, int64_t h, int64_
 extern "C" int shg_correlate1d_rows_f64(const double* src, int64_t k, int64_t n, const double* weights, int radius, int symmetric,
                                         double* dst, shg_stream_t stream) {
     SHG_REQUIRE(src && weights && dst, SHG_E_ARG, "shg_correlate1d_rows_f64: null pointer");
-    SHG_REQUIRE(k > 0 && n > 0 && radius >= 0 && k * n < (1ll << 40), SHG_E_ARG, "shg_correlate1d_rows_f64: bad sizes");
+    SHG_REQUIRE(k > 0 && k < 65536 && n > 0 && radius >= 0, SHG_E_ARG, "shg_correlate1d_rows_f64: bad sizes");
+    SHG_REQUIRE(radius <= CORR_MAXR, SHG_E_UNSUPPORTED, "shg_correlate1d_rows_f64: radius %d > %d", radius, CORR_MAXR);
     hipStream_t st = shg::as_stream(stream);
+    const size_t lds = (size_t)(256 + 4 * radius + 1) * sizeof(double);
     SHG_PROF("correlate1d_rows", st);
-    k_correlate1d_rows<<<(unsigned)((k * n + 255) / 256), 256, 0, st>>>(src, k, n, weights, radius, symmetric ? 1 : 0, dst);
+    k_correlate1d_rows<<<dim3((unsigned)((n + 255) / 256), (unsigned)k), 256, lds, st>>>(src, n, weights, radius, symmetric ? 1 : 0, dst);
     return shg::check_launch("k_correlate1d_rows");
 }
 

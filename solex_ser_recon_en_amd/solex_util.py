@@ -375,7 +375,7 @@ def correct_transversalium2_batch(imgs, circle, borders, options, reqFlag, basef
         stats = torch.stack([ops.rowpair_logratio_stats(t, y1, y2, xa_d, xb_d, rf) for t, rf in zip(tensors, factors)])
         window = savgol_window(stats.shape[1], options['trans_strength'])
         interior = None
-        if 3 < window <= stats.shape[1]:
+        if 3 < window <= stats.shape[1] and window // 2 <= 1024:         # shg_correlate1d_rows_f64 stages 2R+1 weights in LDS
             # the interior of the Savitzky-Golay trend while the statistics are still on the GPU (SciPy's own order of
             # operations); its two edges are LAPACK fits and stay on the host
             both = torch.stack([stats, ops.correlate1d_rows_f64(stats, _savgol_taps(window)[::-1])]).cpu().numpy()
