@@ -236,13 +236,27 @@ __global__ __launch_bounds__(256) void k_flood_minmax(const double* __restrict__
                                                       double very_bright, unsigned long long* __restrict__ acc) {
     // acc[0] = sum as fixed point (units of 2^-20), acc[1] = min key, acc[2] = max key
     unsigned long long s = 0, lo = ~0ull, hi = 0ull;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        s += (unsigned long long)(image[i] * 1048576.0);
-        const double b = blurred[i];
-        if (b < very_bright) {
-            const uint64_t k = f64_key(b);
-            lo = k < lo ? k : lo;
-            hi = k > hi ? k : hi;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    // four elements per trip, all eight loads issued before the first use (clamped index instead of a predicate)
+    for (int64_t base = (int64_t)blockIdx.x * 256 + threadIdx.x; base < n; base += 4 * stride) {
+        double im[4], bl[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = base + u * stride;
+            ok[u] = i < n;
+            im[u] = image[ok[u] ? i : 0];
+            bl[u] = blurred[ok[u] ? i : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!ok[u]) continue;
+            s += (unsigned long long)(im[u] * 1048576.0);
+            if (bl[u] < very_bright) {
+                const uint64_t k = f64_key(bl[u]);
+                lo = k < lo ? k : lo;
+                hi = k > hi ? k : hi;
+            }
         }
     }
 #pragma unroll
@@ -252,7 +266,12 @@ __global__ __launch_bounds__(256) void k_flood_minmax(const double* __restrict__
         lo = ol < lo ? ol : lo;
         hi = oh > hi ? oh : hi;
     }
-    if ((threadIdx.x & 63) == 0) {
+    // one atomic triple per workgroup: same-address atomics serialise chip-wide
+    __shared__ unsigned long long ws[4], wlo[4], whi[4];
+    if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6] = s; wlo[threadIdx.x >> 6] = lo; whi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) { s += ws[i]; lo = wlo[i] < lo ? wlo[i] : lo; hi = whi[i] > hi ? whi[i] : hi; }
         atomicAdd(&acc[0], s);
         atomicMin(&acc[1], lo);
         atomicMax(&acc[2], hi);

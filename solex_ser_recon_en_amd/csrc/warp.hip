@@ -16,12 +16,25 @@ __global__ void k_minmax_init(uint32_t* mm) {
 __global__ __launch_bounds__(256) void k_minmax(const uint16_t* __restrict__ src, int64_t h, int64_t w, int64_t pitch,
                                                 uint32_t* __restrict__ mm) {
     uint32_t lo = 0xffffffffu, hi = 0u;
-    for (int64_t y = blockIdx.x; y < h; y += gridDim.x) {          // one workgroup per row: no per-pixel division
-        const uint16_t* row = src + y * pitch;
+    // a workgroup owns rows blockIdx.x, + gridDim.x, ...; eight of them at a time, so that every lane has eight
+    // independent loads in flight (clamped row instead of a predicate); no per-pixel division
+    for (int64_t y0 = blockIdx.x; y0 < h; y0 += 8 * (int64_t)gridDim.x) {
         for (int64_t x = threadIdx.x; x < w; x += 256) {
-            const uint32_t v = row[x];
-            lo = v < lo ? v : lo;
-            hi = v > hi ? v : hi;
+            uint32_t v[8];
+            bool ok[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t y = y0 + u * (int64_t)gridDim.x;
+                ok[u] = y < h;
+                v[u] = src[(ok[u] ? y : y0) * pitch + x];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (ok[u]) {
+                    lo = v[u] < lo ? v[u] : lo;
+                    hi = v[u] > hi ? v[u] : hi;
+                }
+            }
         }
     }
 #pragma unroll
@@ -54,12 +67,12 @@ __global__ __launch_bounds__(256) void k_warp_rows(const uint16_t* __restrict__ 
     const double x0 = floor(x), x1 = ceil(x);
     const double dc = x - x0;
     const int64_t i0 = (int64_t)x0, i1 = (int64_t)x1;
-    double left = cval, right = cval;
-    if (r < h) {
-        const uint16_t* row = src + r * pitch;
-        if (i0 >= 0 && i0 < w) left = (double)row[i0] * inv;
-        if (i1 >= 0 && i1 < w) right = (double)row[i1] * inv;
-    }
+    // both samples are read unconditionally from clamped positions and replaced by cval afterwards where they fall
+    // outside the image: no branch (and no wait) between the two loads
+    const uint16_t* row = src + (r < h ? r : 0) * pitch;
+    const bool in0 = r < h && i0 >= 0 && i0 < w, in1 = r < h && i1 >= 0 && i1 < w;
+    const double s0 = (double)row[in0 ? i0 : 0] * inv, s1 = (double)row[in1 ? i1 : 0] * inv;
+    const double left = in0 ? s0 : cval, right = in1 ? s1 : cval;
     double v = (1.0 - dc) * left + dc * right;
     const double lo = (double)mm[0] * inv, hi = (double)mm[1] * inv;
     v = v < lo ? lo : v;                                       // np.clip(warped, image.min(), image.max())
