@@ -106,12 +106,18 @@ __global__ __launch_bounds__(1024) void k_tile_lut(const uint32_t* __restrict__ 
         const int batch = excess / HIST;
         const int residual = excess - batch * HIST;
         const int step = residual != 0 ? max(HIST / residual, 1) : 1;
+        // for (i = 0; i < histSize && residual > 0; i += step, residual--) hist[i]++ : bins 0, step, 2 step, ... below
+        // residual * step; one division per lane instead of two per bin
+        const int64_t limit = (int64_t)residual * step;
+        int next = residual != 0 ? ((tid * PER + step - 1) / step) * step : HIST;
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             const int i = tid * PER + j;
             int c = bins[j] + batch;
-            // for (i = 0; i < histSize && residual > 0; i += step, residual--) hist[i]++
-            if (residual != 0 && (i % step) == 0 && (i / step) < residual) c += 1;
+            if (i == next) {
+                if ((int64_t)i < limit) c += 1;
+                next += step;
+            }
             bins[j] = c;
         }
     }
@@ -139,6 +145,94 @@ __global__ __launch_bounds__(1024) void k_tile_lut(const uint32_t* __restrict__ 
             r = r < 0 ? 0 : (r > HIST - 1 ? HIST - 1 : r);
             lout[tid * PER + j] = (uint16_t)r;
         }
+    }
+}
+
+// The same tile LUT for 65536 bins with coalesced global traffic.  In k_tile_lut a lane owns 64 consecutive bins, so
+// every wave-load touches 64 cache lines (27 us per image).  Here the histogram is read lane-contiguously, clipped and
+// parked in LDS as uint16 (needs 0 < clip <= 65535; index padded by one per 64 so that the blocked re-read -- lane t
+// takes bins 64t .. 64t+63 -- spreads over the banks), processed exactly as above, and the LUT goes back through the
+// same LDS array to be stored lane-contiguously.
+__global__ __launch_bounds__(1024) void k_tile_lut16_lds(const uint32_t* __restrict__ hist, int clip, float lut_scale,
+                                                         uint16_t* __restrict__ lut) {
+    constexpr int HIST = 65536, PER = 64;
+    extern __shared__ uint16_t cb[];                      // [HIST + HIST / 64]
+    __shared__ int wsum[16];
+    __shared__ int total_clipped;
+    const int tile = blockIdx.x;
+    const uint32_t* hin = hist + (int64_t)tile * HIST;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    int clipped = 0;
+    for (int j0 = 0; j0 < PER; j0 += 16) {              // sixteen loads in flight per lane
+        int c[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) c[u] = (int)hin[(j0 + u) * 1024 + tid];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = (j0 + u) * 1024 + tid;
+            if (c[u] > clip) { clipped += c[u] - clip; c[u] = clip; }
+            cb[i + (i >> 6)] = (uint16_t)c[u];
+        }
+    }
+    int v = clipped;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if (lane == 0) wsum[wave] = v;
+    __syncthreads();
+    if (tid == 0) {
+        int s = 0;
+        for (int i = 0; i < 16; ++i) s += wsum[i];
+        total_clipped = s;
+    }
+    __syncthreads();
+    const int excess = total_clipped;
+    const int batch = excess / HIST;
+    const int residual = excess - batch * HIST;
+    const int step = residual != 0 ? max(HIST / residual, 1) : 1;
+    int bins[PER];
+    int local = 0;
+    // for (i = 0; i < histSize && residual > 0; i += step, residual--) hist[i]++ : the bins i = 0, step, 2 step, ...
+    // below residual * step.  One division per lane finds the first such bin of its range (a division per bin made this
+    // kernel ALU bound: 2 x 65536 integer divisions on one CU).
+    const int64_t limit = (int64_t)residual * step;
+    int next = residual != 0 ? ((tid * PER + step - 1) / step) * step : HIST;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = tid * PER + j;
+        int c = (int)cb[tid * (PER + 1) + j] + batch;
+        if (i == next) {
+            if ((int64_t)i < limit) c += 1;
+            next += step;
+        }
+        bins[j] = c;
+        local += c;
+    }
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < wave; ++i) base += wsum[i];
+    int run = base + incl - local;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        run += bins[j];
+        int r = __float2int_rn(__int2float_rn(run) * lut_scale);         // saturate_cast<T>(sum * lutScale)
+        r = r < 0 ? 0 : (r > HIST - 1 ? HIST - 1 : r);
+        cb[tid * (PER + 1) + j] = (uint16_t)r;
+    }
+    __syncthreads();
+    uint16_t* lout = lut + (int64_t)tile * HIST;
+#pragma unroll 8
+    for (int j = 0; j < PER; ++j) {
+        const int i = j * 1024 + tid;
+        lout[i] = cb[i + (i >> 6)];
     }
 }
 
@@ -343,6 +437,8 @@ void ensure_lds_attr() {
     if (!done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_image_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_lut16_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (HIST16 + HIST16 / 64) * 2);
         done = true;
     }
 }
@@ -395,7 +491,13 @@ extern "C" int shg_clahe(const void* img, int64_t h, int64_t w, int64_t pitch, i
         dim3 hgrid((unsigned)((area + SLICE_PX - 1) / SLICE_PX), (unsigned)ntiles);
         { SHG_PROF("clahe_hist", st); k_tile_hist16<<<hgrid, 1024, HIST16 * 2, st>>>(static_cast<const uint16_t*>(img), h, w, pitch, tiles, th, tw, hist); }
         if (int e = shg::check_launch("k_tile_hist16")) return e;
-        { SHG_PROF("clahe_lut", st); k_tile_lut<HIST16><<<ntiles, 1024, 0, st>>>(hist, clip, lut_scale, lut); }
+        if (clip > 0 && clip <= 65535) {
+            SHG_PROF("clahe_lut", st);
+            k_tile_lut16_lds<<<ntiles, 1024, (HIST16 + HIST16 / 64) * sizeof(uint16_t), st>>>(hist, clip, lut_scale, lut);
+        } else {
+            SHG_PROF("clahe_lut", st);
+            k_tile_lut<HIST16><<<ntiles, 1024, 0, st>>>(hist, clip, lut_scale, lut);
+        }
         if (int e = shg::check_launch("k_tile_lut")) return e;
         { SHG_PROF("clahe_interp", st); k_clahe_interp<uint16_t, HIST16><<<igrid, 256, 0, st>>>(static_cast<const uint16_t*>(img), h, w, pitch, tiles, inv_tw, inv_th,
                                                                 lut, static_cast<uint16_t*>(dst), dst_pitch); }
