@@ -59,3 +59,33 @@ def test_ops_refuse_cpu_tensors():
     from solex_ser_recon_en_amd import ops
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         ops.accumulate_sum_max(torch.zeros((2, 4, 4), dtype=torch.uint8))
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    """include/shg_hip.h is the drop-in boundary: it must be valid C99 (no C++, no torch types)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    src = os.path.join(os.path.dirname(__file__), 'c_abi', 'header_is_c.c')
+    inc = os.path.join(os.path.dirname(os.path.dirname(__file__)), 'include')
+    r = subprocess.run([gcc, '-std=c99', '-Wall', '-Werror', '-pedantic', '-I', inc, '-c', src, '-o', str(tmp_path / 'h.o')],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_c_caller_builds_against_the_library(tmp_path):
+    """tests/c_abi/abi_smoke.cpp (a torch-free, Python-free caller) compiles and links against libshg_hip.so here;
+    it RUNS in the gpu test of the same name."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    root = os.path.dirname(os.path.dirname(__file__))
+    lib_dir = os.path.join(root, 'solex_ser_recon_en_amd', 'csrc')
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O1', '-I', os.path.join(root, 'include'),
+                        os.path.join(root, 'tests', 'c_abi', 'abi_smoke.cpp'), '-L', lib_dir, '-lshg_hip',
+                        '-Wl,-rpath,' + lib_dir, '-o', str(tmp_path / 'abi_smoke')], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]

@@ -593,3 +593,26 @@ def test_correlate1d_rows_is_scipys(ops, k, n, window):
         with np.errstate(all='ignore'):
             want = convolve1d(rows, taps, axis=-1, mode='constant')
         np.testing.assert_array_equal(host(ops.correlate1d_rows_f64(dev(rows), taps[::-1])), want)
+
+
+def test_c_caller_runs_without_python_or_torch(tmp_path):
+    """tests/c_abi/abi_smoke.cpp: HIP runtime + libshg_hip.so only (hipMalloc'd buffers, plain pointers and sizes).
+    Built with hipcc on the box and run as a child process; exit code 0 = pass A, pass B and a row pass equal CPU loops."""
+    import os
+    import shutil
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc on this box')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, 'solex_ser_recon_en_amd', 'csrc')
+    exe = str(tmp_path / 'abi_smoke')
+    b = subprocess.run([hipcc, '--offload-arch=gfx950', '-O1', '-I', os.path.join(root, 'include'),
+                        os.path.join(root, 'tests', 'c_abi', 'abi_smoke.cpp'), '-L', lib_dir, '-lshg_hip',
+                        '-Wl,-rpath,' + lib_dir, '-o', exe], capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+    assert 'C ABI smoke OK' in r.stdout
