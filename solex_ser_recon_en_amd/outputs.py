@@ -6,11 +6,17 @@ plot costs seconds.  Here every file write is a background task (device -> host 
 encode + write), so the GPU pipeline of the next disk / next file proceeds meanwhile:
 image encoders run on a small pool (byte swaps, deflate, CRC and file writes release the
 GIL; four 8 MB PNGs per file would otherwise take longer than decoding the next file),
-the matplotlib diagnostics on one thread of their own.  flush() re-raises the first failure, so a failed write still
+the matplotlib diagnostics on one thread of their own.  A folder of scans with the default flags is then bound by
+that thread (three 300-400 dpi figures, about 0.4 s each): SHG_PLOT_PROCESSES=N draws them in N spawned worker
+processes instead (they import numpy and matplotlib only; images are copied to the host first; as with any
+spawned pool, a calling script needs the usual `if __name__ == '__main__':` guard).  flush() re-raises the first failure, so a failed write still
 stops the batch the way an exception in the reference's worker does (Solex_recon.py:42).
 """
+import atexit
+import multiprocessing
+import os
 import threading
-from concurrent.futures import ThreadPoolExecutor
+from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
 
 import numpy as np
 
@@ -20,6 +26,31 @@ _lock = threading.Lock()
 _pools = {}
 _pending = []
 ENCODER_THREADS = 4
+_plot_procs = None
+
+
+def _plot_processes():
+    try:
+        return max(0, int(os.environ.get('SHG_PLOT_PROCESSES', '0')))
+    except ValueError:
+        return 0
+
+
+def _host_args(args):
+    """Device images -> NumPy before they cross a process boundary."""
+    return tuple(np.asarray(a) if hasattr(a, '__array__') and not isinstance(a, np.ndarray) else a for a in args)
+
+
+def _plot_in_worker(fn, args):
+    global _plot_procs
+    host = _host_args(args)
+    with _lock:
+        if _plot_procs is None:
+            _plot_procs = ProcessPoolExecutor(max_workers=_plot_processes(), mp_context=multiprocessing.get_context('spawn'))
+            atexit.register(_plot_procs.shutdown)
+        _pending.append(_plot_procs.submit(fn, *host))
+
+
 synchronous = False          # tests can force inline execution
 
 
@@ -32,19 +63,26 @@ def submit(fn, *args):
         if kind not in _pools:
             _pools[kind] = ThreadPoolExecutor(max_workers=1 if kind == 'plot' else ENCODER_THREADS,
                                               thread_name_prefix='shg-' + kind)
-        _pending.append(_pools[kind].submit(fn, *args))
+        if kind == 'plot' and _plot_processes() > 0:
+            # the plot thread only copies the images to the host and hands the figure to a worker process
+            _pending.append(_pools[kind].submit(_plot_in_worker, fn, args))
+        else:
+            _pending.append(_pools[kind].submit(fn, *args))
 
 
 def flush():
-    with _lock:
-        todo = list(_pending)
-        del _pending[:]
     err = None
-    for fut in todo:
-        try:
-            fut.result()
-        except Exception as e:      # noqa: BLE001 -- keep draining, report the first
-            err = err or e
+    while True:
+        with _lock:
+            todo = list(_pending)
+            del _pending[:]
+        if not todo:
+            break                    # (a plot task may have queued its worker-process future while we waited)
+        for fut in todo:
+            try:
+                fut.result()
+            except Exception as e:      # noqa: BLE001 -- keep draining, report the first
+                err = err or e
     if err is not None:
         raise err
 
