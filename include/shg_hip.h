@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SHG_ABI_VERSION 7
+#define SHG_ABI_VERSION 8
 
 #define SHG_E_ARG        (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SHG_E_WORKSPACE  (-2)   /* workspace too small                                 */
@@ -223,6 +223,9 @@ int shg_select_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, con
 int shg_rescale_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch,
                     double lo, double hi, double alpha, uint16_t* dst, int64_t dst_pitch,
                     shg_stream_t stream);
+/* The same for 8-bit images (sat = 255): clahe_apply.py:251 stretches 8-bit PNGs too. */
+int shg_rescale_u8(const uint8_t* img, int64_t h, int64_t w, int64_t pitch, double lo, double hi,
+                   double alpha, uint8_t* dst, int64_t dst_pitch, shg_stream_t stream);
 
 /* cv2.circle(img, (x0, y0), r, value, -1): filled integer midpoint circle, clipped to the
  * image (solex_util.py:542-547).  scratch: unused (may be NULL); kept for ABI stability. */

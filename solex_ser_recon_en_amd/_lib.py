@@ -58,6 +58,7 @@ SIGNATURES = {
     'shg_select_u16_workspace_bytes': (c_size_t, [c_int]),
     'shg_select_u16': (c_int, [P, c_int64, c_int64, c_int64, ctypes.POINTER(c_int64), c_int, P, P, c_size_t, P]),
     'shg_rescale_u16': (c_int, [P, c_int64, c_int64, c_int64, c_double, c_double, c_double, P, c_int64, P]),
+    'shg_rescale_u8': (c_int, [P, c_int64, c_int64, c_int64, c_double, c_double, c_double, P, c_int64, P]),
     'shg_fill_disc_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_uint16, P, P]),
     'shg_downscale_mean_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int, P, P]),
     'shg_box_blur_f64': (c_int, [P, c_int64, c_int64, c_int, P, P, P]),
@@ -77,7 +78,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 if lib.shg_abi_version() != ABI_VERSION:
     raise ImportError('libshg_hip.so ABI %d != expected %d: rebuild it' % (lib.shg_abi_version(), ABI_VERSION))
 

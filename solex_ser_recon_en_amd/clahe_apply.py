@@ -25,10 +25,8 @@ def apply_clahe(file, options, write_file=True):
     dark = percentile_from_hist(hist, options['lo'])
     bright = percentile_from_hist(hist, options['hi'])
     if options['do_stretch']:
-        if frame.dtype == np.uint16:
-            cl1 = np.asarray(rescale_brightness(cl1_t, dark, bright, alpha=options['sat'] / 100))
-        else:
-            cl1 = rescale_brightness(cl1_t.cpu().numpy(), dark, bright, alpha=options['sat'] / 100)
+        out = rescale_brightness(cl1_t, dark, bright, alpha=options['sat'] / 100)
+        cl1 = out.cpu().numpy() if isinstance(out, torch.Tensor) else np.asarray(out)
     else:
         cl1 = cl1_t.cpu().numpy()
     if write_file and isinstance(file, str):

@@ -29,6 +29,18 @@ __global__ __launch_bounds__(256) void k_rescale(const uint16_t* __restrict__ im
     dst[y * dst_pitch + x] = (uint16_t)(int)v;
 }
 
+// the same for 8-bit images (clahe_apply.py:251 stretches 8-bit PNGs too): sat = 255
+__global__ __launch_bounds__(256) void k_rescale_u8(const uint8_t* __restrict__ img, int64_t w, int64_t pitch, double a, double lo,
+                                                    double span, uint8_t* __restrict__ dst, int64_t dst_pitch) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t y = blockIdx.y;
+    if (x >= w) return;
+    double v = a * ((double)img[y * pitch + x] - lo) / span;
+    v = v < 0.0 ? 0.0 : v;
+    v = v > 255.0 ? 255.0 : v;
+    dst[y * dst_pitch + x] = (uint8_t)(int)v;
+}
+
 // OpenCV drawing.cpp Circle(img, c, r, color, fill=true): the integer midpoint circle keeps the invariant
 // err = dx^2 + dy^2 - r^2 <= 0 with dx maximal, so the span drawn on rows y0 +- j is exactly
 // |x - x0| <= isqrt(r^2 - j^2) (checked against the stepwise algorithm for every r < 400 in the tests).
@@ -90,6 +102,17 @@ extern "C" int shg_rescale_u16(const uint16_t* img, int64_t h, int64_t w, int64_
     dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
     { SHG_PROF("rescale", shg::as_stream(stream)); k_rescale<<<grid, 256, 0, shg::as_stream(stream)>>>(img, w, pitch, 65535.0 * alpha, lo, hi - lo, dst, dst_pitch); }
     return shg::check_launch("k_rescale");
+}
+
+extern "C" int shg_rescale_u8(const uint8_t* img, int64_t h, int64_t w, int64_t pitch, double lo, double hi, double alpha,
+                              uint8_t* dst, int64_t dst_pitch, shg_stream_t stream) {
+    SHG_REQUIRE(img && dst, SHG_E_ARG, "shg_rescale_u8: null pointer");
+    SHG_REQUIRE(h > 0 && w > 0 && pitch >= w && dst_pitch >= w, SHG_E_ARG, "shg_rescale_u8: bad image size");
+    SHG_REQUIRE(255.0 >= hi && hi > lo, SHG_E_ARG, "shg_rescale_u8: need sat >= hi > lo (got lo=%g hi=%g)", lo, hi);
+    SHG_REQUIRE(h < 65536, SHG_E_UNSUPPORTED, "shg_rescale_u8: more than 65535 rows");
+    dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
+    { SHG_PROF("rescale", shg::as_stream(stream)); k_rescale_u8<<<grid, 256, 0, shg::as_stream(stream)>>>(img, w, pitch, 255.0 * alpha, lo, hi - lo, dst, dst_pitch); }
+    return shg::check_launch("k_rescale_u8");
 }
 
 extern "C" int shg_fill_disc_u16(uint16_t* img, int64_t h, int64_t w, int64_t pitch, int64_t x0, int64_t y0, int64_t r,

@@ -326,6 +326,14 @@ def histogram(img):
     return hist
 
 
+def rescale_u8(img, lo, hi, alpha=1.0):
+    ptr, h, w, pitch = _img(img, 'img', torch.uint8)
+    out = torch.empty((h, w), dtype=torch.uint8, device=img.device)
+    _lib.check(lib.shg_rescale_u8(ptr, h, w, pitch, float(lo), float(hi), float(alpha), out.data_ptr(), out.stride(0), _stream()),
+               'shg_rescale_u8')
+    return out
+
+
 def rescale_u16(img, lo, hi, alpha=1.0):
     ptr, h, w, pitch = _img(img, 'img', torch.uint16)
     out = pitched_u16(h, w, img.device)

@@ -476,14 +476,9 @@ def as_uint16_image(img):
 
 # ---- a12: rescale_brightness (reference solex_util.py:519-525) ------------------------------
 def rescale_brightness(img, lo, hi, alpha=1.0):
-    if isinstance(img, np.ndarray) and img.dtype == np.uint8:
-        # 8-bit images only reach this function from clahe_apply.py; a few hundred KB -> host float64, as the reference
-        sat = 255
-        assert sat >= hi > lo
-        rescaled = float(sat) * alpha * (img - lo) / (hi - lo)
-        rescaled[rescaled < 0] = 0
-        rescaled[rescaled > sat] = sat
-        return rescaled.astype(img.dtype)
+    if isinstance(img, torch.Tensor) and img.dtype == torch.uint8:
+        assert 255 >= hi > lo                                                          # 8-bit images only reach this from clahe_apply.py
+        return ops.rescale_u8(img, lo, hi, alpha)
     assert 65535 >= hi > lo                                                            # :521
     return DeviceImage(ops.rescale_u16(to_device_u16(img), lo, hi, alpha))
 

@@ -151,6 +151,11 @@ def test_apply_clahe_tool(pkg, tmp_path):
     np.testing.assert_array_equal(clahe_apply.apply_clahe(path, o, write_file=False), want)
     img8 = (img >> 8).astype(np.uint8)
     np.testing.assert_array_equal(clahe_apply.apply_clahe(img8, dict(clahe_apply.options), write_file=False), orc.clahe(img8, 0.8, 2))
+    # the 8-bit stretch (sat = 255) also runs on the GPU
+    want8 = orc.rescale_brightness(orc.clahe(img8, 0.8, 2), np.percentile(img8, 1), np.percentile(img8, 99.5), alpha=0.8)
+    got8 = clahe_apply.apply_clahe(img8, o, write_file=False)
+    assert got8.dtype == np.uint8
+    np.testing.assert_array_equal(got8, want8)
 
 
 def test_folder_of_files_with_prefetch(pkg, scan, tmp_path):
