@@ -21,9 +21,9 @@ namespace {
 constexpr int TY = 64;        // slit rows per workgroup (= lanes of a wave)
 constexpr int TK = 64;        // output columns (frames) per workgroup
 constexpr int TKP = TK + 2;   // padded LDS row stride (33 dwords: odd)
-constexpr int SC = 4;         // shifts per workgroup
+constexpr int SC_MAX = 4;     // shifts per workgroup (2 when the scan has only the two implicit shifts: half the registers)
 
-template <typename T, bool ROT, int BATCH>
+template <typename T, bool ROT, int BATCH, int SC>
 __global__ __launch_bounds__(256) void k_extract(const T* __restrict__ stack, int n_frames, int64_t height, int64_t width, int64_t fstride,
                                                  const int32_t* __restrict__ ind_l, const double* __restrict__ lw,
                                                  const double* __restrict__ rw, int n_shifts,
@@ -140,12 +140,14 @@ extern "C" int shg_extract_columns(const void* stack, int64_t n_frames, int64_t 
     const int64_t ih = rot ? width : height;
     // the tile's 16-byte row segments land on 16-byte boundaries when every row does
     const int vec_store = ((reinterpret_cast<uintptr_t>(disks) & 15) == 0) && (row_pitch % 8 == 0) && (plane_stride % 8 == 0);
-    dim3 grid((unsigned)((n_cols + TK - 1) / TK), (unsigned)((ih + TY - 1) / TY), (unsigned)((n_shifts + SC - 1) / SC));
+    const int sc = n_shifts <= 2 ? 2 : SC_MAX;
+    dim3 grid((unsigned)((n_cols + TK - 1) / TK), (unsigned)((ih + TY - 1) / TY), (unsigned)((n_shifts + sc - 1) / sc));
     hipStream_t st = shg::as_stream(stream);
     const int n = (int)n_frames;
-#define SHG_LAUNCH_B(T, ROT, B)                                                                                         \
-    k_extract<T, ROT, B><<<grid, 256, 0, st>>>(static_cast<const T*>(stack), n, height, width, fstride, ind_l, lw, rw, n_shifts, \
+#define SHG_LAUNCH_BS(T, ROT, B, SCV)                                                                                         \
+    k_extract<T, ROT, B, SCV><<<grid, 256, 0, st>>>(static_cast<const T*>(stack), n, height, width, fstride, ind_l, lw, rw, n_shifts, \
                                                disks, row_pitch, plane_stride, n_cols, k_offset, flip_x, vec_store)
+#define SHG_LAUNCH_B(T, ROT, B) do { if (sc == 2) SHG_LAUNCH_BS(T, ROT, B, 2); else SHG_LAUNCH_BS(T, ROT, B, 4); } while (0)
 #define SHG_LAUNCH(T, ROT)                                                 \
     switch (batch) {                                                       \
         case 1: SHG_LAUNCH_B(T, ROT, 1); break;                            \
@@ -155,8 +157,10 @@ extern "C" int shg_extract_columns(const void* stack, int64_t n_frames, int64_t 
         default: SHG_LAUNCH_B(T, ROT, 4); break;                           \
     }
     static const int batch_env = [] { const char* e = getenv("SHG_EXT_BATCH"); return e ? atoi(e) : 0; }();   // tuning override
-    // measured at C2 (tools/sweep_extract.sh), batch 1 / 2 / 4 / 8 / 16: S=2 18 / 16 / 16 / 16 / 20 us, S=21 124 / 104 / 104 / 95 / 124 us
-    const int batch = batch_env > 0 ? batch_env : (n_shifts > SC ? 8 : 4);
+    // measured at C2 (tools/sweep_extract.sh), batch 1 / 2 / 4 / 8 / 16: S=21 124 / 104 / 104 / 95 / 124 us; S=2 with the two-shift
+    // instantiation 14 / 13 / 14 / 14 us for batch 2 / 4 / 8 / 16 (16 us with the four-shift one)
+    const int batch2 = 4;
+    const int batch = batch_env > 0 ? batch_env : (n_shifts > SC_MAX ? 8 : (n_shifts <= 2 ? batch2 : 4));
     SHG_PROF("extract", st);
     if (bytes_per_px == 2) {
         if (rot) SHG_LAUNCH(uint16_t, true) else SHG_LAUNCH(uint16_t, false)
@@ -164,6 +168,7 @@ extern "C" int shg_extract_columns(const void* stack, int64_t n_frames, int64_t 
         if (rot) SHG_LAUNCH(uint8_t, true) else SHG_LAUNCH(uint8_t, false)
     }
 #undef SHG_LAUNCH_B
+#undef SHG_LAUNCH_BS
 #undef SHG_LAUNCH
     return shg::check_launch("k_extract");
 }
