@@ -476,8 +476,12 @@ def as_uint16_image(img):
 
 # ---- a12: rescale_brightness (reference solex_util.py:519-525) ------------------------------
 def rescale_brightness(img, lo, hi, alpha=1.0):
-    if isinstance(img, torch.Tensor) and img.dtype == torch.uint8:
-        assert 255 >= hi > lo                                                          # 8-bit images only reach this from clahe_apply.py
+    if getattr(img, 'dtype', None) in (torch.uint8, np.uint8):
+        # 8-bit images only reach this from clahe_apply.py: sat = 255; a NumPy image comes back as NumPy
+        assert 255 >= hi > lo
+        if isinstance(img, np.ndarray):
+            from .device import default_device
+            return ops.rescale_u8(torch.from_numpy(np.ascontiguousarray(img)).to(default_device()), lo, hi, alpha).cpu().numpy()
         return ops.rescale_u8(img, lo, hi, alpha)
     assert 65535 >= hi > lo                                                            # :521
     return DeviceImage(ops.rescale_u16(to_device_u16(img), lo, hi, alpha))
