@@ -39,7 +39,9 @@ def synth_frames_numpy(n_frames, width, height, depth_bits=16, seed=0, row_gain=
     """Return frames [k1-k0, Height, Width] (file layout) as uint8/uint16.
 
     scene overrides entries of scene_params() (disk centre / semi-axes, lit slit span, line depth / width, gain,
-    sky, noise) for scans that are off-centre, elongated, noisier ...
+    sky, noise) for scans that are off-centre, elongated, noisier ...; scene['spots'] is a list of
+    (frame, row, radius_frames, radius_rows, depth) Gaussian features: depth > 0 darkens (sunspots), < 0 brightens
+    (plages, or prominences when placed off the limb).
 
     n_total is the length of the whole scan (defaults to n_frames); k0:k1 selects
     a block of frames of that scan (used for sharded generation).  The noise of
@@ -61,6 +63,8 @@ def synth_frames_numpy(n_frames, width, height, depth_bits=16, seed=0, row_gain=
     for k in range(k0, k1):
         r2 = ((k - sp['cx']) / sp['ax']) ** 2 + ((y - sp['cy']) / sp['ay']) ** 2
         bright = np.where(r2 < 1.0, 0.35 + 0.65 * np.sqrt(np.clip(1.0 - r2, 0.0, 1.0)), sp['sky']) * lit
+        for (sk, sy, rk, ry, depth) in sp.get('spots', ()):
+            bright = bright * (1.0 - depth * np.exp(-0.5 * (((k - sk) / rk) ** 2 + ((y - sy) / ry) ** 2)))
         rng = np.random.default_rng([seed, k])
         img = sp['gain'] * bright[:, None] * line + sp['noise'] * rng.standard_normal((ih, iw))
         img = np.clip(np.rint(img * full), 0, full).astype(out.dtype)

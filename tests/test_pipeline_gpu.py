@@ -422,6 +422,10 @@ VARIANTS = {
     'noisy': dict(scene=dict(noise=0.012, depth=0.6), options={'crop_width_square': True}),
     'faint_8bit': dict(bits=8, scene=dict(gain=0.5, sky=0.04)),
     'tilted_line': dict(tilt=0.03, curv=-4e-5, options={'shift': [-3, 3]}),
+    # an active sun: two spots, a plage, a prominence off the limb, dust lines on the slit (transversalium)
+    'active_sun_dusty_slit': dict(scene=dict(spots=[(150.0, 170.0, 9.0, 9.0, 0.7), (260.0, 240.0, 5.0, 6.0, 0.5),
+                                                    (210.0, 120.0, 14.0, 10.0, -0.25), (372.0, 200.0, 6.0, 14.0, -4.0)]),
+                                  row_gain='dust'),
 }
 
 
@@ -432,8 +436,12 @@ def test_scene_variants_vs_oracle(pkg, name):
     SHG_MAIN, Solex_recon, outputs = pkg
     from solex_ser_recon_en_amd.video_reader import array_reader
     v = VARIANTS[name]
+    row_gain = None
+    if v.get('row_gain') == 'dust':
+        row_gain = 1 + 0.005 * np.random.default_rng(5).standard_normal(400)
+        row_gain[[97, 98, 181, 260, 261, 262]] *= [0.93, 0.95, 0.9, 0.96, 0.92, 0.97]
     frames = synth.synth_frames_numpy(v.get('n', 400), 400, 32, v.get('bits', 16), seed=11, tilt=v.get('tilt', 0.01),
-                                      curv=v.get('curv', 5e-5), scene=v.get('scene'))
+                                      curv=v.get('curv', 5e-5), scene=v.get('scene'), row_gain=row_gain)
     extra = v.get('options', {})
     want = po.run(frames, extra)
     opts = SHG_MAIN.default_options()
