@@ -140,8 +140,12 @@ def extract_columns(stack, ind_l, lw, rw, n_cols=None, k_offset=0, flip_x=False,
     dev = stack.device
     ih = max(h, w)
     ind_l = torch.as_tensor(np.ascontiguousarray(ind_l, dtype=np.int32) if not isinstance(ind_l, torch.Tensor) else ind_l).to(dev)
-    lw = torch.as_tensor(np.ascontiguousarray(lw, dtype=np.float64) if not isinstance(lw, torch.Tensor) else lw).to(dev)
-    rw = torch.as_tensor(np.ascontiguousarray(rw, dtype=np.float64) if not isinstance(rw, torch.Tensor) else rw).to(dev)
+    if not isinstance(lw, torch.Tensor) and not isinstance(rw, torch.Tensor) and np.shape(lw) == np.shape(rw):
+        both = torch.from_numpy(np.stack([np.asarray(lw, dtype=np.float64), np.asarray(rw, dtype=np.float64)])).to(dev)   # one upload
+        lw, rw = both[0], both[1]
+    else:
+        lw = torch.as_tensor(np.ascontiguousarray(lw, dtype=np.float64) if not isinstance(lw, torch.Tensor) else lw).to(dev)
+        rw = torch.as_tensor(np.ascontiguousarray(rw, dtype=np.float64) if not isinstance(rw, torch.Tensor) else rw).to(dev)
     if ind_l.dim() != 2 or ind_l.shape[1] != ih or lw.shape != (ih,) or rw.shape != (ih,):
         raise ValueError('ind_l must be [S, %d] and lw, rw [%d]' % (ih, ih))
     if ind_l.dtype != torch.int32 or lw.dtype != torch.float64 or rw.dtype != torch.float64:
@@ -150,7 +154,9 @@ def extract_columns(stack, ind_l, lw, rw, n_cols=None, k_offset=0, flip_x=False,
     n_cols = n if n_cols is None else int(n_cols)
     if out is None:
         pitch = (n_cols + 63) // 64 * 64
-        out = torch.zeros((s, ih, pitch), dtype=torch.uint16, device=dev)[:, :, :n_cols]
+        # every column is written when this call covers the whole scan; a shard's call leaves the others' columns zero
+        alloc = torch.empty if (n_cols == n and int(k_offset) == 0) else torch.zeros
+        out = alloc((s, ih, pitch), dtype=torch.uint16, device=dev)[:, :, :n_cols]
     if out.shape != (s, ih, n_cols) or out.stride(2) != 1:
         raise ValueError('out must be a [S, ih, n_cols] view with unit column stride')
     _lib.check(lib.shg_extract_columns(stack.data_ptr(), n, h, w, bpp, frame_stride(stack), ind_l.contiguous().data_ptr(),

@@ -370,8 +370,8 @@ def correct_transversalium2_batch(imgs, circle, borders, options, reqFlag, basef
     y2 = math.floor(min(circle[1] + circle[2], borders[3]))
     if y2 - y1 >= 1:
         xa, xb = _chord_bounds(circle, borders, y1, y2, w)
-        xa_d = torch.from_numpy(xa).to(tensors[0].device)
-        xb_d = torch.from_numpy(xb).to(tensors[0].device)
+        bounds_d = torch.from_numpy(np.stack([xa, xb])).to(tensors[0].device)          # one upload for both bound vectors
+        xa_d, xb_d = bounds_d[0], bounds_d[1]
         stats = torch.stack([ops.rowpair_logratio_stats(t, y1, y2, xa_d, xb_d, rf) for t, rf in zip(tensors, factors)])
         window = savgol_window(stats.shape[1], options['trans_strength'])
         interior = None
