@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SHG_ABI_VERSION 8
+#define SHG_ABI_VERSION 9
 
 #define SHG_E_ARG        (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SHG_E_WORKSPACE  (-2)   /* workspace too small                                 */
@@ -261,6 +261,12 @@ int shg_select_multi_f64(const double* const* host_arrays, int64_t n, const int6
  * counts[20] = np.histogram(data, bins=20)[0].  workspace: 32 bytes. */
 int shg_flood_stats_f64(const double* image, const double* blurred, int64_t n, double very_bright,
                         double* stats, uint32_t* counts, void* workspace, shg_stream_t stream);
+/* The same with very_bright = np.percentile(blurred, 99) formed on the device from the two order
+ * statistics order_stats[0..1] (device memory, e.g. shg_select_multi_f64's output) by NumPy's _lerp
+ * with weight gamma: b - (b-a)*(1-gamma) if gamma >= 0.5 else a + (b-a)*gamma. */
+int shg_flood_stats_lerp_f64(const double* image, const double* blurred, int64_t n,
+                             const double* order_stats, double gamma, double* stats, uint32_t* counts,
+                             void* workspace, shg_stream_t stream);
 
 /* skimage.feature.canny(flooded, sigma, low, high) up to its two hysteresis masks
  * (ellipse_to_circle.py:245-250), where flooded = (blurred < flood_thresh ? 0 : 65000)

@@ -66,6 +66,7 @@ SIGNATURES = {
     'shg_select_f64': (c_int, [P, c_int64, ctypes.POINTER(c_int64), c_int, P, P, c_size_t, P]),
     'shg_select_multi_f64': (c_int, [ctypes.POINTER(c_void_p), c_int64, ctypes.POINTER(c_int64), c_int, P, P, c_size_t, P]),
     'shg_flood_stats_f64': (c_int, [P, P, c_int64, c_double, P, P, P, P]),
+    'shg_flood_stats_lerp_f64': (c_int, [P, P, c_int64, P, c_double, P, P, P, P]),
     'shg_edge_components_workspace_bytes': (c_size_t, [c_int64, c_int64]),
     'shg_edge_components': (c_int, [P, P, c_int64, c_int64, P, P, P, P, c_size_t, P]),
     'shg_canny_workspace_bytes': (c_size_t, [c_int64, c_int64]),
@@ -78,7 +79,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 if lib.shg_abi_version() != ABI_VERSION:
     raise ImportError('libshg_hip.so ABI %d != expected %d: rebuild it' % (lib.shg_abi_version(), ABI_VERSION))
 

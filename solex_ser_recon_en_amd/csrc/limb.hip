@@ -232,9 +232,27 @@ __global__ __launch_bounds__(256) void k_select_final(const int64_t* __restrict_
 // ---- get_flood_image's statistics (ellipse_to_circle.py:159-169) ----------------------------------------
 // stats[0] = sum(image) (every value is k / 2^20 and the total < 2^18: exact in any order),
 // then over data = blurred[blurred < very_bright]: stats[1] = min, stats[2] = max, counts[20] = np.histogram(data, 20)
+// accumulators, the 20 counters, and very_bright: either the caller's value or NumPy's _lerp of two order statistics
+// that are still on the device (np.percentile(img_blurred, 99), ellipse_to_circle.py:165) -- no host round trip
+__global__ void k_flood_init(unsigned long long* __restrict__ acc, uint32_t* __restrict__ counts, const double* __restrict__ order_stats,
+                             double gamma, double very_bright) {
+    if (threadIdx.x < 20) counts[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        acc[0] = 0ull;
+        acc[1] = ~0ull;
+        acc[2] = 0ull;
+        if (order_stats) {
+            const double a = order_stats[0], b = order_stats[1], diff = b - a;
+            very_bright = gamma >= 0.5 ? b - diff * (1.0 - gamma) : a + diff * gamma;
+        }
+        acc[3] = (unsigned long long)__double_as_longlong(very_bright);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_flood_minmax(const double* __restrict__ image, const double* __restrict__ blurred, int64_t n,
-                                                      double very_bright, unsigned long long* __restrict__ acc) {
-    // acc[0] = sum as fixed point (units of 2^-20), acc[1] = min key, acc[2] = max key
+                                                      unsigned long long* __restrict__ acc) {
+    // acc[0] = sum as fixed point (units of 2^-20), acc[1] = min key, acc[2] = max key, acc[3] = very_bright (double bits, k_flood_init)
+    const double very_bright = __longlong_as_double((long long)acc[3]);
     unsigned long long s = 0, lo = ~0ull, hi = 0ull;
     const int64_t stride = (int64_t)gridDim.x * 256;
     // four elements per trip, all eight loads issued before the first use (clamped index instead of a predicate)
@@ -278,9 +296,10 @@ __global__ __launch_bounds__(256) void k_flood_minmax(const double* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void k_flood_hist(const double* __restrict__ blurred, int64_t n, double very_bright,
+__global__ __launch_bounds__(256) void k_flood_hist(const double* __restrict__ blurred, int64_t n,
                                                     const unsigned long long* __restrict__ acc, double* __restrict__ stats,
                                                     uint32_t* __restrict__ counts) {
+    const double very_bright = __longlong_as_double((long long)acc[3]);
     __shared__ double edges[21];
     __shared__ uint32_t lc[20];
     const double mn = key_f64(acc[1]), mx = key_f64(acc[2]);
@@ -516,23 +535,32 @@ extern "C" int shg_select_multi_f64(const double* const* host_arrays, int64_t n,
     return shg::check_launch("k_select_final");
 }
 
-extern "C" int shg_flood_stats_f64(const double* image, const double* blurred, int64_t n, double very_bright, double* stats,
-                                   uint32_t* counts, void* workspace, shg_stream_t stream) {
-    SHG_REQUIRE(image && blurred && stats && counts && workspace, SHG_E_ARG, "shg_flood_stats_f64: null pointer");
-    SHG_REQUIRE(n > 0, SHG_E_ARG, "shg_flood_stats_f64: empty image");
+static int flood_stats(const double* image, const double* blurred, int64_t n, const double* order_stats, double gamma,
+                       double very_bright, double* stats, uint32_t* counts, void* workspace, shg_stream_t stream, const char* who) {
+    SHG_REQUIRE(image && blurred && stats && counts && workspace, SHG_E_ARG, "%s: null pointer", who);
+    SHG_REQUIRE(n > 0, SHG_E_ARG, "%s: empty image", who);
     hipStream_t st = shg::as_stream(stream);
     unsigned long long* acc = static_cast<unsigned long long*>(workspace);
-    const unsigned long long init[3] = {0ull, ~0ull, 0ull};
-    hipError_t e = hipMemcpyAsync(acc, init, sizeof(init), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemsetAsync(counts, 0, 20 * sizeof(uint32_t), st);
-    if (e != hipSuccess) { shg::set_error("shg_flood_stats_f64: %s", hipGetErrorString(e)); return (int)e; }
     int64_t blocks = (n + 2047) / 2048;
     if (blocks > 256) blocks = 256;
     SHG_PROF("flood_stats", st);
-    k_flood_minmax<<<(unsigned)blocks, 256, 0, st>>>(image, blurred, n, very_bright, acc);
+    k_flood_init<<<1, 64, 0, st>>>(acc, counts, order_stats, gamma, very_bright);
+    k_flood_minmax<<<(unsigned)blocks, 256, 0, st>>>(image, blurred, n, acc);
     if (int err = shg::check_launch("k_flood_minmax")) return err;
-    k_flood_hist<<<(unsigned)blocks, 256, 0, st>>>(blurred, n, very_bright, acc, stats, counts);
+    k_flood_hist<<<(unsigned)blocks, 256, 0, st>>>(blurred, n, acc, stats, counts);
     return shg::check_launch("k_flood_hist");
+}
+
+extern "C" int shg_flood_stats_f64(const double* image, const double* blurred, int64_t n, double very_bright, double* stats,
+                                   uint32_t* counts, void* workspace, shg_stream_t stream) {
+    return flood_stats(image, blurred, n, nullptr, 0.0, very_bright, stats, counts, workspace, stream, "shg_flood_stats_f64");
+}
+
+extern "C" int shg_flood_stats_lerp_f64(const double* image, const double* blurred, int64_t n, const double* order_stats, double gamma,
+                                        double* stats, uint32_t* counts, void* workspace, shg_stream_t stream) {
+    SHG_REQUIRE(order_stats, SHG_E_ARG, "shg_flood_stats_lerp_f64: null pointer");
+    SHG_REQUIRE(gamma >= 0.0 && gamma <= 1.0, SHG_E_ARG, "shg_flood_stats_lerp_f64: gamma %g outside [0, 1]", gamma);
+    return flood_stats(image, blurred, n, order_stats, gamma, 0.0, stats, counts, workspace, stream, "shg_flood_stats_lerp_f64");
 }
 
 extern "C" size_t shg_edge_components_workspace_bytes(int64_t h, int64_t w) {

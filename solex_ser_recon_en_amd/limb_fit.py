@@ -44,6 +44,12 @@ def lerp_order_stats(n, q):
     return lo, hi, combine
 
 
+def lerp_gamma(n, q):
+    """The interpolation weight lerp_order_stats' combine() uses."""
+    virtual = (n - 1) * np.true_divide(q, 100)
+    return virtual - math.floor(virtual)
+
+
 def median_order_stats(n):
     """np.median on n values: the middle order statistic, or the mean of the two middle ones."""
     if n % 2:
@@ -149,15 +155,16 @@ def edge_points(small, sigma=2):
         raise RuntimeError('ellipse fit: the scan needs at least 400 slit rows (cv2.blur kernel int(0.01 * h/4) = 0)')
     blurred = ops.box_blur_f64(small, k)
     m_lo, m_hi, median = median_order_stats(n)
-    p_lo, p_hi, p99 = lerp_order_stats(n, 99)
+    p_lo, p_hi, _ = lerp_order_stats(n, 99)
     blur5 = ops.box_blur_f64(small, 5)
-    sel = ops.select_multi_f64([blur5, blur5, blurred, blurred], [m_lo, m_hi, p_lo, p_hi]).cpu().numpy()
-    low = median(sel[0], sel[1]) / 10                   # low_threshold = median(blur 5x5) / 10 (:241-242)
+    sel_d = ops.select_multi_f64([blur5, blur5, blurred, blurred], [m_lo, m_hi, p_lo, p_hi])
+    # very_bright = np.percentile(img_blurred, 99) (:165) is interpolated on the device from its two order statistics, so
+    # the flood statistics follow without a host round trip; one read brings everything the host needs
+    stats, counts = ops.flood_stats_lerp(small, blurred, sel_d[2:4], lerp_gamma(n, 99))
+    packed = torch.cat([sel_d[:2], stats, counts.to(torch.float64)]).cpu().numpy()
+    low = median(packed[0], packed[1]) / 10             # low_threshold = median(blur 5x5) / 10 (:241-242)
     high = low * 1.5
-    very_bright = p99(sel[2], sel[3])                   # np.percentile(img_blurred, 99) (:165)
-    stats, counts = ops.flood_stats(small, blurred, very_bright)
-    packed = torch.cat([stats, counts.to(torch.float64)]).cpu().numpy()
-    thresh3 = flood_threshold(packed[0], (h, w), packed[1], packed[2], packed[3:].astype(np.int64))
+    thresh3 = flood_threshold(packed[2], (h, w), packed[3], packed[4], packed[5:].astype(np.int64))
     while True:
         if sigma <= 0:
             raise RuntimeError('ellipse fit: could not find any edges of the solar disk')

@@ -458,6 +458,25 @@ def flood_stats(image, blurred, very_bright):
     return stats, counts
 
 
+def flood_stats_lerp(image, blurred, order_stats, gamma):
+    """flood_stats with very_bright = lerp of two device-resident order statistics (np.percentile's last step):
+    the 99th percentile never travels to the host."""
+    _dev(image, 'image')
+    _dev(blurred, 'blurred')
+    _dev(order_stats, 'order_stats')
+    if image.dtype != torch.float64 or blurred.dtype != torch.float64 or image.shape != blurred.shape:
+        raise TypeError('flood_stats needs two dense float64 images of one shape')
+    if order_stats.dtype != torch.float64 or order_stats.numel() != 2 or not order_stats.is_contiguous():
+        raise TypeError('order_stats must be two contiguous float64 values')
+    stats = torch.empty(3, dtype=torch.float64, device=image.device)
+    counts = torch.empty(20, dtype=torch.int32, device=image.device)
+    ws = torch.empty(4, dtype=torch.int64, device=image.device)
+    _lib.check(lib.shg_flood_stats_lerp_f64(image.contiguous().data_ptr(), blurred.contiguous().data_ptr(), image.numel(),
+                                            order_stats.data_ptr(), float(gamma), stats.data_ptr(), counts.data_ptr(), ws.data_ptr(),
+                                            _stream()), 'shg_flood_stats_lerp_f64')
+    return stats, counts
+
+
 def edge_components(low_mask, high_mask, prefetch=16384):
     """Hysteresis + labelling on the GPU.  -> (idx int32 [m], root int32 [m]) HOST arrays: the surviving edge
     pixels in raster order (idx = y*w + x) and the root (smallest linear index) of each pixel's component."""

@@ -325,6 +325,18 @@ def test_flood_stats_match_numpy(ops, golden):
     want, _ = np.histogram(data, bins=20)
     np.testing.assert_array_equal(host(counts), want)
     np.testing.assert_array_equal(host(stats), [np.sum(small), data.min(), data.max()])
+    # very_bright interpolated on the device from the two order statistics np.percentile uses (q = 99 and others)
+    from solex_ser_recon_en_amd.limb_fit import lerp_gamma, lerp_order_stats
+    srt = np.sort(blurred.ravel())
+    for q in (99, 50, 12.5, 99.9999, 0, 100):
+        lo, hi, mix = lerp_order_stats(srt.size, q)
+        vbq = np.percentile(blurred, q)
+        assert mix(srt[lo], srt[hi]) == vbq
+        s2, c2 = ops.flood_stats_lerp(dev(small), dev(blurred), dev(np.array([srt[lo], srt[hi]])), lerp_gamma(srt.size, q))
+        dq = blurred.ravel()[blurred.ravel() < vbq]
+        if dq.size:
+            np.testing.assert_array_equal(host(c2), np.histogram(dq, bins=20)[0])
+            np.testing.assert_array_equal(host(s2), [np.sum(small), dq.min(), dq.max()])
 
 
 @pytest.mark.parametrize('h,w', [(300, 330), (57, 1025), (1, 9), (260, 3)])
