@@ -628,3 +628,24 @@ def test_c_caller_runs_without_python_or_torch(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-500:])
     assert 'C ABI smoke OK' in r.stdout
+
+
+@pytest.mark.parametrize('levels', [1, 2, 3, 17])
+def test_rowpair_stats_with_heavily_tied_ratios(ops, orc, levels):
+    """Rows quantised to a few grey levels: the log-ratios repeat, so the radix select cannot stop early on a
+    singleton bin and the two middle order statistics often share every digit (median / MAD of tied data,
+    MAD = 0 -> every sample is an inlier, solex_util.py:81-86)."""
+    import math
+    rng = np.random.default_rng(levels)
+    h, w = 40, 300
+    img = (1000 + rng.integers(0, levels, (h, w)) * 7).astype(np.uint16)
+    circle, borders = (150.2, 19.6, 148.0), [2.0, 0, 297.0, 39]
+    y1, y2, want = orc.transversalium_row_stats(img, circle, borders)
+    xa = np.zeros(y2 - y1, np.int32)
+    xb = np.zeros(y2 - y1, np.int32)
+    for y in range(y1 + 1, y2):
+        dx = math.floor((circle[2] ** 2 - (y - circle[1]) ** 2) ** 0.5)
+        a, b, _ = slice(math.ceil(max(circle[0] - dx, borders[0])), math.floor(min(circle[0] + dx, borders[2]))).indices(w)
+        xa[y - y1], xb[y - y1] = a, max(a, b)
+    got = host(ops.rowpair_logratio_stats(dev(img), y1, y2, dev(xa), dev(xb)))
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-15)
