@@ -151,8 +151,9 @@ int shg_rowpair_logratio_stats(const uint16_t* img, int64_t h, int64_t w, int64_
 /* scipy.ndimage.correlate1d(src, weights, axis=-1, mode='constant', cval=0) for k rows of n float64
  * samples with 2*radius+1 float64 weights (device memory), in NI_Correlate1D's order of operations:
  * the interior of scipy.signal.savgol_filter(y_ratios_r, window, 3) (solex_util.py:400).  `symmetric`
- * non-zero selects SciPy's symmetric-filter form (pairs summed first, left half of the weights used),
- * which SciPy takes when |w[R+i] - w[R-i]| <= DBL_EPSILON for every i. */
+ * > 0 selects SciPy's symmetric-filter form (pairs summed first, left half of the weights used), which
+ * SciPy takes when |w[R+i] - w[R-i]| <= DBL_EPSILON for every i; < 0 its antisymmetric form (pairs
+ * subtracted; |w[R+i] + w[R-i]| <= DBL_EPSILON); 0 the general form. */
 int shg_correlate1d_rows_f64(const double* src, int64_t k, int64_t n, const double* weights, int radius,
                              int symmetric, double* dst, shg_stream_t stream);
 

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void k_scale_rows(const uint16_t* __restrict__
 // scipy.ndimage.correlate1d(rows, weights, axis=-1, mode='constant', cval=0) for k rows of n float64 samples, in
 // NI_Correlate1D's own order of operations (the interior of scipy.signal.savgol_filter, solex_util.py:400):
 //   symmetric weights : t = x[0]*w[0]; for j = -R..-1: t += (x[j] + x[-j]) * w[j]      (w indexed from the centre)
+//   antisymmetric     : t = x[0]*w[0]; for j = -R..-1: t += (x[j] - x[-j]) * w[j]
 //   otherwise         : t = x[R]*w[R]; for j = -R..R-1: t += x[j] * w[j]
 // One workgroup per (row, 256 output samples): the samples it needs (256 + 2R, zero beyond the row's ends) and the
 // weights are staged in LDS first, so the inner loop has no bounds test and no global load to wait for (with
@@ -227,9 +228,12 @@ __global__ __launch_bounds__(256) void k_correlate1d_rows(const double* __restri
     const double* c = xs + radius + threadIdx.x;         // this lane's sample
     const double* w = ws + radius;
     double t;
-    if (symmetric) {
+    if (symmetric > 0) {
         t = c[0] * w[0];
         for (int j = -radius; j < 0; ++j) t += (c[j] + c[-j]) * w[j];
+    } else if (symmetric < 0) {
+        t = c[0] * w[0];
+        for (int j = -radius; j < 0; ++j) t += (c[j] - c[-j]) * w[j];
     } else {
         t = c[radius] * w[radius];
         for (int j = -radius; j < radius; ++j) t += c[j] * w[j];
@@ -338,7 +342,7 @@ extern "C" int shg_correlate1d_rows_f64(const double* src, int64_t k, int64_t n,
     hipStream_t st = shg::as_stream(stream);
     const size_t lds = (size_t)(256 + 4 * radius + 1) * sizeof(double);
     SHG_PROF("correlate1d_rows", st);
-    k_correlate1d_rows<<<dim3((unsigned)((n + 255) / 256), (unsigned)k), 256, lds, st>>>(src, n, weights, radius, symmetric ? 1 : 0, dst);
+    k_correlate1d_rows<<<dim3((unsigned)((n + 255) / 256), (unsigned)k), 256, lds, st>>>(src, n, weights, radius, symmetric > 0 ? 1 : (symmetric < 0 ? -1 : 0), dst);
     return shg::check_launch("k_correlate1d_rows");
 }
 

@@ -230,7 +230,9 @@ def correlate1d_rows_f64(rows, weights):
     key = (str(rows.device), w.tobytes())
     if key not in _TAPS:
         r = w.size // 2
-        sym = all(abs(w[r + i] - w[r - i]) <= np.finfo(np.float64).eps for i in range(1, r + 1))     # NI_Correlate1D
+        eps = np.finfo(np.float64).eps                                                          # NI_Correlate1D's tests
+        sym = 1 if all(abs(w[r + i] - w[r - i]) <= eps for i in range(1, r + 1)) else (
+            -1 if all(abs(w[r + i] + w[r - i]) <= eps for i in range(1, r + 1)) else 0)
         if len(_TAPS) > 64:
             _TAPS.clear()
         _TAPS[key] = (torch.from_numpy(w).to(rows.device), r, int(sym))

@@ -597,6 +597,8 @@ def test_correlate1d_rows_is_scipys(ops, k, n, window):
     taps = savgol_coeffs(window, 3)
     got = host(ops.correlate1d_rows_f64(dev(rows), taps[::-1]))
     np.testing.assert_array_equal(got, convolve1d(rows, taps, axis=-1, mode='constant'))
+    anti = savgol_coeffs(window, 3, deriv=1) if window > 3 else np.array([-0.5, 0.0, 0.5, 0.25, -0.25])[:window]
+    np.testing.assert_array_equal(host(ops.correlate1d_rows_f64(dev(rows), anti)), correlate1d(rows, anti, axis=-1, mode='constant'))
     skew = rng.standard_normal(window)                                   # neither symmetric nor antisymmetric
     np.testing.assert_array_equal(host(ops.correlate1d_rows_f64(dev(rows), skew)), correlate1d(rows, skew, axis=-1, mode='constant'))
     if n > 20:
