@@ -492,3 +492,18 @@ def test_pathological_scans_fail_like_the_reference(pkg, name):
         outputs.flush()
         close_u16(results[0][0], want['results'][0]['cc'])
     assert (expected is None) == (name == 'half_scan')
+
+
+def test_cli_accepts_an_uncompressed_avi(pkg, tmp_path):
+    """The front door with an .avi argument (CLI_handler.py:123 lets SER and AVI through): same CLAHE product as the SER."""
+    SHG_MAIN, Solex_recon, outputs = pkg
+    from solex_ser_recon_en_amd import png_io
+    frames = synth.synth_frames_numpy(400, 400, 32, 8, seed=7, tilt=0.01, curv=5e-5)
+    ser, avi = str(tmp_path / 'a.ser'), str(tmp_path / 'b.avi')
+    synth.write_ser(ser, frames)
+    synth.write_avi(avi, frames, 'pal8')
+    assert SHG_MAIN.main(['-c', ser, avi]) == 0
+    a = png_io.read_png_gray(str(tmp_path / 'a_shift=0_clahe.png'))
+    b = png_io.read_png_gray(str(tmp_path / 'b_shift=0_clahe.png'))
+    assert a.dtype == np.uint16 and a.shape[0] == 400
+    np.testing.assert_array_equal(a, b)
