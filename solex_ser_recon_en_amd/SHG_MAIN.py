@@ -6,7 +6,6 @@ handling (handle_files :134-143: print the traceback, never re-raise).  The GUI,
 file and the language packs are out of scope.  Under `torchrun` (one process per GPU) a
 single file is frame-sharded over the ranks, several files are dealt one per rank.
 """
-import glob
 import os
 import sys
 import traceback
@@ -80,9 +79,14 @@ def handle_files(files, options, flag_command_line=False):
         return False
 
 
+def scans_in(folder):
+    """The SER / AVI scans of a folder, sorted (the reference's folder mode globs *.ser, SHG_MAIN.py:146-150)."""
+    return sorted(os.path.join(folder, f) for f in os.listdir(folder)
+                  if f.rsplit('.', 1)[-1].upper() in ('SER', 'AVI') and os.path.isfile(os.path.join(folder, f)))
+
+
 def handle_folder(options):
-    files = glob.glob(os.path.join(options['input_dir'], '*.ser')) + glob.glob(os.path.join(options['input_dir'], '*.SER'))
-    return handle_files(sorted(set(files)), options, True)
+    return handle_files(scans_in(options['input_dir']), options, True)
 
 
 def _init_distributed():
@@ -98,6 +102,9 @@ def _init_distributed():
 
 def main(argv=None):
     opts = default_options()
+    argv = sys.argv[1:] if argv is None else list(argv)
+    # a folder argument stands for the scans inside it (one file per GPU under torch.distributed)
+    argv = [f for a in argv for f in (scans_in(a) if not a.startswith('-') and os.path.isdir(a) else [a])]
     serfiles = CLI_handler.handle_CLI(opts, argv)
     if not serfiles:
         print(CLI_handler.usage())

@@ -354,3 +354,11 @@ def test_cubic_fit_coef_is_polynomial_fit_convert():
         np.testing.assert_array_equal(su._savgol_rows(y, win), savgol_filter(y, win, 3, axis=-1))
         y3 = rng.standard_normal((3, n)) * 0.01
         np.testing.assert_array_equal(su._savgol_rows(y3, win), np.stack([savgol_filter(r, win, 3) for r in y3]))
+
+
+def test_folder_argument_expands_to_its_scans(tmp_path):
+    from solex_ser_recon_en_amd import SHG_MAIN
+    for name in ('b.ser', 'a.SER', 'c.avi', 'notes.txt', 'd.png'):
+        (tmp_path / name).write_bytes(b'x')
+    (tmp_path / 'sub.ser').mkdir()
+    assert [os.path.basename(f) for f in SHG_MAIN.scans_in(str(tmp_path))] == ['a.SER', 'b.ser', 'c.avi']

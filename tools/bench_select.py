@@ -1,7 +1,7 @@
 import sys, os
 sys.path.insert(0, '.')
 import numpy as np, torch
-from solex_ser_recon_en_amd import ops, synth
+from solex_ser_recon_en_amd import ops
 from tools.bench_kernels import timeit
 h, w = 2000, 2100
 yy, xx = np.mgrid[0:h, 0:w]

@@ -1,4 +1,4 @@
-import cProfile, pstats, contextlib, io, os, sys, tempfile, time
+import cProfile, pstats, contextlib, io, os, sys, tempfile
 sys.path.insert(0, '.')
 from solex_ser_recon_en_amd import SHG_MAIN, outputs, synth
 tmp = tempfile.mkdtemp(dir='/dev/shm')
