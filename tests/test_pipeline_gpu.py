@@ -422,6 +422,10 @@ VARIANTS = {
     'noisy': dict(scene=dict(noise=0.012, depth=0.6), options={'crop_width_square': True}),
     'faint_8bit': dict(bits=8, scene=dict(gain=0.5, sky=0.04)),
     'tilted_line': dict(tilt=0.03, curv=-4e-5, options={'shift': [-3, 3]}),
+    'rotated_180': dict(options={'img_rotate': 180, 'delta_radius': 3}),
+    'rotated_270_no_disc': dict(options={'img_rotate': 270, 'disk_display': False, 'fixed_width': 380}),
+    'no_transversalium_flip': dict(options={'transversalium': False, 'flip_x': True, 'trans_strength': 51}),
+    'short_trend_window': dict(options={'trans_strength': 21, 'shift': [0, 10]}),
     # an active sun: two spots, a plage, a prominence off the limb, dust lines on the slit (transversalium)
     'active_sun_dusty_slit': dict(scene=dict(spots=[(150.0, 170.0, 9.0, 9.0, 0.7), (260.0, 240.0, 5.0, 6.0, 0.5),
                                                     (210.0, 120.0, 14.0, 10.0, -0.25), (372.0, 200.0, 6.0, 14.0, -4.0)]),
