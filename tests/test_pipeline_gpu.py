@@ -511,3 +511,30 @@ def test_cli_accepts_an_uncompressed_avi(pkg, tmp_path):
     b = png_io.read_png_gray(str(tmp_path / 'b_shift=0_clahe.png'))
     assert a.dtype == np.uint16 and a.shape[0] == 400
     np.testing.assert_array_equal(a, b)
+
+
+ALL_PNG = ['_shift=0_clahe.png', '_shift=0_protus.png', '_shift=0_uncontrasted.png', '_shift=0_high_contrast.png']
+PLOTS = ['_spectral_line_data.png', '_shift=10_ellipse_fit.png', '_shift=0_transversalium_correction.png']
+
+
+@pytest.mark.parametrize('extra,present,absent', [
+    ({'clahe_only': True}, ['_shift=0_clahe.png'], ALL_PNG[1:] + PLOTS),
+    ({'protus_only': True}, ['_shift=0_protus.png'], [ALL_PNG[0]] + ALL_PNG[2:] + PLOTS),
+    ({'clahe_only': True, 'protus_only': True}, ALL_PNG[:2], ALL_PNG[2:] + PLOTS),
+    ({'disk_display': False}, ALL_PNG + PLOTS, []),                      # the CLI's -p: products unchanged, no black disc
+])
+def test_product_selection_options(pkg, scan, tmp_path, extra, present, absent):
+    """clahe_only / protus_only choose the products as solex_util.py:556-566 and switch the diagnostics off (:263,
+    :482, ellipse_to_circle.py:316); the CLI's -p is disk_display (CLI_handler.py:17), not protus_only."""
+    SHG_MAIN, Solex_recon, outputs = pkg
+    g, frames, path = scan
+    work = str(tmp_path / 'scan.ser')
+    synth.write_ser(work, frames)
+    opts = SHG_MAIN.default_options()
+    opts.update(extra)
+    Solex_recon.solex_do_work([(work, opts)], True)
+    base = work[:-4]
+    for suffix in present + ['_log.txt']:
+        assert os.path.exists(base + suffix), 'missing ' + suffix
+    for suffix in absent:
+        assert not os.path.exists(base + suffix), 'unexpected ' + suffix
