@@ -538,3 +538,21 @@ def test_product_selection_options(pkg, scan, tmp_path, extra, present, absent):
         assert os.path.exists(base + suffix), 'missing ' + suffix
     for suffix in absent:
         assert not os.path.exists(base + suffix), 'unexpected ' + suffix
+
+
+def test_output_dir_redirects_every_file(pkg, scan, tmp_path):
+    """options['output_dir'] (solex_util.py:60-63): same file names, other folder; nothing is written next to the scan."""
+    SHG_MAIN, Solex_recon, outputs = pkg
+    g, frames, path = scan
+    src, dst = tmp_path / 'in', tmp_path / 'out'
+    src.mkdir()
+    dst.mkdir()
+    work = str(src / 'scan.ser')
+    synth.write_ser(work, frames)
+    opts = SHG_MAIN.default_options()
+    opts.update(output_dir=str(dst), clahe_only=True, save_fit=True)
+    Solex_recon.solex_do_work([(work, opts)], True)
+    assert sorted(os.listdir(str(src))) == ['scan.ser']
+    names = sorted(os.listdir(str(dst)))
+    for expected in ('scan_log.txt', 'scan_mean.fits', 'scan_shift=0_raw.fits', 'scan_shift=0_clahe.png', 'scan_shift=0_clahe.fits'):
+        assert expected in names, (expected, names)
