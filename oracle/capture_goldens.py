@@ -362,6 +362,10 @@ def g14_pipeline():
         ref_sr.solex_process(opts, disk_list, bounds, hdr)
         out[tag + '_shifts'] = np.array(opts['shift'])
         out[tag + '_bounds'] = np.array(bounds)
+        if tag in ('A', 'B'):                             # the text of <base>_log.txt, minus its two time stamps
+            lines = [ln for ln in open(os.path.join(tmp, 'scan_log.txt')).read().splitlines()
+                     if not ln.startswith(('start time', 'end time'))]
+            out[tag + '_log'] = np.array('\n'.join(lines))
         out[tag + '_geometry'] = np.array([np.nan if opts['ratio_fixe'] is None else opts['ratio_fixe'],
                                            np.nan if opts['slant_fix'] is None else opts['slant_fix']])
         out[tag + '_disk_sha256'] = np.stack([np.frombuffer(hashlib.sha256(np.ascontiguousarray(d).tobytes()).digest(), np.uint8)

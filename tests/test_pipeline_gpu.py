@@ -556,3 +556,21 @@ def test_output_dir_redirects_every_file(pkg, scan, tmp_path):
     names = sorted(os.listdir(str(dst)))
     for expected in ('scan_log.txt', 'scan_mean.fits', 'scan_shift=0_raw.fits', 'scan_shift=0_clahe.png', 'scan_shift=0_clahe.fits'):
         assert expected in names, (expected, names)
+
+
+@pytest.mark.parametrize('tag', ['A', 'B'])
+def test_log_file_text_matches_the_reference(pkg, scan, tmp_path, tag):
+    """<base>_log.txt line for line against the reference's own run (g14, shim mode), time stamps aside: same lines,
+    same order, same number formatting (NumPy's str of the fit / matrix / centre)."""
+    SHG_MAIN, Solex_recon, outputs = pkg
+    g, frames, path = scan
+    work = str(tmp_path / 'scan.ser')
+    synth.write_ser(work, frames)
+    opts = SHG_MAIN.default_options()
+    opts.update(SCENARIOS[tag])
+    Solex_recon.solex_do_work([(work, opts)], True)
+    text = open(work[:-4] + '_log.txt').read().splitlines()
+    assert text[0].startswith('start time: ') and text[-1].startswith('end time: ')
+    got = [ln for ln in text if not ln.startswith(('start time', 'end time'))]
+    want = str(g[tag + '_log']).splitlines()
+    assert got == want, '\n'.join(['--- got'] + got + ['--- want'] + want)
