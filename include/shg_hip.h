@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SHG_ABI_VERSION 9
+#define SHG_ABI_VERSION 10
 
 #define SHG_E_ARG        (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SHG_E_WORKSPACE  (-2)   /* workspace too small                                 */
@@ -290,6 +290,22 @@ size_t shg_edge_components_workspace_bytes(int64_t h, int64_t w);
 int shg_edge_components(const uint8_t* low_mask, const uint8_t* high_mask, int64_t h, int64_t w,
                         int32_t* out_idx, int32_t* out_root, int32_t* out_count,
                         void* workspace, size_t workspace_bytes, shg_stream_t stream);
+
+/* ---- image_process in two calls --------------------------------- solex_util.py:527-547
+ * shg_contrast_stats_u16: cl1 = CLAHE(frame, clip_limit, tiles), then the order statistics np.percentile and np.max
+ * need: out5[0..1] = frame's ranks_frame2[0..1]-th smallest pixels, out5[2..4] = cl1's ranks_cl13[0..2]-th (host
+ * rank arrays).  shg_contrast_products_u16: high_contrast = rescale(frame, lo_hi6[0], lo_hi6[1]), protus =
+ * rescale(frame, lo_hi6[2], lo_hi6[3]), cc = rescale(cl1, lo_hi6[4], lo_hi6[5]) (host doubles), then the filled disc
+ * of value 80 on protus when disc_r > 0 (:542-547).  Same kernels and order as the separate entry points. */
+size_t shg_contrast_stats_workspace_bytes(int tiles);
+int shg_contrast_stats_u16(const uint16_t* frame, int64_t h, int64_t w, int64_t pitch, double clip_limit,
+                           int tiles, uint16_t* cl1, int64_t cl1_pitch, const int64_t* ranks_frame2,
+                           const int64_t* ranks_cl13, double* out5, void* workspace, size_t workspace_bytes,
+                           shg_stream_t stream);
+int shg_contrast_products_u16(const uint16_t* frame, int64_t frame_pitch, const uint16_t* cl1, int64_t cl1_pitch,
+                              int64_t h, int64_t w, const double* lo_hi6, uint16_t* high_contrast,
+                              uint16_t* protus, uint16_t* cc, int64_t dst_pitch, int64_t disc_x0,
+                              int64_t disc_y0, int64_t disc_r, shg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,9 @@ SIGNATURES = {
     'shg_select_u16': (c_int, [P, c_int64, c_int64, c_int64, ctypes.POINTER(c_int64), c_int, P, P, c_size_t, P]),
     'shg_rescale_u16': (c_int, [P, c_int64, c_int64, c_int64, c_double, c_double, c_double, P, c_int64, P]),
     'shg_rescale_u8': (c_int, [P, c_int64, c_int64, c_int64, c_double, c_double, c_double, P, c_int64, P]),
+    'shg_contrast_stats_workspace_bytes': (c_size_t, [c_int]),
+    'shg_contrast_stats_u16': (c_int, [P, c_int64, c_int64, c_int64, c_double, c_int, P, c_int64, P, P, P, P, c_size_t, P]),
+    'shg_contrast_products_u16': (c_int, [P, c_int64, P, c_int64, c_int64, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_int64, P]),
     'shg_fill_disc_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_uint16, P, P]),
     'shg_downscale_mean_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int, P, P]),
     'shg_box_blur_f64': (c_int, [P, c_int64, c_int64, c_int, P, P, P]),
@@ -79,7 +82,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 if lib.shg_abi_version() != ABI_VERSION:
     raise ImportError('libshg_hip.so ABI %d != expected %d: rebuild it' % (lib.shg_abi_version(), ABI_VERSION))
 

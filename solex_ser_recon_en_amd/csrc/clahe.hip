@@ -568,3 +568,25 @@ extern "C" int shg_select_u16(const uint16_t* img, int64_t h, int64_t w, int64_t
     k_select16_final<<<(unsigned)n_ranks, 256, 0, st>>>(ranks, hist, out);
     return shg::check_launch("k_select16_final");
 }
+
+// ---- image_process in two calls (solex_util.py:527-547) -------------------------------------------------------------
+// The contrast stage is a dozen small launches around one host decision (three percentiles -> six rescale bounds).
+// Two composite entry points issue them from C instead of from a dozen ctypes calls: same kernels, same order.
+extern "C" size_t shg_contrast_stats_workspace_bytes(int tiles) {
+    const size_t c = shg_clahe_workspace_bytes(tiles, 2), s2 = shg_select_u16_workspace_bytes(2), s3 = shg_select_u16_workspace_bytes(3);
+    if (c == 0) return 0;
+    return ((c + 255) / 256 + (s2 + 255) / 256 + (s3 + 255) / 256) * 256;
+}
+
+extern "C" int shg_contrast_stats_u16(const uint16_t* frame, int64_t h, int64_t w, int64_t pitch, double clip_limit, int tiles,
+                                      uint16_t* cl1, int64_t cl1_pitch, const int64_t* ranks_frame2, const int64_t* ranks_cl13,
+                                      double* out5, void* workspace, size_t workspace_bytes, shg_stream_t stream) {
+    SHG_REQUIRE(frame && cl1 && ranks_frame2 && ranks_cl13 && out5 && workspace, SHG_E_ARG, "shg_contrast_stats_u16: null pointer");
+    const size_t c = (shg_clahe_workspace_bytes(tiles, 2) + 255) / 256 * 256, s2 = (shg_select_u16_workspace_bytes(2) + 255) / 256 * 256;
+    SHG_REQUIRE(c != 0 && workspace_bytes >= shg_contrast_stats_workspace_bytes(tiles), SHG_E_WORKSPACE,
+                "shg_contrast_stats_u16: workspace too small or bad tile count");
+    char* ws = static_cast<char*>(workspace);
+    if (int e = shg_clahe(frame, h, w, pitch, 2, clip_limit, tiles, cl1, cl1_pitch, ws, c, stream)) return e;
+    if (int e = shg_select_u16(frame, h, w, pitch, ranks_frame2, 2, out5, ws + c, s2, stream)) return e;
+    return shg_select_u16(cl1, h, w, cl1_pitch, ranks_cl13, 3, out5 + 2, ws + c + s2, shg_select_u16_workspace_bytes(3), stream);
+}

@@ -135,3 +135,15 @@ extern "C" int shg_downscale_mean_u16(const uint16_t* img, int64_t h, int64_t w,
     { SHG_PROF("downscale", shg::as_stream(stream)); k_downscale_mean<<<(unsigned)((oh * ow + 255) / 256), 256, 0, shg::as_stream(stream)>>>(img, h, w, pitch, factor, oh, ow, dst); }
     return shg::check_launch("k_downscale_mean");
 }
+
+// The three rescale_brightness calls of image_process and the protuberance disc (solex_util.py:539-547) in one call.
+extern "C" int shg_contrast_products_u16(const uint16_t* frame, int64_t frame_pitch, const uint16_t* cl1, int64_t cl1_pitch, int64_t h,
+                                         int64_t w, const double* lo_hi6, uint16_t* high_contrast, uint16_t* protus, uint16_t* cc,
+                                         int64_t dst_pitch, int64_t disc_x0, int64_t disc_y0, int64_t disc_r, shg_stream_t stream) {
+    SHG_REQUIRE(frame && cl1 && lo_hi6 && high_contrast && protus && cc, SHG_E_ARG, "shg_contrast_products_u16: null pointer");
+    if (int e = shg_rescale_u16(frame, h, w, frame_pitch, lo_hi6[0], lo_hi6[1], 1.0, high_contrast, dst_pitch, stream)) return e;
+    if (int e = shg_rescale_u16(frame, h, w, frame_pitch, lo_hi6[2], lo_hi6[3], 1.0, protus, dst_pitch, stream)) return e;
+    if (int e = shg_rescale_u16(cl1, h, w, cl1_pitch, lo_hi6[4], lo_hi6[5], 1.0, cc, dst_pitch, stream)) return e;
+    if (disc_r > 0) return shg_fill_disc_u16(protus, h, w, dst_pitch, disc_x0, disc_y0, disc_r, 80, nullptr, stream);
+    return 0;
+}

@@ -322,6 +322,40 @@ def clahe(img, clip_limit=0.8, tiles=2):
     return out
 
 
+def contrast_stats_u16(frame, ranks_frame, ranks_cl1, out5, clip_limit=0.8, tiles=2):
+    """cl1 = clahe(frame) plus the order statistics of frame (2 ranks) and cl1 (3 ranks) into out5 (float64 [5], GPU):
+    one C call for the first half of image_process.  -> cl1"""
+    import ctypes
+    ptr, h, w, pitch = _img(frame, 'frame', torch.uint16)
+    need = lib.shg_contrast_stats_workspace_bytes(int(tiles))
+    if need == 0:
+        raise ValueError('contrast_stats: unsupported tile count %r' % (tiles,))
+    ws = torch.empty(need, dtype=torch.uint8, device=frame.device)
+    cl1 = pitched_u16(h, w, frame.device)
+    rf = (ctypes.c_int64 * 2)(*[int(r) for r in ranks_frame])
+    rc = (ctypes.c_int64 * 3)(*[int(r) for r in ranks_cl1])
+    _lib.check(lib.shg_contrast_stats_u16(ptr, h, w, pitch, float(clip_limit), int(tiles), cl1.data_ptr(), cl1.stride(0), rf, rc,
+                                          out5.data_ptr(), ws.data_ptr(), need, _stream()), 'shg_contrast_stats_u16')
+    return cl1
+
+
+def contrast_products_u16(frame, cl1, lo_hi6, disc=None):
+    """-> (high_contrast, protus, cc): the three rescale_brightness calls of image_process and the protuberance disc
+    (disc = (x0, y0, r) or None) in one C call."""
+    import ctypes
+    ptr, h, w, pitch = _img(frame, 'frame', torch.uint16)
+    cptr, ch, cw, cpitch = _img(cl1, 'cl1', torch.uint16)
+    if (ch, cw) != (h, w):
+        raise ValueError('frame and cl1 must share one shape')
+    store = torch.empty((3, h, (w + 63) // 64 * 64), dtype=torch.uint16, device=frame.device)
+    hc, protus, cc = store[0, :, :w], store[1, :, :w], store[2, :, :w]
+    bounds = (ctypes.c_double * 6)(*[float(v) for v in lo_hi6])
+    x0, y0, r = (int(v) for v in disc) if disc is not None else (0, 0, 0)
+    _lib.check(lib.shg_contrast_products_u16(ptr, pitch, cptr, cpitch, h, w, bounds, hc.data_ptr(), protus.data_ptr(), cc.data_ptr(),
+                                             store.stride(1), x0, y0, r, _stream()), 'shg_contrast_products_u16')
+    return hc, protus, cc
+
+
 def histogram(img):
     """-> int32 tensor [65536] (uint16 images) or [256] (uint8)."""
     _dev(img, 'img')

@@ -527,12 +527,12 @@ def image_process_batch(frames, cercle, options, header, basefichs):
     stats = torch.empty((len(tensors), 5), dtype=torch.float64, device=tensors[0].device)
     cl1s = []
     for i, frame_t in enumerate(tensors):
-        cl1 = ops.clahe(frame_t, 0.8, 2)
         n_px = frame_t.shape[0] * frame_t.shape[1]
         b_lo, b_hi, b_mix = lerp_order_stats(n_px, 99.9999)
         d_lo, d_hi, d_mix = lerp_order_stats(n_px, 10)
-        ops.select_u16(frame_t, [b_lo, b_hi], out=stats[i, 0:2])        # np.percentile needs two order statistics
-        ops.select_u16(cl1, [d_lo, d_hi, n_px - 1], out=stats[i, 2:5])  # ... and np.max is the last one
+        # CLAHE, then the two order statistics np.percentile(frame, 99.9999) needs and, on the CLAHE image, those of
+        # np.percentile(cl1, 10) and np.max (the last one): one C call
+        cl1 = ops.contrast_stats_u16(frame_t, [b_lo, b_hi], [d_lo, d_hi, n_px - 1], stats[i])
         cl1s.append((cl1, b_mix, d_mix))
     stats = stats.cpu().numpy()
     results = []
@@ -543,15 +543,15 @@ def image_process_batch(frames, cercle, options, header, basefichs):
         bright_clahe = int(stats[i, 4])
         frame_raw = frame_t
         assert 65535 >= bright > bright * 0.25 and 65535 >= bright * 0.18 > 0 and 65535 >= bright_clahe > dark_clahe
-        frame_HC = ops.rescale_u16(frame_t, bright * 0.25, bright)
-        frame_protus = ops.rescale_u16(frame_t, 0, bright * 0.18)
-        cc = ops.rescale_u16(cl1, dark_clahe, bright_clahe)
+        disc = None
         if not cercle == (-1, -1, -1) and options['disk_display']:
-            x0 = int(cercle[0])
-            y0 = int(cercle[1])
             r = int(cercle[2]) + options['delta_radius']
             if r > 0:
-                ops.fill_disc_u16(frame_protus, x0, y0, r, 80)
+                disc = (int(cercle[0]), int(cercle[1]), r)
+        # frame_HC = rescale(frame, .25 bright, bright); frame_protus = rescale(frame, 0, .18 bright) + cv2.circle(80);
+        # cc = rescale(cl1, dark_clahe, bright_clahe) (:539-547): one C call
+        frame_HC, frame_protus, cc = ops.contrast_products_u16(
+            frame_t, cl1, [bright * 0.25, bright, 0, bright * 0.18, dark_clahe, bright_clahe], disc)
 
         k = options['img_rotate'] // 90
         frame_raw, frame_HC, frame_protus, cc = (_rot90(x, k) for x in (frame_raw, frame_HC, frame_protus, cc))
