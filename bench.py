@@ -1,25 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py -- SER frames/s of the whole SHG hot path (frame stack resident in HBM -> CLAHE /
-contrast products in HBM), plus the HBM-roofline figure of the dominant kernel and a CPU
-baseline (the NumPy oracle of the same path on the host cores).
+"""bench.py -- SER frames/s of the SHG hot path on MI355X, with the HBM-roofline figure of the dominant
+kernel, a decode-inclusive figure and a CPU baseline, as ONE JSON line on stdout (rank 0).
 
     python bench.py --gpus 1 --steps 50 --warmup 5      # the defaults
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one synthetic scan:
-  sum/max over frames -> line detect + cubic fit -> column extraction (raw disks, S = 2:
-  the ellipse-fit shift 10 and the requested shift 0) -> limb ellipse fit -> ellipse->circle
-  warp -> transversalium -> CLAHE + contrast products.  No file is read or written inside
-  the timed region (inputs are resident in HBM; the PNG/FITS encoders are off the path).
+One "step" = one pass of the hot path over one synthetic scan whose frame stack is resident in HBM:
+  sum/max over frames -> line detect + cubic fit -> column extraction (raw disks, S = 2: the ellipse-fit
+  shift 10 and the requested shift 0) -> limb ellipse fit -> ellipse->circle warp -> transversalium ->
+  CLAHE + contrast products (left in HBM).  The K timed steps are K independent scans handed to
+  solex_do_work in one call, the way a folder of files is: the reference overlaps the post-processing of up to
+  four files (Pool(4), Solex_recon.py:30-42), here `--workers` scan threads (default 4) each drive their own HIP
+  stream, so one file's host control plane overlaps the others' kernels.  No file is read or written inside
+  that timed region; `value` is frames / wall time of the K steps (max over ranks).
 
-N = 1: BASELINE.json configs[1] -- 2000 frames of 2000x200 16-bit, single H-alpha shift,
-transversalium + ellipse fit on.  N > 1, default --mode folder (configs[4]'s layout, the reference's own
-batch parallelism: SHG_MAIN.handle_folder + Pool over files): one such scan per rank, the files are
-independent, so there is no data-path collective (weak scaling).  --mode sharded (configs[2]'s layout):
-ONE scan of N x 2000 frames whose frames are sharded over the ranks -- RCCL all-reduce of the integer
-sum/max frames, all-gather of the disk columns, mosaic post-processed on rank 0; its serial per-file tail
-(limb fit, one requested disk) does not shard, see DESIGN.md section 6.
+Beside `value` the line carries:
+  roofline      pass A (k_accumulate_vec), algorithmic bytes / average launch duration from HIP events recorded on
+                the launch streams during the timed region; `uncontended` repeats it from a serial pass (one scan
+                at a time, nothing else on the device), which is the figure rocprofv3 of `--workers 1` agrees with
+  kernel_ms_per_step / gpu_busy_frac   sum of the event-bracketed durations of every library entry point of one scan
+                (serial pass) and its ratio to the timed wall clock per step
+  e2e           the same scans read from a SER file in /dev/shm: file -> pinned host -> HBM -> products, frames/s
+                and achieved host->device GB/s (PCIe-inclusive; never the headline `value`)
+  sharded_c3    BASELINE configs[2]: ONE 4000-frame 2000x200 scan, frames sharded over the ranks, decode-inclusive
+                (each rank reads its own byte range of the file), RCCL all-reduce of the integer sum / max frames and
+                all-gather of the disk columns; strong scaling
+  cpu_baseline  the NumPy oracle of the same path on this box's host cores (rank 0, N = 1 only)
+
+N = 1: BASELINE.json configs[1] (2000 frames of 2000x200 16-bit, single H-alpha shift, transversalium + ellipse
+fit on).  N > 1: the headline is folder mode (configs[4]'s layout, the reference's own batch parallelism,
+SHG_MAIN.handle_folder + Pool over files): K such scans per rank, no data-path collective, weak scaling;
+`--mode sharded` makes the HBM-resident sharded scan the headline instead (strong scaling).
 """
 import argparse
 import contextlib
@@ -34,6 +46,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290
+REFERENCE_CPU_FPS = 310.0      # the reference's own two frame loops on a C2 file, 1 core, read from disk
 
 
 def parse():
@@ -46,7 +59,11 @@ def parse():
     ap.add_argument('--height', type=int, default=200)
     ap.add_argument('--bits', type=int, default=16)
     ap.add_argument('--mode', choices=['folder', 'sharded'], default='folder')
+    ap.add_argument('--workers', type=int, default=0, help='scans in flight per process (0 = SHG_WORKERS or 4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-e2e', action='store_true', help='skip the decode-inclusive legs (e2e, sharded_c3)')
+    ap.add_argument('--e2e-files', type=int, default=8)
+    ap.add_argument('--c3-scans', type=int, default=4)
     ap.add_argument('--cpu-frames', type=int, default=0, help='frames of the CPU-baseline sample (0 = the whole scan)')
     ap.add_argument('--stages', action='store_true', help='print a per-stage wall-clock table to stderr')
     ap.add_argument('--shifts', default='0', help="requested pixel shifts, CLI syntax of -w: '0', 'a,b,c' or 'x:y:w' (C4 = -10:10:1)")
@@ -55,6 +72,10 @@ def parse():
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def scratch_dir():
+    return '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else '/tmp'
 
 
 def main():
@@ -80,12 +101,14 @@ def main():
             td.init_process_group(backend)
 
     from solex_ser_recon_en_amd import SHG_MAIN, Solex_recon, _lib, synth, timing
+    from solex_ser_recon_en_amd import ops as _ops
+    from solex_ser_recon_en_amd.CLI_handler import parse_shift
     from solex_ser_recon_en_amd.video_reader import array_reader
 
-    from solex_ser_recon_en_amd.CLI_handler import parse_shift
     requested_shifts = parse_shift(args.shifts)
     n_disks = len(dict.fromkeys([10, 0] + requested_shifts))
     sharded = world > 1 and args.mode == 'sharded'
+    workers = args.workers or Solex_recon._worker_count(None, 1 << 30)
     n_local = args.frames
     n_scan = n_local * world if sharded else n_local
     k0 = rank * n_local if sharded else 0
@@ -95,30 +118,35 @@ def main():
     torch.cuda.synchronize()
     log('[rank %d] synthetic stack %s %s built in %.1f s' % (rank, tuple(stack.shape), stack.dtype, time.time() - t0))
 
-    def step():
+    def options():
         opts = SHG_MAIN.default_options()
         opts['_nolog'] = True
         opts['shift'] = list(requested_shifts)
-        rdr = array_reader(stack, frame_count=n_scan, frame_range=(k0, k0 + n_local) if sharded else None)
+        return opts
+
+    def run_scans(n, n_workers, results=False):
+        """n scans of the resident stack through the production entry point.  sharded: collectives per scan (and the
+        disks of a Doppler stack dealt to the ranks), one scan at a time; otherwise the scans are independent files."""
+        tasks = [(array_reader(stack, frame_count=n_scan, frame_range=(k0, k0 + n_local) if sharded else None), options())
+                 for _ in range(n)]
         with contextlib.redirect_stdout(io.StringIO()):
-            # the production entry point: sharded = collectives per scan (and the disks of a Doppler stack dealt to
-            # the ranks); folder = every rank processes its own scan
-            return Solex_recon.solex_do_work([(rdr, opts)], True, distribute='frames' if sharded else 'none',
-                                             return_results=True)
+            if sharded:
+                out = [Solex_recon.solex_do_work([t], True, distribute='frames', return_results=results) for t in tasks]
+                return [o[0] for o in out if o] if results else None
+            return Solex_recon.solex_do_work(tasks, True, distribute='none', return_results=results, workers=n_workers)
 
     def barrier():
         if world > 1:
             td.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    if args.warmup > 0:
+        run_scans(args.warmup, workers)
     _lib.profile_reset()
     _lib.profile_enable(True, only=('accumulate', 'extract'))
     barrier()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    run_scans(args.steps, workers)
     barrier()
     elapsed = time.perf_counter() - t_start
     _lib.profile_enable(False)
@@ -133,66 +161,101 @@ def main():
     ih, iw = max(args.width, args.height), min(args.width, args.height)
     bpp = args.bits // 8
     bytes_a = n_local * ih * iw * bpp                                   # algorithmic: every sample read once
-    n_shifts = n_disks
     distinct = sorted(set(s + d for s in dict.fromkeys([10, 0] + requested_shifts) for d in (0, 1)))
     u = len(distinct)                                                   # distinct samples per row (4 for S=2: c, c+1, c+10, c+11)
-    bytes_b = n_local * ih * (u * bpp + 2 * n_shifts)
+    bytes_b = n_local * ih * (u * bpp + 2 * n_disks)
     ach = bytes_a / (acc_ms / acc_n * 1e-3) / 1e9 if acc_n else 0.0
-    traffic = None
+
+    # serial pass: one scan at a time, every entry point bracketed by events -> uncontended kernel durations
+    serial_steps = max(3, min(10, args.steps))
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    barrier()
+    t_serial = time.perf_counter()
+    out = run_scans(serial_steps, 1, results=True)
+    torch.cuda.synchronize()
+    t_serial = time.perf_counter() - t_serial
+    _lib.profile_enable(False)
+    acc1_ms, acc1_n = _lib.profile_get('accumulate')
+    ext1_ms, ext1_n = _lib.profile_get('extract')
+    all_ms, all_n = _lib.profile_total()
+    _lib.profile_reset()
+    kernel_ms_per_step = all_ms / serial_steps
+    ach1 = bytes_a / (acc1_ms / acc1_n * 1e-3) / 1e9 if acc1_n else 0.0
+
+    traffic, traffic_from = None, None
     tpath = os.path.join(REPO, 'profiles', 'traffic.json')
     if os.path.exists(tpath):
         try:
             rec = json.load(open(tpath)).get('%dx%dx%dx%d' % (n_local, args.width, args.height, args.bits))
-            traffic = rec['accumulate_bytes_per_launch'] if rec else None
+            if rec:
+                traffic = rec['accumulate_bytes_per_launch']
+                traffic_from = 'profiles/traffic.json: %s' % rec.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run '
+                                                                    '(PMC counters cannot be read from inside the process)')
         except Exception:      # noqa: BLE001
             traffic = None
-    from solex_ser_recon_en_amd import ops as _ops
     pitch_bytes = _ops.frame_stride(stack) * bpp
     flat = torch.as_strided(stack, (stack.shape[0] * pitch_bytes // bpp,), (1,)) if stack.shape[0] > 1 else stack.reshape(-1)
     ceiling, ceiling_shape = _ops.stream_read_ceiling(flat)
     walk, walk_shape = _ops.stream_read_ceiling(flat, mode=2, vecs_per_frame=pitch_bytes // 16) if pitch_bytes % 16 == 0 else (0.0, None)
     roofline = {'kernel': 'k_accumulate_vec (pass A: sum+max over frames)', 'bound': 'hbm',
                 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                'traffic': traffic, 'algorithmic_bytes_per_launch': bytes_a, 'frame_pitch_bytes': pitch_bytes,
-                'measured_read_ceiling': {'value': round(ceiling, 1), 'unit': 'GB/s', 'frac_of_it': round(ach / ceiling, 4) if ceiling else None,
+                'traffic': traffic, 'traffic_from': traffic_from,
+                'algorithmic_bytes_per_launch': bytes_a, 'frame_pitch_bytes': pitch_bytes,
+                'avg_launch_ms': round(acc_ms / acc_n, 5) if acc_n else None, 'launches': acc_n,
+                'how': 'HIP events on the launch streams over the timed region; with %d scans in flight the launch shares the '
+                       'device with the other scans\' kernels' % workers,
+                'uncontended': {'achieved': round(ach1, 1), 'frac': round(ach1 / HBM_PEAK_GBS, 4),
+                                'avg_launch_ms': round(acc1_ms / acc1_n, 5) if acc1_n else None, 'launches': acc1_n,
+                                'how': 'serial pass after the timed region: one scan at a time, same events'},
+                'measured_read_ceiling': {'value': round(ceiling, 1), 'unit': 'GB/s', 'frac_of_it': round(ach1 / ceiling, 4) if ceiling else None,
                                           'how': 'best of %d launch shapes of a trivial read-only kernel (shg_stream_read_probe) over the same stack, '
-                                                 'blocks x unroll = %s' % (8, ceiling_shape)},
-                'frame_walk_ceiling': {'value': round(walk, 1), 'unit': 'GB/s', 'frac_of_it': round(ach / walk, 4) if walk else None,
+                                                 'blocks x unroll = %s; frac_of_it is of the uncontended figure' % (8, ceiling_shape)},
+                'frame_walk_ceiling': {'value': round(walk, 1), 'unit': 'GB/s', 'frac_of_it': round(ach1 / walk, 4) if walk else None,
                                        'how': 'the same XOR-only kernel with pass A\'s addresses (a lane walks the frame axis), best of 8 '
                                               '(splits x unroll) = %s' % (walk_shape,)},
-                'avg_launch_ms': round(acc_ms / acc_n, 5) if acc_n else None, 'launches': acc_n,
                 'secondary': {'kernel': 'k_extract (pass B)', 'algorithmic_bytes_per_launch': bytes_b,
                               'avg_launch_ms': round(ext_ms / ext_n, 5) if ext_n else None,
-                              'achieved': round(bytes_b / (ext_ms / ext_n * 1e-3) / 1e9, 1) if ext_n else None}}
+                              'achieved': round(bytes_b / (ext_ms / ext_n * 1e-3) / 1e9, 1) if ext_n else None,
+                              'uncontended_avg_launch_ms': round(ext1_ms / ext1_n, 5) if ext1_n else None,
+                              'uncontended_achieved': round(bytes_b / (ext1_ms / ext1_n * 1e-3) / 1e9, 1) if ext1_n else None}}
 
     if args.stages and rank == 0:
         timing.enabled = True
         timing.reset()
-        for _ in range(3):
-            step()
+        run_scans(3, 1)
         timing.enabled = False
         log('per-stage host wall clock (ms / step, each stage fenced by a device sync):')
         for k, v in timing.totals.items():
             log('  %-28s %8.3f' % (k, v / 3 * 1e3))
+
+    # ---- decode-inclusive legs: SER files in /dev/shm -> pinned host -> HBM -> products ---------------
+    e2e, c3 = None, None
+    if not args.no_e2e and not sharded:
+        e2e = e2e_leg(args, world, rank, stack, n_local, options, workers)
+        c3 = sharded_c3_leg(args, world, rank, options, backend)
 
     # ---- CPU baseline: the NumPy oracle of the same path on this box's host cores -------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the CPU baseline is an N=1 figure
         from oracle import pipeline_oracle as po
         n_cpu = args.cpu_frames or n_local
-        if sharded:
-            n_cpu = min(n_cpu, n_local)
         sample = _ops.stack_to_host(stack[:n_cpu])
         t0 = time.perf_counter()
         with contextlib.redirect_stdout(io.StringIO()), np.errstate(all='ignore'):
             ref = po.run(sample, {'shift': list(requested_shifts)})
         t_cpu = time.perf_counter() - t0
         cpu = {'value': round(n_cpu / t_cpu, 1), 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
-               'sample': 'the first %d frames of rank 0\'s stack through the whole path (oracle/pipeline_oracle.py, '
-                         'NumPy, single thread like the reference\'s frame loops), %.1f s' % (n_cpu, t_cpu),
-               'host_cpus': os.cpu_count()}
-        if out and not sharded and n_cpu == n_local and requested_shifts == [0]:
-            cc = np.asarray(out[0][0][0])
+               'sample': 'the first %d frames of rank 0\'s stack through the whole path (oracle/pipeline_oracle.py, NumPy, single '
+                         'thread like the reference\'s frame loops), array already in memory, %.1f s' % (n_cpu, t_cpu),
+               'host_cpus': os.cpu_count(),
+               'reference_measured': {'value': REFERENCE_CPU_FPS, 'unit': 'frames/s', 'cores': 1,
+                                      'what': 'the reference\'s own compute_mean_max + read_video_improved on a C2 file, which it reads '
+                                              'from disk twice, 25 frames at a time (SURVEY.md section 6, measured in the build container, '
+                                              'not on this box: the reference cannot travel); the oracle works on an in-memory array, hence '
+                                              'its ~5x higher figure'}}
+        if out and n_cpu == n_local and requested_shifts == [0]:
+            cc = np.asarray(out[-1][0][0])
             want = ref['results'][0]['cc']
             d = np.abs(cc.astype(np.int64) - want.astype(np.int64)) if cc.shape == want.shape else None
             cpu['parity_vs_gpu'] = 'shape mismatch' if d is None else 'max |diff| %d LSB, %d of %d px differ' % (
@@ -200,24 +263,127 @@ def main():
 
     if rank == 0:
         total_frames = n_scan * args.steps if sharded else n_local * world * args.steps
+        ms_per_step = elapsed / args.steps * 1e3
         line = {
-            'metric': 'SER frames/sec end-to-end (decode->clahe), stack resident in HBM',
+            'metric': 'SER frames/sec through the hot path (mean/max -> line fit -> extraction -> limb fit -> warp -> transversalium '
+                      '-> CLAHE), frame stack resident in HBM; decode-inclusive rates in e2e / sharded_c3',
             'value': round(total_frames / elapsed, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u16' if bpp == 2 else 'u8', 'data': 'synthetic',
+            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
+            'scaling': 'strong' if sharded else 'weak', 'vs_baseline': None, 'dtype': 'u16' if bpp == 2 else 'u8', 'data': 'synthetic',
             'config': {'workload': '%d-frame %d-bit SER, %dx%d frames, %s (S=%d disks), '
                                    'transversalium+ellipse on%s' % (
                                        n_scan, args.bits, args.width, args.height,
                                        'single H-alpha shift' if requested_shifts == [0] else 'shifts -w %s' % args.shifts, n_disks,
                                        '' if world == 1 else (', frames sharded over %d GPUs (RCCL all-reduce + all-gather)' % world
-                                                              if sharded else ', folder mode: one scan per GPU, no collective')),
-                       'frames_per_gpu': n_local, 'mode': 'single' if world == 1 else args.mode},
-            'roofline': roofline, 'cpu_baseline': cpu,
+                                                              if sharded else ', folder mode: %d scans per GPU, no collective' % args.steps)),
+                       'frames_per_gpu': n_local, 'mode': 'single' if world == 1 else args.mode,
+                       'scans_in_flight_per_process': 1 if sharded else min(workers, args.steps),
+                       'backend': backend if world > 1 else None, 'world_size': world,
+                       'collectives_per_scan': 3 if sharded else 0},
+            'kernel_ms_per_step': round(kernel_ms_per_step, 4),
+            'gpu_busy_frac': round(kernel_ms_per_step / ms_per_step, 4),
+            'kernel_time_how': 'sum of the HIP-event-bracketed durations of all %d library entry points of one scan, serial pass '
+                               '(%.3f ms wall per scan there); gpu_busy_frac = that / ms_per_step' % (
+                                   all_n // serial_steps, t_serial / serial_steps * 1e3),
+            'roofline': roofline, 'cpu_baseline': cpu, 'e2e': e2e, 'sharded_c3': c3,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
         td.barrier()
         td.destroy_process_group()
+
+
+def _write_scan(path, n, width, height, bits, rank, world):
+    """Rank 0 writes the synthetic SER file (generated on its GPU), everyone waits for it."""
+    import torch
+    import torch.distributed as td
+    from solex_ser_recon_en_amd import ops, synth
+    if rank == 0:
+        frames = synth.synth_frames_torch(n, width, height, bits, seed=0)
+        host = ops.stack_to_host(frames)
+        del frames
+        synth.write_ser(path, host)
+        del host
+    if world > 1:
+        td.barrier()
+
+
+def e2e_leg(args, world, rank, stack, n_local, options, workers):
+    """Folder of identical C2 files in /dev/shm through solex_do_work: decode (8 reader threads, pinned buffers, async
+    2-D hipMemcpy) of file k+1.. overlaps the scans in flight."""
+    import torch
+    import torch.distributed as td
+    from solex_ser_recon_en_amd import Solex_recon, ops, synth
+    path = os.path.join(scratch_dir(), 'shg_bench_e2e_%d.ser' % rank)
+    try:
+        synth.write_ser(path, ops.stack_to_host(stack))
+        size = os.path.getsize(path)
+        n_files = max(2, args.e2e_files)
+
+        def go(n):
+            with contextlib.redirect_stdout(io.StringIO()):
+                Solex_recon.solex_do_work([(path, options()) for _ in range(n)], True, distribute='none', workers=workers)
+            torch.cuda.synchronize()
+        go(2)
+        if world > 1:
+            td.barrier()
+        t0 = time.perf_counter()
+        go(n_files)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            dt = float(t.item())
+        return {'value': round(n_local * n_files * world / dt, 1), 'unit': 'frames/s', 'ms_per_file': round(dt / n_files * 1e3, 2),
+                'files_per_gpu': n_files, 'file_bytes': size, 'host_to_device_GBps_per_gpu': round(size * n_files / dt / 1e9, 2),
+                'pcie_peak_GBps': 63.0,
+                'what': 'SER file in %s -> pread into pinned host buffers -> asynchronous hipMemcpy2D -> the same hot path, products '
+                        'left in HBM (no PNG / FITS encode); decode of the next files overlaps the scans in flight' % scratch_dir()}
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
+
+
+def sharded_c3_leg(args, world, rank, options, backend):
+    """BASELINE configs[2]: one 4000-frame 2000x200 16-bit scan, frames sharded over the ranks, decode-inclusive."""
+    import torch
+    import torch.distributed as td
+    from solex_ser_recon_en_amd import Solex_recon, dist
+    n, w, h = 4000, 2000, 200
+    path = os.path.join(scratch_dir(), 'shg_bench_c3.ser')
+    try:
+        _write_scan(path, n, w, h, 16, rank, world)
+
+        def go(k):
+            for _ in range(k):
+                with contextlib.redirect_stdout(io.StringIO()):
+                    Solex_recon.solex_do_work([(path, options())], True, distribute='frames' if world > 1 else 'none')
+            torch.cuda.synchronize()
+        go(1)
+        if world > 1:
+            td.barrier()
+        t0 = time.perf_counter()
+        go(args.c3_scans)
+        if world > 1:
+            td.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            dt = float(t.item())
+        return {'value': round(n * args.c3_scans / dt, 1), 'unit': 'frames/s', 'ms_per_scan': round(dt / args.c3_scans * 1e3, 2),
+                'scans': args.c3_scans, 'scaling': 'strong', 'world_size': world, 'backend': backend if world > 1 else None,
+                'collectives_per_scan': 3 if world > 1 else 0,
+                'collectives': 'all_reduce SUM (int64 sum frame), all_reduce MAX (max frame), all_gather (disk column blocks)' if world > 1 else None,
+                'frames_per_rank': dist.frame_block(n, rank, world)[1] - dist.frame_block(n, rank, world)[0],
+                'what': 'one %d-frame %dx%d 16-bit SER in %s, every rank decodes its own frame block (file -> pinned -> HBM), all-reduce '
+                        'after pass A, all-gather after pass B, mosaic post-processed on rank 0; scans run one after the other' % (
+                            n, w, h, scratch_dir())}
+    finally:
+        if world > 1:
+            td.barrier()
+        if rank == 0 and os.path.exists(path):
+            os.remove(path)
 
 
 if __name__ == '__main__':

@@ -30,11 +30,17 @@
 extern "C" {
 #endif
 
-#define SHG_ABI_VERSION 10
+#define SHG_ABI_VERSION 11
 
 #define SHG_E_ARG        (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SHG_E_WORKSPACE  (-2)   /* workspace too small                                 */
 #define SHG_E_UNSUPPORTED (-3)  /* size outside what the kernel supports               */
+/* host control plane: the failure the reference's NumPy / SciPy call would raise at that point */
+#define SHG_E_VALUE      (-4)   /* ValueError                                          */
+#define SHG_E_TYPE       (-5)   /* TypeError                                           */
+#define SHG_E_LINALG     (-6)   /* numpy.linalg.LinAlgError                            */
+#define SHG_E_RUNTIME    (-7)   /* RuntimeError                                        */
+#define SHG_E_QHULL      (-8)   /* scipy.spatial.QhullError                            */
 
 typedef void* shg_stream_t;
 
@@ -49,6 +55,7 @@ int shg_profile_enable(int on);
 int shg_profile_select(const char* tags_csv);   /* only time these tags (NULL or "" = all) */
 int shg_profile_reset(void);
 int shg_profile_get(const char* tag, double* total_ms, int64_t* launches);
+int shg_profile_total(double* total_ms, int64_t* launches);   /* every timed entry point since the last reset */
 
 /* Measurement aid: trivial read-only kernels over `bytes` bytes (16 B/lane non-temporal loads, XOR-folded;
  * out1024: 1024 uint32 words) that bench.py times to quote MEASURED read ceilings beside the spec peak
@@ -306,6 +313,62 @@ int shg_contrast_products_u16(const uint16_t* frame, int64_t frame_pitch, const 
                               int64_t h, int64_t w, const double* lo_hi6, uint16_t* high_contrast,
                               uint16_t* protus, uint16_t* cc, int64_t dst_pitch, int64_t disc_x0,
                               int64_t disc_y0, int64_t disc_r, shg_stream_t stream);
+
+/* ==== host control plane =======================================================================
+ * The 1-D / scalar arithmetic between the kernels, restated from the reference's NumPy / SciPy calls so
+ * that a pipeline stage is one call that holds no interpreter lock (several scans in flight per process).
+ * Every pointer here is a HOST pointer; no GPU is needed.  The line fit follows NumPy operation by
+ * operation and solves its least-squares systems with the very LAPACK routine NumPy loaded
+ * (shg_host_bind_lapack: address of the ILP64 Fortran dgelsd, scipy_dgelsd_64_ in NumPy 2.x wheels), so
+ * `fit` -- and with it the raw disks -- is bit-identical to the reference's on the same host. */
+int shg_host_bind_lapack(void* dgelsd_ilp64);          /* NULL: fall back to a built-in Householder QR */
+int shg_host_lapack_bound(void);
+/* The mode of the rounded line residuals is `values[np.argpartition(-counts, kth=2)[:2][0]]` (solex_util.py:245-247):
+ * one of the two most frequent values, which one being up to NumPy's selection kernel on this CPU.  A binding that
+ * wants NumPy's very choice registers a picker (called with -counts, returns the index); NULL = the first most
+ * frequent value (the scalar introselect's answer). */
+typedef int64_t (*shg_mode_pick_fn)(const int64_t* neg_counts, int64_t n);
+int shg_host_set_mode_pick(shg_mode_pick_fn pick);
+/* np.polyfit(x, y, 3): coefficients, highest power first (solex_util.py:233, 238, 255; scipy _fit_edge) */
+int shg_host_polyfit3(const double* host_x, const double* host_y, int64_t n, double* host_coef4);
+/* detect_bord's decision on the row means of the blurred image (solex_util.py:167-172) */
+int shg_host_detect_bord(const double* host_row_means, int64_t n, int64_t* lb, int64_t* ub);
+/* compute_mean_return_fit from the two argmin traces on (solex_util.py:231-259): trace_blur relative to column
+ * blur_offset (= 12), rows [y1, y2) fitted; p4 lowest power first, fit[ih][4] = [floor(c), c - floor(c), y, c],
+ * mask_good[y2 - y1] (may be NULL).  SHG_E_VALUE when fewer than 3 distinct residuals (:246), SHG_E_TYPE on an
+ * empty fit, SHG_E_LINALG when the SVD fails. */
+int shg_host_line_fit(const int32_t* host_trace_blur, const int32_t* host_trace_sharp, int64_t ih, int64_t y1,
+                      int64_t y2, int32_t blur_offset, double* host_p4, double* host_fit, uint8_t* host_mask_good);
+/* read_video_improved's per-shift sample columns and weights (solex_util.py:113-123) */
+int shg_host_column_plan(const double* host_fit, int64_t ih, int64_t iw, const int32_t* host_shifts, int n_shifts,
+                         int32_t* host_ind_l, double* host_lw, double* host_rw);
+/* get_flood_image's threshold from the reduced image statistics (ellipse_to_circle.py:159-225) */
+int shg_host_flood_threshold(double total, int64_t h, int64_t w, double mn, double mx, const int64_t* host_counts20,
+                             double* thresh_out);
+/* get_edge_list after canny (ellipse_to_circle.py:251-291): region choice, convex-hull filter, row crop on the
+ * labelled edge pixels (shg_edge_components' output); out_sel[m] = 1 for limb points */
+int shg_host_limb_points(const int32_t* host_idx, const int32_t* host_root, int64_t m, int64_t h, int64_t w,
+                         uint8_t* host_out_sel, int64_t* n_selected);
+/* LsqEllipse().fit(points).as_parameters() (ellipse_to_circle.py:57-59), Halir & Flusser */
+int shg_host_fit_ellipse(const double* host_points, int64_t n, double* host_center2, double* width, double* height,
+                         double* phi);
+/* get_correction_matrix (ellipse_to_circle.py:39-50): inverse matrix (row major) and theta */
+int shg_host_correction_matrix(double phi, double r, double* host_inv4, double* theta_out);
+/* two_step (ellipse_to_circle.py:62-91); outline200 = return_fit(n_points=100), may be NULL */
+int shg_host_two_step(const double* host_points, int64_t n, double* host_center2, double* height_out, double* phi_out,
+                      double* ratio_out, uint8_t* host_kept, int64_t* n_kept, double* host_outline200);
+/* correct_image's geometry (ellipse_to_circle.py:100-122) */
+int shg_host_warp_geometry(double phi, double ratio, int64_t h, int64_t w, double* host_mat3_9, double* host_inv4,
+                           double* host_origin2, double* det_out, double* theta_out, int64_t* out_h, int64_t* out_w);
+/* correct_transversalium2's chord slices (solex_util.py:384-391); xa, xb: max(y2-y1, 1) entries */
+int shg_host_chord_bounds(double cx, double cy, double r, double b0, double b2, int64_t y1, int64_t y2, int64_t w,
+                          int32_t* host_xa, int32_t* host_xb);
+/* correction factors from the row-pair statistics (solex_util.py:400-404, 456-472); taps = savgol_coeffs(window, 3) */
+int shg_host_transversalium_factors(const double* host_ratios, const double* host_interior, int64_t k, int64_t n,
+                                    const double* host_taps, int64_t window, int tapered, double* host_out);
+/* np.percentile's two order statistics and lerp weight; NumPy's _lerp */
+int shg_host_percentile_plan(int64_t n, double q, int64_t* rank_lo, int64_t* rank_hi, double* gamma);
+double shg_host_lerp(double a, double b, double gamma);
 
 #ifdef __cplusplus
 }

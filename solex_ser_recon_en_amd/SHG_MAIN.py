@@ -100,6 +100,12 @@ def _init_distributed():
     td.init_process_group(backend)
 
 
+def _shutdown_distributed():
+    import torch.distributed as td
+    if td.is_available() and td.is_initialized():
+        td.destroy_process_group()
+
+
 def main(argv=None):
     opts = default_options()
     argv = sys.argv[1:] if argv is None else list(argv)
@@ -110,7 +116,10 @@ def main(argv=None):
         print(CLI_handler.usage())
         return 1
     _init_distributed()
-    return 0 if handle_files(serfiles, opts, flag_command_line=True) else 1
+    try:
+        return 0 if handle_files(serfiles, opts, flag_command_line=True) else 1
+    finally:
+        _shutdown_distributed()
 
 
 if __name__ == '__main__':

@@ -24,7 +24,7 @@ import threading
 import numpy as np
 
 from . import dist, ops, outputs, timing
-from .device import DeviceImage, to_device_u16
+from .device import DeviceImage, default_device, to_device_u16
 from .ellipse_to_circle import correct_image, ellipse_to_circle
 from .fits_io import write_fits
 from .solex_util import (as_uint16_image, clearlog, compute_mean_return_fit, correct_transversalium2_batch, extract_disks,
@@ -32,75 +32,182 @@ from .solex_util import (as_uint16_image, clearlog, compute_mean_return_fit, cor
 from .video_reader import video_reader
 
 
-class _Prefetch:
-    """Decode file k+1 into HBM (reader threads + copy streams) while file k is being processed:
-    the overlap the reference gets from reading in the parent while Pool workers post-process
-    (Solex_recon.py:30-42)."""
+WORKERS = 4          # the reference post-processes up to four files at once (Pool(4), Solex_recon.py:30)
 
-    def __init__(self, file, frame_range=None):
-        self.file, self.frame_range = file, frame_range
-        self.rdr, self.err = None, None
-        self.thread = threading.Thread(target=self._run, name='shg-prefetch')
+
+def _worker_count(workers, n_tasks):
+    if workers is None:
+        try:
+            workers = int(os.environ.get('SHG_WORKERS', WORKERS))
+        except ValueError:
+            workers = WORKERS
+    return max(1, min(int(workers), n_tasks))
+
+
+class _Decoder:
+    """Decodes the files of a batch into HBM, in order, ahead of the scans that consume them (reader threads + copy
+    streams, video_reader.device_stack): the overlap the reference gets from reading in the parent while its Pool workers
+    post-process (Solex_recon.py:30-42).  At most `ahead` decoded stacks wait for a scan worker.  The thread
+    binds itself to the caller's device: torch's current device is thread-local and a fresh thread starts on
+    device 0, which is the wrong GPU for every rank but the first."""
+
+    def __init__(self, tasks, frame_range, ahead):
+        self.tasks, self.frame_range = tasks, frame_range
+        self.device = default_device()                       # on the caller's thread
+        self.slots = threading.Semaphore(max(1, ahead))
+        self.ready = [threading.Event() for _ in tasks]
+        self.out = [None] * len(tasks)
+        self.stop = False
+        self.thread = threading.Thread(target=self._run, name='shg-decode')
         self.thread.start()
 
     def _run(self):
-        try:
-            rdr = video_reader(self.file)
-            if self.frame_range is not None:
-                rdr.frame_range = self.frame_range(int(rdr.FrameCount))
-            rdr.device_stack()
-            self.rdr = rdr
-        except BaseException as e:      # noqa: BLE001 -- re-raised when this file's turn comes
-            self.err = e
+        import torch
+        torch.cuda.set_device(self.device)
+        for i, (file, _) in enumerate(self.tasks):
+            self.slots.acquire()
+            if self.stop:
+                self.out[i] = (None, RuntimeError('batch cancelled'))
+            elif hasattr(file, 'device_stack'):
+                self.out[i] = (file, None)
+            else:
+                try:
+                    rdr = video_reader(file)
+                    if self.frame_range is not None:
+                        _check_shardable(rdr)
+                        rdr.frame_range = self.frame_range(int(rdr.FrameCount))
+                    rdr.device_stack(device=self.device)
+                    self.out[i] = (rdr, None)
+                except BaseException as e:      # noqa: BLE001 -- re-raised when this file's turn comes
+                    self.out[i] = (None, e)
+            self.ready[i].set()
 
-    def get(self):
+    def get(self, i):
+        """The reader of task i, its frames resident in HBM (raises what its decode raised)."""
+        self.ready[i].wait()
+        rdr, err = self.out[i]
+        self.out[i] = None
+        self.slots.release()                                 # the decoder may start one more file
+        if err is not None:
+            raise err
+        return rdr
+
+    def cancel(self):
+        self.stop = True
+        for _ in self.tasks:
+            self.slots.release()
         self.thread.join()
-        if self.err is not None:
-            raise self.err
-        return self.rdr
 
 
-def solex_do_work(tasks, flag_command_line=False, distribute='auto', return_results=False):
+def solex_do_work(tasks, flag_command_line=False, distribute='auto', return_results=False, workers=None):
     """tasks: list of (file, options).  Raises on failure (the front door catches, SHG_MAIN.py:136-143).
 
     distribute (only matters under torch.distributed with more than one rank):
       'auto'   one file -> its frames are sharded over the ranks; several files -> file i goes to rank i mod G
       'frames' shard the frames of every file over the ranks (collectives per file)
       'none'   this rank processes exactly the tasks it was given (the caller already dealt the files)
-    return_results: also return the list of solex_process results (one list of (cc, protus) per processed file)."""
+    return_results: also return the list of solex_process results (one list of (cc, protus) per processed file).
+    workers: scans in flight at once in this process (default SHG_WORKERS or 4, the reference's Pool(4)): each scan
+      worker is a thread with its own HIP stream, so the host control plane of one file (polynomial fits, limb
+      geometry, Savitzky-Golay trend) overlaps the kernels of the others.  Files are independent, so every product
+      is bit-identical to the serial order.  Frame-sharded scans are collective and stay serial."""
     tasks = list(tasks)
     if distribute not in ('auto', 'frames', 'none'):
         raise ValueError("distribute must be 'auto', 'frames' or 'none'")
     shard_frames = dist.active() and (distribute == 'frames' or (distribute == 'auto' and len(tasks) == 1))
     if dist.active() and distribute == 'auto' and not shard_frames:
         tasks = tasks[dist.rank()::dist.world_size()]       # folder mode: file i belongs to rank i mod G
-    block = dist.frame_block if shard_frames else None
+    if not tasks:
+        return [] if return_results else None
+    n_workers = 1 if shard_frames else _worker_count(workers, len(tasks))
+    decoder = _Decoder(tasks, dist.frame_block if shard_frames else None, ahead=n_workers + 1)
+    collected = [None] * len(tasks)
 
-    def start(i):
-        file = tasks[i][0]
-        return file if hasattr(file, 'device_stack') else _Prefetch(file, block)
-    collected = []
+    def scan(i):
+        file, options = tasks[i]
+        print('file %s is processing' % file)
+        options['_shard_frames'] = shard_frames
+        rdr = decoder.get(i)
+        if shard_frames:
+            _check_shardable(rdr)
+        disk_list, backup_bounds, hdr = solex_read(rdr, options)
+        _release_stack(rdr)                                 # the frame stack goes before the next file's lands
+        if shard_frames:
+            n_requested = sum(1 for s in options['shift'] if s in options['shift_requested'])
+            if n_requested > 1:
+                options['_deal_disks'] = True               # Doppler stack: every rank post-processes its share of the disks
+            elif dist.rank() != 0:
+                return
+        res = solex_process(options, disk_list, backup_bounds, hdr)
+        if return_results:
+            collected[i] = res
+
     try:
-        nxt = start(0) if tasks else None
-        for i, (file, options) in enumerate(tasks):
-            cur, nxt = nxt, (start(i + 1) if i + 1 < len(tasks) else None)
-            print('file %s is processing' % file)
-            options['_shard_frames'] = shard_frames
-            rdr = cur.get() if isinstance(cur, _Prefetch) else cur
-            disk_list, backup_bounds, hdr = solex_read(rdr, options)
-            rdr._stack = None                               # release the frame stack before the next file's lands
-            if shard_frames:
-                n_requested = sum(1 for s in options['shift'] if s in options['shift_requested'])
-                if n_requested > 1:
-                    options['_deal_disks'] = True           # Doppler stack: every rank post-processes its share of the disks
-                elif dist.rank() != 0:
-                    continue                                # one disk: the mosaic is post-processed and written once
-            res = solex_process(options, disk_list, backup_bounds, hdr)
-            if return_results:
-                collected.append(res)
+        if n_workers == 1:
+            for i in range(len(tasks)):
+                scan(i)
+        else:
+            _scan_pool(scan, len(tasks), n_workers, decoder.device)
     finally:
+        decoder.cancel()
         outputs.flush()
-    return collected if return_results else None
+    if not return_results:
+        return None
+    return [c for c in collected if c is not None] if shard_frames else collected
+
+
+def _check_shardable(rdr):
+    """Every rank sees the same header, so every rank raises (none is left waiting in the first all-reduce)."""
+    if int(rdr.FrameCount) < dist.world_size():
+        raise Exception('error input file %s: %d frames cannot be sharded over %d ranks'
+                        % (rdr.file, int(rdr.FrameCount), dist.world_size()))
+
+
+def _release_stack(rdr):
+    """Drop the reader's reference to the frame stack.  The stack was allocated on the decoder's stream; tell the
+    caching allocator that this thread's stream still reads it, so the block is not handed to the next decode
+    while pass B is queued."""
+    import torch
+    stack = getattr(rdr, '_stack', None)
+    if stack is not None and stack.is_cuda:
+        stack.record_stream(torch.cuda.current_stream(stack.device))
+    rdr._stack = None
+
+
+def _scan_pool(scan, n_tasks, n_workers, device):
+    """Run scan(0..n_tasks-1) on n_workers threads, each with its own HIP stream (torch's current stream and device
+    are thread-local; ops.py launches on the current stream).  Tasks are taken in order.  The first failure (lowest
+    task index) is re-raised after the workers have drained, and no new task starts once one has failed -- a batch
+    halts on an unsuitable file, as result.get() makes the reference's (Solex_recon.py:42)."""
+    import torch
+    lock = threading.Lock()
+    state = {'next': 0, 'errors': []}
+
+    def run():
+        torch.cuda.set_device(device)
+        stream = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(stream):
+            while True:
+                with lock:
+                    i = state['next']
+                    if i >= n_tasks or state['errors']:
+                        break
+                    state['next'] = i + 1
+                try:
+                    scan(i)
+                except BaseException as e:      # noqa: BLE001 -- re-raised on the caller's thread
+                    with lock:
+                        state['errors'].append((i, e))
+                    break
+            stream.synchronize()                # results handed back to the caller are complete
+
+    threads = [threading.Thread(target=run, name='shg-scan-%d' % k) for k in range(n_workers)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if state['errors']:
+        raise min(state['errors'], key=lambda ie: ie[0])[1]
 
 
 def _writes_files(options):
@@ -170,13 +277,27 @@ def solex_process(options, disk_list, backup_bounds, hdr):
             turn += 1
         # disk_list[0] is always the ellipse-fit shift (more limb contrast)
         if options['ratio_fixe'] is None and options['slant_fix'] is None:
+            failure = None
             if not deal or dist.rank() == 0:
-                with timing.stage('ellipse_fit+warp'):
-                    frame_circularized, cercle0, options['ratio_fixe'], phi, borders = ellipse_to_circle(
-                        disk_list[i], options, basefich)
+                try:
+                    with timing.stage('ellipse_fit+warp'):
+                        frame_circularized, cercle0, options['ratio_fixe'], phi, borders = ellipse_to_circle(
+                            disk_list[i], options, basefich)
+                except Exception as e:                      # noqa: BLE001
+                    if not deal:
+                        raise
+                    failure = e                             # the other ranks wait in the broadcast: tell them first
             if deal:
-                geometry = dist.broadcast_object((cercle0, options['ratio_fixe'], phi, borders) if dist.rank() == 0 else None)
-                cercle0, options['ratio_fixe'], phi, borders = geometry
+                # (ok, geometry | error text): a limb fit that fails on rank 0 fails the scan on every rank instead of
+                # leaving the others in the collective
+                message = None
+                if dist.rank() == 0:
+                    message = (False, repr(failure)) if failure is not None else (
+                        True, (cercle0, options['ratio_fixe'], phi, borders))
+                ok, payload = dist.broadcast_object(message)
+                if not ok:
+                    raise failure if failure is not None else RuntimeError('limb fit failed on rank 0: ' + payload)
+                cercle0, options['ratio_fixe'], phi, borders = payload
                 if dist.rank() != 0 and flag_requested and mine:
                     # the same warp the fit ran on rank 0 (centre / height only feed the returned circle)
                     frame_circularized = correct_image(disk_list[i], phi, options['ratio_fixe'], np.array([-1.0, -1.0]),

@@ -23,6 +23,8 @@ if not os.path.exists(LIB_PATH):
 lib = ctypes.CDLL(LIB_PATH)
 
 P = c_void_p
+PD = ctypes.POINTER(c_double)
+PI64 = ctypes.POINTER(c_int64)
 SIGNATURES = {
     'shg_abi_version': (c_int, []),
     'shg_last_error_string': (ctypes.c_char_p, []),
@@ -30,6 +32,7 @@ SIGNATURES = {
     'shg_profile_select': (c_int, [ctypes.c_char_p]),
     'shg_profile_reset': (c_int, []),
     'shg_profile_get': (c_int, [ctypes.c_char_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int64)]),
+    'shg_profile_total': (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(c_int64)]),
     'shg_stream_read_probe': (c_int, [P, c_int64, c_int, c_int, c_int, c_int64, P, P]),
     'shg_accumulate_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int64, c_int]),
     'shg_accumulate_sum_max': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int64, P, P, P, c_size_t, P]),
@@ -75,6 +78,24 @@ SIGNATURES = {
     'shg_canny_workspace_bytes': (c_size_t, [c_int64, c_int64]),
     'shg_canny_masks_f64': (c_int, [P, c_int64, c_int64, c_double, ctypes.POINTER(c_double), c_int, c_double, c_double, P, P, P,
                                     c_size_t, P]),
+    # ---- host control plane (host pointers; numpy arrays are passed by address) ----
+    'shg_host_bind_lapack': (c_int, [P]),
+    'shg_host_lapack_bound': (c_int, []),
+    'shg_host_set_mode_pick': (c_int, [P]),
+    'shg_host_polyfit3': (c_int, [P, P, c_int64, P]),
+    'shg_host_detect_bord': (c_int, [P, c_int64, PI64, PI64]),
+    'shg_host_line_fit': (c_int, [P, P, c_int64, c_int64, c_int64, ctypes.c_int32, P, P, P]),
+    'shg_host_column_plan': (c_int, [P, c_int64, c_int64, P, c_int, P, P, P]),
+    'shg_host_flood_threshold': (c_int, [c_double, c_int64, c_int64, c_double, c_double, P, PD]),
+    'shg_host_limb_points': (c_int, [P, P, c_int64, c_int64, c_int64, P, PI64]),
+    'shg_host_fit_ellipse': (c_int, [P, c_int64, P, PD, PD, PD]),
+    'shg_host_correction_matrix': (c_int, [c_double, c_double, P, PD]),
+    'shg_host_two_step': (c_int, [P, c_int64, P, PD, PD, PD, P, PI64, P]),
+    'shg_host_warp_geometry': (c_int, [c_double, c_double, c_int64, c_int64, P, P, P, PD, PD, PI64, PI64]),
+    'shg_host_chord_bounds': (c_int, [c_double, c_double, c_double, c_double, c_double, c_int64, c_int64, c_int64, P, P]),
+    'shg_host_transversalium_factors': (c_int, [P, P, c_int64, c_int64, P, c_int64, c_int, P]),
+    'shg_host_percentile_plan': (c_int, [c_int64, c_double, PI64, PI64, PD]),
+    'shg_host_lerp': (c_double, [c_double, c_double, c_double]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():
@@ -82,7 +103,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 if lib.shg_abi_version() != ABI_VERSION:
     raise ImportError('libshg_hip.so ABI %d != expected %d: rebuild it' % (lib.shg_abi_version(), ABI_VERSION))
 
@@ -91,9 +112,69 @@ def last_error():
     return lib.shg_last_error_string().decode('utf-8', 'replace')
 
 
+def _host_error(status, what):
+    """The host control plane reports the failure the reference's NumPy / SciPy call raises at that point
+    (include/shg_hip.h, SHG_E_VALUE ... SHG_E_QHULL): raise that exception type."""
+    msg = last_error()
+    if status == -4:
+        return ValueError(msg)
+    if status == -5:
+        return TypeError(msg)
+    if status == -6:
+        import numpy
+        return numpy.linalg.LinAlgError(msg)
+    if status == -8:
+        try:
+            from scipy.spatial import QhullError
+            return QhullError(msg)
+        except ImportError:
+            pass
+    return RuntimeError('%s: %s' % (what, msg) if status != -7 else msg)
+
+
 def check(status, what):
     if status != 0:
+        if -8 <= status <= -4:
+            raise _host_error(status, what)
         raise RuntimeError('%s failed (status %d): %s' % (what, status, last_error()))
+
+
+def _bind_numpy_lapack():
+    """Hand the library the dgelsd NumPy itself calls (np.linalg.lstsq under np.polyfit), so that the line fit of
+    the host control plane is bit-identical to the reference's on this host.  NumPy 2.x wheels bundle an ILP64
+    OpenBLAS whose Fortran symbols carry a scipy_ prefix and a 64_ suffix."""
+    import glob
+    import numpy
+    import numpy.linalg           # noqa: F401  -- loads the bundled OpenBLAS
+    root = os.path.dirname(os.path.dirname(os.path.abspath(numpy.__file__)))
+    for path in sorted(glob.glob(os.path.join(root, 'numpy.libs', 'libscipy_openblas64_*.so*'))):
+        try:
+            blas = ctypes.CDLL(path)                   # already mapped: same handle, no second copy
+            fn = getattr(blas, 'scipy_dgelsd_64_')
+        except (OSError, AttributeError):
+            continue
+        lib.shg_host_bind_lapack(ctypes.cast(fn, c_void_p))
+        return path
+    return None
+
+
+LAPACK_PATH = _bind_numpy_lapack()
+
+
+@ctypes.CFUNCTYPE(c_int64, ctypes.POINTER(c_int64), c_int64)
+def _numpy_mode_pick(neg_counts, n):
+    """np.argpartition(-counts, kth=2)[:2][0] by NumPy itself (solex_util.py:246): the one decision of the line fit whose
+    outcome depends on NumPy's selection kernel.  Called once per scan from shg_host_line_fit (ctypes takes the
+    interpreter lock for the call)."""
+    try:
+        import numpy
+        a = numpy.ctypeslib.as_array(neg_counts, shape=(n,)).copy()
+        return int(numpy.argpartition(a, kth=2)[:2][0])
+    except Exception:      # noqa: BLE001 -- reported by the caller as an out-of-range pick
+        return -1
+
+
+lib.shg_host_set_mode_pick(ctypes.cast(_numpy_mode_pick, c_void_p))
 
 
 def profile_enable(on=True, only=None):
@@ -110,4 +191,11 @@ def profile_get(tag):
     """-> (total milliseconds, launches) of the kernel `tag` since the last reset."""
     ms, n = c_double(0.0), c_int64(0)
     check(lib.shg_profile_get(tag.encode(), ctypes.byref(ms), ctypes.byref(n)), 'shg_profile_get')
+    return ms.value, n.value
+
+
+def profile_total():
+    """-> (total milliseconds, entry points timed) over every tag since the last reset."""
+    ms, n = c_double(0.0), c_int64(0)
+    check(lib.shg_profile_total(ctypes.byref(ms), ctypes.byref(n)), 'shg_profile_total')
     return ms.value, n.value

@@ -96,5 +96,20 @@ extern "C" int shg_profile_get(const char* tag, double* total_ms, int64_t* launc
     return 0;
 }
 
+extern "C" int shg_profile_total(double* total_ms, int64_t* launches) {
+    if (!total_ms || !launches) { shg::set_error("shg_profile_total: null pointer"); return SHG_E_ARG; }
+    std::lock_guard<std::mutex> lk(shg::g_mu);
+    double ms = 0.0;
+    for (auto& s : shg::g_samples) {
+        if (hipError_t e = hipEventSynchronize(s.b)) { shg::set_error("shg_profile_total: %s", hipGetErrorString(e)); return (int)e; }
+        float t = 0.f;
+        if (hipError_t e = hipEventElapsedTime(&t, s.a, s.b)) { shg::set_error("shg_profile_total: %s", hipGetErrorString(e)); return (int)e; }
+        ms += t;
+    }
+    *total_ms = ms;
+    *launches = (int64_t)shg::g_samples.size();
+    return 0;
+}
+
 extern "C" int shg_abi_version(void) { return SHG_ABI_VERSION; }
 extern "C" const char* shg_last_error_string(void) { return shg::g_error; }

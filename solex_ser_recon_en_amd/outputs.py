@@ -54,20 +54,38 @@ def _plot_in_worker(fn, args):
 synchronous = False          # tests can force inline execution
 
 
+def _stream_event(args):
+    """The images were produced on the submitting thread's HIP stream; the encoder threads copy them to the host on
+    their own (default) stream, so a task first waits for an event recorded behind the producing kernels."""
+    if not any(hasattr(a, 't') and getattr(a.t, 'is_cuda', False) for a in args):
+        return None
+    import torch
+    done = torch.cuda.Event()
+    done.record()
+    return done
+
+
+def _run_after(done, fn, args):
+    if done is not None:
+        done.synchronize()
+    return fn(*args)
+
+
 def submit(fn, *args):
     if synchronous:
         fn(*args)
         return
     kind = 'plot' if getattr(fn, '__name__', '').startswith('plot_') else 'encode'
+    done = _stream_event(args)
     with _lock:
         if kind not in _pools:
             _pools[kind] = ThreadPoolExecutor(max_workers=1 if kind == 'plot' else ENCODER_THREADS,
                                               thread_name_prefix='shg-' + kind)
         if kind == 'plot' and _plot_processes() > 0:
             # the plot thread only copies the images to the host and hands the figure to a worker process
-            _pending.append(_pools[kind].submit(_plot_in_worker, fn, args))
+            _pending.append(_pools[kind].submit(_run_after, done, _plot_in_worker, (fn, args)))
         else:
-            _pending.append(_pools[kind].submit(fn, *args))
+            _pending.append(_pools[kind].submit(_run_after, done, fn, args))
 
 
 def flush():

@@ -151,6 +151,11 @@ class video_reader:
         counter = itertools.count()
         errors = []
         streams = [torch.cuda.Stream(device=device) for _ in range(readers)]
+        # the stack may be a block the caching allocator recycled from the previous file: kernels queued on the allocating
+        # stream may still read it, so no upload starts before that stream has drained up to here
+        alloc_stream = torch.cuda.current_stream(device)
+        for st in streams:
+            st.wait_stream(alloc_stream)
 
         def work(tid):
             try:
@@ -226,6 +231,7 @@ class video_reader:
         bufs = _lease_pinned_pair(chunk_frames * pitch)
         events = [None, None]
         stream = torch.cuda.Stream(device=device)
+        stream.wait_stream(torch.cuda.current_stream(device))       # `raw` may be a recycled block (see device_stack)
         fd = os.open(self.file, os.O_RDONLY)
         try:
             slot = 0
