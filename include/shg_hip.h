@@ -41,6 +41,8 @@ extern "C" {
 #define SHG_E_LINALG     (-6)   /* numpy.linalg.LinAlgError                            */
 #define SHG_E_RUNTIME    (-7)   /* RuntimeError                                        */
 #define SHG_E_QHULL      (-8)   /* scipy.spatial.QhullError                            */
+#define SHG_E_ASSERT     (-9)   /* AssertionError (rescale_brightness's assert)        */
+#define SHG_E_INDEX      (-10)  /* IndexError                                          */
 
 typedef void* shg_stream_t;
 
@@ -314,6 +316,68 @@ int shg_contrast_products_u16(const uint16_t* frame, int64_t frame_pitch, const 
                               uint16_t* protus, uint16_t* cc, int64_t dst_pitch, int64_t disc_x0,
                               int64_t disc_y0, int64_t disc_r, shg_stream_t stream);
 
+/* ==== stage composites ============================================================================
+ * Each stage function of the reference as one call: the same kernels in the same order as the entry points
+ * above, the scalars / 1-D vectors in between brought to the host through PINNED memory and handled by the
+ * host control plane below -- no interpreter (and no interpreter lock) between the kernels, so several
+ * scans run side by side in one process.  Device `workspace` and pinned `host_pinned` staging areas are
+ * sized by the *_bytes queries; a stage synchronises `stream` where the control plane needs a result. */
+
+/* compute_mean_return_fit (solex_util.py:191-259): pass A (or the given, e.g. all-reduced, sum_in / max_in),
+ * mean / max images [ih][iw] (dense), detect_bord, the two argmin traces, the cubic fit.
+ * host_y12 = clipped (y1, y2); host_p4 lowest power first; host_fit [ih][4]; host_trace_sharp [ih] and
+ * host_mask_good [y2-y1 <= ih] (both may be NULL) feed the reference's diagnostic plot. */
+size_t shg_stage_mean_fit_workspace_bytes(int64_t n_frames, int64_t height, int64_t width, int bytes_per_px);
+size_t shg_stage_mean_fit_host_bytes(int64_t height, int64_t width);
+int shg_stage_mean_fit(const void* stack, int64_t n_frames, int64_t height, int64_t width, int bytes_per_px,
+                       int64_t frame_stride_px, const uint64_t* sum_in, const uint16_t* max_in, int64_t n_total,
+                       uint16_t* mean_out, uint16_t* max_out, int64_t* host_y12, double* host_p4, double* host_fit,
+                       int32_t* host_trace_sharp, uint8_t* host_mask_good, void* workspace, size_t workspace_bytes,
+                       void* host_pinned, size_t host_pinned_bytes, shg_stream_t stream);
+
+/* read_video_improved (solex_util.py:93-144) from the host `fit` and shift list: sample columns and weights
+ * (shg_host_column_plan), upload, shg_extract_columns.  Asynchronous. */
+size_t shg_stage_extract_workspace_bytes(int64_t height, int64_t width, int n_shifts);   /* device and pinned */
+int shg_stage_extract(const void* stack, int64_t n_frames, int64_t height, int64_t width, int bytes_per_px,
+                      int64_t frame_stride_px, const double* host_fit, const int32_t* host_shifts, int n_shifts,
+                      uint16_t* disks, int64_t row_pitch, int64_t plane_stride, int64_t n_cols, int64_t k_offset,
+                      int flip_x, void* workspace, size_t workspace_bytes, void* host_pinned, size_t host_pinned_bytes,
+                      shg_stream_t stream);
+
+/* get_edge_list on the 4x4 block mean of the disk (ellipse_to_circle.py:231-291, 299-302): flood image, canny ladder
+ * (sigma 2, 1.5, 1, 0.5; host_gauss_taps = scipy's taps for those, 17 + 13 + 9 + 5 values), hysteresis + labelling,
+ * region choice, convex-hull filter, row crop.  host_points [points_cap][2]: edge pixels (row, col) of the quarter-size
+ * image in raster order; host_flags [points_cap]: 1 = limb point; host_counts2 = edge pixels, limb points.  The
+ * ellipse fit on the limb points stays with the caller (NumPy, see csrc/hostmath.hip). */
+size_t shg_stage_limb_points_workspace_bytes(int64_t h, int64_t w);
+size_t shg_stage_limb_points_host_bytes(int64_t h, int64_t w);
+int shg_stage_limb_points(const uint16_t* disk, int64_t h, int64_t w, int64_t pitch, const double* host_gauss_taps,
+                          int32_t* host_points, uint8_t* host_flags, int64_t points_cap, int64_t* host_counts2,
+                          void* workspace, size_t workspace_bytes, void* host_pinned, size_t host_pinned_bytes,
+                          shg_stream_t stream);
+
+/* ellipse_to_circle without its warp (ellipse_to_circle.py:294-314): shg_stage_limb_points, then two_step, correct_image's
+ * geometry and the borders (shg_host_limb_geometry).  Flag bit 1 = kept by two_step; host_counts3 = edge pixels, limb
+ * points, kept points. */
+int shg_stage_limb_fit(const uint16_t* disk, int64_t h, int64_t w, int64_t pitch, const double* host_gauss_taps,
+                       int32_t* host_points, uint8_t* host_flags, int64_t points_cap, int64_t* host_counts3,
+                       double* host_geom16, int64_t* host_dims2, double* host_outline200, void* workspace,
+                       size_t workspace_bytes, void* host_pinned, size_t host_pinned_bytes, shg_stream_t stream);
+
+/* single_image_process for the k requested disks of a file (Solex_recon.py:136-174; solex_util.py:383-516,
+ * 527-547): transversalium, crop / pad, CLAHE + order statistics, the three rescales + protuberance disc.
+ * See csrc/stages.hip for the argument list. */
+size_t shg_stage_process_workspace_bytes(int64_t k, int64_t h, int64_t w, int64_t crop_w, int tiles);
+size_t shg_stage_process_host_bytes(int64_t k, int64_t h);
+int shg_stage_process_frames(const uint16_t* const* host_frames, int64_t k, int64_t h, int64_t w, int64_t pitch,
+                             int transversalium, const double* host_circle3, const double* host_borders4,
+                             const double* host_taps, int64_t window, double* host_factors, int64_t crop_w,
+                             int64_t sx0, int64_t dx0, int64_t ncopy, double clip_limit, int tiles, int64_t disc_x0,
+                             int64_t disc_y0, int64_t disc_r, uint16_t* const* host_detrans, int64_t detrans_pitch,
+                             uint16_t* const* host_final, uint16_t* const* host_cl1, uint16_t* const* host_hc,
+                             uint16_t* const* host_protus, uint16_t* const* host_cc, int64_t out_pitch, void* workspace,
+                             size_t workspace_bytes, void* host_pinned, size_t host_pinned_bytes, shg_stream_t stream);
+
 /* ==== host control plane =======================================================================
  * The 1-D / scalar arithmetic between the kernels, restated from the reference's NumPy / SciPy calls so
  * that a pipeline stage is one call that holds no interpreter lock (several scans in flight per process).
@@ -349,17 +413,31 @@ int shg_host_flood_threshold(double total, int64_t h, int64_t w, double mn, doub
  * labelled edge pixels (shg_edge_components' output); out_sel[m] = 1 for limb points */
 int shg_host_limb_points(const int32_t* host_idx, const int32_t* host_root, int64_t m, int64_t h, int64_t w,
                          uint8_t* host_out_sel, int64_t* n_selected);
+/* The limb geometry with NumPy's own BLAS / LAPACK: phi and ratio steer every sample position of the warp, so the
+ * scatter matrices, 3x3 inverses and the eigen-decomposition of the ellipse fit come out of the routines NumPy calls,
+ * called the way its matmul / inv / eig call them (csrc/hostmath.hip).  shg_host_bind_blas takes the ILP64 entry
+ * points cblas_dgemm, cblas_dsyrk, cblas_dgemv, dgesv, dgeev of the OpenBLAS NumPy loaded; without them the
+ * functions below return SHG_E_UNSUPPORTED and the caller keeps the geometry in NumPy. */
+int shg_host_bind_blas(void* cblas_dgemm_ilp64, void* cblas_dsyrk_ilp64, void* cblas_dgemv_ilp64, void* dgesv_ilp64,
+                       void* dgeev_ilp64);
+int shg_host_blas_bound(void);
 /* LsqEllipse().fit(points).as_parameters() (ellipse_to_circle.py:57-59), Halir & Flusser */
 int shg_host_fit_ellipse(const double* host_points, int64_t n, double* host_center2, double* width, double* height,
                          double* phi);
 /* get_correction_matrix (ellipse_to_circle.py:39-50): inverse matrix (row major) and theta */
 int shg_host_correction_matrix(double phi, double r, double* host_inv4, double* theta_out);
-/* two_step (ellipse_to_circle.py:62-91); outline200 = return_fit(n_points=100), may be NULL */
+/* two_step (ellipse_to_circle.py:62-91); host_kept[n] and outline200 = return_fit(n_points=100) may be NULL */
 int shg_host_two_step(const double* host_points, int64_t n, double* host_center2, double* height_out, double* phi_out,
                       double* ratio_out, uint8_t* host_kept, int64_t* n_kept, double* host_outline200);
 /* correct_image's geometry (ellipse_to_circle.py:100-122) */
 int shg_host_warp_geometry(double phi, double ratio, int64_t h, int64_t w, double* host_mat3_9, double* host_inv4,
                            double* host_origin2, double* det_out, double* theta_out, int64_t* out_h, int64_t* out_w);
+/* ellipse_to_circle after get_edge_list (ellipse_to_circle.py:303-314): two_step on the limb points (row, col), the geometry
+ * of the corrected h x w disk, its circle and the borders of the kept points.  host_geom16 = ellipse centre x, y, height,
+ * phi, ratio | circle cx, cy, r | borders[4] | mat3 row 0 (h00, h01, h02 for shg_warp_rows_u16) | theta; host_dims2 = out_h,
+ * out_w; host_kept [n] and host_outline200 may be NULL. */
+int shg_host_limb_geometry(const double* host_points, int64_t n, int64_t h, int64_t w, double* host_geom16,
+                           int64_t* host_dims2, uint8_t* host_kept, int64_t* n_kept, double* host_outline200);
 /* correct_transversalium2's chord slices (solex_util.py:384-391); xa, xb: max(y2-y1, 1) entries */
 int shg_host_chord_bounds(double cx, double cy, double r, double b0, double b2, int64_t y1, int64_t y2, int64_t w,
                           int32_t* host_xa, int32_t* host_xb);

@@ -46,26 +46,31 @@ def default_options():
     return {k: (list(v) if isinstance(v, list) else v) for k, v in options.items()}
 
 
+def _openable(path):
+    try:
+        with open(path, 'rb'):
+            return True
+    except Exception:
+        traceback.print_exc()
+        return False
+
+
 def precheck_files(serfiles, options):
+    """The task list of SHG_MAIN.py:98-132: one (file, copy of the options) per file that has a name and can be opened;
+    the rest are reported and skipped.  `tempo` is the GUI's display pause (unused here, kept in the schema)."""
     options['tempo'] = 30000 if len(serfiles) == 1 else 5000
-    good_tasks = []
-    for serfile in serfiles:
-        print(serfile)
-        if serfile == '':
+    tasks = []
+    for path in serfiles:
+        print(path)
+        if path == '':
             print("ERROR filename empty")
-            continue
-        if os.path.basename(serfile) == '':
-            print('filename ERROR : ', serfile)
-            continue
-        try:
-            with open(serfile, "rb"):
-                pass
-        except Exception:
-            traceback.print_exc()
-            print('ERROR opening file : ', serfile)
-            continue
-        good_tasks.append((serfile, options.copy()))
-    return good_tasks
+        elif os.path.basename(path) == '':
+            print('filename ERROR : ', path)
+        elif not _openable(path):
+            print('ERROR opening file : ', path)
+        else:
+            tasks.append((path, options.copy()))
+    return tasks
 
 
 def handle_files(files, options, flag_command_line=False):

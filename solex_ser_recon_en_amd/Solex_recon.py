@@ -27,8 +27,10 @@ from . import dist, ops, outputs, timing
 from .device import DeviceImage, default_device, to_device_u16
 from .ellipse_to_circle import correct_image, ellipse_to_circle
 from .fits_io import write_fits
+from . import stages
 from .solex_util import (as_uint16_image, clearlog, compute_mean_return_fit, correct_transversalium2_batch, extract_disks,
-                         image_process_batch, logme, make_header, output_path, removeVignette, write_complete)
+                         image_process_batch, logme, make_header, output_path, plots_enabled, removeVignette, savgol_taps,
+                         savgol_window, write_complete, write_products)
 from .video_reader import video_reader
 
 
@@ -174,18 +176,36 @@ def _release_stack(rdr):
     rdr._stack = None
 
 
+_worker_contexts = {}          # (device, k) -> {'stream', 'buffers'}: a scan worker's stream and staging buffers outlive a batch
+_contexts_lock = threading.Lock()
+
+
+def _worker_context(device, k):
+    import torch
+    with _contexts_lock:
+        ctx = _worker_contexts.get((str(device), k))
+        if ctx is None:
+            ctx = {'stream': torch.cuda.Stream(device=device), 'buffers': {}}
+            _worker_contexts[(str(device), k)] = ctx
+    return ctx
+
+
 def _scan_pool(scan, n_tasks, n_workers, device):
     """Run scan(0..n_tasks-1) on n_workers threads, each with its own HIP stream (torch's current stream and device
-    are thread-local; ops.py launches on the current stream).  Tasks are taken in order.  The first failure (lowest
-    task index) is re-raised after the workers have drained, and no new task starts once one has failed -- a batch
-    halts on an unsuitable file, as result.get() makes the reference's (Solex_recon.py:42)."""
+    are thread-local; ops.py launches on the current stream).  Worker k keeps its stream, device workspace and pinned
+    staging buffers from batch to batch (pinning memory and growing the allocator's per-stream pools cost milliseconds).
+    Tasks are taken in order.  The first failure (lowest task index) is re-raised after the workers have drained, and no
+    new task starts once one has failed -- a batch halts on an unsuitable file, as result.get() makes the reference's
+    (Solex_recon.py:42)."""
     import torch
     lock = threading.Lock()
     state = {'next': 0, 'errors': []}
 
-    def run():
+    def run(k):
         torch.cuda.set_device(device)
-        stream = torch.cuda.Stream(device=device)
+        ctx = _worker_context(device, k)
+        stages.use_buffers(ctx['buffers'])
+        stream = ctx['stream']
         with torch.cuda.stream(stream):
             while True:
                 with lock:
@@ -201,7 +221,7 @@ def _scan_pool(scan, n_tasks, n_workers, device):
                     break
             stream.synchronize()                # results handed back to the caller are complete
 
-    threads = [threading.Thread(target=run, name='shg-scan-%d' % k) for k in range(n_workers)]
+    threads = [threading.Thread(target=run, args=(k,), name='shg-scan-%d' % k) for k in range(n_workers)]
     for t in threads:
         t.start()
     for t in threads:
@@ -342,42 +362,94 @@ def single_image_process(frame_circularized, hdr, options, cercle0, borders, bas
 
 
 def crop_to_width(images, cercle, options):
-    """The crop / pad block of single_image_process (Solex_recon.py:155-171) for a list of same-shape images:
-    centre on int(cx) (w // 2 without a circle), crop or pad to `fixed_width` (or to the height for
-    `crop_width_square`), fill with img[0, 0].  Returns (images, cercle) with cx moved to the new centre."""
+    """The crop / pad block of single_image_process (Solex_recon.py:155-171) for a list of same-shape images.
+    Returns (images, cercle) with cx moved to the new centre."""
     # A de-vignetted frame that skipped the transversalium stage is still float64 here; the reference crops
     # the float image and truncates in image_process (solex_util.py:528).  Cropping is a pure copy, so
     # truncating first gives the same pixels (and the same fill value img[0, 0]).
     images = [as_uint16_image(img) for img in images]
-    if options['fixed_width'] is not None or options['crop_width_square']:
-        h, w = images[0].shape
-        nw = h if options['fixed_width'] is None else options['fixed_width']
-        nw2 = nw // 2
-        cx = w // 2 if cercle == (-1, -1, -1) else int(cercle[0])
-        tx = nw2 - cx
-        lo, hi = max(0, cx - nw2), min(cx + nw2, w)
-        if hi < lo:
-            raise ValueError('crop window [%d, %d) lies outside the %d px wide image' % (cx - nw2, cx + nw2, w))
-        # new_img[:, :hi-lo] = img[:, lo:hi]; then np.roll by tx when tx > 0 and refill the first tx columns (:161-167).
-        # The rolled-in tail is fill colour whenever the copied span fits, which it does: hi - lo <= nw - tx.
-        n = hi - lo
-        dx0 = tx if tx > 0 else 0
-        if dx0 + n > nw:
-            n = nw - dx0            # np.roll would wrap these columns round and the refill overwrite them
+    h, w = images[0].shape
+    plan, cercle = crop_plan(h, w, cercle, options)
+    if plan is not None:
+        nw, lo, dx0, n = plan
         # the fill colour img[0, 0] is read on the device (no host round trip per image)
         images = [DeviceImage(ops.crop_pad_u16(to_device_u16(img), nw, lo, dx0, n, None)) for img in images]
-        if not cercle == (-1, -1, -1):
-            cercle = (nw2, cercle[1], cercle[2])
     return images, cercle
 
 
 def process_images(frames, hdr, options, cercle0, borders, basefichs, backup_bounds):
     """single_image_process (Solex_recon.py:136-174) for a list of circularised frames of one file:
-    transversalium, crop, CLAHE + contrast products.  Returns [(cc, frame_protus), ...]."""
+    transversalium, crop, CLAHE + contrast products.  Returns [(cc, frame_protus), ...].
+    The usual case is one stage call (shg_stage_process_frames); de-vignetted frames (float64 row factors) and the
+    stubborn transversalium branch take the step-by-step route."""
     if options['save_fit']:
         for frame, basefich in zip(frames, basefichs):
             outputs.submit(write_fits, output_path(basefich + '_circular.fits', options), _as_image(frame), hdr)
+    factored = any(isinstance(f, DeviceImage) and f.row_factor is not None for f in frames)
+    if factored or (options['transversalium'] and options.get('stubborn_transversalium')):
+        return _process_images_stepwise(frames, hdr, options, cercle0, borders, basefichs, backup_bounds)
 
+    tensors = [to_device_u16(f) for f in frames]
+    if any(t.shape != tensors[0].shape or t.stride() != tensors[0].stride() or t.stride(1) != 1 for t in tensors):
+        tensors = [t.contiguous() for t in tensors]
+    h, w = tensors[0].shape
+    trans = None
+    if options['transversalium']:
+        if not cercle0 == (-1, -1, -1):
+            circle, bds = cercle0, borders
+        else:                                               # no limb fit: the sunlit rows found by the line fit (:146)
+            circle, bds = (0, 0, 99999), [0, backup_bounds[0] + 20, w - 1, backup_bounds[1] - 20]
+        y1 = math.ceil(max(circle[1] - circle[2], bds[1]))
+        y2 = math.floor(min(circle[1] + circle[2], bds[3]))
+        window = savgol_window(max(y2 - y1, 1), options['trans_strength'])
+        trans = {'circle': circle, 'borders': bds, 'window': window, 'taps': savgol_taps(window)}
+    crop, cercle = crop_plan(h, w, cercle0, options)
+    disc = None
+    if not cercle == (-1, -1, -1) and options['disk_display']:
+        r = int(cercle[2]) + options['delta_radius']
+        if r > 0:
+            disc = (int(cercle[0]), int(cercle[1]), r)
+    with timing.stage('transversalium+crop+clahe+contrast'):
+        res = stages.process_frames(tensors, trans, crop, disc, keep_detrans=bool(options['save_fit'] and trans))
+    if trans is not None:
+        for i, basefich in enumerate(basefichs):
+            c = res['factors'][i]
+            options['_transversalium_cache'] = c
+            if plots_enabled(options):
+                outputs.submit(outputs.plot_transversalium, output_path(basefich + '_transversalium_correction.png', options), c)
+            if options['save_fit']:
+                outputs.submit(write_fits, output_path(basefich + '_detransversaliumed.fits', options), DeviceImage(res['detrans'][i]), hdr)
+    return [write_products(res['final'][i], res['cl1'][i], res['hc'][i], res['protus'][i], res['cc'][i], options, hdr, basefichs[i])
+            for i in range(len(tensors))]
+
+
+def crop_plan(h, w, cercle, options):
+    """The crop / pad block of single_image_process (Solex_recon.py:155-171) as numbers: centre on int(cx) (w // 2
+    without a circle), crop or pad to `fixed_width` (or to the height for `crop_width_square`), fill with img[0, 0]:
+    new[:, dx0:dx0+n] = img[:, lo:lo+n].  -> ((nw, lo, dx0, n) or None, cercle with cx moved to the new centre)."""
+    if options['fixed_width'] is None and not options['crop_width_square']:
+        return None, cercle
+    nw = h if options['fixed_width'] is None else options['fixed_width']
+    nw2 = nw // 2
+    cx = w // 2 if cercle == (-1, -1, -1) else int(cercle[0])
+    tx = nw2 - cx
+    lo, hi = max(0, cx - nw2), min(cx + nw2, w)
+    if hi < lo:
+        raise ValueError('crop window [%d, %d) lies outside the %d px wide image' % (cx - nw2, cx + nw2, w))
+    # new_img[:, :hi-lo] = img[:, lo:hi]; then np.roll by tx when tx > 0 and refill the first tx columns (:161-167).
+    # The rolled-in tail is fill colour whenever the copied span fits, which it does: hi - lo <= nw - tx.
+    n = hi - lo
+    dx0 = tx if tx > 0 else 0
+    if dx0 + n > nw:
+        n = nw - dx0            # np.roll would wrap these columns round and the refill overwrite them
+    if not cercle == (-1, -1, -1):
+        cercle = (nw2, cercle[1], cercle[2])
+    return (nw, lo, dx0, n), cercle
+
+
+def _process_images_stepwise(frames, hdr, options, cercle0, borders, basefichs, backup_bounds):
+    """process_images stage by stage (correct_transversalium2_batch, crop_to_width, image_process_batch): the route of
+    de-vignetted frames and of the stubborn transversalium branch."""
     with timing.stage('transversalium'):
         if options['transversalium']:
             if not cercle0 == (-1, -1, -1):

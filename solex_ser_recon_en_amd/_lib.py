@@ -78,6 +78,23 @@ SIGNATURES = {
     'shg_canny_workspace_bytes': (c_size_t, [c_int64, c_int64]),
     'shg_canny_masks_f64': (c_int, [P, c_int64, c_int64, c_double, ctypes.POINTER(c_double), c_int, c_double, c_double, P, P, P,
                                     c_size_t, P]),
+    # ---- stage composites ----
+    'shg_stage_mean_fit_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int64, c_int]),
+    'shg_stage_mean_fit_host_bytes': (c_size_t, [c_int64, c_int64]),
+    'shg_stage_mean_fit': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int64, P, P, c_int64, P, P, P, P, P, P, P, P, c_size_t, P,
+                                   c_size_t, P]),
+    'shg_stage_extract_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int]),
+    'shg_stage_extract': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int64, P, P, c_int, P, c_int64, c_int64, c_int64, c_int64, c_int,
+                                  P, c_size_t, P, c_size_t, P]),
+    'shg_stage_limb_points_workspace_bytes': (c_size_t, [c_int64, c_int64]),
+    'shg_stage_limb_points_host_bytes': (c_size_t, [c_int64, c_int64]),
+    'shg_stage_limb_points': (c_int, [P, c_int64, c_int64, c_int64, P, P, P, c_int64, P, P, c_size_t, P, c_size_t, P]),
+    'shg_stage_limb_fit': (c_int, [P, c_int64, c_int64, c_int64, P, P, P, c_int64, P, P, P, P, P, c_size_t, P, c_size_t, P]),
+    'shg_stage_process_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int64, c_int64, c_int]),
+    'shg_stage_process_host_bytes': (c_size_t, [c_int64, c_int64]),
+    'shg_stage_process_frames': (c_int, [P, c_int64, c_int64, c_int64, c_int64, c_int, P, P, P, c_int64, P, c_int64, c_int64, c_int64,
+                                         c_int64, c_double, c_int, c_int64, c_int64, c_int64, P, c_int64, P, P, P, P, P, c_int64, P, c_size_t,
+                                         P, c_size_t, P]),
     # ---- host control plane (host pointers; numpy arrays are passed by address) ----
     'shg_host_bind_lapack': (c_int, [P]),
     'shg_host_lapack_bound': (c_int, []),
@@ -88,10 +105,13 @@ SIGNATURES = {
     'shg_host_column_plan': (c_int, [P, c_int64, c_int64, P, c_int, P, P, P]),
     'shg_host_flood_threshold': (c_int, [c_double, c_int64, c_int64, c_double, c_double, P, PD]),
     'shg_host_limb_points': (c_int, [P, P, c_int64, c_int64, c_int64, P, PI64]),
+    'shg_host_bind_blas': (c_int, [P, P, P, P, P]),
+    'shg_host_blas_bound': (c_int, []),
     'shg_host_fit_ellipse': (c_int, [P, c_int64, P, PD, PD, PD]),
     'shg_host_correction_matrix': (c_int, [c_double, c_double, P, PD]),
     'shg_host_two_step': (c_int, [P, c_int64, P, PD, PD, PD, P, PI64, P]),
     'shg_host_warp_geometry': (c_int, [c_double, c_double, c_int64, c_int64, P, P, P, PD, PD, PI64, PI64]),
+    'shg_host_limb_geometry': (c_int, [P, c_int64, c_int64, c_int64, P, P, P, PI64, P]),
     'shg_host_chord_bounds': (c_int, [c_double, c_double, c_double, c_double, c_double, c_int64, c_int64, c_int64, P, P]),
     'shg_host_transversalium_factors': (c_int, [P, P, c_int64, c_int64, P, c_int64, c_int, P]),
     'shg_host_percentile_plan': (c_int, [c_int64, c_double, PI64, PI64, PD]),
@@ -123,6 +143,10 @@ def _host_error(status, what):
     if status == -6:
         import numpy
         return numpy.linalg.LinAlgError(msg)
+    if status == -10:
+        return IndexError(msg)
+    if status == -9:
+        return AssertionError(msg)
     if status == -8:
         try:
             from scipy.spatial import QhullError
@@ -134,7 +158,7 @@ def _host_error(status, what):
 
 def check(status, what):
     if status != 0:
-        if -8 <= status <= -4:
+        if -10 <= status <= -4:
             raise _host_error(status, what)
         raise RuntimeError('%s failed (status %d): %s' % (what, status, last_error()))
 
@@ -154,6 +178,11 @@ def _bind_numpy_lapack():
         except (OSError, AttributeError):
             continue
         lib.shg_host_bind_lapack(ctypes.cast(fn, c_void_p))
+        try:                                           # the products, inverses and eigen-decomposition of the limb geometry
+            names = ('scipy_cblas_dgemm64_', 'scipy_cblas_dsyrk64_', 'scipy_cblas_dgemv64_', 'scipy_dgesv_64_', 'scipy_dgeev_64_')
+            lib.shg_host_bind_blas(*[ctypes.cast(getattr(blas, n), c_void_p) for n in names])
+        except AttributeError:
+            pass
         return path
     return None
 

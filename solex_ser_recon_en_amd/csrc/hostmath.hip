@@ -12,9 +12,10 @@
 // polyval) and the least-squares solve is LAPACK's dgelsd itself: _lib.py hands over the address of
 // the routine inside the OpenBLAS that NumPy loaded (shg_host_bind_lapack), called with NumPy's own
 // workspace query.  Without a bound LAPACK a Householder QR solves the same system (same mathematics,
-// last bits may differ).  The limb geometry (ellipse fit, 2x2 algebra) has no bit-exact
-// counterpart in the reference's stack to begin with (lsq-ellipse is unpinned); it is computed in
-// extended precision and agrees with the NumPy restatement to ~1e-12.
+// last bits may differ).  The ellipse fit and the 2x2 correction-matrix algebra stay NumPy calls in the
+// Python layer (limb_fit.two_step, ellipse_to_circle.get_correction_matrix): phi and ratio steer every
+// sample position of the warp, a 1e-12 difference already flips pixels by one grey level, and NumPy's
+// BLAS-backed products cannot be reproduced bit for bit from here.
 //
 // Every function cites the reference lines it replaces.  Compiled with -ffp-contract=off.
 #include <math.h>
@@ -27,6 +28,11 @@
 
 namespace shg {
 namespace host {
+
+// Python's and NumPy's scalar `**` are libm's pow(), whose result is not always the correctly rounded one (x ** 2 can
+// differ from x * x in the last bit); the compiler would fold pow(x, 2.0) into x*x and pow(x, 0.5) into sqrt(x), so
+// the calls that must match the reference go through a volatile pointer.
+static double (*volatile libm_pow)(double, double) = pow;
 
 // ---- LAPACK bridge ---------------------------------------------------------------------------
 // ILP64 Fortran interface of OpenBLAS as NumPy 2.x bundles it (symbol scipy_dgelsd_64_).
@@ -467,236 +473,6 @@ extern "C" int shg_host_limb_points(const int32_t* host_idx, const int32_t* host
     return 0;
 }
 
-// ---- a8: LsqEllipse (Halir & Flusser's numerically stable direct least squares fit) -------------------
-// points[n][2] (first, second coordinate as given).  out: center[2], width, height, phi -- lsq-ellipse 2.0's
-// as_parameters(), ellipse_to_circle.py:57-59.  Extended-precision normal equations: the scatter matrices of pixel
-// coordinates reach 1e18.
-namespace {
-typedef long double ld;
-
-static bool inv3(const ld a[3][3], ld out[3][3]) {
-    const ld c00 = a[1][1] * a[2][2] - a[1][2] * a[2][1], c01 = a[1][2] * a[2][0] - a[1][0] * a[2][2],
-             c02 = a[1][0] * a[2][1] - a[1][1] * a[2][0];
-    const ld det = a[0][0] * c00 + a[0][1] * c01 + a[0][2] * c02;
-    if (det == 0) return false;
-    out[0][0] = c00 / det; out[0][1] = (a[0][2] * a[2][1] - a[0][1] * a[2][2]) / det; out[0][2] = (a[0][1] * a[1][2] - a[0][2] * a[1][1]) / det;
-    out[1][0] = c01 / det; out[1][1] = (a[0][0] * a[2][2] - a[0][2] * a[2][0]) / det; out[1][2] = (a[0][2] * a[1][0] - a[0][0] * a[1][2]) / det;
-    out[2][0] = c02 / det; out[2][1] = (a[0][1] * a[2][0] - a[0][0] * a[2][1]) / det; out[2][2] = (a[0][0] * a[1][1] - a[0][1] * a[1][0]) / det;
-    return true;
-}
-
-static int fit_ellipse(const double* pts, int64_t n, double center[2], double* width, double* height, double* phi) {
-    if (n < 5) { shg::set_error("ellipse fit: %lld limb points (at least 5 needed)", (long long)n); return SHG_E_RUNTIME; }
-    // centre the coordinates for the accumulation (the algebra below is translation covariant: the conic is moved back)
-    ld mx = 0, my = 0;
-    for (int64_t i = 0; i < n; ++i) { mx += pts[2 * i]; my += pts[2 * i + 1]; }
-    mx /= n; my /= n;
-    ld S1[3][3] = {{0}}, S2[3][3] = {{0}}, S3[3][3] = {{0}};
-    for (int64_t i = 0; i < n; ++i) {
-        const ld x = pts[2 * i] - mx, y = pts[2 * i + 1] - my;
-        const ld d1[3] = {x * x, x * y, y * y}, d2[3] = {x, y, 1};
-        for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) { S1[a][b] += d1[a] * d1[b]; S2[a][b] += d1[a] * d2[b]; S3[a][b] += d2[a] * d2[b]; }
-    }
-    ld S3i[3][3];
-    if (!inv3(S3, S3i)) { shg::set_error("Singular matrix"); return SHG_E_LINALG; }
-    // T = -S3^-1 S2^T ;  M = C1^-1 (S1 + S2 T)
-    ld T[3][3], R[3][3], M[3][3];
-    for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) { ld t = 0; for (int c = 0; c < 3; ++c) t += S3i[a][c] * S2[b][c]; T[a][b] = -t; }
-    for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) { ld t = S1[a][b]; for (int c = 0; c < 3; ++c) t += S2[a][c] * T[c][b]; R[a][b] = t; }
-    for (int b = 0; b < 3; ++b) { M[0][b] = R[2][b] / 2; M[1][b] = -R[1][b]; M[2][b] = R[0][b] / 2; }
-    // eigenvalues of M: roots of l^3 - tr l^2 + c1 l - det
-    const ld tr = M[0][0] + M[1][1] + M[2][2];
-    const ld c1 = M[0][0] * M[1][1] - M[0][1] * M[1][0] + M[0][0] * M[2][2] - M[0][2] * M[2][0] + M[1][1] * M[2][2] - M[1][2] * M[2][1];
-    const ld det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
-                   M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
-    // depressed cubic t^3 + p t + q, l = t + tr/3
-    const ld sh = tr / 3;
-    const ld p = c1 - tr * tr / 3, q = -2 * tr * tr * tr / 27 + tr * c1 / 3 - det;
-    ld roots[3];
-    int n_roots = 0;
-    const ld disc = q * q / 4 + p * p * p / 27;
-    if (disc > 0) {
-        const ld sq = sqrtl(disc);
-        roots[n_roots++] = cbrtl(-q / 2 + sq) + cbrtl(-q / 2 - sq) + sh;
-    } else if (p == 0) {
-        roots[n_roots++] = sh;
-    } else {
-        const ld rr = 2 * sqrtl(-p / 3);
-        ld arg = 3 * q / (p * rr);
-        arg = arg > 1 ? 1 : (arg < -1 ? -1 : arg);
-        const ld th = acosl(arg) / 3;
-        for (int k2 = 0; k2 < 3; ++k2) roots[n_roots++] = rr * cosl(th - 2 * (ld)M_PIl * k2 / 3) + sh;
-    }
-    auto charpoly = [&](ld l) { return ((l - tr) * l + c1) * l - det; };
-    auto dchar = [&](ld l) { return (3 * l - 2 * tr) * l + c1; };
-    ld best_a1[3] = {0, 0, 0};
-    bool found = false;
-    for (int r = 0; r < n_roots && !found; ++r) {
-        ld l = roots[r];
-        for (int it = 0; it < 4; ++it) { const ld d = dchar(l); if (d == 0) break; l -= charpoly(l) / d; }    // polish
-        ld A[3][3];
-        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) A[a][b] = M[a][b] - (a == b ? l : 0);
-        // null vector: the largest cross product of two rows
-        ld bestn = -1, v[3] = {0, 0, 0};
-        for (int a = 0; a < 3; ++a)
-            for (int b = a + 1; b < 3; ++b) {
-                const ld cx = A[a][1] * A[b][2] - A[a][2] * A[b][1], cy = A[a][2] * A[b][0] - A[a][0] * A[b][2],
-                         cz = A[a][0] * A[b][1] - A[a][1] * A[b][0];
-                const ld nn = cx * cx + cy * cy + cz * cz;
-                if (nn > bestn) { bestn = nn; v[0] = cx; v[1] = cy; v[2] = cz; }
-            }
-        if (!(bestn > 0)) continue;
-        const ld nv = sqrtl(bestn);
-        for (int a = 0; a < 3; ++a) v[a] /= nv;
-        if (4 * v[0] * v[2] - v[1] * v[1] > 0) { found = true; for (int a = 0; a < 3; ++a) best_a1[a] = v[a]; }
-    }
-    if (!found) { shg::set_error("ellipse fit: no elliptical solution (the limb points do not describe an ellipse)"); return SHG_E_RUNTIME; }
-    ld a2[3];
-    for (int a = 0; a < 3; ++a) { ld t = 0; for (int c = 0; c < 3; ++c) t += T[a][c] * best_a1[c]; a2[a] = t; }
-    // conic in centred coordinates: A x^2 + B xy + C y^2 + D x + E y + F; move back by (mx, my)
-    const ld A_ = best_a1[0], B_ = best_a1[1], C_ = best_a1[2];
-    const ld D_ = a2[0] - 2 * A_ * mx - B_ * my, E_ = a2[1] - 2 * C_ * my - B_ * mx;
-    const ld F_ = a2[2] + A_ * mx * mx + B_ * mx * my + C_ * my * my - a2[0] * mx - a2[1] * my;
-    const ld a = A_, b = B_ / 2, c = C_, d = D_ / 2, f = E_ / 2, g = F_;
-    const ld den = b * b - a * c;
-    const ld x0 = (c * d - b * f) / den, y0 = (a * f - b * d) / den;
-    const ld numerator = 2 * (a * f * f + c * d * d + g * b * b - 2 * b * d * f - a * c * g);
-    const ld root = sqrtl(1 + 4 * b * b / ((a - c) * (a - c)));
-    center[0] = (double)x0;
-    center[1] = (double)y0;
-    *width = (double)sqrtl(numerator / (den * ((c - a) * root - (c + a))));
-    *height = (double)sqrtl(numerator / (den * ((a - c) * root - (c + a))));
-    *phi = (double)(0.5L * atanl((2 * b) / (a - c)));
-    return 0;
-}
-
-static void rot2(double x, double m[2][2]) { m[0][0] = cos(x); m[0][1] = sin(x); m[1][0] = -sin(x); m[1][1] = cos(x); }
-static void mul2(const double a[2][2], const double b[2][2], double o[2][2]) {
-    double t[2][2];
-    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) t[i][j] = a[i][0] * b[0][j] + a[i][1] * b[1][j];
-    memcpy(o, t, sizeof(t));
-}
-static bool inv2(const double a[2][2], double o[2][2]) {
-    const double det = a[0][0] * a[1][1] - a[0][1] * a[1][0];
-    if (det == 0) return false;
-    const double t[2][2] = {{a[1][1] / det, -a[0][1] / det}, {-a[1][0] / det, a[0][0] / det}};
-    memcpy(o, t, sizeof(t));
-    return true;
-}
-}  // namespace
-
-extern "C" int shg_host_fit_ellipse(const double* host_points, int64_t n, double* host_center2, double* width,
-                                    double* height, double* phi) {
-    SHG_REQUIRE(host_points && host_center2 && width && height && phi, SHG_E_ARG, "shg_host_fit_ellipse: null pointer");
-    return fit_ellipse(host_points, n, host_center2, width, height, phi);
-}
-
-// get_correction_matrix(phi, r) (ellipse_to_circle.py:39-50): inverse correction matrix (row major 2x2), theta
-extern "C" int shg_host_correction_matrix(double phi, double r, double* host_inv4, double* theta_out) {
-    SHG_REQUIRE(host_inv4 && theta_out, SHG_E_ARG, "shg_host_correction_matrix: null pointer");
-    double rp[2][2], rm[2][2], st[2][2], dg[2][2] = {{r, 0}, {0, 1}}, rt[2][2], cm[2][2], inv[2][2];
-    rot2(phi, rp);
-    rot2(-phi, rm);
-    mul2(rp, dg, st);
-    mul2(st, rm, st);
-    const double theta = atan(st[1][0] / st[0][0]);
-    rot2(theta, rt);
-    mul2(rt, st, cm);
-    cm[1][0] = 0;
-    const double d = cm[1][1];
-    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) cm[i][j] /= d;
-    if (!inv2(cm, inv)) { shg::set_error("Singular matrix"); return SHG_E_LINALG; }
-    host_inv4[0] = inv[0][0]; host_inv4[1] = inv[0][1]; host_inv4[2] = inv[1][0]; host_inv4[3] = inv[1][1];
-    *theta_out = theta;
-    return 0;
-}
-
-// two_step (ellipse_to_circle.py:62-91): fit, drop the points inside the ellipse by more than the largest outward
-// residual, refit, bring phi within pi/4 of zero.  points[n][2] = (row, col).  kept[n] (may be NULL): 1 for the points
-// of the second fit.  out: center[2] (row, col), height, phi, ratio, outline[100][2] (may be NULL).
-extern "C" int shg_host_two_step(const double* host_points, int64_t n, double* host_center2, double* height_out,
-                                 double* phi_out, double* ratio_out, uint8_t* host_kept, int64_t* n_kept,
-                                 double* host_outline200) {
-    SHG_REQUIRE(host_points && host_center2 && height_out && phi_out && ratio_out && n_kept, SHG_E_ARG, "shg_host_two_step: null pointer");
-    double center[2], width, height, phi;
-    if (int e = fit_ellipse(host_points, n, center, &width, &height, &phi)) return e;
-    double mat[4], theta;
-    if (int e = shg_host_correction_matrix(phi, height / width, mat, &theta)) return e;
-    std::vector<double> values((size_t)n);
-    double vmax = -INFINITY;
-    for (int64_t i = 0; i < n; ++i) {
-        const double dx = host_points[2 * i] - center[0], dy = host_points[2 * i + 1] - center[1];
-        const double xr = (mat[0] * dx + mat[1] * dy) * height, yr = (mat[2] * dx + mat[3] * dy) * height;
-        values[i] = sqrt(xr * xr + yr * yr) - 1;
-        if (values[i] > vmax) vmax = values[i];
-    }
-    std::vector<double> kept;
-    kept.reserve((size_t)n * 2);
-    for (int64_t i = 0; i < n; ++i) {
-        const bool k = values[i] > -vmax;
-        if (host_kept) host_kept[i] = k;
-        if (k) { kept.push_back(host_points[2 * i]); kept.push_back(host_points[2 * i + 1]); }
-    }
-    *n_kept = (int64_t)kept.size() / 2;
-    if (int e = fit_ellipse(kept.data(), *n_kept, center, &width, &height, &phi)) return e;
-    if (host_outline200)
-        for (int i = 0; i < 100; ++i) {                                   // reg.return_fit(n_points=100)
-            const double t = (double)i * (2 * M_PI / 99.0);
-            const double tt = i == 99 ? 2 * M_PI : t;
-            host_outline200[2 * i] = center[0] + width * cos(tt) * cos(phi) - height * sin(tt) * sin(phi);
-            host_outline200[2 * i + 1] = center[1] + width * cos(tt) * sin(phi) + height * sin(tt) * cos(phi);
-        }
-    double ratio = width / height;
-    for (int it = 0; it < 2; ++it) {
-        if (phi > M_PI / 4) { phi -= M_PI / 2; ratio = 1 / ratio; height = height / ratio; }
-        if (phi < -M_PI / 4) { phi += M_PI / 2; ratio = 1 / ratio; height = height / ratio; }
-    }
-    host_center2[0] = center[0];
-    host_center2[1] = center[1];
-    *height_out = height;
-    *phi_out = phi;
-    *ratio_out = ratio;
-    return 0;
-}
-
-// correct_image's geometry (ellipse_to_circle.py:100-122): everything derived from (phi, ratio) and the image shape.
-// out: mat3[9] (row major), inv_mat[4], origin[2], det, theta, out_h, out_w.
-extern "C" int shg_host_warp_geometry(double phi, double ratio, int64_t h, int64_t w, double* host_mat3_9,
-                                      double* host_inv4, double* host_origin2, double* det_out, double* theta_out,
-                                      int64_t* out_h, int64_t* out_w) {
-    SHG_REQUIRE(host_mat3_9 && host_inv4 && host_origin2 && det_out && theta_out && out_h && out_w, SHG_E_ARG,
-                "shg_host_warp_geometry: null pointer");
-    double m4[4];
-    if (int e = shg_host_correction_matrix(phi, ratio, m4, theta_out)) return e;
-    const double mat[2][2] = {{m4[0], m4[1]}, {m4[2], m4[3]}};
-    double inv[2][2];
-    if (!inv2(mat, inv)) { shg::set_error("Singular matrix"); return SHG_E_LINALG; }
-    const double corners[4][2] = {{0, 0}, {0, (double)h}, {(double)w, 0}, {(double)w, (double)h}};
-    double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
-    for (auto& c : corners) {
-        const double x = inv[0][0] * c[0] + inv[0][1] * c[1], y = inv[1][0] * c[0] + inv[1][1] * c[1];
-        xmin = std::min(xmin, x); xmax = std::max(xmax, x); ymin = std::min(ymin, y); ymax = std::max(ymax, y);
-    }
-    const double new_h = ymax - ymin, new_w = xmax - xmin;
-    // mat3 = [[mat, 0], [0, 1]] @ translate(origin)
-    double m3[9] = {mat[0][0], mat[0][1], mat[0][0] * xmin + mat[0][1] * ymin,
-                    mat[1][0], mat[1][1], mat[1][0] * xmin + mat[1][1] * ymin, 0, 0, 1};
-    if (!(m3[3] == 0 && m3[4] == 1 && m3[5] == 0)) {
-        shg::set_error("correct_image: the correction never moves rows (ellipse_to_circle.py:48-49); got row [%g %g %g]", m3[3], m3[4], m3[5]);
-        return SHG_E_RUNTIME;
-    }
-    memcpy(host_mat3_9, m3, sizeof(m3));
-    host_inv4[0] = inv[0][0]; host_inv4[1] = inv[0][1]; host_inv4[2] = inv[1][0]; host_inv4[3] = inv[1][1];
-    host_origin2[0] = xmin; host_origin2[1] = ymin;
-    *det_out = mat[0][0] * mat[1][1] - mat[0][1] * mat[1][0];
-    *out_h = (int64_t)ceil(new_h);
-    *out_w = (int64_t)ceil(new_w);
-    return 0;
-}
-
 // ---- a9: chord bounds of the transversalium rows (solex_util.py:384-391) ---------------------------------
 // xa, xb [max(y2-y1,1)] (entry 0 unused): NumPy-normalised slice [a, b) of row y1+i.
 extern "C" int shg_host_chord_bounds(double cx, double cy, double r, double b0, double b2, int64_t y1, int64_t y2,
@@ -707,7 +483,7 @@ extern "C" int shg_host_chord_bounds(double cx, double cy, double r, double b0, 
     for (int64_t y = y1 + 1; y < y2; ++y) {
         const double v = r * r - ((double)y - cy) * ((double)y - cy);
         if (v < 0) { shg::set_error("transversalium: row outside the disk circle (complex chord length)"); return SHG_E_TYPE; }
-        const double dx = floor(pow(v, 0.5));                         // math.floor((r**2 - (y-cy)**2) ** 0.5)
+        const double dx = floor(shg::host::libm_pow(v, 0.5));                         // math.floor((r**2 - (y-cy)**2) ** 0.5)
         int64_t a = (int64_t)ceil(std::max(cx - dx, b0)), b = (int64_t)floor(std::min(cx + dx, b2));
         a = a < 0 ? std::max<int64_t>(a + w, 0) : std::min(a, w);   // slice(a, b).indices(w)
         b = b < 0 ? std::max<int64_t>(b + w, 0) : std::min(b, w);
@@ -803,3 +579,309 @@ extern "C" int shg_host_percentile_plan(int64_t n, double q, int64_t* rank_lo, i
 }
 
 extern "C" double shg_host_lerp(double a, double b, double gamma) { return np_lerp(a, b, gamma); }
+
+// ---- a8 / a6 / a7: the limb geometry with NumPy's own BLAS / LAPACK calls --------------------------------
+// LsqEllipse().fit (Halir & Flusser), two_step, get_correction_matrix and correct_image's geometry
+// (ellipse_to_circle.py:39-122).  phi and ratio steer every sample position of the warp: a 1e-12 difference
+// already moves pixels by a grey level, so the scatter matrices, the 3x3 inverses and the eigen-decomposition
+// must come out of the very routines NumPy calls, called the way NumPy's matmul / inv / eig call them
+// (umath/matmul.c.src: row-major cblas_dsyrk for A @ A.T, cblas_dgemm with the transposition flags the operand
+// strides imply, cblas_dgemv for a one-column right operand; umath_linalg: dgesv against the identity for inv,
+// dgeev with a workspace query for eig).  shg_host_bind_blas hands over those five entry points of the OpenBLAS
+// NumPy loaded.  What cannot be shared are libm-level transcendentals (cos / sin / arctan of a scalar, which NumPy
+// may serve from SVML): one-ulp differences there change a sample position by ~1e-13 px, far below a grey level.
+namespace shg {
+namespace host {
+
+typedef void (*cblas_dgemm_fn)(int order, int ta, int tb, int64_t m, int64_t n, int64_t k, double alpha, const double* a,
+                               int64_t lda, const double* b, int64_t ldb, double beta, double* c, int64_t ldc);
+typedef void (*cblas_dsyrk_fn)(int order, int uplo, int trans, int64_t n, int64_t k, double alpha, const double* a,
+                               int64_t lda, double beta, double* c, int64_t ldc);
+typedef void (*cblas_dgemv_fn)(int order, int trans, int64_t m, int64_t n, double alpha, const double* a, int64_t lda,
+                               const double* x, int64_t incx, double beta, double* y, int64_t incy);
+typedef void (*dgesv_fn)(const int64_t* n, const int64_t* nrhs, double* a, const int64_t* lda, int64_t* ipiv, double* b,
+                         const int64_t* ldb, int64_t* info);
+typedef void (*dgeev_fn)(const char* jobvl, const char* jobvr, const int64_t* n, double* a, const int64_t* lda, double* wr,
+                         double* wi, double* vl, const int64_t* ldvl, double* vr, const int64_t* ldvr, double* work,
+                         const int64_t* lwork, int64_t* info, size_t, size_t);
+struct Blas {
+    cblas_dgemm_fn gemm;
+    cblas_dsyrk_fn syrk;
+    cblas_dgemv_fn gemv;
+    dgesv_fn gesv;
+    dgeev_fn geev;
+};
+static std::atomic<const Blas*> g_blas{nullptr};
+static Blas g_blas_store;
+
+constexpr int kRowMajor = 101, kColMajor = 102, kNoTrans = 111, kTrans = 112, kUpper = 121;
+
+// A (m x k, row major) @ B.  b_is_transposed_view: B is the .T view of a row-major (n x k) array `b`.
+static void matmul(const Blas& bl, const double* a, const double* b, double* c, int64_t m, int64_t k, int64_t n, bool b_is_transposed_view) {
+    if (b_is_transposed_view) bl.gemm(kRowMajor, kNoTrans, kTrans, m, n, k, 1.0, a, k, b, k, 0.0, c, n);
+    else bl.gemm(kRowMajor, kNoTrans, kNoTrans, m, n, k, 1.0, a, k, b, n, 0.0, c, n);
+}
+
+// A @ A.T for a row-major (n x k) array: NumPy's syrk path, upper triangle mirrored
+static void gram(const Blas& bl, const double* a, double* c, int64_t n, int64_t k) {
+    for (int64_t i = 0; i < n * n; ++i) c[i] = 0.0;
+    bl.syrk(kRowMajor, kUpper, kNoTrans, n, k, 1.0, a, k, 0.0, c, n);
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = i + 1; j < n; ++j) c[j * n + i] = c[i * n + j];
+}
+
+// np.linalg.inv of a row-major n x n matrix (n <= 3)
+static int np_inv(const Blas& bl, const double* a, double* out, int64_t n) {
+    double af[9], bf[9];
+    int64_t ipiv[3], info = 0;
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j < n; ++j) { af[i + j * n] = a[i * n + j]; bf[i + j * n] = i == j ? 1.0 : 0.0; }
+    bl.gesv(&n, &n, af, &n, ipiv, bf, &n, &info);
+    if (info != 0) { set_error("Singular matrix"); return SHG_E_LINALG; }
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j < n; ++j) out[i * n + j] = bf[i + j * n];
+    return 0;
+}
+
+// lsq-ellipse 2.0: LsqEllipse().fit(points).as_parameters() on points[n][2]
+static int fit_ellipse_np(const Blas& bl, const double* pts, int64_t n, double center[2], double* width, double* height, double* phi) {
+    if (n < 1) { set_error("index 0 is out of bounds for axis 0 with size 0"); return SHG_E_INDEX; }
+    std::vector<double> d1((size_t)3 * n), d2((size_t)3 * n);               // np.vstack([...]) : rows x^2, xy, y^2 / x, y, 1
+    for (int64_t i = 0; i < n; ++i) {
+        const double x = pts[2 * i], y = pts[2 * i + 1];
+        d1[i] = x * x; d1[n + i] = x * y; d1[2 * n + i] = y * y;
+        d2[i] = x; d2[n + i] = y; d2[2 * n + i] = 1.0;
+    }
+    double S1[9], S2[9], S3[9], S3i[9], P[9], Q[9], R[9], C1i[9], M[9];
+    gram(bl, d1.data(), S1, 3, n);                                          // D1.T @ D1
+    matmul(bl, d1.data(), d2.data(), S2, 3, n, 3, true);                   // D1.T @ D2
+    gram(bl, d2.data(), S3, 3, n);                                          // D2.T @ D2
+    const double C1[9] = {0., 0., 2., 0., -1., 0., 2., 0., 0.};
+    if (int e = np_inv(bl, S3, S3i, 3)) return e;
+    if (int e = np_inv(bl, C1, C1i, 3)) return e;
+    matmul(bl, S2, S3i, P, 3, 3, 3, false);                                // S2 @ inv(S3)
+    matmul(bl, P, S2, Q, 3, 3, 3, true);                                   // ... @ S2.T
+    for (int i = 0; i < 9; ++i) R[i] = S1[i] - Q[i];
+    matmul(bl, C1i, R, M, 3, 3, 3, false);                                 // inv(C1) @ (...)
+    // np.linalg.eig(M)
+    double af[9], wr[3], wi[3], vr[9], vl[9], wq = 0;
+    int64_t n3 = 3, lwork = -1, info = 0;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) af[i + 3 * j] = M[i * 3 + j];
+    bl.geev("N", "V", &n3, af, &n3, wr, wi, vl, &n3, vr, &n3, &wq, &lwork, &info, 1, 1);
+    if (info != 0) { set_error("eig: workspace query failed"); return SHG_E_LINALG; }
+    lwork = (int64_t)wq;
+    std::vector<double> work((size_t)std::max<int64_t>(lwork, 1));
+    bl.geev("N", "V", &n3, af, &n3, wr, wi, vl, &n3, vr, &n3, work.data(), &lwork, &info, 1, 1);
+    if (info != 0) { set_error("Eigenvalues did not converge"); return SHG_E_LINALG; }
+    if (wi[0] != 0.0 || wi[1] != 0.0 || wi[2] != 0.0) { set_error("ellipse fit: complex eigenvalues (the limb points do not describe an ellipse)"); return SHG_E_RUNTIME; }
+    // eigvec[i][j] = vr[i + 3 j]; cond = 4 * eigvec[0] * eigvec[2] - eigvec[1] ** 2; a1 = eigvec[:, cond > 0]
+    int cols[3], kpos = 0;
+    for (int j = 0; j < 3; ++j) {
+        const double cond = 4 * (vr[0 + 3 * j] * vr[2 + 3 * j]) - libm_pow(vr[1 + 3 * j], 2.0);
+        if (cond > 0) cols[kpos++] = j;
+    }
+    if (kpos == 0) { set_error("index 0 is out of bounds for axis 0 with size 0"); return SHG_E_INDEX; }
+    double a1[9], S3n[9], S3ni[9], T1[9], a2[9];
+    for (int i = 0; i < 3; ++i) for (int c = 0; c < kpos; ++c) a1[i * kpos + c] = vr[i + 3 * cols[c]];
+    for (int i = 0; i < 9; ++i) S3n[i] = -S3[i];
+    if (int e = np_inv(bl, S3n, S3ni, 3)) return e;
+    matmul(bl, S3ni, S2, T1, 3, 3, 3, true);                               // inv(-S3) @ S2.T
+    // ... @ a1: one column -> NumPy's gemv form (the row-major matrix read as column-major and transposed)
+    if (kpos == 1) bl.gemv(kColMajor, kTrans, 3, 3, 1.0, T1, 3, a1, 1, 0.0, a2, 1);
+    else matmul(bl, T1, a1, a2, 3, 3, kpos, false);
+    double coef[6];                                                          // np.vstack([a1, a2]).ravel()[:6]
+    for (int j = 0; j < 6; ++j) { const int r = j / kpos, c = j % kpos; coef[j] = r < 3 ? a1[r * kpos + c] : a2[(r - 3) * kpos + c]; }
+    const double a = coef[0], b = coef[1] / 2., c = coef[2], d = coef[3] / 2., f = coef[4] / 2., g = coef[5];
+    const double x0 = (c * d - b * f) / (libm_pow(b, 2.) - a * c);
+    const double y0 = (a * f - b * d) / (libm_pow(b, 2.) - a * c);
+    const double numerator = 2 * ((((a * libm_pow(f, 2.) + c * libm_pow(d, 2.)) + g * libm_pow(b, 2.)) - 2 * b * d * f) - a * c * g);
+    const double root = sqrt(1 + 4 * b * b / ((a - c) * (a - c)));
+    center[0] = x0;
+    center[1] = y0;
+    *width = sqrt(numerator / ((b * b - a * c) * ((c - a) * root - (c + a))));
+    *height = sqrt(numerator / ((b * b - a * c) * ((a - c) * root - (c + a))));
+    *phi = .5 * atan((2. * b) / (a - c));
+    return 0;
+}
+
+static void rot2(double x, double m[4]) { m[0] = cos(x); m[1] = sin(x); m[2] = -sin(x); m[3] = cos(x); }
+
+// get_correction_matrix(phi, r): (np.linalg.inv(correction_matrix), theta), ellipse_to_circle.py:39-50
+static int correction_matrix_np(const Blas& bl, double phi, double r, double inv4[4], double* theta_out) {
+    double rp[4], rm[4], dg[4] = {r, 0, 0, 1}, t[4], st[4], rt[4], cm[4];
+    rot2(phi, rp);
+    rot2(-phi, rm);
+    matmul(bl, rp, dg, t, 2, 2, 2, false);
+    matmul(bl, t, rm, st, 2, 2, 2, false);
+    const double theta = atan(st[2] / st[0]);
+    rot2(theta, rt);
+    matmul(bl, rt, st, cm, 2, 2, 2, false);
+    cm[2] = 0;
+    const double dd = cm[3];
+    for (int i = 0; i < 4; ++i) cm[i] /= dd;
+    if (int e = np_inv(bl, cm, inv4, 2)) return e;
+    *theta_out = theta;
+    return 0;
+}
+
+}  // namespace host
+}  // namespace shg
+
+extern "C" int shg_host_bind_blas(void* cblas_dgemm_ilp64, void* cblas_dsyrk_ilp64, void* cblas_dgemv_ilp64, void* dgesv_ilp64,
+                                  void* dgeev_ilp64) {
+    if (!cblas_dgemm_ilp64 || !cblas_dsyrk_ilp64 || !cblas_dgemv_ilp64 || !dgesv_ilp64 || !dgeev_ilp64) {
+        g_blas.store(nullptr);
+        return 0;
+    }
+    g_blas_store.gemm = reinterpret_cast<cblas_dgemm_fn>(cblas_dgemm_ilp64);
+    g_blas_store.syrk = reinterpret_cast<cblas_dsyrk_fn>(cblas_dsyrk_ilp64);
+    g_blas_store.gemv = reinterpret_cast<cblas_dgemv_fn>(cblas_dgemv_ilp64);
+    g_blas_store.gesv = reinterpret_cast<dgesv_fn>(dgesv_ilp64);
+    g_blas_store.geev = reinterpret_cast<dgeev_fn>(dgeev_ilp64);
+    g_blas.store(&g_blas_store);
+    return 0;
+}
+
+extern "C" int shg_host_blas_bound(void) { return g_blas.load() != nullptr; }
+
+#define SHG_NEED_BLAS(who)                                                                                                   \
+    const Blas* blp = g_blas.load();                                                                                         \
+    SHG_REQUIRE(blp, SHG_E_UNSUPPORTED, who ": no BLAS / LAPACK bound (shg_host_bind_blas): the limb geometry is computed with " \
+                "the routines NumPy itself calls");                                                                         \
+    const Blas& bl = *blp
+
+extern "C" int shg_host_fit_ellipse(const double* host_points, int64_t n, double* host_center2, double* width, double* height,
+                                    double* phi) {
+    SHG_REQUIRE(host_points && host_center2 && width && height && phi, SHG_E_ARG, "shg_host_fit_ellipse: null pointer");
+    SHG_NEED_BLAS("shg_host_fit_ellipse");
+    return fit_ellipse_np(bl, host_points, n, host_center2, width, height, phi);
+}
+
+extern "C" int shg_host_correction_matrix(double phi, double r, double* host_inv4, double* theta_out) {
+    SHG_REQUIRE(host_inv4 && theta_out, SHG_E_ARG, "shg_host_correction_matrix: null pointer");
+    SHG_NEED_BLAS("shg_host_correction_matrix");
+    return correction_matrix_np(bl, phi, r, host_inv4, theta_out);
+}
+
+// two_step (ellipse_to_circle.py:62-91): fit, drop the points inside the ellipse by more than the largest outward
+// residual, refit, bring phi within pi/4 of zero.  points[n][2] = (row, col).  kept[n] (may be NULL): 1 for the points of the
+// second fit.  out: center[2] (row, col), height, phi, ratio, outline200 = return_fit(n_points=100) (may be NULL).
+extern "C" int shg_host_two_step(const double* host_points, int64_t n, double* host_center2, double* height_out, double* phi_out,
+                                 double* ratio_out, uint8_t* host_kept, int64_t* n_kept, double* host_outline200) {
+    SHG_REQUIRE(host_points && host_center2 && height_out && phi_out && ratio_out && n_kept, SHG_E_ARG, "shg_host_two_step: null pointer");
+    SHG_NEED_BLAS("shg_host_two_step");
+    double center[2], width, height, phi, mat[4], theta;
+    if (int e = fit_ellipse_np(bl, host_points, n, center, &width, &height, &phi)) return e;
+    if (int e = correction_matrix_np(bl, phi, height / width, mat, &theta)) return e;
+    std::vector<double> values((size_t)n);
+    double vmax = -INFINITY;
+    for (int64_t i = 0; i < n; ++i) {                                     // Xr = mat @ (points - center).T * height; norm - 1
+        const double dx = host_points[2 * i] - center[0], dy = host_points[2 * i + 1] - center[1];
+        const double xr = (mat[0] * dx + mat[1] * dy) * height, yr = (mat[2] * dx + mat[3] * dy) * height;
+        values[i] = sqrt(xr * xr + yr * yr) - 1;
+        if (values[i] > vmax) vmax = values[i];
+    }
+    std::vector<double> kept;
+    kept.reserve((size_t)n * 2);
+    for (int64_t i = 0; i < n; ++i) {
+        const bool k = values[i] > -vmax;
+        if (host_kept) host_kept[i] = k;
+        if (k) { kept.push_back(host_points[2 * i]); kept.push_back(host_points[2 * i + 1]); }
+    }
+    *n_kept = (int64_t)kept.size() / 2;
+    if (int e = fit_ellipse_np(bl, kept.data(), *n_kept, center, &width, &height, &phi)) return e;
+    if (host_outline200) {
+        const double step = (2 * M_PI - 0.0) / 99.0;                         // np.linspace(0, 2 * np.pi, 100)
+        for (int i = 0; i < 100; ++i) {
+            const double t = i == 99 ? 2 * M_PI : (double)i * step + 0.0;
+            host_outline200[2 * i] = center[0] + width * cos(t) * cos(phi) - height * sin(t) * sin(phi);
+            host_outline200[2 * i + 1] = center[1] + width * cos(t) * sin(phi) + height * sin(t) * cos(phi);
+        }
+    }
+    double ratio = width / height;
+    for (int it = 0; it < 2; ++it) {
+        if (phi > M_PI / 4) { phi -= M_PI / 2; ratio = 1 / ratio; height = height / ratio; }
+        if (phi < -M_PI / 4) { phi += M_PI / 2; ratio = 1 / ratio; height = height / ratio; }
+    }
+    host_center2[0] = center[0];
+    host_center2[1] = center[1];
+    *height_out = height;
+    *phi_out = phi;
+    *ratio_out = ratio;
+    return 0;
+}
+
+// correct_image's geometry (ellipse_to_circle.py:100-122): mat3[9] (row major), inv_mat[4], origin[2], det, theta,
+// out_h, out_w for an h x w image.
+extern "C" int shg_host_warp_geometry(double phi, double ratio, int64_t h, int64_t w, double* host_mat3_9, double* host_inv4,
+                                      double* host_origin2, double* det_out, double* theta_out, int64_t* out_h, int64_t* out_w) {
+    SHG_REQUIRE(host_mat3_9 && host_inv4 && host_origin2 && det_out && theta_out && out_h && out_w, SHG_E_ARG,
+                "shg_host_warp_geometry: null pointer");
+    SHG_NEED_BLAS("shg_host_warp_geometry");
+    double mat[4], inv[4];
+    if (int e = correction_matrix_np(bl, phi, ratio, mat, theta_out)) return e;
+    if (int e = np_inv(bl, mat, inv, 2)) return e;
+    const double corners[8] = {0, 0, 0, (double)h, (double)w, 0, (double)w, (double)h};        // [4][2]
+    double nc[8];                                                                                // (inv_mat @ corners.T) as [2][4]
+    matmul(bl, inv, corners, nc, 2, 2, 4, true);
+    double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+    for (int i = 0; i < 4; ++i) {
+        xmin = std::min(xmin, nc[i]); xmax = std::max(xmax, nc[i]);
+        ymin = std::min(ymin, nc[4 + i]); ymax = std::max(ymax, nc[4 + i]);
+    }
+    const double m3[9] = {mat[0], mat[1], 0, mat[2], mat[3], 0, 0, 0, 1};
+    const double tr[9] = {1, 0, xmin, 0, 1, ymin, 0, 0, 1};
+    matmul(bl, m3, tr, host_mat3_9, 3, 3, 3, false);
+    if (!(host_mat3_9[3] == 0 && host_mat3_9[4] == 1 && host_mat3_9[5] == 0 && host_mat3_9[6] == 0 && host_mat3_9[7] == 0 && host_mat3_9[8] == 1)) {
+        shg::set_error("correct_image: the correction never moves rows (ellipse_to_circle.py:48-49); got rows [%g %g %g] [%g %g %g]",
+                       host_mat3_9[3], host_mat3_9[4], host_mat3_9[5], host_mat3_9[6], host_mat3_9[7], host_mat3_9[8]);
+        return SHG_E_RUNTIME;
+    }
+    for (int i = 0; i < 4; ++i) host_inv4[i] = inv[i];
+    host_origin2[0] = xmin;
+    host_origin2[1] = ymin;
+    *det_out = mat[0] * mat[3] - mat[1] * mat[2];
+    *out_h = (int64_t)ceil(ymax - ymin);
+    *out_w = (int64_t)ceil(xmax - xmin);
+    return 0;
+}
+
+// ellipse_to_circle after get_edge_list (ellipse_to_circle.py:303-314): two_step on the limb points X (row, col in disk
+// pixels), correct_image's geometry for the h x w disk, the circle of the corrected image and the borders of the kept
+// points.  host_geom16 = ellipse centre x, y, height, phi, ratio | circle cx, cy, r | borders[4] | mat3 row 0 (h00, h01,
+// h02) | theta.  host_dims2 = (out_h, out_w).  host_kept [n] and host_outline200 may be NULL.
+extern "C" int shg_host_limb_geometry(const double* host_points, int64_t n, int64_t h, int64_t w, double* host_geom16,
+                                      int64_t* host_dims2, uint8_t* host_kept, int64_t* n_kept, double* host_outline200) {
+    SHG_REQUIRE(host_points && host_geom16 && host_dims2 && n_kept, SHG_E_ARG, "shg_host_limb_geometry: null pointer");
+    SHG_NEED_BLAS("shg_host_limb_geometry");
+    std::vector<uint8_t> kept_local;
+    if (!host_kept) { kept_local.resize((size_t)std::max<int64_t>(n, 1)); host_kept = kept_local.data(); }
+    double center[2], height, phi, ratio;
+    if (int e = shg_host_two_step(host_points, n, center, &height, &phi, &ratio, host_kept, n_kept, host_outline200)) return e;
+    double mat3[9], inv[4], origin[2], det, theta;
+    if (int e = shg_host_warp_geometry(phi, ratio, h, w, mat3, inv, origin, &det, &theta, &host_dims2[0], &host_dims2[1])) return e;
+    const double cxy[2] = {center[1], center[0]};                             // (x, y): the swap at :305
+    double nc[2];
+    bl.gemv(kColMajor, kTrans, 2, 2, 1.0, inv, 2, cxy, 1, 0.0, nc, 1);       // inv_mat @ center
+    double* g = host_geom16;
+    g[0] = cxy[0]; g[1] = cxy[1]; g[2] = height; g[3] = phi; g[4] = ratio;
+    g[5] = nc[0] - origin[0];
+    g[6] = nc[1] - origin[1];
+    g[7] = height * sqrt(fabs(ratio / det));
+    // borders: (np.linalg.inv(mat3) @ X_f3.T).T over the kept points, X_f3 = (x, y, 1)
+    double inv3[9];
+    if (int e = np_inv(bl, mat3, inv3, 3)) return e;
+    const int64_t m = *n_kept;
+    std::vector<double> xf3((size_t)std::max<int64_t>(m, 1) * 3), tr((size_t)std::max<int64_t>(m, 1) * 3);
+    for (int64_t i = 0, j = 0; i < n; ++i)
+        if (host_kept[i]) { xf3[3 * j] = host_points[2 * i + 1]; xf3[3 * j + 1] = host_points[2 * i]; xf3[3 * j + 2] = 1.0; ++j; }
+    matmul(bl, inv3, xf3.data(), tr.data(), 3, 3, m, true);                  // [3][m]
+    double bx0 = INFINITY, by0 = INFINITY, bx1 = -INFINITY, by1 = -INFINITY;
+    for (int64_t j = 0; j < m; ++j) {
+        bx0 = std::min(bx0, tr[j]); bx1 = std::max(bx1, tr[j]);
+        by0 = std::min(by0, tr[m + j]); by1 = std::max(by1, tr[m + j]);
+    }
+    g[8] = bx0; g[9] = by0; g[10] = bx1; g[11] = by1;
+    g[12] = mat3[0]; g[13] = mat3[1]; g[14] = mat3[2]; g[15] = theta;
+    return 0;
+}

@@ -1,0 +1,472 @@
+// Stage composites: each stage function of the reference as ONE C call.
+//
+//   shg_stage_mean_fit        compute_mean_return_fit     solex_util.py:191-259
+//   shg_stage_extract         read_video_improved         solex_util.py:93-144
+//   shg_stage_limb_points     get_edge_list               ellipse_to_circle.py:231-291 (+ downscale :299-302)
+//   shg_stage_limb_fit        ellipse_to_circle's fit     ellipse_to_circle.py:294-314 (the above + two_step, geometry, borders)
+//   shg_stage_process_frames  single_image_process        Solex_recon.py:136-174 (transversalium, crop, image_process)
+//
+// A stage launches its kernels on the caller's stream, brings the few scalars / 1-D vectors the control plane
+// needs to the host through pinned memory, runs that control plane in C++ (hostmath.hip) and goes on -- the same
+// kernels in the same order as the step-by-step entry points, which stay exported (tests, rare option branches).
+// What changes is who sits between the kernels: no interpreter, hence no interpreter lock, so the scan workers of
+// Solex_recon.solex_do_work really run side by side.  The caller owns every buffer: a device workspace and a
+// pinned host staging area, both sized by the *_bytes queries, and the outputs.
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "shg_common.h"
+
+namespace {
+
+constexpr size_t kAlign = 256;
+inline size_t up(size_t b) { return (b + kAlign - 1) / kAlign * kAlign; }
+
+struct Arena {
+    char* base;
+    size_t cap, off;
+    Arena(void* p, size_t bytes) : base(static_cast<char*>(p)), cap(bytes), off(0) {}
+    template <typename T>
+    T* take(size_t count) {
+        const size_t b = up(count * sizeof(T));
+        if (!base || off + b > cap) return nullptr;
+        T* p = reinterpret_cast<T*>(base + off);
+        off += b;
+        return p;
+    }
+};
+
+#define STAGE_TRY(expr)            \
+    do {                           \
+        if (int e_ = (expr)) return e_; \
+    } while (0)
+
+#define STAGE_HIP(expr, who)                                               \
+    do {                                                                   \
+        hipError_t he_ = (expr);                                           \
+        if (he_ != hipSuccess) {                                           \
+            shg::set_error("%s: %s", who, hipGetErrorString(he_));         \
+            return (int)he_;                                               \
+        }                                                                  \
+    } while (0)
+
+inline int64_t slit_rows(int64_t height, int64_t width) { return width > height ? width : height; }
+inline int64_t spectral_cols(int64_t height, int64_t width) { return width > height ? height : width; }
+
+}  // namespace
+
+// ---- compute_mean_return_fit ------------------------------------------------------------------
+extern "C" size_t shg_stage_mean_fit_workspace_bytes(int64_t n_frames, int64_t height, int64_t width, int bytes_per_px) {
+    if (height <= 0 || width <= 0) return 0;
+    const size_t hw = (size_t)height * (size_t)width, ih = (size_t)slit_rows(height, width);
+    const size_t acc = n_frames > 0 ? shg_accumulate_workspace_bytes(n_frames, height, width, bytes_per_px) : 0;
+    return up(acc) + up(hw * 8) + up(hw * 2) + up(hw * 2) + up(hw * 4) + up(ih * 8) + up(2 * ih * 4) + kAlign;
+}
+
+extern "C" size_t shg_stage_mean_fit_host_bytes(int64_t height, int64_t width) {
+    if (height <= 0 || width <= 0) return 0;
+    const size_t ih = (size_t)slit_rows(height, width);
+    return up(ih * 8) + up(2 * ih * 4);
+}
+
+extern "C" int shg_stage_mean_fit(const void* stack, int64_t n_frames, int64_t height, int64_t width, int bytes_per_px,
+                                  int64_t frame_stride_px, const uint64_t* sum_in, const uint16_t* max_in, int64_t n_total,
+                                  uint16_t* mean_out, uint16_t* max_out, int64_t* host_y12, double* host_p4, double* host_fit,
+                                  int32_t* host_trace_sharp, uint8_t* host_mask_good, void* workspace, size_t workspace_bytes,
+                                  void* host_pinned, size_t host_pinned_bytes, shg_stream_t stream) {
+    SHG_REQUIRE(mean_out && max_out && host_y12 && host_p4 && host_fit && workspace && host_pinned, SHG_E_ARG,
+                "shg_stage_mean_fit: null pointer");
+    SHG_REQUIRE((sum_in == nullptr) == (max_in == nullptr), SHG_E_ARG, "shg_stage_mean_fit: sum_in and max_in go together");
+    SHG_REQUIRE(sum_in || stack, SHG_E_ARG, "shg_stage_mean_fit: neither a stack nor its sums");
+    SHG_REQUIRE(height > 0 && width > 0 && n_total > 0, SHG_E_ARG, "shg_stage_mean_fit: empty input");
+    const int64_t ih = slit_rows(height, width), iw = spectral_cols(height, width);
+    const size_t hw = (size_t)height * (size_t)width;
+    hipStream_t st = shg::as_stream(stream);
+    Arena dev(workspace, workspace_bytes), pin(host_pinned, host_pinned_bytes);
+    const size_t acc_bytes = sum_in ? 0 : shg_accumulate_workspace_bytes(n_frames, height, width, bytes_per_px);
+    char* acc_ws = dev.take<char>(acc_bytes ? acc_bytes : 1);
+    uint64_t* sum = dev.take<uint64_t>(hw);
+    uint16_t* mx = dev.take<uint16_t>(hw);
+    uint16_t* blur = dev.take<uint16_t>(hw);
+    uint32_t* tmp = dev.take<uint32_t>(hw);
+    double* row_means = dev.take<double>((size_t)ih);
+    int32_t* traces = dev.take<int32_t>(2 * (size_t)ih);
+    double* h_means = pin.take<double>((size_t)ih);
+    int32_t* h_traces = pin.take<int32_t>(2 * (size_t)ih);
+    SHG_REQUIRE(acc_ws && sum && mx && blur && tmp && row_means && traces, SHG_E_WORKSPACE, "shg_stage_mean_fit: workspace too small");
+    SHG_REQUIRE(h_means && h_traces, SHG_E_WORKSPACE, "shg_stage_mean_fit: pinned staging area too small");
+
+    if (!sum_in) {                                                                            // solex_util.py:174-188
+        STAGE_TRY(shg_accumulate_sum_max(stack, n_frames, height, width, bytes_per_px, frame_stride_px, sum, mx, acc_ws, acc_bytes, stream));
+        sum_in = sum;
+        max_in = mx;
+    }
+    STAGE_TRY(shg_finalize_mean_max(sum_in, max_in, n_total, height, width, bytes_per_px, mean_out, max_out, stream));
+    // detect_bord(max_img, axis=1) (:223, :165-172)
+    STAGE_TRY(shg_box_blur_u16(max_out, ih, iw, 5, 5, blur, tmp, stream));
+    STAGE_TRY(shg_row_mean_u16(blur, ih, iw, row_means, stream));
+    STAGE_HIP(hipMemcpyAsync(h_means, row_means, (size_t)ih * 8, hipMemcpyDeviceToHost, st), "shg_stage_mean_fit");
+    STAGE_HIP(hipStreamSynchronize(st), "shg_stage_mean_fit");
+    int64_t y1, y2;
+    STAGE_TRY(shg_host_detect_bord(h_means, ih, &y1, &y2));
+    const int64_t clip = (int64_t)((double)(y2 - y1) * 0.05);                                 // :224-226
+    y1 = std::min(ih - 1, y1 + clip);
+    y2 = std::max<int64_t>(0, y2 - clip);
+    host_y12[0] = y1;
+    host_y12[1] = y2;
+    const int blur_w = 25, blur_h = (int)((double)(y2 - y1) * 0.01);                          // :228-229
+    // a zero blur height (sunlit span <= 100 rows) fails here, as cv2.blur does in the reference (:230)
+    STAGE_TRY(shg_box_blur_u16(mean_out, ih, iw, blur_w, blur_h, blur, tmp, stream));
+    const int64_t lo = blur_w / 2, hi = iw + (-(blur_w + 1) / 2);                             // blur[:, 12:-13]  (-25 // 2 == -13)
+    STAGE_TRY(shg_row_argmin_u16(blur, ih, iw, lo, hi, traces, stream));
+    STAGE_TRY(shg_row_argmin_u16(mean_out, ih, iw, 0, iw, traces + ih, stream));
+    STAGE_HIP(hipMemcpyAsync(h_traces, traces, 2 * (size_t)ih * 4, hipMemcpyDeviceToHost, st), "shg_stage_mean_fit");
+    STAGE_HIP(hipStreamSynchronize(st), "shg_stage_mean_fit");
+    if (host_trace_sharp) memcpy(host_trace_sharp, h_traces + ih, (size_t)ih * 4);
+    return shg_host_line_fit(h_traces, h_traces + ih, ih, y1, y2, (int32_t)lo, host_p4, host_fit, host_mask_good);
+}
+
+// ---- read_video_improved -----------------------------------------------------------------------
+extern "C" size_t shg_stage_extract_workspace_bytes(int64_t height, int64_t width, int n_shifts) {
+    if (height <= 0 || width <= 0 || n_shifts <= 0) return 0;
+    const size_t ih = (size_t)slit_rows(height, width);
+    return up((size_t)n_shifts * ih * 4) + up(2 * ih * 8);
+}
+
+extern "C" int shg_stage_extract(const void* stack, int64_t n_frames, int64_t height, int64_t width, int bytes_per_px,
+                                 int64_t frame_stride_px, const double* host_fit, const int32_t* host_shifts, int n_shifts,
+                                 uint16_t* disks, int64_t row_pitch, int64_t plane_stride, int64_t n_cols, int64_t k_offset,
+                                 int flip_x, void* workspace, size_t workspace_bytes, void* host_pinned, size_t host_pinned_bytes,
+                                 shg_stream_t stream) {
+    SHG_REQUIRE(stack && host_fit && host_shifts && disks && workspace && host_pinned, SHG_E_ARG, "shg_stage_extract: null pointer");
+    SHG_REQUIRE(height > 0 && width > 0 && n_shifts > 0, SHG_E_ARG, "shg_stage_extract: empty input");
+    const int64_t ih = slit_rows(height, width), iw = spectral_cols(height, width);
+    Arena dev(workspace, workspace_bytes), pin(host_pinned, host_pinned_bytes);
+    int32_t* ind_l = dev.take<int32_t>((size_t)n_shifts * ih);
+    double* w2 = dev.take<double>(2 * (size_t)ih);
+    int32_t* h_ind = pin.take<int32_t>((size_t)n_shifts * ih);
+    double* h_w2 = pin.take<double>(2 * (size_t)ih);
+    SHG_REQUIRE(ind_l && w2, SHG_E_WORKSPACE, "shg_stage_extract: workspace too small");
+    SHG_REQUIRE(h_ind && h_w2, SHG_E_WORKSPACE, "shg_stage_extract: pinned staging area too small");
+    STAGE_TRY(shg_host_column_plan(host_fit, ih, iw, host_shifts, n_shifts, h_ind, h_w2, h_w2 + ih));
+    hipStream_t st = shg::as_stream(stream);
+    STAGE_HIP(hipMemcpyAsync(ind_l, h_ind, (size_t)n_shifts * ih * 4, hipMemcpyHostToDevice, st), "shg_stage_extract");
+    STAGE_HIP(hipMemcpyAsync(w2, h_w2, 2 * (size_t)ih * 8, hipMemcpyHostToDevice, st), "shg_stage_extract");
+    return shg_extract_columns(stack, n_frames, height, width, bytes_per_px, frame_stride_px, ind_l, w2, w2 + ih, n_shifts, disks,
+                               row_pitch, plane_stride, n_cols, k_offset, flip_x, stream);
+}
+
+// ---- ellipse_to_circle: limb detection and fit --------------------------------------------------------
+namespace {
+constexpr int kFactor = 4;                 // downscale_local_mean(image, (4, 4)), ellipse_to_circle.py:299-301
+constexpr int64_t kPrefetch = 16384;       // edge pixels fetched with the count (a limb has ~1500)
+inline int64_t small_dim(int64_t v) { return (v + kFactor - 1) / kFactor; }
+}  // namespace
+
+extern "C" size_t shg_stage_limb_points_workspace_bytes(int64_t h, int64_t w) {
+    if (h <= 0 || w <= 0) return 0;
+    const int64_t sh = small_dim(h), sw = small_dim(w);
+    const size_t n = (size_t)sh * (size_t)sw;
+    return 4 * up(n * 8) + up(shg_select_workspace_bytes(4)) + up(4 * 8) + up(3 * 8) + up(20 * 4) + up(32) + up(32 * 8) + 2 * up(n) +
+           up(shg_canny_workspace_bytes(sh, sw)) + up(shg_edge_components_workspace_bytes(sh, sw)) + up((2 * n + 1) * 4) + kAlign;
+}
+
+extern "C" size_t shg_stage_limb_points_host_bytes(int64_t h, int64_t w) {
+    if (h <= 0 || w <= 0) return 0;
+    const size_t n = (size_t)small_dim(h) * (size_t)small_dim(w);
+    return up(32 * 8) + up((2 * n + 1) * 4);
+}
+
+// disk: the raw uint16 disk [h][w].  host_gauss_taps: scipy's Gaussian taps for sigma = 2, 1.5, 1, 0.5 (17, 13, 9, 5
+// values, packed one after the other) -- canny's retry ladder (ellipse_to_circle.py:245-256).
+// out: host_points int32 [points_cap][2]: the edge pixels (row, col) of the quarter-size image in raster order;
+//      host_flags [points_cap]: 1 = limb point (get_edge_list's X); host_counts2 = edge pixels, limb points.
+// points_cap < the number of edge pixels: SHG_E_WORKSPACE (ceil(h/4) * ceil(w/4) always suffices).
+extern "C" int shg_stage_limb_points(const uint16_t* disk, int64_t h, int64_t w, int64_t pitch, const double* host_gauss_taps,
+                                     int32_t* host_points, uint8_t* host_flags, int64_t points_cap, int64_t* host_counts2,
+                                     void* workspace, size_t workspace_bytes, void* host_pinned, size_t host_pinned_bytes,
+                                     shg_stream_t stream) {
+    SHG_REQUIRE(disk && host_gauss_taps && host_points && host_flags && host_counts2 && workspace && host_pinned, SHG_E_ARG,
+                "shg_stage_limb_points: null pointer");
+    SHG_REQUIRE(h > 0 && w > 0 && pitch >= w, SHG_E_ARG, "shg_stage_limb_points: bad image size");
+    const int64_t sh = small_dim(h), sw = small_dim(w);
+    const int64_t n = sh * sw;
+    const int k = (int)((double)sh * 0.01);                                                  // cv2.blur kernel, :163
+    if (k <= 0) {
+        shg::set_error("ellipse fit: the scan needs at least 400 slit rows (cv2.blur kernel int(0.01 * h/4) = 0)");
+        return SHG_E_RUNTIME;
+    }
+    hipStream_t st = shg::as_stream(stream);
+    Arena dev(workspace, workspace_bytes), pin(host_pinned, host_pinned_bytes);
+    double* small = dev.take<double>((size_t)n);
+    double* blurred = dev.take<double>((size_t)n);
+    double* blur5 = dev.take<double>((size_t)n);
+    double* tmp = dev.take<double>((size_t)n);
+    const size_t sel_bytes = shg_select_workspace_bytes(4);
+    char* sel_ws = dev.take<char>(sel_bytes);
+    double* packed = dev.take<double>(32);                 // [0..3] order statistics, [4..6] flood stats
+    uint32_t* counts = dev.take<uint32_t>(20);
+    char* flood_ws = dev.take<char>(32);
+    uint8_t* low_mask = dev.take<uint8_t>((size_t)n);
+    uint8_t* high_mask = dev.take<uint8_t>((size_t)n);
+    const size_t canny_bytes = shg_canny_workspace_bytes(sh, sw), cc_bytes = shg_edge_components_workspace_bytes(sh, sw);
+    char* canny_ws = dev.take<char>(canny_bytes);
+    char* cc_ws = dev.take<char>(cc_bytes);
+    int32_t* comp = dev.take<int32_t>(2 * (size_t)n + 1);  // [count | idx[n] | root[n]]
+    double* h_packed = pin.take<double>(32);
+    int32_t* h_comp = pin.take<int32_t>(2 * (size_t)n + 1);
+    SHG_REQUIRE(small && blurred && blur5 && tmp && sel_ws && packed && counts && flood_ws && low_mask && high_mask && canny_ws && cc_ws && comp,
+                SHG_E_WORKSPACE, "shg_stage_limb_points: workspace too small");
+    SHG_REQUIRE(h_packed && h_comp, SHG_E_WORKSPACE, "shg_stage_limb_points: pinned staging area too small");
+
+    STAGE_TRY(shg_downscale_mean_u16(disk, h, w, pitch, kFactor, small, stream));
+    STAGE_TRY(shg_box_blur_f64(small, sh, sw, k, blurred, tmp, stream));
+    STAGE_TRY(shg_box_blur_f64(small, sh, sw, 5, blur5, tmp, stream));
+    // np.median(blur 5x5) (:241) and np.percentile(blurred, 99) (:165): their order statistics
+    int64_t ranks[4];
+    double gamma99;
+    ranks[0] = (n & 1) ? n / 2 : n / 2 - 1;
+    ranks[1] = n / 2;
+    STAGE_TRY(shg_host_percentile_plan(n, 99.0, &ranks[2], &ranks[3], &gamma99));
+    const double* arrays[4] = {blur5, blur5, blurred, blurred};
+    STAGE_TRY(shg_select_multi_f64(arrays, n, ranks, 4, packed, sel_ws, sel_bytes, stream));
+    STAGE_TRY(shg_flood_stats_lerp_f64(small, blurred, n, packed + 2, gamma99, packed + 4, counts, flood_ws, stream));
+    STAGE_HIP(hipMemcpyAsync(h_packed, packed, 7 * 8, hipMemcpyDeviceToHost, st), "shg_stage_limb_points");
+    STAGE_HIP(hipMemcpyAsync(h_packed + 8, counts, 20 * 4, hipMemcpyDeviceToHost, st), "shg_stage_limb_points");
+    STAGE_HIP(hipStreamSynchronize(st), "shg_stage_limb_points");
+    const double median5 = (n & 1) ? h_packed[0] : (h_packed[0] + h_packed[1]) / 2;
+    const double low = median5 / 10, high = low * 1.5;                                       // :241-243
+    int64_t counts64[20];
+    const uint32_t* hc = reinterpret_cast<const uint32_t*>(h_packed + 8);
+    for (int i = 0; i < 20; ++i) counts64[i] = hc[i];
+    double thresh3;
+    STAGE_TRY(shg_host_flood_threshold(h_packed[4], sh, sw, h_packed[5], h_packed[6], counts64, &thresh3));
+
+    int64_t m = 0;
+    const double* taps = host_gauss_taps;
+    for (int rung = 0;; ++rung) {                                                             // sigma = 2, 1.5, 1, 0.5
+        if (rung == 4) { shg::set_error("ellipse fit: could not find any edges of the solar disk"); return SHG_E_RUNTIME; }
+        const double sigma = 2.0 - 0.5 * rung;
+        const int radius = (int)(4.0 * sigma + 0.5);
+        STAGE_TRY(shg_canny_masks_f64(blurred, sh, sw, thresh3, taps, radius, low, high, low_mask, high_mask, canny_ws, canny_bytes, stream));
+        STAGE_TRY(shg_edge_components(low_mask, high_mask, sh, sw, comp + 1, comp + 1 + n, comp, cc_ws, cc_bytes, stream));
+        const int64_t pre = std::min(kPrefetch, n);
+        STAGE_HIP(hipMemcpyAsync(h_comp, comp, (size_t)(1 + pre) * 4, hipMemcpyDeviceToHost, st), "shg_stage_limb_points");
+        STAGE_HIP(hipMemcpyAsync(h_comp + 1 + n, comp + 1 + n, (size_t)pre * 4, hipMemcpyDeviceToHost, st), "shg_stage_limb_points");
+        STAGE_HIP(hipStreamSynchronize(st), "shg_stage_limb_points");
+        m = h_comp[0];
+        if (m > pre) {
+            STAGE_HIP(hipMemcpyAsync(h_comp + 1 + pre, comp + 1 + pre, (size_t)(m - pre) * 4, hipMemcpyDeviceToHost, st), "shg_stage_limb_points");
+            STAGE_HIP(hipMemcpyAsync(h_comp + 1 + n + pre, comp + 1 + n + pre, (size_t)(m - pre) * 4, hipMemcpyDeviceToHost, st), "shg_stage_limb_points");
+            STAGE_HIP(hipStreamSynchronize(st), "shg_stage_limb_points");
+        }
+        if (m > 0) break;
+        taps += 2 * radius + 1;                                                               // try again with less blur (:254-256)
+    }
+    const int32_t* idx = h_comp + 1;
+    const int32_t* root = h_comp + 1 + n;
+    SHG_REQUIRE(points_cap >= m, SHG_E_WORKSPACE, "shg_stage_limb_points: %lld edge pixels, room for %lld", (long long)m, (long long)points_cap);
+    int64_t n_sel = 0;
+    STAGE_TRY(shg_host_limb_points(idx, root, m, sh, sw, host_flags, &n_sel));
+    for (int64_t i = 0; i < m; ++i) {
+        host_points[2 * i] = idx[i] / (int32_t)sw;
+        host_points[2 * i + 1] = idx[i] % (int32_t)sw;
+    }
+    host_counts2[0] = m;
+    host_counts2[1] = n_sel;
+    return 0;
+}
+
+// ellipse_to_circle without its warp (ellipse_to_circle.py:294-314): shg_stage_limb_points, then the two-step ellipse
+// fit, correct_image's geometry and the borders (shg_host_limb_geometry; NumPy's own BLAS / LAPACK routines).
+// host_points / host_flags as shg_stage_limb_points, flag bit 1 = kept by two_step; host_counts3 = edge pixels, limb
+// points, kept points; host_geom16 / host_dims2 / host_outline200 as shg_host_limb_geometry.
+extern "C" int shg_stage_limb_fit(const uint16_t* disk, int64_t h, int64_t w, int64_t pitch, const double* host_gauss_taps,
+                                  int32_t* host_points, uint8_t* host_flags, int64_t points_cap, int64_t* host_counts3,
+                                  double* host_geom16, int64_t* host_dims2, double* host_outline200, void* workspace,
+                                  size_t workspace_bytes, void* host_pinned, size_t host_pinned_bytes, shg_stream_t stream) {
+    SHG_REQUIRE(host_counts3 && host_geom16 && host_dims2, SHG_E_ARG, "shg_stage_limb_fit: null pointer");
+    STAGE_TRY(shg_stage_limb_points(disk, h, w, pitch, host_gauss_taps, host_points, host_flags, points_cap, host_counts3, workspace,
+                                    workspace_bytes, host_pinned, host_pinned_bytes, stream));
+    const int64_t m = host_counts3[0], n_sel = host_counts3[1];
+    std::vector<double> X((size_t)std::max<int64_t>(n_sel, 1) * 2);
+    std::vector<uint8_t> kept((size_t)std::max<int64_t>(n_sel, 1));
+    for (int64_t i = 0, j = 0; i < m; ++i)
+        if (host_flags[i]) {                                                  // down-scaled, then upscaled back (:301-302)
+            X[2 * j] = (double)host_points[2 * i] * kFactor;
+            X[2 * j + 1] = (double)host_points[2 * i + 1] * kFactor;
+            ++j;
+        }
+    STAGE_TRY(shg_host_limb_geometry(X.data(), n_sel, h, w, host_geom16, host_dims2, kept.data(), &host_counts3[2], host_outline200));
+    for (int64_t i = 0, j = 0; i < m; ++i)
+        if (host_flags[i]) { if (kept[j]) host_flags[i] |= 2; ++j; }
+    return 0;
+}
+
+// ---- single_image_process for the requested disks of one file --------------------------------------------
+extern "C" size_t shg_stage_process_workspace_bytes(int64_t k, int64_t h, int64_t w, int64_t crop_w, int tiles) {
+    if (k <= 0 || h <= 0 || w <= 0) return 0;
+    const size_t pitch = ((size_t)std::max(w, crop_w) + 63) / 64 * 64;
+    return 2 * up((size_t)h * 4) + 2 * up((size_t)k * h * 8) + up((size_t)k * h * 8) + up(4096 * 8) +
+           (size_t)k * up((size_t)h * pitch * 2) + up(shg_contrast_stats_workspace_bytes(tiles)) + up((size_t)k * 5 * 8) + kAlign;
+}
+
+extern "C" size_t shg_stage_process_host_bytes(int64_t k, int64_t h) {
+    if (k <= 0 || h <= 0) return 0;
+    return 2 * up((size_t)h * 4) + 2 * up((size_t)k * h * 8) + up((size_t)k * h * 8) + up((size_t)k * 5 * 8) + up(4096 * 8);
+}
+
+// host_frames[k]: device pointers of the circularised uint16 frames [h][w] (rows `pitch` elements apart).
+// transversalium != 0: correct_transversalium2 with `circle` / `borders` as the caller resolved them (Solex_recon.py:
+//   142-148: the limb circle, or (0, 0, 99999) with the backup bounds); host_taps[window] = savgol_coeffs(window, 3) for
+//   window = min(trans_strength, (y2-y1)//2*2-1).  host_factors (may be NULL): float64 [k][h], the row factors c.
+// crop_w > 0: the crop / pad block (Solex_recon.py:155-171) as dst[:, dx0:dx0+ncopy] = src[:, sx0:sx0+ncopy], fill img[0,0].
+// Outputs per frame i (device pointers in host arrays, images [h][out_w] with rows out_pitch apart, out_w = crop_w or w):
+//   host_detrans[i]  (array may be NULL) the frame after the transversalium stage, [h][w], rows detrans_pitch apart
+//   host_final[i]    the frame image_process works on ("uncontrasted")
+//   host_cl1[i], host_hc[i], host_protus[i], host_cc[i]: CLAHE image, high contrast, protus, contrasted CLAHE.
+// disc_r > 0: the filled disc of value 80 on protus (solex_util.py:542-547).
+extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int64_t k, int64_t h, int64_t w, int64_t pitch,
+                                        int transversalium, const double* host_circle3, const double* host_borders4,
+                                        const double* host_taps, int64_t window, double* host_factors,
+                                        int64_t crop_w, int64_t sx0, int64_t dx0, int64_t ncopy,
+                                        double clip_limit, int tiles, int64_t disc_x0, int64_t disc_y0, int64_t disc_r,
+                                        uint16_t* const* host_detrans, int64_t detrans_pitch,
+                                        uint16_t* const* host_final, uint16_t* const* host_cl1, uint16_t* const* host_hc,
+                                        uint16_t* const* host_protus, uint16_t* const* host_cc, int64_t out_pitch,
+                                        void* workspace, size_t workspace_bytes, void* host_pinned, size_t host_pinned_bytes,
+                                        shg_stream_t stream) {
+    SHG_REQUIRE(host_frames && host_final && host_cl1 && host_hc && host_protus && host_cc && workspace && host_pinned, SHG_E_ARG,
+                "shg_stage_process_frames: null pointer");
+    SHG_REQUIRE(k > 0 && h > 0 && w > 0 && pitch >= w, SHG_E_ARG, "shg_stage_process_frames: bad image size");
+    const int64_t out_w = crop_w > 0 ? crop_w : w;
+    SHG_REQUIRE(out_pitch >= out_w, SHG_E_ARG, "shg_stage_process_frames: out_pitch < output width");
+    hipStream_t st = shg::as_stream(stream);
+    Arena dev(workspace, workspace_bytes), pin(host_pinned, host_pinned_bytes);
+    int32_t* xa = dev.take<int32_t>((size_t)h);
+    int32_t* xb = dev.take<int32_t>((size_t)h);
+    double* stats = dev.take<double>((size_t)k * h);
+    double* interior = dev.take<double>((size_t)k * h);
+    double* factors = dev.take<double>((size_t)k * h);
+    double* taps_d = dev.take<double>(4096);
+    const size_t tpitch = ((size_t)w + 63) / 64 * 64;
+    std::vector<uint16_t*> scaled((size_t)k, nullptr);
+    const bool need_tmp = transversalium && crop_w > 0 && !host_detrans;
+    if (need_tmp)
+        for (int64_t i = 0; i < k; ++i) scaled[i] = dev.take<uint16_t>((size_t)h * tpitch);
+    const size_t cs_bytes = shg_contrast_stats_workspace_bytes(tiles);
+    SHG_REQUIRE(cs_bytes != 0, SHG_E_ARG, "shg_stage_process_frames: unsupported tile count %d", tiles);
+    char* cs_ws = dev.take<char>(cs_bytes);
+    double* out5 = dev.take<double>((size_t)k * 5);
+    int32_t* h_xa = pin.take<int32_t>((size_t)h);
+    int32_t* h_xb = pin.take<int32_t>((size_t)h);
+    double* h_stats = pin.take<double>((size_t)k * h);
+    double* h_interior = pin.take<double>((size_t)k * h);
+    double* h_factors = pin.take<double>((size_t)k * h);
+    double* h_out5 = pin.take<double>((size_t)k * 5);
+    double* h_taps = pin.take<double>(4096);
+    SHG_REQUIRE(xa && xb && stats && interior && factors && taps_d && cs_ws && out5 && (!need_tmp || scaled[k - 1]), SHG_E_WORKSPACE,
+                "shg_stage_process_frames: workspace too small");
+    SHG_REQUIRE(h_xa && h_xb && h_stats && h_interior && h_factors && h_out5 && h_taps, SHG_E_WORKSPACE, "shg_stage_process_frames: pinned staging area too small");
+
+    // ---- correct_transversalium2 (solex_util.py:383-516) ----
+    std::vector<const uint16_t*> cur((size_t)k);
+    int64_t cur_pitch = pitch;
+    for (int64_t i = 0; i < k; ++i) cur[i] = host_frames[i];
+    if (transversalium) {
+        SHG_REQUIRE(host_circle3 && host_borders4 && host_taps, SHG_E_ARG, "shg_stage_process_frames: transversalium needs circle, borders, taps");
+        const double cx = host_circle3[0], cy = host_circle3[1], r = host_circle3[2];
+        const int64_t y1 = (int64_t)ceil(std::max(cy - r, host_borders4[1])), y2 = (int64_t)floor(std::min(cy + r, host_borders4[3]));
+        int64_t n = 1;
+        bool have_rows = y2 - y1 >= 1;
+        const double* use_interior = nullptr;
+        if (have_rows) {
+            SHG_REQUIRE(y1 >= 0 && y2 <= h, SHG_E_ARG, "shg_stage_process_frames: rows [%lld, %lld) outside the image", (long long)y1, (long long)y2);
+            n = y2 - y1;
+            STAGE_TRY(shg_host_chord_bounds(cx, cy, r, host_borders4[0], host_borders4[2], y1, y2, w, h_xa, h_xb));
+            STAGE_HIP(hipMemcpyAsync(xa, h_xa, (size_t)n * 4, hipMemcpyHostToDevice, st), "shg_stage_process_frames");
+            STAGE_HIP(hipMemcpyAsync(xb, h_xb, (size_t)n * 4, hipMemcpyHostToDevice, st), "shg_stage_process_frames");
+            for (int64_t i = 0; i < k; ++i)
+                STAGE_TRY(shg_rowpair_logratio_stats(host_frames[i], h, w, pitch, y1, y2, xa, xb, nullptr, stats + i * n, stream));
+            const bool gpu_interior = window > 3 && window <= n && window / 2 <= 1024 && window <= 4096;
+            if (gpu_interior) {
+                // the interior of the Savitzky-Golay trend while the statistics are still on the GPU (SciPy's own order of operations)
+                std::vector<double> rev((size_t)window);
+                for (int64_t i = 0; i < window; ++i) rev[i] = host_taps[window - 1 - i];
+                const int radius = (int)(window / 2);
+                int sym = 1, anti = 1;
+                for (int i = 1; i <= radius; ++i) {
+                    if (fabs(rev[radius + i] - rev[radius - i]) > 2.220446049250313e-16) sym = 0;
+                    if (fabs(rev[radius + i] + rev[radius - i]) > 2.220446049250313e-16) anti = 0;
+                }
+                memcpy(h_taps, rev.data(), (size_t)window * 8);
+                STAGE_HIP(hipMemcpyAsync(taps_d, h_taps, (size_t)window * 8, hipMemcpyHostToDevice, st), "shg_stage_process_frames");
+                STAGE_TRY(shg_correlate1d_rows_f64(stats, k, n, taps_d, radius, sym ? 1 : (anti ? -1 : 0), interior, stream));
+                STAGE_HIP(hipMemcpyAsync(h_interior, interior, (size_t)k * n * 8, hipMemcpyDeviceToHost, st), "shg_stage_process_frames");
+                use_interior = h_interior;
+            }
+            STAGE_HIP(hipMemcpyAsync(h_stats, stats, (size_t)k * n * 8, hipMemcpyDeviceToHost, st), "shg_stage_process_frames");
+            STAGE_HIP(hipStreamSynchronize(st), "shg_stage_process_frames");
+        } else {
+            for (int64_t i = 0; i < k; ++i) h_stats[i] = 0.0;                                 // y_ratios_r = [0], :386
+        }
+        std::vector<double> corr((size_t)k * n);
+        STAGE_TRY(shg_host_transversalium_factors(h_stats, use_interior, k, n, host_taps, window, 1, corr.data()));
+        for (int64_t i = 0; i < k; ++i) {                                                     // c = ones(h); c[y1:y2] = correction_t (:478-479)
+            double* c = h_factors + i * h;
+            for (int64_t y = 0; y < h; ++y) c[y] = 1.0;
+            if (have_rows) memcpy(c + y1, corr.data() + i * n, (size_t)n * 8);
+        }
+        if (host_factors) memcpy(host_factors, h_factors, (size_t)k * h * 8);
+        STAGE_HIP(hipMemcpyAsync(factors, h_factors, (size_t)k * h * 8, hipMemcpyHostToDevice, st), "shg_stage_process_frames");
+        for (int64_t i = 0; i < k; ++i) {
+            uint16_t* dst;
+            int64_t dpitch;
+            if (host_detrans) { dst = host_detrans[i]; dpitch = detrans_pitch; }
+            else if (crop_w > 0) { dst = scaled[i]; dpitch = (int64_t)tpitch; }
+            else { dst = host_final[i]; dpitch = out_pitch; }
+            SHG_REQUIRE(dst && dpitch >= w, SHG_E_ARG, "shg_stage_process_frames: bad de-transversalium output");
+            STAGE_TRY(shg_scale_rows_u16(host_frames[i], h, w, pitch, factors + i * h, nullptr, dst, dpitch, stream));
+            cur[i] = dst;
+            cur_pitch = dpitch;
+        }
+    }
+    // ---- crop / pad (Solex_recon.py:155-171) ----
+    for (int64_t i = 0; i < k; ++i) {
+        if (crop_w > 0) {
+            STAGE_TRY(shg_crop_pad_u16(cur[i], h, w, cur_pitch, host_final[i], crop_w, out_pitch, sx0, dx0, ncopy, -1, stream));
+        } else if (cur[i] != host_final[i]) {
+            // no transversalium into host_final and no crop: the frame itself is the image to contrast; copy it (a crop of
+            // the full width) so that every product lives in the caller's output block
+            STAGE_TRY(shg_crop_pad_u16(cur[i], h, w, cur_pitch, host_final[i], w, out_pitch, 0, 0, w, -1, stream));
+        }
+    }
+    // ---- image_process (solex_util.py:527-547) ----
+    const int64_t n_px = h * out_w;
+    int64_t ranks_frame[2], ranks_cl1[3];
+    double g_bright, g_dark;
+    STAGE_TRY(shg_host_percentile_plan(n_px, 99.9999, &ranks_frame[0], &ranks_frame[1], &g_bright));
+    STAGE_TRY(shg_host_percentile_plan(n_px, 10.0, &ranks_cl1[0], &ranks_cl1[1], &g_dark));
+    ranks_cl1[2] = n_px - 1;                                                                  // np.max
+    for (int64_t i = 0; i < k; ++i)
+        STAGE_TRY(shg_contrast_stats_u16(host_final[i], h, out_w, out_pitch, clip_limit, tiles, host_cl1[i], out_pitch, ranks_frame, ranks_cl1,
+                                         out5 + i * 5, cs_ws, cs_bytes, stream));
+    STAGE_HIP(hipMemcpyAsync(h_out5, out5, (size_t)k * 5 * 8, hipMemcpyDeviceToHost, st), "shg_stage_process_frames");
+    STAGE_HIP(hipStreamSynchronize(st), "shg_stage_process_frames");
+    for (int64_t i = 0; i < k; ++i) {
+        const double* s = h_out5 + i * 5;
+        const double bright = shg_host_lerp(s[0], s[1], g_bright);                            // basically the same as max
+        const double dark_clahe = shg_host_lerp(s[2], s[3], g_dark);
+        const double bright_clahe = (double)(int64_t)s[4];
+        if (!(65535 >= bright && bright > bright * 0.25 && 65535 >= bright * 0.18 && bright * 0.18 > 0 && 65535 >= bright_clahe &&
+              bright_clahe > dark_clahe)) {
+            shg::set_error("rescale_brightness: assert sat >= hi > lo (bright %g, clahe %g .. %g)", bright, dark_clahe, bright_clahe);
+            return SHG_E_ASSERT;
+        }
+        const double lo_hi[6] = {bright * 0.25, bright, 0.0, bright * 0.18, dark_clahe, bright_clahe};
+        STAGE_TRY(shg_contrast_products_u16(host_final[i], out_pitch, host_cl1[i], out_pitch, h, out_w, lo_hi, host_hc[i], host_protus[i],
+                                            host_cc[i], out_pitch, disc_x0, disc_y0, disc_r, stream));
+    }
+    return 0;
+}

@@ -4,8 +4,8 @@ blocks, RCCL (torch.distributed backend "nccl") over xGMI for the two exchange s
   * after pass A  -- all-reduce SUM of the integer sum frame and all-reduce MAX of the max
     frame (ih*iw*8 + ih*iw*4 bytes: 1.6 MB + 0.8 MB at 2000x200).  Integer reductions are
     order independent, so every rank count gives bit-identical mean/max images;
-  * after pass B  -- all-gather of the per-rank column blocks [S, ih, n_local] into the
-    full disks (4 MB per rank at S=2).
+  * after pass B  -- all-reduce SUM of the zero-initialised disk mosaic [S, ih, n_total] into
+    which every rank has extracted the columns of its own frames (16 MB at S=2, C3).
 
 Both messages are small: the collectives are latency-bound, the per-link xGMI bandwidth
 does not bind.  Everything after the gather (fit of the limb, warp, transversalium, CLAHE)
@@ -63,35 +63,34 @@ def allreduce_sum_max(total, mx):
     return total, wide.to(torch.int16).view(torch.uint16)
 
 
-def gather_columns(local, frame_range, n_total, flip_x=False):
-    """local: uint16 [S, ih, n_local] (this rank's frames, in frame order).
-    Returns uint16 [S, ih, n_total] on every rank, columns in frame order (reversed if flip_x)."""
+def mosaic_columns(frame_range, n_total, flip_x=False):
+    """Column span [c0, c1) of the mosaic that this rank's frames [k0, k1) fill (reversed under flip_x)."""
+    k0, k1 = int(frame_range[0]), int(frame_range[1])
+    return (n_total - k1, n_total - k0) if flip_x else (k0, k1)
+
+
+def gather_columns(fill, n_shifts, ih, frame_range, n_total, flip_x, device):
+    """The full disks [S, ih, n_total] on every rank from per-rank column blocks, with ONE collective and no
+    re-layout pass: every rank extracts the columns of its own frames straight into a zeroed mosaic
+    (`fill(mosaic, k0)` -- shg_extract_columns takes the column offset and the flip), then the mosaic is
+    all-reduced with SUM.  Column blocks are disjoint, so every 16-bit cell receives one non-zero contribution:
+    summing the buffer as 32-bit words carries nothing from one cell into the next and the result is the exact
+    mosaic (RCCL has no 16-bit integer type).  BASELINE.json: "all-reduce ... for the final column mosaic"."""
     w = world_size()
-    s, ih, n_local = local.shape
     blocks = [frame_block(n_total, r, w) for r in range(w)]
-    if (blocks[rank()][0], blocks[rank()][1]) != tuple(frame_range) or n_local != frame_range[1] - frame_range[0]:
+    if blocks[rank()] != (int(frame_range[0]), int(frame_range[1])):
         raise RuntimeError('gather_columns: this rank holds frames %s, expected %s' % (tuple(frame_range), blocks[rank()]))
-    n_max = max(b - a for a, b in blocks)
-    send = torch.zeros((s, ih, n_max), dtype=torch.int16, device=local.device)
-    send[:, :, :n_local] = local.view(torch.int16)
-    # neither RCCL nor gloo moves 16-bit integers: gather the bytes
-    send8 = send.view(torch.uint8)
-    if _staged(send8):
-        host = send8.cpu()
-        recv_h = [torch.empty_like(host) for _ in range(w)]
-        td.all_gather(recv_h, host)
-        recv8 = [r.to(local.device) for r in recv_h]
+    pitch = (n_total + 63) // 64 * 64                        # even: whole 32-bit words
+    mosaic = torch.zeros((n_shifts, ih, pitch), dtype=torch.uint16, device=device)
+    fill(mosaic[:, :, :n_total], int(frame_range[0]))
+    words = mosaic.view(torch.int32)
+    if _staged(words):
+        host = words.cpu()
+        td.all_reduce(host, op=td.ReduceOp.SUM)
+        words.copy_(host)
     else:
-        recv8 = [torch.empty_like(send8) for _ in range(w)]
-        td.all_gather(recv8, send8)
-    recv = [r.view(torch.int16) for r in recv8]
-    full = torch.cat([recv[r][:, :, :blocks[r][1] - blocks[r][0]] for r in range(w)], dim=2)
-    if flip_x:
-        full = torch.flip(full, dims=(2,))
-    pitch = (n_total + 63) // 64 * 64
-    out = torch.zeros((s, ih, pitch), dtype=torch.int16, device=local.device)
-    out[:, :, :n_total] = full
-    return out.view(torch.uint16)[:, :, :n_total]
+        td.all_reduce(words, op=td.ReduceOp.SUM)
+    return mosaic[:, :, :n_total]
 
 
 def broadcast_object(obj, src=0):

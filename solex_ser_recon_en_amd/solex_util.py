@@ -16,7 +16,7 @@ import numpy as np
 import torch
 from numpy.polynomial.polynomial import polyval
 
-from . import dist, ops, outputs
+from . import dist, hostmath, ops, outputs, stages
 from .device import DeviceImage, to_device_u16
 from .fits_io import make_header, write_fits  # noqa: F401  (make_header is part of the surface)
 
@@ -56,7 +56,7 @@ def logme(path, options, s):
     _append(path, options, (s() if callable(s) else s) + '\n', 'a')
 
 
-def _plots_enabled(options):
+def plots_enabled(options):
     return not options['clahe_only'] and not options['protus_only'] and '_nolog' not in options
 
 
@@ -81,84 +81,49 @@ def detect_bord(img, axis):
     elif t.stride(0) != t.shape[1]:
         t = t.contiguous()
     ymean = ops.row_mean_u16(ops.box_blur_u16(t, 5, 5)).cpu().numpy()
-    where_sun = ymean > np.median(ymean) / 5
-    lb = np.argmax(where_sun)
-    ub = ymean.shape[0] - 1 - np.argmax(np.flip(where_sun))
-    return lb, ub
+    return hostmath.detect_bord(ymean)
 
 
 # ---- a4: spectral line detection + cubic fit (reference solex_util.py:191-274) -------
 def compute_mean_return_fit(vid_rdr, options, hdr, iw, ih, basefich0):
+    """One stage call (shg_stage_mean_fit): pass A, mean / max images, detect_bord on the max image (:223-226), the
+    blurred and sharp argmin traces (:228-242) and the cubic fits with their outlier logic (:233-259, C++ restatement
+    of the NumPy calls, bit-identical `fit`)."""
     iw, ih = int(iw), int(ih)             # the reader exposes np.uint32 like the reference's
-    mean_img, max_img = compute_mean_max(vid_rdr, options, basefich0)
+    logme(basefich0 + '_log.txt', options, 'Width, Height : ' + str(vid_rdr.Width) + ' ' + str(vid_rdr.Height))
+    logme(basefich0 + '_log.txt', options, 'Number of frames : ' + str(vid_rdr.FrameCount))
+    stack = vid_rdr.device_stack()
+    plots = plots_enabled(options)
+    if dist.is_sharded(vid_rdr):
+        total, mx = ops.accumulate_sum_max(stack)
+        total, mx = dist.allreduce_sum_max(total, mx)          # integer SUM / MAX: bit-identical to one rank
+        res = stages.mean_fit(None, int(vid_rdr.FrameCount), sums=(total, mx), geometry=ops.stack_geometry(stack), want_plot_data=plots)
+    else:
+        res = stages.mean_fit(stack, int(vid_rdr.FrameCount), want_plot_data=plots)
+    mean_img = DeviceImage(res['mean'])
+    y1, y2, p, fit = res['y1'], res['y2'], res['p'], res['fit']
     if options['save_fit']:
         outputs.submit(write_fits, output_path(basefich0 + '_mean.fits', options), mean_img, hdr)
-
-    y1, y2 = detect_bord(max_img, axis=1)
-    clip = int((y2 - y1) * 0.05)
-    y1 = min(max_img.shape[0] - 1, y1 + clip)
-    y2 = max(0, y2 - clip)
     logme(basefich0 + '_log.txt', options, 'Vertical limits y1, y2 : ' + str(y1) + ' ' + str(y2))
-    blur_width_x = 25
-    blur_width_y = int((y2 - y1) * 0.01)
-    # a zero blur height (sunlit span <= 100 rows) raises here, as cv2.blur does in the reference (:229-230)
-    blur = ops.box_blur_u16(mean_img.t, blur_width_x, blur_width_y)
-    lo, hi = blur_width_x // 2, iw + (-blur_width_x // 2)            # blur[:, 12:-13]
-    traces = torch.stack([ops.row_argmin_u16(blur, lo, hi), ops.row_argmin_u16(mean_img.t, 0, iw)]).cpu().numpy()
-    min_intensity = blur_width_x // 2 + traces[0].astype(np.int64)
-    min_intensity_sharp = traces[1].astype(np.int64)
-
-    rows = np.arange(y1, y2)
-    rows_d = np.asarray(rows, dtype='d')
-    p = np.flip(np.asarray(np.polyfit(rows, min_intensity[y1:y2], 3), dtype='d'))
-    delta = polyval(rows_d, p) - min_intensity[y1:y2]
-    stdv = np.std(delta)
-    keep = np.abs(delta / stdv) < 3
-    p = np.flip(np.asarray(np.polyfit(rows[keep], min_intensity[y1:y2][keep], 3), dtype='d'))
-
-    delta_sharp = polyval(rows_d, p) - min_intensity_sharp[y1:y2]
-    values, counts = np.unique(np.around(delta_sharp, 1), return_counts=True)
-    ind = np.argpartition(-counts, kth=2)[:2]                         # needs >= 3 distinct values (:246)
-    shift = values[ind[0]]
-    mask_good = np.abs(delta_sharp - shift) < 5
-    p = np.flip(np.asarray(np.polyfit(rows[mask_good], min_intensity_sharp[y1:y2][mask_good], 3), dtype='d'))
     logme(basefich0 + '_log.txt', options, lambda: 'Spectral line polynomial fit: ' + str(p))
-
-    curve = polyval(np.asarray(np.arange(ih), dtype='d'), p)
-    floor = np.floor(curve)
-    fit = np.stack([floor, curve - floor, np.arange(ih, dtype='d'), curve], axis=1)
-
-    if _plots_enabled(options):
+    if plots:
+        rows = np.arange(y1, y2)
+        mask_good = res['mask_good']
         outputs.submit(outputs.plot_spectral_line, output_path(basefich0 + '_spectral_line_data.png', options),
-                       mean_img, min_intensity_sharp[y1:y2][mask_good], rows[mask_good], curve, ih, (y2 - y1) // 20 + 1)
+                       mean_img, res['sharp'].astype(np.int64)[y1:y2][mask_good], rows[mask_good], fit[:, 3], ih, (y2 - y1) // 20 + 1)
     return mean_img, fit, y1, y2
 
 
 # ---- a5: per-frame column extraction (reference solex_util.py:93-144) ---------------------
-def column_plan(fit, shifts, ih, iw):
-    """Clamped left sample column per shift and the (unclamped) bilinear weights, :113-123."""
-    fit = np.asarray(fit)
-    ind_l = np.empty((len(shifts), ih), dtype=np.int32)
-    for i, shift in enumerate(shifts):
-        col = (fit[:, 0] + np.ones(ih) * shift).astype(int)
-        col[col < 0] = 0
-        col[col > iw - 2] = iw - 2
-        ind_l[i] = col
-    left_weights = np.ones(ih) - fit[:, 1]
-    right_weights = np.ones(ih) - left_weights
-    return ind_l, left_weights, right_weights
-
-
 def extract_disks(rdr, fit, shifts, flip_x=False):
-    """-> uint16 GPU tensor [S, ih, FrameCount]; all ranks hold the full mosaic when sharded."""
-    ih, iw = int(rdr.ih), int(rdr.iw)
-    ind_l, lw, rw = column_plan(fit, shifts, ih, iw)
+    """-> uint16 GPU tensor [S, ih, FrameCount]; all ranks hold the full mosaic when sharded.  One stage call
+    (shg_stage_extract): sample columns and weights from `fit` (:113-123), upload, the extraction kernel."""
     stack = rdr.device_stack()
     n_total = int(rdr.FrameCount)
     if dist.is_sharded(rdr):
-        local = ops.extract_columns(stack, ind_l, lw, rw)
-        return dist.gather_columns(local, rdr.frame_range, n_total, flip_x)
-    return ops.extract_columns(stack, ind_l, lw, rw, n_cols=n_total, k_offset=0, flip_x=flip_x)
+        return dist.gather_columns(lambda out, k0: stages.extract(stack, fit, shifts, n_cols=n_total, k_offset=k0, flip_x=flip_x, out=out),
+                                   len(shifts), int(rdr.ih), rdr.frame_range, n_total, flip_x, stack.device)
+    return stages.extract(stack, fit, shifts, n_cols=n_total, k_offset=0, flip_x=flip_x)
 
 
 def read_video_improved(rdr, fit, options):
@@ -206,102 +171,16 @@ def _tukey_compute(n, a=0.05):
     return taper
 
 
-def _chord_bounds(circle, borders, y1, y2, w):
-    """Column slice [a, b) of every row y1 .. y2-1 (entry 0 unused), as solex_util.py:389-391 computes them:
-    dx = floor((r^2 - (y-cy)^2) ** 0.5), a = ceil(max(cx - dx, b0)), b = floor(min(cx + dx, b2)),
-    then NumPy's slice normalisation.  Vectorised; rows whose square root lands within a few ulp of
-    an integer are redone with Python's own pow so that floor() cannot differ from the reference."""
-    count = max(y2 - y1, 1)
-    xa = np.zeros(count, dtype=np.int32)
-    xb = np.zeros(count, dtype=np.int32)
-    if y2 - y1 < 2:
-        return xa, xb
-    ys = np.arange(y1 + 1, y2, dtype=np.float64)
-    v = circle[2] ** 2 - (ys - circle[1]) ** 2
-    if np.any(v < 0):
-        raise TypeError("transversalium: row outside the disk circle (complex chord length)")   # floor(complex) in the reference
-    root = np.sqrt(v)
-    dx = np.floor(root)
-    near = np.abs(root - np.rint(root)) <= 1e-9 * np.maximum(root, 1.0)
-    for i in np.flatnonzero(near):
-        dx[i] = math.floor(float(v[i]) ** 0.5)
-    a = np.ceil(np.maximum(circle[0] - dx, borders[0])).astype(np.int64)
-    b = np.floor(np.minimum(circle[0] + dx, borders[2])).astype(np.int64)
-    a = np.where(a < 0, np.maximum(a + w, 0), np.minimum(a, w))          # slice(a, b).indices(w)
-    b = np.where(b < 0, np.maximum(b + w, 0), np.minimum(b, w))
-    xa[1:] = a
-    xb[1:] = np.maximum(a, b)
-    return xa, xb
-
-
 @functools.lru_cache(maxsize=32)
-def _savgol_taps(window):
+def savgol_taps(window):
     from scipy.signal import savgol_coeffs
     taps = savgol_coeffs(window, 3)
     taps.setflags(write=False)
     return taps
 
 
-@functools.lru_cache(maxsize=32)
-def _edge_fit_system(window):
-    """What np.polyfit(np.arange(window), y, 3) builds before its lstsq call: the column-scaled Vandermonde matrix,
-    the scale and rcond.  Cached: SciPy's _fit_edge fits the same abscissa for every row and every file."""
-    x = np.arange(0, window) + 0.0
-    lhs = np.vander(x, 4)
-    scale = np.sqrt((lhs * lhs).sum(axis=0))
-    lhs /= scale
-    lhs.setflags(write=False)
-    return lhs, scale, len(x) * np.finfo(x.dtype).eps
-
-
-def _edge_polyfit(window, y):
-    """== np.polyfit(np.arange(0, window), y, 3), bit for bit (same lstsq on the same matrices)."""
-    lhs, scale, rcond = _edge_fit_system(window)
-    c = np.linalg.lstsq(lhs, y + 0.0, rcond)[0]
-    return (c.T / scale).T
-
-
-def _savgol_rows(y, window, interior=None):
-    """scipy.signal.savgol_filter(row, window, 3) (mode 'interp') for every row of y [k, n], bit-identical to k
-    separate calls: the interior is one correlate1d along the rows (row-independent arithmetic), the two edges
-    are the same np.polyfit / np.polyval per row that SciPy's _fit_edge performs (a multi-right-hand-side
-    lstsq would depend on k in the last bits).  The taps depend on the window only and are cached.
-    interior: that correlate1d already computed on the GPU (ops.correlate1d_rows_f64, same order of operations)."""
-    n = y.shape[-1]
-    if window > n:
-        raise ValueError("If mode is 'interp', window_length must be less than or equal to the size of x.")
-    if interior is None:
-        from scipy.ndimage import convolve1d
-        out = convolve1d(y, _savgol_taps(window), axis=-1, mode='constant')
-    else:
-        out = np.array(interior, dtype=np.float64)
-    half = window // 2
-    for row_in, row_out in zip(y, out):
-        head = _edge_polyfit(window, row_in[:window])
-        row_out[:half] = np.polyval(head, np.arange(0, half))
-        tail = _edge_polyfit(window, row_in[n - window:])
-        row_out[n - half:] = np.polyval(tail, np.arange(window - half, window))
-    return out
-
-
 def savgol_window(n, trans_strength):
     return min(trans_strength, n // 2 * 2 - 1)                    # solex_util.py:400
-
-
-def transversalium_factors(y_ratios_r, trans_strength, tapered=True, interior=None):
-    """Row correction factors from the robust row-pair log-ratios (solex_util.py:400-404, 456-472).
-    y_ratios_r: [n] or [k, n] (k disks of one Doppler stack, same geometry).  Every row is processed exactly as
-    a separate call would, so a disk's result does not depend on which other disks share the batch.
-    tapered=False returns `correction` itself (:404), which the stubborn branch thresholds (:416-420)."""
-    y = np.atleast_2d(np.asarray(y_ratios_r, dtype=np.float64))
-    n = y.shape[-1]
-    trend = _savgol_rows(y, savgol_window(n, trans_strength), None if interior is None else np.atleast_2d(interior))
-    detrended = y - trend
-    for row in detrended:
-        row -= np.mean(row)
-    correction = np.exp(-np.cumsum(detrended, axis=-1))
-    out = np.ones(n) + (correction - np.ones(n)) * _tukey(n) if tapered else correction
-    return out if np.ndim(y_ratios_r) == 2 else out[0]
 
 
 # ---- stubborn transversalium: host control plane of solex_util.py:277-375, 415-423 ------------------
@@ -368,17 +247,19 @@ def correct_transversalium2_batch(imgs, circle, borders, options, reqFlag, basef
         raise ValueError('correct_transversalium2_batch: the frames must share one shape')
     y1 = math.ceil(max(circle[1] - circle[2], borders[1]))
     y2 = math.floor(min(circle[1] + circle[2], borders[3]))
+    n_rows = max(y2 - y1, 1)
+    window = savgol_window(n_rows, options['trans_strength'])
+    taps = savgol_taps(window)                       # raises ValueError where scipy.signal.savgol_filter would
     if y2 - y1 >= 1:
-        xa, xb = _chord_bounds(circle, borders, y1, y2, w)
+        xa, xb = hostmath.chord_bounds(circle, borders, y1, y2, w)
         bounds_d = torch.from_numpy(np.stack([xa, xb])).to(tensors[0].device)          # one upload for both bound vectors
         xa_d, xb_d = bounds_d[0], bounds_d[1]
         stats = torch.stack([ops.rowpair_logratio_stats(t, y1, y2, xa_d, xb_d, rf) for t, rf in zip(tensors, factors)])
-        window = savgol_window(stats.shape[1], options['trans_strength'])
         interior = None
         if 3 < window <= stats.shape[1] and window // 2 <= 1024:         # shg_correlate1d_rows_f64 stages 2R+1 weights in LDS
             # the interior of the Savitzky-Golay trend while the statistics are still on the GPU (SciPy's own order of
             # operations); its two edges are LAPACK fits and stay on the host
-            both = torch.stack([stats, ops.correlate1d_rows_f64(stats, _savgol_taps(window)[::-1])]).cpu().numpy()
+            both = torch.stack([stats, ops.correlate1d_rows_f64(stats, taps[::-1])]).cpu().numpy()
             ratios, interior = both[0], both[1]
         else:
             ratios = stats.cpu().numpy()
@@ -387,7 +268,7 @@ def correct_transversalium2_batch(imgs, circle, borders, options, reqFlag, basef
     if options.get('stubborn_transversalium'):
         # :415-423: rows the smooth correction cannot follow are rebuilt from their neighbours by a line filter;
         # no correction plot and no '_transversalium_cache' on this branch
-        correction = transversalium_factors(ratios, options['trans_strength'], tapered=False, interior=interior)
+        correction = hostmath.transversalium_factors(ratios, interior, taps, tapered=False)
         taper = np.zeros(h)
         taper[y1:y2] = _tukey(y2 - y1)
         xa_e, xb_e, edge, edge_half = _limb_edge_plan(circle, h, w, LIN_LEN + LIN_EDGE_FUDGE)
@@ -398,13 +279,13 @@ def correct_transversalium2_batch(imgs, circle, borders, options, reqFlag, basef
             out.append(DeviceImage(ops.lin_filter_u16(t, flag, up, dn, taper, xa_e, xb_e, edge, edge_half, LIN_LEN,
                                                       LIN_HALF_WIDTH, rf)))
         return out
-    correction_t = transversalium_factors(ratios, options['trans_strength'], interior=interior)
+    correction_t = hostmath.transversalium_factors(ratios, interior, taps, tapered=True)
     out = []
     for i, (t, rf) in enumerate(zip(tensors, factors)):
         c = np.ones(h)
         c[y1:y2] = correction_t[i]
         options['_transversalium_cache'] = c
-        if (not reqFlag) and _plots_enabled(options):
+        if (not reqFlag) and plots_enabled(options):
             outputs.submit(outputs.plot_transversalium, output_path(basefichs[i] + '_transversalium_correction.png', options), c)
         out.append(DeviceImage(ops.scale_rows_u16(t, c, rf)))
     return out
@@ -415,55 +296,64 @@ def correct_transversalium2(img, circle, borders, options, reqFlag, basefich):
 
 
 # ---- removeVignette (reference solex_util.py:590-654) ----------------------------------------------
+VIGNETTE_MARGIN = 65          # pixels inside the limb where the brightness profiles start
+
+
+def _profile_inside_disk(profile, centre, radius):
+    """The samples of a 1-D brightness profile that lie VIGNETTE_MARGIN pixels inside the disk, and the offset (in pixels
+    from int(centre)) of the first one."""
+    first = max(0, int(centre - radius + VIGNETTE_MARGIN))
+    stop = min(profile.shape[0], int(centre + radius + 1 - VIGNETTE_MARGIN))
+    return profile[first:stop], first - int(centre)
+
+
+def _fill_gaps(values):
+    """NaN runs take the last finite value before them, leading NaNs the first finite value (forward, then backward fill)."""
+    def forward(v):
+        last_seen = np.maximum.accumulate(np.where(np.isnan(v), 0, np.arange(v.shape[0])))
+        return v[last_seen]
+    return forward(forward(values)[::-1])[::-1]
+
+
 def removeVignette(frame_circularized, cercle0):
-    """Returns the de-vignetted frame: the reference's float64 image frame * correction_factor[:, None],
-    held as (uint16 image, float64 row factor) on the GPU; or the input itself when there is too little data."""
+    """Flat-field the disk along the slit: the horizontal and the vertical brightness profile of a round sun should
+    agree, so their ratio at equal distance from the centre is the row gain to take out (reference :590-654).
+    Returns the reference's float64 image frame * correction_factor[:, None], held as (uint16 image, float64 row factor)
+    on the GPU; or the input itself when there is too little data."""
     from scipy.ndimage import gaussian_filter1d
     from scipy.signal import savgol_filter
     from .limb_fit import lerp_order_stats
     t = to_device_u16(frame_circularized)
     h, w = t.shape
+    cx, cy, radius = cercle0
     # np.percentile(frame, 85, axis): two order statistics per line on the GPU, NumPy's lerp on the host
     lo0, hi0, mix0 = lerp_order_stats(h, 85)
     lo1, hi1, mix1 = lerp_order_stats(w, 85)
     cols = torch.stack(ops.line_order_stats_u16(t, 0, lo0, hi0)).view(torch.int16).cpu().numpy().view(np.uint16).astype(np.float64)
     rows = torch.stack(ops.line_order_stats_u16(t, 1, lo1, hi1)).view(torch.int16).cpu().numpy().view(np.uint16).astype(np.float64)
-    y_arr, y_arr2 = mix0(cols[0], cols[1]), mix1(rows[0], rows[1])          # _lerp is elementwise
-    shrink = 65
-    start1 = max(0, int(cercle0[0] - cercle0[2] + shrink))
-    end1 = min(y_arr.shape[0], int(cercle0[0] + cercle0[2] + 1 - shrink))
-    start2 = max(0, int(cercle0[1] - cercle0[2] + shrink))
-    end2 = min(y_arr2.shape[0], int(cercle0[1] + cercle0[2] + 1 - shrink))
-    y1 = y_arr[start1:end1]
-    y2 = y_arr2[start2:end2]
-    x1 = np.arange(y1.shape[0]) + start1 - int(cercle0[0])
-    x2 = np.arange(y2.shape[0]) + start2 - int(cercle0[1])
-    if y1.shape[0] < 20 or y2.shape[0] < 20:
+    along_x, x_offset = _profile_inside_disk(mix0(cols[0], cols[1]), cx, radius)       # _lerp is elementwise
+    along_y, y_offset = _profile_inside_disk(mix1(rows[0], rows[1]), cy, radius)
+    if along_x.shape[0] < 20 or along_y.shape[0] < 20:
         print("no de-vignette, due to not enough data")
         return frame_circularized
-    print("vignette shapes:", y1.shape, y2.shape)
-    scale_pix = int(min(y1.shape[0] // 2.75, y2.shape[0] // 2.75)) // 2 * 2 - 1
-    trend1 = savgol_filter(y1, min(801, scale_pix), 3)
-    trend2 = savgol_filter(y2, min(801, scale_pix), 3)
-    mm = min(np.min(x1), np.min(x2))
-    dest = np.full((3, int(max(np.max(x1), np.max(x2)) - mm + 1)), np.nan)
-    dest[0, :] = np.arange(dest.shape[1]) + mm
-    dest[1, int(x1[0] - mm): int(x1[-1] - mm + 1)] = trend1
-    dest[2, int(x2[0] - mm): int(x2[-1] - mm + 1)] = trend2
+    print("vignette shapes:", along_x.shape, along_y.shape)
+    span = int(min(along_x.shape[0] // 2.75, along_y.shape[0] // 2.75)) // 2 * 2 - 1
+    smooth_x = savgol_filter(along_x, min(801, span), 3)
+    smooth_y = savgol_filter(along_y, min(801, span), 3)
+    # both profiles on one axis: distance from the disk centre
+    nearest = min(x_offset, y_offset)
+    farthest = max(x_offset + along_x.shape[0], y_offset + along_y.shape[0])
+    horizontal = np.full(farthest - nearest, np.nan)
+    vertical = np.full(farthest - nearest, np.nan)
+    horizontal[x_offset - nearest: x_offset - nearest + along_x.shape[0]] = smooth_x
+    vertical[y_offset - nearest: y_offset - nearest + along_y.shape[0]] = smooth_y
     with np.errstate(divide='ignore', invalid='ignore'):
-        ratio_axes = dest[1, :] / dest[2, :]
-    ratio_axes[dest[1, :] == 0] = np.nan
-    ratio_axes[dest[2, :] == 0] = np.nan
-    correction_factor = np.full(h, np.nan)
-    correction_factor[dest[0, :].astype(int) + int(cercle0[1])] = ratio_axes
-    for i in range(1, len(correction_factor)):                 # forward fill, then backward fill
-        if np.isnan(correction_factor[i]):
-            correction_factor[i] = correction_factor[i - 1]
-    for i in range(len(correction_factor) - 2, -1, -1):
-        if np.isnan(correction_factor[i]):
-            correction_factor[i] = correction_factor[i + 1]
-    correction_factor = gaussian_filter1d(correction_factor, max(2, min(150, scale_pix // 4)))
-    return DeviceImage(t, row_factor=torch.from_numpy(np.ascontiguousarray(correction_factor)).to(t.device))
+        gain = horizontal / vertical
+    gain[(horizontal == 0) | (vertical == 0)] = np.nan
+    row_gain = np.full(h, np.nan)
+    row_gain[np.arange(nearest, farthest) + int(cy)] = gain          # (negative rows wrap, as the reference's fancy index does)
+    row_gain = gaussian_filter1d(_fill_gaps(row_gain), max(2, min(150, span // 4)))
+    return DeviceImage(t, row_factor=torch.from_numpy(np.ascontiguousarray(row_gain)).to(t.device))
 
 
 def as_uint16_image(img):
@@ -553,22 +443,27 @@ def image_process_batch(frames, cercle, options, header, basefichs):
         frame_HC, frame_protus, cc = ops.contrast_products_u16(
             frame_t, cl1, [bright * 0.25, bright, 0, bright * 0.18, dark_clahe, bright_clahe], disc)
 
-        k = options['img_rotate'] // 90
-        frame_raw, frame_HC, frame_protus, cc = (_rot90(x, k) for x in (frame_raw, frame_HC, frame_protus, cc))
-
-        if '_nolog' not in options:
-            if options['clahe_only'] or not options['protus_only']:
-                print('saving image to:' + basefich + '_clahe.png')
-                outputs.submit(outputs.write_png16, output_path(basefich + '_clahe.png', options), DeviceImage(cc))
-            if options['protus_only'] or not options['clahe_only']:
-                outputs.submit(outputs.write_png16, output_path(basefich + '_protus.png', options), DeviceImage(frame_protus))
-            if not options['clahe_only'] and not options['protus_only']:
-                outputs.submit(outputs.write_png16, output_path(basefich + '_uncontrasted.png', options), DeviceImage(frame_raw))
-                outputs.submit(outputs.write_png16, output_path(basefich + '_high_contrast.png', options), DeviceImage(frame_HC))
-        if options['save_fit']:
-            outputs.submit(write_fits, output_path(basefich + '_clahe.fits', options), DeviceImage(cl1), header)
-        results.append((DeviceImage(cc), DeviceImage(frame_protus)))
+        results.append(write_products(frame_raw, cl1, frame_HC, frame_protus, cc, options, header, basefich))
     return results
+
+
+def write_products(frame_raw, cl1, frame_HC, frame_protus, cc, options, header, basefich):
+    """The tail of image_process (solex_util.py:550-588): rot90 by img_rotate, the four PNGs and the CLAHE FITS (background
+    encoders).  -> (cc, frame_protus)"""
+    k = options['img_rotate'] // 90
+    frame_raw, frame_HC, frame_protus, cc = (_rot90(x, k) for x in (frame_raw, frame_HC, frame_protus, cc))
+    if '_nolog' not in options:
+        if options['clahe_only'] or not options['protus_only']:
+            print('saving image to:' + basefich + '_clahe.png')
+            outputs.submit(outputs.write_png16, output_path(basefich + '_clahe.png', options), DeviceImage(cc))
+        if options['protus_only'] or not options['clahe_only']:
+            outputs.submit(outputs.write_png16, output_path(basefich + '_protus.png', options), DeviceImage(frame_protus))
+        if not options['clahe_only'] and not options['protus_only']:
+            outputs.submit(outputs.write_png16, output_path(basefich + '_uncontrasted.png', options), DeviceImage(frame_raw))
+            outputs.submit(outputs.write_png16, output_path(basefich + '_high_contrast.png', options), DeviceImage(frame_HC))
+    if options['save_fit']:
+        outputs.submit(write_fits, output_path(basefich + '_clahe.fits', options), DeviceImage(cl1), header)
+    return DeviceImage(cc), DeviceImage(frame_protus)
 
 
 def image_process(frame, cercle, options, header, basefich):

@@ -1,5 +1,5 @@
 """The multi-GPU exchange steps (dist.py) on CPU tensors with the gloo backend, world size 2:
-integer all-reduce of the sum/max frames and all-gather of the disk column blocks reproduce
+integer all-reduce of the sum/max frames and of the zero-filled disk mosaic reproduce
 the unsharded oracle result bit for bit."""
 import os
 import socket
@@ -52,10 +52,16 @@ def _worker(rank, world, port, frames, fit, shifts, flip, out_dir):
         # what pass B produces on this rank: the columns of its own frames
         rdr = orc.SerReader(frames, k0, k1)
         disks = orc.extract_columns(rdr, fit, shifts)
-        local_disks = torch.from_numpy(np.stack(disks)[:, :, k0:k1].copy())
-        full = dist.gather_columns(local_disks, (k0, k1), n, flip_x=flip)
+        local_disks = np.stack(disks)[:, :, k0:k1]
+
+        def fill(mosaic, k_offset):                      # what shg_extract_columns does with (n_cols, k_offset, flip_x)
+            assert k_offset == k0 and tuple(mosaic.shape) == (len(shifts), frames.shape[2] if frames.shape[2] > frames.shape[1] else frames.shape[1], n)
+            c0, c1 = dist.mosaic_columns((k0, k1), n, flip)
+            block = local_disks[:, :, ::-1] if flip else local_disks
+            mosaic.view(torch.int16)[:, :, c0:c1] = torch.from_numpy(block.copy().view(np.int16))
+        full = dist.gather_columns(fill, len(shifts), local_disks.shape[1], (k0, k1), n, flip, torch.device('cpu'))
         np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), total=total.numpy(), mx=mx.numpy(),
-                 full=full.contiguous().numpy())
+                 full=full.contiguous().view(torch.int16).numpy().view(np.uint16))
     finally:
         td.destroy_process_group()
 

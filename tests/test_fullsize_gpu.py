@@ -71,7 +71,7 @@ def test_frame_passes_at_full_size(env, n, w, h, bits, shifts):
     assert torch.equal(mean.view(torch.int16).to(torch.int64) & 0xffff, want_mean)
     # pass B: integer curve => pure gather, for every shift (incl. the clamped ones)
     fit = integer_fit(ih, iw)
-    from solex_ser_recon_en_amd.solex_util import column_plan
+    from solex_ser_recon_en_amd.hostmath import column_plan
     ind_l, lw, rw = column_plan(fit, shifts, ih, iw)
     disks = ops.extract_columns(stack, ind_l, lw, rw)
     assert disks.shape == (len(shifts), ih, n)

@@ -8,13 +8,15 @@ import pytest
 
 from oracle import limb_oracle as limb
 from oracle import shg_oracle as orc
-from solex_ser_recon_en_amd import CLI_handler, fits_io, limb_fit, png_io, synth
+from solex_ser_recon_en_amd import CLI_handler, fits_io, hostmath, limb_fit, png_io, synth
 from solex_ser_recon_en_amd.ellipse_to_circle import get_correction_matrix
-from solex_ser_recon_en_amd.solex_util import column_plan, max_from_hist, percentile_from_hist
+from solex_ser_recon_en_amd.solex_util import max_from_hist, percentile_from_hist
+from tests import numpy_ref
 
 
 def points_via_scipy_label(edges):
-    """limb_fit.limb_points fed the way the GPU labelling feeds it: raster-ordered points + component roots."""
+    """The product's limb-point selection (shg_host_limb_points) fed the way the GPU labelling feeds it: raster-ordered
+    edge pixels + component roots.  -> (X float [n, 2], raw int [m, 2])"""
     from scipy import ndimage as ndi
     labelled, nf = ndi.label(edges, np.ones((3, 3), int))
     pts = np.argwhere(edges)
@@ -22,13 +24,16 @@ def points_via_scipy_label(edges):
     lin = pts[:, 0] * edges.shape[1] + pts[:, 1]
     first = np.full(nf + 1, np.iinfo(np.int64).max)
     np.minimum.at(first, lab_img, lin)                       # root = smallest linear index of the component
-    lab, n = limb_fit.labels_from_roots(first[lab_img])
+    lab, n = numpy_ref.labels_from_roots(first[lab_img])
     assert n == nf and np.array_equal(lab, lab_img)          # root order == scipy's raster numbering
-    return limb_fit.limb_points(pts, lab, nf, edges.shape[0])
+    sel = hostmath.limb_points(lin, first[lab_img], edges.shape[0], edges.shape[1])
+    X = np.array(pts[sel.astype(bool)], dtype='float')
+    np.testing.assert_array_equal(X, numpy_ref.limb_points(pts, lab, nf, edges.shape[0]))
+    return X, pts
 
 
 def flood_threshold_numpy(small, blurred):
-    """Feed limb_fit.flood_threshold with the statistics the GPU would reduce, computed with NumPy."""
+    """The product's flood threshold (shg_host_flood_threshold) fed with the statistics the GPU would reduce."""
     n = small.size
     lo, hi, p99 = limb_fit.lerp_order_stats(n, 99)
     srt = np.sort(blurred.ravel())
@@ -36,7 +41,9 @@ def flood_threshold_numpy(small, blurred):
     assert very_bright == np.percentile(blurred, 99)
     data = blurred.ravel()[blurred.ravel() < very_bright]
     counts, _ = np.histogram(data, bins=20)
-    return limb_fit.flood_threshold(np.sum(small), small.shape, data.min(), data.max(), counts)
+    got = hostmath.flood_threshold(np.sum(small), small.shape, data.min(), data.max(), counts)
+    assert got == numpy_ref.flood_threshold(np.sum(small), small.shape, data.min(), data.max(), counts)
+    return got
 
 
 def test_order_stat_helpers_are_numpy():
@@ -66,11 +73,11 @@ def test_limb_control_plane_matches_oracle(golden):
     Xo, rawo = limb.get_edge_list(small.copy())
     np.testing.assert_array_equal(X, Xo)
     np.testing.assert_array_equal(np.argwhere(edges), rawo)
-    got = limb_fit.two_step(X * 4, get_correction_matrix)
+    got = hostmath.two_step(X * 4)
     want = limb.two_step(Xo * 4)
     for a, b in zip(got[:4], want[:4]):
-        np.testing.assert_allclose(a, b, rtol=1e-12)
-    np.testing.assert_array_equal(got[4], want[4])
+        np.testing.assert_allclose(a, b, rtol=3e-16)
+    np.testing.assert_array_equal((X * 4)[got[4].astype(bool)], want[4])
 
 
 def test_limb_region_selection_cases():
@@ -140,7 +147,7 @@ def test_column_plan_matches_oracle(golden):
     g = golden('g2_extract')
     fit = g['u16_rot_fit']
     shifts = [10, 0, -25, 7]
-    ind_l, lw, rw = column_plan(fit, shifts, fit.shape[0], 40)
+    ind_l, lw, rw = hostmath.column_plan(fit, shifts, fit.shape[0], 40)
     cols, olw, orw = orc.column_indices(fit, shifts, 40)
     np.testing.assert_array_equal(ind_l, np.stack([c[0] for c in cols]))
     np.testing.assert_array_equal(lw, olw)
@@ -334,26 +341,18 @@ def test_bgr2gray_fixed_point():
     np.testing.assert_array_equal(bgr_to_gray_u8(b, g, r), [29, 150, 76])   # OpenCV's well-known primaries
 
 
-def test_cubic_fit_coef_is_polynomial_fit_convert():
-    """limb_fit.cubic_fit_coef == numpy.polynomial.Polynomial.fit(x, y, 3).convert().coef bit for bit (ellipse_to_circle.py:
-    177-179 uses the latter on the 20-bin histogram), and transversalium's Savitzky-Golay rows == scipy's filter."""
-    from numpy.polynomial import Polynomial
+def test_savgol_trend_is_scipys():
+    """The trend inside shg_host_transversalium_factors (interior correlation + LAPACK edge fits) == scipy's
+    savgol_filter bit for bit: with a zero mean removed and no taper, -log(factor) returns its cumulative sum."""
     from scipy.signal import savgol_filter
     from solex_ser_recon_en_amd import solex_util as su
     rng = np.random.default_rng(0)
-    for t in range(3000):
-        lo = rng.normal() * rng.choice([1e-3, 1, 100])
-        hi = lo + abs(rng.normal()) * rng.choice([1e-3, 1, 50]) + 1e-9
-        x = np.linspace(lo, hi, 21)[1:]
-        y = rng.integers(0, 50000, 20).astype(np.int64) if t % 2 else rng.standard_normal(20)
-        np.testing.assert_array_equal(limb_fit.cubic_fit_coef(x, y), Polynomial.fit(x, y, 3).convert().coef)
-    x = np.full(20, 3.0)                                                   # constant abscissa: the domain is widened by +-1
-    np.testing.assert_array_equal(limb_fit.cubic_fit_coef(x, np.arange(20.0)), Polynomial.fit(x, np.arange(20.0), 3).convert().coef)
     for n, win in [(280, 279), (1800, 301), (40, 21), (5, 5), (302, 301)]:
-        y = rng.standard_normal((1, n)) * 0.01
-        np.testing.assert_array_equal(su._savgol_rows(y, win), savgol_filter(y, win, 3, axis=-1))
-        y3 = rng.standard_normal((3, n)) * 0.01
-        np.testing.assert_array_equal(su._savgol_rows(y3, win), np.stack([savgol_filter(r, win, 3) for r in y3]))
+        y = rng.standard_normal((3, n)) * 0.01
+        got = hostmath.transversalium_factors(y, None, su.savgol_taps(win), tapered=False)
+        for r, g in zip(y, got):
+            d = r - savgol_filter(r, win, 3)
+            np.testing.assert_allclose(g, np.exp(-np.cumsum(d - np.mean(d))), rtol=4e-16, atol=0)
 
 
 def test_folder_argument_expands_to_its_scans(tmp_path):

@@ -1,8 +1,8 @@
 """The C++ host control plane (csrc/hostmath.hip, shg_host_*) against NumPy / SciPy and the oracle.
 
 These functions take host pointers only, so the whole file runs without a GPU.  The line fit must be
-BIT-IDENTICAL to NumPy's (the raw disks are exact only if `fit` is); the limb geometry is compared with
-the NumPy restatement at 1e-10 (the reference's own lsq-ellipse is unpinned)."""
+BIT-IDENTICAL to NumPy's (the raw disks are exact only if `fit` is).  tests/numpy_ref.py holds the NumPy / SciPy
+statements the C++ is compared with."""
 import ctypes
 import math
 
@@ -12,7 +12,7 @@ from numpy.polynomial.polynomial import polyval
 
 from oracle import shg_oracle as orc
 from solex_ser_recon_en_amd import _lib, hostmath, limb_fit, solex_util
-from solex_ser_recon_en_amd.ellipse_to_circle import get_correction_matrix
+from tests import numpy_ref
 
 lib = _lib.lib
 
@@ -157,7 +157,7 @@ def test_column_plan(seed):
     fit = np.stack([np.floor(curve), curve - np.floor(curve), np.arange(ih, dtype='d'), curve], axis=1)
     shifts = [10, 0, -7, 3]
     ind_l, lw, rw = hostmath.column_plan(fit, shifts, ih, iw)
-    w_ind, w_lw, w_rw = solex_util.column_plan(fit, shifts, ih, iw)
+    w_ind, w_lw, w_rw = numpy_ref.column_plan(fit, shifts, ih, iw)
     np.testing.assert_array_equal(ind_l, w_ind)
     np.testing.assert_array_equal(lw, w_lw)
     np.testing.assert_array_equal(rw, w_rw)
@@ -171,10 +171,10 @@ def test_flood_threshold(seed):
     counts[int(rng.integers(8, 16))] += 9000
     total, mn, mx = rng.uniform(1e3, 1e5), rng.uniform(0, 0.01), rng.uniform(0.2, 0.9)
     got = hostmath.flood_threshold(total, (300, 320), mn, mx, counts)
-    assert got == limb_fit.flood_threshold(total, (300, 320), mn, mx, counts)
+    assert got == numpy_ref.flood_threshold(total, (300, 320), mn, mx, counts)
     const = np.zeros(20, dtype=np.int64)                                   # constant data: np.histogram's +-0.5 range
     const[10] = 100
-    assert hostmath.flood_threshold(5.0, (10, 10), 0.25, 0.25, const) == limb_fit.flood_threshold(5.0, (10, 10), 0.25, 0.25, const)
+    assert hostmath.flood_threshold(5.0, (10, 10), 0.25, 0.25, const) == numpy_ref.flood_threshold(5.0, (10, 10), 0.25, 0.25, const)
 
 
 def ring_points(rng, h, w, cy, cx, ay, ax, gap=None, blobs=0):
@@ -209,9 +209,9 @@ def test_limb_points_match_the_numpy_qhull_selection(seed):
     idx, root, labs = ring_points(rng, h, w, 250 + rng.uniform(-20, 20), 260 + rng.uniform(-20, 20),
                                   rng.uniform(150, 220), rng.uniform(150, 230), gap, blobs=seed % 4)
     pts = np.stack([idx // w, idx % w], axis=1).astype(np.int64)
-    lab, nf = limb_fit.labels_from_roots(root)
+    lab, nf = numpy_ref.labels_from_roots(root)
     np.testing.assert_array_equal(lab, labs)
-    want, _ = limb_fit.limb_points(pts, lab, nf, h)
+    want = numpy_ref.limb_points(pts, lab, nf, h)
     sel = hostmath.limb_points(idx, root, h, w)
     np.testing.assert_array_equal(pts[sel.astype(bool)].astype(float), want)
 
@@ -225,28 +225,37 @@ def test_limb_points_failures():
         hostmath.limb_points(np.zeros(0, np.int32), np.zeros(0, np.int32), 40, 40)
 
 
-@pytest.mark.parametrize('seed', range(8))
-def test_ellipse_fit_and_two_step_against_numpy(seed):
+def one_ulp(a, b):
+    return abs(a - b) <= np.spacing(abs(b))
+
+
+@pytest.mark.parametrize('seed', range(40))
+def test_two_step_is_the_numpy_fit_bit_for_bit(seed):
+    """shg_host_two_step (NumPy's own dsyrk / dgemm / dgemv / dgesv / dgeev, called the way NumPy's matmul / inv / eig call
+    them) against the oracle's lsq-ellipse restatement in NumPy: centre, height and ratio bit-identical, phi within the one
+    ulp np.arctan and libm's atan may differ by.  phi and ratio steer every sample position of the warp."""
+    from oracle import limb_oracle
     rng = np.random.default_rng(seed)
-    n = int(rng.integers(300, 2500))
+    n = int(rng.integers(20, 3000))
     t = rng.uniform(0, 2 * np.pi, n)
-    a, b = rng.uniform(600, 900), rng.uniform(600, 900)
-    phi = rng.uniform(-0.3, 0.3)
-    cy, cx = rng.uniform(800, 1200), rng.uniform(800, 1200)
+    a, b = rng.uniform(100, 2900), rng.uniform(100, 2900)
+    phi = rng.uniform(-0.7, 0.7)
+    cy, cx = rng.uniform(300, 3200), rng.uniform(300, 3200)
     r = cy + a * np.cos(t) * np.cos(phi) - b * np.sin(t) * np.sin(phi) + rng.normal(0, 0.7, n)
     c = cx + a * np.cos(t) * np.sin(phi) + b * np.sin(t) * np.cos(phi) + rng.normal(0, 0.7, n)
     pts = np.stack([np.rint(r / 4) * 4, np.rint(c / 4) * 4], axis=1)
     pts[:n // 20] += rng.normal(0, 30, (n // 20, 2))                    # outliers for two_step to reject
-    center, width, height, ph = hostmath.fit_ellipse(pts)
-    wc, ww, wh, wp, _ = limb_fit.fit_ellipse(pts)
-    np.testing.assert_allclose(center, wc, rtol=1e-10)
-    np.testing.assert_allclose([width, height, ph], [ww, wh, wp], rtol=1e-9, atol=1e-12)
     got = hostmath.two_step(pts)
-    want = limb_fit.two_step(pts, get_correction_matrix)
-    np.testing.assert_allclose(got[0], want[0], rtol=1e-10)
-    np.testing.assert_allclose(got[1:4], want[1:4], rtol=1e-9, atol=1e-12)
+    want = limb_oracle.two_step(pts)
+    np.testing.assert_array_equal(got[0], want[0])
+    assert got[1] == want[1] and got[3] == want[3]
+    assert one_ulp(got[2], want[2])
     np.testing.assert_array_equal(pts[got[4].astype(bool)], want[4])
-    np.testing.assert_allclose(got[5], want[5], rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(got[5], want[5], rtol=1e-12, atol=1e-9)
+    center, width, height, ph = hostmath.fit_ellipse(pts)
+    reg = limb_oracle.LsqEllipse().fit(pts)
+    wc, ww, wh, wp = reg.as_parameters()
+    assert tuple(center) == tuple(wc) and (width, height) == (ww, wh) and one_ulp(ph, wp)
 
 
 def test_ellipse_fit_recovers_an_analytic_ellipse():
@@ -255,21 +264,20 @@ def test_ellipse_fit_recovers_an_analytic_ellipse():
     pts = np.stack([cy + a * np.cos(t) * np.cos(phi) - b * np.sin(t) * np.sin(phi),
                     cx + a * np.cos(t) * np.sin(phi) + b * np.sin(t) * np.cos(phi)], axis=1)
     center, width, height, ph = hostmath.fit_ellipse(pts)
-    np.testing.assert_allclose(center, [cy, cx], rtol=1e-12)
-    np.testing.assert_allclose(sorted([width, height]), [b, a], rtol=1e-12)
-    with pytest.raises(RuntimeError):
-        hostmath.fit_ellipse(np.stack([t[:50], 2 * t[:50] + 1], axis=1))        # a straight line is no ellipse
+    np.testing.assert_allclose(center, [cy, cx], rtol=1e-9)
+    np.testing.assert_allclose(sorted([width, height]), [b, a], rtol=1e-9)
 
 
-@pytest.mark.parametrize('phi,ratio', [(0.0, 1.0), (0.1, 1.08), (-0.2, 0.93), (0.7, 1.3), (1e-9, 1.0000001)])
-def test_correction_matrix_and_warp_geometry(golden, phi, ratio):
+@pytest.mark.parametrize('phi,ratio', [(0.0, 1.0), (0.1, 1.08), (-0.2, 0.93), (0.7, 1.3), (1e-9, 1.0000001), (0.0312, 1.0173)])
+def test_correction_matrix_and_warp_geometry_are_numpys(phi, ratio):
+    from solex_ser_recon_en_amd.ellipse_to_circle import get_correction_matrix
     inv, theta = hostmath.correction_matrix(phi, ratio)
     w_inv, w_theta = get_correction_matrix(phi, ratio)
-    np.testing.assert_allclose(inv, w_inv, rtol=1e-13, atol=1e-15)
-    np.testing.assert_allclose(theta, w_theta, rtol=1e-13, atol=1e-16)
+    np.testing.assert_array_equal(inv, w_inv)
+    assert one_ulp(theta, w_theta) or theta == w_theta
     # correct_image's geometry (ellipse_to_circle.py:100-114), NumPy itself
     h, w = 700, 640
-    mat, _ = get_correction_matrix(phi, ratio)
+    mat = w_inv
     mat3 = np.zeros((3, 3))
     mat3[:2, :2] = mat
     mat3[2, 2] = 1
@@ -280,13 +288,12 @@ def test_correction_matrix_and_warp_geometry(golden, phi, ratio):
     out_h = int(np.ceil(np.max(new_corners[:, 1]) - np.min(new_corners[:, 1])))
     out_w = int(np.ceil(np.max(new_corners[:, 0]) - np.min(new_corners[:, 0])))
     mat3 = mat3 @ np.array([[1, 0, origin[0]], [0, 1, origin[1]], [0, 0, 1]])
-    det = np.linalg.det(mat)
-    g = hostmath.warp_geometry(phi, ratio, 700, 640)
+    g = hostmath.warp_geometry(phi, ratio, h, w)
     assert (g['out_h'], g['out_w']) == (out_h, out_w)
-    np.testing.assert_allclose(g['mat3'], mat3, rtol=1e-12, atol=1e-10)
-    np.testing.assert_allclose(g['inv_mat'], inv_mat, rtol=1e-13, atol=1e-15)
-    np.testing.assert_allclose(g['origin'], origin, rtol=1e-12, atol=1e-10)
-    np.testing.assert_allclose(g['det'], det, rtol=1e-13)
+    np.testing.assert_array_equal(g['inv_mat'], inv_mat)
+    np.testing.assert_allclose(g['origin'], origin, rtol=4e-16, atol=0)
+    np.testing.assert_allclose(g['mat3'], mat3, rtol=4e-16, atol=1e-300)      # what shg_warp_rows_u16 samples with
+    np.testing.assert_allclose(g['det'], np.linalg.det(mat), rtol=1e-15)
 
 
 def test_correction_matrix_table_is_the_references(golden):
@@ -295,6 +302,45 @@ def test_correction_matrix_table_is_the_references(golden):
         inv, th = hostmath.correction_matrix(float(phi), float(r))
         np.testing.assert_allclose(inv, want, rtol=1e-12, atol=1e-14)
         np.testing.assert_allclose(th, theta, rtol=1e-12, atol=1e-15)
+
+
+def test_limb_geometry_borders_and_circle():
+    """shg_host_limb_geometry: circle of the corrected image and borders of the kept points, against ellipse_to_circle.py:
+    303-314 in NumPy."""
+    from oracle import limb_oracle
+    from solex_ser_recon_en_amd.ellipse_to_circle import get_correction_matrix
+    rng = np.random.default_rng(11)
+    t = rng.uniform(0, 2 * np.pi, 1400)
+    pts = np.stack([np.rint((1000 + 880 * np.sin(t) + rng.normal(0, 0.6, t.size)) / 4) * 4,
+                    np.rint((1050 + 930 * np.cos(t) + rng.normal(0, 0.6, t.size)) / 4) * 4], axis=1)
+    h, w = 2000, 2100
+    geom = np.empty(16)
+    dims = np.zeros(2, dtype=np.int64)
+    kept = np.zeros(len(pts), dtype=np.uint8)
+    n_kept = ctypes.c_int64()
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)          # noqa: E731
+    _lib.check(lib.shg_host_limb_geometry(P(pts), len(pts), h, w, P(geom), P(dims), P(kept), ctypes.byref(n_kept), None), 'geom')
+    center, height, phi, ratio, X_f, _ = limb_oracle.two_step(pts)
+    center = np.array([center[1], center[0]])
+    mat, theta = get_correction_matrix(phi, ratio)
+    inv_mat = np.linalg.inv(mat)
+    corners = np.array([[0, 0], [0, h], [w, 0], [w, h]])
+    nc = (inv_mat @ corners.T).T
+    origin = np.array([nc[:, 0].min(), nc[:, 1].min()])
+    mat3 = np.zeros((3, 3)); mat3[:2, :2] = mat; mat3[2, 2] = 1
+    mat3 = mat3 @ np.array([[1, 0, origin[0]], [0, 1, origin[1]], [0, 0, 1]])
+    new_center = (inv_mat @ center.T).T - origin
+    new_radius = height * np.sqrt(np.abs(ratio / np.linalg.det(mat)))
+    X_f3 = np.ones((X_f.shape[0], 3)); X_f3[:, 1] = X_f[:, 0]; X_f3[:, 0] = X_f[:, 1]
+    tr = (np.linalg.inv(mat3) @ X_f3.T).T
+    borders = [tr[:, 0].min(), tr[:, 1].min(), tr[:, 0].max(), tr[:, 1].max()]
+    assert n_kept.value == len(X_f)
+    np.testing.assert_allclose(geom[:5], [center[0], center[1], height, phi, ratio], rtol=3e-16)
+    np.testing.assert_allclose(geom[5:7], new_center, rtol=1e-15)
+    np.testing.assert_allclose(geom[7], new_radius, rtol=1e-15)
+    np.testing.assert_allclose(geom[8:12], borders, rtol=1e-15)
+    np.testing.assert_allclose(geom[12:15], mat3[0], rtol=4e-16, atol=1e-300)
+    assert tuple(dims) == (int(np.ceil(nc[:, 1].max() - nc[:, 1].min())), int(np.ceil(nc[:, 0].max() - nc[:, 0].min())))
 
 
 @pytest.mark.parametrize('seed', range(6))
@@ -308,7 +354,7 @@ def test_chord_bounds(seed):
     y1 = math.ceil(circle[1] - circle[2]) + 3
     y2 = math.floor(circle[1] + circle[2]) - 3
     xa, xb = hostmath.chord_bounds(circle, borders, y1, y2, w)
-    wa, wb = solex_util._chord_bounds(circle, borders, y1, y2, w)
+    wa, wb = numpy_ref.chord_bounds(circle, borders, y1, y2, w)
     np.testing.assert_array_equal(xa, wa)
     np.testing.assert_array_equal(xb, wb)
     # the reference's own loop (solex_util.py:389-391)
@@ -326,17 +372,17 @@ def test_transversalium_factors(k, n, strength):
     rng = np.random.default_rng(n)
     ratios = rng.normal(0, 2e-3, (k, n)) + 1e-3 * np.sin(np.arange(n) / 50.0)
     window = solex_util.savgol_window(n, strength)
-    taps = solex_util._savgol_taps(window)
+    taps = solex_util.savgol_taps(window)
     interior = correlate1d(ratios, taps[::-1], axis=-1, mode='constant')
-    want = solex_util.transversalium_factors(ratios, strength)
+    want = numpy_ref.transversalium_factors(ratios, strength)
     for inter in (interior, None):
         got = hostmath.transversalium_factors(ratios, inter, taps, tapered=True)
         # exp() may differ by an ulp between NumPy's SIMD loop and libm; everything before it is bit-identical
         np.testing.assert_allclose(got, want, rtol=3e-16, atol=0)
     raw = hostmath.transversalium_factors(ratios, interior, taps, tapered=False)
-    np.testing.assert_allclose(raw, solex_util.transversalium_factors(ratios, strength, tapered=False), rtol=3e-16)
+    np.testing.assert_allclose(raw, numpy_ref.transversalium_factors(ratios, strength, tapered=False), rtol=3e-16)
     with pytest.raises(ValueError, match='window_length'):
-        hostmath.transversalium_factors(ratios[:, :5], None, solex_util._savgol_taps(7))
+        hostmath.transversalium_factors(ratios[:, :5], None, solex_util.savgol_taps(7))
 
 
 def test_trend_before_exp_is_bit_identical():
@@ -344,7 +390,7 @@ def test_trend_before_exp_is_bit_identical():
     from scipy.signal import savgol_filter
     rng = np.random.default_rng(2)
     r = rng.normal(0, 1e-3, 1500)
-    taps = solex_util._savgol_taps(301)
+    taps = solex_util.savgol_taps(301)
     f = hostmath.transversalium_factors(r[None], None, taps, tapered=False)[0]
     det = r - savgol_filter(r, 301, 3)
     want = np.exp(-np.cumsum(det - np.mean(det)))

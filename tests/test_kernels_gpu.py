@@ -249,7 +249,7 @@ def host_hysteresis(low_mask, high_mask):
 def test_edge_components_match_scipy_label(ops, seed):
     """Random blobs, spirals and long thin chains: components, hysteresis and raster numbering vs scipy."""
     from scipy import ndimage as ndi
-    from solex_ser_recon_en_amd import limb_fit
+    from tests import numpy_ref
     rng = np.random.default_rng(seed)
     h, w = [(97, 131), (256, 256), (500, 500), (33, 700)][seed]
     low = rng.random((h, w)) < [0.3, 0.45, 0.05, 0.5][seed]
@@ -262,7 +262,7 @@ def test_edge_components_match_scipy_label(ops, seed):
     want = host_hysteresis(low, high)
     np.testing.assert_array_equal(idx, np.flatnonzero(want))
     labelled, nf = ndi.label(want, np.ones((3, 3), int))
-    lab, n = limb_fit.labels_from_roots(root)
+    lab, n = numpy_ref.labels_from_roots(root)
     assert n == nf
     np.testing.assert_array_equal(lab, labelled.ravel()[idx])
     # nothing survives without a high pixel
@@ -291,14 +291,22 @@ def test_canny_masks_match_skimage_0_18_3(ops, orc, golden):
     assert host(low_m).shape == noisy.shape
 
 
-def test_edge_points_match_oracle(ops, golden):
+def test_limb_points_stage_matches_oracle(ops, golden):
+    """shg_stage_limb_points (block mean -> flood image -> canny -> labelling -> region / hull / row selection) on a
+    uint16 disk against the oracle's get_edge_list on the same block mean."""
     from oracle import limb_oracle as limb
-    from solex_ser_recon_en_amd import limb_fit
-    g = golden('g13_limb')
-    X, raw = limb_fit.edge_points(dev(g['small']))
-    Xo, rawo = limb.get_edge_list(g['small'].copy())
-    np.testing.assert_array_equal(X, Xo)
-    np.testing.assert_array_equal(raw, rawo)
+    from solex_ser_recon_en_amd import stages, synth
+    rng = np.random.default_rng(3)
+    frames = synth.synth_frames_numpy(900, 820, 24, 16, seed=2)
+    disk = np.ascontiguousarray(frames[:, 12, :].T)                      # [820 rows, 900 columns]: a limb-darkened disk on sky
+    disk = np.clip(disk.astype(np.int64) + rng.integers(-40, 40, disk.shape), 0, 65535).astype(np.uint16)
+    X, raw = stages.limb_points(dev(disk))
+    small = limb.downscale_local_mean(disk / 65536, 4)
+    Xo, rawo = limb.get_edge_list(small.copy())
+    np.testing.assert_array_equal(X, Xo * 4)
+    np.testing.assert_array_equal(raw, rawo * 4)
+    with pytest.raises(RuntimeError, match='at least 400 slit rows'):
+        stages.limb_points(dev(disk[:300]))
 
 
 @pytest.mark.parametrize('n', [1, 2, 5, 1000, 250000])
@@ -378,8 +386,8 @@ def test_row_factor_paths_match_float_image(ops, orc, golden):
     fimg = img * rf.reshape((-1, 1))
     circle, borders = tuple(g['circle']), list(g['borders'])
     y1, y2, want = orc.transversalium_row_stats(fimg, circle, borders)
-    from solex_ser_recon_en_amd.solex_util import _chord_bounds
-    xa, xb = _chord_bounds(circle, borders, y1, y2, img.shape[1])
+    from solex_ser_recon_en_amd.hostmath import chord_bounds
+    xa, xb = chord_bounds(circle, borders, y1, y2, img.shape[1])
     got = host(ops.rowpair_logratio_stats(dev(img), y1, y2, xa, xb, rf))
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-15)
     c = g['a_c']
