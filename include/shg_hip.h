@@ -117,6 +117,16 @@ int shg_row_argmin_u16(const uint16_t* img, int64_t h, int64_t w, int64_t x0, in
 /* np.mean(img, axis=1) in float64 (solex_util.py:167). out[h]. */
 int shg_row_mean_u16(const uint16_t* img, int64_t h, int64_t w, double* out, shg_stream_t stream);
 
+/* The two uses of cv2.blur on the path in fused form (the blurred image never leaves the workgroup): row means of
+ * blur(img, (kw, kh)) for detect_bord (solex_util.py:166-167), and the first arg-minimum over [x0, x1) of every
+ * blurred row together with the first arg-minimum of the unblurred row (solex_util.py:230-231, 242).  Identical
+ * results to shg_box_blur_u16 + shg_row_mean_u16 / shg_row_argmin_u16.  shg_blur_fits_fused: whether (8 + kh - 1)
+ * rows of w horizontal sums fit the LDS tile (otherwise use the separate entry points). */
+int shg_blur_fits_fused(int64_t w, int kh);
+int shg_blur_row_mean_u16(const uint16_t* src, int64_t h, int64_t w, int kw, int kh, double* out, shg_stream_t stream);
+int shg_blur_argmin_u16(const uint16_t* src, int64_t h, int64_t w, int kw, int kh, int64_t x0, int64_t x1,
+                        int32_t* out_blur, int32_t* out_sharp, shg_stream_t stream);
+
 /* ---- pass B: per-frame column extraction ----- solex_util.py:93-144 (read_video_improved)
  * For every frame k, shift s and slit row y:
  *     v = img[y][ind_l[s][y]] * lw[y] + img[y][ind_l[s][y] + 1] * rw[y]     (float64,
@@ -132,6 +142,16 @@ int shg_extract_columns(const void* stack, int64_t n_frames, int64_t height, int
                         int n_shifts, uint16_t* disks, int64_t row_pitch, int64_t plane_stride,
                         int64_t n_cols, int64_t k_offset, int flip_x, shg_stream_t stream);
 
+/* The same, and on the way the minimum and maximum of every plane, as the warp clips to them (ellipse_to_circle.py:
+ * 112-114): minmax_slots is scratch + result, uint32 [n_shifts][64][2] slots (zeroed by the call, folded by a last tiny
+ * kernel) followed by the result [n_shifts][2] = {min, max} -- n_shifts * 130 words in all; pass &result[s * 2] to
+ * shg_warp_rows_minmax_u16.  Only meaningful when the call covers the whole scan (a rank's share of a sharded scan
+ * gives the extrema of its columns only).  minmax_slots may be NULL. */
+int shg_extract_columns_minmax(const void* stack, int64_t n_frames, int64_t height, int64_t width,
+                               int bytes_per_px, int64_t frame_stride_px, const int32_t* ind_l, const double* lw, const double* rw,
+                               int n_shifts, uint16_t* disks, int64_t row_pitch, int64_t plane_stride,
+                               int64_t n_cols, int64_t k_offset, int flip_x, uint32_t* minmax_slots, shg_stream_t stream);
+
 /* ---- the warp ---------------------------------- ellipse_to_circle.py:112-118
  * skimage.transform.warp(order=1, mode='constant', cval=image[0,0], clip) for a
  * transform that never moves rows: out[r][c] samples input row r at
@@ -143,6 +163,13 @@ int shg_warp_rows_u16(const uint16_t* src, int64_t h, int64_t w, int64_t src_pit
                       double h00, double h01, double h02,
                       uint16_t* dst, int64_t out_h, int64_t out_w, int64_t dst_pitch,
                       uint32_t* minmax, shg_stream_t stream);
+
+/* The warp with the input's extrema already known (minmax2 = {min, max}, e.g. from shg_extract_columns_minmax): saves
+ * the pass over the input that shg_warp_rows_u16 makes to find them. */
+int shg_warp_rows_minmax_u16(const uint16_t* src, int64_t h, int64_t w, int64_t src_pitch,
+                             double h00, double h01, double h02,
+                             uint16_t* dst, int64_t out_h, int64_t out_w, int64_t dst_pitch,
+                             const uint32_t* minmax2, shg_stream_t stream);
 
 /* ---- transversalium ---------------------------- solex_util.py:383-395, 76-86
  * Per row y in (y1, y2): the mean of the 2-MAD inliers of log(img[y][a:b] / img[y-1][a:b])
@@ -336,13 +363,13 @@ int shg_stage_mean_fit(const void* stack, int64_t n_frames, int64_t height, int6
                        void* host_pinned, size_t host_pinned_bytes, shg_stream_t stream);
 
 /* read_video_improved (solex_util.py:93-144) from the host `fit` and shift list: sample columns and weights
- * (shg_host_column_plan), upload, shg_extract_columns.  Asynchronous. */
+ * (shg_host_column_plan), upload, shg_extract_columns_minmax (minmax_slots may be NULL).  Asynchronous. */
 size_t shg_stage_extract_workspace_bytes(int64_t height, int64_t width, int n_shifts);   /* device and pinned */
 int shg_stage_extract(const void* stack, int64_t n_frames, int64_t height, int64_t width, int bytes_per_px,
                       int64_t frame_stride_px, const double* host_fit, const int32_t* host_shifts, int n_shifts,
                       uint16_t* disks, int64_t row_pitch, int64_t plane_stride, int64_t n_cols, int64_t k_offset,
-                      int flip_x, void* workspace, size_t workspace_bytes, void* host_pinned, size_t host_pinned_bytes,
-                      shg_stream_t stream);
+                      int flip_x, uint32_t* minmax_slots, void* workspace, size_t workspace_bytes, void* host_pinned,
+                      size_t host_pinned_bytes, shg_stream_t stream);
 
 /* get_edge_list on the 4x4 block mean of the disk (ellipse_to_circle.py:231-291, 299-302): flood image, canny ladder
  * (sigma 2, 1.5, 1, 0.5; host_gauss_taps = scipy's taps for those, 17 + 13 + 9 + 5 values), hysteresis + labelling,

@@ -255,10 +255,10 @@ def solex_read(file, options):
     with timing.stage('mean_max+line_fit'):
         mean_img, fit, backup_y1, backup_y2 = compute_mean_return_fit(rdr, wopts, hdr, iw, ih, basefich0)
     with timing.stage('extract'):
-        disks = extract_disks(rdr, fit, options['shift'], flip_x=bool(options['flip_x']))     # flip fused (:74-76)
+        disks, extrema = extract_disks(rdr, fit, options['shift'], flip_x=bool(options['flip_x']), want_minmax=True)     # flip fused (:74-76)
     hdr['NAXIS1'] = iw          # as the reference (:65); the FITS writer takes NAXIS* from the data anyway
 
-    disk_list = [DeviceImage(disks[i]) for i in range(disks.shape[0])]
+    disk_list = [DeviceImage(disks[i], minmax=None if extrema is None else extrema[i]) for i in range(disks.shape[0])]
     for i, disk in enumerate(disk_list):
         basefich = basefich0 + '_shift=' + str(options['shift'][i])
         flag_requested = options['shift'][i] in options['shift_requested']

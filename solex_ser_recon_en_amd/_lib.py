@@ -43,8 +43,15 @@ SIGNATURES = {
     'shg_box_blur_u16': (c_int, [P, c_int64, c_int64, c_int, c_int, P, P, P]),
     'shg_row_argmin_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int64, P, P]),
     'shg_row_mean_u16': (c_int, [P, c_int64, c_int64, P, P]),
+    'shg_blur_fits_fused': (c_int, [c_int64, c_int]),
+    'shg_blur_row_mean_u16': (c_int, [P, c_int64, c_int64, c_int, c_int, P, P]),
+    'shg_blur_argmin_u16': (c_int, [P, c_int64, c_int64, c_int, c_int, c_int64, c_int64, P, P, P]),
     'shg_extract_columns': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int64, P, P, P, c_int, P, c_int64, c_int64,
                                     c_int64, c_int64, c_int, P]),
+    'shg_extract_columns_minmax': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int64, P, P, P, c_int, P, c_int64, c_int64,
+                                           c_int64, c_int64, c_int, P, P]),
+    'shg_warp_rows_minmax_u16': (c_int, [P, c_int64, c_int64, c_int64, c_double, c_double, c_double, P, c_int64, c_int64,
+                                         c_int64, P, P]),
     'shg_warp_rows_u16': (c_int, [P, c_int64, c_int64, c_int64, c_double, c_double, c_double, P, c_int64, c_int64,
                                   c_int64, P, P]),
     'shg_rowpair_logratio_stats': (c_int, [P, c_int64, c_int64, c_int64, c_int64, c_int64, P, P, P, P, P]),
@@ -85,7 +92,7 @@ SIGNATURES = {
                                    c_size_t, P]),
     'shg_stage_extract_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int]),
     'shg_stage_extract': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int64, P, P, c_int, P, c_int64, c_int64, c_int64, c_int64, c_int,
-                                  P, c_size_t, P, c_size_t, P]),
+                                  P, P, c_size_t, P, c_size_t, P]),
     'shg_stage_limb_points_workspace_bytes': (c_size_t, [c_int64, c_int64]),
     'shg_stage_limb_points_host_bytes': (c_size_t, [c_int64, c_int64]),
     'shg_stage_limb_points': (c_int, [P, c_int64, c_int64, c_int64, P, P, P, c_int64, P, P, c_size_t, P, c_size_t, P]),

@@ -432,6 +432,52 @@ __global__ __launch_bounds__(256) void k_select16_final(Ranks8 ranks, const uint
     if (threadIdx.x == 0) out[blockIdx.x] = (double)((hi << 8) | lo);
 }
 
+// Totals of the summed tile histograms over runs of 64 bins: chunk[c] = sum over tiles and bins 64c .. 64c+63.
+// grid 64 x 1024 threads: a wave's 64 lanes hold exactly one run.
+__global__ __launch_bounds__(1024) void k_chunk_sums(const uint32_t* __restrict__ hist, int ntiles, uint32_t* __restrict__ chunk) {
+    const int bin = blockIdx.x * 1024 + threadIdx.x;
+    uint32_t t = 0;
+    for (int k = 0; k < ntiles; ++k) t += hist[(int64_t)k * HIST16 + bin];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+    if ((threadIdx.x & 63) == 0) chunk[bin >> 6] = t;
+}
+
+// Order statistics of the image whose per-tile histograms CLAHE has just built (valid when the tile grid divides the
+// image: no reflected padding in the histograms).  One workgroup per rank: lane t takes the t-th run of 64 bins from the
+// chunk sums of k_chunk_sums, a workgroup scan finds the run that holds the rank, one wave scans its 64 bins.
+__global__ __launch_bounds__(1024) void k_hist_ranks(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ chunk_sums,
+                                                     int ntiles, Ranks8 ranks, double* __restrict__ out) {
+    __shared__ int64_t wtot[16];
+    __shared__ int64_t pick[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t rank = ranks.v[blockIdx.x];
+    int64_t local = 0;
+    local = chunk_sums[tid];
+    int64_t incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    for (int i = 0; i < wave; ++i) incl += wtot[i];
+    if (incl - local <= rank && rank < incl) { pick[0] = tid; pick[1] = incl - local; }
+    __syncthreads();
+    if (wave != 0) return;
+    const int64_t chunk = pick[0], below = pick[1];
+    int64_t c = 0;
+    for (int t = 0; t < ntiles; ++t) c += hist[(int64_t)t * HIST16 + chunk * 64 + lane];
+    int64_t inc2 = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t o = __shfl_up(inc2, d);
+        if (lane >= d) inc2 += o;
+    }
+    if (below + inc2 - c <= rank && rank < below + inc2) out[blockIdx.x] = (double)(chunk * 64 + lane);
+}
+
 void ensure_lds_attr() {
     static bool done = false;
     if (!done) {
@@ -575,7 +621,8 @@ extern "C" int shg_select_u16(const uint16_t* img, int64_t h, int64_t w, int64_t
 extern "C" size_t shg_contrast_stats_workspace_bytes(int tiles) {
     const size_t c = shg_clahe_workspace_bytes(tiles, 2), s2 = shg_select_u16_workspace_bytes(2), s3 = shg_select_u16_workspace_bytes(3);
     if (c == 0) return 0;
-    return ((c + 255) / 256 + (s2 + 255) / 256 + (s3 + 255) / 256) * 256;
+    const size_t chunks = 1024 * sizeof(uint32_t);           // 64-bin chunk sums of the summed tile histograms
+    return ((c + 255) / 256 + (s2 + 255) / 256 + (s3 + 255) / 256 + (chunks + 255) / 256) * 256;
 }
 
 extern "C" int shg_contrast_stats_u16(const uint16_t* frame, int64_t h, int64_t w, int64_t pitch, double clip_limit, int tiles,
@@ -586,7 +633,23 @@ extern "C" int shg_contrast_stats_u16(const uint16_t* frame, int64_t h, int64_t 
     SHG_REQUIRE(c != 0 && workspace_bytes >= shg_contrast_stats_workspace_bytes(tiles), SHG_E_WORKSPACE,
                 "shg_contrast_stats_u16: workspace too small or bad tile count");
     char* ws = static_cast<char*>(workspace);
+    // When the tile grid divides the image, CLAHE's tile histograms (still at the head of its workspace) add up to the
+    // histogram of the frame: np.percentile(frame, q)'s two order statistics are read off them (k_chunk_sums, k_hist_ranks)
+    // instead of selecting over the image again (two passes of k_select16_pass).
     if (int e = shg_clahe(frame, h, w, pitch, 2, clip_limit, tiles, cl1, cl1_pitch, ws, c, stream)) return e;
-    if (int e = shg_select_u16(frame, h, w, pitch, ranks_frame2, 2, out5, ws + c, s2, stream)) return e;
+    if (h % tiles == 0 && w % tiles == 0) {
+        const size_t s3r = (shg_select_u16_workspace_bytes(3) + 255) / 256 * 256;
+        uint32_t* chunk_sums = reinterpret_cast<uint32_t*>(ws + c + s2 + s3r);
+        Ranks8 ranks = {};
+        for (int i = 0; i < 2; ++i) {
+            SHG_REQUIRE(ranks_frame2[i] >= 0 && ranks_frame2[i] < h * w, SHG_E_ARG, "shg_contrast_stats_u16: rank %lld outside the image", (long long)ranks_frame2[i]);
+            ranks.v[i] = ranks_frame2[i];
+        }
+        hipStream_t st = shg::as_stream(stream);
+        SHG_PROF("hist_ranks", st);
+        k_chunk_sums<<<64, 1024, 0, st>>>(reinterpret_cast<const uint32_t*>(ws), tiles * tiles, chunk_sums);
+        k_hist_ranks<<<2, 1024, 0, st>>>(reinterpret_cast<const uint32_t*>(ws), chunk_sums, tiles * tiles, ranks, out5);
+        if (int e = shg::check_launch("k_hist_ranks")) return e;
+    } else if (int e = shg_select_u16(frame, h, w, pitch, ranks_frame2, 2, out5, ws + c, s2, stream)) return e;
     return shg_select_u16(cl1, h, w, cl1_pitch, ranks_cl13, 3, out5 + 2, ws + c + s2, shg_select_u16_workspace_bytes(3), stream);
 }

@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void k_extract(const T* __restrict__ stack, in
                                                  const int32_t* __restrict__ ind_l, const double* __restrict__ lw,
                                                  const double* __restrict__ rw, int n_shifts,
                                                  uint16_t* __restrict__ disks, int64_t row_pitch, int64_t plane_stride,
-                                                 int64_t n_cols, int64_t k_offset, int flip_x, int vec_store) {
+                                                 int64_t n_cols, int64_t k_offset, int flip_x, int vec_store,
+                                                 uint32_t* __restrict__ mm) {
     __shared__ uint16_t tile[SC][TY][TKP];
     const int64_t ih = ROT ? width : height;
     const int lane = threadIdx.x & 63;
@@ -54,6 +55,11 @@ __global__ __launch_bounds__(256) void k_extract(const T* __restrict__ stack, in
     const int64_t step = ROT ? width : 1;
 #pragma unroll
     for (int s = 0; s < SC; ++s) off[s] = ROT ? (int64_t)il[s] * width + (width - 1 - yc) : yc * width + il[s];
+
+    __shared__ uint32_t wred[4][SC][2];
+    uint32_t vlo[SC], vhi[SC];
+#pragma unroll
+    for (int s = 0; s < SC; ++s) { vlo[s] = 0xffffu; vhi[s] = 0u; }
 
     // Frames of this wave: cc = wave, wave + 4, ...  BATCH of them at a time.
     for (int cb = wave; cb < TK; cb += 4 * BATCH) {
@@ -82,12 +88,43 @@ __global__ __launch_bounds__(256) void k_extract(const T* __restrict__ stack, in
                     const double l = (double)((int)lv[i][s] * scale);
                     const double r = (double)((int)rv[i][s] * scale);
                     const double v = l * wl + r * wr;
-                    tile[s][lane][cc] = (uint16_t)(int)v;
+                    const uint32_t q = (uint32_t)(uint16_t)(int)v;
+                    tile[s][lane][cc] = (uint16_t)q;
+                    vlo[s] = q < vlo[s] ? q : vlo[s];
+                    vhi[s] = q > vhi[s] ? q : vhi[s];
                 }
             }
         }
     }
+
+    if (mm) {
+        // the planes' minimum and maximum (what the warp clips to, ellipse_to_circle.py:112-114), gathered from the values
+        // while they were in registers: wave reduction, then one atomic pair per workgroup and plane into one of 64 slots
+        // (same-address atomics serialise chip-wide; k_fold_minmax folds the slots)
+#pragma unroll
+        for (int s = 0; s < SC; ++s) {
+            uint32_t lo = vlo[s], hi = vhi[s];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const uint32_t ol = __shfl_xor(lo, d), oh = __shfl_xor(hi, d);
+                lo = ol < lo ? ol : lo;
+                hi = oh > hi ? oh : hi;
+            }
+            if (lane == 0) { wred[wave][s][0] = lo; wred[wave][s][1] = hi; }
+        }
+    }
     __syncthreads();
+    if (mm && threadIdx.x < ns) {
+        const int s = threadIdx.x;
+        uint32_t lo = wred[0][s][0], hi = wred[0][s][1];
+        for (int wv = 1; wv < 4; ++wv) { lo = wred[wv][s][0] < lo ? wred[wv][s][0] : lo; hi = wred[wv][s][1] > hi ? wred[wv][s][1] : hi; }
+        if (hi >= lo) {                                   // the workgroup produced at least one value for this plane
+            const int slot = (int)((blockIdx.x * 5u + blockIdx.y * 3u) & 63u);
+            uint32_t* m = mm + ((int64_t)(s0 + s) * 64 + slot) * 2;
+            atomicMax(&m[0], 0xffffu - lo);              // the minimum as the maximum of the complement: both slots start at zero
+            atomicMax(&m[1], hi);
+        }
+    }
 
     // write-out: one 16-byte segment (8 columns) per lane, 8 lanes per row
     const int seg = threadIdx.x & 7;
@@ -119,12 +156,32 @@ __global__ __launch_bounds__(256) void k_extract(const T* __restrict__ stack, in
     }
 }
 
+// fold the 64 slots of every plane: out[s] = {min, max}
+__global__ void k_fold_minmax(const uint32_t* __restrict__ slots, uint32_t* __restrict__ out) {
+    uint32_t a = slots[((int64_t)blockIdx.x * 64 + threadIdx.x) * 2], b = slots[((int64_t)blockIdx.x * 64 + threadIdx.x) * 2 + 1];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t oa = __shfl_xor(a, d), ob = __shfl_xor(b, d);
+        a = oa > a ? oa : a;
+        b = ob > b ? ob : b;
+    }
+    if (threadIdx.x == 0) { out[blockIdx.x * 2] = 0xffffu - a; out[blockIdx.x * 2 + 1] = b; }
+}
+
 }  // namespace
 
 extern "C" int shg_extract_columns(const void* stack, int64_t n_frames, int64_t height, int64_t width,
                                    int bytes_per_px, int64_t frame_stride_px, const int32_t* ind_l, const double* lw, const double* rw,
                                    int n_shifts, uint16_t* disks, int64_t row_pitch, int64_t plane_stride,
                                    int64_t n_cols, int64_t k_offset, int flip_x, shg_stream_t stream) {
+    return shg_extract_columns_minmax(stack, n_frames, height, width, bytes_per_px, frame_stride_px, ind_l, lw, rw, n_shifts, disks,
+                                      row_pitch, plane_stride, n_cols, k_offset, flip_x, nullptr, stream);
+}
+
+extern "C" int shg_extract_columns_minmax(const void* stack, int64_t n_frames, int64_t height, int64_t width,
+                                          int bytes_per_px, int64_t frame_stride_px, const int32_t* ind_l, const double* lw, const double* rw,
+                                          int n_shifts, uint16_t* disks, int64_t row_pitch, int64_t plane_stride,
+                                          int64_t n_cols, int64_t k_offset, int flip_x, uint32_t* minmax_slots, shg_stream_t stream) {
     SHG_REQUIRE(stack && ind_l && lw && rw && disks, SHG_E_ARG, "shg_extract_columns: null pointer");
     SHG_REQUIRE(n_frames > 0 && height > 0 && width > 0 && n_shifts > 0, SHG_E_ARG, "shg_extract_columns: empty input");
     SHG_REQUIRE(bytes_per_px == 1 || bytes_per_px == 2, SHG_E_ARG, "shg_extract_columns: bytes_per_px must be 1 or 2");
@@ -146,7 +203,7 @@ extern "C" int shg_extract_columns(const void* stack, int64_t n_frames, int64_t 
     const int n = (int)n_frames;
 #define SHG_LAUNCH_BS(T, ROT, B, SCV)                                                                                         \
     k_extract<T, ROT, B, SCV><<<grid, 256, 0, st>>>(static_cast<const T*>(stack), n, height, width, fstride, ind_l, lw, rw, n_shifts, \
-                                               disks, row_pitch, plane_stride, n_cols, k_offset, flip_x, vec_store)
+                                               disks, row_pitch, plane_stride, n_cols, k_offset, flip_x, vec_store, minmax_slots)
 #define SHG_LAUNCH_B(T, ROT, B) do { if (sc == 2) SHG_LAUNCH_BS(T, ROT, B, 2); else SHG_LAUNCH_BS(T, ROT, B, 4); } while (0)
 #define SHG_LAUNCH(T, ROT)                                                 \
     switch (batch) {                                                       \
@@ -161,14 +218,27 @@ extern "C" int shg_extract_columns(const void* stack, int64_t n_frames, int64_t 
     // instantiation 14 / 13 / 14 / 14 us for batch 2 / 4 / 8 / 16 (16 us with the four-shift one)
     const int batch2 = 4;
     const int batch = batch_env > 0 ? batch_env : (n_shifts > SC_MAX ? 8 : (n_shifts <= 2 ? batch2 : 4));
-    SHG_PROF("extract", st);
-    if (bytes_per_px == 2) {
-        if (rot) SHG_LAUNCH(uint16_t, true) else SHG_LAUNCH(uint16_t, false)
-    } else {
-        if (rot) SHG_LAUNCH(uint8_t, true) else SHG_LAUNCH(uint8_t, false)
+    if (minmax_slots) {
+        if (hipError_t e = hipMemsetAsync(minmax_slots, 0, (size_t)n_shifts * 64 * 2 * sizeof(uint32_t), st)) {
+            shg::set_error("shg_extract_columns: memset: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+    }
+    {
+        SHG_PROF("extract", st);
+        if (bytes_per_px == 2) {
+            if (rot) SHG_LAUNCH(uint16_t, true) else SHG_LAUNCH(uint16_t, false)
+        } else {
+            if (rot) SHG_LAUNCH(uint8_t, true) else SHG_LAUNCH(uint8_t, false)
+        }
     }
 #undef SHG_LAUNCH_B
 #undef SHG_LAUNCH_BS
 #undef SHG_LAUNCH
-    return shg::check_launch("k_extract");
+    if (int e = shg::check_launch("k_extract")) return e;
+    if (minmax_slots) {
+        k_fold_minmax<<<(unsigned)n_shifts, 64, 0, st>>>(minmax_slots, minmax_slots + (int64_t)n_shifts * 64 * 2);
+        return shg::check_launch("k_fold_minmax");
+    }
+    return 0;
 }

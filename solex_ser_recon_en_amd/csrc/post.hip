@@ -136,14 +136,57 @@ extern "C" int shg_downscale_mean_u16(const uint16_t* img, int64_t h, int64_t w,
     return shg::check_launch("k_downscale_mean");
 }
 
-// The three rescale_brightness calls of image_process and the protuberance disc (solex_util.py:539-547) in one call.
+// The three rescale_brightness calls of image_process and the protuberance disc (solex_util.py:539-547) in one call and
+// ONE pass: frame and cl1 are read once, the three products written once (the separate calls read the frame twice and
+// went back over protus for the disc).  Same arithmetic per pixel as k_rescale / k_fill_disc.
+namespace {
+struct Bounds6 { double lo[3], span[3]; };
+
+__device__ __forceinline__ uint16_t rescale1(double px, double lo, double span) {
+    double v = 65535.0 * (px - lo) / span;             // (float(sat) * alpha * (img - lo)) / (hi - lo), alpha = 1
+    v = v < 0.0 ? 0.0 : v;
+    v = v > 65535.0 ? 65535.0 : v;
+    return (uint16_t)(int)v;
+}
+
+__global__ __launch_bounds__(256) void k_products(const uint16_t* __restrict__ frame, int64_t frame_pitch,
+                                                  const uint16_t* __restrict__ cl1, int64_t cl1_pitch, int64_t w, Bounds6 b,
+                                                  uint16_t* __restrict__ hc, uint16_t* __restrict__ protus, uint16_t* __restrict__ cc,
+                                                  int64_t dst_pitch, int64_t x0, int64_t y0, int64_t r) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t y = blockIdx.y;
+    if (x >= w) return;
+    const double f = (double)frame[y * frame_pitch + x];
+    const double c = (double)cl1[y * cl1_pitch + x];
+    hc[y * dst_pitch + x] = rescale1(f, b.lo[0], b.span[0]);
+    uint16_t p = rescale1(f, b.lo[1], b.span[1]);
+    if (r > 0) {                                            // cv2.circle(frame_protus, (x0, y0), r, 80, -1)
+        const int64_t ady = y > y0 ? y - y0 : y0 - y;
+        const int64_t adx = x > x0 ? x - x0 : x0 - x;
+        if (ady <= r && adx <= r && adx <= isqrt64(r * r - ady * ady)) p = 80;
+    }
+    protus[y * dst_pitch + x] = p;
+    cc[y * dst_pitch + x] = rescale1(c, b.lo[2], b.span[2]);
+}
+}  // namespace
+
 extern "C" int shg_contrast_products_u16(const uint16_t* frame, int64_t frame_pitch, const uint16_t* cl1, int64_t cl1_pitch, int64_t h,
                                          int64_t w, const double* lo_hi6, uint16_t* high_contrast, uint16_t* protus, uint16_t* cc,
                                          int64_t dst_pitch, int64_t disc_x0, int64_t disc_y0, int64_t disc_r, shg_stream_t stream) {
     SHG_REQUIRE(frame && cl1 && lo_hi6 && high_contrast && protus && cc, SHG_E_ARG, "shg_contrast_products_u16: null pointer");
-    if (int e = shg_rescale_u16(frame, h, w, frame_pitch, lo_hi6[0], lo_hi6[1], 1.0, high_contrast, dst_pitch, stream)) return e;
-    if (int e = shg_rescale_u16(frame, h, w, frame_pitch, lo_hi6[2], lo_hi6[3], 1.0, protus, dst_pitch, stream)) return e;
-    if (int e = shg_rescale_u16(cl1, h, w, cl1_pitch, lo_hi6[4], lo_hi6[5], 1.0, cc, dst_pitch, stream)) return e;
-    if (disc_r > 0) return shg_fill_disc_u16(protus, h, w, dst_pitch, disc_x0, disc_y0, disc_r, 80, nullptr, stream);
-    return 0;
+    SHG_REQUIRE(h > 0 && w > 0 && frame_pitch >= w && cl1_pitch >= w && dst_pitch >= w, SHG_E_ARG, "shg_contrast_products_u16: bad image size");
+    SHG_REQUIRE(h < 65536, SHG_E_UNSUPPORTED, "shg_contrast_products_u16: more than 65535 rows");
+    SHG_REQUIRE(disc_r < 32768, SHG_E_UNSUPPORTED, "shg_contrast_products_u16: radius %lld out of range", (long long)disc_r);
+    Bounds6 b;
+    for (int i = 0; i < 3; ++i) {
+        const double lo = lo_hi6[2 * i], hi = lo_hi6[2 * i + 1];
+        SHG_REQUIRE(65535.0 >= hi && hi > lo, SHG_E_ARG, "shg_contrast_products_u16: need sat >= hi > lo (got lo=%g hi=%g)", lo, hi);   // assert, solex_util.py:521
+        b.lo[i] = lo;
+        b.span[i] = hi - lo;
+    }
+    hipStream_t st = shg::as_stream(stream);
+    dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
+    { SHG_PROF("products", st); k_products<<<grid, 256, 0, st>>>(frame, frame_pitch, cl1, cl1_pitch, w, b, high_contrast, protus, cc, dst_pitch,
+                                                                  disc_x0, disc_y0, disc_r > 0 ? disc_r : 0); }
+    return shg::check_launch("k_products");
 }

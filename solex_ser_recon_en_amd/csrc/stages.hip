@@ -104,8 +104,12 @@ extern "C" int shg_stage_mean_fit(const void* stack, int64_t n_frames, int64_t h
     }
     STAGE_TRY(shg_finalize_mean_max(sum_in, max_in, n_total, height, width, bytes_per_px, mean_out, max_out, stream));
     // detect_bord(max_img, axis=1) (:223, :165-172)
-    STAGE_TRY(shg_box_blur_u16(max_out, ih, iw, 5, 5, blur, tmp, stream));
-    STAGE_TRY(shg_row_mean_u16(blur, ih, iw, row_means, stream));
+    if (shg_blur_fits_fused(iw, 5)) {
+        STAGE_TRY(shg_blur_row_mean_u16(max_out, ih, iw, 5, 5, row_means, stream));
+    } else {
+        STAGE_TRY(shg_box_blur_u16(max_out, ih, iw, 5, 5, blur, tmp, stream));
+        STAGE_TRY(shg_row_mean_u16(blur, ih, iw, row_means, stream));
+    }
     STAGE_HIP(hipMemcpyAsync(h_means, row_means, (size_t)ih * 8, hipMemcpyDeviceToHost, st), "shg_stage_mean_fit");
     STAGE_HIP(hipStreamSynchronize(st), "shg_stage_mean_fit");
     int64_t y1, y2;
@@ -117,10 +121,14 @@ extern "C" int shg_stage_mean_fit(const void* stack, int64_t n_frames, int64_t h
     host_y12[1] = y2;
     const int blur_w = 25, blur_h = (int)((double)(y2 - y1) * 0.01);                          // :228-229
     // a zero blur height (sunlit span <= 100 rows) fails here, as cv2.blur does in the reference (:230)
-    STAGE_TRY(shg_box_blur_u16(mean_out, ih, iw, blur_w, blur_h, blur, tmp, stream));
     const int64_t lo = blur_w / 2, hi = iw + (-(blur_w + 1) / 2);                             // blur[:, 12:-13]  (-25 // 2 == -13)
-    STAGE_TRY(shg_row_argmin_u16(blur, ih, iw, lo, hi, traces, stream));
-    STAGE_TRY(shg_row_argmin_u16(mean_out, ih, iw, 0, iw, traces + ih, stream));
+    if (blur_h > 0 && shg_blur_fits_fused(iw, blur_h)) {
+        STAGE_TRY(shg_blur_argmin_u16(mean_out, ih, iw, blur_w, blur_h, lo, hi, traces, traces + ih, stream));
+    } else {
+        STAGE_TRY(shg_box_blur_u16(mean_out, ih, iw, blur_w, blur_h, blur, tmp, stream));
+        STAGE_TRY(shg_row_argmin_u16(blur, ih, iw, lo, hi, traces, stream));
+        STAGE_TRY(shg_row_argmin_u16(mean_out, ih, iw, 0, iw, traces + ih, stream));
+    }
     STAGE_HIP(hipMemcpyAsync(h_traces, traces, 2 * (size_t)ih * 4, hipMemcpyDeviceToHost, st), "shg_stage_mean_fit");
     STAGE_HIP(hipStreamSynchronize(st), "shg_stage_mean_fit");
     if (host_trace_sharp) memcpy(host_trace_sharp, h_traces + ih, (size_t)ih * 4);
@@ -137,8 +145,8 @@ extern "C" size_t shg_stage_extract_workspace_bytes(int64_t height, int64_t widt
 extern "C" int shg_stage_extract(const void* stack, int64_t n_frames, int64_t height, int64_t width, int bytes_per_px,
                                  int64_t frame_stride_px, const double* host_fit, const int32_t* host_shifts, int n_shifts,
                                  uint16_t* disks, int64_t row_pitch, int64_t plane_stride, int64_t n_cols, int64_t k_offset,
-                                 int flip_x, void* workspace, size_t workspace_bytes, void* host_pinned, size_t host_pinned_bytes,
-                                 shg_stream_t stream) {
+                                 int flip_x, uint32_t* minmax_slots, void* workspace, size_t workspace_bytes, void* host_pinned,
+                                 size_t host_pinned_bytes, shg_stream_t stream) {
     SHG_REQUIRE(stack && host_fit && host_shifts && disks && workspace && host_pinned, SHG_E_ARG, "shg_stage_extract: null pointer");
     SHG_REQUIRE(height > 0 && width > 0 && n_shifts > 0, SHG_E_ARG, "shg_stage_extract: empty input");
     const int64_t ih = slit_rows(height, width), iw = spectral_cols(height, width);
@@ -153,8 +161,8 @@ extern "C" int shg_stage_extract(const void* stack, int64_t n_frames, int64_t he
     hipStream_t st = shg::as_stream(stream);
     STAGE_HIP(hipMemcpyAsync(ind_l, h_ind, (size_t)n_shifts * ih * 4, hipMemcpyHostToDevice, st), "shg_stage_extract");
     STAGE_HIP(hipMemcpyAsync(w2, h_w2, 2 * (size_t)ih * 8, hipMemcpyHostToDevice, st), "shg_stage_extract");
-    return shg_extract_columns(stack, n_frames, height, width, bytes_per_px, frame_stride_px, ind_l, w2, w2 + ih, n_shifts, disks,
-                               row_pitch, plane_stride, n_cols, k_offset, flip_x, stream);
+    return shg_extract_columns_minmax(stack, n_frames, height, width, bytes_per_px, frame_stride_px, ind_l, w2, w2 + ih, n_shifts, disks,
+                                      row_pitch, plane_stride, n_cols, k_offset, flip_x, minmax_slots, stream);
 }
 
 // ---- ellipse_to_circle: limb detection and fit --------------------------------------------------------

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void k_warp_rows(const uint16_t* __restrict__ 
                                                    double h00, double h01, double h02, uint16_t* __restrict__ dst,
                                                    int64_t out_h, int64_t out_w, int64_t dst_pitch,
                                                    const uint32_t* __restrict__ mm) {
+    const uint32_t mn = mm[0], mx = mm[1];
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t r = blockIdx.y;
     if (c >= out_w) return;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void k_warp_rows(const uint16_t* __restrict__ 
     const double s0 = (double)row[in0 ? i0 : 0] * inv, s1 = (double)row[in1 ? i1 : 0] * inv;
     const double left = in0 ? s0 : cval, right = in1 ? s1 : cval;
     double v = (1.0 - dc) * left + dc * right;
-    const double lo = (double)mm[0] * inv, hi = (double)mm[1] * inv;
+    const double lo = (double)mn * inv, hi = (double)mx * inv;
     v = v < lo ? lo : v;                                       // np.clip(warped, image.min(), image.max())
     v = v > hi ? hi : v;
     dst[r * dst_pitch + c] = (uint16_t)(int)(65536.0 * v);     // (2**16 * img).astype(uint16)
@@ -96,5 +97,18 @@ extern "C" int shg_warp_rows_u16(const uint16_t* src, int64_t h, int64_t w, int6
     if (int e = shg::check_launch("k_minmax")) return e;
     dim3 grid((unsigned)((out_w + 255) / 256), (unsigned)out_h);
     { SHG_PROF("warp", st); k_warp_rows<<<grid, 256, 0, st>>>(src, h, w, src_pitch, h00, h01, h02, dst, out_h, out_w, dst_pitch, minmax); }
+    return shg::check_launch("k_warp_rows");
+}
+
+extern "C" int shg_warp_rows_minmax_u16(const uint16_t* src, int64_t h, int64_t w, int64_t src_pitch, double h00, double h01,
+                                        double h02, uint16_t* dst, int64_t out_h, int64_t out_w, int64_t dst_pitch,
+                                        const uint32_t* minmax2, shg_stream_t stream) {
+    SHG_REQUIRE(src && dst && minmax2, SHG_E_ARG, "shg_warp_rows_minmax_u16: null pointer");
+    SHG_REQUIRE(h > 0 && w > 0 && out_h > 0 && out_w > 0, SHG_E_ARG, "shg_warp_rows_minmax_u16: empty image");
+    SHG_REQUIRE(src_pitch >= w && dst_pitch >= out_w, SHG_E_ARG, "shg_warp_rows_minmax_u16: pitch smaller than width");
+    SHG_REQUIRE(out_h < 65536, SHG_E_UNSUPPORTED, "shg_warp_rows_minmax_u16: more than 65535 rows");
+    hipStream_t st = shg::as_stream(stream);
+    dim3 grid((unsigned)((out_w + 255) / 256), (unsigned)out_h);
+    { SHG_PROF("warp", st); k_warp_rows<<<grid, 256, 0, st>>>(src, h, w, src_pitch, h00, h01, h02, dst, out_h, out_w, dst_pitch, minmax2); }
     return shg::check_launch("k_warp_rows");
 }

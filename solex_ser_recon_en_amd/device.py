@@ -18,14 +18,17 @@ def default_device():
 class DeviceImage:
     __array_priority__ = 100
 
-    def __init__(self, tensor, row_factor=None):
+    def __init__(self, tensor, row_factor=None, minmax=None):
         """row_factor (float64 GPU tensor [h], optional): the image is then the float64 array
         tensor[y, x] * row_factor[y] -- what the reference's removeVignette returns (solex_util.py:654) --
-        kept factored so that it never has to be materialised in HBM."""
+        kept factored so that it never has to be materialised in HBM.
+        minmax (int32 GPU tensor [2] = {min, max}, optional): the image's extrema as the extraction kernel gathered them
+        (shg_extract_columns_minmax); the warp clips to them without another pass over the image."""
         if not isinstance(tensor, torch.Tensor) or not tensor.is_cuda:
             raise TypeError('DeviceImage wraps a GPU tensor')
         self.t = tensor
         self.row_factor = row_factor
+        self.minmax = minmax
         self._host = None
 
     # ndarray surface -------------------------------------------------------

@@ -48,7 +48,7 @@ def correct_image(image, phi, ratio, center, height, options, print_log=False):
     src = to_device_u16(u16_from_unit_float(image))
     h, w = src.shape
     theta, inv_mat, mat3, out_h, out_w, origin, det = _warp_geometry(float(phi), float(ratio), int(h), int(w))
-    fixed = ops.warp_rows_u16(src, mat3[0, 0], mat3[0, 1], mat3[0, 2], out_h, out_w)
+    fixed = ops.warp_rows_u16(src, mat3[0, 0], mat3[0, 1], mat3[0, 2], out_h, out_w, minmax=getattr(image, 'minmax', None))
     center = np.asarray(center)
     new_center = (inv_mat @ center.T).T - origin
     new_radius = height * np.sqrt(np.abs(ratio / det))
@@ -84,7 +84,8 @@ def ellipse_to_circle(image, options, basefich):
         g = stages.limb_fit(src, want_points=plots)
     phi, ratio = g['phi'], g['ratio']
     with timing.stage('  limb: warp'):
-        fix_img = DeviceImage(ops.warp_rows_u16(src, g['h00'], g['h01'], g['h02'], g['out_h'], g['out_w']))
+        fix_img = DeviceImage(ops.warp_rows_u16(src, g['h00'], g['h01'], g['h02'], g['out_h'], g['out_w'],
+                                                minmax=getattr(image, 'minmax', None)))
     new_circle = g['circle']
     _log_geometry(options, phi, ratio, g['theta'], np.array(new_circle[:2]), new_circle[2])
     borders = g['borders']

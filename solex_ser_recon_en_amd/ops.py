@@ -131,6 +131,27 @@ def row_mean_u16(img):
     return out
 
 
+def blur_row_mean_u16(img, kw, kh):
+    """np.mean(cv2.blur(img, (kw, kh)), axis=1) without materialising the blurred image -> float64 [h]."""
+    ptr, h, w, pitch = _img(img, 'img', torch.uint16)
+    if pitch != w:
+        raise ValueError('blur_row_mean_u16 needs a dense image')
+    out = torch.empty(h, dtype=torch.float64, device=img.device)
+    _lib.check(lib.shg_blur_row_mean_u16(ptr, h, w, int(kw), int(kh), out.data_ptr(), _stream()), 'shg_blur_row_mean_u16')
+    return out
+
+
+def blur_argmin_u16(img, kw, kh, x0, x1):
+    """(np.argmin(cv2.blur(img, (kw, kh))[:, x0:x1], axis=1), np.argmin(img, axis=1)) -> two int32 [h] tensors."""
+    ptr, h, w, pitch = _img(img, 'img', torch.uint16)
+    if pitch != w:
+        raise ValueError('blur_argmin_u16 needs a dense image')
+    out = torch.empty((2, h), dtype=torch.int32, device=img.device)
+    _lib.check(lib.shg_blur_argmin_u16(ptr, h, w, int(kw), int(kh), int(x0), int(x1), out[0].data_ptr(), out[1].data_ptr(), _stream()),
+               'shg_blur_argmin_u16')
+    return out[0], out[1]
+
+
 # ---- pass B ---------------------------------------------------------------
 def extract_columns(stack, ind_l, lw, rw, n_cols=None, k_offset=0, flip_x=False, out=None):
     """-> disks uint16 [S, ih, n_cols] (a view of a row-pitched buffer).
@@ -167,9 +188,14 @@ def extract_columns(stack, ind_l, lw, rw, n_cols=None, k_offset=0, flip_x=False,
 
 
 # ---- post-processing ----------------------------------------------------------
-def warp_rows_u16(img, h00, h01, h02, out_h, out_w):
+def warp_rows_u16(img, h00, h01, h02, out_h, out_w, minmax=None):
+    """minmax: the plane's extrema as shg_extract_columns_minmax left them (int32 [2] = {min, max}); None = found here."""
     ptr, h, w, pitch = _img(img, 'img', torch.uint16)
     out = pitched_u16(out_h, out_w, img.device)
+    if minmax is not None:
+        _lib.check(lib.shg_warp_rows_minmax_u16(ptr, h, w, pitch, float(h00), float(h01), float(h02), out.data_ptr(), int(out_h),
+                                                int(out_w), out.stride(0), minmax.data_ptr(), _stream()), 'shg_warp_rows_minmax_u16')
+        return out
     mm = torch.empty(2, dtype=torch.int32, device=img.device)
     _lib.check(lib.shg_warp_rows_u16(ptr, h, w, pitch, float(h00), float(h01), float(h02), out.data_ptr(),
                                      int(out_h), int(out_w), out.stride(0), mm.data_ptr(), _stream()),

@@ -115,20 +115,22 @@ def compute_mean_return_fit(vid_rdr, options, hdr, iw, ih, basefich0):
 
 
 # ---- a5: per-frame column extraction (reference solex_util.py:93-144) ---------------------
-def extract_disks(rdr, fit, shifts, flip_x=False):
+def extract_disks(rdr, fit, shifts, flip_x=False, want_minmax=False):
     """-> uint16 GPU tensor [S, ih, FrameCount]; all ranks hold the full mosaic when sharded.  One stage call
-    (shg_stage_extract): sample columns and weights from `fit` (:113-123), upload, the extraction kernel."""
+    (shg_stage_extract): sample columns and weights from `fit` (:113-123), upload, the extraction kernel.
+    want_minmax: -> (disks, extrema slots int32 [S, 2] or None for a sharded scan)."""
     stack = rdr.device_stack()
     n_total = int(rdr.FrameCount)
     if dist.is_sharded(rdr):
-        return dist.gather_columns(lambda out, k0: stages.extract(stack, fit, shifts, n_cols=n_total, k_offset=k0, flip_x=flip_x, out=out),
-                                   len(shifts), int(rdr.ih), rdr.frame_range, n_total, flip_x, stack.device)
-    return stages.extract(stack, fit, shifts, n_cols=n_total, k_offset=0, flip_x=flip_x)
+        mosaic = dist.gather_columns(lambda out, k0: stages.extract(stack, fit, shifts, n_cols=n_total, k_offset=k0, flip_x=flip_x, out=out),
+                                     len(shifts), int(rdr.ih), rdr.frame_range, n_total, flip_x, stack.device)
+        return (mosaic, None) if want_minmax else mosaic
+    return stages.extract(stack, fit, shifts, n_cols=n_total, k_offset=0, flip_x=flip_x, want_minmax=want_minmax)
 
 
 def read_video_improved(rdr, fit, options):
-    disks = extract_disks(rdr, fit, options['shift'])
-    return [DeviceImage(disks[i]) for i in range(disks.shape[0])], rdr.ih, rdr.iw, rdr.FrameCount
+    disks, mm = extract_disks(rdr, fit, options['shift'], want_minmax=True)
+    return [DeviceImage(disks[i], minmax=None if mm is None else mm[i]) for i in range(disks.shape[0])], rdr.ih, rdr.iw, rdr.FrameCount
 
 
 # ---- a9: transversalium (reference solex_util.py:76-86, 383-516) ---------------------------

@@ -94,8 +94,9 @@ def mean_fit(stack, n_total, sums=None, geometry=None, want_plot_data=False):
 
 
 # ---- read_video_improved ----------------------------------------------------------------------------------
-def extract(stack, fit, shifts, n_cols=None, k_offset=0, flip_x=False, out=None):
-    """-> uint16 GPU tensor [S, ih, n_cols] (rows padded to 64 elements)."""
+def extract(stack, fit, shifts, n_cols=None, k_offset=0, flip_x=False, out=None, want_minmax=False):
+    """-> uint16 GPU tensor [S, ih, n_cols] (rows padded to 64 elements); with want_minmax also the per-plane extrema
+    int32 [S, 2] = {min, max} for ops.warp_rows_u16 (only meaningful when the call covers the whole scan)."""
     n, h, w, bpp = ops.stack_geometry(stack)
     dev = stack.device
     ih = max(h, w)
@@ -114,10 +115,12 @@ def extract(stack, fit, shifts, n_cols=None, k_offset=0, flip_x=False, out=None)
     need = _sizes('extract', lib.shg_stage_extract_workspace_bytes, h, w, s)
     ws = _scratch('extract', need, dev)
     pin = _scratch('extract', need, pinned=True)
+    mm_store = torch.empty(s * 130, dtype=torch.int32, device=dev) if want_minmax else None      # 64 slots x 2 per plane, then {min, max}
     _lib.check(lib.shg_stage_extract(stack.data_ptr(), n, h, w, bpp, ops.frame_stride(stack), _p(fit), _p(sh), s, out.data_ptr(),
-                                     out.stride(1), out.stride(0), n_cols, int(k_offset), int(bool(flip_x)), ws.data_ptr(), ws.numel(),
+                                     out.stride(1), out.stride(0), n_cols, int(k_offset), int(bool(flip_x)),
+                                     None if mm_store is None else mm_store.data_ptr(), ws.data_ptr(), ws.numel(),
                                      pin.data_ptr(), pin.numel(), ops._stream()), 'shg_stage_extract')
-    return out
+    return (out, mm_store[s * 128:].view(s, 2)) if want_minmax else out
 
 
 # ---- ellipse_to_circle: the limb fit -------------------------------------------------------------------------

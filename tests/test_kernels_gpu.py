@@ -91,7 +91,47 @@ def test_row_argmin_and_mean(ops):
     np.testing.assert_array_equal(host(ops.row_mean_u16(dev(img))), np.mean(img, axis=1))
 
 
+@pytest.mark.parametrize('h,w,kw,kh', [(180, 48, 25, 1), (180, 48, 5, 5), (203, 64, 25, 7), (33, 31, 4, 6), (12, 9, 25, 3),
+                                      (2000, 200, 25, 17), (1001, 257, 25, 36), (7, 300, 5, 5)])
+def test_fused_blur_reductions_match_the_separate_kernels_and_the_oracle(ops, orc, h, w, kw, kh):
+    """shg_blur_row_mean_u16 / shg_blur_argmin_u16 (the blurred image stays in LDS) against cv2.blur's restatement
+    followed by np.mean / np.argmin -- ties included (first occurrence)."""
+    rng = np.random.default_rng(h * 7 + w)
+    img = rng.integers(0, 400 if h % 2 else 65536, (h, w)).astype(np.uint16)
+    blurred = orc.box_blur_u16(img, kw, kh)
+    np.testing.assert_array_equal(host(ops.blur_row_mean_u16(dev(img), kw, kh)), np.mean(blurred, axis=1))
+    x0, x1 = (12, w - 13) if w > 30 else (1, w - 1)
+    a_blur, a_sharp = ops.blur_argmin_u16(dev(img), kw, kh, x0, x1)
+    np.testing.assert_array_equal(host(a_blur), np.argmin(blurred[:, x0:x1], axis=1))
+    np.testing.assert_array_equal(host(a_sharp), np.argmin(img, axis=1))
+    np.testing.assert_array_equal(host(a_blur), host(ops.row_argmin_u16(ops.box_blur_u16(dev(img), kw, kh), x0, x1)))
+
+
 # ---- pass B -----------------------------------------------------------------
+@pytest.mark.parametrize('shape,flip', [((70, 40, 300), False), ((33, 130, 24), True), ((257, 24, 200), False)])
+def test_extract_gathers_the_extrema_the_warp_clips_to(ops, orc, shape, flip):
+    """shg_extract_columns_minmax leaves every plane's min / max, and the warp that takes them equals the warp
+    that looks for them itself (ragged tiles, both orientations, flip)."""
+    from solex_ser_recon_en_amd import stages
+    rng = np.random.default_rng(shape[0])
+    frames = rng.integers(100, 60000, shape).astype(np.uint16)
+    n, h, w = shape
+    ih, iw = max(h, w), min(h, w)
+    curve = np.linspace(2.3, iw - 3.4, ih)
+    fit = np.stack([np.floor(curve), curve - np.floor(curve), np.arange(ih), curve], axis=1)
+    shifts = [10, 0, -2]
+    disks, mm = stages.extract(dev(frames), fit, shifts, flip_x=flip, want_minmax=True)
+    plain = stages.extract(dev(frames), fit, shifts, flip_x=flip)
+    np.testing.assert_array_equal(host(disks), host(plain))
+    extrema = mm.cpu().numpy().astype(np.int64)
+    d = host(disks)
+    for s in range(len(shifts)):
+        assert tuple(extrema[s]) == (d[s].min(), d[s].max())
+        a = ops.warp_rows_u16(disks[s], 0.97, 0.013, 1.7, ih, n + 9, minmax=mm[s])
+        b = ops.warp_rows_u16(disks[s], 0.97, 0.013, 1.7, ih, n + 9)
+        np.testing.assert_array_equal(host(a), host(b))
+
+
 @pytest.mark.parametrize('tag', ['u16_rot', 'u16_norot', 'u8_rot', 'u16_odd'])
 @pytest.mark.parametrize('stag', ['s2', 's21', 's3'])
 def test_extract_golden(ops, orc, golden, tag, stag):
