@@ -182,20 +182,24 @@ def _window_sums(img, kw, kh, dtype):
     return c[kh:kh + h, kw:kw + w] - c[0:h, kw:kw + w] - c[kh:kh + h, 0:w] + c[0:h, 0:w]
 
 
-def box_blur_u16(img, kw, kh):
+def box_blur_u16(img, kw, kh, simd_lanes=8):
     """cv2.blur(img_u16, ksize=(kw, kh)).
 
     OpenCV's ColumnSum<int, ushort> (box_filter.simd.hpp) scales the exact integer
     window sum by 1/(kw*kh): in float32 (`v_round(v_cvt_f32(sum) * (float)scale)`)
-    for the SIMD lanes, i.e. all columns below the last multiple of 8, and in double
-    (`saturate_cast<ushort>(sum * scale)`) for the scalar tail columns.  Both round
-    half to even."""
+    for the SIMD lanes, i.e. all columns below the last multiple of the vector width, and in
+    double (`saturate_cast<ushort>(sum * scale)`) for the scalar tail columns.  Both round
+    half to even.  simd_lanes: uint16 lanes of the vector unit OpenCV was dispatched to --
+    8 for the 128-bit baseline (SSE2 / NEON), 16 for an AVX2 build, 32 for AVX-512; 0 = no SIMD
+    (every column scaled in double).  The HIP kernel uses 8; tests/test_oracle_golden.py shows
+    that everything derived from the blurred images on this path (sunlit rows, both line traces,
+    the fit) is the same for every width."""
     assert img.dtype == np.uint16 and kw >= 1 and kh >= 1
     s = _window_sums(img, kw, kh, np.int64)
     scale = 1.0 / (kw * kh)
     out = np.rint(s.astype(np.float32) * np.float32(scale)).astype(np.int64)
     w = img.shape[1]
-    tail = (w // 8) * 8
+    tail = (w // simd_lanes) * simd_lanes if simd_lanes else 0
     if tail < w:
         out[:, tail:] = np.rint(s[:, tail:].astype(np.float64) * scale).astype(np.int64)
     return np.clip(out, 0, 65535).astype(np.uint16)

@@ -49,6 +49,8 @@ def gather_reference(stack, curve, shift, rotated):
     (2000, 2000, 200, 16, [10, 0]),                                   # C2
     (2000, 2000, 200, 16, [10, 0] + [s for s in range(-10, 11) if s not in (10, 0)]),   # C4: -w -10:10:1 -> 21 disks
     (1000, 2560, 256, 16, [10, 0]),                                   # C5 frame shape
+    (4000, 2560, 256, 16, [10, 0]),                                   # C5: one whole file (5.2 GB stack)
+    (4000, 2000, 200, 16, [10, 0]),                                   # C3: the whole 4000-frame scan on one GPU
     (2000, 200, 2000, 16, [10, 0]),                                   # un-rotated file
     (200, 120, 800, 8, [10, 0]),                                      # C1 (8-bit, Width < Height)
     (200, 800, 120, 8, [10, 0]),                                      # C1 shape stored rotated
@@ -120,29 +122,97 @@ def test_whole_path_c2_against_the_oracle(env):
         assert d.max() <= 1 and np.count_nonzero(d) <= 8, (d.max(), np.count_nonzero(d))
 
 
-def test_multishift_c4_post_processing(env):
-    """-w -10:10:1: 21 requested disks through warp / transversalium / CLAHE; each product is internally
-    consistent (shape, geometry state reused) and the shift-0 product equals the single-shift run."""
+def close_products(results, want, shifts, max_flips=8):
+    for (cc, protus), shift in zip(results, shifts):
+        for got, ref in ((cc, want['results'][shift]['cc']), (protus, want['results'][shift]['protus'])):
+            d = np.abs(np.asarray(got).astype(np.int64) - ref.astype(np.int64))
+            assert d.max() <= 1 and np.count_nonzero(d) <= max_flips, (shift, d.max(), np.count_nonzero(d))
+
+
+def test_multishift_c4_against_the_oracle(env):
+    """BASELINE configs[3] at its size: 2000 frames of 2000x200, -w -10:10:1 -> 21 requested disks.  Three of them
+    (both ends of the Doppler range and the line centre) are held against the oracle, which runs the same scan with
+    just those shifts (a disk depends on its own shift, the common fit and the common limb geometry only); the
+    shift-0 products also equal the single-shift run bit for bit."""
     ops, synth = env
+    from oracle import pipeline_oracle as po
     from solex_ser_recon_en_amd import SHG_MAIN, Solex_recon
     from solex_ser_recon_en_amd.video_reader import array_reader
-    stack = synth.synth_frames_torch(600, 1200, 120, 16, seed=1)
+    stack = synth.synth_frames_torch(2000, 2000, 200, 16, seed=1)
 
     def run(shifts):
         opts = SHG_MAIN.default_options()
         opts.update(_nolog=True, shift=list(shifts))
         disk_list, bounds, hdr = Solex_recon.solex_read(array_reader(stack), opts)
-        return opts, Solex_recon.solex_process(opts, disk_list, bounds, hdr)
-    o21, r21 = run(range(-10, 11))
-    o1, r1 = run([0])
+        return opts, disk_list, Solex_recon.solex_process(opts, disk_list, bounds, hdr)
+    o21, d21, r21 = run(range(-10, 11))
+    o1, d1, r1 = run([0])
     assert o21['shift'] == [10, 0] + [s for s in range(-10, 11) if s not in (10, 0)]
     assert len(r21) == 21 and len(r1) == 1
     assert o21['ratio_fixe'] == o1['ratio_fixe'] and o21['slant_fix'] == o1['slant_fix']
-    shapes = {np.asarray(cc).shape for cc, _ in r21}
-    assert len(shapes) == 1
-    idx0 = [s for s in o21['shift'] if s in o21['shift_requested']].index(0)
+    requested = [s for s in o21['shift'] if s in o21['shift_requested']]
+    idx0 = requested.index(0)
     np.testing.assert_array_equal(np.asarray(r21[idx0][0]), np.asarray(r1[0][0]))
     np.testing.assert_array_equal(np.asarray(r21[idx0][1]), np.asarray(r1[0][1]))
+    probe = [-10, 0, 10]
+    with np.errstate(all='ignore'):
+        want = po.run(stack.cpu().numpy(), {'shift': probe})
+    for shift, ref in zip(want['read']['shifts'], want['read']['disks']):
+        np.testing.assert_array_equal(np.asarray(d21[o21['shift'].index(shift)]), ref)          # raw disks: bit exact
+    np.testing.assert_allclose(o21['ratio_fixe'], want['geometry']['ratio'], rtol=1e-9)
+    close_products([r21[requested.index(s)] for s in probe], want, probe)
+
+
+def test_whole_path_c3_size_against_the_oracle(env):
+    """BASELINE configs[2]'s scan (4000 frames of 2000x200, 16 bit) whole on one GPU vs the CPU oracle (about 30 s of
+    NumPy); tests/test_pipeline_gpu.py shards the same flow over ranks and shows bit-identical products."""
+    ops, synth = env
+    from oracle import pipeline_oracle as po
+    from solex_ser_recon_en_amd import SHG_MAIN, Solex_recon
+    from solex_ser_recon_en_amd.video_reader import array_reader
+    stack = synth.synth_frames_torch(4000, 2000, 200, 16, seed=2)
+    opts = SHG_MAIN.default_options()
+    opts['_nolog'] = True
+    disk_list, bounds, hdr = Solex_recon.solex_read(array_reader(stack), opts)
+    results = Solex_recon.solex_process(opts, disk_list, bounds, hdr)
+    with np.errstate(all='ignore'):
+        want = po.run(stack.cpu().numpy(), {})
+    assert np.asarray(disk_list[0]).shape == (2000, 4000)
+    for got, ref in zip(disk_list, want['read']['disks']):
+        np.testing.assert_array_equal(np.asarray(got), ref)
+    np.testing.assert_allclose(opts['ratio_fixe'], want['geometry']['ratio'], rtol=1e-9)
+    close_products(results, want, [0], max_flips=16)
+
+
+def test_c5_file_through_the_whole_path(env):
+    """BASELINE configs[4]'s file shape (2560x256, 16 bit): the frame passes run on all 4000 frames in
+    test_frame_passes_at_full_size; here the whole per-file flow, CLAHE included, on the first 1000 frames against
+    the oracle, and on the full 4000-frame file for shape / determinism (two runs, identical products)."""
+    ops, synth = env
+    from oracle import pipeline_oracle as po
+    from solex_ser_recon_en_amd import SHG_MAIN, Solex_recon
+    from solex_ser_recon_en_amd.video_reader import array_reader
+    stack = synth.synth_frames_torch(4000, 2560, 256, 16, seed=5)
+
+    def run(frames):
+        opts = SHG_MAIN.default_options()
+        opts['_nolog'] = True
+        disk_list, bounds, hdr = Solex_recon.solex_read(array_reader(frames), opts)
+        return opts, disk_list, Solex_recon.solex_process(opts, disk_list, bounds, hdr)
+    head = stack[:1000]
+    o, disks, results = run(head)
+    with np.errstate(all='ignore'):
+        want = po.run(ops.stack_to_host(head), {})
+    for got, ref in zip(disks, want['read']['disks']):
+        np.testing.assert_array_equal(np.asarray(got), ref)
+    np.testing.assert_allclose(o['ratio_fixe'], want['geometry']['ratio'], rtol=1e-9)
+    close_products(results, want, [0], max_flips=16)
+    oa, da, ra = run(stack)
+    ob, db, rb = run(stack)
+    assert np.asarray(da[0]).shape == (2560, 4000) and np.asarray(ra[0][0]).shape[0] == 2560
+    assert oa['ratio_fixe'] == ob['ratio_fixe']
+    np.testing.assert_array_equal(np.asarray(ra[0][0]), np.asarray(rb[0][0]))
+    np.testing.assert_array_equal(np.asarray(ra[0][1]), np.asarray(rb[0][1]))
 
 
 def test_long_scan_12000_frames_against_the_oracle(env):

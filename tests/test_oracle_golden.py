@@ -104,6 +104,44 @@ def test_line_fit_shim_mode(golden, tag):
     np.testing.assert_allclose(fit[away, 1], ref[away, 1], rtol=0, atol=1e-9)
 
 
+@pytest.mark.parametrize('source', ['g8_u16_rot', 'g8_u8_norot', 'g14_scan', 'c2_like', 'wide_sensor'])
+def test_line_fit_does_not_depend_on_opencvs_simd_width(golden, source):
+    """cv2.blur scales its window sums in float32 for the SIMD lanes and in double for the scalar tail; where that
+    boundary lies depends on the vector unit OpenCV was dispatched to (8 uint16 lanes on the baseline, 16 with AVX2, 32
+    with AVX-512).  The blurred images only steer decisions -- the sunlit rows and the two arg-min traces -- so the fit
+    (and with it every raw disk) must be the same for every width: y1, y2, both traces, the mask and `fit` bit for bit."""
+    import functools
+    from solex_ser_recon_en_amd import synth
+    if source.startswith('g8_'):
+        g = golden('g8_fit_shim')
+        tag = source[3:]
+        mean, mx = g[tag + '_mean'], g[tag + '_max']
+    else:
+        if source == 'g14_scan':
+            g = golden('g14_pipeline')
+            frames = synth.synth_frames_numpy(int(g['param_n']), int(g['param_w']), int(g['param_h']), int(g['param_bits']),
+                                              seed=int(g['param_seed']), tilt=float(g['param_tilt']), curv=float(g['param_curv']),
+                                              row_gain=g['row_gain'])
+        elif source == 'c2_like':
+            frames = synth.synth_frames_numpy(120, 2000, 200, 16, seed=0)       # C2's frame shape (iw = 200 = 25 * 8: tails differ)
+        else:
+            frames = synth.synth_frames_numpy(60, 1203, 157, 16, seed=2, tilt=0.004, curv=9e-6)    # iw = 157: ragged in every width
+        mean, mx = orc.compute_mean_max(orc.SerReader(frames))
+    base = orc.line_fit(mean, mx)
+    for lanes in (0, 16, 32, 64):
+        blur = functools.partial(orc.box_blur_u16, simd_lanes=lanes)
+        fit, y1, y2, p, aux = orc.line_fit(mean, mx, blur=blur)
+        assert (y1, y2) == (base[1], base[2])
+        np.testing.assert_array_equal(aux['min_intensity'], base[4]['min_intensity'])
+        np.testing.assert_array_equal(aux['sharp'], base[4]['sharp'])
+        np.testing.assert_array_equal(aux['mask_good'], base[4]['mask_good'])
+        np.testing.assert_array_equal(fit, base[0])
+    # the blurred images themselves do differ between widths on a handful of pixels, by one grey level
+    kh = max(1, int((base[2] - base[1]) * 0.01))
+    d = orc.box_blur_u16(mean, 25, kh, simd_lanes=0).astype(int) - orc.box_blur_u16(mean, 25, kh, simd_lanes=64).astype(int)
+    assert np.abs(d).max() <= 1
+
+
 # ---- known-answer tests for the UNPINNED third-party primitives ------------
 def test_box_blur_known_answers():
     img = np.zeros((9, 16), np.uint16)

@@ -74,15 +74,19 @@ def test_solex_read_process_vs_oracle_and_reference(pkg, scan, tag):
         np.testing.assert_allclose(opts['slant_fix'], np.degrees(want['geometry']['phi']), rtol=1e-6, atol=1e-9)
     for shift, (cc, protus) in zip(requested, results):
         ref = want['results'][shift]
-        # float stages (warp f64, transversalium f64 + device log, CLAHE f32): <= 1 LSB on a handful of pixels
-        # stubborn scenarios: a 1-LSB flip of the filtered frame (device exp / log) is stretched by the CLAHE slope
-        close_u16(cc, ref['cc'], lsb=4 if tag in 'FG' else 1)
+        # float stages (warp f64, transversalium f64 + device log, CLAHE f32) against the oracle on this host: <= 1 LSB
+        # on a handful of pixels, stubborn scenarios included (measured: all seven scenarios come out bit-identical)
+        close_u16(cc, ref['cc'])
         close_u16(protus, ref['protus'])
         for product in ('clahe', 'protus'):
             key = '%s_s%d_%s' % (tag, shift, product)
-            # (float stages of a de-vignetted frame: the row factors agree to ~1e-15, same 1-LSB allowance)
-            if key in g.files:                          # the reference's own output for this product
-                close_u16({'clahe': cc, 'protus': protus}[product], g[key], lsb=4 if tag in 'FG' and product == 'clahe' else 1)
+            # The reference's own output for this product, captured under NumPy 1.26 / SciPy 1.7 (oracle/capture_goldens.py).
+            # Stubborn scenarios: that host's exp / log / float32 filter sums leave ONE pixel of the filtered frame a grey
+            # level away from this host's, and the CLAHE slope there (about 3) stretches it -- measured 3 LSB on 1 of
+            # 168 000 px in scenario F, 0 in G; every other scenario is exact.
+            if key in g.files:
+                stretched = tag in 'FG' and product == 'clahe'
+                close_u16({'clahe': cc, 'protus': protus}[product], g[key], max_flips=2 if stretched else 4, lsb=4 if stretched else 1)
 
 
 def test_cli_writes_the_reference_file_layout(pkg, scan, tmp_path):
@@ -290,6 +294,40 @@ def test_two_ranks_sharded_scan_equals_one_rank(pkg, scan, tmp_path):
             np.testing.assert_array_equal(png_io.read_png_gray(a), png_io.read_png_gray(b), err_msg=name)
         elif name.endswith('.fits'):
             np.testing.assert_array_equal(fits_io.read_fits_u16(a)[0], fits_io.read_fits_u16(b)[0], err_msg=name)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='the RCCL (nccl) branch needs two GPUs; gloo covers the logic on one')
+def test_rccl_two_gpus_sharded_doppler_and_folder(pkg, scan, tmp_path):
+    """torch.distributed.run with the default backend (nccl = RCCL over xGMI), one process per GPU: a frame-sharded scan,
+    a dealt Doppler stack and a folder of scans.  Every rank's stack and products live on its own device (LOCAL_RANK),
+    and the products equal the single-GPU run bit for bit (tests/rccl_worker.py)."""
+    import subprocess
+    import sys
+    SHG_MAIN, Solex_recon, outputs = pkg
+    g, frames, path = scan
+    second = str(tmp_path / 'other.ser')
+    synth.write_ser(second, frames[::-1].copy())                              # the same scan taken in the other direction
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=repo, MPLBACKEND='Agg')
+    env.pop('SHG_DIST_BACKEND', None)
+    subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                    '--master-port', str(free_port()), os.path.join(repo, 'tests', 'rccl_worker.py'), str(tmp_path), path, second],
+                   check=True, env=env, cwd=repo, timeout=900)
+    r0, r1 = np.load(str(tmp_path / 'rank0.npz')), np.load(str(tmp_path / 'rank1.npz'))
+
+    def single(file, **kw):
+        opts = SHG_MAIN.default_options()
+        opts.update(_nolog=True, **kw)
+        (res,) = Solex_recon.solex_do_work([(file, opts)], True, return_results=True)
+        return [np.asarray(cc) for cc, _ in res]
+    np.testing.assert_array_equal(r0['sharded_cc'], single(path)[0])
+    stack = single(path, shift=[-2, 0, 3])                                     # processing order 0, -2, 3: dealt to ranks 0, 1, 0
+    assert int(r0['doppler_n']) == 2 and int(r1['doppler_n']) == 1
+    np.testing.assert_array_equal(r0['doppler_cc_0'], stack[0])
+    np.testing.assert_array_equal(r1['doppler_cc_0'], stack[1])
+    np.testing.assert_array_equal(r0['doppler_cc_1'], stack[2])
+    np.testing.assert_array_equal(r0['folder_cc_0'], single(path)[0])          # file 0 -> rank 0, file 1 -> rank 1
+    np.testing.assert_array_equal(r1['folder_cc_0'], single(second)[0])
 
 
 @pytest.mark.parametrize('n,w,h,bits,extra', [
