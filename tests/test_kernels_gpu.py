@@ -108,6 +108,31 @@ def test_fused_blur_reductions_match_the_separate_kernels_and_the_oracle(ops, or
 
 
 # ---- pass B -----------------------------------------------------------------
+@pytest.mark.parametrize('n,h,w,bits,shifts,slope,flip', [
+    (150, 48, 600, 16, [10, 0], 0.01, False),              # rotated, two shifts
+    (97, 40, 1028, 16, list(range(-10, 11)), 0.02, True),  # 21 shifts, ragged frame count, flip, clamps at both spectral edges
+    (130, 36, 516, 8, [10, 0, -3], 0.03, False),           # 8-bit file: 4-byte requests
+    (64, 48, 600, 16, [10, 0], 0.9, False),                # a steep line
+    (64, 48, 602, 16, [10, 0], 0.01, False),               # slit length not a multiple of the tile
+])
+def test_extract_stage_equals_the_kernel_entry_point_and_the_oracle(ops, orc, n, h, w, bits, shifts, slope, flip):
+    """shg_stage_extract (host column plan + upload + kernel + extrema) against shg_extract_columns fed with the same plan and
+    against the oracle's read_video_improved."""
+    from solex_ser_recon_en_amd import hostmath, stages
+    rng = np.random.default_rng(n + w)
+    frames = rng.integers(0, 256 if bits == 8 else 65536, (n, h, w)).astype(np.uint8 if bits == 8 else np.uint16)
+    ih, iw = w, h
+    y = np.arange(ih)
+    curve = iw / 2 + slope * (y - ih / 2) + 3 * np.sin(y / 40.0)          # runs past both spectral edges for the larger slopes: clamps
+    fit = np.stack([np.floor(curve), curve - np.floor(curve), y.astype(float), curve], axis=1)
+    got = host(stages.extract(dev(frames), fit, shifts, flip_x=flip))
+    ind_l, lw, rw = hostmath.column_plan(fit, shifts, ih, iw)
+    direct = host(ops.extract_columns(dev(frames), ind_l, lw, rw, flip_x=flip))
+    np.testing.assert_array_equal(got, direct)
+    want = np.stack(orc.extract_columns(orc.SerReader(frames), fit, shifts))
+    np.testing.assert_array_equal(got, want[:, :, ::-1] if flip else want)
+
+
 @pytest.mark.parametrize('shape,flip', [((70, 40, 300), False), ((33, 130, 24), True), ((257, 24, 200), False)])
 def test_extract_gathers_the_extrema_the_warp_clips_to(ops, orc, shape, flip):
     """shg_extract_columns_minmax leaves every plane's min / max, and the warp that takes them equals the warp
