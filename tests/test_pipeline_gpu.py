@@ -187,6 +187,52 @@ def test_folder_of_files_with_prefetch(pkg, scan, tmp_path):
         Solex_recon.solex_do_work([(files[0], SHG_MAIN.default_options()), (str(tmp_path / 'nope.ser'), SHG_MAIN.default_options())], True)
 
 
+def test_scan_workers_give_the_serial_products_bit_for_bit(pkg, tmp_path):
+    """A batch of different scans (files and device-resident stacks, different shapes, depths and options) through one,
+    two and four scan workers: every raw disk and every product is identical to the one-at-a-time order, whatever the
+    interleaving on the GPU -- files are independent, each worker has its own stream, workspace and staging buffers."""
+    SHG_MAIN, Solex_recon, outputs = pkg
+    from solex_ser_recon_en_amd.video_reader import array_reader
+    specs = [(300, 400, 32, 16, 3, {}), (260, 520, 40, 16, 4, {'shift': [-2, 0, 3]}), (300, 400, 32, 8, 5, {'flip_x': True}),
+             (280, 32, 400, 16, 6, {'crop_width_square': True}), (300, 400, 32, 16, 7, {'transversalium': False}),
+             (320, 480, 36, 16, 8, {'de-vignette': True}), (300, 400, 32, 16, 9, {'fixed_width': 300, 'img_rotate': 90}),
+             (300, 400, 32, 16, 10, {}), (300, 400, 32, 16, 11, {'stubborn_transversalium': True, 'trans_strength': 41})]
+    sources = []
+    for i, (n, w, h, bits, seed, extra) in enumerate(specs):
+        frames = synth.synth_frames_numpy(n, w, h, bits, seed=seed, tilt=0.01, curv=5e-5)
+        if i % 2:
+            path = str(tmp_path / ('scan%d.ser' % i))
+            synth.write_ser(path, frames)
+            sources.append((path, extra))
+        else:
+            sources.append((torch.from_numpy(frames).cuda(), extra))
+
+    def run(workers):
+        tasks = []
+        for src, extra in sources:
+            opts = SHG_MAIN.default_options()
+            opts.update(extra, _nolog=True)
+            tasks.append((src if isinstance(src, str) else array_reader(src), opts))
+        res = Solex_recon.solex_do_work(tasks, True, return_results=True, workers=workers)
+        outputs.flush()
+        return [[(np.asarray(cc), np.asarray(pr)) for cc, pr in per_file] for per_file in res], [t[1] for t in tasks]
+    serial, opts1 = run(1)
+    for workers in (2, 4):
+        piped, optsw = run(workers)
+        assert len(piped) == len(serial) == len(specs)
+        for a, b, oa, ob in zip(serial, piped, opts1, optsw):
+            assert len(a) == len(b) and oa['ratio_fixe'] == ob['ratio_fixe'] and oa['slant_fix'] == ob['slant_fix']
+            for (cc1, p1), (cc2, p2) in zip(a, b):
+                np.testing.assert_array_equal(cc1, cc2)
+                np.testing.assert_array_equal(p1, p2)
+    # a failure in the middle of a pipelined batch: the batch stops and the error of the lowest failing task is raised
+    bad = [(array_reader(sources[0][0]), dict(SHG_MAIN.default_options(), _nolog=True)),
+           (str(tmp_path / 'nope.ser'), dict(SHG_MAIN.default_options(), _nolog=True))] * 3
+    with pytest.raises(Exception, match='nope|No such file'):
+        Solex_recon.solex_do_work(bad, True, workers=4)
+    torch.cuda.synchronize()
+
+
 def test_stage_functions_keep_the_reference_call_surface(pkg, scan):
     """The second caller of the stage functions (spectralAnalyserUI.py:155-175, 345-359): all_video_reader ->
     compute_mean_return_fit -> read_video_improved -> ellipse_to_circle -> correct_image(disk / 65536) ->

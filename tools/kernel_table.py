@@ -7,7 +7,7 @@ import os
 
 path = max(glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True), key=os.path.getmtime)
 steps = int(sys.argv[2])
-rows = [r for r in csv.DictReader(open(path)) if 'anonymous namespace' in r['Name'] and int(r['Calls']) >= steps]
+rows = [r for r in csv.DictReader(open(path)) if '(anonymous namespace)::k_' in r['Name'] and 'at::native' not in r['Name'] and int(r['Calls']) >= steps]
 tot = 0.0
 for r in sorted(rows, key=lambda r: -float(r['TotalDurationNs'])):
     per_step = float(r['TotalDurationNs']) / steps / 1e3

@@ -1,4 +1,5 @@
-"""N bench steps on a resident C2 stack and nothing else (rocprofv3 target: per-kernel time of one step)."""
+"""N scans of a resident stack through the production entry point, one at a time, and nothing else (rocprofv3 target: per-kernel
+time of one scan).  step_loop.py [steps] [shifts a,b,c] [frames width height bits]"""
 import contextlib
 import io
 import os
@@ -12,7 +13,8 @@ from solex_ser_recon_en_amd.video_reader import array_reader  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 shifts = [int(s) for s in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0]
-stack = synth.synth_frames_torch(2000, 2000, 200, 16, seed=0, padded=True)
+n, w, h, bits = (int(v) for v in sys.argv[3:7]) if len(sys.argv) > 6 else (2000, 2000, 200, 16)
+stack = synth.synth_frames_torch(n, w, h, bits, seed=0, padded=True)
 torch.cuda.synchronize()
 for _ in range(steps):
     opts = SHG_MAIN.default_options()
