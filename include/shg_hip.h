@@ -281,6 +281,17 @@ int shg_downscale_mean_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pi
 int shg_box_blur_f64(const double* src, int64_t h, int64_t w, int k, double* dst, double* tmp,
                      shg_stream_t stream);
 
+/* cv2.blur for an image whose values are whole numbers of 2^-20 below 1 (the 4x4 block mean of uint16 / 65536,
+ * ellipse_to_circle.py:299-301), k <= 63: also keys[i] = the k x k window sum in units of 2^-20 (exact, < 2^32), so that
+ * np.median / np.percentile of the blurred image can be selected on 32-bit integers: shg_select_keys_u32, out[i] = the
+ * host_ranks[i]-th smallest of host_keys[i][n] turned back into the blurred value, (key * 2^-20) * (1 / (k_i * k_i)) --
+ * three 11-bit radix passes instead of the eight 8-bit passes float64 keys take. */
+int shg_box_blur_key_f64(const double* src, int64_t h, int64_t w, int k, double* dst, uint32_t* keys, double* tmp,
+                         shg_stream_t stream);
+size_t shg_select_keys_workspace_bytes(int n_pairs);
+int shg_select_keys_u32(const uint32_t* const* host_keys, int64_t n, const int64_t* host_ranks, const int* host_k,
+                        int n_pairs, double* out, void* workspace, size_t workspace_bytes, shg_stream_t stream);
+
 /* Exact order statistics: out[i] = the host_ranks[i]-th smallest value (0-based) of values[n]
  * (MSB-first radix select; feeds np.median / np.percentile, ellipse_to_circle.py:165, 241).
  * host_ranks is a HOST array of n_ranks <= 8 entries. */

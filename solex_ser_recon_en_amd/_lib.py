@@ -75,6 +75,9 @@ SIGNATURES = {
     'shg_fill_disc_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_uint16, P, P]),
     'shg_downscale_mean_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int, P, P]),
     'shg_box_blur_f64': (c_int, [P, c_int64, c_int64, c_int, P, P, P]),
+    'shg_box_blur_key_f64': (c_int, [P, c_int64, c_int64, c_int, P, P, P, P]),
+    'shg_select_keys_workspace_bytes': (c_size_t, [c_int]),
+    'shg_select_keys_u32': (c_int, [ctypes.POINTER(c_void_p), c_int64, ctypes.POINTER(c_int64), ctypes.POINTER(c_int), c_int, P, P, c_size_t, P]),
     'shg_select_workspace_bytes': (c_size_t, [c_int]),
     'shg_select_f64': (c_int, [P, c_int64, ctypes.POINTER(c_int64), c_int, P, P, c_size_t, P]),
     'shg_select_multi_f64': (c_int, [ctypes.POINTER(c_void_p), c_int64, ctypes.POINTER(c_int64), c_int, P, P, c_size_t, P]),

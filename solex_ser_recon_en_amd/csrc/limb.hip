@@ -229,6 +229,101 @@ __global__ __launch_bounds__(256) void k_select_final(const int64_t* __restrict_
     if (threadIdx.x == 0) out[blockIdx.x] = key_f64(st.prefix);
 }
 
+// ---- order statistics of a box-blurred block-mean image through its integer window sums -------------------------
+// The 4x4 block mean of uint16 / 65536 is a multiple of 2^-20 below 1, so a k x k window sum is an integer number of
+// 2^-20 units below k*k * 2^20 (< 2^32 for k <= 63) and cv2.blur's value is that sum times 1/(k*k): monotone in the
+// sum.  np.median / np.percentile of the blurred image are therefore order statistics of 32-bit integers -- three
+// 11-bit radix passes instead of the eight 8-bit passes the float64 keys need -- and the selected value is rebuilt
+// with the very multiply the blur kernel performs.
+__global__ __launch_bounds__(256) void k_boxf_cols_key(const double* __restrict__ tmp, int h, int w, int k, double scale,
+                                                       double* __restrict__ dst, uint32_t* __restrict__ keys) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= h * w) return;
+    const int y = i / w, x = i - y * w;
+    const int ya = y - k / 2;
+    double s = 0.0;
+    for (int j = 0; j < k; ++j) s += tmp[(int64_t)shg::reflect101(ya + j, h) * w + x];
+    dst[i] = s * scale;
+    keys[i] = (uint32_t)(s * 1048576.0);                  // exact: s is a whole number of 2^-20 units
+}
+
+constexpr int SEL32_BITS = 11, SEL32_BINS = 1 << SEL32_BITS, SEL32_PASSES = 3;      // 33 bits >= 32
+
+struct Pairs8 { const uint32_t* keys[8]; int64_t rank[8]; double scale[8]; };
+
+// the bin of hist[SEL32_BINS] whose cumulative range holds `rank` (workgroup of 256: eight bins per thread)
+__device__ __forceinline__ void pick_bin(const uint32_t* __restrict__ hist, int64_t rank, int& digit, int64_t& below) {
+    __shared__ int64_t wave_tot[4];
+    __shared__ int64_t chosen[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int PER = SEL32_BINS / 256;
+    int64_t c[PER], local = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { c[j] = hist[tid * PER + j]; local += c[j]; }
+    int64_t incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    for (int i = 0; i < wave; ++i) incl += wave_tot[i];
+    int64_t excl = incl - local;
+    if (excl <= rank && rank < incl) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (rank < excl + c[j]) { chosen[0] = tid * PER + j; chosen[1] = excl; break; }
+            excl += c[j];
+        }
+    }
+    __syncthreads();
+    digit = (int)chosen[0];
+    below = chosen[1];
+    __syncthreads();
+}
+
+// grid (blocks, n_pairs), 256 threads.  hist: [n_pairs][SEL32_PASSES][SEL32_BINS] u32, zeroed.
+__global__ __launch_bounds__(256) void k_select32_pass(Pairs8 p, int64_t n, int pass, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[SEL32_BINS];
+    const uint32_t* __restrict__ v = p.keys[blockIdx.y];
+    uint32_t* myhist = hist + (int64_t)blockIdx.y * SEL32_PASSES * SEL32_BINS;
+    int64_t rank = p.rank[blockIdx.y];
+    uint64_t prefix = 0;
+    for (int q = 0; q < pass; ++q) {                       // replay the digits of the passes before
+        int digit;
+        int64_t below;
+        pick_bin(myhist + q * SEL32_BINS, rank, digit, below);
+        rank -= below;
+        prefix = (prefix << SEL32_BITS) | (uint64_t)digit;
+    }
+    for (int i = threadIdx.x; i < SEL32_BINS; i += 256) lh[i] = 0;
+    __syncthreads();
+    const int shift = SEL32_BITS * (SEL32_PASSES - 1 - pass);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint64_t kk = v[i];
+        if (pass == 0 || (kk >> (shift + SEL32_BITS)) == prefix) atomicAdd(&lh[(kk >> shift) & (SEL32_BINS - 1)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SEL32_BINS; i += 256)
+        if (lh[i]) atomicAdd(&myhist[pass * SEL32_BINS + i], lh[i]);
+}
+
+// grid (n_pairs), 256 threads: out = (key * 2^-20) * scale, the blur kernel's own arithmetic
+__global__ __launch_bounds__(256) void k_select32_final(Pairs8 p, const uint32_t* __restrict__ hist, double* __restrict__ out) {
+    const uint32_t* myhist = hist + (int64_t)blockIdx.x * SEL32_PASSES * SEL32_BINS;
+    int64_t rank = p.rank[blockIdx.x];
+    uint64_t key = 0;
+    for (int q = 0; q < SEL32_PASSES; ++q) {
+        int digit;
+        int64_t below;
+        pick_bin(myhist + q * SEL32_BINS, rank, digit, below);
+        rank -= below;
+        key = (key << SEL32_BITS) | (uint64_t)digit;
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = ((double)key * 9.5367431640625e-07) * p.scale[blockIdx.x];
+}
+
 // ---- get_flood_image's statistics (ellipse_to_circle.py:159-169) ----------------------------------------
 // stats[0] = sum(image) (every value is k / 2^20 and the total < 2^18: exact in any order),
 // then over data = blurred[blurred < very_bright]: stats[1] = min, stats[2] = max, counts[20] = np.histogram(data, 20)
@@ -462,6 +557,57 @@ extern "C" int shg_box_blur_f64(const double* src, int64_t h, int64_t w, int k, 
     if (int e = shg::check_launch("k_boxf_rows")) return e;
     { SHG_PROF("box_blur_f64", st); k_boxf_cols<<<blocks, 256, 0, st>>>(tmp, (int)h, (int)w, k, 1.0 / ((double)k * (double)k), dst); }
     return shg::check_launch("k_boxf_cols");
+}
+
+extern "C" int shg_box_blur_key_f64(const double* src, int64_t h, int64_t w, int k, double* dst, uint32_t* keys, double* tmp,
+                                    shg_stream_t stream) {
+    SHG_REQUIRE(src && dst && keys && tmp, SHG_E_ARG, "shg_box_blur_key_f64: null pointer");
+    SHG_REQUIRE(h > 0 && w > 0 && h * w < (1ll << 30), SHG_E_ARG, "shg_box_blur_key_f64: bad image size");
+    SHG_REQUIRE(k > 0, SHG_E_ARG, "shg_box_blur_f64: kernel %d must be positive", k);
+    SHG_REQUIRE(k <= 63, SHG_E_UNSUPPORTED, "shg_box_blur_key_f64: a %d x %d window sum does not fit 32 bits", k, k);
+    hipStream_t st = shg::as_stream(stream);
+    const unsigned blocks = (unsigned)((h * w + 255) / 256);
+    SHG_PROF("box_blur_f64", st);
+    k_boxf_rows<<<blocks, 256, 0, st>>>(src, (int)h, (int)w, k, tmp);
+    if (int e = shg::check_launch("k_boxf_rows")) return e;
+    k_boxf_cols_key<<<blocks, 256, 0, st>>>(tmp, (int)h, (int)w, k, 1.0 / ((double)k * (double)k), dst, keys);
+    return shg::check_launch("k_boxf_cols_key");
+}
+
+extern "C" size_t shg_select_keys_workspace_bytes(int n_pairs) {
+    if (n_pairs < 1 || n_pairs > 8) return 0;
+    return (size_t)n_pairs * SEL32_PASSES * SEL32_BINS * sizeof(uint32_t);
+}
+
+extern "C" int shg_select_keys_u32(const uint32_t* const* host_keys, int64_t n, const int64_t* host_ranks, const int* host_k,
+                                   int n_pairs, double* out, void* workspace, size_t workspace_bytes, shg_stream_t stream) {
+    SHG_REQUIRE(host_keys && host_ranks && host_k && out && workspace, SHG_E_ARG, "shg_select_keys_u32: null pointer");
+    SHG_REQUIRE(n > 0 && n_pairs >= 1 && n_pairs <= 8, SHG_E_ARG, "shg_select_keys_u32: bad sizes");
+    SHG_REQUIRE(workspace_bytes >= shg_select_keys_workspace_bytes(n_pairs), SHG_E_WORKSPACE, "shg_select_keys_u32: workspace too small");
+    Pairs8 p = {};
+    for (int i = 0; i < n_pairs; ++i) {
+        SHG_REQUIRE(host_keys[i], SHG_E_ARG, "shg_select_keys_u32: null array");
+        SHG_REQUIRE(host_ranks[i] >= 0 && host_ranks[i] < n, SHG_E_ARG, "shg_select_keys_u32: rank %lld outside [0, %lld)", (long long)host_ranks[i], (long long)n);
+        SHG_REQUIRE(host_k[i] > 0 && host_k[i] <= 63, SHG_E_ARG, "shg_select_keys_u32: window %d", host_k[i]);
+        p.keys[i] = host_keys[i];
+        p.rank[i] = host_ranks[i];
+        p.scale[i] = 1.0 / ((double)host_k[i] * (double)host_k[i]);
+    }
+    hipStream_t st = shg::as_stream(stream);
+    uint32_t* hist = static_cast<uint32_t*>(workspace);
+    if (hipError_t e = hipMemsetAsync(hist, 0, shg_select_keys_workspace_bytes(n_pairs), st)) {
+        shg::set_error("shg_select_keys_u32: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    int64_t blocks = (n + 2047) / 2048;
+    if (blocks > 256) blocks = 256;
+    SHG_PROF("select", st);
+    for (int pass = 0; pass < SEL32_PASSES; ++pass) {
+        k_select32_pass<<<dim3((unsigned)blocks, (unsigned)n_pairs), 256, 0, st>>>(p, n, pass, hist);
+        if (int err = shg::check_launch("k_select32_pass")) return err;
+    }
+    k_select32_final<<<(unsigned)n_pairs, 256, 0, st>>>(p, hist, out);
+    return shg::check_launch("k_select32_final");
 }
 
 extern "C" size_t shg_canny_workspace_bytes(int64_t h, int64_t w) {

@@ -176,7 +176,7 @@ extern "C" size_t shg_stage_limb_points_workspace_bytes(int64_t h, int64_t w) {
     if (h <= 0 || w <= 0) return 0;
     const int64_t sh = small_dim(h), sw = small_dim(w);
     const size_t n = (size_t)sh * (size_t)sw;
-    return 4 * up(n * 8) + up(shg_select_workspace_bytes(4)) + up(4 * 8) + up(3 * 8) + up(20 * 4) + up(32) + up(32 * 8) + 2 * up(n) +
+    return 4 * up(n * 8) + up(std::max(shg_select_workspace_bytes(4), shg_select_keys_workspace_bytes(4))) + 2 * up(n * 4) + up(4 * 8) + up(3 * 8) + up(20 * 4) + up(32) + up(32 * 8) + 2 * up(n) +
            up(shg_canny_workspace_bytes(sh, sw)) + up(shg_edge_components_workspace_bytes(sh, sw)) + up((2 * n + 1) * 4) + kAlign;
 }
 
@@ -211,8 +211,10 @@ extern "C" int shg_stage_limb_points(const uint16_t* disk, int64_t h, int64_t w,
     double* blurred = dev.take<double>((size_t)n);
     double* blur5 = dev.take<double>((size_t)n);
     double* tmp = dev.take<double>((size_t)n);
-    const size_t sel_bytes = shg_select_workspace_bytes(4);
+    const size_t sel_bytes = std::max(shg_select_workspace_bytes(4), shg_select_keys_workspace_bytes(4));
     char* sel_ws = dev.take<char>(sel_bytes);
+    uint32_t* keys_k = dev.take<uint32_t>((size_t)n);
+    uint32_t* keys_5 = dev.take<uint32_t>((size_t)n);
     double* packed = dev.take<double>(32);                 // [0..3] order statistics, [4..6] flood stats
     uint32_t* counts = dev.take<uint32_t>(20);
     char* flood_ws = dev.take<char>(32);
@@ -224,21 +226,30 @@ extern "C" int shg_stage_limb_points(const uint16_t* disk, int64_t h, int64_t w,
     int32_t* comp = dev.take<int32_t>(2 * (size_t)n + 1);  // [count | idx[n] | root[n]]
     double* h_packed = pin.take<double>(32);
     int32_t* h_comp = pin.take<int32_t>(2 * (size_t)n + 1);
-    SHG_REQUIRE(small && blurred && blur5 && tmp && sel_ws && packed && counts && flood_ws && low_mask && high_mask && canny_ws && cc_ws && comp,
+    SHG_REQUIRE(small && blurred && blur5 && tmp && sel_ws && keys_k && keys_5 && packed && counts && flood_ws && low_mask && high_mask && canny_ws && cc_ws && comp,
                 SHG_E_WORKSPACE, "shg_stage_limb_points: workspace too small");
     SHG_REQUIRE(h_packed && h_comp, SHG_E_WORKSPACE, "shg_stage_limb_points: pinned staging area too small");
 
     STAGE_TRY(shg_downscale_mean_u16(disk, h, w, pitch, kFactor, small, stream));
-    STAGE_TRY(shg_box_blur_f64(small, sh, sw, k, blurred, tmp, stream));
-    STAGE_TRY(shg_box_blur_f64(small, sh, sw, 5, blur5, tmp, stream));
     // np.median(blur 5x5) (:241) and np.percentile(blurred, 99) (:165): their order statistics
     int64_t ranks[4];
     double gamma99;
     ranks[0] = (n & 1) ? n / 2 : n / 2 - 1;
     ranks[1] = n / 2;
     STAGE_TRY(shg_host_percentile_plan(n, 99.0, &ranks[2], &ranks[3], &gamma99));
-    const double* arrays[4] = {blur5, blur5, blurred, blurred};
-    STAGE_TRY(shg_select_multi_f64(arrays, n, ranks, 4, packed, sel_ws, sel_bytes, stream));
+    if (k <= 63) {
+        // the block means are whole numbers of 2^-20: select on the integer window sums (three passes instead of eight)
+        STAGE_TRY(shg_box_blur_key_f64(small, sh, sw, k, blurred, keys_k, tmp, stream));
+        STAGE_TRY(shg_box_blur_key_f64(small, sh, sw, 5, blur5, keys_5, tmp, stream));
+        const uint32_t* karr[4] = {keys_5, keys_5, keys_k, keys_k};
+        const int kk[4] = {5, 5, k, k};
+        STAGE_TRY(shg_select_keys_u32(karr, n, ranks, kk, 4, packed, sel_ws, sel_bytes, stream));
+    } else {
+        STAGE_TRY(shg_box_blur_f64(small, sh, sw, k, blurred, tmp, stream));
+        STAGE_TRY(shg_box_blur_f64(small, sh, sw, 5, blur5, tmp, stream));
+        const double* arrays[4] = {blur5, blur5, blurred, blurred};
+        STAGE_TRY(shg_select_multi_f64(arrays, n, ranks, 4, packed, sel_ws, sel_bytes, stream));
+    }
     STAGE_TRY(shg_flood_stats_lerp_f64(small, blurred, n, packed + 2, gamma99, packed + 4, counts, flood_ws, stream));
     STAGE_HIP(hipMemcpyAsync(h_packed, packed, 7 * 8, hipMemcpyDeviceToHost, st), "shg_stage_limb_points");
     STAGE_HIP(hipMemcpyAsync(h_packed + 8, counts, 20 * 4, hipMemcpyDeviceToHost, st), "shg_stage_limb_points");

@@ -440,6 +440,34 @@ def box_blur_f64(img, k):
     return out
 
 
+def box_blur_key_f64(img, k):
+    """cv2.blur of a block-mean image (whole numbers of 2^-20 below 1) -> (blurred float64, window sums uint32 in 2^-20 units)."""
+    _dev(img, 'img')
+    if img.dtype != torch.float64 or img.dim() != 2 or not img.is_contiguous():
+        raise TypeError('box_blur_key_f64 needs a dense float64 image')
+    h, w = img.shape
+    out = torch.empty_like(img)
+    tmp = torch.empty_like(img)
+    keys = torch.empty((h, w), dtype=torch.int32, device=img.device)
+    _lib.check(lib.shg_box_blur_key_f64(img.data_ptr(), h, w, int(k), out.data_ptr(), keys.data_ptr(), tmp.data_ptr(), _stream()),
+               'shg_box_blur_key_f64')
+    return out, keys
+
+
+def select_keys_u32(keys, ranks, ks):
+    """out[i] = the ranks[i]-th smallest window sum of keys[i], as the blurred value (key * 2^-20) / (ks[i] ** 2)."""
+    import ctypes
+    n = keys[0].numel()
+    ptrs = (ctypes.c_void_p * len(keys))(*[k.data_ptr() for k in keys])
+    rk = (ctypes.c_int64 * len(ranks))(*[int(r) for r in ranks])
+    kk = (ctypes.c_int * len(ks))(*[int(v) for v in ks])
+    need = lib.shg_select_keys_workspace_bytes(len(keys))
+    ws = torch.empty(need, dtype=torch.uint8, device=keys[0].device)
+    out = torch.empty(len(keys), dtype=torch.float64, device=keys[0].device)
+    _lib.check(lib.shg_select_keys_u32(ptrs, n, rk, kk, len(keys), out.data_ptr(), ws.data_ptr(), need, _stream()), 'shg_select_keys_u32')
+    return out
+
+
 def gaussian_taps(sigma, truncate=4.0):
     """scipy.ndimage's _gaussian_kernel1d(sigma, 0, radius): the taps gaussian_filter correlates with."""
     radius = int(truncate * float(sigma) + 0.5)

@@ -374,6 +374,24 @@ def test_limb_points_stage_matches_oracle(ops, golden):
         stages.limb_points(dev(disk[:300]))
 
 
+@pytest.mark.parametrize('h,w,k', [(203, 230, 2), (500, 525, 5), (97, 131, 7), (640, 1000, 6), (30, 40, 63)])
+def test_integer_key_select_equals_the_float64_select(ops, orc, h, w, k):
+    """Order statistics of cv2.blur(block mean) through the integer window sums (shg_box_blur_key_f64 + shg_select_keys_u32,
+    three 11-bit passes) against the float64 radix select on the blurred image and against np.sort."""
+    rng = np.random.default_rng(h + k)
+    small = rng.integers(0, 1 << 20, (h, w)).astype(np.float64) / (1 << 20)
+    small[: h // 3] = small[0, 0]                                          # heavy ties
+    blurred, keys = ops.box_blur_key_f64(dev(small), k)
+    plain = ops.box_blur_f64(dev(small), k)
+    np.testing.assert_array_equal(host(blurred), host(plain))
+    np.testing.assert_array_equal(host(blurred), orc.box_blur_f64(small, k, k))
+    n = h * w
+    ranks = [0, n // 2 - 1, n // 2, int(0.99 * (n - 1)), int(0.99 * (n - 1)) + 1, n - 1]
+    got = host(ops.select_keys_u32([keys] * len(ranks), ranks, [k] * len(ranks)))
+    np.testing.assert_array_equal(got, host(ops.select_f64(plain, ranks)))
+    np.testing.assert_array_equal(got, np.sort(host(plain).ravel())[ranks])
+
+
 @pytest.mark.parametrize('n', [1, 2, 5, 1000, 250000])
 def test_select_f64_is_exact(ops, n):
     rng = np.random.default_rng(n)
