@@ -25,7 +25,7 @@ Beside `value` the line carries:
                 and achieved host->device GB/s (PCIe-inclusive; never the headline `value`)
   sharded_c3    BASELINE configs[2]: ONE 4000-frame 2000x200 scan, frames sharded over the ranks, decode-inclusive
                 (each rank reads its own byte range of the file), RCCL all-reduce of the integer sum / max frames and
-                all-gather of the disk columns; strong scaling
+                all-reduce of the zero-filled disk mosaic; strong scaling
   cpu_baseline  the NumPy oracle of the same path on this box's host cores (rank 0, N = 1 only)
 
 N = 1: BASELINE.json configs[1] (2000 frames of 2000x200 16-bit, single H-alpha shift, transversalium + ellipse
@@ -74,8 +74,42 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def scratch_dir():
-    return '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else '/tmp'
+def scratch_dir(need_bytes=0):
+    """/dev/shm (page cache, no disk in the path) when it has room for the synthetic files, else /tmp."""
+    import shutil
+    for d in ('/dev/shm', '/tmp'):
+        try:
+            if os.path.isdir(d) and os.access(d, os.W_OK) and shutil.disk_usage(d).free > need_bytes * 1.25 + (64 << 20):
+                return d
+        except OSError:
+            continue
+    raise OSError('no scratch directory with %.1f GB free for the synthetic SER files' % (need_bytes / 1e9))
+
+
+def shared_path(name, need_bytes, rank, world):
+    """Rank 0 picks the scratch directory; every rank learns the path -- or the reason there is none, and raises together."""
+    import torch.distributed as td
+    box = [None]
+    if rank == 0:
+        try:
+            box = [(os.path.join(scratch_dir(need_bytes), name), None)]
+        except OSError as e:
+            box = [(None, str(e))]
+    if world > 1:
+        td.broadcast_object_list(box, src=0)
+    path, err = box[0]
+    if err:
+        raise OSError(err)
+    return path
+
+
+def guarded(leg, *a):
+    """A decode-inclusive leg must not take the headline down with it (no room for its files, ...): report the reason."""
+    try:
+        return leg(*a)
+    except Exception as e:      # noqa: BLE001
+        log('bench.py: %s skipped: %r' % (leg.__name__, e))
+        return {'error': repr(e)}
 
 
 def main():
@@ -232,8 +266,8 @@ def main():
     # ---- decode-inclusive legs: SER files in /dev/shm -> pinned host -> HBM -> products ---------------
     e2e, c3 = None, None
     if not args.no_e2e and not sharded:
-        e2e = e2e_leg(args, world, rank, stack, n_local, options, workers)
-        c3 = sharded_c3_leg(args, world, rank, options, backend)
+        e2e = guarded(e2e_leg, args, world, rank, stack, n_local, options, workers)
+        c3 = guarded(sharded_c3_leg, args, world, rank, options, backend)
 
     # ---- CPU baseline: the NumPy oracle of the same path on this box's host cores -------------------
     cpu = None
@@ -274,7 +308,7 @@ def main():
                                    'transversalium+ellipse on%s' % (
                                        n_scan, args.bits, args.width, args.height,
                                        'single H-alpha shift' if requested_shifts == [0] else 'shifts -w %s' % args.shifts, n_disks,
-                                       '' if world == 1 else (', frames sharded over %d GPUs (RCCL all-reduce + all-gather)' % world
+                                       '' if world == 1 else (', frames sharded over %d GPUs (RCCL all-reduce of sum / max frames and of the disk mosaic)' % world
                                                               if sharded else ', folder mode: %d scans per GPU, no collective' % args.steps)),
                        'frames_per_gpu': n_local, 'mode': 'single' if world == 1 else args.mode,
                        'scans_in_flight_per_process': 1 if sharded else min(workers, args.steps),
@@ -309,14 +343,19 @@ def _write_scan(path, n, width, height, bits, rank, world):
 
 
 def e2e_leg(args, world, rank, stack, n_local, options, workers):
-    """Folder of identical C2 files in /dev/shm through solex_do_work: decode (8 reader threads, pinned buffers, async
-    2-D hipMemcpy) of file k+1.. overlaps the scans in flight."""
+    """Folder of identical C2 files through solex_do_work: decode (8 reader threads, pinned buffers, async 2-D hipMemcpy) of
+    file k+1.. overlaps the scans in flight.  One file on the node, written by rank 0 and read by every rank (each rank
+    reads it n_files times from the page cache and uploads over its own PCIe link)."""
     import torch
     import torch.distributed as td
     from solex_ser_recon_en_amd import Solex_recon, ops, synth
-    path = os.path.join(scratch_dir(), 'shg_bench_e2e_%d.ser' % rank)
+    frame_bytes = stack.shape[1] * stack.shape[2] * stack.element_size()
+    path = shared_path('shg_bench_e2e.ser', stack.shape[0] * frame_bytes, rank, world)
     try:
-        synth.write_ser(path, ops.stack_to_host(stack))
+        if rank == 0:
+            synth.write_ser(path, ops.stack_to_host(stack))
+        if world > 1:
+            td.barrier()
         size = os.path.getsize(path)
         n_files = max(2, args.e2e_files)
 
@@ -338,9 +377,11 @@ def e2e_leg(args, world, rank, stack, n_local, options, workers):
                 'files_per_gpu': n_files, 'file_bytes': size, 'host_to_device_GBps_per_gpu': round(size * n_files / dt / 1e9, 2),
                 'pcie_peak_GBps': 63.0,
                 'what': 'SER file in %s -> pread into pinned host buffers -> asynchronous hipMemcpy2D -> the same hot path, products '
-                        'left in HBM (no PNG / FITS encode); decode of the next files overlaps the scans in flight' % scratch_dir()}
+                        'left in HBM (no PNG / FITS encode); decode of the next files overlaps the scans in flight' % os.path.dirname(path)}
     finally:
-        if os.path.exists(path):
+        if world > 1:
+            td.barrier()
+        if rank == 0 and path and os.path.exists(path):
             os.remove(path)
 
 
@@ -350,7 +391,7 @@ def sharded_c3_leg(args, world, rank, options, backend):
     import torch.distributed as td
     from solex_ser_recon_en_amd import Solex_recon, dist
     n, w, h = 4000, 2000, 200
-    path = os.path.join(scratch_dir(), 'shg_bench_c3.ser')
+    path = shared_path('shg_bench_c3.ser', n * w * h * 2, rank, world)
     try:
         _write_scan(path, n, w, h, 16, rank, world)
 
@@ -374,15 +415,15 @@ def sharded_c3_leg(args, world, rank, options, backend):
         return {'value': round(n * args.c3_scans / dt, 1), 'unit': 'frames/s', 'ms_per_scan': round(dt / args.c3_scans * 1e3, 2),
                 'scans': args.c3_scans, 'scaling': 'strong', 'world_size': world, 'backend': backend if world > 1 else None,
                 'collectives_per_scan': 3 if world > 1 else 0,
-                'collectives': 'all_reduce SUM (int64 sum frame), all_reduce MAX (max frame), all_gather (disk column blocks)' if world > 1 else None,
+                'collectives': 'all_reduce SUM (int64 sum frame), all_reduce MAX (max frame), all_reduce SUM (disk mosaic, disjoint column blocks)' if world > 1 else None,
                 'frames_per_rank': dist.frame_block(n, rank, world)[1] - dist.frame_block(n, rank, world)[0],
                 'what': 'one %d-frame %dx%d 16-bit SER in %s, every rank decodes its own frame block (file -> pinned -> HBM), all-reduce '
-                        'after pass A, all-gather after pass B, mosaic post-processed on rank 0; scans run one after the other' % (
-                            n, w, h, scratch_dir())}
+                        'after pass A, all-reduce of the zero-filled disk mosaic after pass B, mosaic post-processed on rank 0; scans run '
+                        'one after the other' % (n, w, h, os.path.dirname(path))}
     finally:
         if world > 1:
             td.barrier()
-        if rank == 0 and os.path.exists(path):
+        if rank == 0 and path and os.path.exists(path):
             os.remove(path)
 
 

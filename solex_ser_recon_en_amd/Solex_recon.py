@@ -10,11 +10,13 @@ What changed underneath:
     both frame passes are HIP kernels on the resident stack;
   * disks stay in HBM from extraction to the final contrast products (DeviceImage);
     the reference pickles them into a multiprocessing.Pool worker (:38);
-  * file encoders and the matplotlib diagnostics run on a background thread
-    (outputs.py), which is where the reference's Pool(4) overlap came from;
+  * a batch of files is processed by up to four scan workers at once (threads with their own HIP
+    stream, the reference's Pool(4), :30-42), fed by one decoder thread; every stage function is one C
+    call (stages.py), so the workers do not queue for the interpreter;
+  * file encoders and the matplotlib diagnostics run on background threads (outputs.py);
   * with torch.distributed initialised (one process per GPU) the frames of ONE scan are
-    sharded across ranks: all-reduce after the mean/max pass, all-gather of the disk
-    columns after extraction, post-processing on the mosaic (rank 0 writes the files).
+    sharded across ranks: all-reduce after the mean/max pass, all-reduce of the zero-filled disk
+    mosaic after extraction, post-processing on the mosaic (rank 0 writes the files).
     Several files (folder mode) are dealt round-robin to ranks instead: no collective.
 """
 import math

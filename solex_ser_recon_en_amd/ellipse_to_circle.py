@@ -1,9 +1,11 @@
 """Geometric correction: limb ellipse fit and the ellipse -> circle warp.
 
 Same surface as the reference's ellipse_to_circle.py: get_correction_matrix (:39-50),
-correct_image (:94-145) and ellipse_to_circle (:294-342).  The warp runs on the GPU
-(shg_warp_rows_u16); the limb fit works on the GPU-computed 4x4 block mean and is host
-control plane (limb_fit.py); the 2x2 matrix algebra stays NumPy as in the reference.
+correct_image (:94-145) and ellipse_to_circle (:294-342).  The limb detection and the fit are one
+stage call (stages.limb_fit -> shg_stage_limb_fit: kernels on the 4x4 block mean, then the C++ control
+plane with NumPy's own BLAS / LAPACK routines); the warp is a kernel (shg_warp_rows_u16);
+get_correction_matrix stays NumPy as in the reference (public surface; the product path computes the
+same matrix bit for bit in shg_host_correction_matrix).
 """
 import functools
 import math

@@ -324,7 +324,7 @@ def removeVignette(frame_circularized, cercle0):
     on the GPU; or the input itself when there is too little data."""
     from scipy.ndimage import gaussian_filter1d
     from scipy.signal import savgol_filter
-    from .limb_fit import lerp_order_stats
+    from .order_stats import lerp_order_stats
     t = to_device_u16(frame_circularized)
     h, w = t.shape
     cx, cy, radius = cercle0
@@ -414,7 +414,7 @@ def _rot90(t, k):
 def image_process_batch(frames, cercle, options, header, basefichs):
     """image_process for several frames of one shape: CLAHE and the order statistics of every frame are launched
     before the single device->host read of their 5 scalars each."""
-    from .limb_fit import lerp_order_stats
+    from .order_stats import lerp_order_stats
     tensors = [to_device_u16(as_uint16_image(f)) for f in frames]                       # frame.astype(np.uint16), :528
     stats = torch.empty((len(tensors), 5), dtype=torch.float64, device=tensors[0].device)
     cl1s = []

@@ -8,7 +8,7 @@ import pytest
 
 from oracle import limb_oracle as limb
 from oracle import shg_oracle as orc
-from solex_ser_recon_en_amd import CLI_handler, fits_io, hostmath, limb_fit, png_io, synth
+from solex_ser_recon_en_amd import CLI_handler, fits_io, hostmath, order_stats, png_io, synth
 from solex_ser_recon_en_amd.ellipse_to_circle import get_correction_matrix
 from solex_ser_recon_en_amd.solex_util import max_from_hist, percentile_from_hist
 from tests import numpy_ref
@@ -35,7 +35,7 @@ def points_via_scipy_label(edges):
 def flood_threshold_numpy(small, blurred):
     """The product's flood threshold (shg_host_flood_threshold) fed with the statistics the GPU would reduce."""
     n = small.size
-    lo, hi, p99 = limb_fit.lerp_order_stats(n, 99)
+    lo, hi, p99 = order_stats.lerp_order_stats(n, 99)
     srt = np.sort(blurred.ravel())
     very_bright = p99(srt[lo], srt[hi])
     assert very_bright == np.percentile(blurred, 99)
@@ -51,10 +51,10 @@ def test_order_stat_helpers_are_numpy():
     for n in (1, 2, 3, 10, 11, 1000, 12345):
         v = rng.random(n)
         srt = np.sort(v)
-        lo, hi, med = limb_fit.median_order_stats(n)
+        lo, hi, med = order_stats.median_order_stats(n)
         assert med(srt[lo], srt[hi]) == np.median(v)
         for q in (0, 1, 50, 99, 99.9999, 100):
-            lo, hi, f = limb_fit.lerp_order_stats(n, q)
+            lo, hi, f = order_stats.lerp_order_stats(n, q)
             assert f(srt[lo], srt[hi]) == np.percentile(v, q)
 
 

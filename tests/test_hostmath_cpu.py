@@ -11,7 +11,7 @@ import pytest
 from numpy.polynomial.polynomial import polyval
 
 from oracle import shg_oracle as orc
-from solex_ser_recon_en_amd import _lib, hostmath, limb_fit, solex_util
+from solex_ser_recon_en_amd import _lib, hostmath, order_stats, solex_util
 from tests import numpy_ref
 
 lib = _lib.lib
@@ -402,8 +402,8 @@ def test_trend_before_exp_is_bit_identical():
 @pytest.mark.parametrize('n,q', [(4000000, 99.9999), (4000000, 10), (250000, 99), (7, 50), (1, 85), (2098 * 2000, 99.9999)])
 def test_percentile_plan(n, q):
     lo, hi, gamma = hostmath.percentile_plan(n, q)
-    wlo, whi, _ = limb_fit.lerp_order_stats(n, q)
-    assert (lo, hi) == (wlo, whi) and gamma == limb_fit.lerp_gamma(n, q)
+    wlo, whi, _ = order_stats.lerp_order_stats(n, q)
+    assert (lo, hi) == (wlo, whi) and gamma == order_stats.lerp_gamma(n, q)
     rng = np.random.default_rng(0)
     a, b = sorted(rng.random(2))
-    assert lib.shg_host_lerp(a, b, gamma) == limb_fit.lerp_order_stats(n, q)[2](a, b)
+    assert lib.shg_host_lerp(a, b, gamma) == order_stats.lerp_order_stats(n, q)[2](a, b)

@@ -417,7 +417,7 @@ def test_flood_stats_match_numpy(ops, golden):
     np.testing.assert_array_equal(host(counts), want)
     np.testing.assert_array_equal(host(stats), [np.sum(small), data.min(), data.max()])
     # very_bright interpolated on the device from the two order statistics np.percentile uses (q = 99 and others)
-    from solex_ser_recon_en_amd.limb_fit import lerp_gamma, lerp_order_stats
+    from solex_ser_recon_en_amd.order_stats import lerp_gamma, lerp_order_stats
     srt = np.sort(blurred.ravel())
     for q in (99, 50, 12.5, 99.9999, 0, 100):
         lo, hi, mix = lerp_order_stats(srt.size, q)
@@ -432,7 +432,7 @@ def test_flood_stats_match_numpy(ops, golden):
 
 @pytest.mark.parametrize('h,w', [(300, 330), (57, 1025), (1, 9), (260, 3)])
 def test_line_order_stats_and_percentile(ops, h, w):
-    from solex_ser_recon_en_amd.limb_fit import lerp_order_stats
+    from solex_ser_recon_en_amd.order_stats import lerp_order_stats
     rng = np.random.default_rng(h * w)
     img = rng.integers(0, 65536, (h, w)).astype(np.uint16)
     img[:, : w // 3] = 513                                  # ties, and one high byte shared by both ranks
@@ -494,7 +494,7 @@ def test_select_u16_is_exact(ops, h, w):
         padded[:, :w] = dev(img)                          # a pitched view: the padding must not be counted
         got = host(ops.select_u16(padded[:, :w], ranks))
         np.testing.assert_array_equal(got, srt[ranks].astype(np.float64))
-    from solex_ser_recon_en_amd.limb_fit import lerp_order_stats
+    from solex_ser_recon_en_amd.order_stats import lerp_order_stats
     for q in (10, 99.9999):
         lo, hi, mix = lerp_order_stats(n, q)
         a, b = host(ops.select_u16(dev(img), [lo, hi]))
