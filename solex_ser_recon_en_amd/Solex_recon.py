@@ -26,7 +26,7 @@ import threading
 import numpy as np
 
 from . import dist, ops, outputs, timing
-from .device import DeviceImage, default_device, to_device_u16
+from .device import DeviceImage, bind_thread, cpu_plan, default_device, to_device_u16
 from .ellipse_to_circle import correct_image, ellipse_to_circle
 from .fits_io import write_fits
 from . import stages
@@ -66,25 +66,33 @@ class _Decoder:
         self.thread.start()
 
     def _run(self):
-        import torch
-        torch.cuda.set_device(self.device)
-        for i, (file, _) in enumerate(self.tasks):
-            self.slots.acquire()
-            if self.stop:
-                self.out[i] = (None, RuntimeError('batch cancelled'))
-            elif hasattr(file, 'device_stack'):
-                self.out[i] = (file, None)
-            else:
-                try:
-                    rdr = video_reader(file)
-                    if self.frame_range is not None:
-                        _check_shardable(rdr)
-                        rdr.frame_range = self.frame_range(int(rdr.FrameCount))
-                    rdr.device_stack(device=self.device)
-                    self.out[i] = (rdr, None)
-                except BaseException as e:      # noqa: BLE001 -- re-raised when this file's turn comes
-                    self.out[i] = (None, e)
-            self.ready[i].set()
+        i = 0
+        try:
+            import torch
+            torch.cuda.set_device(self.device)
+            bind_thread('io', self.device)                   # the reader threads inherit it: off the scan workers' cores
+            for i, (file, _) in enumerate(self.tasks):
+                self.slots.acquire()
+                if self.stop:
+                    self.out[i] = (None, RuntimeError('batch cancelled'))
+                elif hasattr(file, 'device_stack'):
+                    self.out[i] = (file, None)
+                else:
+                    try:
+                        rdr = video_reader(file)
+                        if self.frame_range is not None:
+                            _check_shardable(rdr)
+                            rdr.frame_range = self.frame_range(int(rdr.FrameCount))
+                        rdr.device_stack(device=self.device)
+                        self.out[i] = (rdr, None)
+                    except BaseException as e:      # noqa: BLE001 -- re-raised when this file's turn comes
+                        self.out[i] = (None, e)
+                self.ready[i].set()
+        except BaseException as e:      # noqa: BLE001 -- whatever stops this thread must not leave a scan waiting for its file
+            for j in range(i, len(self.tasks)):
+                if not self.ready[j].is_set():
+                    self.out[j] = (None, e)
+                    self.ready[j].set()
 
     def get(self, i):
         """The reader of task i, its frames resident in HBM (raises what its decode raised)."""
@@ -124,7 +132,8 @@ def solex_do_work(tasks, flag_command_line=False, distribute='auto', return_resu
     if not tasks:
         return [] if return_results else None
     n_workers = 1 if shard_frames else _worker_count(workers, len(tasks))
-    decoder = _Decoder(tasks, dist.frame_block if shard_frames else None, ahead=n_workers + 1)
+    cpu_plan()                                              # on this thread, before any worker asks (torch's device queries
+    decoder = _Decoder(tasks, dist.frame_block if shard_frames else None, ahead=n_workers + 1)      # are not re-entrant at first use)
     collected = [None] * len(tasks)
 
     def scan(i):
@@ -148,8 +157,13 @@ def solex_do_work(tasks, flag_command_line=False, distribute='auto', return_resu
 
     try:
         if n_workers == 1:
-            for i in range(len(tasks)):
-                scan(i)
+            previous = bind_thread('scan', decoder.device)  # this thread is the scan worker for the duration (device.cpu_plan)
+            try:
+                for i in range(len(tasks)):
+                    scan(i)
+            finally:
+                if previous is not None:
+                    os.sched_setaffinity(0, previous)
         else:
             _scan_pool(scan, len(tasks), n_workers, decoder.device)
     finally:
@@ -204,10 +218,16 @@ def _scan_pool(scan, n_tasks, n_workers, device):
     state = {'next': 0, 'errors': []}
 
     def run(k):
-        torch.cuda.set_device(device)
-        ctx = _worker_context(device, k)
-        stages.use_buffers(ctx['buffers'])
-        stream = ctx['stream']
+        try:
+            torch.cuda.set_device(device)
+            bind_thread('scan', device)                     # one L3 group next to the GPU (device.cpu_plan)
+            ctx = _worker_context(device, k)
+            stages.use_buffers(ctx['buffers'])
+            stream = ctx['stream']
+        except BaseException as e:      # noqa: BLE001 -- a worker that cannot start fails the batch instead of vanishing
+            with lock:
+                state['errors'].append((state['next'], e))
+            return
         with torch.cuda.stream(stream):
             while True:
                 with lock:
@@ -303,8 +323,10 @@ def solex_process(options, disk_list, backup_bounds, hdr):
             if not deal or dist.rank() == 0:
                 try:
                     with timing.stage('ellipse_fit+warp'):
+                        # (the corrected image of the ellipse-fit shift is only computed when somebody uses it: a requested
+                        # disk, or the diagnostic plot)
                         frame_circularized, cercle0, options['ratio_fixe'], phi, borders = ellipse_to_circle(
-                            disk_list[i], options, basefich)
+                            disk_list[i], options, basefich, need_image=flag_requested and mine)
                 except Exception as e:                      # noqa: BLE001
                     if not deal:
                         raise

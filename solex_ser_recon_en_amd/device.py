@@ -15,6 +15,105 @@ def default_device():
     return torch.device('cuda', torch.cuda.current_device())
 
 
+_cpu_plan = {}
+
+
+def _cpulist(text):
+    cpus = []
+    for part in text.strip().split(','):
+        if part:
+            a, _, b = part.partition('-')
+            cpus.extend(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def _l3_groups(node, online, sysfs='/sys'):
+    """The L3 groups (sets of online cpus that share one last-level cache) of a NUMA node, in cpu order."""
+    groups, seen = [], set()
+    for c in sorted(_cpulist(open('%s/devices/system/node/node%d/cpulist' % (sysfs, node)).read())):
+        if c in seen or c not in online:
+            continue
+        grp = set(_cpulist(open('%s/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list' % (sysfs, c)).read())) & online
+        seen |= grp | {c}
+        if grp:
+            groups.append(grp)
+    return groups
+
+
+def _share_of_node(groups, position, n_peers):
+    """{'scan', 'io'} for the GPU at `position` among the `n_peers` GPUs attached to a node with these L3 groups:
+    the groups are dealt round-robin, the first of a GPU's share runs its scan workers, the others its readers and
+    encoders (all of them on the one group when that is all there is).  None when the share is too small to be worth
+    pinning to (fewer than four cpus: pinning four scan workers there would serialise them)."""
+    mine = groups[position::n_peers]
+    if not mine or len(mine[0]) < 4:
+        return None
+    rest = set().union(*mine[1:]) if len(mine) > 1 else set()
+    return {'scan': set(mine[0]), 'io': rest or set(mine[0])}
+
+
+def cpu_plan(device=None):
+    """Where this process's threads should run, or None to leave them to the scheduler: {'scan': cpus, 'io': cpus}.
+
+    The scan workers hand the interpreter lock and HIP completions back and forth thousands of times per second.  With the
+    threads free to roam over a 2 x 64-core host a batch runs at 2.0-2.8 M frames/s (C2); on the eight cores (and their
+    SMT siblings) that share one L3 next to the GPU it runs at 2.8-3.6 M; two L3 groups are already worse
+    (tools/numa_probe.py).  So: 'scan' = one L3 group of the GPU's NUMA node, 'io' = the other L3 groups of this GPU's share
+    of the node (decode readers, encoders: memcpy- and deflate-bound, they should not sit on the scan cores).  GPUs that
+    share a NUMA node take its L3 groups round-robin in PCI order, so eight ranks on one host do not overlap.
+    Only when the process still has the machine-wide default affinity (numactl / taskset / a batch scheduler win);
+    SHG_CPU_AFFINITY=off disables it, SHG_CPU_AFFINITY=<cpu list> puts every thread kind on those cpus.
+
+    The first call for a device must come from the thread that owns it (solex_do_work makes it before it starts its
+    workers): torch's device queries are not safe to run for the first time from several threads at once.  Whatever goes
+    wrong in here means "no placement", never a failed scan."""
+    import os
+    if not hasattr(os, 'sched_setaffinity'):
+        return None
+    device = device if device is not None else default_device()
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    if index in _cpu_plan:
+        return _cpu_plan[index]
+    plan = None
+    choice = os.environ.get('SHG_CPU_AFFINITY', 'auto').strip()
+    try:
+        if choice.lower() in ('off', '0', 'no', 'none'):
+            plan = None
+        elif choice.lower() != 'auto':
+            cpus = set(_cpulist(choice))
+            plan = {'scan': cpus, 'io': cpus} if cpus else None
+        else:
+            online = set(_cpulist(open('/sys/devices/system/cpu/online').read()))
+            if os.sched_getaffinity(0) == online:            # otherwise the caller has already chosen
+                props = [torch.cuda.get_device_properties(i) for i in range(torch.cuda.device_count())]
+                nodes = [int(open('/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node'
+                                  % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)).read()) for p in props]
+                node = nodes[index]
+                if node >= 0:
+                    peers = sorted((i for i in range(len(props)) if nodes[i] == node),
+                                   key=lambda i: (props[i].pci_domain_id, props[i].pci_bus_id, props[i].pci_device_id))
+                    plan = _share_of_node(_l3_groups(node, online), peers.index(index), len(peers))
+    except Exception:      # noqa: BLE001 -- no sysfs, odd topology, torch without PCI ids: placement is optional
+        plan = None
+    _cpu_plan[index] = plan
+    return plan
+
+
+def bind_thread(kind, device=None):
+    """Put the calling thread (and the threads it creates from now on) on the cpus of `kind` ('scan' or 'io').
+    -> the previous mask (to restore with os.sched_setaffinity(0, mask)) or None when nothing was changed."""
+    import os
+    try:
+        plan = cpu_plan(device)
+        if not plan:
+            return None
+        old = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, plan[kind])
+        return old
+    except Exception:      # noqa: BLE001 -- placement is an optimisation, never a reason to fail a scan
+        return None
+
+
 class DeviceImage:
     __array_priority__ = 100
 

@@ -76,8 +76,10 @@ def _log_geometry(options, phi, ratio, theta, new_center, new_radius, known=True
     np.set_printoptions(suppress=False)
 
 
-def ellipse_to_circle(image, options, basefich):
+def ellipse_to_circle(image, options, basefich, need_image=True):
     """image: the uint16 raw disk.  Returns (fix_img, (cx, cy, r), ratio, phi, borders).
+    need_image=False (solex_process, when the ellipse-fit shift is not a requested disk and no diagnostic plot is drawn):
+    the corrected image nobody looks at is not computed, fix_img is None.
     One stage call (shg_stage_limb_fit: block mean, flood image, canny ladder, labelled edges, region / hull / row
     selection, two-step ellipse fit, geometry of the corrected image, borders) and the warp kernel."""
     src = to_device_u16(image)
@@ -85,9 +87,11 @@ def ellipse_to_circle(image, options, basefich):
     with timing.stage('  limb: fit'):
         g = stages.limb_fit(src, want_points=plots)
     phi, ratio = g['phi'], g['ratio']
-    with timing.stage('  limb: warp'):
-        fix_img = DeviceImage(ops.warp_rows_u16(src, g['h00'], g['h01'], g['h02'], g['out_h'], g['out_w'],
-                                                minmax=getattr(image, 'minmax', None)))
+    fix_img = None
+    if need_image or plots:
+        with timing.stage('  limb: warp'):
+            fix_img = DeviceImage(ops.warp_rows_u16(src, g['h00'], g['h01'], g['h02'], g['out_h'], g['out_w'],
+                                                    minmax=getattr(image, 'minmax', None)))
     new_circle = g['circle']
     _log_geometry(options, phi, ratio, g['theta'], np.array(new_circle[:2]), new_circle[2])
     borders = g['borders']

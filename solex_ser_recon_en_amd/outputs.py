@@ -54,6 +54,25 @@ def _plot_in_worker(fn, args):
 synchronous = False          # tests can force inline execution
 
 
+def _submitting_device():
+    try:
+        from .device import default_device
+        return default_device()                             # the current device is thread-local: ask on the submitting thread
+    except Exception:      # noqa: BLE001 -- encoders also serve host-only callers
+        return None
+
+
+def _off_the_scan_cores(device):
+    """Encoders deflate and byte-swap megabytes: keep them off the cores the scan workers share (device.cpu_plan)."""
+    if device is None:
+        return
+    try:
+        from .device import bind_thread
+        bind_thread('io', device)
+    except Exception:      # noqa: BLE001 -- odd topology: stay where we are
+        pass
+
+
 def _stream_event(args):
     """The images were produced on the submitting thread's HIP stream; the encoder threads copy them to the host on
     their own (default) stream, so a task first waits for an event recorded behind the producing kernels."""
@@ -80,7 +99,8 @@ def submit(fn, *args):
     with _lock:
         if kind not in _pools:
             _pools[kind] = ThreadPoolExecutor(max_workers=1 if kind == 'plot' else ENCODER_THREADS,
-                                              thread_name_prefix='shg-' + kind)
+                                              thread_name_prefix='shg-' + kind, initializer=_off_the_scan_cores,
+                                              initargs=(_submitting_device(),))
         if kind == 'plot' and _plot_processes() > 0:
             # the plot thread only copies the images to the host and hands the figure to a worker process
             _pending.append(_pools[kind].submit(_run_after, done, _plot_in_worker, (fn, args)))
