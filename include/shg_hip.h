@@ -183,6 +183,11 @@ int shg_warp_rows_minmax_u16(const uint16_t* src, int64_t h, int64_t w, int64_t 
 int shg_rowpair_logratio_stats(const uint16_t* img, int64_t h, int64_t w, int64_t pitch,
                                int64_t y1, int64_t y2, const int32_t* xa, const int32_t* xb,
                                const double* row_factor, double* out, shg_stream_t stream);
+/* The same, also storing the statistics at out_mirror (may be NULL): a second, GPU-mapped host buffer for the control
+ * plane, so that no copy has to follow (shg_stage_process_frames). */
+int shg_rowpair_logratio_stats_mirrored(const uint16_t* img, int64_t h, int64_t w, int64_t pitch,
+                                        int64_t y1, int64_t y2, const int32_t* xa, const int32_t* xb,
+                                        const double* row_factor, double* out, double* out_mirror, shg_stream_t stream);
 
 /* scipy.ndimage.correlate1d(src, weights, axis=-1, mode='constant', cval=0) for k rows of n float64
  * samples with 2*radius+1 float64 weights (device memory), in NI_Correlate1D's order of operations:

@@ -55,6 +55,7 @@ SIGNATURES = {
     'shg_warp_rows_u16': (c_int, [P, c_int64, c_int64, c_int64, c_double, c_double, c_double, P, c_int64, c_int64,
                                   c_int64, P, P]),
     'shg_rowpair_logratio_stats': (c_int, [P, c_int64, c_int64, c_int64, c_int64, c_int64, P, P, P, P, P]),
+    'shg_rowpair_logratio_stats_mirrored': (c_int, [P, c_int64, c_int64, c_int64, c_int64, c_int64, P, P, P, P, P, P]),
     'shg_line_order_stats_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int64, c_int64, P, P, P]),
     'shg_scale_rows_u16': (c_int, [P, c_int64, c_int64, c_int64, P, P, P, c_int64, P]),
     'shg_correlate1d_rows_f64': (c_int, [P, c_int64, c_int64, P, c_int, c_int, P, P]),

@@ -119,71 +119,91 @@ extern "C" int shg_row_mean_u16(const uint16_t* img, int64_t h, int64_t w, doubl
 namespace {
 constexpr int FROWS = 8;
 
-__device__ __forceinline__ int blur_scaled(uint32_t s, int64_t x, int64_t w, double scale) {
+__device__ __forceinline__ int blur_scaled(uint32_t s, int x, int w, double scale) {
     int r;
-    if (x < (w / 8) * 8) r = __float2int_rn(__int2float_rn((int)s) * (float)scale);
+    if (x < (w & ~7)) r = __float2int_rn(__int2float_rn((int)s) * (float)scale);
     else r = __double2int_rn((double)(int)s * scale);
     return r < 0 ? 0 : (r > 65535 ? 65535 : r);
 }
 
 // MODE 0: row means of the blurred image (float64).  MODE 1: first arg-minimum over [x0, x1) of the blurred row
 // (relative to x0) and first arg-minimum of the unblurred row over all columns.
+// reflect101 without the 64-bit remainder for the indices a window can reach (one reflection at either end)
+__device__ __forceinline__ int reflect_near(int i, int n) {
+    int r = i < 0 ? -i : i;
+    r = r >= n ? 2 * n - 2 - r : r;
+    return (unsigned)r < (unsigned)n ? r : (int)shg::reflect101(i, n);
+}
+
 template <int MODE>
-__global__ __launch_bounds__(256) void k_blur_reduce(const uint16_t* __restrict__ src, int64_t h, int64_t w, int kw, int kh,
-                                                     double scale, int64_t x0, int64_t x1, double* __restrict__ means,
+__global__ __launch_bounds__(256) void k_blur_reduce(const uint16_t* __restrict__ src, int h, int w, int kw, int kh,
+                                                     double scale, int x0, int x1, double* __restrict__ means,
                                                      int32_t* __restrict__ arg_blur, int32_t* __restrict__ arg_sharp) {
-    // LDS: raw[FROWS + kh - 1][w] uint16 (the rows this workgroup needs, reflected), then vs[FROWS][w] uint32 vertical
-    // sums.  Box sums are integers, so summing down the columns first and along the rows second gives the very sums
-    // of k_box_rows + k_box_cols.
+    // LDS: vs[FROWS][w] uint32 vertical sums, then raw[FROWS + kh - 1][w] uint16 (the rows this workgroup needs,
+    // reflected).  Box sums are integers, so summing down the columns first and along the rows second gives the very
+    // sums of k_box_rows + k_box_cols.  All index arithmetic is 32-bit and division-free: with one workgroup per CU the
+    // kernel's time is its longest dependent chain, and a 64-bit i / w in each loop was most of it (17-20 us -> see
+    // profiles/).
     extern __shared__ uint32_t blur_lds[];
     const int nrows = FROWS + kh - 1;
     uint32_t* vs = blur_lds;                                               // [FROWS][w]
-    uint16_t* raw = reinterpret_cast<uint16_t*>(blur_lds + (size_t)FROWS * w);   // [nrows][w]
-    const int64_t r0 = (int64_t)blockIdx.x * FROWS;
-    const int64_t ya = r0 - kh / 2;
-    for (int64_t i = threadIdx.x; i < (int64_t)nrows * w; i += 256) {
-        const int64_t j = i / w, x = i - j * w;
-        raw[i] = src[shg::reflect101(ya + j, h) * w + x];
-    }
-    __syncthreads();
-    for (int64_t i = threadIdx.x; i < (int64_t)FROWS * w; i += 256) {
-        const int64_t rr = i / w, x = i - rr * w;
-        uint32_t s = 0;
-        for (int j = 0; j < kh; ++j) s += raw[(rr + j) * w + x];
-        vs[i] = s;
-    }
-    __syncthreads();
+    uint16_t* raw = reinterpret_cast<uint16_t*>(blur_lds + FROWS * w);     // [nrows][w]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * FROWS;
+    const int ya = r0 - kh / 2;
+    for (int j = wave; j < nrows; j += 4) {                // one wave per staged row
+        const uint16_t* srow = src + (int64_t)reflect_near(ya + j, h) * w;
+        uint16_t* drow = raw + j * w;
+        if ((w & 1) == 0) {                                // even width: every row starts on a 4-byte boundary
+            const uint32_t* s2 = reinterpret_cast<const uint32_t*>(srow);
+            uint32_t* d2 = reinterpret_cast<uint32_t*>(drow);
+            for (int x = lane; x < (w >> 1); x += 64) d2[x] = s2[x];
+        } else {
+            for (int x = lane; x < w; x += 64) drow[x] = srow[x];
+        }
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < w; x += 256) {           // a running sum down each column
+        uint32_t s = 0;
+        for (int j = 0; j < kh; ++j) s += raw[j * w + x];
+        vs[x] = s;
+        for (int rr = 1; rr < FROWS; ++rr) {
+            s += raw[(rr + kh - 1) * w + x];
+            s -= raw[(rr - 1) * w + x];
+            vs[rr * w + x] = s;
+        }
+    }
+    __syncthreads();
     for (int rr = wave; rr < FROWS; rr += 4) {             // one wave per output row
-        const int64_t y = r0 + rr;
+        const int y = r0 + rr;
         if (y >= h) break;
-        const uint32_t* vrow = vs + (int64_t)rr * w;
-        auto blurred = [&](int64_t x) {
-            const int64_t xa = x - kw / 2;
+        const uint32_t* vrow = vs + rr * w;
+        auto blurred = [&](int x) {
+            const int xa = x - kw / 2;
             uint32_t s = 0;
             if (xa >= 0 && xa + kw <= w) {
                 for (int t = 0; t < kw; ++t) s += vrow[xa + t];
             } else {
-                for (int t = 0; t < kw; ++t) s += vrow[shg::reflect101(xa + t, w)];
+                for (int t = 0; t < kw; ++t) s += vrow[reflect_near(xa + t, w)];
             }
             return (uint32_t)blur_scaled(s, x, w, scale);
         };
         if (MODE == 0) {
             uint64_t acc = 0;
-            for (int64_t x = lane; x < w; x += 64) acc += (uint64_t)blurred(x);
+            for (int x = lane; x < w; x += 64) acc += (uint64_t)blurred(x);
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
             if (lane == 0) means[y] = (double)acc / (double)w;
         } else {
             uint32_t best = 0xffffffffu, sbest = 0xffffffffu;
             int32_t best_i = 0x7fffffff, sbest_i = 0x7fffffff;
-            const uint16_t* row = raw + (int64_t)(rr + kh / 2) * w;          // the unblurred row y itself
-            for (int64_t x = lane; x < w; x += 64) {
+            const uint16_t* row = raw + (rr + kh / 2) * w;                  // the unblurred row y itself
+            for (int x = lane; x < w; x += 64) {
                 const uint32_t sv = row[x];
-                if (sv < sbest) { sbest = sv; sbest_i = (int32_t)x; }
+                if (sv < sbest) { sbest = sv; sbest_i = x; }
                 if (x >= x0 && x < x1) {
                     const uint32_t v = blurred(x);
-                    if (v < best) { best = v; best_i = (int32_t)(x - x0); }
+                    if (v < best) { best = v; best_i = x - x0; }
                 }
             }
 #pragma unroll
@@ -209,12 +229,13 @@ extern "C" int shg_blur_row_mean_u16(const uint16_t* src, int64_t h, int64_t w, 
     SHG_REQUIRE(h > 0 && w > 0, SHG_E_ARG, "shg_blur_row_mean_u16: empty image");
     SHG_REQUIRE(kw > 0 && kh > 0, SHG_E_ARG, "shg_box_blur_u16: kernel %d x %d must be positive", kw, kh);
     SHG_REQUIRE((int64_t)kw * kh <= 32768, SHG_E_UNSUPPORTED, "shg_box_blur_u16: window %d x %d overflows int32 sums", kw, kh);
+    SHG_REQUIRE(h < (1ll << 30), SHG_E_UNSUPPORTED, "shg_blur_row_mean_u16: %lld rows", (long long)h);
     SHG_REQUIRE(shg_blur_fits_fused(w, kh), SHG_E_UNSUPPORTED, "shg_blur_row_mean_u16: %lld columns x %d rows do not fit the LDS tile", (long long)w, kh);
     hipStream_t st = shg::as_stream(stream);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_reduce<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlurReduceMaxLds); attr = true; }
     { SHG_PROF("blur_row_mean", st); k_blur_reduce<0><<<(unsigned)((h + FROWS - 1) / FROWS), 256, blur_reduce_lds(w, kh), st>>>(
-          src, h, w, kw, kh, 1.0 / ((double)kw * (double)kh), 0, w, out, nullptr, nullptr); }
+          src, (int)h, (int)w, kw, kh, 1.0 / ((double)kw * (double)kh), 0, (int)w, out, nullptr, nullptr); }
     return shg::check_launch("k_blur_reduce");
 }
 
@@ -225,11 +246,12 @@ extern "C" int shg_blur_argmin_u16(const uint16_t* src, int64_t h, int64_t w, in
     SHG_REQUIRE(kw > 0 && kh > 0, SHG_E_ARG, "shg_box_blur_u16: kernel %d x %d must be positive", kw, kh);
     SHG_REQUIRE((int64_t)kw * kh <= 32768, SHG_E_UNSUPPORTED, "shg_box_blur_u16: window %d x %d overflows int32 sums", kw, kh);
     SHG_REQUIRE(x0 >= 0 && x1 <= w && x0 < x1, SHG_E_ARG, "shg_row_argmin_u16: empty column range [%lld, %lld) of %lld", (long long)x0, (long long)x1, (long long)w);
+    SHG_REQUIRE(h < (1ll << 30), SHG_E_UNSUPPORTED, "shg_blur_argmin_u16: %lld rows", (long long)h);
     SHG_REQUIRE(shg_blur_fits_fused(w, kh), SHG_E_UNSUPPORTED, "shg_blur_argmin_u16: %lld columns x %d rows do not fit the LDS tile", (long long)w, kh);
     hipStream_t st = shg::as_stream(stream);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_reduce<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlurReduceMaxLds); attr = true; }
     { SHG_PROF("blur_argmin", st); k_blur_reduce<1><<<(unsigned)((h + FROWS - 1) / FROWS), 256, blur_reduce_lds(w, kh), st>>>(
-          src, h, w, kw, kh, 1.0 / ((double)kw * (double)kh), x0, x1, nullptr, out_blur, out_sharp); }
+          src, (int)h, (int)w, kw, kh, 1.0 / ((double)kw * (double)kh), (int)x0, (int)x1, nullptr, out_blur, out_sharp); }
     return shg::check_launch("k_blur_reduce");
 }

@@ -51,6 +51,64 @@ struct Arena {
         }                                                                  \
     } while (0)
 
+// ---- host <-> device without the copy engines ---------------------------------------------------------------
+// The control plane moves a few KB per stage.  hipMemcpyAsync sends those through the SDMA queues (or the runtime's
+// blit kernels): ~14 extra operations per scan, and with several scan workers the SDMA path stalls every stream of the
+// process for 3-20 ms now and then (measured: tools/scan_timeline.py; HSA_ENABLE_SDMA=0 removes the stalls but makes
+// every copy a blit launch).  Pinned host memory is mapped into the GPU's address space, so instead: a kernel whose
+// result only the host reads stores it straight into the staging area; everything else crosses with one small
+// kernel of ours (k_words), which also lets the device decide how much to send (k_edge_list).  Visibility follows the
+// stream: host writes before the launch are seen by the kernel, kernel stores are seen after hipStreamSynchronize.
+__global__ __launch_bounds__(256) void k_words(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t n_words) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+// comp = [m | idx[n] | root[n]] on the device -> the same layout in the staging area, only the m entries in use.
+__global__ __launch_bounds__(256) void k_edge_list(const int32_t* __restrict__ comp, int64_t n, int32_t* __restrict__ dst) {
+    const int64_t m = comp[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+        dst[1 + i] = comp[1 + i];
+        dst[1 + n + i] = comp[1 + n + i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) dst[0] = (int32_t)m;
+}
+
+inline int move_words(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    const size_t n_words = (bytes + 3) / 4;                      // arena slots are 256-byte aligned and padded
+    if (n_words == 0) return 0;
+    const unsigned blocks = (unsigned)std::min<size_t>((n_words + 255) / 256, 64);
+    k_words<<<blocks, 256, 0, st>>>(static_cast<uint32_t*>(dst), static_cast<const uint32_t*>(src), n_words);
+    return shg::check_launch("k_words");
+}
+
+// The staging area as the GPU addresses it (the same address under unified addressing; asked for once per area).
+struct Staging {
+    char* host;
+    char* dev;
+    template <typename T>
+    T* on_device(T* host_ptr) const { return reinterpret_cast<T*>(dev + (reinterpret_cast<char*>(host_ptr) - host)); }
+};
+
+inline int map_staging(void* host_pinned, Staging* out, const char* who) {
+    thread_local void* last_host = nullptr;
+    thread_local void* last_dev = nullptr;
+    if (host_pinned != last_host) {
+        void* d = nullptr;
+        hipError_t e = hipHostGetDevicePointer(&d, host_pinned, 0);
+        if (e != hipSuccess || !d) {
+            (void)hipGetLastError();
+            shg::set_error("%s: host_pinned is not page-locked, GPU-mapped memory (hipHostMalloc / hipHostRegister): %s", who,
+                           e != hipSuccess ? hipGetErrorString(e) : "no device address");
+            return SHG_E_ARG;
+        }
+        last_host = host_pinned;
+        last_dev = d;
+    }
+    out->host = static_cast<char*>(host_pinned);
+    out->dev = static_cast<char*>(last_dev);
+    return 0;
+}
+
 inline int64_t slit_rows(int64_t height, int64_t width) { return width > height ? width : height; }
 inline int64_t spectral_cols(int64_t height, int64_t width) { return width > height ? height : width; }
 
@@ -96,6 +154,10 @@ extern "C" int shg_stage_mean_fit(const void* stack, int64_t n_frames, int64_t h
     int32_t* h_traces = pin.take<int32_t>(2 * (size_t)ih);
     SHG_REQUIRE(acc_ws && sum && mx && blur && tmp && row_means && traces, SHG_E_WORKSPACE, "shg_stage_mean_fit: workspace too small");
     SHG_REQUIRE(h_means && h_traces, SHG_E_WORKSPACE, "shg_stage_mean_fit: pinned staging area too small");
+    Staging stg;
+    STAGE_TRY(map_staging(host_pinned, &stg, "shg_stage_mean_fit"));
+    row_means = stg.on_device(h_means);                                                       // only the host reads these: the
+    traces = stg.on_device(h_traces);                                                         // kernels store them where it looks
 
     if (!sum_in) {                                                                            // solex_util.py:174-188
         STAGE_TRY(shg_accumulate_sum_max(stack, n_frames, height, width, bytes_per_px, frame_stride_px, sum, mx, acc_ws, acc_bytes, stream));
@@ -110,7 +172,6 @@ extern "C" int shg_stage_mean_fit(const void* stack, int64_t n_frames, int64_t h
         STAGE_TRY(shg_box_blur_u16(max_out, ih, iw, 5, 5, blur, tmp, stream));
         STAGE_TRY(shg_row_mean_u16(blur, ih, iw, row_means, stream));
     }
-    STAGE_HIP(hipMemcpyAsync(h_means, row_means, (size_t)ih * 8, hipMemcpyDeviceToHost, st), "shg_stage_mean_fit");
     STAGE_HIP(hipStreamSynchronize(st), "shg_stage_mean_fit");
     int64_t y1, y2;
     STAGE_TRY(shg_host_detect_bord(h_means, ih, &y1, &y2));
@@ -129,7 +190,6 @@ extern "C" int shg_stage_mean_fit(const void* stack, int64_t n_frames, int64_t h
         STAGE_TRY(shg_row_argmin_u16(blur, ih, iw, lo, hi, traces, stream));
         STAGE_TRY(shg_row_argmin_u16(mean_out, ih, iw, 0, iw, traces + ih, stream));
     }
-    STAGE_HIP(hipMemcpyAsync(h_traces, traces, 2 * (size_t)ih * 4, hipMemcpyDeviceToHost, st), "shg_stage_mean_fit");
     STAGE_HIP(hipStreamSynchronize(st), "shg_stage_mean_fit");
     if (host_trace_sharp) memcpy(host_trace_sharp, h_traces + ih, (size_t)ih * 4);
     return shg_host_line_fit(h_traces, h_traces + ih, ih, y1, y2, (int32_t)lo, host_p4, host_fit, host_mask_good);
@@ -159,8 +219,10 @@ extern "C" int shg_stage_extract(const void* stack, int64_t n_frames, int64_t he
     SHG_REQUIRE(h_ind && h_w2, SHG_E_WORKSPACE, "shg_stage_extract: pinned staging area too small");
     STAGE_TRY(shg_host_column_plan(host_fit, ih, iw, host_shifts, n_shifts, h_ind, h_w2, h_w2 + ih));
     hipStream_t st = shg::as_stream(stream);
-    STAGE_HIP(hipMemcpyAsync(ind_l, h_ind, (size_t)n_shifts * ih * 4, hipMemcpyHostToDevice, st), "shg_stage_extract");
-    STAGE_HIP(hipMemcpyAsync(w2, h_w2, 2 * (size_t)ih * 8, hipMemcpyHostToDevice, st), "shg_stage_extract");
+    Staging stg;
+    STAGE_TRY(map_staging(host_pinned, &stg, "shg_stage_extract"));
+    // the two arenas have the same layout: indices and weights cross in one piece
+    STAGE_TRY(move_words(ind_l, stg.on_device(h_ind), (size_t)(reinterpret_cast<char*>(h_w2 + 2 * ih) - reinterpret_cast<char*>(h_ind)), st));
     return shg_extract_columns_minmax(stack, n_frames, height, width, bytes_per_px, frame_stride_px, ind_l, w2, w2 + ih, n_shifts, disks,
                                       row_pitch, plane_stride, n_cols, k_offset, flip_x, minmax_slots, stream);
 }
@@ -168,7 +230,6 @@ extern "C" int shg_stage_extract(const void* stack, int64_t n_frames, int64_t he
 // ---- ellipse_to_circle: limb detection and fit --------------------------------------------------------
 namespace {
 constexpr int kFactor = 4;                 // downscale_local_mean(image, (4, 4)), ellipse_to_circle.py:299-301
-constexpr int64_t kPrefetch = 16384;       // edge pixels fetched with the count (a limb has ~1500)
 inline int64_t small_dim(int64_t v) { return (v + kFactor - 1) / kFactor; }
 }  // namespace
 
@@ -215,8 +276,8 @@ extern "C" int shg_stage_limb_points(const uint16_t* disk, int64_t h, int64_t w,
     char* sel_ws = dev.take<char>(sel_bytes);
     uint32_t* keys_k = dev.take<uint32_t>((size_t)n);
     uint32_t* keys_5 = dev.take<uint32_t>((size_t)n);
-    double* packed = dev.take<double>(32);                 // [0..3] order statistics, [4..6] flood stats
-    uint32_t* counts = dev.take<uint32_t>(20);
+    double* packed = dev.take<double>(32);                 // [0..3] order statistics, [4..6] flood stats, [8..17] the 20 counts
+    uint32_t* counts = packed ? reinterpret_cast<uint32_t*>(packed + 8) : nullptr;
     char* flood_ws = dev.take<char>(32);
     uint8_t* low_mask = dev.take<uint8_t>((size_t)n);
     uint8_t* high_mask = dev.take<uint8_t>((size_t)n);
@@ -229,6 +290,8 @@ extern "C" int shg_stage_limb_points(const uint16_t* disk, int64_t h, int64_t w,
     SHG_REQUIRE(small && blurred && blur5 && tmp && sel_ws && keys_k && keys_5 && packed && counts && flood_ws && low_mask && high_mask && canny_ws && cc_ws && comp,
                 SHG_E_WORKSPACE, "shg_stage_limb_points: workspace too small");
     SHG_REQUIRE(h_packed && h_comp, SHG_E_WORKSPACE, "shg_stage_limb_points: pinned staging area too small");
+    Staging stg;
+    STAGE_TRY(map_staging(host_pinned, &stg, "shg_stage_limb_points"));
 
     STAGE_TRY(shg_downscale_mean_u16(disk, h, w, pitch, kFactor, small, stream));
     // np.median(blur 5x5) (:241) and np.percentile(blurred, 99) (:165): their order statistics
@@ -251,8 +314,7 @@ extern "C" int shg_stage_limb_points(const uint16_t* disk, int64_t h, int64_t w,
         STAGE_TRY(shg_select_multi_f64(arrays, n, ranks, 4, packed, sel_ws, sel_bytes, stream));
     }
     STAGE_TRY(shg_flood_stats_lerp_f64(small, blurred, n, packed + 2, gamma99, packed + 4, counts, flood_ws, stream));
-    STAGE_HIP(hipMemcpyAsync(h_packed, packed, 7 * 8, hipMemcpyDeviceToHost, st), "shg_stage_limb_points");
-    STAGE_HIP(hipMemcpyAsync(h_packed + 8, counts, 20 * 4, hipMemcpyDeviceToHost, st), "shg_stage_limb_points");
+    STAGE_TRY(move_words(stg.on_device(h_packed), packed, 8 * 8 + 20 * 4, st));
     STAGE_HIP(hipStreamSynchronize(st), "shg_stage_limb_points");
     const double median5 = (n & 1) ? h_packed[0] : (h_packed[0] + h_packed[1]) / 2;
     const double low = median5 / 10, high = low * 1.5;                                       // :241-243
@@ -270,16 +332,11 @@ extern "C" int shg_stage_limb_points(const uint16_t* disk, int64_t h, int64_t w,
         const int radius = (int)(4.0 * sigma + 0.5);
         STAGE_TRY(shg_canny_masks_f64(blurred, sh, sw, thresh3, taps, radius, low, high, low_mask, high_mask, canny_ws, canny_bytes, stream));
         STAGE_TRY(shg_edge_components(low_mask, high_mask, sh, sw, comp + 1, comp + 1 + n, comp, cc_ws, cc_bytes, stream));
-        const int64_t pre = std::min(kPrefetch, n);
-        STAGE_HIP(hipMemcpyAsync(h_comp, comp, (size_t)(1 + pre) * 4, hipMemcpyDeviceToHost, st), "shg_stage_limb_points");
-        STAGE_HIP(hipMemcpyAsync(h_comp + 1 + n, comp + 1 + n, (size_t)pre * 4, hipMemcpyDeviceToHost, st), "shg_stage_limb_points");
+        k_edge_list<<<16, 256, 0, st>>>(comp, n, stg.on_device(h_comp));                      // the device knows how many: one trip
+        STAGE_TRY(shg::check_launch("k_edge_list"));
         STAGE_HIP(hipStreamSynchronize(st), "shg_stage_limb_points");
         m = h_comp[0];
-        if (m > pre) {
-            STAGE_HIP(hipMemcpyAsync(h_comp + 1 + pre, comp + 1 + pre, (size_t)(m - pre) * 4, hipMemcpyDeviceToHost, st), "shg_stage_limb_points");
-            STAGE_HIP(hipMemcpyAsync(h_comp + 1 + n + pre, comp + 1 + n + pre, (size_t)(m - pre) * 4, hipMemcpyDeviceToHost, st), "shg_stage_limb_points");
-            STAGE_HIP(hipStreamSynchronize(st), "shg_stage_limb_points");
-        }
+        SHG_REQUIRE(m >= 0 && m <= n, SHG_E_RUNTIME, "shg_stage_limb_points: %lld edge pixels in an image of %lld", (long long)m, (long long)n);
         if (m > 0) break;
         taps += 2 * radius + 1;                                                               // try again with less blur (:254-256)
     }
@@ -363,12 +420,12 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
     SHG_REQUIRE(out_pitch >= out_w, SHG_E_ARG, "shg_stage_process_frames: out_pitch < output width");
     hipStream_t st = shg::as_stream(stream);
     Arena dev(workspace, workspace_bytes), pin(host_pinned, host_pinned_bytes);
-    int32_t* xa = dev.take<int32_t>((size_t)h);
-    int32_t* xb = dev.take<int32_t>((size_t)h);
+    int32_t* xa = dev.take<int32_t>((size_t)h);                                                // xa | xb | taps: the same order in
+    int32_t* xb = dev.take<int32_t>((size_t)h);                                                // the staging area, they cross together
+    double* taps_d = dev.take<double>(4096);
     double* stats = dev.take<double>((size_t)k * h);
     double* interior = dev.take<double>((size_t)k * h);
     double* factors = dev.take<double>((size_t)k * h);
-    double* taps_d = dev.take<double>(4096);
     const size_t tpitch = ((size_t)w + 63) / 64 * 64;
     std::vector<uint16_t*> scaled((size_t)k, nullptr);
     const bool need_tmp = transversalium && crop_w > 0 && !host_detrans;
@@ -380,14 +437,17 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
     double* out5 = dev.take<double>((size_t)k * 5);
     int32_t* h_xa = pin.take<int32_t>((size_t)h);
     int32_t* h_xb = pin.take<int32_t>((size_t)h);
+    double* h_taps = pin.take<double>(4096);
     double* h_stats = pin.take<double>((size_t)k * h);
     double* h_interior = pin.take<double>((size_t)k * h);
     double* h_factors = pin.take<double>((size_t)k * h);
     double* h_out5 = pin.take<double>((size_t)k * 5);
-    double* h_taps = pin.take<double>(4096);
     SHG_REQUIRE(xa && xb && stats && interior && factors && taps_d && cs_ws && out5 && (!need_tmp || scaled[k - 1]), SHG_E_WORKSPACE,
                 "shg_stage_process_frames: workspace too small");
     SHG_REQUIRE(h_xa && h_xb && h_stats && h_interior && h_factors && h_out5 && h_taps, SHG_E_WORKSPACE, "shg_stage_process_frames: pinned staging area too small");
+    Staging stg;
+    STAGE_TRY(map_staging(host_pinned, &stg, "shg_stage_process_frames"));
+    out5 = stg.on_device(h_out5);                                                             // order statistics: only the host reads them
 
     // ---- correct_transversalium2 (solex_util.py:383-516) ----
     std::vector<const uint16_t*> cur((size_t)k);
@@ -404,28 +464,30 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
             SHG_REQUIRE(y1 >= 0 && y2 <= h, SHG_E_ARG, "shg_stage_process_frames: rows [%lld, %lld) outside the image", (long long)y1, (long long)y2);
             n = y2 - y1;
             STAGE_TRY(shg_host_chord_bounds(cx, cy, r, host_borders4[0], host_borders4[2], y1, y2, w, h_xa, h_xb));
-            STAGE_HIP(hipMemcpyAsync(xa, h_xa, (size_t)n * 4, hipMemcpyHostToDevice, st), "shg_stage_process_frames");
-            STAGE_HIP(hipMemcpyAsync(xb, h_xb, (size_t)n * 4, hipMemcpyHostToDevice, st), "shg_stage_process_frames");
-            for (int64_t i = 0; i < k; ++i)
-                STAGE_TRY(shg_rowpair_logratio_stats(host_frames[i], h, w, pitch, y1, y2, xa, xb, nullptr, stats + i * n, stream));
             const bool gpu_interior = window > 3 && window <= n && window / 2 <= 1024 && window <= 4096;
+            std::vector<double> rev;
+            if (gpu_interior) {
+                rev.resize((size_t)window);
+                for (int64_t i = 0; i < window; ++i) rev[i] = host_taps[window - 1 - i];
+                memcpy(h_taps, rev.data(), (size_t)window * 8);
+            }
+            const char* plan_end = gpu_interior ? reinterpret_cast<const char*>(h_taps + window) : reinterpret_cast<const char*>(h_xb + n);
+            STAGE_TRY(move_words(xa, stg.on_device(h_xa), (size_t)(plan_end - reinterpret_cast<const char*>(h_xa)), st));
+            for (int64_t i = 0; i < k; ++i)
+                STAGE_TRY(shg_rowpair_logratio_stats_mirrored(host_frames[i], h, w, pitch, y1, y2, xa, xb, nullptr, stats + i * n,
+                                                              stg.on_device(h_stats) + i * n, stream));
             if (gpu_interior) {
                 // the interior of the Savitzky-Golay trend while the statistics are still on the GPU (SciPy's own order of operations)
-                std::vector<double> rev((size_t)window);
-                for (int64_t i = 0; i < window; ++i) rev[i] = host_taps[window - 1 - i];
                 const int radius = (int)(window / 2);
                 int sym = 1, anti = 1;
                 for (int i = 1; i <= radius; ++i) {
                     if (fabs(rev[radius + i] - rev[radius - i]) > 2.220446049250313e-16) sym = 0;
                     if (fabs(rev[radius + i] + rev[radius - i]) > 2.220446049250313e-16) anti = 0;
                 }
-                memcpy(h_taps, rev.data(), (size_t)window * 8);
-                STAGE_HIP(hipMemcpyAsync(taps_d, h_taps, (size_t)window * 8, hipMemcpyHostToDevice, st), "shg_stage_process_frames");
-                STAGE_TRY(shg_correlate1d_rows_f64(stats, k, n, taps_d, radius, sym ? 1 : (anti ? -1 : 0), interior, stream));
-                STAGE_HIP(hipMemcpyAsync(h_interior, interior, (size_t)k * n * 8, hipMemcpyDeviceToHost, st), "shg_stage_process_frames");
+                // only the host reads the interior: the kernel stores it in the staging area
+                STAGE_TRY(shg_correlate1d_rows_f64(stats, k, n, taps_d, radius, sym ? 1 : (anti ? -1 : 0), stg.on_device(h_interior), stream));
                 use_interior = h_interior;
             }
-            STAGE_HIP(hipMemcpyAsync(h_stats, stats, (size_t)k * n * 8, hipMemcpyDeviceToHost, st), "shg_stage_process_frames");
             STAGE_HIP(hipStreamSynchronize(st), "shg_stage_process_frames");
         } else {
             for (int64_t i = 0; i < k; ++i) h_stats[i] = 0.0;                                 // y_ratios_r = [0], :386
@@ -438,7 +500,7 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
             if (have_rows) memcpy(c + y1, corr.data() + i * n, (size_t)n * 8);
         }
         if (host_factors) memcpy(host_factors, h_factors, (size_t)k * h * 8);
-        STAGE_HIP(hipMemcpyAsync(factors, h_factors, (size_t)k * h * 8, hipMemcpyHostToDevice, st), "shg_stage_process_frames");
+        STAGE_TRY(move_words(factors, stg.on_device(h_factors), (size_t)k * h * 8, st));
         for (int64_t i = 0; i < k; ++i) {
             uint16_t* dst;
             int64_t dpitch;
@@ -471,7 +533,6 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
     for (int64_t i = 0; i < k; ++i)
         STAGE_TRY(shg_contrast_stats_u16(host_final[i], h, out_w, out_pitch, clip_limit, tiles, host_cl1[i], out_pitch, ranks_frame, ranks_cl1,
                                          out5 + i * 5, cs_ws, cs_bytes, stream));
-    STAGE_HIP(hipMemcpyAsync(h_out5, out5, (size_t)k * 5 * 8, hipMemcpyDeviceToHost, st), "shg_stage_process_frames");
     STAGE_HIP(hipStreamSynchronize(st), "shg_stage_process_frames");
     for (int64_t i = 0; i < k; ++i) {
         const double* s = h_out5 + i * 5;

@@ -3,9 +3,12 @@
 // reject_outliers (solex_util.py:76-86).
 //
 // k_rowpair_stats: one workgroup per row pair.  The log-ratios of the chord are held in LDS as
-// order-preserving 64-bit keys; the median and the MAD are read by an MSB-first radix select
-// (8 bits per pass, both middle order statistics in the same passes), then the 2-MAD inliers are
-// averaged.  All float64.  (A select moves ~16x less LDS data than sorting the row.)
+// order-preserving 64-bit keys; the median and the MAD are exact order statistics read by a bucket select:
+// one histogram of the keys over [min, max] in 512 equal steps (a monotone map, so buckets are ordered like the
+// keys), the handful of keys in the bucket that holds the wanted rank gathered and ranked directly -- two sweeps over
+// the row per statistic.  Rows with infinities (zero pixels) or pathological spreads take the general MSB-first radix
+// select (8 bits per pass, both middle order statistics in the same passes; up to ten sweeps).  Then the 2-MAD
+// inliers are averaged.  All float64.  (A select moves ~16x less LDS data than sorting the row.)
 // The reference sums the inliers in image order with NumPy's pairwise scheme; here they
 // are summed by a fixed-shape tree, so the mean can differ in the last bits (as NumPy's
 // own log already does between CPUs); the correction factors agree to ~1e-15 relative.
@@ -28,13 +31,19 @@ __device__ __forceinline__ double key_f64(uint64_t k) {
     return __longlong_as_double((long long)b);
 }
 
+constexpr int NB = 512;          // buckets of the bucket select (= the radix select's two 256-bin histograms)
+constexpr int CAP = 128;         // candidates ranked directly
+
 struct Scratch {
-    uint32_t hist[2][256];
+    uint32_t hist[2][256];       // radix select: one histogram per rank; bucket select: one of NB bins
     int64_t wave_tot[2][4];
-    int64_t pick[2][3];          // [which rank][digit, count below, count in the digit's bin]
-    unsigned long long found[2]; // the key a singleton bin holds (early exit of select2)
+    int64_t pick[2][3];          // [which rank][digit / bucket, count below, count in the bin]
+    unsigned long long found[2]; // the key a singleton bin holds (early exit of select2) / the ranked candidates
+    unsigned long long cand[CAP];
+    unsigned long long kmin, kmax;
+    uint32_t n_cand;
     double red[4];
-    int bad;
+    int bad, nonfinite;
 };
 
 // one histogram increment with wave-level aggregation of the most common digit
@@ -118,6 +127,111 @@ __device__ __forceinline__ void select2(KeyFn key, int n, int64_t rank_lo, int64
     out_hi = pref[1];
 }
 
+// The same two order statistics by bucketing, for keys that are all finite and lie in [kmin, kmax] (the extrema of the
+// set, found by the caller).  x -> min(NB-1, int((x - lo) * NB / (hi - lo))) never decreases with x, so every key of a
+// bucket is <= every key of the next one and the bucket holding a rank is found by a prefix sum; its keys (a few
+// dozen of ~2000 for real rows) are ranked against each other.  A crowded bucket is bucketed again between its own
+// extrema.  Returns false (block-uniform) when it gives up: the caller then runs select2.
+template <typename KeyFn>
+__device__ __forceinline__ bool select2_buckets(KeyFn key, int n, int64_t rank_lo, int64_t rank_hi, double lo, double hi,
+                                                Scratch& sc, uint64_t& out_lo, uint64_t& out_hi) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* hist = &sc.hist[0][0];
+    uint32_t below = 0;                                 // keys smaller than kmin
+    uint64_t kmin = 0, kmax = ~0ull;                    // the keys still in play (all of them at first)
+    for (int level = 0; level < 4; ++level) {
+        if (level > 0) {
+            if (kmin == kmax) { out_lo = out_hi = kmin; return true; }
+            lo = key_f64(kmin);
+            hi = key_f64(kmax);
+        }
+        // [lo, hi] only has to spread the keys: values beyond it fall into the end buckets, which keeps the map monotone.
+        // The caller passes the bulk of the distribution (mean +- 3 sigma) rather than the extrema: with the range set by
+        // a few outliers the bulk shares a dozen buckets and the LDS atomics below serialise (measured: 69 us instead of
+        // 51 for the radix select; profiles/).
+        const double inv = (double)NB / (hi - lo);
+        if (!(inv > 0.0) || inv > 1.7e308) return false;
+        auto bucket = [&](uint64_t k) {
+            const double t = (key_f64(k) - lo) * inv;
+            return t >= (double)(NB - 1) ? NB - 1 : (t > 0.0 ? (int)t : 0);
+        };
+        hist[tid] = 0;
+        hist[tid + 256] = 0;
+        if (tid == 0) sc.n_cand = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += NT) {
+            const uint64_t k = key(i);
+            if (k >= kmin && k <= kmax) atomicAdd(&hist[bucket(k)], 1u);
+        }
+        __syncthreads();
+        // prefix sum over the buckets, two per thread
+        const uint32_t c0 = hist[2 * tid], c1 = hist[2 * tid + 1];
+        uint32_t incl = c0 + c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) sc.wave_tot[0][wave] = incl;
+        __syncthreads();
+        for (int i = 0; i < wave; ++i) incl += (uint32_t)sc.wave_tot[0][i];
+        const uint32_t excl = below + incl - c0 - c1;
+        const int64_t rk[2] = {rank_lo, rank_hi};
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (excl <= rk[r] && rk[r] < excl + c0) { sc.pick[r][0] = 2 * tid; sc.pick[r][1] = excl; sc.pick[r][2] = c0; }
+            else if (excl + c0 <= rk[r] && rk[r] < excl + c0 + c1) { sc.pick[r][0] = 2 * tid + 1; sc.pick[r][1] = excl + c0; sc.pick[r][2] = c1; }
+        }
+        __syncthreads();
+        const int b0 = (int)sc.pick[0][0], b1 = (int)sc.pick[1][0];
+        const uint32_t base = (uint32_t)sc.pick[0][1];
+        const uint32_t cnt = (uint32_t)sc.pick[0][2] + (b1 != b0 ? (uint32_t)sc.pick[1][2] : 0u);
+        __syncthreads();                                // pick[] is rewritten by the next level
+        if (cnt <= (uint32_t)CAP) {
+            // adjacent ranks: the buckets between b0 and b1 are empty, so the candidates are consecutive in rank
+            for (int i = tid; i < n; i += NT) {
+                const uint64_t k = key(i);
+                if (k >= kmin && k <= kmax) {
+                    const int b = bucket(k);
+                    if (b == b0 || b == b1) sc.cand[atomicAdd(&sc.n_cand, 1u)] = k;
+                }
+            }
+            __syncthreads();
+            const int m = (int)sc.n_cand;
+            if (tid < m) {
+                const uint64_t mine = sc.cand[tid];
+                uint32_t r = base;
+                for (int j = 0; j < m; ++j) {
+                    const uint64_t o = sc.cand[j];
+                    r += (o < mine || (o == mine && j < tid)) ? 1u : 0u;
+                }
+                if (r == (uint32_t)rank_lo) sc.found[0] = mine;
+                if (r == (uint32_t)rank_hi) sc.found[1] = mine;
+            }
+            __syncthreads();
+            out_lo = sc.found[0];
+            out_hi = sc.found[1];
+            __syncthreads();
+            return true;
+        }
+        if (b0 != b1) return false;                     // a crowded bucket next to the one with the other rank: rare enough
+        if (tid == 0) { sc.kmin = ~0ull; sc.kmax = 0ull; }
+        __syncthreads();
+        uint64_t mn = ~0ull, mx = 0ull;
+        for (int i = tid; i < n; i += NT) {
+            const uint64_t k = key(i);
+            if (k >= kmin && k <= kmax && bucket(k) == b0) { mn = k < mn ? k : mn; mx = k > mx ? k : mx; }
+        }
+        if (mn <= mx) { atomicMin(&sc.kmin, (unsigned long long)mn); atomicMax(&sc.kmax, (unsigned long long)mx); }
+        __syncthreads();
+        kmin = sc.kmin;
+        kmax = sc.kmax;
+        below = base;
+        __syncthreads();
+    }
+    return false;
+}
+
 __device__ __forceinline__ double block_sum(double v, double* red) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
@@ -129,18 +243,26 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 
 __global__ __launch_bounds__(NT) void k_rowpair_stats(const uint16_t* __restrict__ img, int64_t pitch, int64_t y1,
                                                       const int32_t* __restrict__ xa, const int32_t* __restrict__ xb,
-                                                      const double* __restrict__ row_factor, double* __restrict__ out) {
+                                                      const double* __restrict__ row_factor, double* __restrict__ out,
+                                                      double* __restrict__ mirror) {
     extern __shared__ uint64_t keys[];   // [n]
     __shared__ Scratch sc;
     const int t = blockIdx.x + 1;        // out[0] stays 0 (solex_util.py:386)
+    auto emit = [&](double v) {          // mirror: the same values where the host reads them (pinned memory), if wanted
+        if (threadIdx.x == 0) {
+            out[t] = v;
+            if (mirror) mirror[t] = v;
+            if (t == 1) { out[0] = 0.0; if (mirror) mirror[0] = 0.0; }
+        }
+    };
     const int64_t y = y1 + t;
     const int a = xa[t], b = xb[t];
     const int n = b - a;
     if (n <= 0) {                        // np.mean of an empty slice
-        if (threadIdx.x == 0) out[t] = __builtin_nan("");
+        emit(__builtin_nan(""));
         return;
     }
-    if (threadIdx.x == 0) sc.bad = 0;
+    if (threadIdx.x == 0) { sc.bad = 0; sc.nonfinite = 0; }
     __syncthreads();
     const uint16_t* r1 = img + y * pitch + a;
     const uint16_t* r0 = img + (y - 1) * pitch + a;
@@ -148,32 +270,51 @@ __global__ __launch_bounds__(NT) void k_rowpair_stats(const uint16_t* __restrict
     // lets any NaN poison the row statistic (np.median -> nan -> empty inlier set -> nan); same here.
     // a de-vignetted frame is the float64 image img * row_factor[y] (removeVignette, solex_util.py:654)
     const double f1 = row_factor ? row_factor[y] : 1.0, f0 = row_factor ? row_factor[y - 1] : 1.0;
-    for (int i = threadIdx.x; i < n; i += NT) {
-        const double x = log(((double)r1[i] * f1) / ((double)r0[i] * f0));        // np.log(strip1 / strip0)
-        if (x != x) sc.bad = 1;
-        keys[i] = f64_key(x);
+    double sum1 = 0.0, sum2 = 0.0;       // only steer the bucket select (where the bulk of the row lies): any rounding will do
+    {
+        bool odd = false;
+        for (int i = threadIdx.x; i < n; i += NT) {
+            const double x = log(((double)r1[i] * f1) / ((double)r0[i] * f0));        // np.log(strip1 / strip0)
+            if (x != x) sc.bad = 1;
+            odd = odd || !(fabs(x) <= 1.7976931348623157e308);
+            keys[i] = f64_key(x);
+            sum1 += x;
+            sum2 += x * x;
+        }
+        if (odd) sc.nonfinite = 1;
     }
+    sum1 = block_sum(sum1, sc.red);
+    sum2 = block_sum(sum2, sc.red);
     __syncthreads();
     if (sc.bad) {
-        if (threadIdx.x == 0) out[t] = __builtin_nan("");
+        emit(__builtin_nan(""));
         return;
     }
+    const bool finite = !sc.nonfinite;
+    const double mean = sum1 / (double)n;
+    const double var = sum2 / (double)n - mean * mean;
+    const double sigma = var > 0.0 ? sqrt(var) : 0.0;
     // np.median: the middle order statistic, or the mean of the two middle ones
     const int64_t lo = (n & 1) ? (n >> 1) : (n >> 1) - 1, hi = n >> 1;
     uint64_t ka, kb;
-    select2([&](int i) { return keys[i]; }, n, lo, hi, sc, ka, kb);
+    auto row_key = [&](int i) { return keys[i]; };
+    if (!(finite && select2_buckets(row_key, n, lo, hi, mean - 3.0 * sigma, mean + 3.0 * sigma, sc, ka, kb)))
+        select2(row_key, n, lo, hi, sc, ka, kb);
     const double med = (n & 1) ? key_f64(ka) : (key_f64(ka) + key_f64(kb)) / 2.0;
-    for (int i = threadIdx.x; i < n; i += NT) {
-        const double dv = fabs(key_f64(keys[i]) - med);             // inf - inf or a NaN median -> NaN
-        if (dv != dv) sc.bad = 1;
-    }
-    __syncthreads();
-    if (sc.bad) {
-        if (threadIdx.x == 0) out[t] = __builtin_nan("");
-        return;
+    if (!finite) {                       // (finite values and a finite median cannot make a NaN)
+        for (int i = threadIdx.x; i < n; i += NT) {
+            const double dv = fabs(key_f64(keys[i]) - med);             // inf - inf or a NaN median -> NaN
+            if (dv != dv) sc.bad = 1;
+        }
+        __syncthreads();
+        if (sc.bad) {
+            emit(__builtin_nan(""));
+            return;
+        }
     }
     // |x - med| >= 0: its bit pattern is already order preserving
-    select2([&](int i) { return f64_key(fabs(key_f64(keys[i]) - med)); }, n, lo, hi, sc, ka, kb);
+    auto dev_key = [&](int i) { return f64_key(fabs(key_f64(keys[i]) - med)); };
+    if (!(finite && select2_buckets(dev_key, n, lo, hi, 0.0, 2.0 * sigma, sc, ka, kb))) select2(dev_key, n, lo, hi, sc, ka, kb);
     const double mdev = (n & 1) ? key_f64(ka) : (key_f64(ka) + key_f64(kb)) / 2.0;
     double s = 0.0, cnt = 0.0;
     for (int i = threadIdx.x; i < n; i += NT) {
@@ -184,7 +325,7 @@ __global__ __launch_bounds__(NT) void k_rowpair_stats(const uint16_t* __restrict
     }
     s = block_sum(s, sc.red);
     cnt = block_sum(cnt, sc.red);
-    if (threadIdx.x == 0) out[t] = s / cnt;
+    emit(s / cnt);
 }
 
 __global__ __launch_bounds__(256) void k_scale_rows(const uint16_t* __restrict__ img, int64_t w, int64_t pitch,
@@ -312,25 +453,35 @@ extern "C" int shg_line_order_stats_u16(const uint16_t* img, int64_t h, int64_t 
 extern "C" int shg_rowpair_logratio_stats(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, int64_t y1, int64_t y2,
                                           const int32_t* xa, const int32_t* xb, const double* row_factor, double* out,
                                           shg_stream_t stream) {
+    return shg_rowpair_logratio_stats_mirrored(img, h, w, pitch, y1, y2, xa, xb, row_factor, out, nullptr, stream);
+}
+
+extern "C" int shg_rowpair_logratio_stats_mirrored(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, int64_t y1, int64_t y2,
+                                                   const int32_t* xa, const int32_t* xb, const double* row_factor, double* out,
+                                                   double* out_mirror, shg_stream_t stream) {
     SHG_REQUIRE(img && xa && xb && out, SHG_E_ARG, "shg_rowpair_logratio_stats: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w, SHG_E_ARG, "shg_rowpair_logratio_stats: bad image size");
     SHG_REQUIRE(y1 >= 0 && y2 <= h && y2 > y1, SHG_E_ARG, "shg_rowpair_logratio_stats: rows [%lld, %lld) outside the image",
                 (long long)y1, (long long)y2);
     SHG_REQUIRE(w <= MAXN, SHG_E_UNSUPPORTED, "shg_rowpair_logratio_stats: width %lld > %d", (long long)w, MAXN);
     hipStream_t st = shg::as_stream(stream);
-    if (hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st)) {
-        shg::set_error("shg_rowpair_logratio_stats: memset: %s", hipGetErrorString(e));
-        return (int)e;
-    }
     const int64_t rows = y2 - y1 - 1;
-    if (rows <= 0) return 0;
+    if (rows <= 0) {                                     // a single row: its statistic is the leading 0 (the kernel writes it otherwise)
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
+        if (e == hipSuccess && out_mirror) e = hipMemsetAsync(out_mirror, 0, sizeof(double), st);
+        if (e != hipSuccess) {
+            shg::set_error("shg_rowpair_logratio_stats: memset: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        return 0;
+    }
     const size_t lds_bytes = (size_t)w * sizeof(uint64_t);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowpair_stats), hipFuncAttributeMaxDynamicSharedMemorySize, MAXN * 8);
         attr_set = true;
     }
-    { SHG_PROF("rowpair_stats", st); k_rowpair_stats<<<(unsigned)rows, NT, lds_bytes, st>>>(img, pitch, y1, xa, xb, row_factor, out); }
+    { SHG_PROF("rowpair_stats", st); k_rowpair_stats<<<(unsigned)rows, NT, lds_bytes, st>>>(img, pitch, y1, xa, xb, row_factor, out, out_mirror); }
     return shg::check_launch("k_rowpair_stats");
 }
 

@@ -109,4 +109,18 @@ def test_a_decoder_thread_that_cannot_start_fails_its_files_instead_of_hanging(m
         with pytest.raises(RuntimeError, match='no such device'):
             d.get(i)
     d.cancel()
-    assert not d.thread.is_alive()
+    assert d.finished.is_set()
+
+
+def test_service_threads_survive_a_failing_job_and_are_reused():
+    from solex_ser_recon_en_amd import Solex_recon as sr
+    a = sr._Service.named('shg-test-service')
+    seen = []
+    done = threading.Event()
+
+    def bad():
+        raise RuntimeError('job failed')
+    a.jobs.put(bad)
+    a.jobs.put(lambda: (seen.append(threading.current_thread().name), done.set()))
+    assert done.wait(10) and seen == ['shg-test-service']
+    assert sr._Service.named('shg-test-service') is a and a.thread.daemon
