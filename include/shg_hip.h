@@ -245,6 +245,9 @@ int shg_crop_pad_u16(const uint16_t* src, int64_t h, int64_t w, int64_t pitch,
  * or uint8 (hist_size 256) images.  workspace: tiles*tiles*hist_size uint32 histograms
  * followed by tiles*tiles*hist_size LUT entries (uint16); query the size first. */
 size_t shg_clahe_workspace_bytes(int tiles, int bytes_per_px);
+/* The size that lets a 16-bit call build its tile histograms without global atomics (slice histograms stored whole
+ * and reduced once, the LUT by 32 workgroups per tile): shg_clahe takes that path whenever workspace_bytes allows. */
+size_t shg_clahe_workspace_bytes_for(int64_t h, int64_t w, int tiles, int bytes_per_px);
 int shg_clahe(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_per_px,
               double clip_limit, int tiles, void* dst, int64_t dst_pitch,
               void* workspace, size_t workspace_bytes, shg_stream_t stream);
@@ -350,6 +353,7 @@ int shg_edge_components(const uint8_t* low_mask, const uint8_t* high_mask, int64
  * rescale(frame, lo_hi6[2], lo_hi6[3]), cc = rescale(cl1, lo_hi6[4], lo_hi6[5]) (host doubles), then the filled disc
  * of value 80 on protus when disc_r > 0 (:542-547).  Same kernels and order as the separate entry points. */
 size_t shg_contrast_stats_workspace_bytes(int tiles);
+size_t shg_contrast_stats_workspace_bytes_for(int64_t h, int64_t w, int tiles);   /* with shg_clahe_workspace_bytes_for's room */
 int shg_contrast_stats_u16(const uint16_t* frame, int64_t h, int64_t w, int64_t pitch, double clip_limit,
                            int tiles, uint16_t* cl1, int64_t cl1_pitch, const int64_t* ranks_frame2,
                            const int64_t* ranks_cl13, double* out5, void* workspace, size_t workspace_bytes,

@@ -64,6 +64,7 @@ SIGNATURES = {
     'shg_crop_pad_u16': (c_int, [P, c_int64, c_int64, c_int64, P, c_int64, c_int64, c_int64, c_int64, c_int64,
                                  c_int, P]),
     'shg_clahe_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'shg_clahe_workspace_bytes_for': (c_size_t, [c_int64, c_int64, c_int, c_int]),
     'shg_clahe': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_double, c_int, P, c_int64, P, c_size_t, P]),
     'shg_hist': (c_int, [P, c_int64, c_int64, c_int64, c_int, P, P]),
     'shg_select_u16_workspace_bytes': (c_size_t, [c_int]),
@@ -71,6 +72,7 @@ SIGNATURES = {
     'shg_rescale_u16': (c_int, [P, c_int64, c_int64, c_int64, c_double, c_double, c_double, P, c_int64, P]),
     'shg_rescale_u8': (c_int, [P, c_int64, c_int64, c_int64, c_double, c_double, c_double, P, c_int64, P]),
     'shg_contrast_stats_workspace_bytes': (c_size_t, [c_int]),
+    'shg_contrast_stats_workspace_bytes_for': (c_size_t, [c_int64, c_int64, c_int]),
     'shg_contrast_stats_u16': (c_int, [P, c_int64, c_int64, c_int64, c_double, c_int, P, c_int64, P, P, P, P, c_size_t, P]),
     'shg_contrast_products_u16': (c_int, [P, c_int64, P, c_int64, c_int64, c_int64, P, P, P, P, c_int64, c_int64, c_int64, c_int64, P]),
     'shg_fill_disc_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_uint16, P, P]),

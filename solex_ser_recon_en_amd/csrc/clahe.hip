@@ -36,10 +36,33 @@ __global__ __launch_bounds__(1024) void k_tile_hist16(const uint16_t* __restrict
     const int64_t p1 = p0 + SLICE_PX < area ? p0 + SLICE_PX : area;
     for (int i = threadIdx.x; i < HIST16 / 2; i += 1024) lh[i] = 0;
     __syncthreads();
-    for (int64_t p = p0 + threadIdx.x; p < p1; p += 1024) {
-        const int64_t yy = p / tw, xx = p - yy * tw;
-        const uint32_t v = ext_pixel(img, h, w, pitch, ty * th + yy, tx * tw + xx);
-        atomicAdd(&lh[v >> 1], (v & 1) ? 0x10000u : 1u);
+    {
+        // the slice [p0, p1) of the tile's raster order, walked row by row: one wave per row, lanes along it.  (A division
+        // per pixel to turn p into (yy, xx) made this kernel ALU bound: 26 us, see profiles/.)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int twi = (int)tw;
+        const int ya = (int)(p0 / tw), yb = (int)((p1 - 1) / tw);
+        const int xs_first = (int)(p0 - (int64_t)ya * tw), xe_last = (int)(p1 - (int64_t)yb * tw);
+        for (int yy = ya + wave; yy <= yb; yy += 16) {
+            const int xs = yy == ya ? xs_first : 0, xe = yy == yb ? xe_last : twi;
+            int64_t y = ty * th + yy;
+            if (y >= h) y = shg::reflect101(y, h);
+            const uint16_t* row = img + y * pitch;
+            const int64_t xbase = tx * tw;
+            for (int x0 = xs; x0 < xe; x0 += 64) {
+                const int xx = x0 + lane;
+                const bool in = xx < xe;
+                int64_t x = xbase + (in ? xx : xs);
+                if (x >= w) x = shg::reflect101(x, w);
+                const uint32_t v = row[x];
+                // the sky around the disc puts whole waves into one bin: its lanes are counted by one atomic
+                const unsigned long long act = __ballot(in);
+                const uint32_t v0 = __shfl(v, __ffsll((long long)act) - 1);
+                const unsigned long long same = __ballot(in && v == v0);
+                if (lane == __ffsll((long long)same) - 1) atomicAdd(&lh[v0 >> 1], (uint32_t)__popcll(same) << (16 * (v0 & 1)));
+                if (in && v != v0) atomicAdd(&lh[v >> 1], (v & 1) ? 0x10000u : 1u);
+            }
+        }
     }
     __syncthreads();
     uint32_t* gh = hist + (int64_t)tile * HIST16;
@@ -48,6 +71,154 @@ __global__ __launch_bounds__(1024) void k_tile_hist16(const uint16_t* __restrict
         if (c & 0xffffu) atomicAdd(&gh[2 * i], c & 0xffffu);
         if (c >> 16) atomicAdd(&gh[2 * i + 1], c >> 16);
     }
+}
+
+// ---- the same histograms without global atomics ----------------------------------------------------------------------
+// k_tile_hist16 flushes each slice's non-zero bins with device-scope atomics: ~20 000 per workgroup, 2.5 M per image,
+// as many as there are pixels (26 us).  With room for them (shg_clahe_workspace_bytes_for) the slices' private u16
+// histograms are stored as they are, coalesced (k_tile_hist16_slices), and one pass adds them up -- and, since it
+// reads every bin anyway, also leaves what the next steps need: the 64-bin chunk sums the percentiles start from
+// (k_hist_ranks) and, per 2048 bins, the clipped total and the clipped-off excess, so that the LUT no longer has to be
+// built by one workgroup per tile (k_tile_lut16_blocks: 32 workgroups per tile instead of one).
+__global__ __launch_bounds__(1024) void k_tile_hist16_slices(const uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch,
+                                                             int tiles, int64_t th, int64_t tw, uint32_t* __restrict__ part) {
+    extern __shared__ uint32_t lh[];   // HIST16/2 dwords, two u16 counters each
+    const int tile = blockIdx.y;
+    const int64_t ty = tile / tiles, tx = tile % tiles;
+    const int64_t area = th * tw;
+    const int64_t p0 = (int64_t)blockIdx.x * SLICE_PX;
+    const int64_t p1 = p0 + SLICE_PX < area ? p0 + SLICE_PX : area;
+    for (int i = threadIdx.x; i < HIST16 / 8; i += 1024) reinterpret_cast<uint4*>(lh)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int twi = (int)tw;
+        const int ya = (int)(p0 / tw), yb = (int)((p1 - 1) / tw);
+        const int xs_first = (int)(p0 - (int64_t)ya * tw), xe_last = (int)(p1 - (int64_t)yb * tw);
+        for (int yy = ya + wave; yy <= yb; yy += 16) {
+            const int xs = yy == ya ? xs_first : 0, xe = yy == yb ? xe_last : twi;
+            int64_t y = ty * th + yy;
+            if (y >= h) y = shg::reflect101(y, h);
+            const uint16_t* row = img + y * pitch;
+            const int64_t xbase = tx * tw;
+            // eight loads in flight per lane before the first count: one load per trip left this kernel waiting on memory
+            // latency 33 times over (20 us)
+            for (int x0 = xs + lane; x0 < xe; x0 += 64 * 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int xx = x0 + 64 * u;
+                    int64_t x = xbase + (xx < xe ? xx : xs);
+                    if (x >= w) x = shg::reflect101(x, w);
+                    v[u] = row[x];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (x0 + 64 * u < xe) atomicAdd(&lh[v[u] >> 1], (v[u] & 1) ? 0x10000u : 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* out = part + ((int64_t)tile * gridDim.x + blockIdx.x) * (HIST16 / 2);
+    for (int i = threadIdx.x; i < HIST16 / 8; i += 1024) reinterpret_cast<uint4*>(out)[i] = reinterpret_cast<const uint4*>(lh)[i];
+}
+
+// grid (32, ntiles) x 1024 threads: lane d of the tile owns the counter pair d = bins 2d, 2d + 1.
+// hist [tile][65536] u32; chunk_tile [tile][1024] (64-bin sums); se [tile][32][2] = clipped total, excess per 2048 bins.
+__global__ __launch_bounds__(1024) void k_hist_reduce(const uint32_t* __restrict__ part, int slices, int clip,
+                                                      uint32_t* __restrict__ hist, uint32_t* __restrict__ chunk_tile,
+                                                      int32_t* __restrict__ se) {
+    __shared__ int wsum[2][16];
+    const int tile = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = blockIdx.x * 1024 + tid;
+    const uint32_t* p = part + (int64_t)tile * slices * (HIST16 / 2) + d;
+    uint32_t c0 = 0, c1 = 0;
+    int s = 0;
+    for (; s + 8 <= slices; s += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(s + u) * (HIST16 / 2)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { c0 += v[u] & 0xffffu; c1 += v[u] >> 16; }
+    }
+    for (; s < slices; ++s) {
+        const uint32_t v = p[(int64_t)s * (HIST16 / 2)];
+        c0 += v & 0xffffu;
+        c1 += v >> 16;
+    }
+    *reinterpret_cast<uint2*>(hist + (int64_t)tile * HIST16 + 2 * d) = make_uint2(c0, c1);
+    uint32_t t = c0 + c1;
+#pragma unroll
+    for (int k = 16; k >= 1; k >>= 1) t += __shfl_xor(t, k);
+    if ((lane & 31) == 0) chunk_tile[tile * 1024 + (d >> 5)] = t;
+    int kept = (int)min(c0, (uint32_t)clip) + (int)min(c1, (uint32_t)clip);
+    int over = (int)(c0 + c1) - kept;
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) { kept += __shfl_xor(kept, k); over += __shfl_xor(over, k); }
+    if (lane == 0) { wsum[0][wave] = kept; wsum[1][wave] = over; }
+    __syncthreads();
+    if (tid < 2) {
+        int a = 0;
+        for (int i = 0; i < 16; ++i) a += wsum[tid][i];
+        se[(tile * 32 + blockIdx.x) * 2 + tid] = a;
+    }
+}
+
+// The tile LUT (clip, redistribute, prefix sum, scale: as k_tile_lut16_lds) by 32 workgroups per tile, 2048 bins each:
+// the counts before a workgroup's first bin are the clipped totals of the workgroups before it, plus what the
+// redistribution adds there -- `batch` per bin and one more for the bins 0, step, 2 step, ... below residual * step.
+__global__ __launch_bounds__(1024) void k_tile_lut16_blocks(const uint32_t* __restrict__ hist, const int32_t* __restrict__ se, int clip,
+                                                            float lut_scale, uint16_t* __restrict__ lut) {
+    constexpr int HIST = 65536;
+    __shared__ int s_before, s_excess;
+    __shared__ int wsum[16];
+    const int tile = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wave == 0) {
+        int kept = 0, over = 0;
+        if (lane < 32) {
+            kept = lane < b ? se[(tile * 32 + lane) * 2] : 0;
+            over = se[(tile * 32 + lane) * 2 + 1];
+        }
+#pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) { kept += __shfl_xor(kept, k); over += __shfl_xor(over, k); }
+        if (lane == 0) { s_before = kept; s_excess = over; }
+    }
+    __syncthreads();
+    const int excess = s_excess;
+    const int batch = excess / HIST;
+    const int residual = excess - batch * HIST;
+    const int step = residual != 0 ? max(HIST / residual, 1) : 1;
+    const int64_t limit = (int64_t)residual * step;
+    const int first = b * 2048, i0 = first + 2 * tid;
+    const uint2 hh = *reinterpret_cast<const uint2*>(hist + (int64_t)tile * HIST + i0);
+    int c0 = (int)min(hh.x, (uint32_t)clip) + batch, c1 = (int)min(hh.y, (uint32_t)clip) + batch;
+    if (residual != 0) {
+        if ((int64_t)i0 < limit && i0 % step == 0) c0 += 1;
+        if ((int64_t)(i0 + 1) < limit && (i0 + 1) % step == 0) c1 += 1;
+    }
+    const int local = c0 + c1;
+    int incl = local;
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) {
+        const int o = __shfl_up(incl, k);
+        if (lane >= k) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < wave; ++i) base += wsum[i];
+    const int64_t reach = (int64_t)first < limit ? (int64_t)first : limit;
+    const int bumped = residual != 0 ? (int)((reach + step - 1) / step) : 0;      // bins 0, step, ... before `first`
+    const int run0 = s_before + batch * first + bumped + base + incl - local + c0;
+    const int run1 = run0 + c1;
+    int r0 = __float2int_rn(__int2float_rn(run0) * lut_scale);                    // saturate_cast<T>(sum * lutScale)
+    int r1 = __float2int_rn(__int2float_rn(run1) * lut_scale);
+    r0 = r0 < 0 ? 0 : (r0 > HIST - 1 ? HIST - 1 : r0);
+    r1 = r1 < 0 ? 0 : (r1 > HIST - 1 ? HIST - 1 : r1);
+    // stored value-major, [value][tile]: the (up to) four tile LUT entries a pixel blends sit side by side (k_clahe_interp_vm)
+    const int ntiles = gridDim.y;
+    lut[(int64_t)i0 * ntiles + tile] = (uint16_t)r0;
+    lut[(int64_t)(i0 + 1) * ntiles + tile] = (uint16_t)r1;
 }
 
 // 8-bit images: 256 bins, LDS-private u32 histogram
@@ -268,6 +439,74 @@ __global__ __launch_bounds__(256) void k_clahe_interp(const T* __restrict__ img,
     dst[y * dst_pitch + x] = (T)r;
 }
 
+// The same blend from a value-major LUT, lut[value][tile] (k_tile_lut16_blocks).  k_clahe_interp is bound by the rate
+// of its LUT reads: four 2-byte gathers per pixel, each lane of each one in a cache line of its own (neighbouring
+// pixels differ by more than the 32 values a line holds), 16.8 M line requests per image, 18 us.  Value-major, a
+// pixel's four entries share a line; with the reference's 2 x 2 grid they are one aligned 8-byte word.
+// PX pixels per lane (4: rows 8-byte aligned, one 8-byte load and store).
+template <int PX>
+__global__ __launch_bounds__(256) void k_clahe_interp_vm(const uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch,
+                                                         int tiles, float inv_tw, float inv_th,
+                                                         const uint16_t* __restrict__ lut, uint16_t* __restrict__ dst, int64_t dst_pitch) {
+    constexpr int HIST = 65536;
+    const int64_t x0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * PX;
+    const int64_t y = blockIdx.y;
+    if (x0 >= w) return;
+    const int ntiles = tiles * tiles;
+    const float tyf = (float)(int)y * inv_th - 0.5f;
+    int ty1 = (int)floorf(tyf);
+    int ty2 = ty1 + 1;
+    const float ya = tyf - (float)ty1;
+    const float ya1 = 1.0f - ya;
+    ty1 = max(ty1, 0);
+    ty2 = min(ty2, tiles - 1);
+    const int n = (int)min((int64_t)PX, w - x0);
+    uint32_t px[PX];
+    if (PX == 4 && n == 4) {
+        const uint2 q = *reinterpret_cast<const uint2*>(img + y * pitch + x0);
+        px[0] = q.x & 0xffffu; px[1 % PX] = q.x >> 16; px[2 % PX] = q.y & 0xffffu; px[3 % PX] = q.y >> 16;
+    } else {
+#pragma unroll
+        for (int j = 0; j < PX; ++j) px[j] = j < n ? img[y * pitch + x0 + j] : 0;
+    }
+    uint32_t out[PX];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        const float txf = (float)(int)(x0 + j) * inv_tw - 0.5f;
+        int tx1 = (int)floorf(txf);
+        int tx2 = tx1 + 1;
+        const float xa = txf - (float)tx1;
+        const float xa1 = 1.0f - xa;
+        tx1 = max(tx1, 0);
+        tx2 = min(tx2, tiles - 1);
+        const uint16_t* e = lut + (int64_t)px[j] * ntiles;
+        uint32_t l11, l12, l21, l22;
+        if (tiles == 2) {
+            const uint2 q = *reinterpret_cast<const uint2*>(e);
+            const uint64_t four = (uint64_t)q.x | ((uint64_t)q.y << 32);
+            l11 = (uint32_t)(four >> (16 * (ty1 * 2 + tx1))) & 0xffffu;
+            l12 = (uint32_t)(four >> (16 * (ty1 * 2 + tx2))) & 0xffffu;
+            l21 = (uint32_t)(four >> (16 * (ty2 * 2 + tx1))) & 0xffffu;
+            l22 = (uint32_t)(four >> (16 * (ty2 * 2 + tx2))) & 0xffffu;
+        } else {
+            l11 = e[ty1 * tiles + tx1];
+            l12 = e[ty1 * tiles + tx2];
+            l21 = e[ty2 * tiles + tx1];
+            l22 = e[ty2 * tiles + tx2];
+        }
+        const float res = ((float)(int)l11 * xa1 + (float)(int)l12 * xa) * ya1 + ((float)(int)l21 * xa1 + (float)(int)l22 * xa) * ya;
+        const int r = __float2int_rn(res);
+        out[j] = (uint32_t)(r < 0 ? 0 : (r > HIST - 1 ? HIST - 1 : r));
+    }
+    if (PX == 4 && n == 4) {
+        *reinterpret_cast<uint2*>(dst + y * dst_pitch + x0) = make_uint2(out[0] | (out[1 % PX] << 16), out[2 % PX] | (out[3 % PX] << 16));
+    } else {
+#pragma unroll
+        for (int j = 0; j < PX; ++j)
+            if (j < n) dst[y * dst_pitch + x0 + j] = (uint16_t)out[j];
+    }
+}
+
 // whole-image histogram (65536 or 256 bins) with the same LDS privatisation
 __global__ __launch_bounds__(1024) void k_image_hist16(const uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch,
                                                        uint32_t* __restrict__ hist) {
@@ -447,13 +686,13 @@ __global__ __launch_bounds__(1024) void k_chunk_sums(const uint32_t* __restrict_
 // image: no reflected padding in the histograms).  One workgroup per rank: lane t takes the t-th run of 64 bins from the
 // chunk sums of k_chunk_sums, a workgroup scan finds the run that holds the rank, one wave scans its 64 bins.
 __global__ __launch_bounds__(1024) void k_hist_ranks(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ chunk_sums,
-                                                     int ntiles, Ranks8 ranks, double* __restrict__ out) {
+                                                     int chunk_sets, int ntiles, Ranks8 ranks, double* __restrict__ out) {
     __shared__ int64_t wtot[16];
     __shared__ int64_t pick[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t rank = ranks.v[blockIdx.x];
     int64_t local = 0;
-    local = chunk_sums[tid];
+    for (int k = 0; k < chunk_sets; ++k) local += chunk_sums[k * 1024 + tid];     // one set (k_chunk_sums) or one per tile (k_hist_reduce)
     int64_t incl = local;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -482,6 +721,7 @@ void ensure_lds_attr() {
     static bool done = false;
     if (!done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16_slices), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_image_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_lut16_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (HIST16 + HIST16 / 64) * 2);
@@ -497,8 +737,61 @@ extern "C" size_t shg_clahe_workspace_bytes(int tiles, int bytes_per_px) {
     return (size_t)tiles * tiles * hist * (sizeof(uint32_t) + sizeof(uint16_t));
 }
 
-extern "C" int shg_clahe(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_per_px, double clip_limit, int tiles,
-                         void* dst, int64_t dst_pitch, void* workspace, size_t workspace_bytes, shg_stream_t stream) {
+namespace {
+inline void launch_interp16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, int tiles, float inv_tw, float inv_th,
+                            const uint16_t* lut, bool value_major, uint16_t* dst, int64_t dst_pitch, hipStream_t st) {
+    if (!value_major) {
+        k_clahe_interp<uint16_t, HIST16><<<dim3((unsigned)((w + 255) / 256), (unsigned)h), 256, 0, st>>>(img, h, w, pitch, tiles, inv_tw, inv_th, lut, dst, dst_pitch);
+        return;
+    }
+    const bool vec = ((reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(dst)) & 7) == 0 && pitch % 4 == 0 && dst_pitch % 4 == 0;
+    if (vec) {
+        k_clahe_interp_vm<4><<<dim3((unsigned)((w + 1023) / 1024), (unsigned)h), 256, 0, st>>>(img, h, w, pitch, tiles, inv_tw, inv_th, lut, dst, dst_pitch);
+    } else {
+        k_clahe_interp_vm<1><<<dim3((unsigned)((w + 255) / 256), (unsigned)h), 256, 0, st>>>(img, h, w, pitch, tiles, inv_tw, inv_th, lut, dst, dst_pitch);
+    }
+}
+
+// tile geometry as OpenCV pads it (copyMakeBorder(0, t - h%t, 0, t - w%t, REFLECT_101), clahe.cpp)
+inline void tile_geometry(int64_t h, int64_t w, int tiles, int64_t* th, int64_t* tw) {
+    int64_t he = h, we = w;
+    if (!(w % tiles == 0 && h % tiles == 0)) {
+        he = h + (tiles - h % tiles);
+        we = w + (tiles - w % tiles);
+    }
+    *th = he / tiles;
+    *tw = we / tiles;
+}
+
+// extra workspace of the atomics-free 16-bit path, after the [hist | lut] block: slice histograms, chunk sums, se
+struct FastLayout { size_t part, chunk, se, total; int64_t slices; };
+inline FastLayout fast_layout(int64_t h, int64_t w, int tiles) {
+    int64_t th, tw;
+    tile_geometry(h, w, tiles, &th, &tw);
+    FastLayout f;
+    const size_t ntiles = (size_t)tiles * tiles;
+    f.slices = (th * tw + SLICE_PX - 1) / SLICE_PX;
+    f.part = 0;
+    f.chunk = ntiles * (size_t)f.slices * (HIST16 / 2) * sizeof(uint32_t);
+    f.se = f.chunk + ntiles * 1024 * sizeof(uint32_t);
+    f.total = f.se + ntiles * 32 * 2 * sizeof(int32_t);
+    return f;
+}
+}  // namespace
+
+extern "C" size_t shg_clahe_workspace_bytes_for(int64_t h, int64_t w, int tiles, int bytes_per_px) {
+    const size_t base = shg_clahe_workspace_bytes(tiles, bytes_per_px);
+    if (base == 0 || h <= 0 || w <= 0) return 0;
+    if (bytes_per_px != 2) return base;
+    return (base + 255) / 256 * 256 + fast_layout(h, w, tiles).total;
+}
+
+namespace {
+// chunk_tile_out (may be NULL): where the per-tile 64-bin chunk sums were left, or NULL when the call took the
+// histogram-with-atomics path (small workspace, 8-bit image, clip out of the u16 range).
+int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_per_px, double clip_limit, int tiles,
+               void* dst, int64_t dst_pitch, void* workspace, size_t workspace_bytes, shg_stream_t stream, const uint32_t** chunk_tile_out) {
+    if (chunk_tile_out) *chunk_tile_out = nullptr;
     SHG_REQUIRE(img && dst && workspace, SHG_E_ARG, "shg_clahe: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w && dst_pitch >= w, SHG_E_ARG, "shg_clahe: bad image size");
     SHG_REQUIRE(bytes_per_px == 1 || bytes_per_px == 2, SHG_E_ARG, "shg_clahe: bytes_per_px must be 1 or 2");
@@ -510,12 +803,8 @@ extern "C" int shg_clahe(const void* img, int64_t h, int64_t w, int64_t pitch, i
     hipStream_t st = shg::as_stream(stream);
     const int hist_size = bytes_per_px == 1 ? 256 : HIST16;
     const int ntiles = tiles * tiles;
-    int64_t he = h, we = w;
-    if (!(w % tiles == 0 && h % tiles == 0)) {   // copyMakeBorder(0, t - h%t, 0, t - w%t, REFLECT_101), clahe.cpp
-        he = h + (tiles - h % tiles);
-        we = w + (tiles - w % tiles);
-    }
-    const int64_t th = he / tiles, tw = we / tiles;
+    int64_t th, tw;
+    tile_geometry(h, w, tiles, &th, &tw);
     const int64_t area = th * tw;
     SHG_REQUIRE(area < (1ll << 31), SHG_E_UNSUPPORTED, "shg_clahe: tile too large");
     const float lut_scale = (float)(hist_size - 1) / (float)area;
@@ -526,12 +815,31 @@ extern "C" int shg_clahe(const void* img, int64_t h, int64_t w, int64_t pitch, i
     }
     uint32_t* hist = static_cast<uint32_t*>(workspace);
     uint16_t* lut = reinterpret_cast<uint16_t*>(hist + (size_t)ntiles * hist_size);
+    const float inv_tw = 1.0f / (float)tw, inv_th = 1.0f / (float)th;
+    dim3 igrid((unsigned)((w + 255) / 256), (unsigned)h);
+    if (bytes_per_px == 2 && clip > 0 && clip <= 65535 && workspace_bytes >= shg_clahe_workspace_bytes_for(h, w, tiles, 2)) {
+        // no atomics, no memset: slice histograms stored whole, one reduction, the LUT by 32 workgroups per tile
+        ensure_lds_attr();
+        const FastLayout f = fast_layout(h, w, tiles);
+        char* extra = static_cast<char*>(workspace) + (shg_clahe_workspace_bytes(tiles, 2) + 255) / 256 * 256;
+        uint32_t* part = reinterpret_cast<uint32_t*>(extra + f.part);
+        uint32_t* chunk_tile = reinterpret_cast<uint32_t*>(extra + f.chunk);
+        int32_t* se = reinterpret_cast<int32_t*>(extra + f.se);
+        { SHG_PROF("clahe_hist", st);
+          k_tile_hist16_slices<<<dim3((unsigned)f.slices, (unsigned)ntiles), 1024, HIST16 * 2, st>>>(static_cast<const uint16_t*>(img), h, w, pitch, tiles, th, tw, part);
+          if (int e = shg::check_launch("k_tile_hist16_slices")) return e;
+          k_hist_reduce<<<dim3(32, (unsigned)ntiles), 1024, 0, st>>>(part, (int)f.slices, clip, hist, chunk_tile, se); }
+        if (int e = shg::check_launch("k_hist_reduce")) return e;
+        { SHG_PROF("clahe_lut", st); k_tile_lut16_blocks<<<dim3(32, (unsigned)ntiles), 1024, 0, st>>>(hist, se, clip, lut_scale, lut); }
+        if (int e = shg::check_launch("k_tile_lut16_blocks")) return e;
+        { SHG_PROF("clahe_interp", st); launch_interp16(static_cast<const uint16_t*>(img), h, w, pitch, tiles, inv_tw, inv_th, lut, true, static_cast<uint16_t*>(dst), dst_pitch, st); }
+        if (chunk_tile_out) *chunk_tile_out = chunk_tile;
+        return shg::check_launch("k_clahe_interp");
+    }
     if (hipError_t e = hipMemsetAsync(hist, 0, (size_t)ntiles * hist_size * sizeof(uint32_t), st)) {
         shg::set_error("shg_clahe: memset: %s", hipGetErrorString(e));
         return (int)e;
     }
-    const float inv_tw = 1.0f / (float)tw, inv_th = 1.0f / (float)th;
-    dim3 igrid((unsigned)((w + 255) / 256), (unsigned)h);
     if (bytes_per_px == 2) {
         ensure_lds_attr();
         dim3 hgrid((unsigned)((area + SLICE_PX - 1) / SLICE_PX), (unsigned)ntiles);
@@ -545,8 +853,7 @@ extern "C" int shg_clahe(const void* img, int64_t h, int64_t w, int64_t pitch, i
             k_tile_lut<HIST16><<<ntiles, 1024, 0, st>>>(hist, clip, lut_scale, lut);
         }
         if (int e = shg::check_launch("k_tile_lut")) return e;
-        { SHG_PROF("clahe_interp", st); k_clahe_interp<uint16_t, HIST16><<<igrid, 256, 0, st>>>(static_cast<const uint16_t*>(img), h, w, pitch, tiles, inv_tw, inv_th,
-                                                                lut, static_cast<uint16_t*>(dst), dst_pitch); }
+        { SHG_PROF("clahe_interp", st); launch_interp16(static_cast<const uint16_t*>(img), h, w, pitch, tiles, inv_tw, inv_th, lut, false, static_cast<uint16_t*>(dst), dst_pitch, st); }
     } else {
         int64_t hb = (area + 4095) / 4096;
         if (hb > 256) hb = 256;
@@ -559,6 +866,12 @@ extern "C" int shg_clahe(const void* img, int64_t h, int64_t w, int64_t pitch, i
                                                             static_cast<uint8_t*>(dst), dst_pitch); }
     }
     return shg::check_launch("k_clahe_interp");
+}
+}  // namespace
+
+extern "C" int shg_clahe(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_per_px, double clip_limit, int tiles,
+                         void* dst, int64_t dst_pitch, void* workspace, size_t workspace_bytes, shg_stream_t stream) {
+    return clahe_impl(img, h, w, pitch, bytes_per_px, clip_limit, tiles, dst, dst_pitch, workspace, workspace_bytes, stream, nullptr);
 }
 
 extern "C" int shg_hist(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_per_px, uint32_t* hist, shg_stream_t stream) {
@@ -602,6 +915,7 @@ extern "C" int shg_select_u16(const uint16_t* img, int64_t h, int64_t w, int64_t
     hipError_t e = hipMemsetAsync(hist, 0, (size_t)(1 + n_ranks) * 256 * sizeof(uint32_t), st);
     if (e != hipSuccess) { shg::set_error("shg_select_u16: %s", hipGetErrorString(e)); return (int)e; }
     // ~8192 pixels per workgroup, at most 1024 workgroups, whole rows each
+    // (measured, tools/bench_select.py: 2048 / 4096 / 8192 / 16384 pixels per workgroup -> 92 / 58 / 45 / 44 us for two ranks)
     int64_t want = (h * w + 8191) / 8192;
     want = want < 1 ? 1 : (want > 1024 ? 1024 : want);
     const unsigned blocks = (unsigned)(h < want ? h : want);
@@ -625,18 +939,30 @@ extern "C" size_t shg_contrast_stats_workspace_bytes(int tiles) {
     return ((c + 255) / 256 + (s2 + 255) / 256 + (s3 + 255) / 256 + (chunks + 255) / 256) * 256;
 }
 
+extern "C" size_t shg_contrast_stats_workspace_bytes_for(int64_t h, int64_t w, int tiles) {
+    const size_t base = shg_contrast_stats_workspace_bytes(tiles);
+    if (base == 0 || h <= 0 || w <= 0) return 0;
+    const size_t c_old = (shg_clahe_workspace_bytes(tiles, 2) + 255) / 256 * 256, c_new = (shg_clahe_workspace_bytes_for(h, w, tiles, 2) + 255) / 256 * 256;
+    return base - c_old + c_new;
+}
+
 extern "C" int shg_contrast_stats_u16(const uint16_t* frame, int64_t h, int64_t w, int64_t pitch, double clip_limit, int tiles,
                                       uint16_t* cl1, int64_t cl1_pitch, const int64_t* ranks_frame2, const int64_t* ranks_cl13,
                                       double* out5, void* workspace, size_t workspace_bytes, shg_stream_t stream) {
     SHG_REQUIRE(frame && cl1 && ranks_frame2 && ranks_cl13 && out5 && workspace, SHG_E_ARG, "shg_contrast_stats_u16: null pointer");
-    const size_t c = (shg_clahe_workspace_bytes(tiles, 2) + 255) / 256 * 256, s2 = (shg_select_u16_workspace_bytes(2) + 255) / 256 * 256;
-    SHG_REQUIRE(c != 0 && workspace_bytes >= shg_contrast_stats_workspace_bytes(tiles), SHG_E_WORKSPACE,
+    const size_t c_old = (shg_clahe_workspace_bytes(tiles, 2) + 255) / 256 * 256, s2 = (shg_select_u16_workspace_bytes(2) + 255) / 256 * 256;
+    SHG_REQUIRE(c_old != 0 && workspace_bytes >= shg_contrast_stats_workspace_bytes(tiles), SHG_E_WORKSPACE,
                 "shg_contrast_stats_u16: workspace too small or bad tile count");
+    SHG_REQUIRE(h > 0 && w > 0, SHG_E_ARG, "shg_contrast_stats_u16: empty image");
+    // a workspace of shg_contrast_stats_workspace_bytes_for(h, w, tiles) lets CLAHE build its histograms without atomics
+    const bool roomy = workspace_bytes >= shg_contrast_stats_workspace_bytes_for(h, w, tiles);
+    const size_t c = roomy ? (shg_clahe_workspace_bytes_for(h, w, tiles, 2) + 255) / 256 * 256 : c_old;
     char* ws = static_cast<char*>(workspace);
+    const uint32_t* chunk_tile = nullptr;
     // When the tile grid divides the image, CLAHE's tile histograms (still at the head of its workspace) add up to the
     // histogram of the frame: np.percentile(frame, q)'s two order statistics are read off them (k_chunk_sums, k_hist_ranks)
     // instead of selecting over the image again (two passes of k_select16_pass).
-    if (int e = shg_clahe(frame, h, w, pitch, 2, clip_limit, tiles, cl1, cl1_pitch, ws, c, stream)) return e;
+    if (int e = clahe_impl(frame, h, w, pitch, 2, clip_limit, tiles, cl1, cl1_pitch, ws, c, stream, &chunk_tile)) return e;
     if (h % tiles == 0 && w % tiles == 0) {
         const size_t s3r = (shg_select_u16_workspace_bytes(3) + 255) / 256 * 256;
         uint32_t* chunk_sums = reinterpret_cast<uint32_t*>(ws + c + s2 + s3r);
@@ -647,8 +973,12 @@ extern "C" int shg_contrast_stats_u16(const uint16_t* frame, int64_t h, int64_t 
         }
         hipStream_t st = shg::as_stream(stream);
         SHG_PROF("hist_ranks", st);
-        k_chunk_sums<<<64, 1024, 0, st>>>(reinterpret_cast<const uint32_t*>(ws), tiles * tiles, chunk_sums);
-        k_hist_ranks<<<2, 1024, 0, st>>>(reinterpret_cast<const uint32_t*>(ws), chunk_sums, tiles * tiles, ranks, out5);
+        if (chunk_tile) {                                // left by k_hist_reduce, one set per tile
+            k_hist_ranks<<<2, 1024, 0, st>>>(reinterpret_cast<const uint32_t*>(ws), chunk_tile, tiles * tiles, tiles * tiles, ranks, out5);
+        } else {
+            k_chunk_sums<<<64, 1024, 0, st>>>(reinterpret_cast<const uint32_t*>(ws), tiles * tiles, chunk_sums);
+            k_hist_ranks<<<2, 1024, 0, st>>>(reinterpret_cast<const uint32_t*>(ws), chunk_sums, 1, tiles * tiles, ranks, out5);
+        }
         if (int e = shg::check_launch("k_hist_ranks")) return e;
     } else if (int e = shg_select_u16(frame, h, w, pitch, ranks_frame2, 2, out5, ws + c, s2, stream)) return e;
     return shg_select_u16(cl1, h, w, cl1_pitch, ranks_cl13, 3, out5 + 2, ws + c + s2, shg_select_u16_workspace_bytes(3), stream);

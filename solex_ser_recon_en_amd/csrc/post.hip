@@ -62,11 +62,21 @@ __global__ __launch_bounds__(256) void k_fill_disc(uint16_t* __restrict__ img, i
 }
 
 __global__ __launch_bounds__(256) void k_downscale_mean(const uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch,
-                                                        int f, int64_t oh, int64_t ow, double* __restrict__ dst) {
+                                                        int f, int64_t oh, int64_t ow, int vec4, double* __restrict__ dst) {
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= oh * ow) return;
     const int64_t oy = o / ow, ox = o - oy * ow;
     uint64_t s = 0;                     // zero padded blocks (block_reduce cval=0); the integer sum is exact
+    if (f == 4 && vec4 && ox * 4 + 4 <= w && oy * 4 + 4 <= h) {
+        // the usual block (ellipse_to_circle.py:299): four 8-byte loads in flight instead of sixteen 2-byte ones
+        uint2 q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = *reinterpret_cast<const uint2*>(img + (oy * 4 + j) * pitch + ox * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += (uint64_t)((q[j].x & 0xffffu) + (q[j].x >> 16) + (q[j].y & 0xffffu) + (q[j].y >> 16));
+        dst[o] = ((double)s / 65536.0) / 16.0;
+        return;
+    }
     for (int j = 0; j < f; ++j) {
         const int64_t y = oy * f + j;
         if (y >= h) break;
@@ -132,7 +142,8 @@ extern "C" int shg_downscale_mean_u16(const uint16_t* img, int64_t h, int64_t w,
     SHG_REQUIRE(img && dst, SHG_E_ARG, "shg_downscale_mean_u16: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w && factor >= 1 && factor <= 64, SHG_E_ARG, "shg_downscale_mean_u16: bad size");
     const int64_t oh = (h + factor - 1) / factor, ow = (w + factor - 1) / factor;
-    { SHG_PROF("downscale", shg::as_stream(stream)); k_downscale_mean<<<(unsigned)((oh * ow + 255) / 256), 256, 0, shg::as_stream(stream)>>>(img, h, w, pitch, factor, oh, ow, dst); }
+    { SHG_PROF("downscale", shg::as_stream(stream)); k_downscale_mean<<<(unsigned)((oh * ow + 255) / 256), 256, 0, shg::as_stream(stream)>>>(
+          img, h, w, pitch, factor, oh, ow, (reinterpret_cast<uintptr_t>(img) & 7) == 0 && pitch % 4 == 0, dst); }
     return shg::check_launch("k_downscale_mean");
 }
 
@@ -147,6 +158,82 @@ __device__ __forceinline__ uint16_t rescale1(double px, double lo, double span) 
     v = v < 0.0 ? 0.0 : v;
     v = v > 65535.0 ? 65535.0 : v;
     return (uint16_t)(int)v;
+}
+
+// rescale1 without the division for all but a handful of pixels.  t = 65535 * (px - lo) is rounded as the reference
+// rounds it; q = t * (1 / span) is within 2^-50 * 65535 < 1e-10 of the correctly rounded t / span, so unless q sits that
+// close to a whole number both truncate to the same integer (and clamp alike beyond 0 / 65535).  The rare pixel near a
+// boundary takes the exact division.  Three float64 divisions per pixel made k_products ALU bound (20 us
+// for 40 MB of traffic, see profiles/).
+__device__ __forceinline__ uint32_t rescale1_fast(double px, double lo, double span, double inv_span) {
+    const double t = 65535.0 * (px - lo);
+    const double q = t * inv_span;
+    if (q < -1e-7) return 0u;                          // the clamps decide (sky below lo, saturated disc above hi)
+    if (q > 65535.0 + 1e-7) return 65535u;
+    const double fl = floor(q);
+    const double frac = q - fl;
+    if (frac > 1e-7 && frac < 1.0 - 1e-7) return (uint32_t)(int)fl;
+    double v = t / span;
+    v = v < 0.0 ? 0.0 : v;
+    v = v > 65535.0 ? 65535.0 : v;
+    return (uint32_t)(int)v;
+}
+
+// Eight pixels per lane: 16-byte loads of frame and cl1, 16-byte stores of the three products (rows 16-byte aligned,
+// pitches multiples of 8; a row's last, partial vector goes pixel by pixel).
+__global__ __launch_bounds__(256) void k_products8(const uint16_t* __restrict__ frame, int64_t frame_pitch,
+                                                   const uint16_t* __restrict__ cl1, int64_t cl1_pitch, int64_t w, Bounds6 b,
+                                                   uint16_t* __restrict__ hc, uint16_t* __restrict__ protus, uint16_t* __restrict__ cc,
+                                                   int64_t dst_pitch, int64_t x0, int64_t y0, int64_t r) {
+    const int64_t x = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    const int64_t y = blockIdx.y;
+    if (x >= w) return;
+    const double i0 = 1.0 / b.span[0], i1 = 1.0 / b.span[1], i2 = 1.0 / b.span[2];
+    // the disc's span on this row: [x0 - half, x0 + half] (cv2.circle(frame_protus, (x0, y0), r, 80, -1))
+    int64_t d_lo = 1, d_hi = 0;
+    if (r > 0) {
+        const int64_t ady = y > y0 ? y - y0 : y0 - y;
+        if (ady <= r) {
+            const int64_t half = isqrt64(r * r - ady * ady);
+            d_lo = x0 - half;
+            d_hi = x0 + half;
+        }
+    }
+    if (x + 8 <= w) {
+        const uint4 qf = *reinterpret_cast<const uint4*>(frame + y * frame_pitch + x);
+        const uint4 qc = *reinterpret_cast<const uint4*>(cl1 + y * cl1_pitch + x);
+        const uint32_t fw[4] = {qf.x, qf.y, qf.z, qf.w}, cw[4] = {qc.x, qc.y, qc.z, qc.w};
+        uint32_t oh[4], op[4], oc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t h2[2], p2[2], c2[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const double f = (double)((fw[j] >> (16 * e)) & 0xffffu);
+                const double c = (double)((cw[j] >> (16 * e)) & 0xffffu);
+                const int64_t xi = x + 2 * j + e;
+                h2[e] = rescale1_fast(f, b.lo[0], b.span[0], i0);
+                p2[e] = (xi >= d_lo && xi <= d_hi) ? 80u : rescale1_fast(f, b.lo[1], b.span[1], i1);
+                c2[e] = rescale1_fast(c, b.lo[2], b.span[2], i2);
+            }
+            oh[j] = h2[0] | (h2[1] << 16);
+            op[j] = p2[0] | (p2[1] << 16);
+            oc[j] = c2[0] | (c2[1] << 16);
+        }
+        // the products are final: nobody on the GPU reads them again, so they bypass the caches (frame and cl1 stay)
+        typedef unsigned int __attribute__((ext_vector_type(4))) u32x4;
+        __builtin_nontemporal_store((u32x4){oh[0], oh[1], oh[2], oh[3]}, reinterpret_cast<u32x4*>(hc + y * dst_pitch + x));
+        __builtin_nontemporal_store((u32x4){op[0], op[1], op[2], op[3]}, reinterpret_cast<u32x4*>(protus + y * dst_pitch + x));
+        __builtin_nontemporal_store((u32x4){oc[0], oc[1], oc[2], oc[3]}, reinterpret_cast<u32x4*>(cc + y * dst_pitch + x));
+    } else {
+        for (int64_t xi = x; xi < w; ++xi) {
+            const double f = (double)frame[y * frame_pitch + xi];
+            const double c = (double)cl1[y * cl1_pitch + xi];
+            hc[y * dst_pitch + xi] = (uint16_t)rescale1_fast(f, b.lo[0], b.span[0], i0);
+            protus[y * dst_pitch + xi] = (xi >= d_lo && xi <= d_hi) ? (uint16_t)80 : (uint16_t)rescale1_fast(f, b.lo[1], b.span[1], i1);
+            cc[y * dst_pitch + xi] = (uint16_t)rescale1_fast(c, b.lo[2], b.span[2], i2);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_products(const uint16_t* __restrict__ frame, int64_t frame_pitch,
@@ -185,8 +272,18 @@ extern "C" int shg_contrast_products_u16(const uint16_t* frame, int64_t frame_pi
         b.span[i] = hi - lo;
     }
     hipStream_t st = shg::as_stream(stream);
-    dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
-    { SHG_PROF("products", st); k_products<<<grid, 256, 0, st>>>(frame, frame_pitch, cl1, cl1_pitch, w, b, high_contrast, protus, cc, dst_pitch,
-                                                                  disc_x0, disc_y0, disc_r > 0 ? disc_r : 0); }
+    const uintptr_t ptrs = reinterpret_cast<uintptr_t>(frame) | reinterpret_cast<uintptr_t>(cl1) | reinterpret_cast<uintptr_t>(high_contrast) |
+                           reinterpret_cast<uintptr_t>(protus) | reinterpret_cast<uintptr_t>(cc);
+    const bool vec = (ptrs & 15) == 0 && frame_pitch % 8 == 0 && cl1_pitch % 8 == 0 && dst_pitch % 8 == 0;
+    SHG_PROF("products", st);
+    if (vec) {
+        dim3 grid((unsigned)((w + 8 * 256 - 1) / (8 * 256)), (unsigned)h);
+        k_products8<<<grid, 256, 0, st>>>(frame, frame_pitch, cl1, cl1_pitch, w, b, high_contrast, protus, cc, dst_pitch, disc_x0, disc_y0,
+                                          disc_r > 0 ? disc_r : 0);
+    } else {
+        dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
+        k_products<<<grid, 256, 0, st>>>(frame, frame_pitch, cl1, cl1_pitch, w, b, high_contrast, protus, cc, dst_pitch, disc_x0, disc_y0,
+                                         disc_r > 0 ? disc_r : 0);
+    }
     return shg::check_launch("k_products");
 }

@@ -385,7 +385,7 @@ extern "C" size_t shg_stage_process_workspace_bytes(int64_t k, int64_t h, int64_
     if (k <= 0 || h <= 0 || w <= 0) return 0;
     const size_t pitch = ((size_t)std::max(w, crop_w) + 63) / 64 * 64;
     return 2 * up((size_t)h * 4) + 2 * up((size_t)k * h * 8) + up((size_t)k * h * 8) + up(4096 * 8) +
-           (size_t)k * up((size_t)h * pitch * 2) + up(shg_contrast_stats_workspace_bytes(tiles)) + up((size_t)k * 5 * 8) + kAlign;
+           (size_t)k * up((size_t)h * pitch * 2) + up(shg_contrast_stats_workspace_bytes_for(h, crop_w > 0 ? crop_w : w, tiles)) + up((size_t)k * 5 * 8) + kAlign;
 }
 
 extern "C" size_t shg_stage_process_host_bytes(int64_t k, int64_t h) {
@@ -431,7 +431,7 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
     const bool need_tmp = transversalium && crop_w > 0 && !host_detrans;
     if (need_tmp)
         for (int64_t i = 0; i < k; ++i) scaled[i] = dev.take<uint16_t>((size_t)h * tpitch);
-    const size_t cs_bytes = shg_contrast_stats_workspace_bytes(tiles);
+    const size_t cs_bytes = shg_contrast_stats_workspace_bytes_for(h, out_w, tiles);
     SHG_REQUIRE(cs_bytes != 0, SHG_E_ARG, "shg_stage_process_frames: unsupported tile count %d", tiles);
     char* cs_ws = dev.take<char>(cs_bytes);
     double* out5 = dev.take<double>((size_t)k * 5);

@@ -329,7 +329,9 @@ def crop_pad_u16(img, nw, sx0, dx0, n, fill):
     return out
 
 
-def clahe(img, clip_limit=0.8, tiles=2):
+def clahe(img, clip_limit=0.8, tiles=2, small_workspace=False):
+    """small_workspace: give shg_clahe only shg_clahe_workspace_bytes (it then builds the 16-bit tile histograms with
+    global atomics); the default is the roomier shg_clahe_workspace_bytes_for."""
     _dev(img, 'img')
     if img.dtype == torch.uint16:
         bpp = 2
@@ -338,7 +340,7 @@ def clahe(img, clip_limit=0.8, tiles=2):
     else:
         raise TypeError('clahe needs uint8 or uint16')
     ptr, h, w, pitch = _img(img, 'img')
-    need = lib.shg_clahe_workspace_bytes(int(tiles), bpp)
+    need = lib.shg_clahe_workspace_bytes(int(tiles), bpp) if small_workspace else lib.shg_clahe_workspace_bytes_for(h, w, int(tiles), bpp)
     if need == 0:
         raise ValueError('clahe: unsupported tile count %r' % (tiles,))
     ws = torch.empty(need, dtype=torch.uint8, device=img.device)
@@ -348,12 +350,13 @@ def clahe(img, clip_limit=0.8, tiles=2):
     return out
 
 
-def contrast_stats_u16(frame, ranks_frame, ranks_cl1, out5, clip_limit=0.8, tiles=2):
+def contrast_stats_u16(frame, ranks_frame, ranks_cl1, out5, clip_limit=0.8, tiles=2, small_workspace=False):
     """cl1 = clahe(frame) plus the order statistics of frame (2 ranks) and cl1 (3 ranks) into out5 (float64 [5], GPU):
     one C call for the first half of image_process.  -> cl1"""
     import ctypes
     ptr, h, w, pitch = _img(frame, 'frame', torch.uint16)
-    need = lib.shg_contrast_stats_workspace_bytes(int(tiles))
+    need = (lib.shg_contrast_stats_workspace_bytes(int(tiles)) if small_workspace
+            else lib.shg_contrast_stats_workspace_bytes_for(h, w, int(tiles)))
     if need == 0:
         raise ValueError('contrast_stats: unsupported tile count %r' % (tiles,))
     ws = torch.empty(need, dtype=torch.uint8, device=frame.device)

@@ -290,6 +290,24 @@ def test_clahe_matches_oracle(ops, orc, h, w, tiles, dtype):
     want = orc.clahe(img, 0.8, tiles)
     # float32 arithmetic restated operation by operation: identical bits expected
     np.testing.assert_array_equal(got, want)
+    # the other histogram path (global atomics, one workgroup per tile LUT) gives the same image
+    np.testing.assert_array_equal(host(ops.clahe(dev(img), 0.8, tiles, small_workspace=True)), want)
+
+
+@pytest.mark.parametrize('h,w,tiles,clip_limit', [(1100, 1000, 2, 0.8), (1100, 1000, 2, 40.0), (901, 1203, 2, 3.0), (640, 960, 4, 8.0),
+                                                  (1100, 1000, 2, 0.0)])
+def test_clahe_paths_agree_with_the_oracle_on_several_slices_per_tile(ops, orc, h, w, tiles, clip_limit):
+    """Tiles of more than one 32768-pixel slice, clip limits from 1 count to hundreds (batch and residual redistribution
+    both at work), a padded (reflected) tile grid, no clipping at all: slice histograms + block-wise LUT, the atomics path
+    and the oracle agree bit for bit.  A solar-like image: a bright disc with limb darkening on a near-constant sky."""
+    rng = np.random.default_rng(17)
+    yy, xx = np.mgrid[0:h, 0:w]
+    r = np.hypot(yy - h / 2, xx - w / 2) / (0.42 * min(h, w))
+    disc = np.where(r < 1, 0.35 + 0.55 * np.sqrt(np.clip(1 - r * r, 0, 1)), 0.01)
+    img = np.clip((disc + 0.01 * rng.standard_normal((h, w))) * 65535, 0, 65535).astype(np.uint16)
+    want = orc.clahe(img, clip_limit, tiles)
+    np.testing.assert_array_equal(host(ops.clahe(dev(img), clip_limit, tiles)), want)
+    np.testing.assert_array_equal(host(ops.clahe(dev(img), clip_limit, tiles, small_workspace=True)), want)
 
 
 # ---- limb detection kernels -----------------------------------------------------------
