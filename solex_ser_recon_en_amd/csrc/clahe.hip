@@ -548,10 +548,10 @@ __global__ __launch_bounds__(256) void k_image_hist8(const uint8_t* __restrict__
 // pixels whose high byte was chosen.  hist: [n_ranks][2][256] u32, zeroed.  Every workgroup replays pass 0's
 // choice with a workgroup-wide scan (one bin per thread).
 __device__ __forceinline__ void pick_digit(const uint32_t* __restrict__ hist, int64_t rank, int& digit, int64_t& below) {
-    __shared__ int64_t wave_tot[4];
+    __shared__ int64_t wave_tot[16];
     __shared__ int64_t chosen[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t c = hist[tid];
+    const int64_t c = tid < 256 ? hist[tid] : 0;           // one bin per thread; a wider workgroup's other threads idle
     int64_t incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -580,7 +580,7 @@ constexpr int SEL_COPIES0 = 16, SEL_COPIES1 = 4;
 
 struct Ranks8 { int64_t v[8]; };            // the requested ranks travel as a kernel argument: no host-to-device copy per call
 
-__global__ __launch_bounds__(256) void k_select16_pass(const uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch, int pass,
+__global__ __launch_bounds__(1024) void k_select16_pass(const uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch, int pass,
                                                        Ranks8 ranks, int n_ranks, uint32_t* __restrict__ hist,
                                                        int vec_ok) {
     __shared__ uint32_t lh[8 * 256 * SEL_COPIES1];        // pass 0: [bin][16 copies]; pass 1: [rank][bin][4 copies]
@@ -594,7 +594,8 @@ __global__ __launch_bounds__(256) void k_select16_pass(const uint16_t* __restric
         }
     }
     const int n_words = pass == 0 ? 256 * SEL_COPIES0 : n_ranks * 256 * SEL_COPIES1;
-    for (int i = threadIdx.x; i < n_words; i += 256) lh[i] = 0;
+    const int nt = blockDim.x;
+    for (int i = threadIdx.x; i < n_words; i += nt) lh[i] = 0;
     __syncthreads();
     int his[8];
 #pragma unroll
@@ -617,12 +618,12 @@ __global__ __launch_bounds__(256) void k_select16_pass(const uint16_t* __restric
         const int64_t vpr = vec_ok ? w / 8 : 0;           // 16-byte vectors per row
         // four independent 16-byte loads per lane before the first use; out-of-range slots re-read vector 0 and are dropped
         const int64_t nvec = nrows * vpr;
-        for (int64_t base = 0; base < nvec; base += 4 * 256) {
+        for (int64_t base = 0; base < nvec; base += 4 * nt) {
             uint4 q[4];
             bool ok[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int64_t i = base + u * 256 + threadIdx.x;
+                const int64_t i = base + u * nt + threadIdx.x;
                 ok[u] = i < nvec;
                 const int64_t ii = ok[u] ? i : 0;
                 const int64_t r = ii / vpr, vx = ii - r * vpr;
@@ -640,12 +641,13 @@ __global__ __launch_bounds__(256) void k_select16_pass(const uint16_t* __restric
             }
         }
         const int64_t tail = w - vpr * 8;
-        for (int64_t i = threadIdx.x; i < nrows * tail; i += 256) {
+        for (int64_t i = threadIdx.x; i < nrows * tail; i += nt) {
             const int64_t r = i / tail, x = vpr * 8 + (i - r * tail);
             count(img[(r0 + r) * pitch + x]);
         }
     }
     __syncthreads();
+    if (threadIdx.x >= 256) return;
     if (pass == 0) {
         uint32_t c = 0;
 #pragma unroll
@@ -922,7 +924,9 @@ extern "C" int shg_select_u16(const uint16_t* img, int64_t h, int64_t w, int64_t
     const int vec_ok = ((reinterpret_cast<uintptr_t>(img) & 15) == 0) && (pitch % 8 == 0);
     SHG_PROF("select_u16", st);
     for (int pass = 0; pass < 2; ++pass) {
-        k_select16_pass<<<blocks, 256, 0, st>>>(img, h, w, pitch, pass, ranks, n_ranks, hist, vec_ok);
+        // 512 threads: the zeroing / replay / flush around the pixel loop is shared by twice the waves (256 / 512 / 1024
+        // threads: 44.7 / 40.6 / 40.3 us for two ranks, tools/bench_select.py)
+        k_select16_pass<<<blocks, 512, 0, st>>>(img, h, w, pitch, pass, ranks, n_ranks, hist, vec_ok);
         if (int err = shg::check_launch("k_select16_pass")) return err;
     }
     k_select16_final<<<(unsigned)n_ranks, 256, 0, st>>>(ranks, hist, out);

@@ -303,13 +303,18 @@ extern "C" int shg_stage_limb_points(const uint16_t* disk, int64_t h, int64_t w,
     if (k <= 63) {
         // the block means are whole numbers of 2^-20: select on the integer window sums (three passes instead of eight)
         STAGE_TRY(shg_box_blur_key_f64(small, sh, sw, k, blurred, keys_k, tmp, stream));
-        STAGE_TRY(shg_box_blur_key_f64(small, sh, sw, 5, blur5, keys_5, tmp, stream));
+        if (k == 5) {                                    // 2000-2399 slit rows: cv2.blur(img, (k, k)) is the 5 x 5 blur itself
+            blur5 = blurred;
+            keys_5 = keys_k;
+        } else {
+            STAGE_TRY(shg_box_blur_key_f64(small, sh, sw, 5, blur5, keys_5, tmp, stream));
+        }
         const uint32_t* karr[4] = {keys_5, keys_5, keys_k, keys_k};
         const int kk[4] = {5, 5, k, k};
         STAGE_TRY(shg_select_keys_u32(karr, n, ranks, kk, 4, packed, sel_ws, sel_bytes, stream));
     } else {
         STAGE_TRY(shg_box_blur_f64(small, sh, sw, k, blurred, tmp, stream));
-        STAGE_TRY(shg_box_blur_f64(small, sh, sw, 5, blur5, tmp, stream));
+        STAGE_TRY(shg_box_blur_f64(small, sh, sw, 5, blur5, tmp, stream));      // (k > 63 here, never 5)
         const double* arrays[4] = {blur5, blur5, blurred, blurred};
         STAGE_TRY(shg_select_multi_f64(arrays, n, ranks, 4, packed, sel_ws, sel_bytes, stream));
     }
