@@ -314,7 +314,7 @@ int shg_select_multi_f64(const double* const* host_arrays, int64_t n, const int6
 /* get_flood_image's statistics (ellipse_to_circle.py:159-169): stats[0] = np.sum(image) (image
  * values are multiples of 2^-20, as the 4x4 block mean of uint16/65536 is), and over
  * data = blurred[blurred < very_bright]: stats[1] = min, stats[2] = max,
- * counts[20] = np.histogram(data, bins=20)[0].  workspace: 32 bytes. */
+ * counts[20] = np.histogram(data, bins=20)[0].  workspace: 256 bytes. */
 int shg_flood_stats_f64(const double* image, const double* blurred, int64_t n, double very_bright,
                         double* stats, uint32_t* counts, void* workspace, shg_stream_t stream);
 /* The same with very_bright = np.percentile(blurred, 99) formed on the device from the two order

@@ -547,11 +547,17 @@ __global__ __launch_bounds__(256) void k_image_hist8(const uint8_t* __restrict__
 // MSB-first radix select on the 16-bit values: pass 0 histograms the high byte, pass 1 the low byte of the
 // pixels whose high byte was chosen.  hist: [n_ranks][2][256] u32, zeroed.  Every workgroup replays pass 0's
 // choice with a workgroup-wide scan (one bin per thread).
-__device__ __forceinline__ void pick_digit(const uint32_t* __restrict__ hist, int64_t rank, int& digit, int64_t& below) {
+// Workgroups flush their histograms into one of SEL_SLOTS copies (blockIdx % SEL_SLOTS): ~500 workgroups adding to the
+// same 256 addresses queue up behind each other in the memory-side atomic units; readers add the copies up.
+constexpr int SEL_SLOTS = 8;
+
+__device__ __forceinline__ void pick_digit(const uint32_t* __restrict__ hist, int slot_stride, int64_t rank, int& digit, int64_t& below) {
     __shared__ int64_t wave_tot[16];
     __shared__ int64_t chosen[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t c = tid < 256 ? hist[tid] : 0;           // one bin per thread; a wider workgroup's other threads idle
+    int64_t c = 0;                                         // one bin per thread; a wider workgroup's other threads idle
+    if (tid < 256)
+        for (int k = 0; k < SEL_SLOTS; ++k) c += hist[(int64_t)k * slot_stride + tid];
     int64_t incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -589,7 +595,7 @@ __global__ __launch_bounds__(1024) void k_select16_pass(const uint16_t* __restri
         for (int r = 0; r < n_ranks; ++r) {
             int hi;
             int64_t below;
-            pick_digit(hist, ranks.v[r], hi, below);
+            pick_digit(hist, (1 + n_ranks) * 256, ranks.v[r], hi, below);
             if (threadIdx.x == 0) his_s[r] = hi;
         }
     }
@@ -625,8 +631,8 @@ __global__ __launch_bounds__(1024) void k_select16_pass(const uint16_t* __restri
             for (int u = 0; u < 4; ++u) {
                 const int64_t i = base + u * nt + threadIdx.x;
                 ok[u] = i < nvec;
-                const int64_t ii = ok[u] ? i : 0;
-                const int64_t r = ii / vpr, vx = ii - r * vpr;
+                const uint32_t ii = ok[u] ? (uint32_t)i : 0u;        // (a workgroup's share is far below 2^32 vectors:
+                const uint32_t r = ii / (uint32_t)vpr, vx = ii - r * (uint32_t)vpr;      //  32-bit division, a fifth of the 64-bit one)
                 q[u] = *reinterpret_cast<const uint4*>(img + (r0 + r) * pitch + vx * 8);
             }
 #pragma unroll
@@ -648,6 +654,7 @@ __global__ __launch_bounds__(1024) void k_select16_pass(const uint16_t* __restri
     }
     __syncthreads();
     if (threadIdx.x >= 256) return;
+    hist += (int64_t)(blockIdx.x % SEL_SLOTS) * (1 + n_ranks) * 256;
     if (pass == 0) {
         uint32_t c = 0;
 #pragma unroll
@@ -668,8 +675,8 @@ __global__ __launch_bounds__(256) void k_select16_final(Ranks8 ranks, const uint
                                                         double* __restrict__ out) {
     int hi, lo;
     int64_t below, below2;
-    pick_digit(hist, ranks.v[blockIdx.x], hi, below);
-    pick_digit(hist + (1 + blockIdx.x) * 256, ranks.v[blockIdx.x] - below, lo, below2);
+    pick_digit(hist, (1 + (int)gridDim.x) * 256, ranks.v[blockIdx.x], hi, below);
+    pick_digit(hist + (1 + blockIdx.x) * 256, (1 + (int)gridDim.x) * 256, ranks.v[blockIdx.x] - below, lo, below2);
     if (threadIdx.x == 0) out[blockIdx.x] = (double)((hi << 8) | lo);
 }
 
@@ -900,7 +907,7 @@ extern "C" int shg_hist(const void* img, int64_t h, int64_t w, int64_t pitch, in
 
 extern "C" size_t shg_select_u16_workspace_bytes(int n_ranks) {
     if (n_ranks < 1 || n_ranks > 8) return 0;
-    return (size_t)(1 + n_ranks) * 256 * sizeof(uint32_t) + (size_t)n_ranks * sizeof(int64_t);
+    return (size_t)8 * (1 + n_ranks) * 256 * sizeof(uint32_t) + (size_t)n_ranks * sizeof(int64_t);      // SEL_SLOTS histogram copies
 }
 
 extern "C" int shg_select_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, const int64_t* host_ranks, int n_ranks,
@@ -914,7 +921,7 @@ extern "C" int shg_select_u16(const uint16_t* img, int64_t h, int64_t w, int64_t
     uint32_t* hist = static_cast<uint32_t*>(workspace);
     Ranks8 ranks = {};
     for (int i = 0; i < n_ranks; ++i) ranks.v[i] = host_ranks[i];
-    hipError_t e = hipMemsetAsync(hist, 0, (size_t)(1 + n_ranks) * 256 * sizeof(uint32_t), st);
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)SEL_SLOTS * (1 + n_ranks) * 256 * sizeof(uint32_t), st);
     if (e != hipSuccess) { shg::set_error("shg_select_u16: %s", hipGetErrorString(e)); return (int)e; }
     // ~8192 pixels per workgroup, at most 1024 workgroups, whole rows each
     // (measured, tools/bench_select.py: 2048 / 4096 / 8192 / 16384 pixels per workgroup -> 92 / 58 / 45 / 44 us for two ranks)

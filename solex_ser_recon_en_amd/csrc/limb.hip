@@ -11,6 +11,7 @@
 //   symmetric kernel  : t = x[0]*w[0]; for j = -R..-1: t += (x[j] + x[-j]) * w[j]
 //   antisymmetric     : t = x[0]*w[0]; for j = -R..-1: t += (x[j] - x[-j]) * w[j]
 #include <math.h>
+#include <stdlib.h>
 #include "shg_common.h"
 
 namespace {
@@ -329,9 +330,18 @@ __global__ __launch_bounds__(256) void k_select32_final(Pairs8 p, const uint32_t
 // then over data = blurred[blurred < very_bright]: stats[1] = min, stats[2] = max, counts[20] = np.histogram(data, 20)
 // accumulators, the 20 counters, and very_bright: either the caller's value or NumPy's _lerp of two order statistics
 // that are still on the device (np.percentile(img_blurred, 99), ellipse_to_circle.py:165) -- no host round trip
+// Workgroups add their partial results to one of FLOOD_SLOTS slots (blockIdx % FLOOD_SLOTS), the reader folds the slots:
+// 128 workgroups on the same three addresses queue up in the memory-side atomic units for most of the kernel's 9 us.
+constexpr int FLOOD_SLOTS = 9;                            // 4 + 3 * 9 = 31 u64 of the 256-byte workspace
+
 __global__ void k_flood_init(unsigned long long* __restrict__ acc, uint32_t* __restrict__ counts, const double* __restrict__ order_stats,
                              double gamma, double very_bright) {
     if (threadIdx.x < 20) counts[threadIdx.x] = 0;
+    if (threadIdx.x < FLOOD_SLOTS) {                      // per-slot sum, min key, max key (k_flood_minmax)
+        acc[4 + 3 * threadIdx.x] = 0ull;
+        acc[5 + 3 * threadIdx.x] = ~0ull;
+        acc[6 + 3 * threadIdx.x] = 0ull;
+    }
     if (threadIdx.x == 0) {
         acc[0] = 0ull;
         acc[1] = ~0ull;
@@ -385,9 +395,10 @@ __global__ __launch_bounds__(256) void k_flood_minmax(const double* __restrict__
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int i = 1; i < 4; ++i) { s += ws[i]; lo = wlo[i] < lo ? wlo[i] : lo; hi = whi[i] > hi ? whi[i] : hi; }
-        atomicAdd(&acc[0], s);
-        atomicMin(&acc[1], lo);
-        atomicMax(&acc[2], hi);
+        unsigned long long* slot = acc + 4 + 3 * (blockIdx.x % FLOOD_SLOTS);
+        atomicAdd(&slot[0], s);
+        atomicMin(&slot[1], lo);
+        atomicMax(&slot[2], hi);
     }
 }
 
@@ -397,7 +408,13 @@ __global__ __launch_bounds__(256) void k_flood_hist(const double* __restrict__ b
     const double very_bright = __longlong_as_double((long long)acc[3]);
     __shared__ double edges[21];
     __shared__ uint32_t lc[20];
-    const double mn = key_f64(acc[1]), mx = key_f64(acc[2]);
+    unsigned long long total = 0, klo = ~0ull, khi = 0ull;
+    for (int k = 0; k < FLOOD_SLOTS; ++k) {
+        total += acc[4 + 3 * k];
+        klo = acc[5 + 3 * k] < klo ? acc[5 + 3 * k] : klo;
+        khi = acc[6 + 3 * k] > khi ? acc[6 + 3 * k] : khi;
+    }
+    const double mn = key_f64(klo), mx = key_f64(khi);
     if (threadIdx.x < 21) {
         // np.histogram: first == last -> (first - 0.5, last + 0.5); bin_edges = np.linspace(first, last, 21)
         double first = mn, last = mx;
@@ -417,7 +434,7 @@ __global__ __launch_bounds__(256) void k_flood_hist(const double* __restrict__ b
     __syncthreads();
     if (threadIdx.x < 20 && lc[threadIdx.x]) atomicAdd(&counts[threadIdx.x], lc[threadIdx.x]);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        stats[0] = (double)acc[0] / 1048576.0;
+        stats[0] = (double)total / 1048576.0;
         stats[1] = mn;
         stats[2] = mx;
     }
@@ -599,7 +616,7 @@ extern "C" int shg_select_keys_u32(const uint32_t* const* host_keys, int64_t n, 
         shg::set_error("shg_select_keys_u32: %s", hipGetErrorString(e));
         return (int)e;
     }
-    int64_t blocks = (n + 2047) / 2048;
+    int64_t blocks = (n + 2047) / 2048;                  // (fewer, longer workgroups are slower: 64 / 32 / 16 -> 7.2 / 9.8 / 15.5 us per pass)
     if (blocks > 256) blocks = 256;
     SHG_PROF("select", st);
     for (int pass = 0; pass < SEL32_PASSES; ++pass) {

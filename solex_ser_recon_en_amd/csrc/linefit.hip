@@ -117,7 +117,7 @@ extern "C" int shg_row_mean_u16(const uint16_t* img, int64_t h, int64_t w, doubl
 // rounding and the row reduction follow in registers.  Same integer sums and the same float32 / double scaling per column as k_box_rows / k_box_cols,
 // so the results are identical; what disappears is two image-sized round trips through HBM and two launches.
 namespace {
-constexpr int FROWS = 8;
+constexpr int FROWS = 4;
 
 __device__ __forceinline__ int blur_scaled(uint32_t s, int x, int w, double scale) {
     int r;
@@ -151,14 +151,29 @@ __global__ __launch_bounds__(256) void k_blur_reduce(const uint16_t* __restrict_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = blockIdx.x * FROWS;
     const int ya = r0 - kh / 2;
-    for (int j = wave; j < nrows; j += 4) {                // one wave per staged row
-        const uint16_t* srow = src + (int64_t)reflect_near(ya + j, h) * w;
-        uint16_t* drow = raw + j * w;
-        if ((w & 1) == 0) {                                // even width: every row starts on a 4-byte boundary
-            const uint32_t* s2 = reinterpret_cast<const uint32_t*>(srow);
-            uint32_t* d2 = reinterpret_cast<uint32_t*>(drow);
-            for (int x = lane; x < (w >> 1); x += 64) d2[x] = s2[x];
-        } else {
+    if ((w & 1) == 0) {
+        // even width: every row starts on a 4-byte boundary, the tile is nrows x w/2 dwords.  Four loads in flight per
+        // lane before the first LDS store (a load -> store loop waits for each load in turn: ~10 round trips to memory
+        // were most of this kernel's time)
+        const int w2 = w >> 1, total = nrows * w2;
+        const uint32_t* s2 = reinterpret_cast<const uint32_t*>(src);
+        uint32_t* d2 = reinterpret_cast<uint32_t*>(raw);
+        for (int base = threadIdx.x; base < total; base += 4 * 256) {
+            uint32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + 256 * u < total ? base + 256 * u : base;
+                const int j = i / w2, x = i - j * w2;
+                v[u] = s2[(int64_t)reflect_near(ya + j, h) * w2 + x];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (base + 256 * u < total) d2[base + 256 * u] = v[u];
+        }
+    } else {
+        for (int j = wave; j < nrows; j += 4) {            // one wave per staged row
+            const uint16_t* srow = src + (int64_t)reflect_near(ya + j, h) * w;
+            uint16_t* drow = raw + j * w;
             for (int x = lane; x < w; x += 64) drow[x] = srow[x];
         }
     }

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_downscale_mean(const uint16_t* __restri
                                                         int f, int64_t oh, int64_t ow, int vec4, double* __restrict__ dst) {
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= oh * ow) return;
-    const int64_t oy = o / ow, ox = o - oy * ow;
+    const int64_t oy = (int64_t)((uint32_t)o / (uint32_t)ow), ox = o - oy * ow;      // (oh * ow < 2^31: checked by the entry point)
     uint64_t s = 0;                     // zero padded blocks (block_reduce cval=0); the integer sum is exact
     if (f == 4 && vec4 && ox * 4 + 4 <= w && oy * 4 + 4 <= h) {
         // the usual block (ellipse_to_circle.py:299): four 8-byte loads in flight instead of sixteen 2-byte ones
@@ -142,6 +142,7 @@ extern "C" int shg_downscale_mean_u16(const uint16_t* img, int64_t h, int64_t w,
     SHG_REQUIRE(img && dst, SHG_E_ARG, "shg_downscale_mean_u16: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w && factor >= 1 && factor <= 64, SHG_E_ARG, "shg_downscale_mean_u16: bad size");
     const int64_t oh = (h + factor - 1) / factor, ow = (w + factor - 1) / factor;
+    SHG_REQUIRE(oh * ow < (1ll << 31), SHG_E_UNSUPPORTED, "shg_downscale_mean_u16: image too large");
     { SHG_PROF("downscale", shg::as_stream(stream)); k_downscale_mean<<<(unsigned)((oh * ow + 255) / 256), 256, 0, shg::as_stream(stream)>>>(
           img, h, w, pitch, factor, oh, ow, (reinterpret_cast<uintptr_t>(img) & 7) == 0 && pitch % 4 == 0, dst); }
     return shg::check_launch("k_downscale_mean");

@@ -237,7 +237,7 @@ extern "C" size_t shg_stage_limb_points_workspace_bytes(int64_t h, int64_t w) {
     if (h <= 0 || w <= 0) return 0;
     const int64_t sh = small_dim(h), sw = small_dim(w);
     const size_t n = (size_t)sh * (size_t)sw;
-    return 4 * up(n * 8) + up(std::max(shg_select_workspace_bytes(4), shg_select_keys_workspace_bytes(4))) + 2 * up(n * 4) + up(4 * 8) + up(3 * 8) + up(20 * 4) + up(32) + up(32 * 8) + 2 * up(n) +
+    return 4 * up(n * 8) + up(std::max(shg_select_workspace_bytes(4), shg_select_keys_workspace_bytes(4))) + 2 * up(n * 4) + up(4 * 8) + up(3 * 8) + up(20 * 4) + up(256) + up(32 * 8) + 2 * up(n) +
            up(shg_canny_workspace_bytes(sh, sw)) + up(shg_edge_components_workspace_bytes(sh, sw)) + up((2 * n + 1) * 4) + kAlign;
 }
 
@@ -278,7 +278,7 @@ extern "C" int shg_stage_limb_points(const uint16_t* disk, int64_t h, int64_t w,
     uint32_t* keys_5 = dev.take<uint32_t>((size_t)n);
     double* packed = dev.take<double>(32);                 // [0..3] order statistics, [4..6] flood stats, [8..17] the 20 counts
     uint32_t* counts = packed ? reinterpret_cast<uint32_t*>(packed + 8) : nullptr;
-    char* flood_ws = dev.take<char>(32);
+    char* flood_ws = dev.take<char>(256);
     uint8_t* low_mask = dev.take<uint8_t>((size_t)n);
     uint8_t* high_mask = dev.take<uint8_t>((size_t)n);
     const size_t canny_bytes = shg_canny_workspace_bytes(sh, sw), cc_bytes = shg_edge_components_workspace_bytes(sh, sw);

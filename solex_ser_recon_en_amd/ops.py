@@ -544,7 +544,7 @@ def flood_stats(image, blurred, very_bright):
         raise TypeError('flood_stats needs two dense float64 images of one shape')
     stats = torch.empty(3, dtype=torch.float64, device=image.device)
     counts = torch.empty(20, dtype=torch.int32, device=image.device)
-    ws = torch.empty(4, dtype=torch.int64, device=image.device)
+    ws = torch.empty(32, dtype=torch.int64, device=image.device)
     _lib.check(lib.shg_flood_stats_f64(image.contiguous().data_ptr(), blurred.contiguous().data_ptr(), image.numel(),
                                        float(very_bright), stats.data_ptr(), counts.data_ptr(), ws.data_ptr(), _stream()),
                'shg_flood_stats_f64')
@@ -563,7 +563,7 @@ def flood_stats_lerp(image, blurred, order_stats, gamma):
         raise TypeError('order_stats must be two contiguous float64 values')
     stats = torch.empty(3, dtype=torch.float64, device=image.device)
     counts = torch.empty(20, dtype=torch.int32, device=image.device)
-    ws = torch.empty(4, dtype=torch.int64, device=image.device)
+    ws = torch.empty(32, dtype=torch.int64, device=image.device)
     _lib.check(lib.shg_flood_stats_lerp_f64(image.contiguous().data_ptr(), blurred.contiguous().data_ptr(), image.numel(),
                                             order_stats.data_ptr(), float(gamma), stats.data_ptr(), counts.data_ptr(), ws.data_ptr(),
                                             _stream()), 'shg_flood_stats_lerp_f64')
