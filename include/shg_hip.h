@@ -102,6 +102,12 @@ int shg_unpack_dib_frames(const uint8_t* raw, int64_t n_frames, int64_t raw_pitc
 int shg_finalize_mean_max(const uint64_t* sum, const uint16_t* max_raw, int64_t n_total,
                           int64_t height, int64_t width, int bytes_per_px,
                           uint16_t* mean_out, uint16_t* max_out, shg_stream_t stream);
+/* compute_mean_max (solex_util.py:174-188) for a scan that is whole on this GPU: pass A, then mean and max images straight
+ * from its per-slab partials (shg_accumulate_sum_max + shg_finalize_mean_max without the 64-bit totals in between).
+ * workspace: shg_accumulate_workspace_bytes. */
+int shg_accumulate_mean_max(const void* stack, int64_t n_frames, int64_t height, int64_t width, int bytes_per_px,
+                            int64_t frame_stride_px, uint16_t* mean_out, uint16_t* max_out, void* workspace,
+                            size_t workspace_bytes, shg_stream_t stream);
 
 /* ---- cv2.blur(img_u16, (kw, kh)) ------------- solex_util.py:166, 230
  * Normalised box filter, anchor (kw/2, kh/2), BORDER_REFLECT_101, round half even.

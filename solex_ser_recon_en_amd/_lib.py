@@ -40,6 +40,7 @@ SIGNATURES = {
     'shg_upload_frames': (c_int, [P, c_int64, P, c_int64, c_int64, P]),
     'shg_unpack_dib_frames': (c_int, [P, c_int64, c_int64, c_int64, c_int64, c_int, c_int64, c_int, P, P, c_int64, P]),
     'shg_finalize_mean_max': (c_int, [P, P, c_int64, c_int64, c_int64, c_int, P, P, P]),
+    'shg_accumulate_mean_max': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int64, P, P, P, c_size_t, P]),
     'shg_box_blur_u16': (c_int, [P, c_int64, c_int64, c_int, c_int, P, P, P]),
     'shg_row_argmin_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int64, P, P]),
     'shg_row_mean_u16': (c_int, [P, c_int64, c_int64, P, P]),

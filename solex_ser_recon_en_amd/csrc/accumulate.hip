@@ -250,10 +250,33 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const uint32_t* __restr
     max_out[i] = (uint16_t)m;
 }
 
+// Where the finalising kernels take a pixel's total and maximum from: the reduced arrays (a sharded scan: after the
+// all-reduce) or pass A's per-slab partials directly (one launch and one array round trip less for a scan on one GPU).
+struct FromSums {
+    const uint64_t* sum;
+    const uint16_t* mx;
+    __device__ __forceinline__ void get(int64_t i, uint64_t& s, uint32_t& m) const { s = sum[i]; m = mx[i]; }
+};
+struct FromPartials {
+    const uint32_t* psum;
+    const uint16_t* pmax;
+    int nsplit;
+    int64_t npix;
+    __device__ __forceinline__ void get(int64_t i, uint64_t& s, uint32_t& m) const {
+        s = 0;
+        m = 0;
+        for (int j = 0; j < nsplit; ++j) {
+            s += psum[(int64_t)j * npix + i];
+            const uint32_t v = pmax[(int64_t)j * npix + i];
+            m = m > v ? m : v;
+        }
+    }
+};
+
 // mean = sum // n (== trunc(float64(sum)/n) for sums < 2^53, solex_util.py:188), x256 for 8-bit
 // (video_reader.py:121-122), rotated: out[y][x] = in[x][W-1-y] when W > H (video_reader.py:119-120).
-__global__ __launch_bounds__(256) void k_finalize(const uint64_t* __restrict__ sum, const uint16_t* __restrict__ mx,
-                                                  uint64_t n_total, int64_t height, int64_t width, int scale,
+template <typename Src>
+__global__ __launch_bounds__(256) void k_finalize(Src in, uint64_t n_total, int64_t height, int64_t width, int scale,
                                                   uint16_t* __restrict__ mean_out, uint16_t* __restrict__ max_out) {
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= height * width) return;
@@ -265,15 +288,18 @@ __global__ __launch_bounds__(256) void k_finalize(const uint64_t* __restrict__ s
     } else {
         src = o;
     }
-    mean_out[o] = (uint16_t)((sum[src] * (uint64_t)scale) / n_total);
-    max_out[o] = (uint16_t)(mx[src] * scale);
+    uint64_t sv;
+    uint32_t mv;
+    in.get(src, sv, mv);
+    mean_out[o] = (uint16_t)((sv * (uint64_t)scale) / n_total);
+    max_out[o] = (uint16_t)(mv * scale);
 }
 
 // The rotated case through a 32 x 32 LDS tile: the plain kernel reads `sum` along file columns (one 8-byte value per 16 KB
 // of addresses: 15.6 MB fetched for a 4 MB input at C2, PMC round 1).  Here a workgroup reads 32 file rows x 32 file
 // columns row-wise (256-byte runs) and writes 32 output rows x 32 output columns row-wise.
-__global__ __launch_bounds__(256) void k_finalize_rot(const uint64_t* __restrict__ sum, const uint16_t* __restrict__ mx,
-                                                      uint64_t n_total, int64_t height, int64_t width, int scale,
+template <typename Src>
+__global__ __launch_bounds__(256) void k_finalize_rot(Src in, uint64_t n_total, int64_t height, int64_t width, int scale,
                                                       uint16_t* __restrict__ mean_out, uint16_t* __restrict__ max_out) {
     __shared__ uint16_t tm[32][33], tx[32][33];
     const int64_t fx0 = (int64_t)blockIdx.x * 32;          // file column block  (slit rows y = W-1-fx, descending)
@@ -282,9 +308,11 @@ __global__ __launch_bounds__(256) void k_finalize_rot(const uint64_t* __restrict
     for (int r = ty_; r < 32; r += 8) {
         const int64_t fy = fy0 + r, fx = fx0 + tx_;
         if (fy < height && fx < width) {
-            const int64_t src = fy * width + fx;
-            tm[r][tx_] = (uint16_t)((sum[src] * (uint64_t)scale) / n_total);
-            tx[r][tx_] = (uint16_t)(mx[src] * scale);
+            uint64_t sv;
+            uint32_t mv;
+            in.get(fy * width + fx, sv, mv);
+            tm[r][tx_] = (uint16_t)((sv * (uint64_t)scale) / n_total);
+            tx[r][tx_] = (uint16_t)(mv * scale);
         }
     }
     __syncthreads();
@@ -331,10 +359,11 @@ extern "C" size_t shg_accumulate_workspace_bytes(int64_t n_frames, int64_t heigh
     return slab_bytes(make_plan(nullptr, n_frames, height, width, bytes_per_px, 0));
 }
 
-extern "C" int shg_accumulate_sum_max(const void* stack, int64_t n_frames, int64_t height, int64_t width,
-                                      int bytes_per_px, int64_t frame_stride_px, uint64_t* sum_out, uint16_t* max_out,
-                                      void* workspace, size_t workspace_bytes, shg_stream_t stream) {
-    SHG_REQUIRE(stack && sum_out && max_out && workspace, SHG_E_ARG, "shg_accumulate_sum_max: null pointer");
+namespace {
+// pass A into the per-slab partials at the head of `workspace`: psum u32 [nsplit][npix], pmax u16 [nsplit][npix]
+int accumulate_partials(const void* stack, int64_t n_frames, int64_t height, int64_t width, int bytes_per_px, int64_t frame_stride_px,
+                        void* workspace, size_t workspace_bytes, shg_stream_t stream, Plan* plan_out, uint32_t** psum_out, uint16_t** pmax_out) {
+    SHG_REQUIRE(stack && workspace, SHG_E_ARG, "shg_accumulate_sum_max: null pointer");
     SHG_REQUIRE(n_frames > 0 && height > 0 && width > 0, SHG_E_ARG, "shg_accumulate_sum_max: empty stack (%lld x %lld x %lld)",
                 (long long)n_frames, (long long)height, (long long)width);
     SHG_REQUIRE(bytes_per_px == 1 || bytes_per_px == 2, SHG_E_ARG, "shg_accumulate_sum_max: bytes_per_px must be 1 or 2");
@@ -362,9 +391,48 @@ extern "C" int shg_accumulate_sum_max(const void* stack, int64_t n_frames, int64
         else
             { SHG_PROF("accumulate", st); k_accumulate_scalar<uint8_t><<<grid, 256, 0, st>>>(static_cast<const uint8_t*>(stack), p.npix, p.stride_px, n, p.frames_per_split, psum, pmax); }
     }
-    if (int e = shg::check_launch("k_accumulate")) return e;
+    *plan_out = p;
+    *psum_out = psum;
+    *pmax_out = pmax;
+    return shg::check_launch("k_accumulate");
+}
+
+template <typename Src>
+int launch_finalize(Src in, int64_t n_total, int64_t height, int64_t width, int bytes_per_px, uint16_t* mean_out, uint16_t* max_out, hipStream_t st) {
+    SHG_PROF("finalize", st);
+    const int scale = bytes_per_px == 1 ? 256 : 1;
+    if (width > height) {
+        dim3 grid((unsigned)((width + 31) / 32), (unsigned)((height + 31) / 32));
+        k_finalize_rot<Src><<<grid, 256, 0, st>>>(in, (uint64_t)n_total, height, width, scale, mean_out, max_out);
+    } else {
+        k_finalize<Src><<<(unsigned)((height * width + 255) / 256), 256, 0, st>>>(in, (uint64_t)n_total, height, width, scale, mean_out, max_out);
+    }
+    return shg::check_launch("k_finalize");
+}
+}  // namespace
+
+extern "C" int shg_accumulate_sum_max(const void* stack, int64_t n_frames, int64_t height, int64_t width,
+                                      int bytes_per_px, int64_t frame_stride_px, uint64_t* sum_out, uint16_t* max_out,
+                                      void* workspace, size_t workspace_bytes, shg_stream_t stream) {
+    SHG_REQUIRE(sum_out && max_out, SHG_E_ARG, "shg_accumulate_sum_max: null pointer");
+    Plan p;
+    uint32_t* psum;
+    uint16_t* pmax;
+    if (int e = accumulate_partials(stack, n_frames, height, width, bytes_per_px, frame_stride_px, workspace, workspace_bytes, stream, &p, &psum, &pmax)) return e;
+    hipStream_t st = shg::as_stream(stream);
     { SHG_PROF("reduce_partials", st); k_reduce_partials<<<(unsigned)((p.npix + 255) / 256), 256, 0, st>>>(psum, pmax, p.nsplit, p.npix, sum_out, max_out); }
     return shg::check_launch("k_reduce_partials");
+}
+
+extern "C" int shg_accumulate_mean_max(const void* stack, int64_t n_frames, int64_t height, int64_t width, int bytes_per_px,
+                                       int64_t frame_stride_px, uint16_t* mean_out, uint16_t* max_out, void* workspace,
+                                       size_t workspace_bytes, shg_stream_t stream) {
+    SHG_REQUIRE(mean_out && max_out, SHG_E_ARG, "shg_accumulate_mean_max: null pointer");
+    Plan p;
+    uint32_t* psum;
+    uint16_t* pmax;
+    if (int e = accumulate_partials(stack, n_frames, height, width, bytes_per_px, frame_stride_px, workspace, workspace_bytes, stream, &p, &psum, &pmax)) return e;
+    return launch_finalize(FromPartials{psum, pmax, p.nsplit, p.npix}, n_frames, height, width, bytes_per_px, mean_out, max_out, shg::as_stream(stream));
 }
 
 extern "C" int shg_finalize_mean_max(const uint64_t* sum, const uint16_t* max_raw, int64_t n_total,
@@ -373,14 +441,5 @@ extern "C" int shg_finalize_mean_max(const uint64_t* sum, const uint16_t* max_ra
     SHG_REQUIRE(sum && max_raw && mean_out && max_out, SHG_E_ARG, "shg_finalize_mean_max: null pointer");
     SHG_REQUIRE(n_total > 0 && height > 0 && width > 0, SHG_E_ARG, "shg_finalize_mean_max: bad size");
     SHG_REQUIRE(bytes_per_px == 1 || bytes_per_px == 2, SHG_E_ARG, "shg_finalize_mean_max: bytes_per_px must be 1 or 2");
-    const int64_t npix = height * width;
-    hipStream_t st = shg::as_stream(stream);
-    SHG_PROF("finalize", st);
-    if (width > height) {
-        dim3 grid((unsigned)((width + 31) / 32), (unsigned)((height + 31) / 32));
-        k_finalize_rot<<<grid, 256, 0, st>>>(sum, max_raw, (uint64_t)n_total, height, width, bytes_per_px == 1 ? 256 : 1, mean_out, max_out);
-    } else {
-        k_finalize<<<(unsigned)((npix + 255) / 256), 256, 0, st>>>(sum, max_raw, (uint64_t)n_total, height, width, bytes_per_px == 1 ? 256 : 1, mean_out, max_out);
-    }
-    return shg::check_launch("k_finalize");
+    return launch_finalize(FromSums{sum, max_raw}, n_total, height, width, bytes_per_px, mean_out, max_out, shg::as_stream(stream));
 }

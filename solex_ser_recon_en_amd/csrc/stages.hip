@@ -160,11 +160,11 @@ extern "C" int shg_stage_mean_fit(const void* stack, int64_t n_frames, int64_t h
     traces = stg.on_device(h_traces);                                                         // kernels store them where it looks
 
     if (!sum_in) {                                                                            // solex_util.py:174-188
-        STAGE_TRY(shg_accumulate_sum_max(stack, n_frames, height, width, bytes_per_px, frame_stride_px, sum, mx, acc_ws, acc_bytes, stream));
-        sum_in = sum;
-        max_in = mx;
+        SHG_REQUIRE(n_total == n_frames, SHG_E_ARG, "shg_stage_mean_fit: n_total %lld != %lld frames of the stack", (long long)n_total, (long long)n_frames);
+        STAGE_TRY(shg_accumulate_mean_max(stack, n_frames, height, width, bytes_per_px, frame_stride_px, mean_out, max_out, acc_ws, acc_bytes, stream));
+    } else {
+        STAGE_TRY(shg_finalize_mean_max(sum_in, max_in, n_total, height, width, bytes_per_px, mean_out, max_out, stream));
     }
-    STAGE_TRY(shg_finalize_mean_max(sum_in, max_in, n_total, height, width, bytes_per_px, mean_out, max_out, stream));
     // detect_bord(max_img, axis=1) (:223, :165-172)
     if (shg_blur_fits_fused(iw, 5)) {
         STAGE_TRY(shg_blur_row_mean_u16(max_out, ih, iw, 5, 5, row_means, stream));

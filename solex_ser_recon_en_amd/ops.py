@@ -90,6 +90,22 @@ def accumulate_sum_max(stack, workspace=None):
     return total, mx
 
 
+def accumulate_mean_max(stack, workspace=None):
+    """compute_mean_max for a stack that is whole on this GPU -> (mean uint16 [ih, iw], max uint16 [ih, iw]):
+    pass A and the division / rotation straight from its per-slab partials."""
+    n, h, w, bpp = stack_geometry(stack)
+    dev = stack.device
+    need = lib.shg_accumulate_workspace_bytes(n, h, w, bpp)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    ih, iw = (w, h) if w > h else (h, w)
+    mean = torch.empty((ih, iw), dtype=torch.uint16, device=dev)
+    mout = torch.empty((ih, iw), dtype=torch.uint16, device=dev)
+    _lib.check(lib.shg_accumulate_mean_max(stack.data_ptr(), n, h, w, bpp, frame_stride(stack), mean.data_ptr(), mout.data_ptr(),
+                                           workspace.data_ptr(), workspace.numel(), _stream()), 'shg_accumulate_mean_max')
+    return mean, mout
+
+
 def finalize_mean_max(total, mx, n_total, height, width, bpp):
     """-> (mean uint16 [ih, iw], max uint16 [ih, iw]) in the reference's orientation."""
     _dev(total, 'sum')

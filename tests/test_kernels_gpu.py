@@ -46,6 +46,9 @@ def test_mean_max_golden(ops, golden, tag):
     np.testing.assert_array_equal(host(mean), g[tag + '_mean'])
     np.testing.assert_array_equal(host(mxo), g[tag + '_max'])
     np.testing.assert_array_equal(host(total), frames.astype(np.int64).sum(0).ravel())
+    mean1, max1 = ops.accumulate_mean_max(dev(frames))          # the one-GPU form: no 64-bit totals in between
+    np.testing.assert_array_equal(host(mean1), g[tag + '_mean'])
+    np.testing.assert_array_equal(host(max1), g[tag + '_max'])
 
 
 @pytest.mark.parametrize('shape,dtype', [((300, 24, 160), np.uint16), ((257, 160, 24), np.uint16),
@@ -61,6 +64,9 @@ def test_mean_max_oracle_random(ops, orc, shape, dtype):
     ref_mean, ref_max = orc.compute_mean_max(orc.SerReader(frames))
     np.testing.assert_array_equal(host(mean), ref_mean)
     np.testing.assert_array_equal(host(mxo), ref_max)
+    mean1, max1 = ops.accumulate_mean_max(dev(frames))
+    np.testing.assert_array_equal(host(mean1), ref_mean)
+    np.testing.assert_array_equal(host(max1), ref_max)
 
 
 def test_mean_max_sharding_is_bit_identical(ops):
