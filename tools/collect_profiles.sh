@@ -31,4 +31,4 @@ cd $R
 python3 tools/kernel_table.py gpurun_out/${TAG}_step_trace 20 > gpurun_out/${TAG}_step_kernel_table.txt
 python3 tools/kernel_table.py gpurun_out/${TAG}_step_trace_c4 10 > gpurun_out/${TAG}_step_kernel_table_c4.txt
 python3 tools/kernel_table.py gpurun_out/${TAG}_step_trace_c5 10 > gpurun_out/${TAG}_step_kernel_table_c5.txt
-tail -1 gpurun_out/${TAG}_step_kernel_table*.txt
+for f in gpurun_out/${TAG}_step_kernel_table*.txt; do tail -n 1 $f; done

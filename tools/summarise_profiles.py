@@ -1,4 +1,5 @@
-"""gpurun_out/<tag>_* (tools/collect_profiles.sh) -> profiles/<tag>_* summaries and profiles/traffic.json."""
+"""gpurun_out/<tag>_* (tools/collect_profiles.sh) -> profiles/<tag>_* summaries, profiles/traffic.json and
+profiles/<tag>_numbers.txt (what this script prints: the figures DESIGN.md / profiles/README.md quote)."""
 import collections
 import csv
 import glob
@@ -8,6 +9,14 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+_lines = []
+
+
+def say(*a):
+    line = ' '.join(str(x) for x in a)
+    _lines.append(line)
+    print(line)
+
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go, pr = os.path.join(root, 'gpurun_out'), os.path.join(root, 'profiles')
 
@@ -65,21 +74,26 @@ for suffix, key, what in (('', '2000x2000x200x16', 'bench.py --workers 1'), ('_c
                         'source': 'profiles/%s_pmc_fetch_write_per_kernel%s.json (%s): 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE '
                                   'half-count correction), separate rocprofv3 --pmc passes; PMC counters cannot be read from inside the '
                                   'process, so bench.py quotes this file' % (tag, suffix, what)}
-        print(key, 'traffic per launch', t)
+        say(key, 'pass A HBM traffic per launch (PMC)', t, 'bytes')
 json.dump(traffic, open(os.path.join(pr, 'traffic.json'), 'w'), indent=1)
 for which in ('', '_w1'):
     for r in csv.DictReader(open(os.path.join(pr, tag + '_bench%s_kernel_stats.csv' % which))):
         if 'k_accumulate' in r['Name'] or 'k_extract' in r['Name']:
-            print(which or 'default', r['Name'][:60], 'calls', r['Calls'], 'avg_ns', r['AverageNs'])
+            say('rocprofv3 --stats, bench %s:' % ('--workers 1' if which else '(4 workers)'), r['Name'].split('::')[-1][:40], 'calls', r['Calls'], 'avg_ns', r['AverageNs'])
 for name in ('bench', 'bench_driver_flags', 'bench_w1', 'bench_c1', 'bench_c3_one_gpu', 'bench_c4', 'bench_c5_per_gpu', 'bench_u8', 'bench_n500'):
     p = os.path.join(pr, '%s_%s.json' % (tag, name))
     if os.path.exists(p) and os.path.getsize(p):
         d = json.load(open(p))
         r = d['roofline']
-        print('%-20s %10.0f f/s  %.3f ms/step  kernels %.3f ms  busy %.2f  passA in-flight %.0f GB/s (%.3f ms)  uncontended %.0f GB/s (%.3f ms)  extract %.1f us' % (
+        say('%-20s %10.0f f/s  %.3f ms/step  kernels %.3f ms  busy %.2f  passA in-flight %.0f GB/s (%.3f ms)  uncontended %.0f GB/s (%.3f ms)  extract %.1f us' % (
             name, d['value'], d['ms_per_step'], d['kernel_ms_per_step'], d['gpu_busy_frac'], r['achieved'], r['avg_launch_ms'],
             r['uncontended']['achieved'], r['uncontended']['avg_launch_ms'], r['secondary']['uncontended_avg_launch_ms'] * 1e3))
         if d.get('e2e'):
-            print('   e2e', d['e2e']['value'], 'f/s', d['e2e']['host_to_device_GBps_per_gpu'], 'GB/s;  c3', d['sharded_c3']['value'], 'f/s', d['sharded_c3']['ms_per_scan'], 'ms/scan')
+            say('   e2e', d['e2e']['value'], 'f/s', d['e2e']['host_to_device_GBps_per_gpu'], 'GB/s;  c3', d['sharded_c3']['value'], 'f/s', d['sharded_c3']['ms_per_scan'], 'ms/scan')
         if d.get('cpu_baseline'):
-            print('   cpu', d['cpu_baseline']['value'], d['cpu_baseline'].get('parity_vs_gpu'))
+            say('   cpu', d['cpu_baseline']['value'], d['cpu_baseline'].get('parity_vs_gpu'))
+for name in ('step_kernel_table', 'step_kernel_table_c4', 'step_kernel_table_c5'):
+    f = os.path.join(pr, '%s_%s.txt' % (tag, name))
+    if os.path.exists(f):
+        say(name, open(f).read().strip().splitlines()[-1])
+open(os.path.join(pr, tag + '_numbers.txt'), 'w').write('\n'.join(_lines) + '\n')
