@@ -52,7 +52,7 @@ def _sizes(tag, fn, *args):
 
 
 def _p(a):
-    return a.ctypes.data_as(ctypes.c_void_p)
+    return a.ctypes.data          # (an int is accepted for a void* argument; data_as builds a ctypes object: twice the time)
 
 
 # ---- compute_mean_return_fit ----------------------------------------------------------------------------

@@ -18,6 +18,8 @@ stack = synth.synth_frames_torch(2000, 2000, 200, 16, seed=0, padded=True)
 torch.cuda.synchronize()
 
 acc = {}
+gaps = None
+last = [0.0]
 
 
 class Timed:
@@ -27,10 +29,16 @@ class Timed:
     def __call__(self, *a):
         t = time.perf_counter()
         r = self.fn(*a)
-        d = time.perf_counter() - t
+        t1 = time.perf_counter()
+        d = t1 - t
         e = acc.setdefault(self.name, [0.0, 0])
         e[0] += d
         e[1] += 1
+        if gaps is not None and self.name.startswith(('shg_stage', 'shg_warp')):
+            g = gaps.setdefault('before ' + self.name, [0.0, 0])
+            g[0] += t - last[0]
+            g[1] += 1
+            last[0] = t1
         return r
 
 
@@ -65,9 +73,14 @@ def run(n):
 
 run(5)
 acc.clear()
+gaps = {}
 t0 = time.perf_counter()
+last[0] = t0
 run(steps)
 wall = time.perf_counter() - t0
+for k, v in gaps.items():
+    print('  Python %-42s %7.1f us/scan' % (k, v[0] / steps * 1e6))
+gaps = None
 in_c = sum(v[0] for v in acc.values())
 print('wall %.3f ms per scan; inside C calls %.3f ms; Python (interpreter lock held) %.3f ms' % (
     wall / steps * 1e3, in_c / steps * 1e3, (wall - in_c) / steps * 1e3))
