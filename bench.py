@@ -234,6 +234,7 @@ def main():
     walk, walk_shape = _ops.stream_read_ceiling(flat, mode=2, vecs_per_frame=pitch_bytes // 16) if pitch_bytes % 16 == 0 else (0.0, None)
     roofline = {'kernel': 'k_accumulate_vec (pass A: sum+max over frames)', 'bound': 'hbm',
                 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
+                'frac_uncontended': round(ach1 / HBM_PEAK_GBS, 4),      # the kernel by itself (= rocprofv3 of bench.py --workers 1)
                 'traffic': traffic, 'traffic_from': traffic_from,
                 'algorithmic_bytes_per_launch': bytes_a, 'frame_pitch_bytes': pitch_bytes,
                 'avg_launch_ms': round(acc_ms / acc_n, 5) if acc_n else None, 'launches': acc_n,

@@ -15,6 +15,9 @@
 namespace {
 
 constexpr int HIST16 = 65536;
+// Workgroups flush their select histograms into one of SEL_SLOTS copies (blockIdx % SEL_SLOTS): ~500 workgroups adding to
+// the same 256 addresses queue up behind each other in the memory-side atomic units; readers add the copies up.
+constexpr int SEL_SLOTS = 8;
 constexpr int SLICE_PX = 32768;        // pixels per workgroup (< 65536 so that u16 counters cannot wrap)
 
 // pixel (ty, tx, i) -> source coordinates with the bottom/right REFLECT_101 extension
@@ -443,67 +446,99 @@ __global__ __launch_bounds__(256) void k_clahe_interp(const T* __restrict__ img,
 // of its LUT reads: four 2-byte gathers per pixel, each lane of each one in a cache line of its own (neighbouring
 // pixels differ by more than the 32 values a line holds), 16.8 M line requests per image, 18 us.  Value-major, a
 // pixel's four entries share a line; with the reference's 2 x 2 grid they are one aligned 8-byte word.
-// PX pixels per lane (4: rows 8-byte aligned, one 8-byte load and store).
-template <int PX>
+// PX pixels per lane (4: rows 8-byte aligned, one 8-byte load and store); a workgroup takes `rows` image rows.
+// COUNT: also the first pass of the order statistics that follow (np.percentile(cl1, 10), np.max(cl1)) -- the histogram
+// of the high bytes of the pixels it has just produced, in sel_hist's slot layout (k_select16_pass, pass 0): the values
+// are in registers here, which saves that pass its read of the image.
+template <int PX, bool COUNT>
 __global__ __launch_bounds__(256) void k_clahe_interp_vm(const uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch,
                                                          int tiles, float inv_tw, float inv_th,
-                                                         const uint16_t* __restrict__ lut, uint16_t* __restrict__ dst, int64_t dst_pitch) {
+                                                         const uint16_t* __restrict__ lut, uint16_t* __restrict__ dst, int64_t dst_pitch,
+                                                         int rows, uint32_t* __restrict__ sel_hist, int sel_stride) {
     constexpr int HIST = 65536;
+    constexpr int COPIES = 8;                            // interleaved copies of each bin: a row's pixels crowd a few bins
+    __shared__ uint32_t lh[COUNT ? 256 * COPIES : 1];
+    if (COUNT) {
+        for (int i = threadIdx.x; i < 256 * COPIES; i += 256) lh[i] = 0;
+        __syncthreads();
+    }
     const int64_t x0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * PX;
-    const int64_t y = blockIdx.y;
-    if (x0 >= w) return;
     const int ntiles = tiles * tiles;
-    const float tyf = (float)(int)y * inv_th - 0.5f;
-    int ty1 = (int)floorf(tyf);
-    int ty2 = ty1 + 1;
-    const float ya = tyf - (float)ty1;
-    const float ya1 = 1.0f - ya;
-    ty1 = max(ty1, 0);
-    ty2 = min(ty2, tiles - 1);
-    const int n = (int)min((int64_t)PX, w - x0);
-    uint32_t px[PX];
-    if (PX == 4 && n == 4) {
-        const uint2 q = *reinterpret_cast<const uint2*>(img + y * pitch + x0);
-        px[0] = q.x & 0xffffu; px[1 % PX] = q.x >> 16; px[2 % PX] = q.y & 0xffffu; px[3 % PX] = q.y >> 16;
-    } else {
-#pragma unroll
-        for (int j = 0; j < PX; ++j) px[j] = j < n ? img[y * pitch + x0 + j] : 0;
-    }
-    uint32_t out[PX];
-#pragma unroll
-    for (int j = 0; j < PX; ++j) {
-        const float txf = (float)(int)(x0 + j) * inv_tw - 0.5f;
-        int tx1 = (int)floorf(txf);
-        int tx2 = tx1 + 1;
-        const float xa = txf - (float)tx1;
-        const float xa1 = 1.0f - xa;
-        tx1 = max(tx1, 0);
-        tx2 = min(tx2, tiles - 1);
-        const uint16_t* e = lut + (int64_t)px[j] * ntiles;
-        uint32_t l11, l12, l21, l22;
-        if (tiles == 2) {
-            const uint2 q = *reinterpret_cast<const uint2*>(e);
-            const uint64_t four = (uint64_t)q.x | ((uint64_t)q.y << 32);
-            l11 = (uint32_t)(four >> (16 * (ty1 * 2 + tx1))) & 0xffffu;
-            l12 = (uint32_t)(four >> (16 * (ty1 * 2 + tx2))) & 0xffffu;
-            l21 = (uint32_t)(four >> (16 * (ty2 * 2 + tx1))) & 0xffffu;
-            l22 = (uint32_t)(four >> (16 * (ty2 * 2 + tx2))) & 0xffffu;
+    const int n = x0 < w ? (int)min((int64_t)PX, w - x0) : 0;
+    const int copy = threadIdx.x & (COPIES - 1);
+    for (int64_t y = (int64_t)blockIdx.y * rows; y < min(h, ((int64_t)blockIdx.y + 1) * rows) && n > 0; ++y) {
+        const float tyf = (float)(int)y * inv_th - 0.5f;
+        int ty1 = (int)floorf(tyf);
+        int ty2 = ty1 + 1;
+        const float ya = tyf - (float)ty1;
+        const float ya1 = 1.0f - ya;
+        ty1 = max(ty1, 0);
+        ty2 = min(ty2, tiles - 1);
+        uint32_t px[PX];
+        if (PX == 4 && n == 4) {
+            const uint2 q = *reinterpret_cast<const uint2*>(img + y * pitch + x0);
+            px[0] = q.x & 0xffffu; px[1 % PX] = q.x >> 16; px[2 % PX] = q.y & 0xffffu; px[3 % PX] = q.y >> 16;
         } else {
-            l11 = e[ty1 * tiles + tx1];
-            l12 = e[ty1 * tiles + tx2];
-            l21 = e[ty2 * tiles + tx1];
-            l22 = e[ty2 * tiles + tx2];
-        }
-        const float res = ((float)(int)l11 * xa1 + (float)(int)l12 * xa) * ya1 + ((float)(int)l21 * xa1 + (float)(int)l22 * xa) * ya;
-        const int r = __float2int_rn(res);
-        out[j] = (uint32_t)(r < 0 ? 0 : (r > HIST - 1 ? HIST - 1 : r));
-    }
-    if (PX == 4 && n == 4) {
-        *reinterpret_cast<uint2*>(dst + y * dst_pitch + x0) = make_uint2(out[0] | (out[1 % PX] << 16), out[2 % PX] | (out[3 % PX] << 16));
-    } else {
 #pragma unroll
-        for (int j = 0; j < PX; ++j)
-            if (j < n) dst[y * dst_pitch + x0 + j] = (uint16_t)out[j];
+            for (int j = 0; j < PX; ++j) px[j] = j < n ? img[y * pitch + x0 + j] : 0;
+        }
+        uint32_t out[PX];
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const float txf = (float)(int)(x0 + j) * inv_tw - 0.5f;
+            int tx1 = (int)floorf(txf);
+            int tx2 = tx1 + 1;
+            const float xa = txf - (float)tx1;
+            const float xa1 = 1.0f - xa;
+            tx1 = max(tx1, 0);
+            tx2 = min(tx2, tiles - 1);
+            const uint16_t* e = lut + (int64_t)px[j] * ntiles;
+            uint32_t l11, l12, l21, l22;
+            if (tiles == 2) {
+                const uint2 q = *reinterpret_cast<const uint2*>(e);
+                const uint64_t four = (uint64_t)q.x | ((uint64_t)q.y << 32);
+                l11 = (uint32_t)(four >> (16 * (ty1 * 2 + tx1))) & 0xffffu;
+                l12 = (uint32_t)(four >> (16 * (ty1 * 2 + tx2))) & 0xffffu;
+                l21 = (uint32_t)(four >> (16 * (ty2 * 2 + tx1))) & 0xffffu;
+                l22 = (uint32_t)(four >> (16 * (ty2 * 2 + tx2))) & 0xffffu;
+            } else {
+                l11 = e[ty1 * tiles + tx1];
+                l12 = e[ty1 * tiles + tx2];
+                l21 = e[ty2 * tiles + tx1];
+                l22 = e[ty2 * tiles + tx2];
+            }
+            const float res = ((float)(int)l11 * xa1 + (float)(int)l12 * xa) * ya1 + ((float)(int)l21 * xa1 + (float)(int)l22 * xa) * ya;
+            const int r = __float2int_rn(res);
+            out[j] = (uint32_t)(r < 0 ? 0 : (r > HIST - 1 ? HIST - 1 : r));
+        }
+        if (PX == 4 && n == 4) {
+            *reinterpret_cast<uint2*>(dst + y * dst_pitch + x0) = make_uint2(out[0] | (out[1 % PX] << 16), out[2 % PX] | (out[3 % PX] << 16));
+        } else {
+#pragma unroll
+            for (int j = 0; j < PX; ++j)
+                if (j < n) dst[y * dst_pitch + x0 + j] = (uint16_t)out[j];
+        }
+        if (COUNT) {
+            const uint32_t b0 = out[0] >> 8;
+            bool same = n == PX;
+#pragma unroll
+            for (int j = 1; j < PX; ++j) same = same && (out[j] >> 8) == b0;
+            if (same) {                                  // neighbours mostly share their high byte: one atomic for the lane
+                atomicAdd(&lh[b0 * COPIES + copy], (uint32_t)PX);
+            } else {
+#pragma unroll
+                for (int j = 0; j < PX; ++j)
+                    if (j < n) atomicAdd(&lh[(out[j] >> 8) * COPIES + copy], 1u);
+            }
+        }
+    }
+    if (COUNT) {
+        __syncthreads();
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < COPIES; ++k) c += lh[threadIdx.x * COPIES + k];
+        const unsigned slot = (blockIdx.y * gridDim.x + blockIdx.x) % SEL_SLOTS;
+        if (c) atomicAdd(&sel_hist[(int64_t)slot * sel_stride + threadIdx.x], c);
     }
 }
 
@@ -547,10 +582,6 @@ __global__ __launch_bounds__(256) void k_image_hist8(const uint8_t* __restrict__
 // MSB-first radix select on the 16-bit values: pass 0 histograms the high byte, pass 1 the low byte of the
 // pixels whose high byte was chosen.  hist: [n_ranks][2][256] u32, zeroed.  Every workgroup replays pass 0's
 // choice with a workgroup-wide scan (one bin per thread).
-// Workgroups flush their histograms into one of SEL_SLOTS copies (blockIdx % SEL_SLOTS): ~500 workgroups adding to the
-// same 256 addresses queue up behind each other in the memory-side atomic units; readers add the copies up.
-constexpr int SEL_SLOTS = 8;
-
 __device__ __forceinline__ void pick_digit(const uint32_t* __restrict__ hist, int slot_stride, int64_t rank, int& digit, int64_t& below) {
     __shared__ int64_t wave_tot[16];
     __shared__ int64_t chosen[2];
@@ -747,18 +778,27 @@ extern "C" size_t shg_clahe_workspace_bytes(int tiles, int bytes_per_px) {
 }
 
 namespace {
-inline void launch_interp16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, int tiles, float inv_tw, float inv_th,
-                            const uint16_t* lut, bool value_major, uint16_t* dst, int64_t dst_pitch, hipStream_t st) {
+// sel_hist (may be NULL): the zeroed slot histograms of the select that follows on dst; the kernel then counts its first pass
+inline bool launch_interp16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, int tiles, float inv_tw, float inv_th,
+                            const uint16_t* lut, bool value_major, uint16_t* dst, int64_t dst_pitch, uint32_t* sel_hist, int sel_stride,
+                            hipStream_t st) {
     if (!value_major) {
         k_clahe_interp<uint16_t, HIST16><<<dim3((unsigned)((w + 255) / 256), (unsigned)h), 256, 0, st>>>(img, h, w, pitch, tiles, inv_tw, inv_th, lut, dst, dst_pitch);
-        return;
+        return false;
     }
     const bool vec = ((reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(dst)) & 7) == 0 && pitch % 4 == 0 && dst_pitch % 4 == 0;
-    if (vec) {
-        k_clahe_interp_vm<4><<<dim3((unsigned)((w + 1023) / 1024), (unsigned)h), 256, 0, st>>>(img, h, w, pitch, tiles, inv_tw, inv_th, lut, dst, dst_pitch);
-    } else {
-        k_clahe_interp_vm<1><<<dim3((unsigned)((w + 255) / 256), (unsigned)h), 256, 0, st>>>(img, h, w, pitch, tiles, inv_tw, inv_th, lut, dst, dst_pitch);
+    if (vec && sel_hist) {
+        const int rows = 4;                              // per workgroup: amortises the histogram's zeroing and flush
+        k_clahe_interp_vm<4, true><<<dim3((unsigned)((w + 1023) / 1024), (unsigned)((h + rows - 1) / rows)), 256, 0, st>>>(
+            img, h, w, pitch, tiles, inv_tw, inv_th, lut, dst, dst_pitch, rows, sel_hist, sel_stride);
+        return true;
     }
+    if (vec) {
+        k_clahe_interp_vm<4, false><<<dim3((unsigned)((w + 1023) / 1024), (unsigned)h), 256, 0, st>>>(img, h, w, pitch, tiles, inv_tw, inv_th, lut, dst, dst_pitch, 1, nullptr, 0);
+    } else {
+        k_clahe_interp_vm<1, false><<<dim3((unsigned)((w + 255) / 256), (unsigned)h), 256, 0, st>>>(img, h, w, pitch, tiles, inv_tw, inv_th, lut, dst, dst_pitch, 1, nullptr, 0);
+    }
+    return false;
 }
 
 // tile geometry as OpenCV pads it (copyMakeBorder(0, t - h%t, 0, t - w%t, REFLECT_101), clahe.cpp)
@@ -799,8 +839,10 @@ namespace {
 // chunk_tile_out (may be NULL): where the per-tile 64-bin chunk sums were left, or NULL when the call took the
 // histogram-with-atomics path (small workspace, 8-bit image, clip out of the u16 range).
 int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_per_px, double clip_limit, int tiles,
-               void* dst, int64_t dst_pitch, void* workspace, size_t workspace_bytes, shg_stream_t stream, const uint32_t** chunk_tile_out) {
+               void* dst, int64_t dst_pitch, void* workspace, size_t workspace_bytes, shg_stream_t stream, const uint32_t** chunk_tile_out,
+               uint32_t* sel_hist, int sel_stride, bool* sel_pass0_done) {
     if (chunk_tile_out) *chunk_tile_out = nullptr;
+    if (sel_pass0_done) *sel_pass0_done = false;
     SHG_REQUIRE(img && dst && workspace, SHG_E_ARG, "shg_clahe: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w && dst_pitch >= w, SHG_E_ARG, "shg_clahe: bad image size");
     SHG_REQUIRE(bytes_per_px == 1 || bytes_per_px == 2, SHG_E_ARG, "shg_clahe: bytes_per_px must be 1 or 2");
@@ -841,7 +883,10 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
         if (int e = shg::check_launch("k_hist_reduce")) return e;
         { SHG_PROF("clahe_lut", st); k_tile_lut16_blocks<<<dim3(32, (unsigned)ntiles), 1024, 0, st>>>(hist, se, clip, lut_scale, lut); }
         if (int e = shg::check_launch("k_tile_lut16_blocks")) return e;
-        { SHG_PROF("clahe_interp", st); launch_interp16(static_cast<const uint16_t*>(img), h, w, pitch, tiles, inv_tw, inv_th, lut, true, static_cast<uint16_t*>(dst), dst_pitch, st); }
+        { SHG_PROF("clahe_interp", st);
+          const bool counted = launch_interp16(static_cast<const uint16_t*>(img), h, w, pitch, tiles, inv_tw, inv_th, lut, true, static_cast<uint16_t*>(dst), dst_pitch,
+                                               sel_hist, sel_stride, st);
+          if (sel_pass0_done) *sel_pass0_done = counted; }
         if (chunk_tile_out) *chunk_tile_out = chunk_tile;
         return shg::check_launch("k_clahe_interp");
     }
@@ -862,7 +907,7 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
             k_tile_lut<HIST16><<<ntiles, 1024, 0, st>>>(hist, clip, lut_scale, lut);
         }
         if (int e = shg::check_launch("k_tile_lut")) return e;
-        { SHG_PROF("clahe_interp", st); launch_interp16(static_cast<const uint16_t*>(img), h, w, pitch, tiles, inv_tw, inv_th, lut, false, static_cast<uint16_t*>(dst), dst_pitch, st); }
+        { SHG_PROF("clahe_interp", st); launch_interp16(static_cast<const uint16_t*>(img), h, w, pitch, tiles, inv_tw, inv_th, lut, false, static_cast<uint16_t*>(dst), dst_pitch, nullptr, 0, st); }
     } else {
         int64_t hb = (area + 4095) / 4096;
         if (hb > 256) hb = 256;
@@ -880,7 +925,7 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
 
 extern "C" int shg_clahe(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_per_px, double clip_limit, int tiles,
                          void* dst, int64_t dst_pitch, void* workspace, size_t workspace_bytes, shg_stream_t stream) {
-    return clahe_impl(img, h, w, pitch, bytes_per_px, clip_limit, tiles, dst, dst_pitch, workspace, workspace_bytes, stream, nullptr);
+    return clahe_impl(img, h, w, pitch, bytes_per_px, clip_limit, tiles, dst, dst_pitch, workspace, workspace_bytes, stream, nullptr, nullptr, 0, nullptr);
 }
 
 extern "C" int shg_hist(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_per_px, uint32_t* hist, shg_stream_t stream) {
@@ -910,8 +955,10 @@ extern "C" size_t shg_select_u16_workspace_bytes(int n_ranks) {
     return (size_t)8 * (1 + n_ranks) * 256 * sizeof(uint32_t) + (size_t)n_ranks * sizeof(int64_t);      // SEL_SLOTS histogram copies
 }
 
-extern "C" int shg_select_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, const int64_t* host_ranks, int n_ranks,
-                              double* out, void* workspace, size_t workspace_bytes, shg_stream_t stream) {
+namespace {
+// pass0_done: the slot histograms are zeroed and already hold the high-byte counts (k_clahe_interp_vm<.., true>)
+int select_u16_impl(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, const int64_t* host_ranks, int n_ranks,
+                    double* out, void* workspace, size_t workspace_bytes, shg_stream_t stream, bool zeroed, bool pass0_done) {
     SHG_REQUIRE(img && host_ranks && out && workspace, SHG_E_ARG, "shg_select_u16: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w && n_ranks >= 1 && n_ranks <= 8, SHG_E_ARG, "shg_select_u16: bad sizes");
     SHG_REQUIRE(workspace_bytes >= shg_select_u16_workspace_bytes(n_ranks), SHG_E_WORKSPACE, "shg_select_u16: workspace too small");
@@ -921,8 +968,10 @@ extern "C" int shg_select_u16(const uint16_t* img, int64_t h, int64_t w, int64_t
     uint32_t* hist = static_cast<uint32_t*>(workspace);
     Ranks8 ranks = {};
     for (int i = 0; i < n_ranks; ++i) ranks.v[i] = host_ranks[i];
-    hipError_t e = hipMemsetAsync(hist, 0, (size_t)SEL_SLOTS * (1 + n_ranks) * 256 * sizeof(uint32_t), st);
-    if (e != hipSuccess) { shg::set_error("shg_select_u16: %s", hipGetErrorString(e)); return (int)e; }
+    if (!zeroed) {
+        hipError_t e = hipMemsetAsync(hist, 0, (size_t)SEL_SLOTS * (1 + n_ranks) * 256 * sizeof(uint32_t), st);
+        if (e != hipSuccess) { shg::set_error("shg_select_u16: %s", hipGetErrorString(e)); return (int)e; }
+    }
     // ~8192 pixels per workgroup, at most 1024 workgroups, whole rows each
     // (measured, tools/bench_select.py: 2048 / 4096 / 8192 / 16384 pixels per workgroup -> 92 / 58 / 45 / 44 us for two ranks)
     int64_t want = (h * w + 8191) / 8192;
@@ -930,7 +979,7 @@ extern "C" int shg_select_u16(const uint16_t* img, int64_t h, int64_t w, int64_t
     const unsigned blocks = (unsigned)(h < want ? h : want);
     const int vec_ok = ((reinterpret_cast<uintptr_t>(img) & 15) == 0) && (pitch % 8 == 0);
     SHG_PROF("select_u16", st);
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = pass0_done ? 1 : 0; pass < 2; ++pass) {
         // 512 threads: the zeroing / replay / flush around the pixel loop is shared by twice the waves (256 / 512 / 1024
         // threads: 44.7 / 40.6 / 40.3 us for two ranks, tools/bench_select.py)
         k_select16_pass<<<blocks, 512, 0, st>>>(img, h, w, pitch, pass, ranks, n_ranks, hist, vec_ok);
@@ -938,6 +987,12 @@ extern "C" int shg_select_u16(const uint16_t* img, int64_t h, int64_t w, int64_t
     }
     k_select16_final<<<(unsigned)n_ranks, 256, 0, st>>>(ranks, hist, out);
     return shg::check_launch("k_select16_final");
+}
+}  // namespace
+
+extern "C" int shg_select_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, const int64_t* host_ranks, int n_ranks,
+                              double* out, void* workspace, size_t workspace_bytes, shg_stream_t stream) {
+    return select_u16_impl(img, h, w, pitch, host_ranks, n_ranks, out, workspace, workspace_bytes, stream, false, false);
 }
 
 // ---- image_process in two calls (solex_util.py:527-547) -------------------------------------------------------------
@@ -973,7 +1028,15 @@ extern "C" int shg_contrast_stats_u16(const uint16_t* frame, int64_t h, int64_t 
     // When the tile grid divides the image, CLAHE's tile histograms (still at the head of its workspace) add up to the
     // histogram of the frame: np.percentile(frame, q)'s two order statistics are read off them (k_chunk_sums, k_hist_ranks)
     // instead of selecting over the image again (two passes of k_select16_pass).
-    if (int e = clahe_impl(frame, h, w, pitch, 2, clip_limit, tiles, cl1, cl1_pitch, ws, c, stream, &chunk_tile)) return e;
+    // the select on the CLAHE image (3 ranks): its histograms are zeroed up front so that the interpolation kernel can count
+    // the first pass while the pixels are in its registers
+    uint32_t* sel3 = reinterpret_cast<uint32_t*>(ws + c + s2);
+    {
+        hipError_t e = hipMemsetAsync(sel3, 0, (size_t)SEL_SLOTS * (1 + 3) * 256 * sizeof(uint32_t), shg::as_stream(stream));
+        if (e != hipSuccess) { shg::set_error("shg_contrast_stats_u16: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    bool pass0_done = false;
+    if (int e = clahe_impl(frame, h, w, pitch, 2, clip_limit, tiles, cl1, cl1_pitch, ws, c, stream, &chunk_tile, sel3, (1 + 3) * 256, &pass0_done)) return e;
     if (h % tiles == 0 && w % tiles == 0) {
         const size_t s3r = (shg_select_u16_workspace_bytes(3) + 255) / 256 * 256;
         uint32_t* chunk_sums = reinterpret_cast<uint32_t*>(ws + c + s2 + s3r);
@@ -992,5 +1055,5 @@ extern "C" int shg_contrast_stats_u16(const uint16_t* frame, int64_t h, int64_t 
         }
         if (int e = shg::check_launch("k_hist_ranks")) return e;
     } else if (int e = shg_select_u16(frame, h, w, pitch, ranks_frame2, 2, out5, ws + c, s2, stream)) return e;
-    return shg_select_u16(cl1, h, w, cl1_pitch, ranks_cl13, 3, out5 + 2, ws + c + s2, shg_select_u16_workspace_bytes(3), stream);
+    return select_u16_impl(cl1, h, w, cl1_pitch, ranks_cl13, 3, out5 + 2, sel3, shg_select_u16_workspace_bytes(3), stream, true, pass0_done);
 }
