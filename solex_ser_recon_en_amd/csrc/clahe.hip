@@ -623,12 +623,26 @@ __global__ __launch_bounds__(1024) void k_select16_pass(const uint16_t* __restri
     __shared__ uint32_t lh[8 * 256 * SEL_COPIES1];        // pass 0: [bin][16 copies]; pass 1: [rank][bin][4 copies]
     __shared__ int his_s[8];
     if (pass == 1) {
-        for (int r = 0; r < n_ranks; ++r) {
-            int hi;
-            int64_t below;
-            pick_digit(hist, (1 + n_ranks) * 256, ranks.v[r], hi, below);
-            if (threadIdx.x == 0) his_s[r] = hi;
+        // replay pass 0's choice for every rank: ONE scan of the shared high-byte histogram (a scan per rank was a third of
+        // this kernel's 15 us: every workgroup pays it before its first pixel)
+        __shared__ int64_t wave_tot[16];
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int stride = (1 + n_ranks) * 256;
+        int64_t c = 0;
+        if (tid < 256)
+            for (int k = 0; k < SEL_SLOTS; ++k) c += hist[(int64_t)k * stride + tid];
+        int64_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
         }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        for (int i = 0; i < wave; ++i) incl += wave_tot[i];
+        const int64_t excl = incl - c;
+        for (int r = 0; r < n_ranks; ++r)
+            if (excl <= ranks.v[r] && ranks.v[r] < incl) his_s[r] = tid;
     }
     const int n_words = pass == 0 ? 256 * SEL_COPIES0 : n_ranks * 256 * SEL_COPIES1;
     const int nt = blockDim.x;
