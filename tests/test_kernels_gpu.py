@@ -139,6 +139,35 @@ def test_extract_stage_equals_the_kernel_entry_point_and_the_oracle(ops, orc, n,
     np.testing.assert_array_equal(got, want[:, :, ::-1] if flip else want)
 
 
+def test_stage_refuses_a_staging_area_the_gpu_cannot_address(ops):
+    """The stage composites store host-bound results straight into the staging area and read their plans from it: it has to
+    be page-locked, GPU-mapped memory.  Pageable memory is refused with the reason, nothing is launched."""
+    import ctypes
+    from solex_ser_recon_en_amd import _lib
+    lib = _lib.lib
+    n, h, w = 8, 16, 64
+    frames = dev(np.zeros((n, h, w), dtype=np.uint16))
+    ih = w
+    fit = np.zeros((ih, 4))
+    shifts = np.zeros(1, dtype=np.int32)
+    need = lib.shg_stage_extract_workspace_bytes(h, w, 1)
+    ws = torch.empty(need, dtype=torch.uint8, device='cuda')
+    pageable = np.zeros(need, dtype=np.uint8)
+    out = torch.empty((1, ih, 64), dtype=torch.uint16, device='cuda')
+    rc = lib.shg_stage_extract(frames.data_ptr(), n, h, w, 2, ops.frame_stride(frames), fit.ctypes.data, shifts.ctypes.data, 1,
+                               out.data_ptr(), out.stride(1), out.stride(0), n, 0, 0, None, ws.data_ptr(), need,
+                               pageable.ctypes.data, need, ops._stream())
+    assert rc == -1                                                        # SHG_E_ARG
+    assert b'page-locked' in lib.shg_last_error_string()
+    pinned = torch.empty(need, dtype=torch.uint8).pin_memory()
+    rc = lib.shg_stage_extract(frames.data_ptr(), n, h, w, 2, ops.frame_stride(frames), fit.ctypes.data, shifts.ctypes.data, 1,
+                               out.data_ptr(), out.stride(1), out.stride(0), n, 0, 0, None, ws.data_ptr(), need,
+                               pinned.data_ptr(), need, ops._stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert int(host(out)[0, :, :n].max()) == 0
+
+
 @pytest.mark.parametrize('shape,flip', [((70, 40, 300), False), ((33, 130, 24), True), ((257, 24, 200), False)])
 def test_extract_gathers_the_extrema_the_warp_clips_to(ops, orc, shape, flip):
     """shg_extract_columns_minmax leaves every plane's min / max, and the warp that takes them equals the warp
