@@ -1,7 +1,6 @@
 """Soak for the scan workers: batches of different scans (shapes, depths, options) through 4 workers, every product hashed
 and compared with the one-at-a-time order, round after round.  soak_workers.py [rounds] [workers]"""
 import contextlib
-import hashlib
 import io
 import os
 import random
