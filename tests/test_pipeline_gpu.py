@@ -226,8 +226,9 @@ def test_scan_workers_give_the_serial_products_bit_for_bit(pkg, tmp_path):
                 np.testing.assert_array_equal(cc1, cc2)
                 np.testing.assert_array_equal(p1, p2)
     # a failure in the middle of a pipelined batch: the batch stops and the error of the lowest failing task is raised
-    bad = [(array_reader(sources[0][0]), dict(SHG_MAIN.default_options(), _nolog=True)),
-           (str(tmp_path / 'nope.ser'), dict(SHG_MAIN.default_options(), _nolog=True))] * 3
+    # (a reader per task: a reader gives its stack up once its scan has read it, it cannot serve two scans at once)
+    bad = [task for _ in range(3) for task in ((array_reader(sources[0][0]), dict(SHG_MAIN.default_options(), _nolog=True)),
+                                               (str(tmp_path / 'nope.ser'), dict(SHG_MAIN.default_options(), _nolog=True)))]
     with pytest.raises(Exception, match='nope|No such file'):
         Solex_recon.solex_do_work(bad, True, workers=4)
     torch.cuda.synchronize()
