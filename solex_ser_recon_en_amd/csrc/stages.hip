@@ -13,6 +13,7 @@
 // Solex_recon.solex_do_work really run side by side.  The caller owns every buffer: a device workspace and a
 // pinned host staging area, both sized by the *_bytes queries, and the outputs.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <vector>
@@ -505,7 +506,9 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
             if (have_rows) memcpy(c + y1, corr.data() + i * n, (size_t)n * 8);
         }
         if (host_factors) memcpy(host_factors, h_factors, (size_t)k * h * 8);
-        STAGE_TRY(move_words(factors, stg.on_device(h_factors), (size_t)k * h * 8, st));
+        // k_scale_rows reads one factor per workgroup: straight from the staging area (a copy kernel first: 3.8 us for the launch,
+        // 2.8 us saved in the reader)
+        factors = stg.on_device(h_factors);
         for (int64_t i = 0; i < k; ++i) {
             uint16_t* dst;
             int64_t dpitch;
