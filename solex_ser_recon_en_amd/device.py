@@ -27,10 +27,13 @@ def _cpulist(text):
     return cpus
 
 
-def _l3_groups(node, online, sysfs='/sys'):
-    """The L3 groups (sets of online cpus that share one last-level cache) of a NUMA node, in cpu order."""
+def _l3_groups(node, online, sysfs='/sys', cpus=None):
+    """The L3 groups (sets of online cpus that share one last-level cache) of a NUMA node -- or of the given cpus --
+    in cpu order."""
     groups, seen = [], set()
-    for c in sorted(_cpulist(open('%s/devices/system/node/node%d/cpulist' % (sysfs, node)).read())):
+    if cpus is None:
+        cpus = _cpulist(open('%s/devices/system/node/node%d/cpulist' % (sysfs, node)).read())
+    for c in sorted(cpus):
         if c in seen or c not in online:
             continue
         grp = set(_cpulist(open('%s/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list' % (sysfs, c)).read())) & online
@@ -52,6 +55,24 @@ def _share_of_node(groups, position, n_peers):
     return {'scan': set(mine[0]), 'io': rest or set(mine[0])}
 
 
+def _plan_within(allowed, nodes, pci_ids, index, groups_of_node, groups_of_cpus):
+    """The plan for GPU `index` inside the cpus this process may use.  First choice: the L3 groups of the GPU's NUMA node,
+    shared round-robin with the other GPUs of that node; when none of them is allowed (or the node is unknown), the L3
+    groups of whatever is allowed, shared among all GPUs.  Groups with fewer than four allowed cpus do not count."""
+    node = nodes[index]
+    if node >= 0:
+        groups = [g & allowed for g in groups_of_node(node)]
+        groups = [g for g in groups if len(g) >= 4]
+        if groups:
+            peers = sorted((i for i in range(len(nodes)) if nodes[i] == node), key=lambda i: pci_ids[i])
+            return _share_of_node(groups, peers.index(index), len(peers))
+    groups = [g & allowed for g in groups_of_cpus(allowed)]
+    groups = [g for g in groups if len(g) >= 4]
+    if len(groups) < 2:
+        return None                                          # one group (or less) to choose from: nothing to narrow
+    return _share_of_node(groups, index % len(groups), max(len(nodes), 1))
+
+
 def cpu_plan(device=None):
     """Where this process's threads should run, or None to leave them to the scheduler: {'scan': cpus, 'io': cpus}.
 
@@ -61,8 +82,8 @@ def cpu_plan(device=None):
     (tools/numa_probe.py).  So: 'scan' = one L3 group of the GPU's NUMA node, 'io' = the other L3 groups of this GPU's share
     of the node (decode readers, encoders: memcpy- and deflate-bound, they should not sit on the scan cores).  GPUs that
     share a NUMA node take its L3 groups round-robin in PCI order, so eight ranks on one host do not overlap.
-    Only when the process still has the machine-wide default affinity (numactl / taskset / a batch scheduler win);
-    SHG_CPU_AFFINITY=off disables it, SHG_CPU_AFFINITY=<cpu list> puts every thread kind on those cpus.
+    Always inside the cpus the process is allowed to use (taskset / numactl / a cpuset only get narrowed, and a mask that
+    is one L3 group or less is left alone); SHG_CPU_AFFINITY=off disables it, SHG_CPU_AFFINITY=<cpu list> puts every thread kind on those cpus.
 
     The first call for a device must come from the thread that owns it (solex_do_work makes it before it starts its
     workers): torch's device queries are not safe to run for the first time from several threads at once.  Whatever goes
@@ -84,15 +105,12 @@ def cpu_plan(device=None):
             plan = {'scan': cpus, 'io': cpus} if cpus else None
         else:
             online = set(_cpulist(open('/sys/devices/system/cpu/online').read()))
-            if os.sched_getaffinity(0) == online:            # otherwise the caller has already chosen
-                props = [torch.cuda.get_device_properties(i) for i in range(torch.cuda.device_count())]
-                nodes = [int(open('/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node'
-                                  % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)).read()) for p in props]
-                node = nodes[index]
-                if node >= 0:
-                    peers = sorted((i for i in range(len(props)) if nodes[i] == node),
-                                   key=lambda i: (props[i].pci_domain_id, props[i].pci_bus_id, props[i].pci_device_id))
-                    plan = _share_of_node(_l3_groups(node, online), peers.index(index), len(peers))
+            allowed = set(os.sched_getaffinity(0)) & online      # a cpuset / taskset is respected: the plan only narrows it
+            props = [torch.cuda.get_device_properties(i) for i in range(torch.cuda.device_count())]
+            nodes = [int(open('/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node'
+                              % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)).read()) for p in props]
+            plan = _plan_within(allowed, nodes, [(p.pci_domain_id, p.pci_bus_id, p.pci_device_id) for p in props], index,
+                                lambda node: _l3_groups(node, online), lambda cpus: _l3_groups(None, online, cpus=cpus))
     except Exception:      # noqa: BLE001 -- no sysfs, odd topology, torch without PCI ids: placement is optional
         plan = None
     _cpu_plan[index] = plan

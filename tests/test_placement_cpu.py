@@ -55,6 +55,37 @@ def test_gpus_on_one_node_get_disjoint_shares():
     assert dev._share_of_node([{0, 1}], 0, 1) is None                              # too small to pin four workers to
 
 
+def test_plan_stays_inside_the_cpus_the_process_may_use():
+    """Two sockets of 4 L3 groups x 8 cpus, GPUs 0-3 on node 0 and 4-7 on node 1."""
+    node_groups = {0: [set(range(8 * g, 8 * g + 8)) for g in range(4)], 1: [set(range(32 + 8 * g, 40 + 8 * g)) for g in range(4)]}
+    everything = set(range(64))
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    pci = [(0, 10 * i, 0) for i in range(8)]
+
+    def of_node(n):
+        return node_groups[n]
+
+    def of_cpus(cpus):
+        return [g for n in (0, 1) for g in node_groups[n] if g & set(cpus)]
+    # the whole machine: GPU k of a node gets that node's k-th group
+    for i in range(8):
+        plan = dev._plan_within(everything, nodes, pci, i, of_node, of_cpus)
+        assert plan['scan'] == node_groups[nodes[i]][i % 4] and plan['io'] == plan['scan']
+    # a cpuset that only holds node 0's first two groups: GPUs 0 and 1 keep a group each, 2 and 3 get none of their own
+    half = set(range(16))
+    assert dev._plan_within(half, nodes, pci, 0, of_node, of_cpus)['scan'] == set(range(8))
+    assert dev._plan_within(half, nodes, pci, 1, of_node, of_cpus)['scan'] == set(range(8, 16))
+    assert dev._plan_within(half, nodes, pci, 2, of_node, of_cpus) is None
+    # GPU 5 (node 1) confined to node 0's cpus: a group of what is allowed, never a cpu outside it
+    plan = dev._plan_within(set(range(32)), nodes, pci, 5, of_node, of_cpus)
+    assert plan['scan'] == set(range(8, 16)) and plan['io'] <= set(range(32))
+    # a mask of one group, or of a few cores: left alone
+    assert dev._plan_within(set(range(40, 48)), nodes, pci, 5, of_node, of_cpus) is None
+    assert dev._plan_within(set(range(40, 48)), nodes, pci, 4, of_node, of_cpus) == {'scan': set(range(40, 48)), 'io': set(range(40, 48))}
+    assert dev._plan_within({3, 4}, nodes, pci, 0, of_node, of_cpus) is None
+    assert dev._plan_within(set(range(8)), [-1], [(0, 0, 0)], 0, of_node, of_cpus) is None      # unknown node, one group
+
+
 def test_cpu_plan_env_override_and_off(monkeypatch):
     import torch
     monkeypatch.setattr(dev, '_cpu_plan', {})
