@@ -55,14 +55,19 @@ def _share_of_node(groups, position, n_peers):
     return {'scan': set(mine[0]), 'io': rest or set(mine[0])}
 
 
-def _plan_within(allowed, nodes, pci_ids, index, groups_of_node, groups_of_cpus):
+def _plan_within(allowed, nodes, pci_ids, index, groups_of_node, groups_of_cpus, local_rank=None):
     """The plan for GPU `index` inside the cpus this process may use.  First choice: the L3 groups of the GPU's NUMA node,
     shared round-robin with the other GPUs of that node; when none of them is allowed (or the node is unknown), the L3
-    groups of whatever is allowed, shared among all GPUs.  Groups with fewer than four allowed cpus do not count."""
+    groups of whatever is allowed, shared among all GPUs.  Groups with fewer than four allowed cpus do not count.
+    local_rank: set when every rank of the node sees only its own GPU (its peers are invisible): the ranks then take the
+    groups by their rank on the node."""
     node = nodes[index]
     if node >= 0:
         groups = [g & allowed for g in groups_of_node(node)]
         groups = [g for g in groups if len(g) >= 4]
+        if groups and local_rank is not None:
+            g = groups[local_rank % len(groups)]
+            return {'scan': set(g), 'io': set(g)}
         if groups:
             peers = sorted((i for i in range(len(nodes)) if nodes[i] == node), key=lambda i: pci_ids[i])
             return _share_of_node(groups, peers.index(index), len(peers))
@@ -109,8 +114,11 @@ def cpu_plan(device=None):
             props = [torch.cuda.get_device_properties(i) for i in range(torch.cuda.device_count())]
             nodes = [int(open('/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node'
                               % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)).read()) for p in props]
+            local_world = int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1)
+            hidden_peers = local_world > len(props)          # e.g. one visible GPU per rank (HIP_VISIBLE_DEVICES set by a launcher)
             plan = _plan_within(allowed, nodes, [(p.pci_domain_id, p.pci_bus_id, p.pci_device_id) for p in props], index,
-                                lambda node: _l3_groups(node, online), lambda cpus: _l3_groups(None, online, cpus=cpus))
+                                lambda node: _l3_groups(node, online), lambda cpus: _l3_groups(None, online, cpus=cpus),
+                                local_rank=int(os.environ.get('LOCAL_RANK', '0') or 0) if hidden_peers else None)
     except Exception:      # noqa: BLE001 -- no sysfs, odd topology, torch without PCI ids: placement is optional
         plan = None
     _cpu_plan[index] = plan

@@ -84,6 +84,9 @@ def test_plan_stays_inside_the_cpus_the_process_may_use():
     assert dev._plan_within(set(range(40, 48)), nodes, pci, 4, of_node, of_cpus) == {'scan': set(range(40, 48)), 'io': set(range(40, 48))}
     assert dev._plan_within({3, 4}, nodes, pci, 0, of_node, of_cpus) is None
     assert dev._plan_within(set(range(8)), [-1], [(0, 0, 0)], 0, of_node, of_cpus) is None      # unknown node, one group
+    # every rank sees only its own GPU (index 0 everywhere): the ranks of a node take its groups by local rank
+    seen = [dev._plan_within(everything, [0], [(0, 0, 0)], 0, of_node, of_cpus, local_rank=r)['scan'] for r in range(4)]
+    assert seen == node_groups[0]
 
 
 def test_cpu_plan_env_override_and_off(monkeypatch):
