@@ -13,7 +13,6 @@
 // Solex_recon.solex_do_work really run side by side.  The caller owns every buffer: a device workspace and a
 // pinned host staging area, both sized by the *_bytes queries, and the outputs.
 #include <math.h>
-#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <vector>
