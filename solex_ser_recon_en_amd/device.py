@@ -43,19 +43,49 @@ def _l3_groups(node, online, sysfs='/sys', cpus=None):
     return groups
 
 
-def _share_of_node(groups, position, n_peers):
+def _cpu_busy(interval=0.03, stat='/proc/stat'):
+    """{cpu: fraction of `interval` it spent busy}, from two readings of /proc/stat."""
+    import time
+
+    def read():
+        out = {}
+        for line in open(stat):
+            if line.startswith('cpu') and line[3].isdigit():
+                f = line.split()
+                v = [int(x) for x in f[1:]]
+                idle = v[3] + (v[4] if len(v) > 4 else 0)
+                out[int(f[0][3:])] = (sum(v[:8]) - idle, sum(v[:8]))
+        return out
+    a = read()
+    time.sleep(interval)
+    b = read()
+    busy = {}
+    for c, (bb, bt) in b.items():
+        ab, at = a.get(c, (bb, bt))
+        busy[c] = (bb - ab) / (bt - at) if bt > at else 0.0
+    return busy
+
+
+def _share_of_node(groups, position, n_peers, busy=None):
     """{'scan', 'io'} for the GPU at `position` among the `n_peers` GPUs attached to a node with these L3 groups:
     the groups are dealt round-robin, the first of a GPU's share runs its scan workers, the others its readers and
     encoders (all of them on the one group when that is all there is).  None when the share is too small to be worth
-    pinning to (fewer than four cpus: pinning four scan workers there would serialise them)."""
+    pinning to (fewer than four cpus: pinning four scan workers there would serialise them).
+    busy ({cpu: busy fraction}, optional): which of the GPU's groups is the quietest decides where the scan workers go."""
     mine = groups[position::n_peers]
     if not mine or len(mine[0]) < 4:
         return None
+    if busy and len(mine) > 1:
+        # the host is shared: of this GPU's groups the scan workers take the one other tenants use least right now (pinned
+        # to cores somebody else keeps busy, a batch ran at half speed)
+        load = [sum(busy.get(c, 0.0) for c in g) / len(g) for g in mine]
+        best = min(range(len(mine)), key=lambda i: (round(load[i], 2), i))
+        mine = [mine[best]] + mine[:best] + mine[best + 1:]
     rest = set().union(*mine[1:]) if len(mine) > 1 else set()
     return {'scan': set(mine[0]), 'io': rest or set(mine[0])}
 
 
-def _plan_within(allowed, nodes, pci_ids, index, groups_of_node, groups_of_cpus, local_rank=None):
+def _plan_within(allowed, nodes, pci_ids, index, groups_of_node, groups_of_cpus, local_rank=None, busy=None):
     """The plan for GPU `index` inside the cpus this process may use.  First choice: the L3 groups of the GPU's NUMA node,
     shared round-robin with the other GPUs of that node; when none of them is allowed (or the node is unknown), the L3
     groups of whatever is allowed, shared among all GPUs.  Groups with fewer than four allowed cpus do not count.
@@ -70,12 +100,12 @@ def _plan_within(allowed, nodes, pci_ids, index, groups_of_node, groups_of_cpus,
             return {'scan': set(g), 'io': set(g)}
         if groups:
             peers = sorted((i for i in range(len(nodes)) if nodes[i] == node), key=lambda i: pci_ids[i])
-            return _share_of_node(groups, peers.index(index), len(peers))
+            return _share_of_node(groups, peers.index(index), len(peers), busy)
     groups = [g & allowed for g in groups_of_cpus(allowed)]
     groups = [g for g in groups if len(g) >= 4]
     if len(groups) < 2:
         return None                                          # one group (or less) to choose from: nothing to narrow
-    return _share_of_node(groups, index % len(groups), max(len(nodes), 1))
+    return _share_of_node(groups, index % len(groups), max(len(nodes), 1), busy)
 
 
 def cpu_plan(device=None):
@@ -118,7 +148,7 @@ def cpu_plan(device=None):
             hidden_peers = local_world > len(props)          # e.g. one visible GPU per rank (HIP_VISIBLE_DEVICES set by a launcher)
             plan = _plan_within(allowed, nodes, [(p.pci_domain_id, p.pci_bus_id, p.pci_device_id) for p in props], index,
                                 lambda node: _l3_groups(node, online), lambda cpus: _l3_groups(None, online, cpus=cpus),
-                                local_rank=int(os.environ.get('LOCAL_RANK', '0') or 0) if hidden_peers else None)
+                                local_rank=int(os.environ.get('LOCAL_RANK', '0') or 0) if hidden_peers else None, busy=_cpu_busy())
     except Exception:      # noqa: BLE001 -- no sysfs, odd topology, torch without PCI ids: placement is optional
         plan = None
     _cpu_plan[index] = plan

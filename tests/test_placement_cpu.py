@@ -89,6 +89,20 @@ def test_plan_stays_inside_the_cpus_the_process_may_use():
     assert seen == node_groups[0]
 
 
+def test_scan_workers_go_to_the_quietest_group_of_the_gpus_share(tmp_path):
+    groups = [set(range(8 * g, 8 * g + 8)) for g in range(8)]
+    busy = {c: 0.0 for c in range(64)}
+    busy.update({c: 0.9 for c in range(0, 8)})                                     # another tenant sits on the first group
+    plan = dev._share_of_node(groups, 0, 1, busy)
+    assert plan['scan'] == groups[1] and plan['io'] == set(range(64)) - groups[1]
+    assert dev._share_of_node(groups, 0, 4, busy)['scan'] == groups[4]             # this GPU's share: groups 0 and 4
+    assert dev._share_of_node(groups, 1, 4, busy)['scan'] == groups[1]             # untouched shares keep their order
+    assert dev._share_of_node(groups, 0, 1, None)['scan'] == groups[0]
+    stat = tmp_path / 'stat'
+    stat.write_text('cpu  10 0 10 100 0 0 0 0 0 0\ncpu0 5 0 5 50 0 0 0 0 0 0\ncpu1 5 0 5 50 0 0 0 0 0 0\nintr 1\n')
+    assert dev._cpu_busy(0.0, str(stat)) == {0: 0.0, 1: 0.0}
+
+
 def test_cpu_plan_env_override_and_off(monkeypatch):
     import torch
     monkeypatch.setattr(dev, '_cpu_plan', {})
