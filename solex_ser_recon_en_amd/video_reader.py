@@ -118,13 +118,14 @@ class video_reader:
         self.FrameIndex = -1
 
     # ---- decode into HBM -----------------------------------------------------
-    def device_stack(self, device=None, chunk_bytes=32 << 20, readers=None):
+    def device_stack(self, device=None, chunk_bytes=16 << 20, readers=None):
         """Frames [k0:k1) of the file as one tensor [n, Height, Width] in HBM (file layout).
 
         `readers` threads (default min(8, cpus)) each own two pinned staging buffers and a copy
         stream: preadv() of whole frames into pinned memory (GIL released), one asynchronous 2-D hipMemcpy
         into the (8 KiB-pitched) frames of the stack, next chunk.  One thread tops out at the page-cache memcpy rate (~12 GB/s
-        measured); several saturate the PCIe link."""
+        measured); several saturate the PCIe link (tools/sweep_decode.py: 8 readers x 16 MB chunks 50 GB/s; 32 MB 47.7, 64 MB
+        42.6, 4 MB 45.8; 4 readers 33; more than 8 readers no faster)."""
         if self._stack is not None:
             return self._stack
         device = device or default_device()
