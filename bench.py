@@ -176,6 +176,12 @@ def main():
 
     if args.warmup > 0:
         run_scans(args.warmup, workers)
+    # What the interpreter holds now (torch, the package, the stack) stays: exempt it from the cyclic collector, as timeit
+    # does by switching it off.  Otherwise about one batch in a hundred meets a full collection of those ~10^6 objects --
+    # 85 ms with every scan worker stopped (tools/scan_timeline.py with GC=cb), five times a 20-scan timed region.
+    import gc
+    gc.collect()
+    gc.freeze()
     _lib.profile_reset()
     _lib.profile_enable(True, only=('accumulate', 'extract'))
     barrier()
