@@ -81,7 +81,7 @@ inline int move_words(void* dst, const void* src, size_t bytes, hipStream_t st) 
     return shg::check_launch("k_words");
 }
 
-// The staging area as the GPU addresses it (the same address under unified addressing; asked for once per area).
+// The staging area as the GPU addresses it (the same address under unified addressing).
 struct Staging {
     char* host;
     char* dev;
@@ -90,22 +90,16 @@ struct Staging {
 };
 
 inline int map_staging(void* host_pinned, Staging* out, const char* who) {
-    thread_local void* last_host = nullptr;
-    thread_local void* last_dev = nullptr;
-    if (host_pinned != last_host) {
-        void* d = nullptr;
-        hipError_t e = hipHostGetDevicePointer(&d, host_pinned, 0);
-        if (e != hipSuccess || !d) {
-            (void)hipGetLastError();
-            shg::set_error("%s: host_pinned is not page-locked, GPU-mapped memory (hipHostMalloc / hipHostRegister): %s", who,
-                           e != hipSuccess ? hipGetErrorString(e) : "no device address");
-            return SHG_E_ARG;
-        }
-        last_host = host_pinned;
-        last_dev = d;
+    void* d = nullptr;                                   // asked on every call (a microsecond): an address that was pinned
+    hipError_t e = hipHostGetDevicePointer(&d, host_pinned, 0);      // once may belong to pageable memory by now
+    if (e != hipSuccess || !d) {
+        (void)hipGetLastError();
+        shg::set_error("%s: host_pinned is not page-locked, GPU-mapped memory (hipHostMalloc / hipHostRegister): %s", who,
+                       e != hipSuccess ? hipGetErrorString(e) : "no device address");
+        return SHG_E_ARG;
     }
     out->host = static_cast<char*>(host_pinned);
-    out->dev = static_cast<char*>(last_dev);
+    out->dev = static_cast<char*>(d);
     return 0;
 }
 
