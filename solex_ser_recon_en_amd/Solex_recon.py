@@ -258,6 +258,9 @@ def _scan_pool(scan, n_tasks, n_workers, device):
     def run(k):
         try:
             work(k)
+        except BaseException as e:      # noqa: BLE001 -- e.g. the final stream.synchronize(): fails the batch, is not lost
+            with lock:
+                state['errors'].append((n_tasks, e))
         finally:
             done.release()
 

@@ -172,3 +172,23 @@ def test_service_threads_survive_a_failing_job_and_are_reused():
     a.jobs.put(lambda: (seen.append(threading.current_thread().name), done.set()))
     assert done.wait(10) and seen == ['shg-test-service']
     assert sr._Service.named('shg-test-service') is a and a.thread.daemon
+
+
+def test_a_worker_error_outside_a_scan_fails_the_batch(monkeypatch):
+    """An exception a scan worker meets outside scan(i) -- here its final stream.synchronize() -- is raised by the batch, not
+    swallowed by the service thread."""
+    import contextlib
+    import torch
+    from solex_ser_recon_en_amd import Solex_recon as sr
+
+    class FakeStream:
+        def synchronize(self):
+            raise RuntimeError('device lost')
+    monkeypatch.setattr(torch.cuda, 'set_device', lambda d: None)
+    monkeypatch.setattr(torch.cuda, 'stream', lambda s: contextlib.nullcontext())
+    monkeypatch.setattr(sr, '_worker_context', lambda device, k: {'stream': FakeStream(), 'buffers': {}})
+    monkeypatch.setattr(sr, 'bind_thread', lambda kind, device=None: None)
+    done = []
+    with pytest.raises(RuntimeError, match='device lost'):
+        sr._scan_pool(done.append, 3, 2, torch.device('cuda', 0))
+    assert sorted(done) == [0, 1, 2]
