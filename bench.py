@@ -60,6 +60,9 @@ def parse():
     ap.add_argument('--bits', type=int, default=16)
     ap.add_argument('--mode', choices=['folder', 'sharded'], default='folder')
     ap.add_argument('--workers', type=int, default=0, help='scans in flight per process (0 = SHG_WORKERS or 4)')
+    ap.add_argument('--repeats', type=int, default=5, help='timed regions of --steps scans each; the median one is quoted')
+    ap.add_argument('--stacks', type=int, default=0, help='distinct resident stacks the timed scans cycle over (0 = workers + 1)')
+    ap.add_argument('--no-extra', action='store_true', help='skip the C4 (21 disks) and one-C5-file legs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-e2e', action='store_true', help='skip the decode-inclusive legs (e2e, sharded_c3)')
     ap.add_argument('--e2e-files', type=int, default=8)
@@ -146,23 +149,30 @@ def main():
     n_local = args.frames
     n_scan = n_local * world if sharded else n_local
     k0 = rank * n_local if sharded else 0
+    # A folder holds a different stack per file: the scans in flight must not all read the same 1.6 GB (what one scan pulls
+    # through the Infinity Cache another would find there), so the timed scans cycle over workers + 1 resident stacks.
+    n_stacks = 1 if sharded else max(1, args.stacks or workers + 1)
     t0 = time.time()
-    stack = synth.synth_frames_torch(n_scan, args.width, args.height, args.bits, seed=rank if not sharded else 0,
-                                     k0=k0, k1=k0 + n_local, n_total=n_scan, padded=True)
+    stacks = [synth.synth_frames_torch(n_scan, args.width, args.height, args.bits, seed=(rank * 64 + j) if not sharded else 0,
+                                       k0=k0, k1=k0 + n_local, n_total=n_scan, padded=True) for j in range(n_stacks)]
+    stack = stacks[0]
     torch.cuda.synchronize()
-    log('[rank %d] synthetic stack %s %s built in %.1f s' % (rank, tuple(stack.shape), stack.dtype, time.time() - t0))
+    log('[rank %d] %d synthetic stack(s) %s %s built in %.1f s' % (rank, n_stacks, tuple(stack.shape), stack.dtype, time.time() - t0))
 
-    def options():
+    def options(shifts=None):
         opts = SHG_MAIN.default_options()
         opts['_nolog'] = True
-        opts['shift'] = list(requested_shifts)
+        opts['shift'] = list(requested_shifts if shifts is None else shifts)
         return opts
 
-    def run_scans(n, n_workers, results=False):
-        """n scans of the resident stack through the production entry point.  sharded: collectives per scan (and the
-        disks of a Doppler stack dealt to the ranks), one scan at a time; otherwise the scans are independent files."""
-        tasks = [(array_reader(stack, frame_count=n_scan, frame_range=(k0, k0 + n_local) if sharded else None), options())
-                 for _ in range(n)]
+    def run_scans(n, n_workers, results=False, shifts=None, pool=None, first=0):
+        """n scans of resident stacks through the production entry point, scan i on stack (first + i) mod len(pool).
+        sharded: collectives per scan (and the disks of a Doppler stack dealt to the ranks), one scan at a time; otherwise the
+        scans are independent files."""
+        pool = stacks if pool is None else pool
+        n_total = n_scan if pool is stacks else pool[0].shape[0]
+        tasks = [(array_reader(pool[(first + i) % len(pool)], frame_count=n_total,
+                               frame_range=(k0, k0 + n_local) if sharded else None), options(shifts)) for i in range(n)]
         with contextlib.redirect_stdout(io.StringIO()):
             if sharded:
                 out = [Solex_recon.solex_do_work([t], True, distribute='frames', return_results=results) for t in tasks]
@@ -174,6 +184,22 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
+    def timed_regions(steps, repeats, **kw):
+        """`repeats` timed regions of exactly `steps` scans each, every one bracketed by barrier + synchronize on both sides;
+        -> seconds per region, the maximum over ranks of each."""
+        times = []
+        for r in range(repeats):
+            barrier()
+            t_start = time.perf_counter()
+            run_scans(steps, workers, first=r * steps, **kw)
+            barrier()
+            times.append(time.perf_counter() - t_start)
+        if world > 1:
+            t = torch.tensor(times, dtype=torch.float64, device='cuda')
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            times = [float(v) for v in t.tolist()]
+        return times
+
     if args.warmup > 0:
         run_scans(args.warmup, workers)
     # What the interpreter holds now (torch, the package, the stack) stays: exempt it from the cyclic collector, as timeit
@@ -184,16 +210,9 @@ def main():
     gc.freeze()
     _lib.profile_reset()
     _lib.profile_enable(True, only=('accumulate', 'extract'))
-    barrier()
-    t_start = time.perf_counter()
-    run_scans(args.steps, workers)
-    barrier()
-    elapsed = time.perf_counter() - t_start
+    region_s = timed_regions(args.steps, max(1, args.repeats))
     _lib.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sorted(region_s)[len(region_s) // 2]                       # the median region is the one quoted
 
     # ---- roofline of the dominant kernel (pass A: sum/max over the stack), live HIP events --------
     acc_ms, acc_n = _lib.profile_get('accumulate')
@@ -222,6 +241,10 @@ def main():
     _lib.profile_reset()
     kernel_ms_per_step = all_ms / serial_steps
     ach1 = bytes_a / (acc1_ms / acc1_n * 1e-3) / 1e9 if acc1_n else 0.0
+    # post-processing bytes of one requested disk: warp 2 + 2, row-pair statistics 2, row scaling 2 + 2,
+    # CLAHE histograms 2, CLAHE blend 2 + 2, percentile select 2, contrast products 2 x 2 + 3 x 2 = 28 bytes per output pixel
+    out_px = sum(int(np.prod(cc.shape)) for cc, _ in out[-1]) if out and out[-1] else 0
+    bytes_post = 28 * out_px
 
     traffic, traffic_from = None, None
     tpath = os.path.join(REPO, 'profiles', 'traffic.json')
@@ -244,8 +267,9 @@ def main():
                 'traffic': traffic, 'traffic_from': traffic_from,
                 'algorithmic_bytes_per_launch': bytes_a, 'frame_pitch_bytes': pitch_bytes,
                 'avg_launch_ms': round(acc_ms / acc_n, 5) if acc_n else None, 'launches': acc_n,
-                'how': 'HIP events on the launch streams over the timed region; with %d scans in flight the launch shares the '
-                       'device with the other scans\' kernels' % workers,
+                'how': 'HIP events around the launch, on the stream it is launched on, over the %d timed regions; with %d scans in '
+                       'flight pass A of every scan goes through one stream (the frame-pass lane, csrc/streams.hip): the passes run '
+                       'one after the other, each beside the small kernels of the other scans' % (len(region_s), workers),
                 'uncontended': {'achieved': round(ach1, 1), 'frac': round(ach1 / HBM_PEAK_GBS, 4),
                                 'avg_launch_ms': round(acc1_ms / acc1_n, 5) if acc1_n else None, 'launches': acc1_n,
                                 'how': 'serial pass after the timed region: one scan at a time, same events'},
@@ -269,6 +293,25 @@ def main():
         log('per-stage host wall clock (ms / step, each stage fenced by a device sync):')
         for k, v in timing.totals.items():
             log('  %-28s %8.3f' % (k, v / 3 * 1e3))
+
+    # ---- BASELINE configs[3] (Doppler stack, 21 disks) and one file of configs[4] (4000 x 2560x256), stack resident -----
+    c4, c5 = None, None
+    if not sharded and not args.no_extra and requested_shifts == [0] and (args.frames, args.width, args.height, args.bits) == (2000, 2000, 200, 16):
+        c4 = guarded(extra_leg, 'C4: 2000-frame 16-bit SER 2000x200, -w -10:10:1 (21 disks), stack resident', stacks, parse_shift('-10:10:1'),
+                     8, 2, workers, run_scans, barrier, _lib, world)
+        del stacks[1:]                                                   # the legs below use rank 0's first stack only
+        torch.cuda.empty_cache()
+
+        def c5_file():
+            pool = [synth.synth_frames_torch(4000, 2560, 256, 16, seed=rank * 64 + j, padded=True) for j in range(2)]
+            torch.cuda.synchronize()
+            try:
+                return extra_leg('one file of C5: 4000-frame 16-bit SER 2560x256, single shift, stack resident', pool, [0], 6, 2, workers,
+                                 run_scans, barrier, _lib, world)
+            finally:
+                del pool
+                torch.cuda.empty_cache()
+        c5 = guarded(c5_file)
 
     # ---- decode-inclusive legs: SER files in /dev/shm -> pinned host -> HBM -> products ---------------
     e2e, c3 = None, None
@@ -296,7 +339,7 @@ def main():
                                               'not on this box: the reference cannot travel); the oracle works on an in-memory array, hence '
                                               'its ~5x higher figure'}}
         if out and n_cpu == n_local and requested_shifts == [0]:
-            cc = np.asarray(out[-1][0][0])
+            cc = np.asarray(out[0][0][0])                                   # the serial pass's first scan read stacks[0], like the oracle
             want = ref['results'][0]['cc']
             d = np.abs(cc.astype(np.int64) - want.astype(np.int64)) if cc.shape == want.shape else None
             cpu['parity_vs_gpu'] = 'shape mismatch' if d is None else 'max |diff| %d LSB, %d of %d px differ' % (
@@ -321,17 +364,69 @@ def main():
                        'scans_in_flight_per_process': 1 if sharded else min(workers, args.steps),
                        'backend': backend if world > 1 else None, 'world_size': world,
                        'collectives_per_scan': 3 if sharded else 0},
+            'repeats': {'n': len(region_s), 'ms_per_step': [round(t / args.steps * 1e3, 4) for t in region_s],
+                        'min': round(min(region_s) / args.steps * 1e3, 4), 'median': round(ms_per_step, 4),
+                        'max': round(max(region_s) / args.steps * 1e3, 4),
+                        'how': '%d timed regions of exactly %d scans, each bracketed by barrier + synchronize; value / ms_per_step are the '
+                               'median region; the scans cycle over %d distinct resident stacks' % (len(region_s), args.steps, n_stacks)},
+            'whole_step': {'bytes': bytes_a + bytes_b + bytes_post, 'pass_a': bytes_a, 'pass_b': bytes_b, 'post': bytes_post,
+                           'achieved': round((bytes_a + bytes_b + bytes_post) / (ms_per_step * 1e-3) / 1e9, 1), 'unit': 'GB/s',
+                           'frac': round((bytes_a + bytes_b + bytes_post) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           'how': 'algorithmic bytes of a whole scan (pass A + pass B + 28 B per output pixel of post-processing, '
+                                  'DESIGN.md section 3) / ms_per_step / %.0f GB/s' % HBM_PEAK_GBS},
             'kernel_ms_per_step': round(kernel_ms_per_step, 4),
             'gpu_busy_frac': round(kernel_ms_per_step / ms_per_step, 4),
             'kernel_time_how': 'sum of the HIP-event-bracketed durations of all %d library entry points of one scan, serial pass '
                                '(%.3f ms wall per scan there); gpu_busy_frac = that / ms_per_step' % (
                                    all_n // serial_steps, t_serial / serial_steps * 1e3),
-            'roofline': roofline, 'cpu_baseline': cpu, 'e2e': e2e, 'sharded_c3': c3,
+            'roofline': roofline, 'cpu_baseline': cpu, 'e2e': e2e, 'sharded_c3': c3, 'c4': c4, 'c5_file': c5,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
         td.barrier()
         td.destroy_process_group()
+
+
+def extra_leg(what, pool, shifts, steps, warmup, workers, run_scans, barrier, _lib, world):
+    """Another BASELINE configuration on resident stacks: `steps` scans over `pool` (after `warmup`), timed like the headline;
+    then a serial pass with every entry point bracketed by events for the kernel time per scan and the two frame passes."""
+    import torch
+    import torch.distributed as td
+    n, h, w = pool[0].shape
+    bpp = pool[0].element_size()
+    run_scans(warmup, workers, shifts=shifts, pool=pool)
+    times = []
+    for r in range(3):
+        barrier()
+        t0 = time.perf_counter()
+        run_scans(steps, workers, shifts=shifts, pool=pool, first=r * steps)
+        barrier()
+        times.append(time.perf_counter() - t0)
+    if world > 1:
+        t = torch.tensor(times, dtype=torch.float64, device='cuda')
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        times = [float(v) for v in t.tolist()]
+    dt = sorted(times)[1]
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    run_scans(3, 1, shifts=shifts, pool=pool)
+    torch.cuda.synchronize()
+    _lib.profile_enable(False)
+    acc_ms, acc_n = _lib.profile_get('accumulate')
+    ext_ms, ext_n = _lib.profile_get('extract')
+    all_ms, _ = _lib.profile_total()
+    _lib.profile_reset()
+    s_all = len(dict.fromkeys([10, 0] + list(shifts)))
+    u = len(set(s + d for s in dict.fromkeys([10, 0] + list(shifts)) for d in (0, 1)))
+    ih = max(h, w)
+    bytes_a, bytes_b = n * h * w * bpp, n * ih * (u * bpp + 2 * s_all)
+    return {'workload': what, 'value': round(n * steps * world / dt, 1), 'unit': 'frames/s', 'ms_per_step': round(dt / steps * 1e3, 3),
+            'steps': steps, 'regions_ms_per_step': [round(t / steps * 1e3, 3) for t in times], 'disks_per_scan': len(shifts),
+            'kernel_ms_per_step': round(all_ms / 3, 4),
+            'pass_a': {'avg_launch_ms': round(acc_ms / acc_n, 5) if acc_n else None, 'algorithmic_bytes': bytes_a,
+                       'frac_uncontended': round(bytes_a / (acc_ms / acc_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if acc_n else None},
+            'pass_b': {'avg_launch_us': round(ext_ms / ext_n * 1e3, 2) if ext_n else None, 'algorithmic_bytes': bytes_b,
+                       'frac_uncontended': round(bytes_b / (ext_ms / ext_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ext_n else None}}
 
 
 def _write_scan(path, n, width, height, bits, rank, world):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SHG_ABI_VERSION 12
+#define SHG_ABI_VERSION 13
 
 #define SHG_E_ARG        (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SHG_E_WORKSPACE  (-2)   /* workspace too small                                 */
@@ -430,6 +430,113 @@ int shg_stage_process_frames(const uint16_t* const* host_frames, int64_t k, int6
                              uint16_t* const* host_final, uint16_t* const* host_cl1, uint16_t* const* host_hc,
                              uint16_t* const* host_protus, uint16_t* const* host_cc, int64_t out_pitch, void* workspace,
                              size_t workspace_bytes, void* host_pinned, size_t host_pinned_bytes, shg_stream_t stream);
+
+/* ==== one scan, one call =========================================================================
+ * The whole per-file flow of solex_do_work's loop body (Solex_recon.py:33-42: solex_read :50-83, solex_process :94-134,
+ * single_image_process :136-174) as ONE call, so that nothing of a scan in flight waits for the caller's interpreter:
+ * shg_stage_mean_fit -> shg_stage_extract -> (limb fit of the first disk, or the fixed ratio / slant of the options) ->
+ * the warp of every requested disk -> shg_stage_process_frames.  Same kernels and host control plane as the stage
+ * composites; what the caller's language would have done between them (shift bookkeeping, phi through degrees and back
+ * as options['slant_fix'] stores it, the crop plan, the protuberance disc, the Savitzky-Golay window) is restated here.
+ * Image sizes after the warp are only known once the limb is fitted, so the images go into two ARENAS the caller sizes by
+ * guess: when one (or the workspace) turns out too small the call returns SHG_E_WORKSPACE with needed_* filled in and
+ * phase_done = 3; the caller grows the buffers and calls again with start_phase = 3 and the same result struct (the raw
+ * disks and the geometry are kept; nothing is computed twice). */
+typedef struct shg_scan_request {
+    uint32_t struct_bytes;            /* sizeof(shg_scan_request) of the caller */
+    int32_t  start_phase;             /* 0: whole scan; 3: resume at the warp after SHG_E_WORKSPACE */
+    /* the frame stack, file layout */
+    const void* stack;
+    int64_t  n_frames, height, width, frame_stride_px;
+    int32_t  bytes_per_px;
+    int32_t  flip_x;                  /* options['flip_x'] (Solex_recon.py:74-76) */
+    /* options['shift'] after solex_read's de-duplication (:55): [ellipse_fit_shift, 0, requested...] */
+    const int32_t* host_shifts;
+    const uint8_t* host_requested;    /* [n_shifts]: shift in options['shift_requested'] */
+    int32_t  n_shifts;
+    int32_t  want_fit_image;          /* warp the first disk even when it is not requested (diagnostic plot) */
+    double   ratio_fixe, slant_fix_deg;   /* options['ratio_fixe'] / ['slant_fix']; NaN = None (both NaN: fit the limb) */
+    int32_t  transversalium, keep_detrans;
+    int64_t  trans_strength;
+    const double* host_taps;          /* savgol_coeffs(taps_window, 3) for the window the caller expects (may be NULL); */
+    int64_t  taps_window;             /* another window is asked from shg_host_set_savgol_taps's callback */
+    int32_t  crop_square, has_fixed_width;
+    int64_t  fixed_width;
+    int32_t  disk_display, tiles;
+    int64_t  delta_radius;
+    double   clip_limit;
+    const double* host_gauss_taps;    /* as shg_stage_limb_points */
+    /* device buffers of the caller */
+    uint16_t* mean_out;               /* [ih][iw] dense */
+    uint16_t* max_out;
+    uint16_t* disks;                  /* [n_shifts] planes, rows of disk_pitch elements */
+    int64_t  disk_pitch, disk_plane_stride;
+    uint32_t* minmax_slots;           /* n_shifts * 130 words (shg_extract_columns_minmax) */
+    void*    arena;                   /* images the caller may drop early: corrected frames, final / CLAHE / high-contrast */
+    size_t   arena_bytes;
+    void*    results;                 /* the images solex_process returns: protus and cc of every requested disk */
+    size_t   results_bytes;
+    void*    workspace;
+    size_t   workspace_bytes;
+    void*    host_pinned;             /* page-locked, GPU-mapped; read by the GPU until the call's last kernel has run */
+    size_t   host_pinned_bytes;
+    /* host outputs */
+    double*  host_fit;                /* [ih][4] */
+    int32_t* host_trace_sharp;        /* [ih] or NULL */
+    uint8_t* host_mask_good;          /* [ih] or NULL */
+    int32_t* host_points;             /* [points_cap][2] */
+    uint8_t* host_flags;              /* [points_cap] */
+    int64_t  points_cap;              /* ceil(ih/4) * ceil(n_frames/4) always suffices */
+    double*  host_outline200;         /* or NULL */
+    double*  host_factors;            /* [n_out][ih] transversalium row factors, or NULL */
+} shg_scan_request;
+
+typedef struct shg_scan_result {
+    int32_t phase_done;               /* 0 nothing | 1 line fit | 2 raw disks | 3 geometry | 4 products */
+    int32_t limb_fitted;              /* this call fitted the limb (options['ratio_fixe'] / ['slant_fix'] are to be set) */
+    int64_t y1, y2;                   /* backup bounds */
+    double  p4[4];
+    int64_t counts3[3];               /* edge pixels, limb points, kept points */
+    double  geom16[16];               /* shg_host_limb_geometry (when limb_fitted) */
+    double  phi, ratio;               /* limb fit: its phi and ratio; else radians(slant_fix) or 0, ratio_fixe or 1 */
+    double  h_first[3], h_rest[3];    /* warp row (h00, h01, h02) of the first disk / of the others (phi through degrees) */
+    double  theta_first, theta_rest;
+    double  circle3[3], borders4[4];  /* cercle0 ((-1,-1,-1) without a limb fit), borders */
+    double  circle_out3[3];           /* the circle after the crop block */
+    int64_t out_h, out_w, frame_pitch;        /* circularised frames: [out_h][out_w], rows frame_pitch elements apart */
+    int64_t n_out, prod_w, prod_pitch;        /* requested disks; products [out_h][prod_w] */
+    int64_t window;                   /* Savitzky-Golay window used (0: transversalium off) */
+    int64_t crop4[4];                 /* crop plan (new width, source x0, destination x0, columns copied); new width 0 = none */
+    int64_t disc3[3];                 /* protuberance disc x0, y0, r (r = 0: none) */
+    /* byte offsets into the arena; -1 = absent */
+    int64_t fit_image_off;            /* the corrected first disk when it is not a requested one */
+    int64_t frames_off;               /* [n_out][out_h][frame_pitch] */
+    int64_t detrans_off;              /* [n_out][out_h][frame_pitch] */
+    int64_t products_off;             /* [n_out][3][out_h][prod_pitch]: final, cl1, high contrast */
+    int64_t results_off;              /* into `results`: [n_out][2][out_h][prod_pitch]: protus, cc */
+    size_t  needed_arena_bytes, needed_results_bytes, needed_workspace_bytes;
+} shg_scan_result;
+
+size_t shg_scan_workspace_bytes(const shg_scan_request* req);      /* phases 0-2; the rest is reported by needed_workspace_bytes */
+size_t shg_scan_host_bytes(const shg_scan_request* req);           /* the whole call */
+int shg_scan_file(const shg_scan_request* req, shg_scan_result* res, shg_stream_t stream);
+/* savgol_coeffs(window, 3) for a window other than request.taps_window: fn(window, out[window]) returns 0, or an SHG_E_*
+ * code (SHG_E_VALUE where SciPy raises ValueError). */
+typedef int (*shg_savgol_taps_fn)(int64_t window, double* out);
+int shg_host_set_savgol_taps(shg_savgol_taps_fn fn);
+
+/* ==== streams of a scan worker pool ==============================================================
+ * The reference post-processes up to four files at once (Pool(4), Solex_recon.py:30-42).  Scans in flight share one
+ * device: shg_frame_pass_lane_set names ONE stream of the current device through which pass A of every scan runs
+ * (shg_accumulate_mean_max, and with it shg_stage_mean_fit / shg_scan_file) -- HBM-bound passes side by side only halve
+ * each other's bandwidth; the caller's stream waits for its pass through an event.  NULL switches the lane off.
+ * shg_stream_create: priority < 0 high, 0 normal, > 0 low; host_cu_mask (n_mask_words 32-bit words, bit i = CU i, may be
+ * NULL) confines the stream's kernels to those CUs (hipExtStreamCreateWithCUMask; priority is ignored then). */
+int shg_device_cu_count(int* out);
+int shg_stream_create(int priority, const uint32_t* host_cu_mask, int n_mask_words, shg_stream_t* out);
+int shg_stream_destroy(shg_stream_t stream);
+int shg_frame_pass_lane_set(shg_stream_t lane);
+shg_stream_t shg_frame_pass_lane_get(void);
 
 /* ==== host control plane =======================================================================
  * The 1-D / scalar arithmetic between the kernels, restated from the reference's NumPy / SciPy calls so

@@ -178,6 +178,11 @@ def solex_do_work(tasks, flag_command_line=False, distribute='auto', return_resu
         rdr = decoder.get(i)
         if shard_frames:
             _check_shardable(rdr)
+        if _one_call_ok(rdr, options):
+            res = scan_one_call(rdr, options)               # the whole file below the interpreter (shg_scan_file)
+            if return_results:
+                collected[i] = res
+            return
         disk_list, backup_bounds, hdr = solex_read(rdr, options)
         _release_stack(rdr)                                 # the frame stack goes before the next file's lands
         if shard_frames:
@@ -200,6 +205,7 @@ def solex_do_work(tasks, flag_command_line=False, distribute='auto', return_resu
                 if previous is not None:
                     os.sched_setaffinity(0, previous)
         else:
+            _ensure_lane(decoder.device)
             _scan_pool(scan, len(tasks), n_workers, decoder.device)
     finally:
         decoder.cancel()
@@ -229,14 +235,75 @@ def _release_stack(rdr):
 
 _worker_contexts = {}          # (device, k) -> {'stream', 'buffers'}: a scan worker's stream and staging buffers outlive a batch
 _contexts_lock = threading.Lock()
+_lanes = {}                    # device -> the frame-pass lane's stream (csrc/streams.hip), created once per process
+
+
+def _chain_cu_mask(n_cus):
+    """The CU mask of the scan workers' streams, as 32-bit words, or None: SHG_CHAIN_CU_MASK=<hex> verbatim, or
+    SHG_CHAIN_CUS=<count> CUs spread evenly over the device (every XCD keeps its share).  Off by default."""
+    explicit = os.environ.get('SHG_CHAIN_CU_MASK', '').strip()
+    words = (n_cus + 31) // 32
+    if explicit:
+        value = int(explicit, 16) & ((1 << n_cus) - 1)
+    else:
+        try:
+            want = int(os.environ.get('SHG_CHAIN_CUS', '0'))
+        except ValueError:
+            want = 0
+        if want <= 0 or want >= n_cus:
+            return None
+        value = 0
+        for j in range(want):
+            value |= 1 << (j * n_cus // want)
+    if value == 0:
+        return None
+    return [(value >> (32 * i)) & 0xffffffff for i in range(words)]
+
+
+def _native_stream(device, priority=0, cu_mask=None):
+    """A stream made by the library (shg_stream_create: priority or CU mask), as a torch stream."""
+    import ctypes
+    import torch
+    from ._lib import check, lib
+    out = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        if cu_mask:
+            arr = (ctypes.c_uint32 * len(cu_mask))(*cu_mask)
+            check(lib.shg_stream_create(0, arr, len(cu_mask), ctypes.byref(out)), 'shg_stream_create')
+        else:
+            check(lib.shg_stream_create(priority, None, 0, ctypes.byref(out)), 'shg_stream_create')
+    return torch.cuda.ExternalStream(out.value, device=device)
+
+
+def _ensure_lane(device):
+    """The frame-pass lane of this device: ONE stream through which pass A of every scan in flight runs (HBM-bound passes
+    side by side only halve each other's bandwidth).  SHG_FRAME_LANE=0 leaves every pass on its scan's own stream."""
+    import torch
+    from ._lib import check, lib
+    if os.environ.get('SHG_FRAME_LANE', '1') == '0':
+        return None
+    with _contexts_lock:
+        lane = _lanes.get(str(device))
+        if lane is None:
+            lane = _lanes[str(device)] = _native_stream(device, priority=-1)
+            with torch.cuda.device(device):
+                check(lib.shg_frame_pass_lane_set(lane.cuda_stream), 'shg_frame_pass_lane_set')
+    return lane
 
 
 def _worker_context(device, k):
+    import ctypes
     import torch
+    from ._lib import check, lib
     with _contexts_lock:
         ctx = _worker_contexts.get((str(device), k))
         if ctx is None:
-            ctx = {'stream': torch.cuda.Stream(device=device), 'buffers': {}}
+            n_cus = ctypes.c_int(0)
+            with torch.cuda.device(device):
+                check(lib.shg_device_cu_count(ctypes.byref(n_cus)), 'shg_device_cu_count')
+            mask = _chain_cu_mask(n_cus.value)
+            stream = _native_stream(device, cu_mask=mask) if mask else torch.cuda.Stream(device=device)
+            ctx = {'stream': stream, 'buffers': {}}
             _worker_contexts[(str(device), k)] = ctx
     return ctx
 
@@ -296,6 +363,111 @@ def _scan_pool(scan, n_tasks, n_workers, device):
         done.acquire()
     if state['errors']:
         raise min(state['errors'], key=lambda ie: ie[0])[1]
+
+
+def _one_call_ok(rdr, options):
+    """Whether shg_scan_file covers this scan: everything but frame-sharded scans (collectives between the stages), the
+    de-vignette and stubborn-transversalium branches (host SciPy filters between the kernels), AVI input re-laid on the fly,
+    and runs that time every stage (timing.enabled).  SHG_SCAN_CALL=0 forces the stage-by-stage route."""
+    if os.environ.get('SHG_SCAN_CALL', '1') == '0' or timing.enabled:
+        return False
+    if options.get('_shard_frames') or dist.is_sharded(rdr):
+        return False
+    if options['de-vignette'] or (options['transversalium'] and options.get('stubborn_transversalium')):
+        return False
+    return True
+
+
+def scan_one_call(rdr, options):
+    """solex_read + solex_process for one file as ONE C call (stages.scan_file -> shg_scan_file): the same kernels and the
+    same host control plane as the stage-by-stage route, and the same log lines, files and `options` side effects
+    (basefich0, shift_requested, shift, ratio_fixe, slant_fix, _transversalium_cache) -- produced here after the call from
+    what it returned.  A scan that fails half-way leaves the log the reference would have left, then raises.
+    -> [(cc, frame_protus), ...] like solex_process."""
+    from .ellipse_to_circle import _log_geometry, _warp_geometry
+    basefich0 = os.path.splitext(str(rdr.file))[0]
+    options['basefich0'] = basefich0
+    log = basefich0 + '_log.txt'
+    clearlog(log, options)
+    logme(log, options, 'Pixel shift : ' + str(options['shift']))
+    options['shift_requested'] = options['shift']
+    options['shift'] = list(dict.fromkeys([options['ellipse_fit_shift'], 0] + options['shift']))
+    hdr = make_header(rdr)
+    logme(log, options, 'Width, Height : ' + str(rdr.Width) + ' ' + str(rdr.Height))
+    logme(log, options, 'Number of frames : ' + str(rdr.FrameCount))
+    shifts = options['shift']
+    requested = [sh in options['shift_requested'] for sh in shifts]
+    plots = plots_enabled(options)
+    stack = rdr.device_stack()
+    r, error = stages.scan_file(stack, shifts, requested, options, savgol_taps, want_plot_data=plots, want_fit_image=plots)
+    _release_stack(rdr)
+    phase = r['phase']
+    # ---- compute_mean_return_fit's outputs (solex_util.py:191-274) ----
+    if phase >= 1:
+        mean_img = DeviceImage(r['mean'])
+        y1, y2, fit = r['y1'], r['y2'], r['fit']
+        if options['save_fit']:
+            outputs.submit(write_fits, output_path(basefich0 + '_mean.fits', options), mean_img, hdr)
+        logme(log, options, 'Vertical limits y1, y2 : ' + str(y1) + ' ' + str(y2))
+        logme(log, options, lambda: 'Spectral line polynomial fit: ' + str(r['p']))
+        if plots:
+            rows = np.arange(y1, y2)
+            good = r['mask_good']
+            outputs.submit(outputs.plot_spectral_line, output_path(basefich0 + '_spectral_line_data.png', options), mean_img,
+                           r['sharp'].astype(np.int64)[y1:y2][good], rows[good], fit[:, 3], int(rdr.ih), (y2 - y1) // 20 + 1)
+    # ---- the raw disks (Solex_recon.py:65-83) and solex_process's header lines (:95-102) ----
+    disk_list = []
+    if phase >= 2:
+        hdr['NAXIS1'] = rdr.iw
+        disk_list = [DeviceImage(r['disks'][i], minmax=r['extrema'][i]) for i in range(len(shifts))]
+        for i, disk in enumerate(disk_list):
+            if options['save_fit'] and requested[i]:
+                outputs.submit(write_fits, output_path(basefich0 + '_shift=' + str(shifts[i]) + '_raw.fits', options), disk, hdr)
+        if options['transversalium']:
+            logme(log, options, 'Transversalium correction : ' + str(options['trans_strength']))
+        else:
+            logme(log, options, 'Transversalium disabled')
+        logme(log, options, 'Mirror X : ' + str(options['flip_x']))
+        logme(log, options, 'Post-rotation : ' + str(options['img_rotate']) + ' degrees')
+        logme(log, options, f'Protus adjustment : {options["delta_radius"]}')
+        logme(log, options, f'de-vignette : {options["de-vignette"]}')
+    # ---- the geometry: ellipse_to_circle's / correct_image's log lines (ellipse_to_circle.py:131-143, 313) ----
+    if phase >= 3:
+        if r['limb_fitted']:
+            options['ratio_fixe'] = r['ratio']
+            _log_geometry(options, r['phi'], r['ratio'], r['theta_first'], np.array(r['circle'][:2]), r['circle'][2])
+            print('sun borders found:' + str(r['borders']))
+            options['slant_fix'] = math.degrees(r['phi'])
+        elif requested[0] and '_nolog' not in options:
+            # correct_image(..., center (-1, -1), height -1, print_log=True) of the first disk (Solex_recon.py:122)
+            ih_, n_ = disk_list[0].shape
+            theta, inv_mat, _, _, _, origin, det = _warp_geometry(float(r['phi']), float(r['ratio']), int(ih_), int(n_))
+            _log_geometry(options, r['phi'], r['ratio'], theta, (inv_mat @ np.array([-1.0, -1.0]).T).T - origin,
+                          -1.0 * np.sqrt(np.abs(r['ratio'] / det)), known=False)
+    if error is not None:
+        raise error
+    # ---- single_image_process's files (Solex_recon.py:136-174) ----
+    names = [basefich0 + '_shift=' + str(shifts[i]) for i in range(len(shifts)) if requested[i]]
+    if plots and r['limb_fitted']:
+        fix_img = r['frames'][0] if requested[0] else r['fit_image']
+        outputs.submit(outputs.plot_ellipse_fit, output_path(basefich0 + '_shift=' + str(shifts[0]) + '_ellipse_fit.png', options),
+                       disk_list[0], DeviceImage(fix_img), r['raw_X'], r['X_f'], r['outline'], r['borders'])
+    if options['save_fit']:
+        for frame, basefich in zip(r['frames'], names):
+            outputs.submit(write_fits, output_path(basefich + '_circular.fits', options), DeviceImage(frame), hdr)
+    if options['transversalium']:
+        for i, basefich in enumerate(names):
+            c = r['factors'][i]
+            options['_transversalium_cache'] = c
+            if plots:
+                outputs.submit(outputs.plot_transversalium, output_path(basefich + '_transversalium_correction.png', options), c)
+            if options['save_fit']:
+                outputs.submit(write_fits, output_path(basefich + '_detransversaliumed.fits', options), DeviceImage(r['detrans'][i]), hdr)
+    results = [write_products(r['final'][i], r['cl1'][i], r['hc'][i], r['protus'][i], r['cc'][i], options, hdr, names[i])
+               for i in range(len(names))]
+    for _ in names:
+        write_complete(log, options)
+    return results
 
 
 def _writes_files(options):

@@ -8,7 +8,7 @@ exactly like an exception inside the reference's pool worker does
 """
 import ctypes
 import os
-from ctypes import c_double, c_int, c_int64, c_size_t, c_uint16, c_void_p
+from ctypes import c_double, c_int, c_int32, c_int64, c_size_t, c_uint16, c_uint32, c_void_p
 
 import torch  # noqa: F401  -- loads torch's own libamdhip64.so first so that ours binds to the same HIP runtime
 
@@ -25,6 +25,40 @@ lib = ctypes.CDLL(LIB_PATH)
 P = c_void_p
 PD = ctypes.POINTER(c_double)
 PI64 = ctypes.POINTER(c_int64)
+
+
+class ScanRequest(ctypes.Structure):
+    """shg_scan_request (include/shg_hip.h); pointers as plain addresses."""
+    _fields_ = [('struct_bytes', c_uint32), ('start_phase', c_int32),
+                ('stack', P), ('n_frames', c_int64), ('height', c_int64), ('width', c_int64), ('frame_stride_px', c_int64),
+                ('bytes_per_px', c_int32), ('flip_x', c_int32),
+                ('host_shifts', P), ('host_requested', P), ('n_shifts', c_int32), ('want_fit_image', c_int32),
+                ('ratio_fixe', c_double), ('slant_fix_deg', c_double),
+                ('transversalium', c_int32), ('keep_detrans', c_int32), ('trans_strength', c_int64),
+                ('host_taps', P), ('taps_window', c_int64),
+                ('crop_square', c_int32), ('has_fixed_width', c_int32), ('fixed_width', c_int64),
+                ('disk_display', c_int32), ('tiles', c_int32), ('delta_radius', c_int64), ('clip_limit', c_double),
+                ('host_gauss_taps', P),
+                ('mean_out', P), ('max_out', P), ('disks', P), ('disk_pitch', c_int64), ('disk_plane_stride', c_int64),
+                ('minmax_slots', P), ('arena', P), ('arena_bytes', c_size_t), ('results', P), ('results_bytes', c_size_t), ('workspace', P), ('workspace_bytes', c_size_t),
+                ('host_pinned', P), ('host_pinned_bytes', c_size_t),
+                ('host_fit', P), ('host_trace_sharp', P), ('host_mask_good', P), ('host_points', P), ('host_flags', P),
+                ('points_cap', c_int64), ('host_outline200', P), ('host_factors', P)]
+
+
+class ScanResult(ctypes.Structure):
+    """shg_scan_result (include/shg_hip.h)."""
+    _fields_ = [('phase_done', c_int32), ('limb_fitted', c_int32), ('y1', c_int64), ('y2', c_int64), ('p4', c_double * 4),
+                ('counts3', c_int64 * 3), ('geom16', c_double * 16), ('phi', c_double), ('ratio', c_double),
+                ('h_first', c_double * 3), ('h_rest', c_double * 3), ('theta_first', c_double), ('theta_rest', c_double),
+                ('circle3', c_double * 3), ('borders4', c_double * 4), ('circle_out3', c_double * 3),
+                ('out_h', c_int64), ('out_w', c_int64), ('frame_pitch', c_int64),
+                ('n_out', c_int64), ('prod_w', c_int64), ('prod_pitch', c_int64), ('window', c_int64),
+                ('crop4', c_int64 * 4), ('disc3', c_int64 * 3),
+                ('fit_image_off', c_int64), ('frames_off', c_int64), ('detrans_off', c_int64), ('products_off', c_int64),
+                ('results_off', c_int64), ('needed_arena_bytes', c_size_t), ('needed_results_bytes', c_size_t), ('needed_workspace_bytes', c_size_t)]
+
+
 SIGNATURES = {
     'shg_abi_version': (c_int, []),
     'shg_last_error_string': (ctypes.c_char_p, []),
@@ -109,6 +143,16 @@ SIGNATURES = {
     'shg_stage_process_frames': (c_int, [P, c_int64, c_int64, c_int64, c_int64, c_int, P, P, P, c_int64, P, c_int64, c_int64, c_int64,
                                          c_int64, c_double, c_int, c_int64, c_int64, c_int64, P, c_int64, P, P, P, P, P, c_int64, P, c_size_t,
                                          P, c_size_t, P]),
+    # ---- one scan, one call; streams ----
+    'shg_scan_workspace_bytes': (c_size_t, [ctypes.POINTER(ScanRequest)]),
+    'shg_scan_host_bytes': (c_size_t, [ctypes.POINTER(ScanRequest)]),
+    'shg_scan_file': (c_int, [ctypes.POINTER(ScanRequest), ctypes.POINTER(ScanResult), P]),
+    'shg_host_set_savgol_taps': (c_int, [P]),
+    'shg_device_cu_count': (c_int, [ctypes.POINTER(c_int)]),
+    'shg_stream_create': (c_int, [c_int, P, c_int, ctypes.POINTER(c_void_p)]),
+    'shg_stream_destroy': (c_int, [P]),
+    'shg_frame_pass_lane_set': (c_int, [P]),
+    'shg_frame_pass_lane_get': (c_void_p, []),
     # ---- host control plane (host pointers; numpy arrays are passed by address) ----
     'shg_host_bind_lapack': (c_int, [P]),
     'shg_host_lapack_bound': (c_int, []),
@@ -137,7 +181,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 if lib.shg_abi_version() != ABI_VERSION:
     raise ImportError('libshg_hip.so ABI %d != expected %d: rebuild it' % (lib.shg_abi_version(), ABI_VERSION))
 
@@ -218,6 +262,33 @@ def _numpy_mode_pick(neg_counts, n):
 
 
 lib.shg_host_set_mode_pick(ctypes.cast(_numpy_mode_pick, c_void_p))
+
+
+_taps_error = {}          # thread id -> the exception SciPy raised inside the callback (re-raised by the caller of the C entry point)
+
+
+@ctypes.CFUNCTYPE(c_int, c_int64, ctypes.POINTER(c_double))
+def _savgol_taps(window, out):
+    """scipy.signal.savgol_coeffs(window, 3) for shg_scan_file, when the window differs from the one the request carried
+    taps for (a scan with few sunlit rows; solex_util.py:400).  SciPy's own exception is kept for the caller."""
+    import threading
+    try:
+        from .solex_util import savgol_taps
+        taps = savgol_taps(int(window))
+        ctypes.memmove(out, taps.ctypes.data, taps.size * 8)
+        return 0
+    except Exception as e:      # noqa: BLE001
+        _taps_error[threading.get_ident()] = e
+        return -4 if isinstance(e, ValueError) else -7
+
+
+lib.shg_host_set_savgol_taps(ctypes.cast(_savgol_taps, c_void_p))
+
+
+def take_callback_error():
+    """The exception a registered callback met on this thread during the last C call, if any."""
+    import threading
+    return _taps_error.pop(threading.get_ident(), None)
 
 
 def profile_enable(on=True, only=None):

@@ -424,15 +424,36 @@ extern "C" int shg_accumulate_sum_max(const void* stack, int64_t n_frames, int64
     return shg::check_launch("k_reduce_partials");
 }
 
+namespace {
+struct PassA {
+    const void* stack;
+    int64_t n_frames, height, width;
+    int bytes_per_px;
+    int64_t frame_stride_px;
+    void* workspace;
+    size_t workspace_bytes;
+    Plan p;
+    uint32_t* psum;
+    uint16_t* pmax;
+};
+int launch_pass_a(hipStream_t st, void* arg) {
+    PassA* a = static_cast<PassA*>(arg);
+    return accumulate_partials(a->stack, a->n_frames, a->height, a->width, a->bytes_per_px, a->frame_stride_px, a->workspace, a->workspace_bytes,
+                               reinterpret_cast<shg_stream_t>(st), &a->p, &a->psum, &a->pmax);
+}
+}  // namespace
+
+// Pass A goes through the frame-pass lane when the process has one (streams.hip): the passes of all scans in flight run
+// one after the other there instead of halving each other's bandwidth.  Only the pass itself: its partials live in the
+// caller's workspace, which no other stream touches, while mean_out / max_out may be memory the caller's stream has
+// only just let go of -- the finalising kernel stays on `stream`, behind the lane's event.
 extern "C" int shg_accumulate_mean_max(const void* stack, int64_t n_frames, int64_t height, int64_t width, int bytes_per_px,
                                        int64_t frame_stride_px, uint16_t* mean_out, uint16_t* max_out, void* workspace,
                                        size_t workspace_bytes, shg_stream_t stream) {
     SHG_REQUIRE(mean_out && max_out, SHG_E_ARG, "shg_accumulate_mean_max: null pointer");
-    Plan p;
-    uint32_t* psum;
-    uint16_t* pmax;
-    if (int e = accumulate_partials(stack, n_frames, height, width, bytes_per_px, frame_stride_px, workspace, workspace_bytes, stream, &p, &psum, &pmax)) return e;
-    return launch_finalize(FromPartials{psum, pmax, p.nsplit, p.npix}, n_frames, height, width, bytes_per_px, mean_out, max_out, shg::as_stream(stream));
+    PassA a{stack, n_frames, height, width, bytes_per_px, frame_stride_px, workspace, workspace_bytes, Plan{}, nullptr, nullptr};
+    if (int e = shg::on_frame_pass_lane(shg::as_stream(stream), launch_pass_a, &a)) return e;
+    return launch_finalize(FromPartials{a.psum, a.pmax, a.p.nsplit, a.p.npix}, n_frames, height, width, bytes_per_px, mean_out, max_out, shg::as_stream(stream));
 }
 
 extern "C" int shg_finalize_mean_max(const uint64_t* sum, const uint16_t* max_raw, int64_t n_total,

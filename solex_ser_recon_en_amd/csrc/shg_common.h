@@ -28,6 +28,10 @@ inline int check_launch(const char* what) {
 
 inline hipStream_t as_stream(shg_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// The frame-pass lane (streams.hip): launch(stream, arg) runs on the current device's lane when one is set -- `st` then
+// waits for it through an event -- and on `st` itself otherwise.
+int on_frame_pass_lane(hipStream_t st, int (*launch)(hipStream_t, void*), void* arg);
+
 // Optional per-kernel timing with HIP events recorded on the launch stream, right around
 // the launch (bench.py's roofline leg).  Disabled by default: no events, no overhead.
 struct ProfScope {

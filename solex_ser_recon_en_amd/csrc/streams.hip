@@ -1,0 +1,116 @@
+// Streams of a scan worker pool, and the frame-pass lane.
+//
+// The reference overlaps up to four files (Pool(4), Solex_recon.py:30-42).  Here every scan in flight has a stream of
+// its own, and what the scans share is the device.  Two facts decide how they should share it:
+//   * pass A (k_accumulate_vec, 1.6 GB at C2) is bound by HBM: two of them side by side each take twice as long,
+//     nothing is gained, and every later kernel of both scans starts later;
+//   * everything else of a scan is a chain of small, latency-bound kernels that leave HBM almost idle.
+// So pass A of ALL scans goes through one stream -- the lane -- where they run back to back in the order the scans
+// asked, each alone with the small kernels of the other scans, and the chains run on the workers' own streams
+// (optionally confined to a subset of the CUs, hipExtStreamCreateWithCUMask).  A scan's stream waits for its pass A
+// through an event; nothing is synchronised on the host.
+#include <mutex>
+#include <vector>
+#include "shg_common.h"
+
+namespace shg {
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_lane_mu;                         // guards g_lanes, and keeps one scan's (launch, record) pair together
+hipStream_t g_lanes[kMaxDevices] = {};
+struct LaneEvents {
+    hipEvent_t ev[kMaxDevices] = {};
+    ~LaneEvents() {
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+};
+thread_local LaneEvents t_events;             // one event per (thread, device): a thread has one pass A pending at most
+}  // namespace
+
+hipStream_t frame_pass_lane(int device) {
+    if (device < 0 || device >= kMaxDevices) return nullptr;
+    return g_lanes[device];                   // read without the lock: set once per process before the workers start
+}
+
+// Launch `launch(stream)` on the device's lane when there is one (and make `st` wait for it), else on `st`.
+int on_frame_pass_lane(hipStream_t st, int (*launch)(hipStream_t, void*), void* arg) {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) device = -1;
+    hipStream_t lane = frame_pass_lane(device);
+    if (!lane || lane == st) return launch(st, arg);
+    hipEvent_t& ev = t_events.ev[device];
+    if (!ev) {
+        hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) { ev = nullptr; set_error("frame-pass lane: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    if (int e = launch(lane, arg)) return e;
+    hipError_t e = hipEventRecord(ev, lane);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st, ev, 0);
+    if (e != hipSuccess) { set_error("frame-pass lane: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+}  // namespace shg
+
+extern "C" int shg_device_cu_count(int* out) {
+    SHG_REQUIRE(out, SHG_E_ARG, "shg_device_cu_count: null pointer");
+    int device = 0, n = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device);
+    if (e != hipSuccess) { shg::set_error("shg_device_cu_count: %s", hipGetErrorString(e)); return (int)e; }
+    *out = n;
+    return 0;
+}
+
+extern "C" int shg_stream_create(int priority, const uint32_t* host_cu_mask, int n_mask_words, shg_stream_t* out) {
+    SHG_REQUIRE(out, SHG_E_ARG, "shg_stream_create: null pointer");
+    SHG_REQUIRE((host_cu_mask == nullptr) == (n_mask_words == 0) && n_mask_words >= 0, SHG_E_ARG, "shg_stream_create: mask and its length go together");
+    hipStream_t st = nullptr;
+    hipError_t e;
+    if (host_cu_mask) {
+        bool any = false;
+        for (int i = 0; i < n_mask_words; ++i) any = any || host_cu_mask[i] != 0;
+        SHG_REQUIRE(any, SHG_E_ARG, "shg_stream_create: empty CU mask");
+        e = hipExtStreamCreateWithCUMask(&st, (uint32_t)n_mask_words, host_cu_mask);
+    } else {
+        int least = 0, greatest = 0;                              // numerically: greatest priority <= least priority
+        e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (e == hipSuccess) {
+            const int p = priority < 0 ? greatest : (priority > 0 ? least : (least + greatest) / 2);
+            e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, p);
+        }
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); shg::set_error("shg_stream_create: %s", hipGetErrorString(e)); return (int)e; }
+    *out = st;
+    return 0;
+}
+
+extern "C" int shg_stream_destroy(shg_stream_t stream) {
+    hipStream_t st = shg::as_stream(stream);
+    if (!st) return 0;
+    {
+        std::lock_guard<std::mutex> lk(shg::g_lane_mu);
+        for (hipStream_t& l : shg::g_lanes)
+            if (l == st) l = nullptr;
+    }
+    hipError_t e = hipStreamDestroy(st);
+    if (e != hipSuccess) { shg::set_error("shg_stream_destroy: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
+extern "C" int shg_frame_pass_lane_set(shg_stream_t lane) {
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) { shg::set_error("shg_frame_pass_lane_set: %s", hipGetErrorString(e)); return (int)e; }
+    SHG_REQUIRE(device >= 0 && device < shg::kMaxDevices, SHG_E_UNSUPPORTED, "shg_frame_pass_lane_set: device %d", device);
+    std::lock_guard<std::mutex> lk(shg::g_lane_mu);
+    shg::g_lanes[device] = shg::as_stream(lane);
+    return 0;
+}
+
+extern "C" shg_stream_t shg_frame_pass_lane_get(void) {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return nullptr;
+    return shg::frame_pass_lane(device);
+}

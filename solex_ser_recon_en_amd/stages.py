@@ -232,3 +232,143 @@ def process_frames(frames, transversalium=None, crop=None, disc=None, clip_limit
         ws.data_ptr(), ws.numel(), pin.data_ptr(), pin.numel(), ops._stream()), 'shg_stage_process_frames')
     return {'final': views[0], 'cl1': views[1], 'hc': views[2], 'protus': views[3], 'cc': views[4], 'factors': factors,
             'detrans': detrans}
+
+
+# ---- one scan, one call ---------------------------------------------------------------------------------------------
+_arena_hint = {}          # (S, k, ih, n, crop, detrans, fit image) -> (arena bytes, results bytes, workspace bytes) the last such scan needed
+_NAN = float('nan')
+FIRST_GUESS_SCALE = 1.05      # width of the corrected images a first scan of a shape is assumed to have, in raw-disk widths
+
+
+def _plane(buf, off, h, pitch, w):
+    """A uint16 image [h, w] (rows `pitch` elements apart) at byte offset `off` of a uint8 arena."""
+    return buf[off:off + h * pitch * 2].view(torch.uint16).view(h, pitch)[:, :w]
+
+
+def scan_file(stack, shifts, requested, options, taps_for, want_plot_data=False, want_fit_image=False):
+    """The whole per-file flow as ONE C call (shg_scan_file, csrc/scan.hip): pass A, line fit, extraction, limb fit (or the
+    fixed ratio / slant of `options`), the warp of every requested disk, transversalium, crop, CLAHE, contrast products.
+    stack: the frame stack in HBM; shifts: options['shift'] after solex_read's de-duplication; requested: one flag per
+    shift; taps_for(window) -> savgol_coeffs(window, 3).
+    -> (dict of everything the phases that ran produced, error or None): the caller logs what was reached, then raises."""
+    n, h, w, bpp = ops.stack_geometry(stack)
+    dev = stack.device
+    ih, iw = (w, h) if w > h else (h, w)
+    sh = np.ascontiguousarray(shifts, dtype=np.int32)
+    rqd = np.ascontiguousarray(requested, dtype=np.uint8)
+    s, k = int(sh.size), int(rqd.sum())
+    ratio_fixe, slant_fix = options['ratio_fixe'], options['slant_fix']
+    limb = ratio_fixe is None and slant_fix is None
+    trans = bool(options['transversalium'])
+    keep_detrans = bool(options['save_fit'] and trans)
+    fit_image = bool(want_fit_image and not rqd[0])
+
+    images = torch.empty((2, ih, iw), dtype=torch.uint16, device=dev)
+    pitch = (n + 63) // 64 * 64
+    disks = torch.empty((s, ih, pitch), dtype=torch.uint16, device=dev)
+    mm_store = torch.empty(s * 130, dtype=torch.int32, device=dev)
+    fit = np.empty((ih, 4))
+    sharp = np.empty(ih, dtype=np.int32) if want_plot_data else None
+    mask = np.zeros(ih, dtype=np.uint8) if want_plot_data else None
+    cap = (-(-ih // 4)) * (-(-n // 4))
+    points = np.empty((cap, 2), dtype=np.int32) if limb else None
+    flags = np.empty(cap, dtype=np.uint8) if limb else None
+    outline = np.empty((100, 2)) if (limb and want_plot_data) else None
+    factors = np.empty((k, ih)) if (trans and k) else None
+    gauss = _canny_ladder_taps()
+    ts = int(options['trans_strength'])
+    taps = taps_for(ts) if trans and ts > 3 and ts % 2 == 1 else None       # the usual window; any other one: the callback
+
+    rq = _lib.ScanRequest()
+    rq.struct_bytes = ctypes.sizeof(_lib.ScanRequest)
+    rq.stack, rq.n_frames, rq.height, rq.width, rq.frame_stride_px, rq.bytes_per_px = stack.data_ptr(), n, h, w, ops.frame_stride(stack), bpp
+    rq.flip_x = int(bool(options['flip_x']))
+    rq.host_shifts, rq.host_requested, rq.n_shifts, rq.want_fit_image = _p(sh), _p(rqd), s, int(fit_image)
+    rq.ratio_fixe = _NAN if ratio_fixe is None else float(ratio_fixe)
+    rq.slant_fix_deg = _NAN if slant_fix is None else float(slant_fix)
+    rq.transversalium, rq.keep_detrans, rq.trans_strength = int(trans), int(keep_detrans), ts
+    rq.host_taps, rq.taps_window = (None, 0) if taps is None else (_p(taps), ts)
+    rq.crop_square = int(bool(options['crop_width_square']))
+    rq.has_fixed_width = int(options['fixed_width'] is not None)
+    rq.fixed_width = 0 if options['fixed_width'] is None else int(options['fixed_width'])
+    rq.disk_display, rq.tiles, rq.delta_radius, rq.clip_limit = int(bool(options['disk_display'])), 2, int(options['delta_radius']), 0.8
+    rq.host_gauss_taps = _p(gauss)
+    rq.mean_out, rq.max_out = images[0].data_ptr(), images[1].data_ptr()
+    rq.disks, rq.disk_pitch, rq.disk_plane_stride, rq.minmax_slots = disks.data_ptr(), pitch, ih * pitch, mm_store.data_ptr()
+    rq.host_fit = _p(fit)
+    rq.host_trace_sharp, rq.host_mask_good = (None, None) if sharp is None else (_p(sharp), _p(mask))
+    rq.host_points, rq.host_flags, rq.points_cap = (None, None, 0) if points is None else (_p(points), _p(flags), cap)
+    rq.host_outline200 = None if outline is None else _p(outline)
+    rq.host_factors = None if factors is None else _p(factors)
+
+    key = (s, k, ih, n, bpp, bool(options['crop_width_square']), options['fixed_width'], keep_detrans, fit_image, limb)
+    hint = _arena_hint.get(key)
+    if hint is None:
+        # first scan of this shape: corrected images about as wide as the raw disk (Y/X ratio near 1)
+        guess_w = (int(n * FIRST_GUESS_SCALE) + 127) // 64 * 64
+        prod_w = max(guess_w, ih if options['crop_width_square'] else 0, rq.fixed_width)
+        hint = ((k * (1 + keep_detrans) + fit_image) * ih * guess_w * 2 + k * 3 * ih * prod_w * 2 + (1 << 16), k * 2 * ih * prod_w * 2 + 4096,
+                lib.shg_scan_workspace_bytes(ctypes.byref(rq)) + (lib.shg_stage_process_workspace_bytes(k, ih, guess_w, prod_w, 2) if k else 0) + 4096)
+    pin = _scratch('scan', _sizes('scan_pin', lambda *a: lib.shg_scan_host_bytes(ctypes.byref(rq)), s, k, n, h, w, bpp, limb), pinned=True)
+    rs = _lib.ScanResult()
+    stream = ops._stream()
+    status = None
+    while True:
+        arena = torch.empty(max(hint[0], 256), dtype=torch.uint8, device=dev)
+        results = torch.empty(max(hint[1], 256), dtype=torch.uint8, device=dev)
+        ws = _scratch('scan', hint[2], dev)
+        rq.arena, rq.arena_bytes, rq.results, rq.results_bytes = arena.data_ptr(), arena.numel(), results.data_ptr(), results.numel()
+        rq.workspace, rq.workspace_bytes, rq.host_pinned, rq.host_pinned_bytes = ws.data_ptr(), ws.numel(), pin.data_ptr(), pin.numel()
+        status = lib.shg_scan_file(ctypes.byref(rq), ctypes.byref(rs), stream)
+        if status == -2 and rs.phase_done == 3 and rq.start_phase == 0:
+            hint = (rs.needed_arena_bytes + 4096, rs.needed_results_bytes + 4096, rs.needed_workspace_bytes + 4096)
+            rq.start_phase = 3                                 # the raw disks and the geometry stay: resume at the warp
+            continue
+        break
+    if rs.phase_done >= 3:
+        # a little headroom: the next file's ellipse differs in the third digit, its images by a few columns
+        _arena_hint[key] = (int(rs.needed_arena_bytes * 1.03) + 4096, int(rs.needed_results_bytes * 1.03) + 4096,
+                            int(rs.needed_workspace_bytes * 1.03) + 4096)
+    error = None
+    if status != 0:
+        error = _lib.take_callback_error()
+        if error is None:
+            try:
+                _lib.check(status, 'shg_scan_file')
+            except Exception as e:      # noqa: BLE001 -- handed to the caller, which logs what the scan reached first
+                error = e
+    out = {'phase': int(rs.phase_done), 'mean': images[0], 'max': images[1], 'fit': fit, 'limb_fitted': bool(rs.limb_fitted)}
+    if rs.phase_done >= 1:
+        y1, y2 = int(rs.y1), int(rs.y2)
+        out.update(y1=y1, y2=y2, p=np.array(rs.p4))
+        if want_plot_data:
+            out['sharp'] = sharp
+            out['mask_good'] = mask[:max(y2 - y1, 0)].astype(bool)
+    if rs.phase_done >= 2:
+        out['disks'] = disks[:, :, :n]
+        out['extrema'] = mm_store[s * 128:].view(s, 2)
+    if rs.phase_done >= 3:
+        g = rs.geom16
+        out.update(phi=float(rs.phi), ratio=float(rs.ratio), theta_first=float(rs.theta_first), theta_rest=float(rs.theta_rest),
+                   circle=tuple(float(v) for v in rs.circle3), borders=[float(v) for v in rs.borders4],
+                   circle_out=tuple(float(v) for v in rs.circle_out3), out_h=int(rs.out_h), out_w=int(rs.out_w))
+        if rs.limb_fitted and want_plot_data:
+            m = int(rs.counts3[0])
+            pts, fl = points[:m].astype(np.int64) * 4, flags[:m]
+            out.update(raw_X=pts, X_f=pts[(fl & 2) != 0].astype(float), outline=outline)
+        if rs.limb_fitted:
+            out['center'] = (float(g[0]), float(g[1]))
+            out['height'] = float(g[2])
+    if rs.phase_done >= 4:
+        oh, ow, fp, pw, pp = int(rs.out_h), int(rs.out_w), int(rs.frame_pitch), int(rs.prod_w), int(rs.prod_pitch)
+        fb = (oh * fp * 2 + 255) // 256 * 256
+        pb = (oh * pp * 2 + 255) // 256 * 256
+        out['fit_image'] = _plane(arena, int(rs.fit_image_off), oh, fp, ow) if rs.fit_image_off >= 0 else None
+        out['frames'] = [_plane(arena, int(rs.frames_off) + j * fb, oh, fp, ow) for j in range(k)]
+        out['detrans'] = [_plane(arena, int(rs.detrans_off) + j * fb, oh, fp, ow) for j in range(k)] if rs.detrans_off >= 0 else None
+        for idx, name in enumerate(('final', 'cl1', 'hc')):
+            out[name] = [_plane(arena, int(rs.products_off) + (j * 3 + idx) * pb, oh, pp, pw) for j in range(k)]
+        for idx, name in enumerate(('protus', 'cc')):
+            out[name] = [_plane(results, (j * 2 + idx) * pb, oh, pp, pw) for j in range(k)]
+        out['factors'] = factors
+    return out, error

@@ -659,3 +659,106 @@ def test_log_file_text_matches_the_reference(pkg, scan, tmp_path, tag):
     got = [ln for ln in text if not ln.startswith(('start time', 'end time'))]
     want = str(g[tag + '_log']).splitlines()
     assert got == want, '\n'.join(['--- got'] + got + ['--- want'] + want)
+
+
+ONE_CALL_CASES = {
+    'plain': {},
+    'doppler_flip_square': {'shift': [-2, 0, 3], 'flip_x': True, 'crop_width_square': True},
+    'fit_shift_requested': {'shift': [10, 0, 1]},                   # the ellipse-fit disk is a product too
+    'fixed_ratio': {'ratio_fixe': 1, 'fixed_width': 300, 'disk_display': False, 'img_rotate': 90},
+    'fixed_slant': {'slant_fix': 1.5, 'shift': [0, 2]},
+    'fixed_both': {'ratio_fixe': 0.97, 'slant_fix': -2.0, 'delta_radius': 4},
+    'no_transversalium': {'transversalium': False, 'fixed_width': 520},
+    'short_trend': {'trans_strength': 21, 'shift': [0, 10]},
+    'even_window': {'trans_strength': 300},                          # not the window the request carries taps for
+}
+
+
+def _run_route(pkg, frames, tmp_path, name, extra, one_call, monkeypatch, files):
+    SHG_MAIN, Solex_recon, outputs = pkg
+    from solex_ser_recon_en_amd.video_reader import array_reader
+    monkeypatch.setenv('SHG_SCAN_CALL', '1' if one_call else '0')
+    opts = SHG_MAIN.default_options()
+    opts.update(extra)
+    if files:
+        d = tmp_path / ('%s_%d' % (name, one_call))
+        d.mkdir()
+        work = str(d / 'scan.ser')
+        synth.write_ser(work, frames)
+        opts.update(save_fit=True)
+        src = work
+    else:
+        opts.update(_nolog=True)
+        src = array_reader(torch.from_numpy(frames).cuda())
+    err = None
+    res = None
+    try:
+        (res,) = Solex_recon.solex_do_work([(src, opts)], True, return_results=True)
+    except Exception as e:      # noqa: BLE001
+        err = e
+    outputs.flush()
+    torch.cuda.synchronize()
+    images = None if res is None else [(np.asarray(cc), np.asarray(pr)) for cc, pr in res]
+    listing, log = None, None
+    if files:
+        listing = sorted(os.listdir(str(d)))
+        log = [ln for ln in open(work[:-4] + '_log.txt').read().splitlines() if not ln.startswith(('start time', 'end time'))]
+    return images, opts, err, listing, log, (str(d) if files else None)
+
+
+@pytest.mark.parametrize('name', sorted(ONE_CALL_CASES))
+def test_one_call_route_equals_the_stage_route(pkg, scan, tmp_path, monkeypatch, name):
+    """shg_scan_file (one C call per file, the default of solex_do_work) against the stage-by-stage route
+    (SHG_SCAN_CALL=0): products bit for bit, the same `options` side effects, and -- with files on -- the same set of
+    files, the same log text and byte-identical FITS / PNG products."""
+    g, frames, path = scan
+    extra = ONE_CALL_CASES[name]
+    files = name in ('plain', 'doppler_flip_square', 'fixed_ratio')
+    a_img, a_opts, a_err, a_ls, a_log, a_dir = _run_route(pkg, frames, tmp_path, name, extra, False, monkeypatch, files)
+    b_img, b_opts, b_err, b_ls, b_log, b_dir = _run_route(pkg, frames, tmp_path, name, extra, True, monkeypatch, files)
+    assert a_err is None and b_err is None, (a_err, b_err)
+    assert len(a_img) == len(b_img) and len(a_img) == len(extra.get('shift', [0]))
+    for (cc1, p1), (cc2, p2) in zip(a_img, b_img):
+        np.testing.assert_array_equal(cc1, cc2)
+        np.testing.assert_array_equal(p1, p2)
+    for key in ('ratio_fixe', 'slant_fix', 'shift', 'shift_requested'):
+        assert a_opts[key] == b_opts[key], key
+    if a_opts['transversalium']:
+        np.testing.assert_array_equal(a_opts['_transversalium_cache'], b_opts['_transversalium_cache'])
+    if files:
+        assert a_ls == b_ls and a_log == b_log
+        for f in a_ls:
+            if f.endswith(('.fits', '_clahe.png', '_protus.png', '_uncontrasted.png', '_high_contrast.png')):
+                assert open(os.path.join(a_dir, f), 'rb').read() == open(os.path.join(b_dir, f), 'rb').read(), f
+
+
+def test_one_call_route_resumes_when_its_arena_guess_was_too_small(pkg, scan, monkeypatch):
+    """The corrected images' size is only known after the limb fit: a first guess that is too small makes shg_scan_file
+    return SHG_E_WORKSPACE with the sizes it needs, and the second call resumes at the warp -- same products."""
+    from solex_ser_recon_en_amd import stages
+    g, frames, path = scan
+    want, _, err, _, _, _ = _run_route(pkg, frames, None, 'resume', {'shift': [0, 2]}, True, monkeypatch, False)
+    assert err is None
+    monkeypatch.setattr(stages, 'FIRST_GUESS_SCALE', 0.1)
+    stages._arena_hint.clear()
+    got, _, err, _, _, _ = _run_route(pkg, frames, None, 'resume', {'shift': [0, 2]}, True, monkeypatch, False)
+    assert err is None and len(stages._arena_hint) == 1
+    for (cc1, p1), (cc2, p2) in zip(want, got):
+        np.testing.assert_array_equal(cc1, cc2)
+        np.testing.assert_array_equal(p1, p2)
+    stages._arena_hint.clear()
+
+
+@pytest.mark.parametrize('name', ['noise_only', 'tiny_disk', 'few_rows'])
+def test_one_call_route_fails_like_the_stage_route(pkg, tmp_path, monkeypatch, name):
+    """A scan that fails half-way: the same exception type and message from both routes, and the same log lines up to
+    the failure (the one-call route writes them after the call, from what the call reached)."""
+    base = synth.synth_frames_numpy(400, 400, 32, 16, seed=1, tilt=0.01, curv=5e-5)
+    frames = {'noise_only': np.random.default_rng(0).integers(0, 3000, base.shape).astype(np.uint16),
+              'tiny_disk': synth.synth_frames_numpy(400, 400, 32, 16, seed=1, scene=dict(ax=20.0, ay=20.0)),
+              'few_rows': synth.synth_frames_numpy(400, 90, 32, 16, seed=1, tilt=0.01, curv=5e-5)}[name]
+    _, _, a_err, a_ls, a_log, _ = _run_route(pkg, frames, tmp_path, name, {}, False, monkeypatch, True)
+    _, _, b_err, b_ls, b_log, _ = _run_route(pkg, frames, tmp_path, name, {}, True, monkeypatch, True)
+    assert a_err is not None and b_err is not None
+    assert type(a_err) is type(b_err) and str(a_err) == str(b_err)
+    assert a_log == b_log
