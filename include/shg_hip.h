@@ -58,6 +58,11 @@ int shg_profile_select(const char* tags_csv);   /* only time these tags (NULL or
 int shg_profile_reset(void);
 int shg_profile_get(const char* tag, double* total_ms, int64_t* launches);
 int shg_profile_total(double* total_ms, int64_t* launches);   /* every timed entry point since the last reset */
+/* Where a scan worker's HOST time goes inside the stage composites (waiting in stream synchronises, control-plane routines):
+ * wall clock per section tag while enabled; the report is "tag seconds calls" lines.  Measurement aid (tools/host_budget.py). */
+int shg_host_timing_enable(int on);
+int shg_host_timing_report(char* buf, size_t cap);
+int shg_profile_dump(const char* path);   /* "tag,stream,start_ms,stop_ms" per sample: the streams' timeline without a profiler */
 
 /* Measurement aid: trivial read-only kernels over `bytes` bytes (16 B/lane non-temporal loads, XOR-folded;
  * out1024: 1024 uint32 words) that bench.py times to quote MEASURED read ceilings beside the spec peak
@@ -524,6 +529,20 @@ int shg_scan_file(const shg_scan_request* req, shg_scan_result* res, shg_stream_
  * code (SHG_E_VALUE where SciPy raises ValueError). */
 typedef int (*shg_savgol_taps_fn)(int64_t window, double* out);
 int shg_host_set_savgol_taps(shg_savgol_taps_fn fn);
+
+/* ==== scan pool ===================================================================================
+ * The reference's Pool(4) (Solex_recon.py:30-42) as native threads: n_workers threads of the current device, thread k
+ * with streams[k], run the submitted shg_scan_file requests in submission order; host_cpus (may be NULL) is where the
+ * threads should run.  The request, its buffers and the result must stay alive until shg_pool_wait has returned for the
+ * ticket; by then the scan's last kernel has run (the worker synchronises its stream).  shg_pool_wait: blocks until the
+ * ticket is done, -> *scan_status = what shg_scan_file returned, error_buf = its message.  shg_pool_poll: 1 done, 0 not yet.
+ * shg_pool_destroy runs what is queued, then joins the threads. */
+typedef struct shg_pool shg_pool;
+int shg_pool_create(const shg_stream_t* streams, int n_workers, const int32_t* host_cpus, int n_cpus, shg_pool** out);
+int shg_pool_submit(shg_pool* pool, const shg_scan_request* req, shg_scan_result* res, int64_t* ticket);
+int shg_pool_poll(shg_pool* pool, int64_t ticket);
+int shg_pool_wait(shg_pool* pool, int64_t ticket, int* scan_status, char* error_buf, size_t error_cap);
+int shg_pool_destroy(shg_pool* pool);
 
 /* ==== streams of a scan worker pool ==============================================================
  * The reference post-processes up to four files at once (Pool(4), Solex_recon.py:30-42).  Scans in flight share one

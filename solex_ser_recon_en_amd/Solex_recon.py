@@ -168,14 +168,17 @@ def solex_do_work(tasks, flag_command_line=False, distribute='auto', return_resu
         return [] if return_results else None
     n_workers = 1 if shard_frames else _worker_count(workers, len(tasks))
     cpu_plan()                                              # on this thread, before any worker asks (torch's device queries
-    decoder = _Decoder(tasks, dist.frame_block if shard_frames else None, ahead=n_workers + 1)      # are not re-entrant at first use)
+    native = n_workers > 1 and os.environ.get('SHG_SCAN_POOL', 'native') != 'threads'             # are not re-entrant at first use)
+    # decoded stacks waiting for a scan: the native pool holds its in-flight scans' stacks itself (workers + 2), so two ahead
+    decoder = _Decoder(tasks, dist.frame_block if shard_frames else None, ahead=2 if native else n_workers + 1)
     collected = [None] * len(tasks)
 
-    def scan(i):
+    def scan(i, rdr=None):
         file, options = tasks[i]
-        print('file %s is processing' % file)
-        options['_shard_frames'] = shard_frames
-        rdr = decoder.get(i)
+        if rdr is None:
+            print('file %s is processing' % file)
+            options['_shard_frames'] = shard_frames
+            rdr = decoder.get(i)
         if shard_frames:
             _check_shardable(rdr)
         if _one_call_ok(rdr, options):
@@ -204,6 +207,9 @@ def solex_do_work(tasks, flag_command_line=False, distribute='auto', return_resu
             finally:
                 if previous is not None:
                     os.sched_setaffinity(0, previous)
+        elif native:
+            _ensure_lane(decoder.device)
+            _scan_batch_native(tasks, decoder, n_workers, scan, collected if return_results else None)
         else:
             _ensure_lane(decoder.device)
             _scan_pool(scan, len(tasks), n_workers, decoder.device)
@@ -308,6 +314,80 @@ def _worker_context(device, k):
     return ctx
 
 
+_native_pools = {}             # (device, workers) -> shg_pool handle; the threads live as long as the process
+
+
+def _native_pool(device, n_workers):
+    """The native scan pool of this device (csrc/pool.hip): n_workers threads, thread k on worker k's stream, placed on the
+    cpus the scan workers are meant to run on (device.cpu_plan)."""
+    import ctypes
+    import torch
+    from ._lib import check, lib
+    key = (str(device), n_workers)
+    pool = _native_pools.get(key)
+    if pool is None:
+        streams = [_worker_context(device, k)['stream'] for k in range(n_workers)]
+        arr = (ctypes.c_void_p * n_workers)(*[st.cuda_stream for st in streams])
+        plan = cpu_plan(device)
+        cpus = sorted(plan['scan']) if plan else []
+        carr = (ctypes.c_int32 * len(cpus))(*cpus) if cpus else None
+        out = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            check(lib.shg_pool_create(arr, n_workers, carr, len(cpus), ctypes.byref(out)), 'shg_pool_create')
+        pool = _native_pools[key] = out
+    return pool
+
+
+def _scan_batch_native(tasks, decoder, n_workers, scan_here, collected):
+    """The files of a batch through the native scan pool: this ONE thread prepares each scan (buffers, options), submits it
+    and, when its turn comes, turns what the pool computed into log lines, files and results -- in file order.  Up to
+    n_workers scans run at once (plus two prepared ones waiting), none of them inside the interpreter.  Files the one-call
+    route does not cover (de-vignette, stubborn transversalium) run here, stage by stage, between the others.
+    The first failure (lowest file index) is re-raised once the scans in flight have finished; no new file starts after it --
+    a batch halts on an unsuitable file, as result.get() makes the reference's (Solex_recon.py:42)."""
+    import collections
+    pool = _native_pool(decoder.device, n_workers)
+    depth = n_workers + 2
+    inflight = collections.deque()
+    errors = []
+    previous = bind_thread('scan', decoder.device)
+
+    def finish_oldest():
+        i, call = inflight.popleft()
+        try:
+            res = call.finish()
+            if collected is not None:
+                collected[i] = res
+        except BaseException as e:      # noqa: BLE001 -- re-raised below, lowest index first
+            errors.append((i, e))
+
+    try:
+        nxt = 0
+        while nxt < len(tasks) and not errors:
+            if len(inflight) >= depth or (inflight and not decoder.ready[nxt].is_set()):
+                finish_oldest()                             # nothing to submit yet: collect (waits for the oldest scan in flight)
+                continue
+            i, nxt = nxt, nxt + 1
+            file, options = tasks[i]
+            try:
+                print('file %s is processing' % file)
+                options['_shard_frames'] = False
+                rdr = decoder.get(i)
+                if _one_call_ok(rdr, options):
+                    inflight.append((i, _OneCall(rdr, options, pooled=True).submit(pool)))
+                else:
+                    scan_here(i, rdr)
+            except BaseException as e:      # noqa: BLE001
+                errors.append((i, e))
+        while inflight:
+            finish_oldest()
+    finally:
+        if previous is not None:
+            os.sched_setaffinity(0, previous)
+    if errors:
+        raise min(errors, key=lambda ie: ie[0])[1]
+
+
 def _scan_pool(scan, n_tasks, n_workers, device):
     """Run scan(0..n_tasks-1) on n_workers threads, each with its own HIP stream (torch's current stream and device
     are thread-local; ops.py launches on the current stream).  Worker k keeps its thread (_Service), stream, device
@@ -379,95 +459,126 @@ def _one_call_ok(rdr, options):
 
 
 def scan_one_call(rdr, options):
-    """solex_read + solex_process for one file as ONE C call (stages.scan_file -> shg_scan_file): the same kernels and the
+    """solex_read + solex_process for one file as ONE C call, on this thread's stream.  -> [(cc, frame_protus), ...]"""
+    return _OneCall(rdr, options).run().finish()
+
+
+class _OneCall:
+    """solex_read + solex_process for one file as ONE C call (stages.ScanCall -> shg_scan_file): the same kernels and the
     same host control plane as the stage-by-stage route, and the same log lines, files and `options` side effects
-    (basefich0, shift_requested, shift, ratio_fixe, slant_fix, _transversalium_cache) -- produced here after the call from
-    what it returned.  A scan that fails half-way leaves the log the reference would have left, then raises.
-    -> [(cc, frame_protus), ...] like solex_process."""
-    from .ellipse_to_circle import _log_geometry, _warp_geometry
-    basefich0 = os.path.splitext(str(rdr.file))[0]
-    options['basefich0'] = basefich0
-    log = basefich0 + '_log.txt'
-    clearlog(log, options)
-    logme(log, options, 'Pixel shift : ' + str(options['shift']))
-    options['shift_requested'] = options['shift']
-    options['shift'] = list(dict.fromkeys([options['ellipse_fit_shift'], 0] + options['shift']))
-    hdr = make_header(rdr)
-    logme(log, options, 'Width, Height : ' + str(rdr.Width) + ' ' + str(rdr.Height))
-    logme(log, options, 'Number of frames : ' + str(rdr.FrameCount))
-    shifts = options['shift']
-    requested = [sh in options['shift_requested'] for sh in shifts]
-    plots = plots_enabled(options)
-    stack = rdr.device_stack()
-    r, error = stages.scan_file(stack, shifts, requested, options, savgol_taps, want_plot_data=plots, want_fit_image=plots)
-    _release_stack(rdr)
-    phase = r['phase']
-    # ---- compute_mean_return_fit's outputs (solex_util.py:191-274) ----
-    if phase >= 1:
-        mean_img = DeviceImage(r['mean'])
-        y1, y2, fit = r['y1'], r['y2'], r['fit']
-        if options['save_fit']:
-            outputs.submit(write_fits, output_path(basefich0 + '_mean.fits', options), mean_img, hdr)
-        logme(log, options, 'Vertical limits y1, y2 : ' + str(y1) + ' ' + str(y2))
-        logme(log, options, lambda: 'Spectral line polynomial fit: ' + str(r['p']))
-        if plots:
-            rows = np.arange(y1, y2)
-            good = r['mask_good']
-            outputs.submit(outputs.plot_spectral_line, output_path(basefich0 + '_spectral_line_data.png', options), mean_img,
-                           r['sharp'].astype(np.int64)[y1:y2][good], rows[good], fit[:, 3], int(rdr.ih), (y2 - y1) // 20 + 1)
-    # ---- the raw disks (Solex_recon.py:65-83) and solex_process's header lines (:95-102) ----
-    disk_list = []
-    if phase >= 2:
-        hdr['NAXIS1'] = rdr.iw
-        disk_list = [DeviceImage(r['disks'][i], minmax=r['extrema'][i]) for i in range(len(shifts))]
-        for i, disk in enumerate(disk_list):
-            if options['save_fit'] and requested[i]:
-                outputs.submit(write_fits, output_path(basefich0 + '_shift=' + str(shifts[i]) + '_raw.fits', options), disk, hdr)
-        if options['transversalium']:
-            logme(log, options, 'Transversalium correction : ' + str(options['trans_strength']))
-        else:
-            logme(log, options, 'Transversalium disabled')
-        logme(log, options, 'Mirror X : ' + str(options['flip_x']))
-        logme(log, options, 'Post-rotation : ' + str(options['img_rotate']) + ' degrees')
-        logme(log, options, f'Protus adjustment : {options["delta_radius"]}')
-        logme(log, options, f'de-vignette : {options["de-vignette"]}')
-    # ---- the geometry: ellipse_to_circle's / correct_image's log lines (ellipse_to_circle.py:131-143, 313) ----
-    if phase >= 3:
-        if r['limb_fitted']:
-            options['ratio_fixe'] = r['ratio']
-            _log_geometry(options, r['phi'], r['ratio'], r['theta_first'], np.array(r['circle'][:2]), r['circle'][2])
-            print('sun borders found:' + str(r['borders']))
-            options['slant_fix'] = math.degrees(r['phi'])
-        elif requested[0] and '_nolog' not in options:
-            # correct_image(..., center (-1, -1), height -1, print_log=True) of the first disk (Solex_recon.py:122)
-            ih_, n_ = disk_list[0].shape
-            theta, inv_mat, _, _, _, origin, det = _warp_geometry(float(r['phi']), float(r['ratio']), int(ih_), int(n_))
-            _log_geometry(options, r['phi'], r['ratio'], theta, (inv_mat @ np.array([-1.0, -1.0]).T).T - origin,
-                          -1.0 * np.sqrt(np.abs(r['ratio'] / det)), known=False)
-    if error is not None:
-        raise error
-    # ---- single_image_process's files (Solex_recon.py:136-174) ----
-    names = [basefich0 + '_shift=' + str(shifts[i]) for i in range(len(shifts)) if requested[i]]
-    if plots and r['limb_fitted']:
-        fix_img = r['frames'][0] if requested[0] else r['fit_image']
-        outputs.submit(outputs.plot_ellipse_fit, output_path(basefich0 + '_shift=' + str(shifts[0]) + '_ellipse_fit.png', options),
-                       disk_list[0], DeviceImage(fix_img), r['raw_X'], r['X_f'], r['outline'], r['borders'])
-    if options['save_fit']:
-        for frame, basefich in zip(r['frames'], names):
-            outputs.submit(write_fits, output_path(basefich + '_circular.fits', options), DeviceImage(frame), hdr)
-    if options['transversalium']:
-        for i, basefich in enumerate(names):
-            c = r['factors'][i]
-            options['_transversalium_cache'] = c
-            if plots:
-                outputs.submit(outputs.plot_transversalium, output_path(basefich + '_transversalium_correction.png', options), c)
+    (basefich0, shift_requested, shift, ratio_fixe, slant_fix, _transversalium_cache) -- produced by finish() from what the
+    call returned.  A scan that fails half-way leaves the log the reference would have left, then raises.
+    run(): the call is made here, on this thread's current stream; submit(pool): a native scan pool makes it
+    (several scans in flight, none of them holding the interpreter)."""
+
+    def __init__(self, rdr, options, pooled=False):
+        self.rdr, self.options = rdr, options
+        self.basefich0 = basefich0 = os.path.splitext(str(rdr.file))[0]
+        options['basefich0'] = basefich0
+        self.log = log = basefich0 + '_log.txt'
+        clearlog(log, options)
+        logme(log, options, 'Pixel shift : ' + str(options['shift']))
+        options['shift_requested'] = options['shift']
+        options['shift'] = list(dict.fromkeys([options['ellipse_fit_shift'], 0] + options['shift']))
+        self.hdr = make_header(rdr)
+        logme(log, options, 'Width, Height : ' + str(rdr.Width) + ' ' + str(rdr.Height))
+        logme(log, options, 'Number of frames : ' + str(rdr.FrameCount))
+        self.shifts = shifts = options['shift']
+        self.requested = [sh in options['shift_requested'] for sh in shifts]
+        self.plots = plots = plots_enabled(options)
+        self.call = stages.ScanCall(rdr.device_stack(), shifts, self.requested, options, savgol_taps, want_plot_data=plots,
+                                    want_fit_image=plots, own_buffers=pooled)
+
+    def run(self):
+        self.call.run()
+        return self
+
+    def submit(self, pool):
+        self.call.submit(pool)
+        return self
+
+    def done(self):
+        return self.call.done()
+
+    def finish(self):
+        """-> [(cc, frame_protus), ...] like solex_process; raises what the scan raised."""
+        from .ellipse_to_circle import _log_geometry, _warp_geometry
+        rdr, options, hdr, log, basefich0 = self.rdr, self.options, self.hdr, self.log, self.basefich0
+        shifts, requested, plots = self.shifts, self.requested, self.plots
+        r, error = self.call.wait().collect()
+        self.call = None
+        _release_stack(rdr)
+        phase = r['phase']
+        # ---- compute_mean_return_fit's outputs (solex_util.py:191-274) ----
+        if phase >= 1:
+            mean_img = DeviceImage(r['mean'])
+            y1, y2 = r['y1'], r['y2']
             if options['save_fit']:
-                outputs.submit(write_fits, output_path(basefich + '_detransversaliumed.fits', options), DeviceImage(r['detrans'][i]), hdr)
-    results = [write_products(r['final'][i], r['cl1'][i], r['hc'][i], r['protus'][i], r['cc'][i], options, hdr, names[i])
-               for i in range(len(names))]
-    for _ in names:
-        write_complete(log, options)
-    return results
+                outputs.submit(write_fits, output_path(basefich0 + '_mean.fits', options), mean_img, hdr)
+            logme(log, options, 'Vertical limits y1, y2 : ' + str(y1) + ' ' + str(y2))
+            logme(log, options, lambda: 'Spectral line polynomial fit: ' + str(r['p']))
+            if plots:
+                rows = np.arange(y1, y2)
+                good = r['mask_good']
+                outputs.submit(outputs.plot_spectral_line, output_path(basefich0 + '_spectral_line_data.png', options), mean_img,
+                               r['sharp'].astype(np.int64)[y1:y2][good], rows[good], r['fit'][:, 3], int(rdr.ih), (y2 - y1) // 20 + 1)
+        # ---- the raw disks (Solex_recon.py:65-83) and solex_process's header lines (:95-102) ----
+        disk_list = []
+        if phase >= 2:
+            hdr['NAXIS1'] = rdr.iw
+            if options['save_fit'] or plots or (phase >= 3 and not r['limb_fitted'] and requested[0] and '_nolog' not in options):
+                disk_list = [DeviceImage(r['disks'][i], minmax=r['extrema'][i]) for i in range(len(shifts))]
+            for i, disk in enumerate(disk_list):
+                if options['save_fit'] and requested[i]:
+                    outputs.submit(write_fits, output_path(basefich0 + '_shift=' + str(shifts[i]) + '_raw.fits', options), disk, hdr)
+            if options['transversalium']:
+                logme(log, options, 'Transversalium correction : ' + str(options['trans_strength']))
+            else:
+                logme(log, options, 'Transversalium disabled')
+            logme(log, options, 'Mirror X : ' + str(options['flip_x']))
+            logme(log, options, 'Post-rotation : ' + str(options['img_rotate']) + ' degrees')
+            logme(log, options, f'Protus adjustment : {options["delta_radius"]}')
+            logme(log, options, f'de-vignette : {options["de-vignette"]}')
+        # ---- the geometry: ellipse_to_circle's / correct_image's log lines (ellipse_to_circle.py:131-143, 313) ----
+        if phase >= 3:
+            if r['limb_fitted']:
+                options['ratio_fixe'] = r['ratio']
+                _log_geometry(options, r['phi'], r['ratio'], r['theta_first'], np.array(r['circle'][:2]), r['circle'][2])
+                print('sun borders found:' + str(r['borders']))
+                options['slant_fix'] = math.degrees(r['phi'])
+            elif requested[0] and '_nolog' not in options:
+                # correct_image(..., center (-1, -1), height -1, print_log=True) of the first disk (Solex_recon.py:122)
+                ih_, n_ = disk_list[0].shape
+                theta, inv_mat, _, _, _, origin, det = _warp_geometry(float(r['phi']), float(r['ratio']), int(ih_), int(n_))
+                _log_geometry(options, r['phi'], r['ratio'], theta, (inv_mat @ np.array([-1.0, -1.0]).T).T - origin,
+                              -1.0 * np.sqrt(np.abs(r['ratio'] / det)), known=False)
+        if error is not None:
+            raise error
+        # ---- single_image_process's files (Solex_recon.py:136-174) ----
+        names = [basefich0 + '_shift=' + str(shifts[i]) for i in range(len(shifts)) if requested[i]]
+        if plots and r['limb_fitted']:
+            fix_img = r['frames'][0] if requested[0] else r['fit_image']
+            outputs.submit(outputs.plot_ellipse_fit, output_path(basefich0 + '_shift=' + str(shifts[0]) + '_ellipse_fit.png', options),
+                           disk_list[0], DeviceImage(fix_img), r['raw_X'], r['X_f'], r['outline'], r['borders'])
+        if options['save_fit']:
+            for j, basefich in enumerate(names):
+                outputs.submit(write_fits, output_path(basefich + '_circular.fits', options), DeviceImage(r['frames'][j]), hdr)
+        if options['transversalium']:
+            for i, basefich in enumerate(names):
+                c = r['factors'][i]
+                options['_transversalium_cache'] = c
+                if plots:
+                    outputs.submit(outputs.plot_transversalium, output_path(basefich + '_transversalium_correction.png', options), c)
+                if options['save_fit']:
+                    outputs.submit(write_fits, output_path(basefich + '_detransversaliumed.fits', options), DeviceImage(r['detrans'][i]), hdr)
+        if '_nolog' in options and not options['save_fit'] and options['img_rotate'] // 90 % 4 == 0:
+            # nothing is written and nothing turned: only the two returned images are ever looked at
+            return [(DeviceImage(r['cc'][i]), DeviceImage(r['protus'][i])) for i in range(len(names))]
+        results = [write_products(r['final'][i], r['cl1'][i], r['hc'][i], r['protus'][i], r['cc'][i], options, hdr, names[i])
+                   for i in range(len(names))]
+        for _ in names:
+            write_complete(log, options)
+        return results
 
 
 def _writes_files(options):

@@ -67,6 +67,9 @@ SIGNATURES = {
     'shg_profile_reset': (c_int, []),
     'shg_profile_get': (c_int, [ctypes.c_char_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int64)]),
     'shg_profile_total': (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(c_int64)]),
+    'shg_profile_dump': (c_int, [ctypes.c_char_p]),
+    'shg_host_timing_enable': (c_int, [c_int]),
+    'shg_host_timing_report': (c_int, [ctypes.c_char_p, c_size_t]),
     'shg_stream_read_probe': (c_int, [P, c_int64, c_int, c_int, c_int, c_int64, P, P]),
     'shg_accumulate_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int64, c_int]),
     'shg_accumulate_sum_max': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int64, P, P, P, c_size_t, P]),
@@ -148,6 +151,11 @@ SIGNATURES = {
     'shg_scan_host_bytes': (c_size_t, [ctypes.POINTER(ScanRequest)]),
     'shg_scan_file': (c_int, [ctypes.POINTER(ScanRequest), ctypes.POINTER(ScanResult), P]),
     'shg_host_set_savgol_taps': (c_int, [P]),
+    'shg_pool_create': (c_int, [P, c_int, P, c_int, ctypes.POINTER(c_void_p)]),
+    'shg_pool_submit': (c_int, [P, ctypes.POINTER(ScanRequest), ctypes.POINTER(ScanResult), ctypes.POINTER(c_int64)]),
+    'shg_pool_poll': (c_int, [P, c_int64]),
+    'shg_pool_wait': (c_int, [P, c_int64, ctypes.POINTER(c_int), ctypes.c_char_p, c_size_t]),
+    'shg_pool_destroy': (c_int, [P]),
     'shg_device_cu_count': (c_int, [ctypes.POINTER(c_int)]),
     'shg_stream_create': (c_int, [c_int, P, c_int, ctypes.POINTER(c_void_p)]),
     'shg_stream_destroy': (c_int, [P]),
@@ -190,10 +198,10 @@ def last_error():
     return lib.shg_last_error_string().decode('utf-8', 'replace')
 
 
-def _host_error(status, what):
+def _host_error(status, what, message=None):
     """The host control plane reports the failure the reference's NumPy / SciPy call raises at that point
     (include/shg_hip.h, SHG_E_VALUE ... SHG_E_QHULL): raise that exception type."""
-    msg = last_error()
+    msg = last_error() if message is None else message
     if status == -4:
         return ValueError(msg)
     if status == -5:
@@ -214,11 +222,12 @@ def _host_error(status, what):
     return RuntimeError('%s: %s' % (what, msg) if status != -7 else msg)
 
 
-def check(status, what):
+def check(status, what, message=None):
+    """message: the error text when it was produced on another thread (a scan pool worker); default: this thread's last error."""
     if status != 0:
         if -10 <= status <= -4:
-            raise _host_error(status, what)
-        raise RuntimeError('%s failed (status %d): %s' % (what, status, last_error()))
+            raise _host_error(status, what, message)
+        raise RuntimeError('%s failed (status %d): %s' % (what, status, last_error() if message is None else message))
 
 
 def _bind_numpy_lapack():
@@ -264,31 +273,29 @@ def _numpy_mode_pick(neg_counts, n):
 lib.shg_host_set_mode_pick(ctypes.cast(_numpy_mode_pick, c_void_p))
 
 
-_taps_error = {}          # thread id -> the exception SciPy raised inside the callback (re-raised by the caller of the C entry point)
+_taps_error = {}          # window -> the exception SciPy raised inside the callback (re-raised by the caller of the C entry point)
 
 
 @ctypes.CFUNCTYPE(c_int, c_int64, ctypes.POINTER(c_double))
 def _savgol_taps(window, out):
     """scipy.signal.savgol_coeffs(window, 3) for shg_scan_file, when the window differs from the one the request carried
     taps for (a scan with few sunlit rows; solex_util.py:400).  SciPy's own exception is kept for the caller."""
-    import threading
     try:
         from .solex_util import savgol_taps
         taps = savgol_taps(int(window))
         ctypes.memmove(out, taps.ctypes.data, taps.size * 8)
         return 0
-    except Exception as e:      # noqa: BLE001
-        _taps_error[threading.get_ident()] = e
+    except Exception as e:      # noqa: BLE001 -- the call may come from a scan pool thread: keyed by what was asked for
+        _taps_error[int(window)] = e
         return -4 if isinstance(e, ValueError) else -7
 
 
 lib.shg_host_set_savgol_taps(ctypes.cast(_savgol_taps, c_void_p))
 
 
-def take_callback_error():
-    """The exception a registered callback met on this thread during the last C call, if any."""
-    import threading
-    return _taps_error.pop(threading.get_ident(), None)
+def take_callback_error(window):
+    """The exception the Savitzky-Golay callback met when it was asked for `window`, if any."""
+    return _taps_error.pop(int(window), None)
 
 
 def profile_enable(on=True, only=None):

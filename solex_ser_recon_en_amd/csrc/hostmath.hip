@@ -224,6 +224,7 @@ extern "C" int shg_host_polyfit3(const double* host_x, const double* host_y, int
 
 // ---- a3: detect_bord on the row means (solex_util.py:165-172) ------------------------------------
 extern "C" int shg_host_detect_bord(const double* host_row_means, int64_t n, int64_t* lb, int64_t* ub) {
+    SHG_HOST_TIME("host detect_bord");
     SHG_REQUIRE(host_row_means && lb && ub && n > 0, SHG_E_ARG, "shg_host_detect_bord: bad argument");
     std::vector<double> s(host_row_means, host_row_means + n);
     std::sort(s.begin(), s.end());
@@ -244,6 +245,7 @@ extern "C" int shg_host_detect_bord(const double* host_row_means, int64_t n, int
 extern "C" int shg_host_line_fit(const int32_t* host_trace_blur, const int32_t* host_trace_sharp, int64_t ih,
                                  int64_t y1, int64_t y2, int32_t blur_offset, double* host_p4, double* host_fit,
                                  uint8_t* host_mask_good) {
+    SHG_HOST_TIME("host line_fit");
     SHG_REQUIRE(host_trace_blur && host_trace_sharp && host_p4 && host_fit, SHG_E_ARG, "shg_host_line_fit: null pointer");
     SHG_REQUIRE(ih > 0 && y1 >= 0 && y2 <= ih, SHG_E_ARG, "shg_host_line_fit: rows [%lld, %lld) outside the image", (long long)y1, (long long)y2);
     const int64_t n = std::max<int64_t>(y2 - y1, 0);
@@ -320,6 +322,7 @@ extern "C" int shg_host_line_fit(const int32_t* host_trace_blur, const int32_t* 
 // ---- a5: clamped sample columns and weights (solex_util.py:113-123) --------------------------------
 extern "C" int shg_host_column_plan(const double* host_fit, int64_t ih, int64_t iw, const int32_t* host_shifts,
                                     int n_shifts, int32_t* host_ind_l, double* host_lw, double* host_rw) {
+    SHG_HOST_TIME("host column_plan");
     SHG_REQUIRE(host_fit && host_shifts && host_ind_l && host_lw && host_rw, SHG_E_ARG, "shg_host_column_plan: null pointer");
     SHG_REQUIRE(ih > 0 && iw >= 2 && n_shifts > 0, SHG_E_ARG, "shg_host_column_plan: bad size");
     for (int s = 0; s < n_shifts; ++s)
@@ -342,6 +345,7 @@ extern "C" int shg_host_column_plan(const double* host_fit, int64_t ih, int64_t 
 // total = np.sum(image); over data = blurred[blurred < very_bright]: mn, mx, counts = np.histogram(data, 20)[0].
 extern "C" int shg_host_flood_threshold(double total, int64_t h, int64_t w, double mn, double mx,
                                         const int64_t* host_counts20, double* thresh_out) {
+    SHG_HOST_TIME("host flood_threshold");
     SHG_REQUIRE(host_counts20 && thresh_out && h > 0 && w > 0, SHG_E_ARG, "shg_host_flood_threshold: bad argument");
     const double thresh = 0.9 * total / (double)(h * w);
     if (mn == mx) { mn -= 0.5; mx += 0.5; }                      // np.histogram's range for constant data
@@ -401,6 +405,7 @@ extern "C" int shg_host_flood_threshold(double total, int64_t h, int64_t w, doub
 // out_sel[m]: 1 where the pixel is a limb point.  Returns SHG_E_QHULL where scipy.spatial.ConvexHull raises.
 extern "C" int shg_host_limb_points(const int32_t* host_idx, const int32_t* host_root, int64_t m, int64_t h, int64_t w,
                                     uint8_t* host_out_sel, int64_t* n_selected) {
+    SHG_HOST_TIME("host limb_points");
     SHG_REQUIRE(host_idx && host_root && host_out_sel && n_selected && h > 0 && w > 0, SHG_E_ARG, "shg_host_limb_points: bad argument");
     SHG_REQUIRE(m > 0, SHG_E_RUNTIME, "ellipse fit: could not find any edges of the solar disk");
     std::vector<int32_t> uniq(host_root, host_root + m);
@@ -477,6 +482,7 @@ extern "C" int shg_host_limb_points(const int32_t* host_idx, const int32_t* host
 // xa, xb [max(y2-y1,1)] (entry 0 unused): NumPy-normalised slice [a, b) of row y1+i.
 extern "C" int shg_host_chord_bounds(double cx, double cy, double r, double b0, double b2, int64_t y1, int64_t y2,
                                      int64_t w, int32_t* host_xa, int32_t* host_xb) {
+    SHG_HOST_TIME("host chord_bounds");
     SHG_REQUIRE(host_xa && host_xb && w > 0, SHG_E_ARG, "shg_host_chord_bounds: bad argument");
     const int64_t count = std::max<int64_t>(y2 - y1, 1);
     for (int64_t i = 0; i < count; ++i) host_xa[i] = host_xb[i] = 0;
@@ -499,6 +505,7 @@ extern "C" int shg_host_chord_bounds(double cx, double cy, double r, double b0, 
 // mean)) - 1) * taper, or the untapered correction when tapered == 0 (the stubborn branch, :404).
 extern "C" int shg_host_transversalium_factors(const double* host_ratios, const double* host_interior, int64_t k, int64_t n,
                                                const double* host_taps, int64_t window, int tapered, double* host_out) {
+    SHG_HOST_TIME("host transversalium_factors");
     SHG_REQUIRE(host_ratios && host_taps && host_out && k > 0 && n > 0, SHG_E_ARG, "shg_host_transversalium_factors: bad argument");
     if (window > n) { shg::set_error("If mode is 'interp', window_length must be less than or equal to the size of x."); return SHG_E_VALUE; }
     SHG_REQUIRE(window >= 1 && (window & 1), SHG_E_VALUE, "window_length must be odd and positive, got %lld", (long long)window);
@@ -852,6 +859,7 @@ extern "C" int shg_host_warp_geometry(double phi, double ratio, int64_t h, int64
 // h02) | theta.  host_dims2 = (out_h, out_w).  host_kept [n] and host_outline200 may be NULL.
 extern "C" int shg_host_limb_geometry(const double* host_points, int64_t n, int64_t h, int64_t w, double* host_geom16,
                                       int64_t* host_dims2, uint8_t* host_kept, int64_t* n_kept, double* host_outline200) {
+    SHG_HOST_TIME("host limb_geometry");
     SHG_REQUIRE(host_points && host_geom16 && host_dims2 && n_kept, SHG_E_ARG, "shg_host_limb_geometry: null pointer");
     SHG_NEED_BLAS("shg_host_limb_geometry");
     std::vector<uint8_t> kept_local;

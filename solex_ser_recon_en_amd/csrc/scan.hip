@@ -157,6 +157,7 @@ extern "C" size_t shg_scan_host_bytes(const shg_scan_request* rq) {
 }
 
 extern "C" int shg_scan_file(const shg_scan_request* rq, shg_scan_result* rs, shg_stream_t stream) {
+    SHG_HOST_TIME("scan_file");
     SHG_REQUIRE(rq && rs, SHG_E_ARG, "shg_scan_file: null pointer");
     SHG_REQUIRE(rq->struct_bytes == sizeof(shg_scan_request), SHG_E_ARG, "shg_scan_file: the caller's shg_scan_request has %u bytes, the library's %zu",
                 rq->struct_bytes, sizeof(shg_scan_request));

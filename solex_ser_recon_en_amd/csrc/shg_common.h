@@ -39,8 +39,22 @@ struct ProfScope {
     ~ProfScope();
     int slot;
     hipStream_t stream;
+    unsigned generation;
 };
 #define SHG_PROF(tag, st) shg::ProfScope shg_prof_scope_(tag, st)
+
+// Host-side wall clock of a section of a stage composite (waiting in a stream synchronise, a control-plane routine, ...),
+// accumulated per tag while shg_host_timing_enable(1): where a scan worker's time goes between the kernels
+// (tools/host_budget.py).  Off by default: one relaxed load.
+struct HostScope {
+    explicit HostScope(const char* tag);
+    ~HostScope();
+    const char* tag;
+    double t0;
+};
+#define SHG_HOST_CAT2(a, b) a##b
+#define SHG_HOST_CAT(a, b) SHG_HOST_CAT2(a, b)
+#define SHG_HOST_TIME(tag) shg::HostScope SHG_HOST_CAT(shg_host_scope_, __LINE__)(tag)
 
 constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kCUs = 256;          // MI355X

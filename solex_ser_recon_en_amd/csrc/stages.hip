@@ -44,6 +44,7 @@ struct Arena {
 
 #define STAGE_HIP(expr, who)                                               \
     do {                                                                   \
+        SHG_HOST_TIME("sync " #expr);                                      \
         hipError_t he_ = (expr);                                           \
         if (he_ != hipSuccess) {                                           \
             shg::set_error("%s: %s", who, hipGetErrorString(he_));         \
@@ -127,6 +128,7 @@ extern "C" int shg_stage_mean_fit(const void* stack, int64_t n_frames, int64_t h
                                   uint16_t* mean_out, uint16_t* max_out, int64_t* host_y12, double* host_p4, double* host_fit,
                                   int32_t* host_trace_sharp, uint8_t* host_mask_good, void* workspace, size_t workspace_bytes,
                                   void* host_pinned, size_t host_pinned_bytes, shg_stream_t stream) {
+    SHG_HOST_TIME("stage mean_fit");
     SHG_REQUIRE(mean_out && max_out && host_y12 && host_p4 && host_fit && workspace && host_pinned, SHG_E_ARG,
                 "shg_stage_mean_fit: null pointer");
     SHG_REQUIRE((sum_in == nullptr) == (max_in == nullptr), SHG_E_ARG, "shg_stage_mean_fit: sum_in and max_in go together");
@@ -201,6 +203,7 @@ extern "C" int shg_stage_extract(const void* stack, int64_t n_frames, int64_t he
                                  uint16_t* disks, int64_t row_pitch, int64_t plane_stride, int64_t n_cols, int64_t k_offset,
                                  int flip_x, uint32_t* minmax_slots, void* workspace, size_t workspace_bytes, void* host_pinned,
                                  size_t host_pinned_bytes, shg_stream_t stream) {
+    SHG_HOST_TIME("stage extract");
     SHG_REQUIRE(stack && host_fit && host_shifts && disks && workspace && host_pinned, SHG_E_ARG, "shg_stage_extract: null pointer");
     SHG_REQUIRE(height > 0 && width > 0 && n_shifts > 0, SHG_E_ARG, "shg_stage_extract: empty input");
     const int64_t ih = slit_rows(height, width), iw = spectral_cols(height, width);
@@ -361,6 +364,7 @@ extern "C" int shg_stage_limb_fit(const uint16_t* disk, int64_t h, int64_t w, in
                                   int32_t* host_points, uint8_t* host_flags, int64_t points_cap, int64_t* host_counts3,
                                   double* host_geom16, int64_t* host_dims2, double* host_outline200, void* workspace,
                                   size_t workspace_bytes, void* host_pinned, size_t host_pinned_bytes, shg_stream_t stream) {
+    SHG_HOST_TIME("stage limb_fit");
     SHG_REQUIRE(host_counts3 && host_geom16 && host_dims2, SHG_E_ARG, "shg_stage_limb_fit: null pointer");
     STAGE_TRY(shg_stage_limb_points(disk, h, w, pitch, host_gauss_taps, host_points, host_flags, points_cap, host_counts3, workspace,
                                     workspace_bytes, host_pinned, host_pinned_bytes, stream));
@@ -412,6 +416,7 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
                                         uint16_t* const* host_protus, uint16_t* const* host_cc, int64_t out_pitch,
                                         void* workspace, size_t workspace_bytes, void* host_pinned, size_t host_pinned_bytes,
                                         shg_stream_t stream) {
+    SHG_HOST_TIME("stage process_frames");
     SHG_REQUIRE(host_frames && host_final && host_cl1 && host_hc && host_protus && host_cc && workspace && host_pinned, SHG_E_ARG,
                 "shg_stage_process_frames: null pointer");
     SHG_REQUIRE(k > 0 && h > 0 && w > 0 && pitch >= w, SHG_E_ARG, "shg_stage_process_frames: bad image size");

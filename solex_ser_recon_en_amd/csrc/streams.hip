@@ -7,8 +7,9 @@
 //   * everything else of a scan is a chain of small, latency-bound kernels that leave HBM almost idle.
 // So pass A of ALL scans goes through one stream -- the lane -- where they run back to back in the order the scans
 // asked, each alone with the small kernels of the other scans, and the chains run on the workers' own streams
-// (optionally confined to a subset of the CUs, hipExtStreamCreateWithCUMask).  A scan's stream waits for its pass A
-// through an event; nothing is synchronised on the host.
+// (optionally confined to a subset of the CUs, hipExtStreamCreateWithCUMask).  A scan waits for its own pass A through
+// an event (on the host by default, see on_frame_pass_lane).
+#include <stdlib.h>
 #include <mutex>
 #include <vector>
 #include "shg_common.h"
@@ -44,10 +45,21 @@ int on_frame_pass_lane(hipStream_t st, int (*launch)(hipStream_t, void*), void* 
         hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         if (e != hipSuccess) { ev = nullptr; set_error("frame-pass lane: %s", hipGetErrorString(e)); return (int)e; }
     }
-    std::lock_guard<std::mutex> lk(g_lane_mu);
-    if (int e = launch(lane, arg)) return e;
-    hipError_t e = hipEventRecord(ev, lane);
-    if (e == hipSuccess) e = hipStreamWaitEvent(st, ev, 0);
+    hipError_t e;
+    {
+        std::lock_guard<std::mutex> lk(g_lane_mu);
+        if (int le = launch(lane, arg)) return le;
+        e = hipEventRecord(ev, lane);
+    }
+    // How the scan's own stream learns that its pass has run.  A barrier in the stream (hipStreamWaitEvent) costs the host
+    // nothing, but the runtime multiplexes streams onto a few hardware queues (4 by default) and a barrier that waits for
+    // the lane holds up every stream that shares the queue -- with more scan workers than queues, whole chains of OTHER scans.
+    // Waiting on the host keeps the queue free; the stage synchronises a few kernels later anyway.
+    static const bool host_wait = [] { const char* v = getenv("SHG_LANE_WAIT"); return !(v && v[0] == 's'); }();
+    if (e == hipSuccess) {
+        SHG_HOST_TIME("lane wait (queue + pass A)");
+        e = host_wait ? hipEventSynchronize(ev) : hipStreamWaitEvent(st, ev, 0);
+    }
     if (e != hipSuccess) { set_error("frame-pass lane: %s", hipGetErrorString(e)); return (int)e; }
     return 0;
 }

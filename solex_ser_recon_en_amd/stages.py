@@ -240,135 +240,278 @@ _NAN = float('nan')
 FIRST_GUESS_SCALE = 1.05      # width of the corrected images a first scan of a shape is assumed to have, in raw-disk widths
 
 
-def _plane(buf, off, h, pitch, w):
-    """A uint16 image [h, w] (rows `pitch` elements apart) at byte offset `off` of a uint8 arena."""
-    return buf[off:off + h * pitch * 2].view(torch.uint16).view(h, pitch)[:, :w]
+class _Planes:
+    """uint16 images inside a uint8 arena, made on demand: plane(off, h, pitch, w) -> [h, w] view with rows `pitch` elements
+    apart at byte offset `off`.  (A view costs microseconds of interpreter time; a scan that writes no files only ever
+    looks at two of its eleven images.)"""
+    __slots__ = ('words',)
+
+    def __init__(self, buf):
+        self.words = buf.view(torch.uint16)
+
+    def plane(self, off, h, pitch, w):
+        return torch.as_strided(self.words, (h, w), (pitch, 1), off // 2)
+
+
+class _LazyImages:
+    """list-like: image j of a family of equally spaced planes, built when asked for."""
+    __slots__ = ('planes', 'off', 'step', 'count', 'geom')
+
+    def __init__(self, planes, off, step, count, h, pitch, w):
+        self.planes, self.off, self.step, self.count, self.geom = planes, off, step, count, (h, pitch, w)
+
+    def __len__(self):
+        return self.count
+
+    def __getitem__(self, j):
+        if not 0 <= j < self.count:
+            raise IndexError(j)
+        return self.planes.plane(self.off + j * self.step, *self.geom)
+
+
+def _host_buffers(name, specs):
+    """Per-thread NumPy buffers that outlive a scan (a fresh 2 MB array per scan is an mmap, its page faults and a munmap)."""
+    store = _local.__dict__.setdefault('host', {})
+    out = []
+    for tag, shape, dtype in specs:
+        key = (name, tag)
+        buf = store.get(key)
+        if buf is None or buf.shape != tuple(shape) or buf.dtype != np.dtype(dtype):
+            buf = store[key] = np.empty(shape, dtype=dtype)
+        out.append(buf)
+    return out
+
+
+_pinned_free = []          # pinned staging areas of scans that went through a pool (a scan leases one for its lifetime)
+_pinned_lock = threading.Lock()
+
+
+PINNED_SLAB = 12           # staging areas cut from one pinned allocation: page-locking memory costs tens of milliseconds per call
+
+
+def _lease_pinned(nbytes):
+    with _pinned_lock:
+        for i, buf in enumerate(_pinned_free):
+            if buf.numel() >= nbytes:
+                return _pinned_free.pop(i)
+        each = (max(int(nbytes), 1) + 4095) // 4096 * 4096
+        slab = torch.empty(each * PINNED_SLAB, dtype=torch.uint8).pin_memory()
+        parts = [slab[i * each:(i + 1) * each] for i in range(PINNED_SLAB)]
+        _pinned_free.extend(parts[1:])
+        return parts[0]
+
+
+def _return_pinned(buf):
+    with _pinned_lock:
+        if len(_pinned_free) < 64:
+            _pinned_free.append(buf)
+
+
+_host_free = {}            # spec tuple -> [lists of NumPy arrays]: host outputs of pooled scans, leased like the staging areas
+
+
+def _lease_host(specs):
+    with _pinned_lock:
+        free = _host_free.get(specs)
+        if free:
+            return free.pop()
+    return [np.empty(shape, dtype=dt) for _, shape, dt in specs]
+
+
+def _return_host(specs, bufs):
+    with _pinned_lock:
+        free = _host_free.setdefault(specs, [])
+        if len(free) < 32:
+            free.append(bufs)
+
+
+def _even256(nbytes):
+    return (max(int(nbytes), 256) + 255) // 256 * 256
+
+
+class ScanCall:
+    """One shg_scan_file call (csrc/scan.hip): the whole per-file flow -- pass A, line fit, extraction, limb fit (or the fixed
+    ratio / slant of `options`), the warp of every requested disk, transversalium, crop, CLAHE, contrast products.
+    stack: the frame stack in HBM; shifts: options['shift'] after solex_read's de-duplication; requested: one flag per
+    shift; taps_for(window) -> savgol_coeffs(window, 3).
+    run() makes the call on this thread's current stream; submit(pool) / wait() hand it to a native scan pool.
+    collect() -> (dict of everything the phases that ran produced, error or None): the caller logs what was reached, then raises."""
+
+    def __init__(self, stack, shifts, requested, options, taps_for, want_plot_data=False, want_fit_image=False, own_buffers=False):
+        n, h, w, bpp = ops.stack_geometry(stack)
+        dev = stack.device
+        ih, iw = (w, h) if w > h else (h, w)
+        self.stack, self.dev, self.n, self.ih, self.plot = stack, dev, n, ih, want_plot_data
+        self.sh = sh = np.ascontiguousarray(shifts, dtype=np.int32)
+        self.rqd = rqd = np.ascontiguousarray(requested, dtype=np.uint8)
+        self.s, self.k = s, k = int(sh.size), int(rqd.sum())
+        ratio_fixe, slant_fix = options['ratio_fixe'], options['slant_fix']
+        self.limb = limb = ratio_fixe is None and slant_fix is None
+        self.trans = trans = bool(options['transversalium'])
+        keep_detrans = bool(options['save_fit'] and trans)
+        fit_image = bool(want_fit_image and not rqd[0])
+        self.own = own_buffers
+
+        self.pitch = pitch = (n + 63) // 64 * 64
+        self.images = images = torch.empty((2, ih, iw), dtype=torch.uint16, device=dev)
+        self.disks = disks = torch.empty((s, ih, pitch), dtype=torch.uint16, device=dev)
+        self.mm_store = mm_store = torch.empty(s * 130, dtype=torch.int32, device=dev)
+        self.cap = cap = (-(-ih // 4)) * (-(-n // 4)) if limb else 1
+        self.specs = specs = (('fit', (ih, 4), 'f8'), ('sharp', (ih,), 'i4'), ('mask', (ih,), 'u1'), ('points', (cap, 2), 'i4'),
+                              ('flags', (cap,), 'u1'), ('outline', (100, 2), 'f8'), ('factors', (max(k, 1), ih), 'f8'))
+        # a scan in a pool keeps its host arrays to itself (several are in flight per caller thread)
+        self.bufs = bufs = _lease_host(specs) if own_buffers else _host_buffers('scan', specs)
+        self.fit, self.sharp, self.mask, self.points, self.flags, self.outline, self.factors = bufs
+        self.gauss = gauss = _canny_ladder_taps()
+        ts = int(options['trans_strength'])
+        self.taps = taps = taps_for(ts) if trans and ts > 3 and ts % 2 == 1 else None   # the usual window; any other one: the callback
+
+        self.rq = rq = _lib.ScanRequest()
+        rq.struct_bytes = ctypes.sizeof(_lib.ScanRequest)
+        rq.stack, rq.n_frames, rq.height, rq.width, rq.frame_stride_px, rq.bytes_per_px = stack.data_ptr(), n, h, w, ops.frame_stride(stack), bpp
+        rq.flip_x = int(bool(options['flip_x']))
+        rq.host_shifts, rq.host_requested, rq.n_shifts, rq.want_fit_image = _p(sh), _p(rqd), s, int(fit_image)
+        rq.ratio_fixe = _NAN if ratio_fixe is None else float(ratio_fixe)
+        rq.slant_fix_deg = _NAN if slant_fix is None else float(slant_fix)
+        rq.transversalium, rq.keep_detrans, rq.trans_strength = int(trans), int(keep_detrans), ts
+        rq.host_taps, rq.taps_window = (None, 0) if taps is None else (_p(taps), ts)
+        rq.crop_square = int(bool(options['crop_width_square']))
+        rq.has_fixed_width = int(options['fixed_width'] is not None)
+        rq.fixed_width = 0 if options['fixed_width'] is None else int(options['fixed_width'])
+        rq.disk_display, rq.tiles, rq.delta_radius, rq.clip_limit = int(bool(options['disk_display'])), 2, int(options['delta_radius']), 0.8
+        rq.host_gauss_taps = _p(gauss)
+        rq.mean_out, rq.max_out = images[0].data_ptr(), images[1].data_ptr()
+        rq.disks, rq.disk_pitch, rq.disk_plane_stride, rq.minmax_slots = disks.data_ptr(), pitch, ih * pitch, mm_store.data_ptr()
+        rq.host_fit = _p(self.fit)
+        rq.host_trace_sharp, rq.host_mask_good = (_p(self.sharp), _p(self.mask)) if want_plot_data else (None, None)
+        rq.host_points, rq.host_flags, rq.points_cap = (_p(self.points), _p(self.flags), cap) if limb else (None, None, 0)
+        rq.host_outline200 = _p(self.outline) if (limb and want_plot_data) else None
+        rq.host_factors = _p(self.factors) if (trans and k) else None
+
+        self.key = key = (s, k, ih, n, bpp, bool(options['crop_width_square']), options['fixed_width'], keep_detrans, fit_image, limb)
+        hint = _arena_hint.get(key)
+        if hint is None:
+            # first scan of this shape: corrected images about as wide as the raw disk (Y/X ratio near 1)
+            guess_w = (int(n * FIRST_GUESS_SCALE) + 127) // 64 * 64
+            prod_w = max(guess_w, ih if options['crop_width_square'] else 0, rq.fixed_width)
+            hint = ((k * (1 + keep_detrans) + fit_image) * ih * guess_w * 2 + k * 3 * ih * prod_w * 2 + (1 << 16), k * 2 * ih * prod_w * 2 + 4096,
+                    lib.shg_scan_workspace_bytes(ctypes.byref(rq)) + (lib.shg_stage_process_workspace_bytes(k, ih, guess_w, prod_w, 2) if k else 0) + 4096)
+        self.hint = hint
+        pin_bytes = _sizes('scan_pin', lambda *a: lib.shg_scan_host_bytes(ctypes.byref(rq)), s, k, n, h, w, bpp, limb)
+        self.pin = _lease_pinned(pin_bytes) if own_buffers else _scratch('scan', pin_bytes, pinned=True)
+        self.rs = _lib.ScanResult()
+        self.status = None
+        self.message = None
+        self.pool = self.ticket = None
+        self._buffers()
+
+    def _buffers(self):
+        rq, hint, dev = self.rq, self.hint, self.dev
+        self.arena = arena = torch.empty(_even256(hint[0]), dtype=torch.uint8, device=dev)
+        self.results = results = torch.empty(_even256(hint[1]), dtype=torch.uint8, device=dev)
+        self.ws = ws = torch.empty(_even256(hint[2]), dtype=torch.uint8, device=dev) if self.own else _scratch('scan', hint[2], dev)
+        rq.arena, rq.arena_bytes, rq.results, rq.results_bytes = arena.data_ptr(), arena.numel(), results.data_ptr(), results.numel()
+        rq.workspace, rq.workspace_bytes = ws.data_ptr(), ws.numel()
+        rq.host_pinned, rq.host_pinned_bytes = self.pin.data_ptr(), self.pin.numel()
+
+    def _needs_resume(self):
+        """The corrected images turned out larger than the arenas: grow them; the call resumes at the warp (the raw disks and
+        the geometry stay)."""
+        rs = self.rs
+        if self.status == -2 and rs.phase_done == 3 and self.rq.start_phase == 0:
+            self.hint = (rs.needed_arena_bytes + 4096, rs.needed_results_bytes + 4096, rs.needed_workspace_bytes + 4096)
+            self.rq.start_phase = 3
+            self._buffers()
+            return True
+        return False
+
+    def run(self):
+        stream = ops._stream()
+        while True:
+            self.status = lib.shg_scan_file(ctypes.byref(self.rq), ctypes.byref(self.rs), stream)
+            self.message = _lib.last_error() if self.status else None
+            if not self._needs_resume():
+                return self
+
+    def submit(self, pool):
+        self.pool = pool
+        ticket = ctypes.c_int64()
+        _lib.check(lib.shg_pool_submit(pool, ctypes.byref(self.rq), ctypes.byref(self.rs), ctypes.byref(ticket)), 'shg_pool_submit')
+        self.ticket = ticket.value
+        return self
+
+    def done(self):
+        return self.ticket is None or lib.shg_pool_poll(self.pool, self.ticket) != 0
+
+    def wait(self):
+        """Blocks (without the interpreter lock) until the pool has run the scan; resubmits once when the arenas were too small."""
+        while self.ticket is not None:
+            status = ctypes.c_int()
+            buf = ctypes.create_string_buffer(512)
+            _lib.check(lib.shg_pool_wait(self.pool, self.ticket, ctypes.byref(status), buf, len(buf)), 'shg_pool_wait')
+            self.ticket = None
+            self.status = status.value
+            self.message = buf.value.decode('utf-8', 'replace') if self.status else None
+            if self._needs_resume():
+                self.submit(self.pool)
+        return self
+
+    def collect(self):
+        rs, rq = self.rs, self.rq
+        s, k, n = self.s, self.k, self.n
+        phase = int(rs.phase_done)
+        if (phase >= 3 and _arena_hint.get(self.key) is None) or rq.start_phase == 3:
+            # a little headroom: the next file's ellipse differs in the third digit, its images by a few columns
+            _arena_hint[self.key] = (int(rs.needed_arena_bytes * 1.03) + 4096, int(rs.needed_results_bytes * 1.03) + 4096,
+                                     int(rs.needed_workspace_bytes * 1.03) + 4096)
+        error = None
+        if self.status != 0:
+            error = _lib.take_callback_error(rs.window)
+            if error is None:
+                try:
+                    _lib.check(self.status, 'shg_scan_file', self.message)
+                except Exception as e:      # noqa: BLE001 -- handed to the caller, which logs what the scan reached first
+                    error = e
+        out = {'phase': phase, 'mean': self.images[0], 'max': self.images[1], 'limb_fitted': bool(rs.limb_fitted)}
+        if phase >= 1:
+            y1, y2 = int(rs.y1), int(rs.y2)
+            out['y1'], out['y2'], out['p'] = y1, y2, np.array(rs.p4)
+            if self.plot:
+                out['fit'] = self.fit.copy()
+                out['sharp'] = self.sharp.copy()
+                out['mask_good'] = self.mask[:max(y2 - y1, 0)].astype(bool)
+        if phase >= 2:
+            out['disks'] = self.disks[:, :, :n]
+            out['extrema'] = self.mm_store[s * 128:].view(s, 2)
+        if phase >= 3:
+            out['phi'], out['ratio'] = float(rs.phi), float(rs.ratio)
+            out['theta_first'] = float(rs.theta_first)
+            out['circle'] = (rs.circle3[0], rs.circle3[1], rs.circle3[2])
+            out['borders'] = list(rs.borders4)
+            if rs.limb_fitted and self.plot:
+                m = int(rs.counts3[0])
+                pts, fl = self.points[:m].astype(np.int64) * 4, self.flags[:m]
+                out['raw_X'], out['X_f'], out['outline'] = pts, pts[(fl & 2) != 0].astype(float), self.outline.copy()
+        if phase >= 4:
+            oh, ow, fp, pw, pp = int(rs.out_h), int(rs.out_w), int(rs.frame_pitch), int(rs.prod_w), int(rs.prod_pitch)
+            fb = (oh * fp * 2 + 255) // 256 * 256
+            pb = (oh * pp * 2 + 255) // 256 * 256
+            ap, rp = _Planes(self.arena), _Planes(self.results)
+            out['fit_image'] = ap.plane(int(rs.fit_image_off), oh, fp, ow) if rs.fit_image_off >= 0 else None
+            out['frames'] = _LazyImages(ap, int(rs.frames_off), fb, k, oh, fp, ow)
+            out['detrans'] = _LazyImages(ap, int(rs.detrans_off), fb, k, oh, fp, ow) if rs.detrans_off >= 0 else None
+            for idx, name in enumerate(('final', 'cl1', 'hc')):
+                out[name] = _LazyImages(ap, int(rs.products_off) + idx * pb, 3 * pb, k, oh, pp, pw)
+            for idx, name in enumerate(('protus', 'cc')):
+                out[name] = _LazyImages(rp, idx * pb, 2 * pb, k, oh, pp, pw)
+            out['factors'] = self.factors[:k].copy() if (self.trans and k) else None
+        if self.own:
+            _return_pinned(self.pin)                           # (the pool worker synchronised its stream: nothing reads it any more)
+            _return_host(self.specs, self.bufs)                # (everything handed out above is a copy)
+            self.pin = self.bufs = self.fit = self.sharp = self.mask = self.points = self.flags = self.outline = self.factors = None
+        return out, error
 
 
 def scan_file(stack, shifts, requested, options, taps_for, want_plot_data=False, want_fit_image=False):
-    """The whole per-file flow as ONE C call (shg_scan_file, csrc/scan.hip): pass A, line fit, extraction, limb fit (or the
-    fixed ratio / slant of `options`), the warp of every requested disk, transversalium, crop, CLAHE, contrast products.
-    stack: the frame stack in HBM; shifts: options['shift'] after solex_read's de-duplication; requested: one flag per
-    shift; taps_for(window) -> savgol_coeffs(window, 3).
-    -> (dict of everything the phases that ran produced, error or None): the caller logs what was reached, then raises."""
-    n, h, w, bpp = ops.stack_geometry(stack)
-    dev = stack.device
-    ih, iw = (w, h) if w > h else (h, w)
-    sh = np.ascontiguousarray(shifts, dtype=np.int32)
-    rqd = np.ascontiguousarray(requested, dtype=np.uint8)
-    s, k = int(sh.size), int(rqd.sum())
-    ratio_fixe, slant_fix = options['ratio_fixe'], options['slant_fix']
-    limb = ratio_fixe is None and slant_fix is None
-    trans = bool(options['transversalium'])
-    keep_detrans = bool(options['save_fit'] and trans)
-    fit_image = bool(want_fit_image and not rqd[0])
-
-    images = torch.empty((2, ih, iw), dtype=torch.uint16, device=dev)
-    pitch = (n + 63) // 64 * 64
-    disks = torch.empty((s, ih, pitch), dtype=torch.uint16, device=dev)
-    mm_store = torch.empty(s * 130, dtype=torch.int32, device=dev)
-    fit = np.empty((ih, 4))
-    sharp = np.empty(ih, dtype=np.int32) if want_plot_data else None
-    mask = np.zeros(ih, dtype=np.uint8) if want_plot_data else None
-    cap = (-(-ih // 4)) * (-(-n // 4))
-    points = np.empty((cap, 2), dtype=np.int32) if limb else None
-    flags = np.empty(cap, dtype=np.uint8) if limb else None
-    outline = np.empty((100, 2)) if (limb and want_plot_data) else None
-    factors = np.empty((k, ih)) if (trans and k) else None
-    gauss = _canny_ladder_taps()
-    ts = int(options['trans_strength'])
-    taps = taps_for(ts) if trans and ts > 3 and ts % 2 == 1 else None       # the usual window; any other one: the callback
-
-    rq = _lib.ScanRequest()
-    rq.struct_bytes = ctypes.sizeof(_lib.ScanRequest)
-    rq.stack, rq.n_frames, rq.height, rq.width, rq.frame_stride_px, rq.bytes_per_px = stack.data_ptr(), n, h, w, ops.frame_stride(stack), bpp
-    rq.flip_x = int(bool(options['flip_x']))
-    rq.host_shifts, rq.host_requested, rq.n_shifts, rq.want_fit_image = _p(sh), _p(rqd), s, int(fit_image)
-    rq.ratio_fixe = _NAN if ratio_fixe is None else float(ratio_fixe)
-    rq.slant_fix_deg = _NAN if slant_fix is None else float(slant_fix)
-    rq.transversalium, rq.keep_detrans, rq.trans_strength = int(trans), int(keep_detrans), ts
-    rq.host_taps, rq.taps_window = (None, 0) if taps is None else (_p(taps), ts)
-    rq.crop_square = int(bool(options['crop_width_square']))
-    rq.has_fixed_width = int(options['fixed_width'] is not None)
-    rq.fixed_width = 0 if options['fixed_width'] is None else int(options['fixed_width'])
-    rq.disk_display, rq.tiles, rq.delta_radius, rq.clip_limit = int(bool(options['disk_display'])), 2, int(options['delta_radius']), 0.8
-    rq.host_gauss_taps = _p(gauss)
-    rq.mean_out, rq.max_out = images[0].data_ptr(), images[1].data_ptr()
-    rq.disks, rq.disk_pitch, rq.disk_plane_stride, rq.minmax_slots = disks.data_ptr(), pitch, ih * pitch, mm_store.data_ptr()
-    rq.host_fit = _p(fit)
-    rq.host_trace_sharp, rq.host_mask_good = (None, None) if sharp is None else (_p(sharp), _p(mask))
-    rq.host_points, rq.host_flags, rq.points_cap = (None, None, 0) if points is None else (_p(points), _p(flags), cap)
-    rq.host_outline200 = None if outline is None else _p(outline)
-    rq.host_factors = None if factors is None else _p(factors)
-
-    key = (s, k, ih, n, bpp, bool(options['crop_width_square']), options['fixed_width'], keep_detrans, fit_image, limb)
-    hint = _arena_hint.get(key)
-    if hint is None:
-        # first scan of this shape: corrected images about as wide as the raw disk (Y/X ratio near 1)
-        guess_w = (int(n * FIRST_GUESS_SCALE) + 127) // 64 * 64
-        prod_w = max(guess_w, ih if options['crop_width_square'] else 0, rq.fixed_width)
-        hint = ((k * (1 + keep_detrans) + fit_image) * ih * guess_w * 2 + k * 3 * ih * prod_w * 2 + (1 << 16), k * 2 * ih * prod_w * 2 + 4096,
-                lib.shg_scan_workspace_bytes(ctypes.byref(rq)) + (lib.shg_stage_process_workspace_bytes(k, ih, guess_w, prod_w, 2) if k else 0) + 4096)
-    pin = _scratch('scan', _sizes('scan_pin', lambda *a: lib.shg_scan_host_bytes(ctypes.byref(rq)), s, k, n, h, w, bpp, limb), pinned=True)
-    rs = _lib.ScanResult()
-    stream = ops._stream()
-    status = None
-    while True:
-        arena = torch.empty(max(hint[0], 256), dtype=torch.uint8, device=dev)
-        results = torch.empty(max(hint[1], 256), dtype=torch.uint8, device=dev)
-        ws = _scratch('scan', hint[2], dev)
-        rq.arena, rq.arena_bytes, rq.results, rq.results_bytes = arena.data_ptr(), arena.numel(), results.data_ptr(), results.numel()
-        rq.workspace, rq.workspace_bytes, rq.host_pinned, rq.host_pinned_bytes = ws.data_ptr(), ws.numel(), pin.data_ptr(), pin.numel()
-        status = lib.shg_scan_file(ctypes.byref(rq), ctypes.byref(rs), stream)
-        if status == -2 and rs.phase_done == 3 and rq.start_phase == 0:
-            hint = (rs.needed_arena_bytes + 4096, rs.needed_results_bytes + 4096, rs.needed_workspace_bytes + 4096)
-            rq.start_phase = 3                                 # the raw disks and the geometry stay: resume at the warp
-            continue
-        break
-    if rs.phase_done >= 3:
-        # a little headroom: the next file's ellipse differs in the third digit, its images by a few columns
-        _arena_hint[key] = (int(rs.needed_arena_bytes * 1.03) + 4096, int(rs.needed_results_bytes * 1.03) + 4096,
-                            int(rs.needed_workspace_bytes * 1.03) + 4096)
-    error = None
-    if status != 0:
-        error = _lib.take_callback_error()
-        if error is None:
-            try:
-                _lib.check(status, 'shg_scan_file')
-            except Exception as e:      # noqa: BLE001 -- handed to the caller, which logs what the scan reached first
-                error = e
-    out = {'phase': int(rs.phase_done), 'mean': images[0], 'max': images[1], 'fit': fit, 'limb_fitted': bool(rs.limb_fitted)}
-    if rs.phase_done >= 1:
-        y1, y2 = int(rs.y1), int(rs.y2)
-        out.update(y1=y1, y2=y2, p=np.array(rs.p4))
-        if want_plot_data:
-            out['sharp'] = sharp
-            out['mask_good'] = mask[:max(y2 - y1, 0)].astype(bool)
-    if rs.phase_done >= 2:
-        out['disks'] = disks[:, :, :n]
-        out['extrema'] = mm_store[s * 128:].view(s, 2)
-    if rs.phase_done >= 3:
-        g = rs.geom16
-        out.update(phi=float(rs.phi), ratio=float(rs.ratio), theta_first=float(rs.theta_first), theta_rest=float(rs.theta_rest),
-                   circle=tuple(float(v) for v in rs.circle3), borders=[float(v) for v in rs.borders4],
-                   circle_out=tuple(float(v) for v in rs.circle_out3), out_h=int(rs.out_h), out_w=int(rs.out_w))
-        if rs.limb_fitted and want_plot_data:
-            m = int(rs.counts3[0])
-            pts, fl = points[:m].astype(np.int64) * 4, flags[:m]
-            out.update(raw_X=pts, X_f=pts[(fl & 2) != 0].astype(float), outline=outline)
-        if rs.limb_fitted:
-            out['center'] = (float(g[0]), float(g[1]))
-            out['height'] = float(g[2])
-    if rs.phase_done >= 4:
-        oh, ow, fp, pw, pp = int(rs.out_h), int(rs.out_w), int(rs.frame_pitch), int(rs.prod_w), int(rs.prod_pitch)
-        fb = (oh * fp * 2 + 255) // 256 * 256
-        pb = (oh * pp * 2 + 255) // 256 * 256
-        out['fit_image'] = _plane(arena, int(rs.fit_image_off), oh, fp, ow) if rs.fit_image_off >= 0 else None
-        out['frames'] = [_plane(arena, int(rs.frames_off) + j * fb, oh, fp, ow) for j in range(k)]
-        out['detrans'] = [_plane(arena, int(rs.detrans_off) + j * fb, oh, fp, ow) for j in range(k)] if rs.detrans_off >= 0 else None
-        for idx, name in enumerate(('final', 'cl1', 'hc')):
-            out[name] = [_plane(arena, int(rs.products_off) + (j * 3 + idx) * pb, oh, pp, pw) for j in range(k)]
-        for idx, name in enumerate(('protus', 'cc')):
-            out[name] = [_plane(results, (j * 2 + idx) * pb, oh, pp, pw) for j in range(k)]
-        out['factors'] = factors
-    return out, error
+    """ScanCall on this thread's current stream, start to finish."""
+    return ScanCall(stack, shifts, requested, options, taps_for, want_plot_data, want_fit_image).run().collect()

@@ -1,0 +1,54 @@
+"""Where does a scan worker's wall clock go?  `steps` scans through `workers` scan workers with the library's host-side
+section timer on (shg_host_timing_*): per scan, the time inside shg_scan_file, inside each stage composite, waiting in each
+stream synchronise and inside each control-plane routine -- and what is left for the interpreter between two calls.
+    python3 tools/host_budget.py [steps] [workers]"""
+import contextlib
+import ctypes
+import io
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from solex_ser_recon_en_amd import SHG_MAIN, Solex_recon, _lib, synth  # noqa: E402
+from solex_ser_recon_en_amd.video_reader import array_reader  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+stacks = [synth.synth_frames_torch(2000, 2000, 200, 16, seed=j, padded=True) for j in range(5)]
+torch.cuda.synchronize()
+
+
+def batch(n, workers):
+    tasks = []
+    for i in range(n):
+        opts = SHG_MAIN.default_options()
+        opts.update(_nolog=True)
+        tasks.append((array_reader(stacks[i % len(stacks)]), opts))
+    with contextlib.redirect_stdout(io.StringIO()):
+        Solex_recon.solex_do_work(tasks, True, distribute='none', workers=workers)
+    torch.cuda.synchronize()
+
+
+import gc  # noqa: E402
+for workers in ([int(sys.argv[2])] if len(sys.argv) > 2 else [1, 4]):
+    batch(8, workers)
+    gc.collect()
+    gc.freeze()
+    _lib.lib.shg_host_timing_enable(1)
+    t0 = time.perf_counter()
+    batch(steps, workers)
+    wall = time.perf_counter() - t0
+    _lib.lib.shg_host_timing_enable(0)
+    buf = ctypes.create_string_buffer(1 << 16)
+    _lib.lib.shg_host_timing_report(buf, len(buf))
+    print('== %d workers: %.3f ms per scan; a worker\'s cycle %.3f ms' % (workers, wall / steps * 1e3, wall / steps * 1e3 * workers))
+    rows = []
+    for line in buf.value.decode().splitlines():
+        tag, sec, calls = line.rsplit(' ', 2)
+        rows.append((tag, float(sec), int(calls)))
+    for tag, sec, calls in sorted(rows, key=lambda r: -r[1]):
+        print('  %-58s %8.1f us per scan  (%5.2f calls, %7.1f us each)' % (tag, sec / steps * 1e6, calls / steps, sec / calls * 1e6))
+    scan = dict((t, s) for t, s, _ in rows).get('scan_file', 0.0)
+    print('  outside shg_scan_file (interpreter, allocation, waiting for a task): %.1f us per scan' % ((wall * workers - scan) / steps * 1e6))

@@ -44,3 +44,28 @@ for s, e, n, q in sel:
 for tag, v in (('pass A mostly alone', alone), ('pass A with company', shared)):
     if v:
         print('%-22s n=%3d  mean duration %.1f us, other kernels overlapping it %.1f us' % (tag, len(v), sum(a for a, _ in v) / len(v), sum(b for _, b in v) / len(v)))
+
+# what sharing the device with a pass A does to the small kernels: mean duration of every kernel of the per-file chain when it
+# runs entirely inside a pass A of another scan, and when no pass A is running at all
+acc_iv = [(s, e) for s, e, n, _ in sel if n.startswith('k_accumulate')]
+
+
+def cover(s, e):
+    return sum(max(0, min(e, ae) - max(s, as_)) for as_, ae in acc_iv if ae > s and as_ < e)
+
+
+per = {}
+for s, e, n, q in others:
+    c = cover(s, e) / max(e - s, 1)
+    slot = per.setdefault(n, [[], [], []])
+    slot[0 if c > 0.9 else (1 if c < 0.1 else 2)].append((e - s) / 1e3)
+print('%-34s %6s %9s %6s %9s %7s' % ('kernel', 'n', 'beside A', 'n', 'no A', 'ratio'))
+tot_in = tot_out = 0.0
+for n, (a, b, _) in sorted(per.items(), key=lambda kv: -sum(kv[1][0] + kv[1][1] + kv[1][2])):
+    if a and b:
+        ma, mb = sum(a) / len(a), sum(b) / len(b)
+        print('%-34s %6d %9.1f %6d %9.1f %7.2f' % (n[:34], len(a), ma, len(b), mb, ma / mb))
+        per_scan = (len(a) + len(b)) / max(n_acc, 1)
+        tot_in += ma * per_scan
+        tot_out += mb * per_scan
+print('chain per scan: %.1f us if all of it ran beside a pass A, %.1f us if none did' % (tot_in, tot_out))
