@@ -374,6 +374,28 @@ int shg_contrast_products_u16(const uint16_t* frame, int64_t frame_pitch, const 
                               uint16_t* protus, uint16_t* cc, int64_t dst_pitch, int64_t disc_x0,
                               int64_t disc_y0, int64_t disc_r, shg_stream_t stream);
 
+/* ---- the limb stage's kernels fused through LDS tiles ------ ellipse_to_circle.py:148-291, 299-302 (csrc/limb_fused.hip)
+ * The same arithmetic as shg_downscale_mean_u16 / shg_box_blur_key_f64 / shg_select_keys_u32 / shg_flood_stats_lerp_f64 and
+ * shg_canny_masks_f64 / shg_edge_components, bit for bit, in 5 + 3 launches instead of 12 + 11.
+ * shg_limb_fused_fits: whether the k x k blur window (k = int(0.01 * sh)) fits the tile (k <= 16).
+ * shg_limb_prepare: for the uint16 disk [h][w] and its 4x4 block mean [sh = ceil(h/4)][sw = ceil(w/4)]: cv2.blur with windows k
+ *   and 5 (as 32-bit window sums in units of 2^-20), host_ranks4 = the two order statistics of np.median(blur 5) and the two
+ *   of np.percentile(blur k, 99), very_bright = NumPy's _lerp of the latter with weight gamma99, and np.sum(image), min, max,
+ *   np.histogram(., 20) of blur k below very_bright.  packed (device or GPU-mapped host memory, 32 doubles): [0..3] order
+ *   statistics, [4] sum, [5] min, [6] max, 20 uint32 counts at packed + 8.  *keys_out: the window sums of blur k, inside the
+ *   workspace, for shg_limb_edges.
+ * shg_limb_edges: canny (flooded = blurred < flood_thresh ? 0 : 65000; Gaussian taps as shg_canny_masks_f64) and the
+ *   8-connected labelling of its LOW mask: comp (device or GPU-mapped host memory, 2 * sh * sw + 1 int32) = [m | idx[n] |
+ *   root[n]]: the m low-mask pixels in raster order, root = smallest linear index of the pixel's component, bit 30 of root set
+ *   where the pixel is in the HIGH mask (hysteresis = keep the components holding such a pixel: one pass for the caller). */
+int shg_limb_fused_fits(int64_t sh, int64_t sw, int k);
+size_t shg_limb_prepare_workspace_bytes(int64_t sh, int64_t sw, int k);
+int shg_limb_prepare(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, int k, const int64_t* host_ranks4, double gamma99,
+                     double* packed, const uint32_t** keys_out, void* workspace, size_t workspace_bytes, shg_stream_t stream);
+size_t shg_limb_edges_workspace_bytes(int64_t sh, int64_t sw);
+int shg_limb_edges(const uint32_t* keys, int64_t sh, int64_t sw, int k, double flood_thresh, const double* host_gauss_weights,
+                   int radius, double low, double high, int32_t* comp, void* workspace, size_t workspace_bytes, shg_stream_t stream);
+
 /* ==== stage composites ============================================================================
  * Each stage function of the reference as one call: the same kernels in the same order as the entry points
  * above, the scalars / 1-D vectors in between brought to the host through PINNED memory and handled by the

@@ -129,6 +129,11 @@ SIGNATURES = {
     'shg_canny_workspace_bytes': (c_size_t, [c_int64, c_int64]),
     'shg_canny_masks_f64': (c_int, [P, c_int64, c_int64, c_double, ctypes.POINTER(c_double), c_int, c_double, c_double, P, P, P,
                                     c_size_t, P]),
+    'shg_limb_fused_fits': (c_int, [c_int64, c_int64, c_int]),
+    'shg_limb_prepare_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int]),
+    'shg_limb_prepare': (c_int, [P, c_int64, c_int64, c_int64, c_int, PI64, c_double, P, ctypes.POINTER(c_void_p), P, c_size_t, P]),
+    'shg_limb_edges_workspace_bytes': (c_size_t, [c_int64, c_int64]),
+    'shg_limb_edges': (c_int, [P, c_int64, c_int64, c_int, c_double, PD, c_int, c_double, c_double, P, P, c_size_t, P]),
     # ---- stage composites ----
     'shg_stage_mean_fit_workspace_bytes': (c_size_t, [c_int64, c_int64, c_int64, c_int]),
     'shg_stage_mean_fit_host_bytes': (c_size_t, [c_int64, c_int64]),

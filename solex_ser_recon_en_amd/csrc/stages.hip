@@ -13,6 +13,7 @@
 // Solex_recon.solex_do_work really run side by side.  The caller owns every buffer: a device workspace and a
 // pinned host staging area, both sized by the *_bytes queries, and the outputs.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <vector>
@@ -228,12 +229,37 @@ extern "C" int shg_stage_extract(const void* stack, int64_t n_frames, int64_t he
 namespace {
 constexpr int kFactor = 4;                 // downscale_local_mean(image, (4, 4)), ellipse_to_circle.py:299-301
 inline int64_t small_dim(int64_t v) { return (v + kFactor - 1) / kFactor; }
+
+// The fused kernels of limb_fused.hip (8 launches) take the stage when the blur window fits their tile; SHG_LIMB_FUSED=0
+// keeps the one-kernel-per-call chain of limb.hip (23 launches), which also serves the larger windows.
+inline bool limb_fused(int64_t sh, int64_t sw, int k) {
+    static const bool enabled = [] { const char* v = getenv("SHG_LIMB_FUSED"); return !(v && v[0] == '0'); }();
+    return enabled && k > 0 && shg_limb_fused_fits(sh, sw, k);
+}
+
+// skimage's hysteresis on the emitted LOW-mask pixels (limb_fused.hip: bit 30 of root = the pixel is in the HIGH mask): keep
+// the components that hold a high pixel, in place, raster order kept.  -> pixels kept
+int64_t keep_strong_components(int32_t* idx, int32_t* root, int64_t m, int64_t n) {
+    thread_local std::vector<uint8_t> strong;
+    if ((int64_t)strong.size() < n) strong.assign((size_t)n, 0);
+    for (int64_t i = 0; i < m; ++i)
+        if (root[i] & (1 << 30)) strong[(size_t)(root[i] & 0x3fffffff)] = 1;
+    int64_t kept = 0;
+    for (int64_t i = 0; i < m; ++i) {
+        const int32_t r = root[i] & 0x3fffffff;
+        if (strong[(size_t)r]) { idx[kept] = idx[i]; root[kept] = r; ++kept; }
+    }
+    for (int64_t i = 0; i < kept; ++i) strong[(size_t)root[i]] = 0;          // (every marked root kept at least its marking pixel)
+    return kept;
+}
 }  // namespace
 
 extern "C" size_t shg_stage_limb_points_workspace_bytes(int64_t h, int64_t w) {
     if (h <= 0 || w <= 0) return 0;
     const int64_t sh = small_dim(h), sw = small_dim(w);
     const size_t n = (size_t)sh * (size_t)sw;
+    const int k = (int)((double)sh * 0.01);
+    if (limb_fused(sh, sw, k)) return up(shg_limb_prepare_workspace_bytes(sh, sw, k)) + up(shg_limb_edges_workspace_bytes(sh, sw)) + kAlign;
     return 4 * up(n * 8) + up(std::max(shg_select_workspace_bytes(4), shg_select_keys_workspace_bytes(4))) + 2 * up(n * 4) + up(4 * 8) + up(3 * 8) + up(20 * 4) + up(256) + up(32 * 8) + 2 * up(n) +
            up(shg_canny_workspace_bytes(sh, sw)) + up(shg_edge_components_workspace_bytes(sh, sw)) + up((2 * n + 1) * 4) + kAlign;
 }
@@ -264,6 +290,59 @@ extern "C" int shg_stage_limb_points(const uint16_t* disk, int64_t h, int64_t w,
         return SHG_E_RUNTIME;
     }
     hipStream_t st = shg::as_stream(stream);
+    if (limb_fused(sh, sw, k)) {
+        Arena dev(workspace, workspace_bytes), pin(host_pinned, host_pinned_bytes);
+        const size_t prep_bytes = shg_limb_prepare_workspace_bytes(sh, sw, k), edge_bytes = shg_limb_edges_workspace_bytes(sh, sw);
+        char* prep_ws = dev.take<char>(prep_bytes);
+        char* edge_ws = dev.take<char>(edge_bytes);
+        double* h_packed = pin.take<double>(32);
+        int32_t* h_comp = pin.take<int32_t>(2 * (size_t)n + 1);
+        SHG_REQUIRE(prep_ws && edge_ws, SHG_E_WORKSPACE, "shg_stage_limb_points: workspace too small");
+        SHG_REQUIRE(h_packed && h_comp, SHG_E_WORKSPACE, "shg_stage_limb_points: pinned staging area too small");
+        Staging stg;
+        STAGE_TRY(map_staging(host_pinned, &stg, "shg_stage_limb_points"));
+        int64_t ranks[4];
+        double gamma99;
+        ranks[0] = (n & 1) ? n / 2 : n / 2 - 1;                                               // np.median(blur 5x5) (:241)
+        ranks[1] = n / 2;
+        STAGE_TRY(shg_host_percentile_plan(n, 99.0, &ranks[2], &ranks[3], &gamma99));          // np.percentile(blurred, 99) (:165)
+        const uint32_t* keys = nullptr;
+        STAGE_TRY(shg_limb_prepare(disk, h, w, pitch, k, ranks, gamma99, stg.on_device(h_packed), &keys, prep_ws, prep_bytes, stream));
+        STAGE_HIP(hipStreamSynchronize(st), "shg_stage_limb_points");
+        const double median5 = (n & 1) ? h_packed[0] : (h_packed[0] + h_packed[1]) / 2;
+        const double low = median5 / 10, high = low * 1.5;                                   // :241-243
+        int64_t counts64[20];
+        const uint32_t* hc = reinterpret_cast<const uint32_t*>(h_packed + 8);
+        for (int i = 0; i < 20; ++i) counts64[i] = hc[i];
+        double thresh3;
+        STAGE_TRY(shg_host_flood_threshold(h_packed[4], sh, sw, h_packed[5], h_packed[6], counts64, &thresh3));
+        int64_t m = 0;
+        const double* taps = host_gauss_taps;
+        int32_t* idx = h_comp + 1;
+        int32_t* root = h_comp + 1 + n;
+        for (int rung = 0;; ++rung) {                                                         // sigma = 2, 1.5, 1, 0.5
+            if (rung == 4) { shg::set_error("ellipse fit: could not find any edges of the solar disk"); return SHG_E_RUNTIME; }
+            const double sigma = 2.0 - 0.5 * rung;
+            const int radius = (int)(4.0 * sigma + 0.5);
+            STAGE_TRY(shg_limb_edges(keys, sh, sw, k, thresh3, taps, radius, low, high, stg.on_device(h_comp), edge_ws, edge_bytes, stream));
+            STAGE_HIP(hipStreamSynchronize(st), "shg_stage_limb_points");
+            const int64_t m_low = h_comp[0];
+            SHG_REQUIRE(m_low >= 0 && m_low <= n, SHG_E_RUNTIME, "shg_stage_limb_points: %lld edge pixels in an image of %lld", (long long)m_low, (long long)n);
+            m = keep_strong_components(idx, root, m_low, n);
+            if (m > 0) break;
+            taps += 2 * radius + 1;                                                           // try again with less blur (:254-256)
+        }
+        SHG_REQUIRE(points_cap >= m, SHG_E_WORKSPACE, "shg_stage_limb_points: %lld edge pixels, room for %lld", (long long)m, (long long)points_cap);
+        int64_t n_sel = 0;
+        STAGE_TRY(shg_host_limb_points(idx, root, m, sh, sw, host_flags, &n_sel));
+        for (int64_t i = 0; i < m; ++i) {
+            host_points[2 * i] = idx[i] / (int32_t)sw;
+            host_points[2 * i + 1] = idx[i] % (int32_t)sw;
+        }
+        host_counts2[0] = m;
+        host_counts2[1] = n_sel;
+        return 0;
+    }
     Arena dev(workspace, workspace_bytes), pin(host_pinned, host_pinned_bytes);
     double* small = dev.take<double>((size_t)n);
     double* blurred = dev.take<double>((size_t)n);

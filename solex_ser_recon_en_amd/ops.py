@@ -608,6 +608,49 @@ def edge_components(low_mask, high_mask, prefetch=16384):
     return out[1:1 + m].cpu().numpy(), out[1 + n:1 + n + m].cpu().numpy()
 
 
+def limb_prepare(disk, k, ranks4, gamma99):
+    """shg_limb_prepare (csrc/limb_fused.hip): the block mean of the uint16 disk, cv2.blur with windows k and 5, their order
+    statistics and the flood statistics in five launches.  -> (packed float64 [32] on the GPU: [0..3] order statistics, [4] sum,
+    [5] min, [6] max, 20 uint32 counts from packed[8]; keys int32 [sh, sw]: the window sums of blur k; the workspace that
+    holds them)."""
+    import ctypes
+    ptr, h, w, pitch = _img(disk, 'disk', torch.uint16)
+    sh, sw = -(-h // 4), -(-w // 4)
+    need = lib.shg_limb_prepare_workspace_bytes(sh, sw, int(k))
+    if need == 0:
+        raise ValueError('limb_prepare: a %d x %d window is outside the fused path' % (k, k))
+    ws = torch.empty(need, dtype=torch.uint8, device=disk.device)
+    packed = torch.zeros(32, dtype=torch.float64, device=disk.device)
+    rk = (ctypes.c_int64 * 4)(*[int(r) for r in ranks4])
+    keys_ptr = ctypes.c_void_p()
+    _lib.check(lib.shg_limb_prepare(ptr, h, w, pitch, int(k), rk, float(gamma99), packed.data_ptr(), ctypes.byref(keys_ptr), ws.data_ptr(),
+                                    need, _stream()), 'shg_limb_prepare')
+    off = keys_ptr.value - ws.data_ptr()
+    keys = ws[off:off + sh * sw * 4].view(torch.int32).view(sh, sw)
+    return packed, keys, ws
+
+
+def limb_edges(keys, k, flood_thresh, sigma, low, high):
+    """shg_limb_edges: canny and the labelling of its low mask from the window sums of the blurred image, three launches.
+    -> (idx int32 [m], root int32 [m], high bool [m]) HOST arrays: the LOW-mask pixels in raster order, the smallest linear index
+    of each pixel's component, and whether the pixel is in the HIGH mask."""
+    import ctypes
+    _dev(keys, 'keys')
+    sh, sw = keys.shape
+    n = sh * sw
+    taps, radius = gaussian_taps(sigma)
+    taps = np.ascontiguousarray(taps, dtype=np.float64)
+    need = lib.shg_limb_edges_workspace_bytes(sh, sw)
+    ws = torch.empty(need, dtype=torch.uint8, device=keys.device)
+    comp = torch.zeros(2 * n + 1, dtype=torch.int32, device=keys.device)
+    _lib.check(lib.shg_limb_edges(keys.data_ptr(), sh, sw, int(k), float(flood_thresh), taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                  radius, float(low), float(high), comp.data_ptr(), ws.data_ptr(), need, _stream()), 'shg_limb_edges')
+    host = comp.cpu().numpy()
+    m = int(host[0])
+    idx, root = host[1:1 + m], host[1 + n:1 + n + m]
+    return idx, root & 0x3fffffff, (root >> 30 & 1).astype(bool)
+
+
 def select_u16(img, ranks, out=None):
     """-> float64 GPU tensor: the ranks[i]-th smallest pixels (0-based) of a uint16 image."""
     import ctypes

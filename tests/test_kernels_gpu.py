@@ -795,3 +795,63 @@ def test_rowpair_stats_with_heavily_tied_ratios(ops, orc, levels):
         xa[y - y1], xb[y - y1] = a, max(a, b)
     got = host(ops.rowpair_logratio_stats(dev(img), y1, y2, dev(xa), dev(xb)))
     np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-15)
+
+
+# ---- the limb stage's fused kernels against the one-kernel-per-call chain (csrc/limb_fused.hip vs csrc/limb.hip) ----------
+def _limb_disk(h, w, seed):
+    """A disk-like uint16 image [h, w]: a bright ellipse with limb darkening, sky, noise, a few saturated pixels."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    r2 = ((xx - 0.52 * w) / (0.40 * w)) ** 2 + ((yy - 0.49 * h) / (0.43 * h)) ** 2
+    img = np.where(r2 < 1, 9000 + 30000 * np.sqrt(np.clip(1 - r2, 0, 1)), 900.0)
+    img = img + rng.normal(0, 250, img.shape)
+    img[rng.integers(0, h, 40), rng.integers(0, w, 40)] = 65535
+    return np.clip(img, 0, 65535).astype(np.uint16)
+
+
+@pytest.mark.parametrize('h,w,seed', [(2000, 2000, 1), (1203, 997, 2), (3204, 1601, 3), (6400, 800, 4), (420, 640, 5)])
+def test_fused_limb_kernels_equal_the_separate_ones(ops, h, w, seed):
+    """shg_limb_prepare == downscale + cv2.blur (k and 5) + the two selects + the flood statistics, and shg_limb_edges ==
+    canny masks + hysteresis labelling, value for value: same window sums, same order statistics, same sum / min / max /
+    histogram, same edge pixels with the same roots -- for blur windows 5, 3, 8, 16 and 1, images whose sides are not
+    multiples of 4 or of the tile, and every rung of canny's retry ladder."""
+
+    disk = torch.from_numpy(_limb_disk(h, w, seed)).cuda()
+    sh, sw = -(-h // 4), -(-w // 4)
+    n = sh * sw
+    k = int(sh * 0.01)
+    assert k >= 1
+    from solex_ser_recon_en_amd import hostmath
+    ranks = [n // 2 if n & 1 else n // 2 - 1, n // 2]
+    lo, hi, gamma = hostmath.percentile_plan(n, 99.0)
+    ranks += [lo, hi]
+    # the separate kernels
+    small = ops.downscale_mean_u16(disk, 4)
+    blurred, keys_k = ops.box_blur_key_f64(small, k)
+    _, keys_5 = (blurred, keys_k) if k == 5 else ops.box_blur_key_f64(small, 5)
+    want_os = ops.select_keys_u32([keys_5, keys_5, keys_k, keys_k], ranks, [5, 5, k, k]).cpu().numpy()
+    stats, counts = ops.flood_stats_lerp(small, blurred, torch.from_numpy(want_os[2:4].copy()).cuda(), gamma)
+    # the fused ones
+    packed, keys, ws = ops.limb_prepare(disk, k, ranks, gamma)
+    torch.cuda.synchronize()
+    got = packed.cpu().numpy()
+    np.testing.assert_array_equal(keys.cpu().numpy(), keys_k.cpu().numpy())
+    np.testing.assert_array_equal(got[0:4], want_os)
+    np.testing.assert_array_equal(got[4:7], stats.cpu().numpy())
+    np.testing.assert_array_equal(got[8:18].view(np.uint32), counts.cpu().numpy().view(np.uint32))
+    # canny + labelling, every rung of the ladder
+    counts64 = counts.cpu().numpy().astype(np.int64)
+    thresh = hostmath.flood_threshold(float(got[4]), (sh, sw), float(got[5]), float(got[6]), counts64)
+    median5 = got[0] if n & 1 else (got[0] + got[1]) / 2
+    low, high = median5 / 10, median5 / 10 * 1.5
+    for sigma in (2.0, 1.5, 1.0, 0.5):
+        lm, hm = ops.canny_masks(blurred, thresh, sigma, low, high)
+        want_idx, want_root = ops.edge_components(lm, hm, prefetch=n)
+        idx, root, strong = ops.limb_edges(keys, k, thresh, sigma, low, high)
+        flat_low = np.flatnonzero(lm.cpu().numpy().reshape(-1))
+        np.testing.assert_array_equal(idx, flat_low)                              # every low pixel, raster order
+        np.testing.assert_array_equal(strong, hm.cpu().numpy().reshape(-1)[idx].astype(bool))
+        keep = np.isin(root, np.unique(root[strong]))                              # the hysteresis the stage does on the host
+        np.testing.assert_array_equal(idx[keep], want_idx)
+        np.testing.assert_array_equal(root[keep], want_root)
+        assert len(want_idx) > 0

@@ -1,8 +1,6 @@
-for w in 8 8 4; do python3 bench.py --steps 20 --warmup 5 --no-e2e --no-cpu-baseline --no-extra --workers $w --repeats 8 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print('native pool, workers $w: ms/step %.3f' % d['ms_per_step'], d['repeats']['ms_per_step'])"; done
-python3 bench.py --steps 20 --warmup 30 --no-e2e --no-cpu-baseline --no-extra --workers 8 --repeats 8 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print('warmup 30, workers 8: ms/step %.3f' % d['ms_per_step'], d['repeats']['ms_per_step'])"
+python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "fused_limb or limb" 2>&1 | tail -4
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/k/step_trace -- python3 $R/tools/step_loop.py 20 > /dev/null 2>&1
+cd $R
+python3 tools/kernel_table.py gpurun_out/k/step_trace 20 | grep -E "limb|library"
