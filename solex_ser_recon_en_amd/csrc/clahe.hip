@@ -10,9 +10,17 @@
 // private 65536 x u16 LDS histogram (128 KiB) for a slice of <= 65535 pixels of one
 // tile and flushes only its non-zero bins with global atomics.
 #include <stdlib.h>
+#include <type_traits>
+#include <algorithm>
 #include "shg_common.h"
 
 namespace {
+// A launch over several disks (blockIdx.z): every disk has a workspace of its own, `zs` bytes after the previous one, so a
+// pointer into the first disk's workspace becomes the disk's by adding blockIdx.z * zs bytes.
+template <typename T>
+__device__ __forceinline__ T* zdisk(T* p, size_t zs) {
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(p)) + (size_t)blockIdx.z * zs);
+}
 
 constexpr int HIST16 = 65536;
 // Workgroups flush their select histograms into one of SEL_SLOTS copies (blockIdx % SEL_SLOTS): ~500 workgroups adding to
@@ -83,9 +91,11 @@ __global__ __launch_bounds__(1024) void k_tile_hist16(const uint16_t* __restrict
 // reads every bin anyway, also leaves what the next steps need: the 64-bin chunk sums the percentiles start from
 // (k_hist_ranks) and, per 2048 bins, the clipped total and the clipped-off excess, so that the LUT no longer has to be
 // built by one workgroup per tile (k_tile_lut16_blocks: 32 workgroups per tile instead of one).
-__global__ __launch_bounds__(1024) void k_tile_hist16_slices(const uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch,
-                                                             int tiles, int64_t th, int64_t tw, uint32_t* __restrict__ part) {
+__global__ __launch_bounds__(1024) void k_tile_hist16_slices(shg::PtrBatch imgs, int64_t h, int64_t w, int64_t pitch,
+                                                             int tiles, int64_t th, int64_t tw, uint32_t* __restrict__ part, size_t zs) {
     extern __shared__ uint32_t lh[];   // HIST16/2 dwords, two u16 counters each
+    const uint16_t* __restrict__ img = imgs.at<const uint16_t>(blockIdx.z);
+    part = zdisk(part, zs);
     const int tile = blockIdx.y;
     const int64_t ty = tile / tiles, tx = tile % tiles;
     const int64_t area = th * tw;
@@ -130,8 +140,12 @@ __global__ __launch_bounds__(1024) void k_tile_hist16_slices(const uint16_t* __r
 // hist [tile][65536] u32; chunk_tile [tile][1024] (64-bin sums); se [tile][32][2] = clipped total, excess per 2048 bins.
 __global__ __launch_bounds__(1024) void k_hist_reduce(const uint32_t* __restrict__ part, int slices, int clip,
                                                       uint32_t* __restrict__ hist, uint32_t* __restrict__ chunk_tile,
-                                                      int32_t* __restrict__ se) {
+                                                      int32_t* __restrict__ se, size_t zs) {
     __shared__ int wsum[2][16];
+    part = zdisk(part, zs);
+    hist = zdisk(hist, zs);
+    chunk_tile = zdisk(chunk_tile, zs);
+    se = zdisk(se, zs);
     const int tile = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d = blockIdx.x * 1024 + tid;
     const uint32_t* p = part + (int64_t)tile * slices * (HIST16 / 2) + d;
@@ -171,9 +185,12 @@ __global__ __launch_bounds__(1024) void k_hist_reduce(const uint32_t* __restrict
 // the counts before a workgroup's first bin are the clipped totals of the workgroups before it, plus what the
 // redistribution adds there -- `batch` per bin and one more for the bins 0, step, 2 step, ... below residual * step.
 __global__ __launch_bounds__(1024) void k_tile_lut16_blocks(const uint32_t* __restrict__ hist, const int32_t* __restrict__ se, int clip,
-                                                            float lut_scale, uint16_t* __restrict__ lut) {
+                                                            float lut_scale, uint16_t* __restrict__ lut, size_t zs) {
     constexpr int HIST = 65536;
     __shared__ int s_before, s_excess;
+    hist = zdisk(hist, zs);
+    se = zdisk(se, zs);
+    lut = zdisk(lut, zs);
     __shared__ int wsum[16];
     const int tile = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (wave == 0) {
@@ -451,13 +468,17 @@ __global__ __launch_bounds__(256) void k_clahe_interp(const T* __restrict__ img,
 // of the high bytes of the pixels it has just produced, in sel_hist's slot layout (k_select16_pass, pass 0): the values
 // are in registers here, which saves that pass its read of the image.
 template <int PX, bool COUNT>
-__global__ __launch_bounds__(256) void k_clahe_interp_vm(const uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch,
+__global__ __launch_bounds__(256) void k_clahe_interp_vm(shg::PtrBatch imgs, int64_t h, int64_t w, int64_t pitch,
                                                          int tiles, float inv_tw, float inv_th,
-                                                         const uint16_t* __restrict__ lut, uint16_t* __restrict__ dst, int64_t dst_pitch,
-                                                         int rows, uint32_t* __restrict__ sel_hist, int sel_stride) {
+                                                         const uint16_t* __restrict__ lut, shg::PtrBatch dsts, int64_t dst_pitch,
+                                                         int rows, uint32_t* __restrict__ sel_hist, int sel_stride, size_t zs) {
     constexpr int HIST = 65536;
     constexpr int COPIES = 8;                            // interleaved copies of each bin: a row's pixels crowd a few bins
     __shared__ uint32_t lh[COUNT ? 256 * COPIES : 1];
+    const uint16_t* __restrict__ img = imgs.at<const uint16_t>(blockIdx.z);
+    uint16_t* __restrict__ dst = dsts.at<uint16_t>(blockIdx.z);
+    lut = zdisk(lut, zs);
+    if (COUNT) sel_hist = zdisk(sel_hist, zs);
     if (COUNT) {
         for (int i = threadIdx.x; i < 256 * COPIES; i += 256) lh[i] = 0;
         __syncthreads();
@@ -617,10 +638,12 @@ constexpr int SEL_COPIES0 = 16, SEL_COPIES1 = 4;
 
 struct Ranks8 { int64_t v[8]; };            // the requested ranks travel as a kernel argument: no host-to-device copy per call
 
-__global__ __launch_bounds__(1024) void k_select16_pass(const uint16_t* __restrict__ img, int64_t h, int64_t w, int64_t pitch, int pass,
+__global__ __launch_bounds__(1024) void k_select16_pass(shg::PtrBatch imgs, int64_t h, int64_t w, int64_t pitch, int pass,
                                                        Ranks8 ranks, int n_ranks, uint32_t* __restrict__ hist,
-                                                       int vec_ok) {
+                                                       int vec_ok, size_t zs) {
     __shared__ uint32_t lh[8 * 256 * SEL_COPIES1];        // pass 0: [bin][16 copies]; pass 1: [rank][bin][4 copies]
+    const uint16_t* __restrict__ img = imgs.at<const uint16_t>(blockIdx.z);
+    hist = zdisk(hist, zs);
     __shared__ int his_s[8];
     if (pass == 1) {
         // replay pass 0's choice for every rank: ONE scan of the shared high-byte histogram (a scan per rank was a third of
@@ -717,7 +740,9 @@ __global__ __launch_bounds__(1024) void k_select16_pass(const uint16_t* __restri
 
 // grid (n_ranks), 256 threads
 __global__ __launch_bounds__(256) void k_select16_final(Ranks8 ranks, const uint32_t* __restrict__ hist,
-                                                        double* __restrict__ out) {
+                                                        double* __restrict__ out, size_t zs, int out_zstride) {
+    hist = zdisk(hist, zs);
+    out += (int64_t)blockIdx.z * out_zstride;
     int hi, lo;
     int64_t below, below2;
     pick_digit(hist, (1 + (int)gridDim.x) * 256, ranks.v[blockIdx.x], hi, below);
@@ -740,8 +765,12 @@ __global__ __launch_bounds__(1024) void k_chunk_sums(const uint32_t* __restrict_
 // image: no reflected padding in the histograms).  One workgroup per rank: lane t takes the t-th run of 64 bins from the
 // chunk sums of k_chunk_sums, a workgroup scan finds the run that holds the rank, one wave scans its 64 bins.
 __global__ __launch_bounds__(1024) void k_hist_ranks(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ chunk_sums,
-                                                     int chunk_sets, int ntiles, Ranks8 ranks, double* __restrict__ out) {
+                                                     int chunk_sets, int ntiles, Ranks8 ranks, double* __restrict__ out, size_t zs,
+                                                     int out_zstride) {
     __shared__ int64_t wtot[16];
+    hist = zdisk(hist, zs);
+    chunk_sums = zdisk(chunk_sums, zs);
+    out += (int64_t)blockIdx.z * out_zstride;
     __shared__ int64_t pick[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t rank = ranks.v[blockIdx.x];
@@ -793,24 +822,46 @@ extern "C" size_t shg_clahe_workspace_bytes(int tiles, int bytes_per_px) {
 
 namespace {
 // sel_hist (may be NULL): the zeroed slot histograms of the select that follows on dst; the kernel then counts its first pass
-inline bool launch_interp16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, int tiles, float inv_tw, float inv_th,
-                            const uint16_t* lut, bool value_major, uint16_t* dst, int64_t dst_pitch, uint32_t* sel_hist, int sel_stride,
+// The disks of one launch: their images, where their results go, how many, and the byte distance between their workspaces.
+struct Disks {
+    shg::PtrBatch src, dst;
+    int n;
+    size_t zs;
+    bool aligned(unsigned mask) const {
+        uintptr_t bits = 0;
+        for (int i = 0; i < n; ++i) bits |= reinterpret_cast<uintptr_t>(src.p[i]) | reinterpret_cast<uintptr_t>(dst.p[i]);
+        return (bits & mask) == 0;
+    }
+};
+inline Disks one_disk(const void* src, void* dst) {
+    Disks d = {};
+    d.src.p[0] = src;
+    d.dst.p[0] = dst ? dst : src;
+    d.n = 1;
+    d.zs = 0;
+    return d;
+}
+
+inline bool launch_interp16(const Disks& d, int64_t h, int64_t w, int64_t pitch, int tiles, float inv_tw, float inv_th,
+                            const uint16_t* lut, bool value_major, int64_t dst_pitch, uint32_t* sel_hist, int sel_stride,
                             hipStream_t st) {
-    if (!value_major) {
-        k_clahe_interp<uint16_t, HIST16><<<dim3((unsigned)((w + 255) / 256), (unsigned)h), 256, 0, st>>>(img, h, w, pitch, tiles, inv_tw, inv_th, lut, dst, dst_pitch);
+    const unsigned nz = (unsigned)d.n;
+    if (!value_major) {                                  // (single image only: the caller checked)
+        k_clahe_interp<uint16_t, HIST16><<<dim3((unsigned)((w + 255) / 256), (unsigned)h), 256, 0, st>>>(
+            static_cast<const uint16_t*>(d.src.p[0]), h, w, pitch, tiles, inv_tw, inv_th, lut, static_cast<uint16_t*>(const_cast<void*>(d.dst.p[0])), dst_pitch);
         return false;
     }
-    const bool vec = ((reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(dst)) & 7) == 0 && pitch % 4 == 0 && dst_pitch % 4 == 0;
+    const bool vec = d.aligned(7) && pitch % 4 == 0 && dst_pitch % 4 == 0;
     if (vec && sel_hist) {
         const int rows = 4;                              // per workgroup: amortises the histogram's zeroing and flush
-        k_clahe_interp_vm<4, true><<<dim3((unsigned)((w + 1023) / 1024), (unsigned)((h + rows - 1) / rows)), 256, 0, st>>>(
-            img, h, w, pitch, tiles, inv_tw, inv_th, lut, dst, dst_pitch, rows, sel_hist, sel_stride);
+        k_clahe_interp_vm<4, true><<<dim3((unsigned)((w + 1023) / 1024), (unsigned)((h + rows - 1) / rows), nz), 256, 0, st>>>(
+            d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, rows, sel_hist, sel_stride, d.zs);
         return true;
     }
     if (vec) {
-        k_clahe_interp_vm<4, false><<<dim3((unsigned)((w + 1023) / 1024), (unsigned)h), 256, 0, st>>>(img, h, w, pitch, tiles, inv_tw, inv_th, lut, dst, dst_pitch, 1, nullptr, 0);
+        k_clahe_interp_vm<4, false><<<dim3((unsigned)((w + 1023) / 1024), (unsigned)h, nz), 256, 0, st>>>(d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, 1, nullptr, 0, d.zs);
     } else {
-        k_clahe_interp_vm<1, false><<<dim3((unsigned)((w + 255) / 256), (unsigned)h), 256, 0, st>>>(img, h, w, pitch, tiles, inv_tw, inv_th, lut, dst, dst_pitch, 1, nullptr, 0);
+        k_clahe_interp_vm<1, false><<<dim3((unsigned)((w + 255) / 256), (unsigned)h, nz), 256, 0, st>>>(d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, 1, nullptr, 0, d.zs);
     }
     return false;
 }
@@ -852,12 +903,15 @@ extern "C" size_t shg_clahe_workspace_bytes_for(int64_t h, int64_t w, int tiles,
 namespace {
 // chunk_tile_out (may be NULL): where the per-tile 64-bin chunk sums were left, or NULL when the call took the
 // histogram-with-atomics path (small workspace, 8-bit image, clip out of the u16 range).
+// disks (may be NULL: the one image img -> dst): several images of one shape in one launch per kernel, disk i working in the
+// workspace at `workspace + i * disks->zs`; only the atomics-free 16-bit path takes more than one.
 int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_per_px, double clip_limit, int tiles,
                void* dst, int64_t dst_pitch, void* workspace, size_t workspace_bytes, shg_stream_t stream, const uint32_t** chunk_tile_out,
-               uint32_t* sel_hist, int sel_stride, bool* sel_pass0_done) {
+               uint32_t* sel_hist, int sel_stride, bool* sel_pass0_done, const Disks* disks = nullptr) {
     if (chunk_tile_out) *chunk_tile_out = nullptr;
     if (sel_pass0_done) *sel_pass0_done = false;
     SHG_REQUIRE(img && dst && workspace, SHG_E_ARG, "shg_clahe: null pointer");
+    const Disks dset = disks ? *disks : one_disk(img, dst);
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w && dst_pitch >= w, SHG_E_ARG, "shg_clahe: bad image size");
     SHG_REQUIRE(bytes_per_px == 1 || bytes_per_px == 2, SHG_E_ARG, "shg_clahe: bytes_per_px must be 1 or 2");
     SHG_REQUIRE(tiles >= 1 && tiles <= 16, SHG_E_UNSUPPORTED, "shg_clahe: tiles must be in 1..16");
@@ -891,19 +945,20 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
         uint32_t* chunk_tile = reinterpret_cast<uint32_t*>(extra + f.chunk);
         int32_t* se = reinterpret_cast<int32_t*>(extra + f.se);
         { SHG_PROF("clahe_hist", st);
-          k_tile_hist16_slices<<<dim3((unsigned)f.slices, (unsigned)ntiles), 1024, HIST16 * 2, st>>>(static_cast<const uint16_t*>(img), h, w, pitch, tiles, th, tw, part);
+          const unsigned nz = (unsigned)dset.n;
+          k_tile_hist16_slices<<<dim3((unsigned)f.slices, (unsigned)ntiles, nz), 1024, HIST16 * 2, st>>>(dset.src, h, w, pitch, tiles, th, tw, part, dset.zs);
           if (int e = shg::check_launch("k_tile_hist16_slices")) return e;
-          k_hist_reduce<<<dim3(32, (unsigned)ntiles), 1024, 0, st>>>(part, (int)f.slices, clip, hist, chunk_tile, se); }
+          k_hist_reduce<<<dim3(32, (unsigned)ntiles, nz), 1024, 0, st>>>(part, (int)f.slices, clip, hist, chunk_tile, se, dset.zs); }
         if (int e = shg::check_launch("k_hist_reduce")) return e;
-        { SHG_PROF("clahe_lut", st); k_tile_lut16_blocks<<<dim3(32, (unsigned)ntiles), 1024, 0, st>>>(hist, se, clip, lut_scale, lut); }
+        { SHG_PROF("clahe_lut", st); k_tile_lut16_blocks<<<dim3(32, (unsigned)ntiles, (unsigned)dset.n), 1024, 0, st>>>(hist, se, clip, lut_scale, lut, dset.zs); }
         if (int e = shg::check_launch("k_tile_lut16_blocks")) return e;
         { SHG_PROF("clahe_interp", st);
-          const bool counted = launch_interp16(static_cast<const uint16_t*>(img), h, w, pitch, tiles, inv_tw, inv_th, lut, true, static_cast<uint16_t*>(dst), dst_pitch,
-                                               sel_hist, sel_stride, st);
+          const bool counted = launch_interp16(dset, h, w, pitch, tiles, inv_tw, inv_th, lut, true, dst_pitch, sel_hist, sel_stride, st);
           if (sel_pass0_done) *sel_pass0_done = counted; }
         if (chunk_tile_out) *chunk_tile_out = chunk_tile;
         return shg::check_launch("k_clahe_interp");
     }
+    SHG_REQUIRE(dset.n == 1, SHG_E_UNSUPPORTED, "shg_clahe: several disks per launch need the roomy 16-bit workspace");
     if (hipError_t e = hipMemsetAsync(hist, 0, (size_t)ntiles * hist_size * sizeof(uint32_t), st)) {
         shg::set_error("shg_clahe: memset: %s", hipGetErrorString(e));
         return (int)e;
@@ -921,7 +976,7 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
             k_tile_lut<HIST16><<<ntiles, 1024, 0, st>>>(hist, clip, lut_scale, lut);
         }
         if (int e = shg::check_launch("k_tile_lut")) return e;
-        { SHG_PROF("clahe_interp", st); launch_interp16(static_cast<const uint16_t*>(img), h, w, pitch, tiles, inv_tw, inv_th, lut, false, static_cast<uint16_t*>(dst), dst_pitch, nullptr, 0, st); }
+        { SHG_PROF("clahe_interp", st); launch_interp16(dset, h, w, pitch, tiles, inv_tw, inv_th, lut, false, dst_pitch, nullptr, 0, st); }
     } else {
         int64_t hb = (area + 4095) / 4096;
         if (hb > 256) hb = 256;
@@ -971,8 +1026,12 @@ extern "C" size_t shg_select_u16_workspace_bytes(int n_ranks) {
 
 namespace {
 // pass0_done: the slot histograms are zeroed and already hold the high-byte counts (k_clahe_interp_vm<.., true>)
+// disks (may be NULL: the one image img): several images per launch, disk i with its histograms at workspace + i * zs and its
+// results at out + i * out_zstride
 int select_u16_impl(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, const int64_t* host_ranks, int n_ranks,
-                    double* out, void* workspace, size_t workspace_bytes, shg_stream_t stream, bool zeroed, bool pass0_done) {
+                    double* out, void* workspace, size_t workspace_bytes, shg_stream_t stream, bool zeroed, bool pass0_done,
+                    const Disks* disks = nullptr, int out_zstride = 0) {
+    const Disks dset = disks ? *disks : one_disk(img, nullptr);
     SHG_REQUIRE(img && host_ranks && out && workspace, SHG_E_ARG, "shg_select_u16: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w && n_ranks >= 1 && n_ranks <= 8, SHG_E_ARG, "shg_select_u16: bad sizes");
     SHG_REQUIRE(workspace_bytes >= shg_select_u16_workspace_bytes(n_ranks), SHG_E_WORKSPACE, "shg_select_u16: workspace too small");
@@ -991,15 +1050,18 @@ int select_u16_impl(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, co
     int64_t want = (h * w + 8191) / 8192;
     want = want < 1 ? 1 : (want > 1024 ? 1024 : want);
     const unsigned blocks = (unsigned)(h < want ? h : want);
-    const int vec_ok = ((reinterpret_cast<uintptr_t>(img) & 15) == 0) && (pitch % 8 == 0);
+    uintptr_t bits = 0;
+    for (int i = 0; i < dset.n; ++i) bits |= reinterpret_cast<uintptr_t>(dset.src.p[i]);
+    const int vec_ok = ((bits & 15) == 0) && (pitch % 8 == 0);
+    SHG_REQUIRE(zeroed || dset.n == 1, SHG_E_ARG, "shg_select_u16: several disks need their histograms zeroed by the caller");
     SHG_PROF("select_u16", st);
     for (int pass = pass0_done ? 1 : 0; pass < 2; ++pass) {
         // 512 threads: the zeroing / replay / flush around the pixel loop is shared by twice the waves (256 / 512 / 1024
         // threads: 44.7 / 40.6 / 40.3 us for two ranks, tools/bench_select.py)
-        k_select16_pass<<<blocks, 512, 0, st>>>(img, h, w, pitch, pass, ranks, n_ranks, hist, vec_ok);
+        k_select16_pass<<<dim3(blocks, 1u, (unsigned)dset.n), 512, 0, st>>>(dset.src, h, w, pitch, pass, ranks, n_ranks, hist, vec_ok, dset.zs);
         if (int err = shg::check_launch("k_select16_pass")) return err;
     }
-    k_select16_final<<<(unsigned)n_ranks, 256, 0, st>>>(ranks, hist, out);
+    k_select16_final<<<dim3((unsigned)n_ranks, 1u, (unsigned)dset.n), 256, 0, st>>>(ranks, hist, out, dset.zs, out_zstride);
     return shg::check_launch("k_select16_final");
 }
 }  // namespace
@@ -1062,12 +1124,84 @@ extern "C" int shg_contrast_stats_u16(const uint16_t* frame, int64_t h, int64_t 
         hipStream_t st = shg::as_stream(stream);
         SHG_PROF("hist_ranks", st);
         if (chunk_tile) {                                // left by k_hist_reduce, one set per tile
-            k_hist_ranks<<<2, 1024, 0, st>>>(reinterpret_cast<const uint32_t*>(ws), chunk_tile, tiles * tiles, tiles * tiles, ranks, out5);
+            k_hist_ranks<<<2, 1024, 0, st>>>(reinterpret_cast<const uint32_t*>(ws), chunk_tile, tiles * tiles, tiles * tiles, ranks, out5, 0, 0);
         } else {
             k_chunk_sums<<<64, 1024, 0, st>>>(reinterpret_cast<const uint32_t*>(ws), tiles * tiles, chunk_sums);
-            k_hist_ranks<<<2, 1024, 0, st>>>(reinterpret_cast<const uint32_t*>(ws), chunk_sums, 1, tiles * tiles, ranks, out5);
+            k_hist_ranks<<<2, 1024, 0, st>>>(reinterpret_cast<const uint32_t*>(ws), chunk_sums, 1, tiles * tiles, ranks, out5, 0, 0);
         }
         if (int e = shg::check_launch("k_hist_ranks")) return e;
     } else if (int e = shg_select_u16(frame, h, w, pitch, ranks_frame2, 2, out5, ws + c, s2, stream)) return e;
     return select_u16_impl(cl1, h, w, cl1_pitch, ranks_cl13, 3, out5 + 2, sel3, shg_select_u16_workspace_bytes(3), stream, true, pass0_done);
+}
+
+// image_process's CLAHE + order statistics for the k disks of a file in one launch per kernel (shg_stage_process_frames; a
+// Doppler stack, Solex_recon.py:105-133).  host_frames / host_cl1: device pointers of k images of one shape; out5: [k][5];
+// workspace: k areas of shg_contrast_stats_workspace_bytes_for(h, w, tiles) bytes.  The batched launches need the atomics-free
+// CLAHE path (clip limit within the u16 range) and a tile grid that divides the image (percentiles read off the tile
+// histograms); anything else goes disk by disk through shg_contrast_stats_u16 -- same results either way.
+int shg::contrast_stats_batch(const uint16_t* const* host_frames, int64_t k, int64_t h, int64_t w, int64_t pitch, double clip_limit, int tiles,
+                              uint16_t* const* host_cl1, int64_t cl1_pitch, const int64_t* ranks_frame2, const int64_t* ranks_cl13, double* out5,
+                              void* workspace, size_t workspace_bytes, shg_stream_t stream) {
+    SHG_REQUIRE(host_frames && host_cl1 && ranks_frame2 && ranks_cl13 && out5 && workspace && k > 0, SHG_E_ARG, "shg_contrast_stats_u16: null pointer");
+    SHG_REQUIRE(h > 0 && w > 0, SHG_E_ARG, "shg_contrast_stats_u16: empty image");
+    const size_t per = shg_contrast_stats_workspace_bytes_for(h, w, tiles);
+    SHG_REQUIRE(per != 0, SHG_E_WORKSPACE, "shg_contrast_stats_u16: bad tile count");
+    bool batched = k > 1 && workspace_bytes >= (size_t)k * per && tiles >= 1 && tiles <= 16 && h % tiles == 0 && w % tiles == 0 && clip_limit > 0.0;
+    if (batched) {
+        int64_t th, tw;
+        tile_geometry(h, w, tiles, &th, &tw);
+        const int clip = (int)(clip_limit * (double)(th * tw) / HIST16);
+        batched = clip <= 65535;                                   // (clip = max(clip, 1) >= 1)
+    }
+    if (!batched) {
+        const size_t each = workspace_bytes >= (size_t)k * per ? per : 0;       // every disk its own area if there is room, else one after the other in the same
+        for (int64_t i = 0; i < k; ++i)
+            if (int e = shg_contrast_stats_u16(host_frames[i], h, w, pitch, clip_limit, tiles, host_cl1[i], cl1_pitch, ranks_frame2, ranks_cl13,
+                                               out5 + 5 * i, static_cast<char*>(workspace) + (size_t)i * each, each ? each : workspace_bytes, stream))
+                return e;
+        return 0;
+    }
+    hipStream_t st = shg::as_stream(stream);
+    const size_t c = (shg_clahe_workspace_bytes_for(h, w, tiles, 2) + 255) / 256 * 256, s2 = (shg_select_u16_workspace_bytes(2) + 255) / 256 * 256;
+    Ranks8 ranks = {};
+    for (int i = 0; i < 2; ++i) {
+        SHG_REQUIRE(ranks_frame2[i] >= 0 && ranks_frame2[i] < h * w, SHG_E_ARG, "shg_contrast_stats_u16: rank %lld outside the image", (long long)ranks_frame2[i]);
+        ranks.v[i] = ranks_frame2[i];
+    }
+    for (int64_t i0 = 0; i0 < k; i0 += shg::kMaxBatch) {
+        const int m = (int)std::min<int64_t>(shg::kMaxBatch, k - i0);
+        char* ws = static_cast<char*>(workspace) + (size_t)i0 * per;
+        Disks d = {};
+        d.n = m;
+        d.zs = per;
+        for (int i = 0; i < m; ++i) {
+            SHG_REQUIRE(host_frames[i0 + i] && host_cl1[i0 + i], SHG_E_ARG, "shg_contrast_stats_u16: null image");
+            d.src.p[i] = host_frames[i0 + i];
+            d.dst.p[i] = host_cl1[i0 + i];
+        }
+        // the selects on the CLAHE images: their slot histograms zeroed up front, every disk's in its own area
+        uint32_t* sel3 = reinterpret_cast<uint32_t*>(ws + c + s2);
+        if (hipError_t e = hipMemset2DAsync(sel3, per, 0, (size_t)SEL_SLOTS * (1 + 3) * 256 * sizeof(uint32_t), (size_t)m, st)) {
+            shg::set_error("shg_contrast_stats_u16: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        const uint32_t* chunk_tile = nullptr;
+        bool pass0_done = false;
+        if (int e = clahe_impl(host_frames[i0], h, w, pitch, 2, clip_limit, tiles, host_cl1[i0], cl1_pitch, ws, c, stream, &chunk_tile, sel3, (1 + 3) * 256,
+                               &pass0_done, &d))
+            return e;
+        SHG_REQUIRE(chunk_tile, SHG_E_RUNTIME, "shg_contrast_stats_u16: the batched path did not take the slice histograms");
+        {
+            SHG_PROF("hist_ranks", st);
+            k_hist_ranks<<<dim3(2u, 1u, (unsigned)m), 1024, 0, st>>>(reinterpret_cast<const uint32_t*>(ws), chunk_tile, tiles * tiles, tiles * tiles, ranks,
+                                                                      out5 + 5 * i0, per, 5);
+            if (int e = shg::check_launch("k_hist_ranks")) return e;
+        }
+        Disks dc = d;
+        dc.src = d.dst;                                            // the selects read the CLAHE images
+        if (int e = select_u16_impl(host_cl1[i0], h, w, cl1_pitch, ranks_cl13, 3, out5 + 5 * i0 + 2, sel3, shg_select_u16_workspace_bytes(3), stream, true,
+                                    pass0_done, &dc, 5))
+            return e;
+    }
+    return 0;
 }

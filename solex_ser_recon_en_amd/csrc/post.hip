@@ -2,16 +2,20 @@
 // 4x4 block mean.  Reference: Solex_recon.py:155-171 (crop), solex_util.py:519-525
 // (rescale_brightness), solex_util.py:542-547 (cv2.circle), ellipse_to_circle.py:299-302
 // (downscale_local_mean).  All are single streaming passes over a few-MB image.
+#include <algorithm>
 #include "shg_common.h"
 
 namespace {
 
-__global__ __launch_bounds__(256) void k_crop_pad(const uint16_t* __restrict__ src, int64_t pitch, uint16_t* __restrict__ dst,
+// grid (x, rows, disks)
+__global__ __launch_bounds__(256) void k_crop_pad(shg::PtrBatch srcs, int64_t pitch, shg::PtrBatch dsts,
                                                   int64_t nw, int64_t dst_pitch, int64_t sx0, int64_t dx0, int64_t n,
                                                   uint16_t fill, int fill_is_src00) {
     const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t y = blockIdx.y;
     if (x >= nw) return;
+    const uint16_t* __restrict__ src = srcs.at<const uint16_t>(blockIdx.z);
+    uint16_t* __restrict__ dst = dsts.at<uint16_t>(blockIdx.z);
     if (fill_is_src00) fill = src[0];                   // np.full(..., img[0, 0]) without a host round trip
     const int64_t j = x - dx0;
     dst[y * dst_pitch + x] = (j >= 0 && j < n) ? src[y * pitch + sx0 + j] : fill;
@@ -94,13 +98,27 @@ __global__ __launch_bounds__(256) void k_downscale_mean(const uint16_t* __restri
 extern "C" int shg_crop_pad_u16(const uint16_t* src, int64_t h, int64_t w, int64_t pitch, uint16_t* dst, int64_t nw,
                                 int64_t dst_pitch, int64_t sx0, int64_t dx0, int64_t n, int32_t fill, shg_stream_t stream) {
     SHG_REQUIRE(src && dst, SHG_E_ARG, "shg_crop_pad_u16: null pointer");
+    return shg::crop_pad_batch(&src, 1, h, w, pitch, &dst, nw, dst_pitch, sx0, dx0, n, fill, stream);
+}
+
+int shg::crop_pad_batch(const uint16_t* const* host_srcs, int64_t k, int64_t h, int64_t w, int64_t pitch, uint16_t* const* host_dsts, int64_t nw,
+                        int64_t dst_pitch, int64_t sx0, int64_t dx0, int64_t n, int32_t fill, shg_stream_t stream) {
+    SHG_REQUIRE(host_srcs && host_dsts && k > 0, SHG_E_ARG, "shg_crop_pad_u16: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && nw > 0 && pitch >= w && dst_pitch >= nw, SHG_E_ARG, "shg_crop_pad_u16: bad image size");
     SHG_REQUIRE(n >= 0 && sx0 >= 0 && sx0 + n <= w && dx0 >= 0 && dx0 + n <= nw, SHG_E_ARG, "shg_crop_pad_u16: copy window outside the images");
     SHG_REQUIRE(h < 65536, SHG_E_UNSUPPORTED, "shg_crop_pad_u16: more than 65535 rows");
     SHG_REQUIRE(fill <= 65535, SHG_E_ARG, "shg_crop_pad_u16: fill must be 0..65535, or negative for src[0][0]");
-    dim3 grid((unsigned)((nw + 255) / 256), (unsigned)h);
-    { SHG_PROF("crop_pad", shg::as_stream(stream)); k_crop_pad<<<grid, 256, 0, shg::as_stream(stream)>>>(src, pitch, dst, nw, dst_pitch, sx0, dx0, n, (uint16_t)(fill < 0 ? 0 : fill), fill < 0 ? 1 : 0); }
-    return shg::check_launch("k_crop_pad");
+    for (int64_t i = 0; i < k; ++i) SHG_REQUIRE(host_srcs[i] && host_dsts[i], SHG_E_ARG, "shg_crop_pad_u16: null image");
+    hipStream_t st = shg::as_stream(stream);
+    SHG_PROF("crop_pad", st);
+    for (int64_t i0 = 0; i0 < k; i0 += shg::kMaxBatch) {
+        const int m = (int)std::min<int64_t>(shg::kMaxBatch, k - i0);
+        dim3 grid((unsigned)((nw + 255) / 256), (unsigned)h, (unsigned)m);
+        k_crop_pad<<<grid, 256, 0, st>>>(shg::make_batch(host_srcs, (int)i0, m), pitch, shg::make_batch(host_dsts, (int)i0, m), nw, dst_pitch, sx0, dx0, n,
+                                         (uint16_t)(fill < 0 ? 0 : fill), fill < 0 ? 1 : 0);
+        if (int e = shg::check_launch("k_crop_pad")) return e;
+    }
+    return 0;
 }
 
 extern "C" int shg_rescale_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, double lo, double hi, double alpha,
@@ -153,6 +171,8 @@ extern "C" int shg_downscale_mean_u16(const uint16_t* img, int64_t h, int64_t w,
 // went back over protus for the disc).  Same arithmetic per pixel as k_rescale / k_fill_disc.
 namespace {
 struct Bounds6 { double lo[3], span[3]; };
+constexpr int kProductsBatch = 16;                  // disks per launch of the products kernels (their bounds travel by value)
+struct BoundsBatch { Bounds6 v[kProductsBatch]; };
 
 __device__ __forceinline__ uint16_t rescale1(double px, double lo, double span) {
     double v = 65535.0 * (px - lo) / span;             // (float(sat) * alpha * (img - lo)) / (hi - lo), alpha = 1
@@ -182,13 +202,20 @@ __device__ __forceinline__ uint32_t rescale1_fast(double px, double lo, double s
 
 // Eight pixels per lane: 16-byte loads of frame and cl1, 16-byte stores of the three products (rows 16-byte aligned,
 // pitches multiples of 8; a row's last, partial vector goes pixel by pixel).
-__global__ __launch_bounds__(256) void k_products8(const uint16_t* __restrict__ frame, int64_t frame_pitch,
-                                                   const uint16_t* __restrict__ cl1, int64_t cl1_pitch, int64_t w, Bounds6 b,
-                                                   uint16_t* __restrict__ hc, uint16_t* __restrict__ protus, uint16_t* __restrict__ cc,
+// grid (x, rows, disks)
+__global__ __launch_bounds__(256) void k_products8(shg::PtrBatch frames, int64_t frame_pitch,
+                                                   shg::PtrBatch cl1s, int64_t cl1_pitch, int64_t w, BoundsBatch bb,
+                                                   shg::PtrBatch hcs, shg::PtrBatch protuss, shg::PtrBatch ccs,
                                                    int64_t dst_pitch, int64_t x0, int64_t y0, int64_t r) {
     const int64_t x = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
     const int64_t y = blockIdx.y;
     if (x >= w) return;
+    const uint16_t* __restrict__ frame = frames.at<const uint16_t>(blockIdx.z);
+    const uint16_t* __restrict__ cl1 = cl1s.at<const uint16_t>(blockIdx.z);
+    uint16_t* __restrict__ hc = hcs.at<uint16_t>(blockIdx.z);
+    uint16_t* __restrict__ protus = protuss.at<uint16_t>(blockIdx.z);
+    uint16_t* __restrict__ cc = ccs.at<uint16_t>(blockIdx.z);
+    const Bounds6& b = bb.v[blockIdx.z];
     const double i0 = 1.0 / b.span[0], i1 = 1.0 / b.span[1], i2 = 1.0 / b.span[2];
     // the disc's span on this row: [x0 - half, x0 + half] (cv2.circle(frame_protus, (x0, y0), r, 80, -1))
     int64_t d_lo = 1, d_hi = 0;
@@ -237,13 +264,19 @@ __global__ __launch_bounds__(256) void k_products8(const uint16_t* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void k_products(const uint16_t* __restrict__ frame, int64_t frame_pitch,
-                                                  const uint16_t* __restrict__ cl1, int64_t cl1_pitch, int64_t w, Bounds6 b,
-                                                  uint16_t* __restrict__ hc, uint16_t* __restrict__ protus, uint16_t* __restrict__ cc,
+__global__ __launch_bounds__(256) void k_products(shg::PtrBatch frames, int64_t frame_pitch,
+                                                  shg::PtrBatch cl1s, int64_t cl1_pitch, int64_t w, BoundsBatch bb,
+                                                  shg::PtrBatch hcs, shg::PtrBatch protuss, shg::PtrBatch ccs,
                                                   int64_t dst_pitch, int64_t x0, int64_t y0, int64_t r) {
     const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t y = blockIdx.y;
     if (x >= w) return;
+    const uint16_t* __restrict__ frame = frames.at<const uint16_t>(blockIdx.z);
+    const uint16_t* __restrict__ cl1 = cl1s.at<const uint16_t>(blockIdx.z);
+    uint16_t* __restrict__ hc = hcs.at<uint16_t>(blockIdx.z);
+    uint16_t* __restrict__ protus = protuss.at<uint16_t>(blockIdx.z);
+    uint16_t* __restrict__ cc = ccs.at<uint16_t>(blockIdx.z);
+    const Bounds6& b = bb.v[blockIdx.z];
     const double f = (double)frame[y * frame_pitch + x];
     const double c = (double)cl1[y * cl1_pitch + x];
     hc[y * dst_pitch + x] = rescale1(f, b.lo[0], b.span[0]);
@@ -262,29 +295,51 @@ extern "C" int shg_contrast_products_u16(const uint16_t* frame, int64_t frame_pi
                                          int64_t w, const double* lo_hi6, uint16_t* high_contrast, uint16_t* protus, uint16_t* cc,
                                          int64_t dst_pitch, int64_t disc_x0, int64_t disc_y0, int64_t disc_r, shg_stream_t stream) {
     SHG_REQUIRE(frame && cl1 && lo_hi6 && high_contrast && protus && cc, SHG_E_ARG, "shg_contrast_products_u16: null pointer");
+    return shg::contrast_products_batch(&frame, frame_pitch, &cl1, cl1_pitch, 1, h, w, lo_hi6, &high_contrast, &protus, &cc, dst_pitch, disc_x0,
+                                        disc_y0, disc_r, stream);
+}
+
+// k disks of one shape in one launch (per kProductsBatch): host_lo_hi6 is [k][6]
+int shg::contrast_products_batch(const uint16_t* const* host_frames, int64_t frame_pitch, const uint16_t* const* host_cl1, int64_t cl1_pitch,
+                                 int64_t k, int64_t h, int64_t w, const double* host_lo_hi6, uint16_t* const* host_hc,
+                                 uint16_t* const* host_protus, uint16_t* const* host_cc, int64_t dst_pitch, int64_t disc_x0, int64_t disc_y0,
+                                 int64_t disc_r, shg_stream_t stream) {
+    SHG_REQUIRE(host_frames && host_cl1 && host_lo_hi6 && host_hc && host_protus && host_cc && k > 0, SHG_E_ARG, "shg_contrast_products_u16: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && frame_pitch >= w && cl1_pitch >= w && dst_pitch >= w, SHG_E_ARG, "shg_contrast_products_u16: bad image size");
     SHG_REQUIRE(h < 65536, SHG_E_UNSUPPORTED, "shg_contrast_products_u16: more than 65535 rows");
     SHG_REQUIRE(disc_r < 32768, SHG_E_UNSUPPORTED, "shg_contrast_products_u16: radius %lld out of range", (long long)disc_r);
-    Bounds6 b;
-    for (int i = 0; i < 3; ++i) {
-        const double lo = lo_hi6[2 * i], hi = lo_hi6[2 * i + 1];
-        SHG_REQUIRE(65535.0 >= hi && hi > lo, SHG_E_ARG, "shg_contrast_products_u16: need sat >= hi > lo (got lo=%g hi=%g)", lo, hi);   // assert, solex_util.py:521
-        b.lo[i] = lo;
-        b.span[i] = hi - lo;
+    uintptr_t ptrs = 0;
+    for (int64_t d = 0; d < k; ++d) {
+        SHG_REQUIRE(host_frames[d] && host_cl1[d] && host_hc[d] && host_protus[d] && host_cc[d], SHG_E_ARG, "shg_contrast_products_u16: null image");
+        ptrs |= reinterpret_cast<uintptr_t>(host_frames[d]) | reinterpret_cast<uintptr_t>(host_cl1[d]) | reinterpret_cast<uintptr_t>(host_hc[d]) |
+                reinterpret_cast<uintptr_t>(host_protus[d]) | reinterpret_cast<uintptr_t>(host_cc[d]);
+        for (int i = 0; i < 3; ++i) {
+            const double lo = host_lo_hi6[6 * d + 2 * i], hi = host_lo_hi6[6 * d + 2 * i + 1];
+            SHG_REQUIRE(65535.0 >= hi && hi > lo, SHG_E_ARG, "shg_contrast_products_u16: need sat >= hi > lo (got lo=%g hi=%g)", lo, hi);   // assert, solex_util.py:521
+        }
     }
     hipStream_t st = shg::as_stream(stream);
-    const uintptr_t ptrs = reinterpret_cast<uintptr_t>(frame) | reinterpret_cast<uintptr_t>(cl1) | reinterpret_cast<uintptr_t>(high_contrast) |
-                           reinterpret_cast<uintptr_t>(protus) | reinterpret_cast<uintptr_t>(cc);
     const bool vec = (ptrs & 15) == 0 && frame_pitch % 8 == 0 && cl1_pitch % 8 == 0 && dst_pitch % 8 == 0;
     SHG_PROF("products", st);
-    if (vec) {
-        dim3 grid((unsigned)((w + 8 * 256 - 1) / (8 * 256)), (unsigned)h);
-        k_products8<<<grid, 256, 0, st>>>(frame, frame_pitch, cl1, cl1_pitch, w, b, high_contrast, protus, cc, dst_pitch, disc_x0, disc_y0,
-                                          disc_r > 0 ? disc_r : 0);
-    } else {
-        dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
-        k_products<<<grid, 256, 0, st>>>(frame, frame_pitch, cl1, cl1_pitch, w, b, high_contrast, protus, cc, dst_pitch, disc_x0, disc_y0,
-                                         disc_r > 0 ? disc_r : 0);
+    for (int64_t i0 = 0; i0 < k; i0 += kProductsBatch) {
+        const int m = (int)std::min<int64_t>(kProductsBatch, k - i0);
+        BoundsBatch bb;
+        for (int d = 0; d < m; ++d)
+            for (int i = 0; i < 3; ++i) {
+                bb.v[d].lo[i] = host_lo_hi6[6 * (i0 + d) + 2 * i];
+                bb.v[d].span[i] = host_lo_hi6[6 * (i0 + d) + 2 * i + 1] - bb.v[d].lo[i];
+            }
+        for (int d = m; d < kProductsBatch; ++d) bb.v[d] = bb.v[0];
+        const shg::PtrBatch f = shg::make_batch(host_frames, (int)i0, m), c = shg::make_batch(host_cl1, (int)i0, m), hc = shg::make_batch(host_hc, (int)i0, m),
+                            pr = shg::make_batch(host_protus, (int)i0, m), cc = shg::make_batch(host_cc, (int)i0, m);
+        if (vec) {
+            dim3 grid((unsigned)((w + 8 * 256 - 1) / (8 * 256)), (unsigned)h, (unsigned)m);
+            k_products8<<<grid, 256, 0, st>>>(f, frame_pitch, c, cl1_pitch, w, bb, hc, pr, cc, dst_pitch, disc_x0, disc_y0, disc_r > 0 ? disc_r : 0);
+        } else {
+            dim3 grid((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)m);
+            k_products<<<grid, 256, 0, st>>>(f, frame_pitch, c, cl1_pitch, w, bb, hc, pr, cc, dst_pitch, disc_x0, disc_y0, disc_r > 0 ? disc_r : 0);
+        }
+        if (int e = shg::check_launch("k_products")) return e;
     }
-    return shg::check_launch("k_products");
+    return 0;
 }

@@ -284,27 +284,37 @@ extern "C" int shg_scan_file(const shg_scan_request* rq, shg_scan_result* rs, sh
     char* arena = static_cast<char*>(rq->arena);
     char* results = static_cast<char*>(rq->results);
     const uint32_t* extrema = rq->minmax_slots + (size_t)S * 128;                  // {min, max} per plane, after the slots
-    auto warp = [&](int i, uint16_t* dst) {
+    // every warp of the file in one launch: the requested disks and, for the diagnostic plot, the ellipse-fit disk
+    std::vector<const uint16_t*> w_src;
+    std::vector<uint16_t*> w_dst;
+    std::vector<const uint32_t*> w_mm;
+    std::vector<double> w_h;
+    auto add_warp = [&](int i, uint16_t* dst) {
         const double* hr = i == 0 ? rs->h_first : rs->h_rest;
-        return shg_warp_rows_minmax_u16(rq->disks + (size_t)i * rq->disk_plane_stride, ih, n_cols, rq->disk_pitch, hr[0], hr[1], hr[2], dst, out_h,
-                                        out_w, frame_pitch, extrema + 2 * i, stream);
+        w_src.push_back(rq->disks + (size_t)i * rq->disk_plane_stride);
+        w_dst.push_back(dst);
+        w_mm.push_back(extrema + 2 * i);
+        w_h.insert(w_h.end(), hr, hr + 3);
     };
-    if (fit_image) SCAN_TRY(warp(0, reinterpret_cast<uint16_t*>(arena + rs->fit_image_off)));
+    if (fit_image) add_warp(0, reinterpret_cast<uint16_t*>(arena + rs->fit_image_off));
+    std::vector<const uint16_t*> frames((size_t)k);
+    std::vector<uint16_t*> det((size_t)k), prod[5];
+    for (auto& v : prod) v.resize((size_t)k);
+    int64_t j = 0;
+    for (int i = 0; i < S; ++i) {
+        if (!rq->host_requested[i]) continue;
+        uint16_t* f = reinterpret_cast<uint16_t*>(arena + rs->frames_off + (size_t)j * frame_bytes);
+        add_warp(i, f);
+        frames[j] = f;
+        if (detrans) det[j] = reinterpret_cast<uint16_t*>(arena + rs->detrans_off + (size_t)j * frame_bytes);
+        for (int p = 0; p < 3; ++p) prod[p][j] = reinterpret_cast<uint16_t*>(arena + rs->products_off + ((size_t)j * 3 + p) * prod_bytes);
+        for (int p = 0; p < 2; ++p) prod[3 + p][j] = reinterpret_cast<uint16_t*>(results + ((size_t)j * 2 + p) * prod_bytes);
+        ++j;
+    }
+    if (!w_src.empty())
+        SCAN_TRY(shg::warp_rows_batch(w_src.data(), (int64_t)w_src.size(), ih, n_cols, rq->disk_pitch, w_h.data(), w_dst.data(), out_h, out_w, frame_pitch,
+                                      w_mm.data(), stream));
     if (k > 0) {
-        std::vector<const uint16_t*> frames((size_t)k);
-        std::vector<uint16_t*> det((size_t)k), prod[5];
-        for (auto& v : prod) v.resize((size_t)k);
-        int64_t j = 0;
-        for (int i = 0; i < S; ++i) {
-            if (!rq->host_requested[i]) continue;
-            uint16_t* f = reinterpret_cast<uint16_t*>(arena + rs->frames_off + (size_t)j * frame_bytes);
-            SCAN_TRY(warp(i, f));
-            frames[j] = f;
-            if (detrans) det[j] = reinterpret_cast<uint16_t*>(arena + rs->detrans_off + (size_t)j * frame_bytes);
-            for (int p = 0; p < 3; ++p) prod[p][j] = reinterpret_cast<uint16_t*>(arena + rs->products_off + ((size_t)j * 3 + p) * prod_bytes);
-            for (int p = 0; p < 2; ++p) prod[3 + p][j] = reinterpret_cast<uint16_t*>(results + ((size_t)j * 2 + p) * prod_bytes);
-            ++j;
-        }
         SCAN_TRY(shg_stage_process_frames(frames.data(), k, out_h, out_w, frame_pitch, rq->transversalium, pl.trans_circle, pl.trans_borders,
                                           pl.taps_ptr, pl.window, rq->host_factors, pl.crop_w, pl.sx0, pl.dx0, pl.ncopy, rq->clip_limit, rq->tiles,
                                           pl.disc[0], pl.disc[1], pl.disc[2], detrans ? det.data() : nullptr, frame_pitch, prod[0].data(),

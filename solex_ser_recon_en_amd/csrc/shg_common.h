@@ -56,6 +56,40 @@ struct HostScope {
 #define SHG_HOST_CAT(a, b) SHG_HOST_CAT2(a, b)
 #define SHG_HOST_TIME(tag) shg::HostScope SHG_HOST_CAT(shg_host_scope_, __LINE__)(tag)
 
+// The images of one launch over several disks of a file (a Doppler stack: Solex_recon.py:105-133 loops over the shifts):
+// blockIdx.z picks the disk, the kernel its pointers from this by-value table.  At most kMaxBatch disks per launch.
+constexpr int kMaxBatch = 32;
+struct PtrBatch {
+    const void* p[kMaxBatch];
+    template <typename T>
+    __device__ __forceinline__ T* at(int i) const { return static_cast<T*>(const_cast<void*>(p[i])); }
+};
+template <typename T>
+inline PtrBatch make_batch(T* const* host_ptrs, int first, int count) {
+    PtrBatch b = {};
+    for (int i = 0; i < count && i < kMaxBatch; ++i) b.p[i] = host_ptrs[first + i];
+    return b;
+}
+
+// One launch per kernel for the k disks of a file (host arrays of device pointers; any k, cut into launches of kMaxBatch):
+// the per-disk stages of shg_stage_process_frames and the warps of shg_scan_file.  The single-image entry points of the C ABI
+// are these with k = 1.
+int rowpair_stats_batch(const uint16_t* const* host_imgs, int64_t k, int64_t h, int64_t w, int64_t pitch, int64_t y1, int64_t y2,
+                        const int32_t* xa, const int32_t* xb, const double* row_factor, double* out, double* out_mirror, shg_stream_t stream);
+int scale_rows_batch(const uint16_t* const* host_imgs, int64_t k, int64_t h, int64_t w, int64_t pitch, const double* c,
+                     const double* row_factor, uint16_t* const* host_dsts, int64_t dst_pitch, shg_stream_t stream);
+int crop_pad_batch(const uint16_t* const* host_srcs, int64_t k, int64_t h, int64_t w, int64_t pitch, uint16_t* const* host_dsts, int64_t nw,
+                   int64_t dst_pitch, int64_t sx0, int64_t dx0, int64_t n, int32_t fill, shg_stream_t stream);
+int contrast_products_batch(const uint16_t* const* host_frames, int64_t frame_pitch, const uint16_t* const* host_cl1, int64_t cl1_pitch,
+                            int64_t k, int64_t h, int64_t w, const double* host_lo_hi6, uint16_t* const* host_hc, uint16_t* const* host_protus,
+                            uint16_t* const* host_cc, int64_t dst_pitch, int64_t disc_x0, int64_t disc_y0, int64_t disc_r, shg_stream_t stream);
+int warp_rows_batch(const uint16_t* const* host_srcs, int64_t k, int64_t h, int64_t w, int64_t src_pitch, const double* host_h3,
+                    uint16_t* const* host_dsts, int64_t out_h, int64_t out_w, int64_t dst_pitch, const uint32_t* const* host_minmax2,
+                    shg_stream_t stream);
+int contrast_stats_batch(const uint16_t* const* host_frames, int64_t k, int64_t h, int64_t w, int64_t pitch, double clip_limit, int tiles,
+                         uint16_t* const* host_cl1, int64_t cl1_pitch, const int64_t* ranks_frame2, const int64_t* ranks_cl13, double* out5,
+                         void* workspace, size_t workspace_bytes, shg_stream_t stream);
+
 constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kCUs = 256;          // MI355X
 

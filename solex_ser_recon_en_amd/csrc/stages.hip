@@ -467,7 +467,7 @@ extern "C" size_t shg_stage_process_workspace_bytes(int64_t k, int64_t h, int64_
     if (k <= 0 || h <= 0 || w <= 0) return 0;
     const size_t pitch = ((size_t)std::max(w, crop_w) + 63) / 64 * 64;
     return 2 * up((size_t)h * 4) + 2 * up((size_t)k * h * 8) + up((size_t)k * h * 8) + up(4096 * 8) +
-           (size_t)k * up((size_t)h * pitch * 2) + up(shg_contrast_stats_workspace_bytes_for(h, crop_w > 0 ? crop_w : w, tiles)) + up((size_t)k * 5 * 8) + kAlign;
+           (size_t)k * up((size_t)h * pitch * 2) + (size_t)k * up(shg_contrast_stats_workspace_bytes_for(h, crop_w > 0 ? crop_w : w, tiles)) + up((size_t)k * 5 * 8) + kAlign;
 }
 
 extern "C" size_t shg_stage_process_host_bytes(int64_t k, int64_t h) {
@@ -514,8 +514,9 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
     const bool need_tmp = transversalium && crop_w > 0 && !host_detrans;
     if (need_tmp)
         for (int64_t i = 0; i < k; ++i) scaled[i] = dev.take<uint16_t>((size_t)h * tpitch);
-    const size_t cs_bytes = shg_contrast_stats_workspace_bytes_for(h, out_w, tiles);
-    SHG_REQUIRE(cs_bytes != 0, SHG_E_ARG, "shg_stage_process_frames: unsupported tile count %d", tiles);
+    const size_t cs_each = up(shg_contrast_stats_workspace_bytes_for(h, out_w, tiles));      // one area per disk: all disks go through a kernel together
+    SHG_REQUIRE(cs_each != 0, SHG_E_ARG, "shg_stage_process_frames: unsupported tile count %d", tiles);
+    const size_t cs_bytes = (size_t)k * cs_each;
     char* cs_ws = dev.take<char>(cs_bytes);
     double* out5 = dev.take<double>((size_t)k * 5);
     int32_t* h_xa = pin.take<int32_t>((size_t)h);
@@ -556,9 +557,7 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
             }
             const char* plan_end = gpu_interior ? reinterpret_cast<const char*>(h_taps + window) : reinterpret_cast<const char*>(h_xb + n);
             STAGE_TRY(move_words(xa, stg.on_device(h_xa), (size_t)(plan_end - reinterpret_cast<const char*>(h_xa)), st));
-            for (int64_t i = 0; i < k; ++i)
-                STAGE_TRY(shg_rowpair_logratio_stats_mirrored(host_frames[i], h, w, pitch, y1, y2, xa, xb, nullptr, stats + i * n,
-                                                              stg.on_device(h_stats) + i * n, stream));
+            STAGE_TRY(shg::rowpair_stats_batch(host_frames, k, h, w, pitch, y1, y2, xa, xb, nullptr, stats, stg.on_device(h_stats), stream));
             if (gpu_interior) {
                 // the interior of the Savitzky-Golay trend while the statistics are still on the GPU (SciPy's own order of operations)
                 const int radius = (int)(window / 2);
@@ -586,27 +585,25 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
         // k_scale_rows reads one factor per workgroup: straight from the staging area (a copy kernel first: 3.8 us for the launch,
         // 2.8 us saved in the reader)
         factors = stg.on_device(h_factors);
+        std::vector<uint16_t*> dsts((size_t)k);
+        int64_t dpitch = out_pitch;
         for (int64_t i = 0; i < k; ++i) {
-            uint16_t* dst;
-            int64_t dpitch;
-            if (host_detrans) { dst = host_detrans[i]; dpitch = detrans_pitch; }
-            else if (crop_w > 0) { dst = scaled[i]; dpitch = (int64_t)tpitch; }
-            else { dst = host_final[i]; dpitch = out_pitch; }
-            SHG_REQUIRE(dst && dpitch >= w, SHG_E_ARG, "shg_stage_process_frames: bad de-transversalium output");
-            STAGE_TRY(shg_scale_rows_u16(host_frames[i], h, w, pitch, factors + i * h, nullptr, dst, dpitch, stream));
-            cur[i] = dst;
-            cur_pitch = dpitch;
+            if (host_detrans) { dsts[i] = host_detrans[i]; dpitch = detrans_pitch; }
+            else if (crop_w > 0) { dsts[i] = scaled[i]; dpitch = (int64_t)tpitch; }
+            else { dsts[i] = host_final[i]; dpitch = out_pitch; }
+            SHG_REQUIRE(dsts[i] && dpitch >= w, SHG_E_ARG, "shg_stage_process_frames: bad de-transversalium output");
+            cur[i] = dsts[i];
         }
+        cur_pitch = dpitch;
+        STAGE_TRY(shg::scale_rows_batch(host_frames, k, h, w, pitch, factors, nullptr, dsts.data(), dpitch, stream));
     }
     // ---- crop / pad (Solex_recon.py:155-171) ----
-    for (int64_t i = 0; i < k; ++i) {
-        if (crop_w > 0) {
-            STAGE_TRY(shg_crop_pad_u16(cur[i], h, w, cur_pitch, host_final[i], crop_w, out_pitch, sx0, dx0, ncopy, -1, stream));
-        } else if (cur[i] != host_final[i]) {
-            // no transversalium into host_final and no crop: the frame itself is the image to contrast; copy it (a crop of
-            // the full width) so that every product lives in the caller's output block
-            STAGE_TRY(shg_crop_pad_u16(cur[i], h, w, cur_pitch, host_final[i], w, out_pitch, 0, 0, w, -1, stream));
-        }
+    if (crop_w > 0) {
+        STAGE_TRY(shg::crop_pad_batch(cur.data(), k, h, w, cur_pitch, host_final, crop_w, out_pitch, sx0, dx0, ncopy, -1, stream));
+    } else if (cur[0] != host_final[0]) {
+        // no transversalium into host_final and no crop: the frame itself is the image to contrast; copy it (a crop of
+        // the full width) so that every product lives in the caller's output block
+        STAGE_TRY(shg::crop_pad_batch(cur.data(), k, h, w, cur_pitch, host_final, w, out_pitch, 0, 0, w, -1, stream));
     }
     // ---- image_process (solex_util.py:527-547) ----
     const int64_t n_px = h * out_w;
@@ -615,10 +612,10 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
     STAGE_TRY(shg_host_percentile_plan(n_px, 99.9999, &ranks_frame[0], &ranks_frame[1], &g_bright));
     STAGE_TRY(shg_host_percentile_plan(n_px, 10.0, &ranks_cl1[0], &ranks_cl1[1], &g_dark));
     ranks_cl1[2] = n_px - 1;                                                                  // np.max
-    for (int64_t i = 0; i < k; ++i)
-        STAGE_TRY(shg_contrast_stats_u16(host_final[i], h, out_w, out_pitch, clip_limit, tiles, host_cl1[i], out_pitch, ranks_frame, ranks_cl1,
-                                         out5 + i * 5, cs_ws, cs_bytes, stream));
+    STAGE_TRY(shg::contrast_stats_batch(host_final, k, h, out_w, out_pitch, clip_limit, tiles, host_cl1, out_pitch, ranks_frame, ranks_cl1, out5, cs_ws,
+                                        cs_bytes, stream));
     STAGE_HIP(hipStreamSynchronize(st), "shg_stage_process_frames");
+    std::vector<double> lo_hi((size_t)k * 6);
     for (int64_t i = 0; i < k; ++i) {
         const double* s = h_out5 + i * 5;
         const double bright = shg_host_lerp(s[0], s[1], g_bright);                            // basically the same as max
@@ -629,9 +626,9 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
             shg::set_error("rescale_brightness: assert sat >= hi > lo (bright %g, clahe %g .. %g)", bright, dark_clahe, bright_clahe);
             return SHG_E_ASSERT;
         }
-        const double lo_hi[6] = {bright * 0.25, bright, 0.0, bright * 0.18, dark_clahe, bright_clahe};
-        STAGE_TRY(shg_contrast_products_u16(host_final[i], out_pitch, host_cl1[i], out_pitch, h, out_w, lo_hi, host_hc[i], host_protus[i],
-                                            host_cc[i], out_pitch, disc_x0, disc_y0, disc_r, stream));
+        const double v[6] = {bright * 0.25, bright, 0.0, bright * 0.18, dark_clahe, bright_clahe};
+        memcpy(&lo_hi[(size_t)i * 6], v, sizeof(v));
     }
-    return 0;
+    return shg::contrast_products_batch(host_final, out_pitch, host_cl1, out_pitch, k, h, out_w, lo_hi.data(), host_hc, host_protus, host_cc, out_pitch,
+                                        disc_x0, disc_y0, disc_r, stream);
 }

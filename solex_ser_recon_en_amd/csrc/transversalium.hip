@@ -15,6 +15,7 @@
 //
 // k_scale_rows: img * c[y], saturate, truncate -- a pure streaming pass.
 #include <math.h>
+#include <algorithm>
 #include "shg_common.h"
 
 namespace {
@@ -241,12 +242,16 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(NT) void k_rowpair_stats(const uint16_t* __restrict__ img, int64_t pitch, int64_t y1,
+// grid (rows, 1, disks): blockIdx.z picks the image and its slice (out_stride doubles apart) of out / mirror
+__global__ __launch_bounds__(NT) void k_rowpair_stats(shg::PtrBatch imgs, int64_t pitch, int64_t y1,
                                                       const int32_t* __restrict__ xa, const int32_t* __restrict__ xb,
                                                       const double* __restrict__ row_factor, double* __restrict__ out,
-                                                      double* __restrict__ mirror) {
+                                                      double* __restrict__ mirror, int64_t out_stride) {
     extern __shared__ uint64_t keys[];   // [n]
     __shared__ Scratch sc;
+    const uint16_t* __restrict__ img = imgs.at<const uint16_t>(blockIdx.z);
+    out += (int64_t)blockIdx.z * out_stride;
+    if (mirror) mirror += (int64_t)blockIdx.z * out_stride;
     const int t = blockIdx.x + 1;        // out[0] stays 0 (solex_util.py:386)
     auto emit = [&](double v) {          // mirror: the same values where the host reads them (pinned memory), if wanted
         if (threadIdx.x == 0) {
@@ -328,12 +333,15 @@ __global__ __launch_bounds__(NT) void k_rowpair_stats(const uint16_t* __restrict
     emit(s / cnt);
 }
 
-__global__ __launch_bounds__(256) void k_scale_rows(const uint16_t* __restrict__ img, int64_t w, int64_t pitch,
+__global__ __launch_bounds__(256) void k_scale_rows(shg::PtrBatch imgs, int64_t w, int64_t pitch,
                                                     const double* __restrict__ c, const double* __restrict__ row_factor,
-                                                    uint16_t* __restrict__ dst, int64_t dst_pitch) {
+                                                    shg::PtrBatch dsts, int64_t dst_pitch) {
     const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t y = blockIdx.y;
     if (x >= w) return;
+    const uint16_t* __restrict__ img = imgs.at<const uint16_t>(blockIdx.z);
+    uint16_t* __restrict__ dst = dsts.at<uint16_t>(blockIdx.z);
+    c += (int64_t)blockIdx.z * gridDim.y;
     double v = (double)img[y * pitch + x];
     if (row_factor) v = v * row_factor[y];              // the float64 de-vignetted pixel, rounded as NumPy stores it
     v = v * c[y];
@@ -343,12 +351,16 @@ __global__ __launch_bounds__(256) void k_scale_rows(const uint16_t* __restrict__
 
 // The same with eight pixels per lane (rows 16-byte aligned, pitches multiples of 8; a row's last, partial vector goes
 // pixel by pixel).
-__global__ __launch_bounds__(256) void k_scale_rows8(const uint16_t* __restrict__ img, int64_t w, int64_t pitch,
+// grid (x, rows, disks): blockIdx.z picks source, destination and the disk's h factors
+__global__ __launch_bounds__(256) void k_scale_rows8(shg::PtrBatch imgs, int64_t w, int64_t pitch,
                                                      const double* __restrict__ c, const double* __restrict__ row_factor,
-                                                     uint16_t* __restrict__ dst, int64_t dst_pitch) {
+                                                     shg::PtrBatch dsts, int64_t dst_pitch) {
     const int64_t x = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
     const int64_t y = blockIdx.y;
     if (x >= w) return;
+    const uint16_t* __restrict__ img = imgs.at<const uint16_t>(blockIdx.z);
+    uint16_t* __restrict__ dst = dsts.at<uint16_t>(blockIdx.z);
+    c += (int64_t)blockIdx.z * gridDim.y;
     const double cy = c[y], fy = row_factor ? row_factor[y] : 1.0;
     const bool factored = row_factor != nullptr;
     auto one = [&](uint32_t px) {
@@ -489,16 +501,26 @@ extern "C" int shg_rowpair_logratio_stats(const uint16_t* img, int64_t h, int64_
 extern "C" int shg_rowpair_logratio_stats_mirrored(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, int64_t y1, int64_t y2,
                                                    const int32_t* xa, const int32_t* xb, const double* row_factor, double* out,
                                                    double* out_mirror, shg_stream_t stream) {
-    SHG_REQUIRE(img && xa && xb && out, SHG_E_ARG, "shg_rowpair_logratio_stats: null pointer");
+    SHG_REQUIRE(img, SHG_E_ARG, "shg_rowpair_logratio_stats: null pointer");
+    return shg::rowpair_stats_batch(&img, 1, h, w, pitch, y1, y2, xa, xb, row_factor, out, out_mirror, stream);
+}
+
+// The k images of a Doppler stack in one launch (they share circle, borders and shape, Solex_recon.py:105-133): out /
+// out_mirror are [k][max(y2 - y1, 1)].
+int shg::rowpair_stats_batch(const uint16_t* const* host_imgs, int64_t k, int64_t h, int64_t w, int64_t pitch, int64_t y1, int64_t y2,
+                             const int32_t* xa, const int32_t* xb, const double* row_factor, double* out, double* out_mirror,
+                             shg_stream_t stream) {
+    SHG_REQUIRE(host_imgs && xa && xb && out && k > 0, SHG_E_ARG, "shg_rowpair_logratio_stats: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w, SHG_E_ARG, "shg_rowpair_logratio_stats: bad image size");
     SHG_REQUIRE(y1 >= 0 && y2 <= h && y2 > y1, SHG_E_ARG, "shg_rowpair_logratio_stats: rows [%lld, %lld) outside the image",
                 (long long)y1, (long long)y2);
     SHG_REQUIRE(w <= MAXN, SHG_E_UNSUPPORTED, "shg_rowpair_logratio_stats: width %lld > %d", (long long)w, MAXN);
+    for (int64_t i = 0; i < k; ++i) SHG_REQUIRE(host_imgs[i], SHG_E_ARG, "shg_rowpair_logratio_stats: null image");
     hipStream_t st = shg::as_stream(stream);
-    const int64_t rows = y2 - y1 - 1;
+    const int64_t rows = y2 - y1 - 1, n = y2 - y1;
     if (rows <= 0) {                                     // a single row: its statistic is the leading 0 (the kernel writes it otherwise)
-        hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
-        if (e == hipSuccess && out_mirror) e = hipMemsetAsync(out_mirror, 0, sizeof(double), st);
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)k * sizeof(double), st);
+        if (e == hipSuccess && out_mirror) e = hipMemsetAsync(out_mirror, 0, (size_t)k * sizeof(double), st);
         if (e != hipSuccess) {
             shg::set_error("shg_rowpair_logratio_stats: memset: %s", hipGetErrorString(e));
             return (int)e;
@@ -511,8 +533,14 @@ extern "C" int shg_rowpair_logratio_stats_mirrored(const uint16_t* img, int64_t 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowpair_stats), hipFuncAttributeMaxDynamicSharedMemorySize, MAXN * 8);
         attr_set = true;
     }
-    { SHG_PROF("rowpair_stats", st); k_rowpair_stats<<<(unsigned)rows, NT, lds_bytes, st>>>(img, pitch, y1, xa, xb, row_factor, out, out_mirror); }
-    return shg::check_launch("k_rowpair_stats");
+    SHG_PROF("rowpair_stats", st);
+    for (int64_t i0 = 0; i0 < k; i0 += shg::kMaxBatch) {
+        const int m = (int)std::min<int64_t>(shg::kMaxBatch, k - i0);
+        k_rowpair_stats<<<dim3((unsigned)rows, 1u, (unsigned)m), NT, lds_bytes, st>>>(shg::make_batch(host_imgs, (int)i0, m), pitch, y1, xa, xb, row_factor,
+                                                                                     out + i0 * n, out_mirror ? out_mirror + i0 * n : nullptr, n);
+        if (int e = shg::check_launch("k_rowpair_stats")) return e;
+    }
+    return 0;
 }
 
 extern "C" int shg_correlate1d_rows_f64(const double* src, int64_t k, int64_t n, const double* weights, int radius, int symmetric,
@@ -529,18 +557,35 @@ extern "C" int shg_correlate1d_rows_f64(const double* src, int64_t k, int64_t n,
 
 extern "C" int shg_scale_rows_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, const double* c,
                                   const double* row_factor, uint16_t* dst, int64_t dst_pitch, shg_stream_t stream) {
-    SHG_REQUIRE(img && c && dst, SHG_E_ARG, "shg_scale_rows_u16: null pointer");
+    SHG_REQUIRE(img && dst, SHG_E_ARG, "shg_scale_rows_u16: null pointer");
+    return shg::scale_rows_batch(&img, 1, h, w, pitch, c, row_factor, &dst, dst_pitch, stream);
+}
+
+// k images in one launch: c is [k][h] (row_factor, if given, applies to all of them)
+int shg::scale_rows_batch(const uint16_t* const* host_imgs, int64_t k, int64_t h, int64_t w, int64_t pitch, const double* c,
+                          const double* row_factor, uint16_t* const* host_dsts, int64_t dst_pitch, shg_stream_t stream) {
+    SHG_REQUIRE(host_imgs && c && host_dsts && k > 0, SHG_E_ARG, "shg_scale_rows_u16: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w && dst_pitch >= w, SHG_E_ARG, "shg_scale_rows_u16: bad image size");
     SHG_REQUIRE(h < 65536, SHG_E_UNSUPPORTED, "shg_scale_rows_u16: more than 65535 rows");
     hipStream_t st = shg::as_stream(stream);
-    const bool vec = ((reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 && pitch % 8 == 0 && dst_pitch % 8 == 0;
-    SHG_PROF("scale_rows", st);
-    if (vec) {                                           // eight pixels per lane: 16-byte loads and stores
-        dim3 grid((unsigned)((w + 8 * 256 - 1) / (8 * 256)), (unsigned)h);
-        k_scale_rows8<<<grid, 256, 0, st>>>(img, w, pitch, c, row_factor, dst, dst_pitch);
-    } else {
-        dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
-        k_scale_rows<<<grid, 256, 0, st>>>(img, w, pitch, c, row_factor, dst, dst_pitch);
+    uintptr_t bits = 0;
+    for (int64_t i = 0; i < k; ++i) {
+        SHG_REQUIRE(host_imgs[i] && host_dsts[i], SHG_E_ARG, "shg_scale_rows_u16: null image");
+        bits |= reinterpret_cast<uintptr_t>(host_imgs[i]) | reinterpret_cast<uintptr_t>(host_dsts[i]);
     }
-    return shg::check_launch("k_scale_rows");
+    const bool vec = (bits & 15) == 0 && pitch % 8 == 0 && dst_pitch % 8 == 0;
+    SHG_PROF("scale_rows", st);
+    for (int64_t i0 = 0; i0 < k; i0 += shg::kMaxBatch) {
+        const int m = (int)std::min<int64_t>(shg::kMaxBatch, k - i0);
+        const shg::PtrBatch src = shg::make_batch(host_imgs, (int)i0, m), dst = shg::make_batch(host_dsts, (int)i0, m);
+        if (vec) {                                       // eight pixels per lane: 16-byte loads and stores
+            dim3 grid((unsigned)((w + 8 * 256 - 1) / (8 * 256)), (unsigned)h, (unsigned)m);
+            k_scale_rows8<<<grid, 256, 0, st>>>(src, w, pitch, c + i0 * h, row_factor, dst, dst_pitch);
+        } else {
+            dim3 grid((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)m);
+            k_scale_rows<<<grid, 256, 0, st>>>(src, w, pitch, c + i0 * h, row_factor, dst, dst_pitch);
+        }
+        if (int e = shg::check_launch("k_scale_rows")) return e;
+    }
+    return 0;
 }

@@ -4,6 +4,7 @@
 // 1-D linear resample of the same input row: 2 reads + 1 write per output pixel,
 // HBM/L2-bound.  Arithmetic follows scikit-image 0.18.3 (_warp_fast,
 // bilinear_interpolation, _clip_warp_output) in float64, unfused.
+#include <algorithm>
 #include "shg_common.h"
 
 namespace {
@@ -54,10 +55,18 @@ __global__ __launch_bounds__(256) void k_minmax(const uint16_t* __restrict__ src
     }
 }
 
-__global__ __launch_bounds__(256) void k_warp_rows(const uint16_t* __restrict__ src, int64_t h, int64_t w, int64_t pitch,
-                                                   double h00, double h01, double h02, uint16_t* __restrict__ dst,
+constexpr int kWarpBatch = 16;                     // disks per launch (their transform rows travel by value)
+struct WarpRows { double h[kWarpBatch][3]; };
+
+// grid (x, rows, disks): blockIdx.z picks source, destination, transform row and extrema
+__global__ __launch_bounds__(256) void k_warp_rows(shg::PtrBatch srcs, int64_t h, int64_t w, int64_t pitch,
+                                                   WarpRows rows, shg::PtrBatch dsts,
                                                    int64_t out_h, int64_t out_w, int64_t dst_pitch,
-                                                   const uint32_t* __restrict__ mm) {
+                                                   shg::PtrBatch mms) {
+    const uint16_t* __restrict__ src = srcs.at<const uint16_t>(blockIdx.z);
+    uint16_t* __restrict__ dst = dsts.at<uint16_t>(blockIdx.z);
+    const uint32_t* __restrict__ mm = mms.at<const uint32_t>(blockIdx.z);
+    const double h00 = rows.h[blockIdx.z][0], h01 = rows.h[blockIdx.z][1], h02 = rows.h[blockIdx.z][2];
     const uint32_t mn = mm[0], mx = mm[1];
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t r = blockIdx.y;
@@ -95,20 +104,39 @@ extern "C" int shg_warp_rows_u16(const uint16_t* src, int64_t h, int64_t w, int6
     int64_t blocks = h < 256 ? h : 256;
     { SHG_PROF("minmax", st); k_minmax<<<(unsigned)blocks, 256, 0, st>>>(src, h, w, src_pitch, minmax); }
     if (int e = shg::check_launch("k_minmax")) return e;
-    dim3 grid((unsigned)((out_w + 255) / 256), (unsigned)out_h);
-    { SHG_PROF("warp", st); k_warp_rows<<<grid, 256, 0, st>>>(src, h, w, src_pitch, h00, h01, h02, dst, out_h, out_w, dst_pitch, minmax); }
-    return shg::check_launch("k_warp_rows");
+    const double h3[3] = {h00, h01, h02};
+    const uint32_t* mm = minmax;
+    return shg::warp_rows_batch(&src, 1, h, w, src_pitch, h3, &dst, out_h, out_w, dst_pitch, &mm, stream);
 }
 
 extern "C" int shg_warp_rows_minmax_u16(const uint16_t* src, int64_t h, int64_t w, int64_t src_pitch, double h00, double h01,
                                         double h02, uint16_t* dst, int64_t out_h, int64_t out_w, int64_t dst_pitch,
                                         const uint32_t* minmax2, shg_stream_t stream) {
     SHG_REQUIRE(src && dst && minmax2, SHG_E_ARG, "shg_warp_rows_minmax_u16: null pointer");
+    const double h3[3] = {h00, h01, h02};
+    return shg::warp_rows_batch(&src, 1, h, w, src_pitch, h3, &dst, out_h, out_w, dst_pitch, &minmax2, stream);
+}
+
+// k disks of one shape (a Doppler stack) in one launch: host_h3 is [k][3], host_minmax2[i] -> {min, max} of disk i on the device
+int shg::warp_rows_batch(const uint16_t* const* host_srcs, int64_t k, int64_t h, int64_t w, int64_t src_pitch, const double* host_h3,
+                         uint16_t* const* host_dsts, int64_t out_h, int64_t out_w, int64_t dst_pitch, const uint32_t* const* host_minmax2,
+                         shg_stream_t stream) {
+    SHG_REQUIRE(host_srcs && host_h3 && host_dsts && host_minmax2 && k > 0, SHG_E_ARG, "shg_warp_rows_minmax_u16: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && out_h > 0 && out_w > 0, SHG_E_ARG, "shg_warp_rows_minmax_u16: empty image");
     SHG_REQUIRE(src_pitch >= w && dst_pitch >= out_w, SHG_E_ARG, "shg_warp_rows_minmax_u16: pitch smaller than width");
     SHG_REQUIRE(out_h < 65536, SHG_E_UNSUPPORTED, "shg_warp_rows_minmax_u16: more than 65535 rows");
+    for (int64_t i = 0; i < k; ++i) SHG_REQUIRE(host_srcs[i] && host_dsts[i] && host_minmax2[i], SHG_E_ARG, "shg_warp_rows_minmax_u16: null image");
     hipStream_t st = shg::as_stream(stream);
-    dim3 grid((unsigned)((out_w + 255) / 256), (unsigned)out_h);
-    { SHG_PROF("warp", st); k_warp_rows<<<grid, 256, 0, st>>>(src, h, w, src_pitch, h00, h01, h02, dst, out_h, out_w, dst_pitch, minmax2); }
-    return shg::check_launch("k_warp_rows");
+    SHG_PROF("warp", st);
+    for (int64_t i0 = 0; i0 < k; i0 += kWarpBatch) {
+        const int m = (int)std::min<int64_t>(kWarpBatch, k - i0);
+        WarpRows rows = {};
+        for (int d = 0; d < m; ++d)
+            for (int j = 0; j < 3; ++j) rows.h[d][j] = host_h3[3 * (i0 + d) + j];
+        dim3 grid((unsigned)((out_w + 255) / 256), (unsigned)out_h, (unsigned)m);
+        k_warp_rows<<<grid, 256, 0, st>>>(shg::make_batch(host_srcs, (int)i0, m), h, w, src_pitch, rows, shg::make_batch(host_dsts, (int)i0, m), out_h,
+                                          out_w, dst_pitch, shg::make_batch(host_minmax2, (int)i0, m));
+        if (int e = shg::check_launch("k_warp_rows")) return e;
+    }
+    return 0;
 }
