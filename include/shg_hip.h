@@ -163,6 +163,18 @@ int shg_extract_columns_minmax(const void* stack, int64_t n_frames, int64_t heig
                                int n_shifts, uint16_t* disks, int64_t row_pitch, int64_t plane_stride,
                                int64_t n_cols, int64_t k_offset, int flip_x, uint32_t* minmax_slots, shg_stream_t stream);
 
+/* The same for a Doppler stack whose shifts are consecutive integers in any order (-w a:b:1 with the two implicit shifts inside
+ * the range; 3 <= n_shifts <= 24, shg_extract_dense_fits): a lane loads the n_shifts + 1 distinct samples of a (row, frame)
+ * once instead of 2 * n_shifts.  host_shifts [n_shifts]: the shift of every plane; base_col [ih]: the column of the smallest
+ * shift before the clamps (fit[:, 0] + min shift); ind_l as above, used for the rows whose line lies within n_shifts columns
+ * of the frame's edge.  Bit-identical to shg_extract_columns_minmax. */
+int shg_extract_dense_fits(const int32_t* host_shifts, int n_shifts);
+int shg_extract_columns_dense(const void* stack, int64_t n_frames, int64_t height, int64_t width, int bytes_per_px,
+                              int64_t frame_stride_px, const int32_t* ind_l, const int32_t* base_col, const double* lw,
+                              const double* rw, const int32_t* host_shifts, int n_shifts, uint16_t* disks, int64_t row_pitch,
+                              int64_t plane_stride, int64_t n_cols, int64_t k_offset, int flip_x, uint32_t* minmax_slots,
+                              shg_stream_t stream);
+
 /* ---- the warp ---------------------------------- ellipse_to_circle.py:112-118
  * skimage.transform.warp(order=1, mode='constant', cval=image[0,0], clip) for a
  * transform that never moves rows: out[r][c] samples input row r at
@@ -416,7 +428,9 @@ int shg_stage_mean_fit(const void* stack, int64_t n_frames, int64_t height, int6
                        void* host_pinned, size_t host_pinned_bytes, shg_stream_t stream);
 
 /* read_video_improved (solex_util.py:93-144) from the host `fit` and shift list: sample columns and weights
- * (shg_host_column_plan), upload, shg_extract_columns_minmax (minmax_slots may be NULL).  Asynchronous. */
+ * (shg_host_column_plan), upload, shg_extract_columns_minmax -- or shg_extract_columns_dense for consecutive shifts
+ * (minmax_slots may be NULL).  Asynchronous: host_pinned is read by the GPU after the call has returned and must stay untouched
+ * until the work queued on `stream` up to here has run. */
 size_t shg_stage_extract_workspace_bytes(int64_t height, int64_t width, int n_shifts);   /* device and pinned */
 int shg_stage_extract(const void* stack, int64_t n_frames, int64_t height, int64_t width, int bytes_per_px,
                       int64_t frame_stride_px, const double* host_fit, const int32_t* host_shifts, int n_shifts,

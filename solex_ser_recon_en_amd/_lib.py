@@ -88,6 +88,9 @@ SIGNATURES = {
                                     c_int64, c_int64, c_int, P]),
     'shg_extract_columns_minmax': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int64, P, P, P, c_int, P, c_int64, c_int64,
                                            c_int64, c_int64, c_int, P, P]),
+    'shg_extract_dense_fits': (c_int, [P, c_int]),
+    'shg_extract_columns_dense': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int64, P, P, P, P, P, c_int, P, c_int64, c_int64, c_int64, c_int64,
+                                          c_int, P, P]),
     'shg_warp_rows_minmax_u16': (c_int, [P, c_int64, c_int64, c_int64, c_double, c_double, c_double, P, c_int64, c_int64,
                                          c_int64, P, P]),
     'shg_warp_rows_u16': (c_int, [P, c_int64, c_int64, c_int64, c_double, c_double, c_double, P, c_int64, c_int64,

@@ -14,6 +14,7 @@
 //    issued BATCH frames at a time before the first use (S=21 at C2: 211 -> 95 us).
 // Arithmetic is float64 with separately rounded products (compile with
 // -ffp-contract=off) and a truncating store, to be bit-exact with NumPy.
+#include <stdlib.h>
 #include "shg_common.h"
 
 namespace {
@@ -156,6 +157,163 @@ __global__ __launch_bounds__(256) void k_extract(const T* __restrict__ stack, in
     }
 }
 
+// ---- a Doppler stack of consecutive shifts (-w a:b:1): every distinct sample is loaded once ------------------------------------------
+// The S shifts of such a scan read the columns base .. base + S of a slit row (base = the fitted column plus the smallest
+// shift): S + 1 distinct samples per (row, frame), which the general kernel fetches as 2 S loads in groups of SC shifts (48
+// loads for 22 samples at S = 21).  Here a lane loads the S + 1 samples of a frame once and forms all S values from registers;
+// the tile is [S][64 rows][DK frames].  Measured (tools/bench_extract.py, tools/pmc_extract.sh, C4's shape): on UN-ROTATED files,
+// where every lane's samples sit in a cache line of their own, 335 us against the general kernel's 684; on rotated files 185
+// against 107 -- the general kernel's re-reads of shared lines hit L2 (FETCH_SIZE 129 against 154 MB), and with 114 VGPRs and
+// 34 KB of LDS it keeps 16 waves per CU where this one (200 VGPRs, 48 KB) keeps 8 for the same total of wave cycles.  So the
+// stage uses it for un-rotated files only (shg_stage_extract).
+// Rows whose line lies within S columns of the frame's edge (the clamps of solex_util.py:114-119 bite) are redone by the
+// general rule from the clamped indices, after the main loop: rare, and bit-identical either way.
+constexpr int DS_MAX = 24;             // most shifts of the dense path
+struct PlaneOfOffset { int v[DS_MAX]; };
+
+// NW waves per workgroup, DK frames per workgroup (LDS row stride DK + 2: an odd number of dwords)
+template <typename T, bool ROT, int BATCH, int NW, int DK>
+__global__ __launch_bounds__(64 * NW) void k_extract_dense(const T* __restrict__ stack, int n_frames, int64_t height, int64_t width, int64_t fstride,
+                                                       const int32_t* __restrict__ ind_l, const int32_t* __restrict__ base_col,
+                                                       const double* __restrict__ lw, const double* __restrict__ rw, int S, PlaneOfOffset plane_of,
+                                                       uint16_t* __restrict__ disks, int64_t row_pitch, int64_t plane_stride,
+                                                       int64_t n_cols, int64_t k_offset, int flip_x, int vec_store, uint32_t* __restrict__ mm) {
+    constexpr int DKP = DK + 2;
+    extern __shared__ uint16_t dtile[];                    // [S][TY][DKP]
+    __shared__ uint32_t wred[NW][DS_MAX][2];
+    __shared__ int any_edge;
+    const int64_t ih = ROT ? width : height, iw = ROT ? height : width;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c0 = (int64_t)blockIdx.x * DK;
+    const int64_t y = (int64_t)blockIdx.y * TY + lane;
+    const bool y_ok = y < ih;
+    const int64_t yc = y_ok ? y : ih - 1;
+    constexpr int scale = sizeof(T) == 1 ? 256 : 1;
+    const double wl = lw[yc], wr = rw[yc];
+    const int base = base_col[yc];
+    const bool plain = base >= 0 && (int64_t)base + S <= iw - 1;          // columns base .. base + S all lie inside the frame
+    if (threadIdx.x == 0) any_edge = 0;
+    // element offset of column `base` inside a frame and the distance between neighbouring columns; a lane near the edge
+    // reads stand-in addresses (column 0 ..) here and is redone below
+    const int64_t b0 = plain ? base : 0;
+    const int64_t step = ROT ? width : 1;
+    const int64_t off0 = ROT ? b0 * width + (width - 1 - yc) : yc * width + b0;
+    uint32_t vlo[DS_MAX], vhi[DS_MAX];
+#pragma unroll
+    for (int d = 0; d < DS_MAX; ++d) { vlo[d] = 0xffffu; vhi[d] = 0u; }
+    __syncthreads();
+    if (y_ok && !plain) any_edge = 1;
+
+    for (int cb = wave; cb < DK; cb += NW * BATCH) {
+        T v[BATCH][DS_MAX + 1];
+        bool ok[BATCH];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            const int cc = cb + NW * i;
+            const int64_t col = c0 + cc;
+            const int64_t k = (flip_x ? (n_cols - 1 - col) : col) - k_offset;   // wave-uniform
+            ok[i] = cc < DK && col < n_cols && k >= 0 && k < n_frames;
+            const T* f = stack + (ok[i] ? k : 0) * fstride + off0;
+            // (unconditional: a load under `if (d <= S)` becomes a branch with a wait at its join -- one request in flight;
+            // the columns beyond S re-read column S)
+#pragma unroll
+            for (int d = 0; d <= DS_MAX; ++d) v[i][d] = f[(int64_t)(d < S ? d : S) * step];
+        }
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            const int cc = cb + NW * i;
+            if (!ok[i] || !y_ok) continue;
+#pragma unroll
+            for (int d = 0; d < DS_MAX; ++d) {
+                if (d < S) {
+                    const double l = (double)((int)v[i][d] * scale);
+                    const double r = (double)((int)v[i][d + 1] * scale);
+                    const double val = l * wl + r * wr;
+                    const uint32_t q = (uint32_t)(uint16_t)(int)val;
+                    dtile[((size_t)d * TY + lane) * DKP + cc] = (uint16_t)q;
+                    if (plain) {
+                        vlo[d] = q < vlo[d] ? q : vlo[d];
+                        vhi[d] = q > vhi[d] ? q : vhi[d];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (any_edge) {
+        // the general rule for the rows the clamps touch: left sample at the clamped index of every shift, right one beside it
+        for (int cc = wave; cc < DK; cc += NW) {
+            const int64_t col = c0 + cc;
+            const int64_t k = (flip_x ? (n_cols - 1 - col) : col) - k_offset;
+            if (!(col < n_cols && k >= 0 && k < n_frames) || !y_ok || plain) continue;
+            const T* f = stack + k * fstride;
+            for (int d = 0; d < S; ++d) {
+                const int il = ind_l[(int64_t)plane_of.v[d] * ih + yc];
+                const int64_t off = ROT ? (int64_t)il * width + (width - 1 - yc) : yc * width + il;
+                const double l = (double)((int)f[off] * scale);
+                const double r = (double)((int)f[off + step] * scale);
+                const double val = l * wl + r * wr;
+                const uint32_t q = (uint32_t)(uint16_t)(int)val;
+                dtile[((size_t)d * TY + lane) * DKP + cc] = (uint16_t)q;
+                vlo[d] = q < vlo[d] ? q : vlo[d];
+                vhi[d] = q > vhi[d] ? q : vhi[d];
+            }
+        }
+    }
+    if (mm) {
+#pragma unroll
+        for (int d = 0; d < DS_MAX; ++d) {
+            if (d < S) {
+                uint32_t lo = vlo[d], hi = vhi[d];
+#pragma unroll
+                for (int e = 32; e >= 1; e >>= 1) {
+                    const uint32_t ol = __shfl_xor(lo, e), oh = __shfl_xor(hi, e);
+                    lo = ol < lo ? ol : lo;
+                    hi = oh > hi ? oh : hi;
+                }
+                if (lane == 0) { wred[wave][d][0] = lo; wred[wave][d][1] = hi; }
+            }
+        }
+    }
+    __syncthreads();
+    if (mm && threadIdx.x < S) {
+        const int d = threadIdx.x;
+        uint32_t lo = wred[0][d][0], hi = wred[0][d][1];
+        for (int wv = 1; wv < NW; ++wv) { lo = wred[wv][d][0] < lo ? wred[wv][d][0] : lo; hi = wred[wv][d][1] > hi ? wred[wv][d][1] : hi; }
+        if (hi >= lo) {
+            const int slot = (int)((blockIdx.x * 5u + blockIdx.y * 3u) & 63u);
+            uint32_t* m = mm + ((int64_t)plane_of.v[d] * 64 + slot) * 2;
+            atomicMax(&m[0], 0xffffu - lo);
+            atomicMax(&m[1], hi);
+        }
+    }
+    // write-out: one 16-byte segment (8 columns) per lane, DK / 8 lanes per row; the threads cover (plane, row) pairs
+    constexpr int SEGS = DK / 8, ROWS = 64 * NW / SEGS;
+    const int seg = threadIdx.x % SEGS;
+    const int64_t col = c0 + seg * 8;
+    for (int pr = threadIdx.x / SEGS; pr < S * TY; pr += ROWS) {
+        const int d = pr / TY, r = pr % TY;
+        const int64_t yy = (int64_t)blockIdx.y * TY + r;
+        if (yy >= ih) continue;
+        uint16_t* dst = disks + (int64_t)plane_of.v[d] * plane_stride + yy * row_pitch + col;
+        const uint16_t* src = &dtile[((size_t)d * TY + r) * DKP + seg * 8];
+        if (vec_store && col + 8 <= n_cols) {
+            const int64_t ka = (flip_x ? (n_cols - 1 - col) : col) - k_offset;
+            const int64_t kb = (flip_x ? (n_cols - 1 - (col + 7)) : (col + 7)) - k_offset;
+            if (ka >= 0 && ka < n_frames && kb >= 0 && kb < n_frames) {
+                const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
+                *reinterpret_cast<uint4*>(dst) = make_uint4(s32[0], s32[1], s32[2], s32[3]);
+                continue;
+            }
+        }
+        for (int j = 0; j < 8; ++j) {
+            const int64_t cj = col + j;
+            const int64_t kj = (flip_x ? (n_cols - 1 - cj) : cj) - k_offset;
+            if (cj < n_cols && kj >= 0 && kj < n_frames) dst[j] = src[j];
+        }
+    }
+}
+
 // fold the 64 slots of every plane: out[s] = {min, max}
 __global__ void k_fold_minmax(const uint32_t* __restrict__ slots, uint32_t* __restrict__ out) {
     uint32_t a = slots[((int64_t)blockIdx.x * 64 + threadIdx.x) * 2], b = slots[((int64_t)blockIdx.x * 64 + threadIdx.x) * 2 + 1];
@@ -236,6 +394,91 @@ extern "C" int shg_extract_columns_minmax(const void* stack, int64_t n_frames, i
 #undef SHG_LAUNCH_BS
 #undef SHG_LAUNCH
     if (int e = shg::check_launch("k_extract")) return e;
+    if (minmax_slots) {
+        k_fold_minmax<<<(unsigned)n_shifts, 64, 0, st>>>(minmax_slots, minmax_slots + (int64_t)n_shifts * 64 * 2);
+        return shg::check_launch("k_fold_minmax");
+    }
+    return 0;
+}
+
+// The same for a Doppler stack whose shifts are consecutive integers (any order): host_shifts[n_shifts] as the planes are laid
+// out; base_col [ih] = the column of the smallest shift, NOT clamped (fit[:, 0] + min shift); ind_l as above (clamped), used for
+// the rows near the frame's edge.  3 <= n_shifts <= 24.  Bit-identical to shg_extract_columns_minmax.
+extern "C" int shg_extract_dense_fits(const int32_t* host_shifts, int n_shifts) {
+    if (!host_shifts || n_shifts < 3 || n_shifts > DS_MAX) return 0;
+    int lo = host_shifts[0], hi = host_shifts[0];
+    for (int i = 1; i < n_shifts; ++i) { lo = host_shifts[i] < lo ? host_shifts[i] : lo; hi = host_shifts[i] > hi ? host_shifts[i] : hi; }
+    if ((int64_t)hi - lo != n_shifts - 1) return 0;
+    bool seen[DS_MAX] = {};
+    for (int i = 0; i < n_shifts; ++i) {
+        if (seen[host_shifts[i] - lo]) return 0;
+        seen[host_shifts[i] - lo] = true;
+    }
+    return 1;
+}
+
+extern "C" int shg_extract_columns_dense(const void* stack, int64_t n_frames, int64_t height, int64_t width, int bytes_per_px,
+                                         int64_t frame_stride_px, const int32_t* ind_l, const int32_t* base_col, const double* lw,
+                                         const double* rw, const int32_t* host_shifts, int n_shifts, uint16_t* disks, int64_t row_pitch,
+                                         int64_t plane_stride, int64_t n_cols, int64_t k_offset, int flip_x, uint32_t* minmax_slots,
+                                         shg_stream_t stream) {
+    SHG_REQUIRE(stack && ind_l && base_col && lw && rw && host_shifts && disks, SHG_E_ARG, "shg_extract_columns_dense: null pointer");
+    SHG_REQUIRE(n_frames > 0 && height > 0 && width > 0, SHG_E_ARG, "shg_extract_columns_dense: empty input");
+    SHG_REQUIRE(shg_extract_dense_fits(host_shifts, n_shifts), SHG_E_UNSUPPORTED, "shg_extract_columns_dense: the shifts are not 3..%d consecutive integers", DS_MAX);
+    SHG_REQUIRE(bytes_per_px == 1 || bytes_per_px == 2, SHG_E_ARG, "shg_extract_columns_dense: bytes_per_px must be 1 or 2");
+    SHG_REQUIRE(n_frames < (1ll << 31), SHG_E_UNSUPPORTED, "shg_extract_columns_dense: too many frames");
+    SHG_REQUIRE(n_cols >= n_frames && k_offset >= 0 && k_offset + n_frames <= n_cols, SHG_E_ARG, "shg_extract_columns_dense: frames do not fit the columns");
+    SHG_REQUIRE(row_pitch >= n_cols, SHG_E_ARG, "shg_extract_columns_dense: row_pitch < n_cols");
+    SHG_REQUIRE((height < width ? height : width) > n_shifts, SHG_E_UNSUPPORTED, "shg_extract_columns_dense: the spectral axis must be wider than the shift range");
+    SHG_REQUIRE(frame_stride_px == 0 || frame_stride_px >= height * width, SHG_E_ARG, "shg_extract_columns_dense: frame stride smaller than a frame");
+    const int64_t fstride = frame_stride_px > 0 ? frame_stride_px : height * width;
+    const bool rot = width > height;
+    const int64_t ih = rot ? width : height;
+    const int vec_store = ((reinterpret_cast<uintptr_t>(disks) & 15) == 0) && (row_pitch % 8 == 0) && (plane_stride % 8 == 0);
+    int lo = host_shifts[0];
+    for (int i = 1; i < n_shifts; ++i) lo = host_shifts[i] < lo ? host_shifts[i] : lo;
+    PlaneOfOffset po = {};
+    for (int i = 0; i < n_shifts; ++i) po.v[host_shifts[i] - lo] = i;
+    hipStream_t st = shg::as_stream(stream);
+    if (minmax_slots) {
+        if (hipError_t e = hipMemsetAsync(minmax_slots, 0, (size_t)n_shifts * 64 * 2 * sizeof(uint32_t), st)) {
+            shg::set_error("shg_extract_columns_dense: memset: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+    }
+    const int n = (int)n_frames;
+    // launch shape (tools/bench_extract.py): waves per workgroup x frames per workgroup x frames in flight per wave
+    static const int shape = [] { const char* e = getenv("SHG_EXT_DENSE_SHAPE"); return e ? atoi(e) : 0; }();
+#define SHG_DENSE(T, ROT, B, NW, DKV)                                                                                                               \
+    do {                                                                                                                                            \
+        static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_extract_dense<T, ROT, B, NW, DKV>),                            \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;                         \
+        if (!ok_) (void)hipGetLastError();                                                                                                          \
+        const size_t lds = (size_t)n_shifts * TY * (DKV + 2) * sizeof(uint16_t);                                                                    \
+        dim3 grid((unsigned)((n_cols + DKV - 1) / DKV), (unsigned)((ih + TY - 1) / TY));                                                            \
+        k_extract_dense<T, ROT, B, NW, DKV><<<grid, 64 * NW, lds, st>>>(static_cast<const T*>(stack), n, height, width, fstride, ind_l, base_col, lw, rw, \
+                                                                       n_shifts, po, disks, row_pitch, plane_stride, n_cols, k_offset, flip_x, vec_store, minmax_slots); \
+    } while (0)
+#define SHG_DENSE_S(T, ROT)                                                                  \
+    do {                                                                                     \
+        switch (shape) {                                                                     \
+            case 1: SHG_DENSE(T, ROT, 4, 8, 32); break;                                      \
+            case 2: SHG_DENSE(T, ROT, 2, 16, 32); break;                                     \
+            case 3: SHG_DENSE(T, ROT, 4, 4, 16); break;                                      \
+            case 4: SHG_DENSE(T, ROT, 2, 8, 16); break;                                      \
+            case 5: SHG_DENSE(T, ROT, 2, 4, 8); break;                                       \
+            case 6: SHG_DENSE(T, ROT, 4, 4, 32); break;                                      \
+            default: SHG_DENSE(T, ROT, 4, 4, 16); break;                                     \
+        }                                                                                    \
+    } while (0)
+    {
+        SHG_PROF("extract", st);
+        if (bytes_per_px == 2) { if (rot) SHG_DENSE_S(uint16_t, true); else SHG_DENSE_S(uint16_t, false); }
+        else { if (rot) SHG_DENSE_S(uint8_t, true); else SHG_DENSE_S(uint8_t, false); }
+    }
+#undef SHG_DENSE_S
+#undef SHG_DENSE
+    if (int e = shg::check_launch("k_extract_dense")) return e;
     if (minmax_slots) {
         k_fold_minmax<<<(unsigned)n_shifts, 64, 0, st>>>(minmax_slots, minmax_slots + (int64_t)n_shifts * 64 * 2);
         return shg::check_launch("k_fold_minmax");

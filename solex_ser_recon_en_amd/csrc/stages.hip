@@ -196,9 +196,11 @@ extern "C" int shg_stage_mean_fit(const void* stack, int64_t n_frames, int64_t h
 extern "C" size_t shg_stage_extract_workspace_bytes(int64_t height, int64_t width, int n_shifts) {
     if (height <= 0 || width <= 0 || n_shifts <= 0) return 0;
     const size_t ih = (size_t)slit_rows(height, width);
-    return up((size_t)n_shifts * ih * 4) + up(2 * ih * 8);
+    return up((size_t)n_shifts * ih * 4) + up(2 * ih * 8) + up(ih * 4);
 }
 
+// host_pinned is read by the GPU (one small copy kernel) after the call has returned: it must stay untouched until the work
+// queued on `stream` up to here has run -- e.g. until the caller's next synchronisation of that stream.
 extern "C" int shg_stage_extract(const void* stack, int64_t n_frames, int64_t height, int64_t width, int bytes_per_px,
                                  int64_t frame_stride_px, const double* host_fit, const int32_t* host_shifts, int n_shifts,
                                  uint16_t* disks, int64_t row_pitch, int64_t plane_stride, int64_t n_cols, int64_t k_offset,
@@ -209,18 +211,39 @@ extern "C" int shg_stage_extract(const void* stack, int64_t n_frames, int64_t he
     SHG_REQUIRE(height > 0 && width > 0 && n_shifts > 0, SHG_E_ARG, "shg_stage_extract: empty input");
     const int64_t ih = slit_rows(height, width), iw = spectral_cols(height, width);
     Arena dev(workspace, workspace_bytes), pin(host_pinned, host_pinned_bytes);
+    // the two arenas have the same layout: indices, weights and base columns cross in one piece
     int32_t* ind_l = dev.take<int32_t>((size_t)n_shifts * ih);
     double* w2 = dev.take<double>(2 * (size_t)ih);
+    int32_t* base = dev.take<int32_t>((size_t)ih);
     int32_t* h_ind = pin.take<int32_t>((size_t)n_shifts * ih);
     double* h_w2 = pin.take<double>(2 * (size_t)ih);
-    SHG_REQUIRE(ind_l && w2, SHG_E_WORKSPACE, "shg_stage_extract: workspace too small");
-    SHG_REQUIRE(h_ind && h_w2, SHG_E_WORKSPACE, "shg_stage_extract: pinned staging area too small");
+    int32_t* h_base = pin.take<int32_t>((size_t)ih);
+    SHG_REQUIRE(ind_l && w2 && base, SHG_E_WORKSPACE, "shg_stage_extract: workspace too small");
+    SHG_REQUIRE(h_ind && h_w2 && h_base, SHG_E_WORKSPACE, "shg_stage_extract: pinned staging area too small");
     STAGE_TRY(shg_host_column_plan(host_fit, ih, iw, host_shifts, n_shifts, h_ind, h_w2, h_w2 + ih));
+    // A Doppler stack of consecutive shifts on an UN-ROTATED file (Height > Width: a slit row's samples lie side by side, every
+    // lane in a cache line of its own): every distinct sample once (shg_extract_columns_dense: 335 us against 684 at C4's shape).
+    // On rotated files the general kernel stays: its re-reads of shared lines hit L2, it keeps twice the waves per CU
+    // (114 VGPRs, 34 KB of LDS against 200 and 48-91 KB) and measures 107 us against 185 (tools/pmc_extract.sh).
+    // SHG_EXT_DENSE=0: never, 2: also on rotated files.
+    static const int dense_mode = [] { const char* v = getenv("SHG_EXT_DENSE"); return v ? atoi(v) : 1; }();
+    const bool dense = dense_mode > 0 && (dense_mode > 1 || height > width) && iw > n_shifts && shg_extract_dense_fits(host_shifts, n_shifts);
+    if (dense) {
+        int lo = host_shifts[0];
+        for (int i = 1; i < n_shifts; ++i) lo = std::min(lo, (int)host_shifts[i]);
+        for (int64_t y = 0; y < ih; ++y) {
+            const double v = host_fit[y * 4] + 1.0 * (double)lo;                          // fit[:, 0] + shift, before .astype(int) and the clamps
+            h_base[y] = (v == v && v > -1e9 && v < 1e9) ? (int32_t)(int64_t)v : INT32_MIN;     // (a NaN fit: every shift clamps -- the general rule)
+        }
+    }
     hipStream_t st = shg::as_stream(stream);
     Staging stg;
     STAGE_TRY(map_staging(host_pinned, &stg, "shg_stage_extract"));
-    // the two arenas have the same layout: indices and weights cross in one piece
-    STAGE_TRY(move_words(ind_l, stg.on_device(h_ind), (size_t)(reinterpret_cast<char*>(h_w2 + 2 * ih) - reinterpret_cast<char*>(h_ind)), st));
+    const char* end = dense ? reinterpret_cast<const char*>(h_base + ih) : reinterpret_cast<const char*>(h_w2 + 2 * ih);
+    STAGE_TRY(move_words(ind_l, stg.on_device(h_ind), (size_t)(end - reinterpret_cast<const char*>(h_ind)), st));
+    if (dense)
+        return shg_extract_columns_dense(stack, n_frames, height, width, bytes_per_px, frame_stride_px, ind_l, base, w2, w2 + ih, host_shifts, n_shifts,
+                                         disks, row_pitch, plane_stride, n_cols, k_offset, flip_x, minmax_slots, stream);
     return shg_extract_columns_minmax(stack, n_frames, height, width, bytes_per_px, frame_stride_px, ind_l, w2, w2 + ih, n_shifts, disks,
                                       row_pitch, plane_stride, n_cols, k_offset, flip_x, minmax_slots, stream);
 }

@@ -203,6 +203,32 @@ def extract_columns(stack, ind_l, lw, rw, n_cols=None, k_offset=0, flip_x=False,
     return out
 
 
+def extract_columns_dense(stack, fit, shifts, flip_x=False, want_minmax=False):
+    """shg_extract_columns_dense for consecutive shifts (any order, 3..24 of them): every distinct sample of a (row, frame) loaded
+    once.  fit: host [ih, 4] as compute_mean_return_fit returns it.  -> disks uint16 [S, ih, n] (and the extrema int32 [S, 2])."""
+    from . import hostmath
+    n, h, w, bpp = stack_geometry(stack)
+    dev = stack.device
+    ih, iw = (w, h) if w > h else (h, w)
+    sh = np.ascontiguousarray(shifts, dtype=np.int32)
+    s = int(sh.size)
+    if not lib.shg_extract_dense_fits(sh.ctypes.data, s):
+        raise ValueError('extract_columns_dense needs 3..24 consecutive shifts')
+    fit = np.ascontiguousarray(fit, dtype=np.float64)
+    ind_l, lw, rw = hostmath.column_plan(fit, sh, ih, iw)
+    base = (fit[:, 0] + 1.0 * float(sh.min())).astype(np.int64).astype(np.int32)
+    ind_d = torch.from_numpy(ind_l).to(dev)
+    w_d = torch.from_numpy(np.stack([lw, rw])).to(dev)
+    base_d = torch.from_numpy(base).to(dev)
+    pitch = (n + 63) // 64 * 64
+    out = torch.empty((s, ih, pitch), dtype=torch.uint16, device=dev)[:, :, :n]
+    mm = torch.empty(s * 130, dtype=torch.int32, device=dev) if want_minmax else None
+    _lib.check(lib.shg_extract_columns_dense(stack.data_ptr(), n, h, w, bpp, frame_stride(stack), ind_d.data_ptr(), base_d.data_ptr(),
+                                             w_d[0].data_ptr(), w_d[1].data_ptr(), sh.ctypes.data, s, out.data_ptr(), out.stride(1), out.stride(0),
+                                             n, 0, int(bool(flip_x)), None if mm is None else mm.data_ptr(), _stream()), 'shg_extract_columns_dense')
+    return (out, mm[s * 128:].view(s, 2)) if want_minmax else out
+
+
 # ---- post-processing ----------------------------------------------------------
 def warp_rows_u16(img, h00, h01, h02, out_h, out_w, minmax=None):
     """minmax: the plane's extrema as shg_extract_columns_minmax left them (int32 [2] = {min, max}); None = found here."""

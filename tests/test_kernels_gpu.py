@@ -120,6 +120,12 @@ def test_fused_blur_reductions_match_the_separate_kernels_and_the_oracle(ops, or
     (130, 36, 516, 8, [10, 0, -3], 0.03, False),           # 8-bit file: 4-byte requests
     (64, 48, 600, 16, [10, 0], 0.9, False),                # a steep line
     (64, 48, 602, 16, [10, 0], 0.01, False),               # slit length not a multiple of the tile
+    # consecutive shifts in any order take the load-each-sample-once kernel (shg_extract_columns_dense):
+    (75, 40, 700, 16, [2, 0, 1, 3, -1], 0.05, False),      # five of them, unordered, the line runs past both edges
+    (61, 30, 333, 8, [1, 0, -1], 0.03, True),              # three, 8-bit, flip, ragged everything
+    (50, 64, 520, 16, list(range(-12, 12)), 0.02, False),  # twenty-four: the most the dense path takes
+    (40, 500, 36, 16, list(range(-3, 4)), 0.004, False),   # un-rotated file (Height > Width)
+    (33, 26, 300, 16, list(range(-12, 12)), 0.0, False),   # frames barely wider than the shift range
 ])
 def test_extract_stage_equals_the_kernel_entry_point_and_the_oracle(ops, orc, n, h, w, bits, shifts, slope, flip):
     """shg_stage_extract (host column plan + upload + kernel + extrema) against shg_extract_columns fed with the same plan and
@@ -127,7 +133,7 @@ def test_extract_stage_equals_the_kernel_entry_point_and_the_oracle(ops, orc, n,
     from solex_ser_recon_en_amd import hostmath, stages
     rng = np.random.default_rng(n + w)
     frames = rng.integers(0, 256 if bits == 8 else 65536, (n, h, w)).astype(np.uint8 if bits == 8 else np.uint16)
-    ih, iw = w, h
+    ih, iw = (w, h) if w > h else (h, w)
     y = np.arange(ih)
     curve = iw / 2 + slope * (y - ih / 2) + 3 * np.sin(y / 40.0)          # runs past both spectral edges for the larger slopes: clamps
     fit = np.stack([np.floor(curve), curve - np.floor(curve), y.astype(float), curve], axis=1)
@@ -135,6 +141,12 @@ def test_extract_stage_equals_the_kernel_entry_point_and_the_oracle(ops, orc, n,
     ind_l, lw, rw = hostmath.column_plan(fit, shifts, ih, iw)
     direct = host(ops.extract_columns(dev(frames), ind_l, lw, rw, flip_x=flip))
     np.testing.assert_array_equal(got, direct)
+    if 3 <= len(shifts) <= 24 and max(shifts) - min(shifts) == len(shifts) - 1 and iw > len(shifts):
+        # (the stage takes this kernel for un-rotated files only; the entry point serves both layouts)
+        dense, mm = ops.extract_columns_dense(dev(frames), fit, shifts, flip_x=flip, want_minmax=True)
+        np.testing.assert_array_equal(host(dense), direct)
+        ext = mm.cpu().numpy().astype(np.int64)
+        assert [tuple(e) for e in ext] == [(int(p.min()), int(p.max())) for p in direct]
     want = np.stack(orc.extract_columns(orc.SerReader(frames), fit, shifts))
     np.testing.assert_array_equal(got, want[:, :, ::-1] if flip else want)
 
