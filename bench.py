@@ -174,9 +174,8 @@ def main():
         tasks = [(array_reader(pool[(first + i) % len(pool)], frame_count=n_total,
                                frame_range=(k0, k0 + n_local) if sharded else None), options(shifts)) for i in range(n)]
         with contextlib.redirect_stdout(io.StringIO()):
-            if sharded:
-                out = [Solex_recon.solex_do_work([t], True, distribute='frames', return_results=results) for t in tasks]
-                return [o[0] for o in out if o] if results else None
+            if sharded:                                  # one call: rank 0's post-processing of scan k overlaps everybody's read of scan k + 1
+                return Solex_recon.solex_do_work(tasks, True, distribute='frames', return_results=results)
             return Solex_recon.solex_do_work(tasks, True, distribute='none', return_results=results, workers=n_workers)
 
     def barrier():
@@ -498,9 +497,8 @@ def sharded_c3_leg(args, world, rank, options, backend):
         _write_scan(path, n, w, h, 16, rank, world)
 
         def go(k):
-            for _ in range(k):
-                with contextlib.redirect_stdout(io.StringIO()):
-                    Solex_recon.solex_do_work([(path, options())], True, distribute='frames' if world > 1 else 'none')
+            with contextlib.redirect_stdout(io.StringIO()):
+                Solex_recon.solex_do_work([(path, options()) for _ in range(k)], True, distribute='frames' if world > 1 else 'none')
             torch.cuda.synchronize()
         go(1)
         if world > 1:
@@ -520,8 +518,8 @@ def sharded_c3_leg(args, world, rank, options, backend):
                 'collectives': 'all_reduce SUM (int64 sum frame), all_reduce MAX (max frame), all_reduce SUM (disk mosaic, disjoint column blocks)' if world > 1 else None,
                 'frames_per_rank': dist.frame_block(n, rank, world)[1] - dist.frame_block(n, rank, world)[0],
                 'what': 'one %d-frame %dx%d 16-bit SER in %s, every rank decodes its own frame block (file -> pinned -> HBM), all-reduce '
-                        'after pass A, all-reduce of the zero-filled disk mosaic after pass B, mosaic post-processed on rank 0; scans run '
-                        'one after the other' % (n, w, h, os.path.dirname(path))}
+                        'after pass A, all-reduce of the zero-filled disk mosaic after pass B, mosaic post-processed on rank 0 while '
+                        'all ranks read the next scan' % (n, w, h, os.path.dirname(path))}
     finally:
         if world > 1:
             td.barrier()

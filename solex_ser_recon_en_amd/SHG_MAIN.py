@@ -76,7 +76,9 @@ def precheck_files(serfiles, options):
 def handle_files(files, options, flag_command_line=False):
     good_tasks = precheck_files(files, options)
     try:
-        Solex_recon.solex_do_work(good_tasks, flag_command_line)
+        # several files under torch.distributed: one file per rank (folder mode) unless SHG_DISTRIBUTE=frames asks for every
+        # file's frames to be sharded over the ranks (scans longer than one GPU's share of the link / of HBM)
+        Solex_recon.solex_do_work(good_tasks, flag_command_line, distribute=os.environ.get('SHG_DISTRIBUTE', 'auto'))
         return True
     except Exception:
         print('ERROR ENCOUNTERED')

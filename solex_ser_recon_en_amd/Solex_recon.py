@@ -199,7 +199,9 @@ def solex_do_work(tasks, flag_command_line=False, distribute='auto', return_resu
             collected[i] = res
 
     try:
-        if n_workers == 1:
+        if shard_frames and len(tasks) > 1 and os.environ.get('SHG_SHARD_OVERLAP', '1') != '0':
+            _sharded_series(tasks, decoder, collected if return_results else None)
+        elif n_workers == 1:
             previous = bind_thread('scan', decoder.device)  # this thread is the scan worker for the duration (device.cpu_plan)
             try:
                 for i in range(len(tasks)):
@@ -223,9 +225,7 @@ def solex_do_work(tasks, flag_command_line=False, distribute='auto', return_resu
 
 def _check_shardable(rdr):
     """Every rank sees the same header, so every rank raises (none is left waiting in the first all-reduce)."""
-    if int(rdr.FrameCount) < dist.world_size():
-        raise Exception('error input file %s: %d frames cannot be sharded over %d ranks'
-                        % (rdr.file, int(rdr.FrameCount), dist.world_size()))
+    dist.refuse_unshardable(rdr.FrameCount, rdr.file)
 
 
 def _release_stack(rdr):
@@ -312,6 +312,91 @@ def _worker_context(device, k):
             ctx = {'stream': stream, 'buffers': {}}
             _worker_contexts[(str(device), k)] = ctx
     return ctx
+
+
+def _sharded_series(tasks, decoder, collected):
+    """Several scans, each sharded over the ranks: this thread reads them one after the other (decode, pass A, all-reduce,
+    extraction, all-reduce of the mosaic -- every collective here, in file order, on every rank), and what has no collective
+    in it, rank 0's post-processing of a finished mosaic, runs behind on a second thread with a stream of its own.  So while
+    rank 0 fits the limb and contrasts scan k, all ranks are already decoding and reducing scan k + 1 (before: every rank but
+    the first idled through rank 0's tail, Solex_recon.py:33-42 has no counterpart -- the reference never shards a scan).
+    A Doppler stack (several requested disks) deals its disks to all ranks and agrees on the limb fit: collectives inside
+    solex_process, so such a scan is post-processed here, in line.  Before every scan the ranks ask each other whether anyone
+    has failed (dist.any_failed): a failure stops all of them together."""
+    import torch
+    device = decoder.device
+    post = _Service.named('shg-post-%s' % device)
+    ctx = _worker_context(device, 'post')
+    slots = threading.Semaphore(2)                          # mosaics waiting for / in post-processing
+    pending = []
+    errors = []
+    lock = threading.Lock()
+
+    def post_job(i, options, disk_list, bounds, hdr, ready, done):
+        try:
+            torch.cuda.set_device(device)
+            bind_thread('scan', device)
+            stages.use_buffers(ctx['buffers'])
+            stream = ctx['stream']
+            stream.wait_event(ready)                        # the mosaic was written on the reading thread's stream
+            for d in disk_list:
+                d.t.record_stream(stream)
+                if d.minmax is not None:
+                    d.minmax.record_stream(stream)
+            with torch.cuda.stream(stream):
+                res = solex_process(options, disk_list, bounds, hdr)
+                stream.synchronize()
+            if collected is not None:
+                collected[i] = res
+        except BaseException as e:      # noqa: BLE001 -- re-raised on the caller's thread
+            with lock:
+                errors.append((i, e))
+        finally:
+            slots.release()
+            done.set()
+
+    previous = bind_thread('scan', device)
+    try:
+        for i, (file, options) in enumerate(tasks):
+            with lock:
+                failed = bool(errors)
+            if dist.any_failed(failed, device):
+                break
+            try:
+                print('file %s is processing' % file)
+                options['_shard_frames'] = True
+                rdr = decoder.get(i)
+                _check_shardable(rdr)
+                disk_list, bounds, hdr = solex_read(rdr, options)
+                _release_stack(rdr)
+                n_requested = sum(1 for s in options['shift'] if s in options['shift_requested'])
+                if n_requested > 1:
+                    options['_deal_disks'] = True           # every rank post-processes its share: collectives inside
+                    res = solex_process(options, disk_list, bounds, hdr)
+                    if collected is not None:
+                        collected[i] = res
+                elif dist.rank() == 0:
+                    slots.acquire()
+                    ready = torch.cuda.Event()
+                    ready.record(torch.cuda.current_stream(device))
+                    done = threading.Event()
+                    pending.append(done)
+                    post.jobs.put(functools.partial(post_job, i, options, disk_list, bounds, hdr, ready, done))
+            except BaseException as e:      # noqa: BLE001
+                with lock:
+                    errors.append((i, e))
+        for done in pending:
+            done.wait()
+        with lock:
+            failed = bool(errors)
+        dist.any_failed(failed, device)                     # (keeps the number of collectives equal on every rank)
+    finally:
+        for done in pending:
+            done.wait()
+        if previous is not None:
+            os.sched_setaffinity(0, previous)
+    if errors:
+        raise min(errors, key=lambda ie: ie[0])[1]
 
 
 _native_pools = {}             # (device, workers) -> shg_pool handle; the threads live as long as the process
@@ -644,34 +729,28 @@ def solex_process(options, disk_list, backup_bounds, hdr):
         basefich = basefich0 + '_shift=' + str(options['shift'][i])
         mine = True
         if deal and flag_requested:
-            mine = turn % dist.world_size() == dist.rank()
+            mine = dist.my_share(turn)
             turn += 1
         # disk_list[0] is always the ellipse-fit shift (more limb contrast)
         if options['ratio_fixe'] is None and options['slant_fix'] is None:
-            failure = None
-            if not deal or dist.rank() == 0:
-                try:
-                    with timing.stage('ellipse_fit+warp'):
-                        # (the corrected image of the ellipse-fit shift is only computed when somebody uses it: a requested
-                        # disk, or the diagnostic plot)
-                        frame_circularized, cercle0, options['ratio_fixe'], phi, borders = ellipse_to_circle(
-                            disk_list[i], options, basefich, need_image=flag_requested and mine)
-                except Exception as e:                      # noqa: BLE001
-                    if not deal:
-                        raise
-                    failure = e                             # the other ranks wait in the broadcast: tell them first
-            if deal:
-                # (ok, geometry | error text): a limb fit that fails on rank 0 fails the scan on every rank instead of
-                # leaving the others in the collective
-                message = None
+            def fit_limb():
+                # (the corrected image of the ellipse-fit shift is only computed when somebody uses it: a requested
+                # disk, or the diagnostic plot)
+                with timing.stage('ellipse_fit+warp'):
+                    return ellipse_to_circle(disk_list[i], options, basefich, need_image=flag_requested and mine)
+            if not deal:
+                frame_circularized, cercle0, options['ratio_fixe'], phi, borders = fit_limb()
+            else:
+                # rank 0 fits, every rank learns the geometry -- or fails with rank 0 (dist.agree) instead of waiting for it
+                kept = {}
+
+                def fit_and_keep():
+                    kept['frame'], c, ratio, ph, b = fit_limb()
+                    return c, ratio, ph, b
+                cercle0, options['ratio_fixe'], phi, borders = dist.agree(fit_and_keep)
                 if dist.rank() == 0:
-                    message = (False, repr(failure)) if failure is not None else (
-                        True, (cercle0, options['ratio_fixe'], phi, borders))
-                ok, payload = dist.broadcast_object(message)
-                if not ok:
-                    raise failure if failure is not None else RuntimeError('limb fit failed on rank 0: ' + payload)
-                cercle0, options['ratio_fixe'], phi, borders = payload
-                if dist.rank() != 0 and flag_requested and mine:
+                    frame_circularized = kept['frame']
+                elif flag_requested and mine:
                     # the same warp the fit ran on rank 0 (centre / height only feed the returned circle)
                     frame_circularized = correct_image(disk_list[i], phi, options['ratio_fixe'], np.array([-1.0, -1.0]),
                                                        -1.0, dict(options, _nolog=True))[0]

@@ -98,3 +98,45 @@ def broadcast_object(obj, src=0):
     box = [obj]
     td.broadcast_object_list(box, src=src)
     return box[0]
+
+
+def my_share(index):
+    """Round-robin dealing of the requested disks of a frame-sharded Doppler stack: disk `index` (in request order) is
+    post-processed by rank index mod world."""
+    return index % world_size() == rank()
+
+
+def agree(fn, src=0):
+    """Run fn() on rank `src` and give every rank its outcome: the (picklable) result everywhere, or an exception everywhere --
+    rank `src` re-raises its own, the others a RuntimeError carrying its text.  What keeps a failure on one rank (the limb
+    fit of a sharded scan runs on rank 0 only) from leaving the others waiting in the next collective."""
+    failure, message = None, None
+    if rank() == src:
+        try:
+            message = (True, fn())
+        except Exception as e:      # noqa: BLE001 -- handed to every rank below
+            failure = e
+            message = (False, repr(e))
+    ok, payload = broadcast_object(message, src=src)
+    if not ok:
+        raise failure if failure is not None else RuntimeError('rank %d failed: %s' % (src, payload))
+    return payload
+
+
+def refuse_unshardable(n_frames, what=''):
+    """A scan with fewer frames than ranks cannot be sharded: every rank sees the same header, so every rank raises (none is
+    left waiting in the first all-reduce)."""
+    if int(n_frames) < world_size():
+        raise Exception('error input file %s: %d frames cannot be sharded over %d ranks' % (what, int(n_frames), world_size()))
+
+
+def any_failed(failed, device=None):
+    """Whether ANY rank reports a failure (one tiny all-reduce): ranks that shard a series of scans ask before every scan, so that
+    a rank that failed outside a collective (rank 0 post-processing the previous scan) stops all of them together instead of
+    leaving the others waiting in the next scan's all-reduce."""
+    if not active():
+        return bool(failed)
+    on_gpu = td.get_backend() != 'gloo' and device is not None
+    t = torch.tensor([1 if failed else 0], dtype=torch.int32, device=device if on_gpu else 'cpu')
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    return bool(int(t.item()))

@@ -1,6 +1,8 @@
-"""The multi-GPU exchange steps (dist.py) on CPU tensors with the gloo backend, world size 2:
+"""The multi-GPU exchange steps (dist.py) on CPU tensors with the gloo backend, world sizes 2, 3 and 8:
 integer all-reduce of the sum/max frames and of the zero-filled disk mosaic reproduce
-the unsharded oracle result bit for bit."""
+the unsharded oracle result bit for bit (uneven frame blocks included); a scan with fewer frames than ranks is
+refused on every rank; the disks of a Doppler stack are dealt so that every disk has exactly one owner; an outcome decided
+on rank 0 (the limb fit) reaches every rank, failures included."""
 import os
 import socket
 
@@ -66,15 +68,14 @@ def _worker(rank, world, port, frames, fit, shifts, flip, out_dir):
         td.destroy_process_group()
 
 
-@pytest.mark.parametrize('flip', [False, True])
-def test_sharded_exchange_matches_unsharded_oracle(tmp_path, flip):
-    frames = synth.synth_frames_numpy(21, 96, 40, 16, seed=4)       # 21 frames over 2 ranks: uneven blocks
+@pytest.mark.parametrize('flip,world', [(False, 2), (True, 2), (False, 3), (True, 8)])
+def test_sharded_exchange_matches_unsharded_oracle(tmp_path, flip, world):
+    frames = synth.synth_frames_numpy(21, 96, 40, 16, seed=4)       # 21 frames over 2 / 3 / 8 ranks: uneven blocks (3, 3, 3, 3, 3, 2, 2, 2 at 8)
     frames[5] = 65535                                                # full-scale maxima must survive the widened MAX
     ih, iw = 96, 40
     curve = np.linspace(3.2, iw - 5.1, ih)
     fit = np.stack([np.floor(curve), curve - np.floor(curve), np.arange(ih), curve], axis=1)
     shifts = [10, 0, -3]
-    world = 2
     mp.spawn(_worker, args=(world, _free_port(), frames, fit, shifts, flip, str(tmp_path)), nprocs=world, join=True)
     want_sum = frames.astype(np.int64).sum(0).ravel()
     want_max = frames.max(0).ravel()
@@ -86,3 +87,54 @@ def test_sharded_exchange_matches_unsharded_oracle(tmp_path, flip):
         np.testing.assert_array_equal(got['total'], want_sum)
         np.testing.assert_array_equal(got['mx'], want_max)
         np.testing.assert_array_equal(got['full'], want_disks)
+
+
+def _protocol_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    td.init_process_group('gloo', rank=rank, world_size=world)
+    report = {}
+    try:
+        # 1. a scan with fewer frames than ranks: every rank refuses it, before any collective
+        try:
+            dist.refuse_unshardable(world - 1, 'short.ser')
+            report['refused'] = False
+        except Exception as e:      # noqa: BLE001
+            report['refused'] = 'cannot be sharded over %d ranks' % world in str(e)
+        dist.refuse_unshardable(world, 'enough.ser')                       # exactly one frame per rank is fine
+        assert dist.frame_block(world) == (rank, rank + 1)
+        # 2. the 21 requested disks of a Doppler stack: dealt round-robin, every disk exactly one owner
+        mine = [i for i in range(21) if dist.my_share(i)]
+        owners = [None] * world
+        td.all_gather_object(owners, mine)
+        report['dealt_once'] = sorted(i for o in owners for i in o) == list(range(21))
+        report['balanced'] = max(len(o) for o in owners) - min(len(o) for o in owners) <= 1
+        # 3. an outcome decided on rank 0 reaches everyone ...
+        geometry = dist.agree(lambda: ((101.5, 99.25, 80.0), 0.97, 0.0123, [1.0, 2.0, 3.0, 4.0]))
+        report['agreed'] = geometry == ((101.5, 99.25, 80.0), 0.97, 0.0123, [1.0, 2.0, 3.0, 4.0])
+        # ... a failure too: rank 0 re-raises its own exception, the others learn its text -- nobody waits
+        def fails():
+            raise ValueError('ellipse fit: could not find any edges of the solar disk')
+        try:
+            dist.agree(fails)
+            report['failure'] = 'no exception'
+        except ValueError as e:
+            report['failure'] = 'own' if rank == 0 else 'wrong type on rank %d: %r' % (rank, e)
+        except RuntimeError as e:
+            report['failure'] = 'told' if (rank != 0 and 'could not find any edges' in str(e)) else repr(e)
+        # 4. the next collective still works (nobody is stuck in the failed step)
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        td.all_reduce(t)
+        report['after'] = int(t.item()) == world * (world + 1) // 2
+        np.save(os.path.join(out_dir, 'report%d.npy' % rank), np.array([repr(report)]))
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3, 8])
+def test_sharding_protocol_on_every_rank(tmp_path, world):
+    mp.spawn(_protocol_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        report = eval(str(np.load(str(tmp_path / ('report%d.npy' % r)))[0]))      # noqa: S307 -- our own repr
+        assert report['refused'] is True and report['dealt_once'] and report['balanced'] and report['agreed'] and report['after'], (r, report)
+        assert report['failure'] == ('own' if r == 0 else 'told'), (r, report)

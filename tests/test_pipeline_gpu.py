@@ -343,6 +343,37 @@ def test_two_ranks_sharded_scan_equals_one_rank(pkg, scan, tmp_path):
             np.testing.assert_array_equal(fits_io.read_fits_u16(a)[0], fits_io.read_fits_u16(b)[0], err_msg=name)
 
 
+def test_two_ranks_series_of_sharded_scans_overlaps_and_equals_one_rank(pkg, scan, tmp_path):
+    """SHG_DISTRIBUTE=frames with several files: every file's frames are sharded over the two ranks; rank 0 post-processes file k on
+    a second thread while both ranks already read file k + 1 (collectives in file order).  Three different files must come
+    out like the single-process run, written by rank 0 only."""
+    import subprocess
+    import sys
+    g, frames, path = scan
+    from solex_ser_recon_en_amd import png_io
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=repo, SHG_DIST_BACKEND='gloo', MPLBACKEND='Agg', SHG_DISTRIBUTE='frames')
+    dirs = {}
+    for tag in ('one', 'two'):
+        d = tmp_path / tag
+        d.mkdir()
+        for j in range(3):
+            synth.write_ser(str(d / ('scan%d.ser' % j)), np.roll(frames, 3 * j, axis=0) if j else frames)
+        dirs[tag] = d
+    files = lambda d: [str(d / ('scan%d.ser' % j)) for j in range(3)]      # noqa: E731
+    subprocess.run([sys.executable, '-m', 'solex_ser_recon_en_amd.SHG_MAIN', '-c'] + files(dirs['one']), check=True,
+                   env=dict(env, SHG_DISTRIBUTE='auto'), cwd=repo, stdout=subprocess.DEVNULL, timeout=900)
+    subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                    '--master-port', str(free_port()), '-m', 'solex_ser_recon_en_amd.SHG_MAIN', '-c'] + files(dirs['two']),
+                   check=True, env=env, cwd=repo, stdout=subprocess.DEVNULL, timeout=900)
+    names = sorted(os.listdir(str(dirs['one'])))
+    assert names == sorted(os.listdir(str(dirs['two'])))
+    assert sum(n.endswith('_clahe.png') for n in names) == 3
+    for name in names:
+        if name.endswith('.png'):
+            np.testing.assert_array_equal(png_io.read_png_gray(str(dirs['one'] / name)), png_io.read_png_gray(str(dirs['two'] / name)), err_msg=name)
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='the RCCL (nccl) branch needs two GPUs; gloo covers the logic on one')
 def test_rccl_two_gpus_sharded_doppler_and_folder(pkg, scan, tmp_path):
     """torch.distributed.run with the default backend (nccl = RCCL over xGMI), one process per GPU: a frame-sharded scan,
