@@ -144,6 +144,7 @@ class _Decoder:
         for _ in self.tasks:
             self.slots.release()
         self.finished.wait()
+        self.out = [None] * len(self.tasks)                  # stacks decoded for scans that will not run: let go of them (GBs of HBM)
 
 
 def solex_do_work(tasks, flag_command_line=False, distribute='auto', return_results=False, workers=None):

@@ -238,31 +238,57 @@ def check(status, what, message=None):
         raise RuntimeError('%s failed (status %d): %s' % (what, status, last_error() if message is None else message))
 
 
+# (library glob under site-packages, prefix, suffix of the ILP64 Fortran symbols, suffix of the ILP64 cblas symbols)
+_OPENBLAS_LAYOUTS = (
+    ('numpy.libs/libscipy_openblas64_*.so*', 'scipy_', '_64_', '64_'),       # NumPy 2.x wheels
+    ('numpy.libs/libopenblas64_*.so*', '', '_64_', '64_'),                    # NumPy 1.2x wheels
+    ('numpy/.libs/libopenblas64_*.so*', '', '_64_', '64_'),                   # older wheel layout
+)
+
+
 def _bind_numpy_lapack():
-    """Hand the library the dgelsd NumPy itself calls (np.linalg.lstsq under np.polyfit), so that the line fit of
-    the host control plane is bit-identical to the reference's on this host.  NumPy 2.x wheels bundle an ILP64
-    OpenBLAS whose Fortran symbols carry a scipy_ prefix and a 64_ suffix."""
+    """Hand the library the dgelsd NumPy itself calls (np.linalg.lstsq under np.polyfit) and the five BLAS / LAPACK entry
+    points behind NumPy's matmul / inv / eig, so that the line fit and the limb geometry of the host control plane are
+    bit-identical to the reference's on this host.  NumPy's wheels bundle an ILP64 OpenBLAS whose symbols carry a 64_ suffix
+    (and, since 2.0, a scipy_ prefix).  A NumPy built against another BLAS (conda's MKL, a distribution's OpenBLAS) exports
+    none of these: the library then uses its built-in routines (a Householder least squares, plain-loop 3 x 3 algebra), whose
+    results agree with NumPy's to ~1e-12 but are not bit-identical -- said once, at import, with the names that were missing.
+    -> (path of the library bound, or None; list of the symbols that could not be found)"""
     import glob
     import numpy
     import numpy.linalg           # noqa: F401  -- loads the bundled OpenBLAS
     root = os.path.dirname(os.path.dirname(os.path.abspath(numpy.__file__)))
-    for path in sorted(glob.glob(os.path.join(root, 'numpy.libs', 'libscipy_openblas64_*.so*'))):
-        try:
-            blas = ctypes.CDLL(path)                   # already mapped: same handle, no second copy
-            fn = getattr(blas, 'scipy_dgelsd_64_')
-        except (OSError, AttributeError):
-            continue
-        lib.shg_host_bind_lapack(ctypes.cast(fn, c_void_p))
-        try:                                           # the products, inverses and eigen-decomposition of the limb geometry
-            names = ('scipy_cblas_dgemm64_', 'scipy_cblas_dsyrk64_', 'scipy_cblas_dgemv64_', 'scipy_dgesv_64_', 'scipy_dgeev_64_')
-            lib.shg_host_bind_blas(*[ctypes.cast(getattr(blas, n), c_void_p) for n in names])
-        except AttributeError:
-            pass
-        return path
-    return None
+    missing = ['dgelsd', 'cblas_dgemm', 'cblas_dsyrk', 'cblas_dgemv', 'dgesv', 'dgeev']
+    for pattern, prefix, fsuffix, csuffix in _OPENBLAS_LAYOUTS:
+        for path in sorted(glob.glob(os.path.join(root, pattern))):
+            try:
+                blas = ctypes.CDLL(path)               # already mapped: same handle, no second copy
+            except OSError:
+                continue
+            found = {}
+            for name in missing:
+                sym = prefix + name + (csuffix if name.startswith('cblas_') else fsuffix)
+                try:
+                    found[name] = ctypes.cast(getattr(blas, sym), c_void_p)
+                except AttributeError:
+                    pass
+            if 'dgelsd' not in found:
+                continue
+            lib.shg_host_bind_lapack(found['dgelsd'])
+            rest = ['cblas_dgemm', 'cblas_dsyrk', 'cblas_dgemv', 'dgesv', 'dgeev']
+            if all(n in found for n in rest):
+                lib.shg_host_bind_blas(*[found[n] for n in rest])
+            return path, [n for n in missing if n not in found]
+    return None, missing
 
 
-LAPACK_PATH = _bind_numpy_lapack()
+LAPACK_PATH, LAPACK_MISSING = _bind_numpy_lapack()
+if LAPACK_MISSING:
+    import warnings
+    warnings.warn('solex_ser_recon_en_amd: NumPy\'s own %s could not be found (looked for the OpenBLAS bundled with NumPy\'s wheels); '
+                  'the line fit / limb geometry run on the library\'s built-in routines: results agree with NumPy to ~1e-12 but the raw '
+                  'disks and products are no longer guaranteed bit-identical to the reference\'s on this host.' % ', '.join(LAPACK_MISSING),
+                  RuntimeWarning, stacklevel=2)
 
 
 @ctypes.CFUNCTYPE(c_int64, ctypes.POINTER(c_int64), c_int64)

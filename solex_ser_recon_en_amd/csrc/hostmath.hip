@@ -621,6 +621,154 @@ struct Blas {
 static std::atomic<const Blas*> g_blas{nullptr};
 static Blas g_blas_store;
 
+// ---- built-in stand-ins, for hosts where NumPy's own routines cannot be found ----------------------------------------------
+// shg_host_bind_blas gets its five entry points from the OpenBLAS that NumPy's wheel bundles (_lib.py); a NumPy built against
+// another BLAS (MKL, a system OpenBLAS, Accelerate) does not export them under names the binding knows.  The limb geometry
+// then runs on the routines below: the same algebra on the same operands, plain loops instead of OpenBLAS's kernels -- results
+// agree with NumPy's to ~1e-12 relative (tests/test_hostmath_cpu.py), they are no longer bit-identical.  Same signatures as
+// the cblas / LAPACK entry points, only the cases the callers above use (n <= 3 for gesv / geev).
+namespace builtin {
+inline double at(const double* a, int64_t ld, bool row_major, bool trans, int64_t i, int64_t j) {      // op(A)[i][j]
+    if (trans) { const int64_t t = i; i = j; j = t; }
+    return row_major ? a[i * ld + j] : a[i + j * ld];
+}
+void gemm(int order, int ta, int tb, int64_t m, int64_t n, int64_t k, double alpha, const double* a, int64_t lda, const double* b,
+          int64_t ldb, double beta, double* c, int64_t ldc) {
+    const bool rm = order == 101;
+    for (int64_t i = 0; i < m; ++i)
+        for (int64_t j = 0; j < n; ++j) {
+            long double acc = 0;
+            for (int64_t l = 0; l < k; ++l) acc += (long double)at(a, lda, rm, ta == 112, i, l) * at(b, ldb, rm, tb == 112, l, j);
+            double& out = rm ? c[i * ldc + j] : c[i + j * ldc];
+            out = (double)(alpha * acc) + (beta != 0.0 ? beta * out : 0.0);
+        }
+}
+void syrk(int order, int uplo, int trans, int64_t n, int64_t k, double alpha, const double* a, int64_t lda, double beta, double* c, int64_t ldc) {
+    const bool rm = order == 101;
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j < n; ++j) {
+            const bool upper = j >= i;
+            if ((uplo == 121) != upper && i != j) continue;
+            long double acc = 0;
+            for (int64_t l = 0; l < k; ++l) acc += (long double)at(a, lda, rm, trans == 112, i, l) * at(a, lda, rm, trans == 112, j, l);
+            double& out = rm ? c[i * ldc + j] : c[i + j * ldc];
+            out = (double)(alpha * acc) + (beta != 0.0 ? beta * out : 0.0);
+        }
+}
+void gemv(int order, int trans, int64_t m, int64_t n, double alpha, const double* a, int64_t lda, const double* x, int64_t incx, double beta,
+          double* y, int64_t incy) {
+    const bool rm = order == 101, tr = trans == 112;
+    const int64_t rows = tr ? n : m, cols = tr ? m : n;
+    for (int64_t i = 0; i < rows; ++i) {
+        long double acc = 0;
+        for (int64_t j = 0; j < cols; ++j) acc += (long double)at(a, lda, rm, tr, i, j) * x[j * incx];
+        y[i * incy] = (double)(alpha * acc) + (beta != 0.0 ? beta * y[i * incy] : 0.0);
+    }
+}
+// column-major A (n x n), B (n x nrhs): Gaussian elimination with partial pivoting, the solution in B
+void gesv(const int64_t* pn, const int64_t* pnrhs, double* a, const int64_t* plda, int64_t* ipiv, double* b, const int64_t* pldb, int64_t* info) {
+    const int64_t n = *pn, nrhs = *pnrhs, lda = *plda, ldb = *pldb;
+    *info = 0;
+    for (int64_t c = 0; c < n; ++c) {
+        int64_t p = c;
+        for (int64_t r = c + 1; r < n; ++r)
+            if (fabs(a[r + c * lda]) > fabs(a[p + c * lda])) p = r;
+        ipiv[c] = p + 1;
+        if (a[p + c * lda] == 0.0) { *info = c + 1; return; }
+        if (p != c) {
+            for (int64_t j = 0; j < n; ++j) std::swap(a[c + j * lda], a[p + j * lda]);
+            for (int64_t j = 0; j < nrhs; ++j) std::swap(b[c + j * ldb], b[p + j * ldb]);
+        }
+        for (int64_t r = c + 1; r < n; ++r) {
+            const double f = a[r + c * lda] / a[c + c * lda];
+            for (int64_t j = c; j < n; ++j) a[r + j * lda] -= f * a[c + j * lda];
+            for (int64_t j = 0; j < nrhs; ++j) b[r + j * ldb] -= f * b[c + j * ldb];
+        }
+    }
+    for (int64_t j = 0; j < nrhs; ++j)
+        for (int64_t r = n - 1; r >= 0; --r) {
+            long double sacc = b[r + j * ldb];
+            for (int64_t c = r + 1; c < n; ++c) sacc -= (long double)a[r + c * lda] * b[c + j * ldb];
+            b[r + j * ldb] = (double)(sacc / a[r + r * lda]);
+        }
+}
+// right eigenvectors of a real 3 x 3 matrix (column major): roots of the characteristic cubic (closed form, polished by Newton
+// steps in extended precision), every eigenvector as the cross product of the two most independent rows of A - lambda I, scaled
+// to unit length.  A complex pair is reported through wi (its vectors are not formed: the callers reject that case).
+void geev(const char*, const char*, const int64_t* pn, double* a, const int64_t* plda, double* wr, double* wi, double*, const int64_t*,
+          double* vr, const int64_t* pldvr, double* work, const int64_t* lwork, int64_t* info, size_t, size_t) {
+    *info = 0;
+    if (*lwork == -1) { work[0] = 1.0; return; }
+    if (*pn != 3) { *info = -3; return; }
+    const int64_t lda = *plda, ldv = *pldvr;
+    long double m[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m[i][j] = a[i + j * lda];
+    long double scale = 0;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) scale = fabsl(m[i][j]) > scale ? fabsl(m[i][j]) : scale;
+    if (scale == 0) scale = 1;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m[i][j] /= scale;
+    const long double tr = m[0][0] + m[1][1] + m[2][2];
+    const long double c1 = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) + (m[0][0] * m[2][2] - m[0][2] * m[2][0]) + (m[1][1] * m[2][2] - m[1][2] * m[2][1]);
+    const long double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                            m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+    // t^3 + p t + q = 0 with lambda = t + tr / 3
+    const long double sh = tr / 3, p = c1 - tr * tr / 3, q = -2 * tr * tr * tr / 27 + tr * c1 / 3 - det;
+    const long double disc = q * q / 4 + p * p * p / 27;
+    long double lam[3];
+    int n_real = 3;
+    if (disc > 0) {
+        const long double sq = sqrtl(disc), u = cbrtl(-q / 2 + sq), v = cbrtl(-q / 2 - sq);
+        lam[0] = u + v + sh;
+        n_real = 1;
+        const long double re = -(u + v) / 2 + sh, im = (u - v) * sqrtl(3.0L) / 2;
+        if (fabsl(im) <= 1e-15L * (fabsl(re) + 1)) { lam[1] = lam[2] = re; n_real = 3; }
+        else { lam[1] = re; lam[2] = im; }
+    } else {
+        const long double r = sqrtl(-p / 3), arg = p == 0 ? 0 : (3 * q / (2 * p)) / r;
+        const long double th = acosl(arg > 1 ? 1 : (arg < -1 ? -1 : arg)) / 3;
+        const long double pi = 3.141592653589793238462643383279502884L;
+        for (int k = 0; k < 3; ++k) lam[k] = 2 * r * cosl(th - 2 * pi * k / 3) + sh;
+    }
+    for (int k = 0; k < (n_real == 3 ? 3 : 1); ++k)                          // Newton polish on the characteristic polynomial
+        for (int it = 0; it < 4; ++it) {
+            const long double x = lam[k], f = ((x - tr) * x + c1) * x - det, df = (3 * x - 2 * tr) * x + c1;
+            if (df == 0) break;
+            lam[k] = x - f / df;
+        }
+    if (n_real == 3) {                                                       // LAPACK's order is not promised; ascending is as good as any
+        for (int k = 0; k < 3; ++k) { wr[k] = (double)(lam[k] * scale); wi[k] = 0.0; }
+    } else {
+        wr[0] = (double)(lam[0] * scale); wi[0] = 0.0;
+        wr[1] = wr[2] = (double)(lam[1] * scale);
+        wi[1] = (double)(lam[2] * scale); wi[2] = -wi[1];
+    }
+    for (int k = 0; k < 3; ++k) {
+        double* v = vr + k * ldv;
+        v[0] = v[1] = v[2] = 0.0;
+        if (wi[k] != 0.0) continue;
+        long double b[3][3];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) b[i][j] = m[i][j] - (i == j ? lam[k] : 0);
+        long double best[3] = {0, 0, 0}, best_n = -1;
+        for (int r0 = 0; r0 < 3; ++r0)
+            for (int r1 = r0 + 1; r1 < 3; ++r1) {
+                const long double c[3] = {b[r0][1] * b[r1][2] - b[r0][2] * b[r1][1], b[r0][2] * b[r1][0] - b[r0][0] * b[r1][2],
+                                          b[r0][0] * b[r1][1] - b[r0][1] * b[r1][0]};
+                const long double nn = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+                if (nn > best_n) { best_n = nn; best[0] = c[0]; best[1] = c[1]; best[2] = c[2]; }
+            }
+        if (best_n <= 0) { best[0] = 1; best[1] = best[2] = 0; best_n = 1; }    // A - lambda I = 0: any vector
+        const long double inv = 1 / sqrtl(best_n);
+        for (int i = 0; i < 3; ++i) v[i] = (double)(best[i] * inv);
+    }
+}
+const Blas kBuiltin = {gemm, syrk, gemv, gesv, geev};
+}  // namespace builtin
+
+static inline const Blas& active_blas() {
+    const Blas* b = g_blas.load();
+    return b ? *b : builtin::kBuiltin;
+}
+
 constexpr int kRowMajor = 101, kColMajor = 102, kNoTrans = 111, kTrans = 112, kUpper = 121;
 
 // A (m x k, row major) @ B.  b_is_transposed_view: B is the .T view of a row-major (n x k) array `b`.
@@ -751,11 +899,8 @@ extern "C" int shg_host_bind_blas(void* cblas_dgemm_ilp64, void* cblas_dsyrk_ilp
 
 extern "C" int shg_host_blas_bound(void) { return g_blas.load() != nullptr; }
 
-#define SHG_NEED_BLAS(who)                                                                                                   \
-    const Blas* blp = g_blas.load();                                                                                         \
-    SHG_REQUIRE(blp, SHG_E_UNSUPPORTED, who ": no BLAS / LAPACK bound (shg_host_bind_blas): the limb geometry is computed with " \
-                "the routines NumPy itself calls");                                                                         \
-    const Blas& bl = *blp
+// NumPy's own routines when they are bound (bit-identical geometry), the built-in stand-ins otherwise
+#define SHG_NEED_BLAS(who) const Blas& bl = active_blas()
 
 extern "C" int shg_host_fit_ellipse(const double* host_points, int64_t n, double* host_center2, double* width, double* height,
                                     double* phi) {

@@ -39,6 +39,34 @@ def _scratch(name, nbytes, device=None, pinned=False):
     return buf
 
 
+def _staging_slot(name, nbytes):
+    """A pinned staging area the GPU may still be reading when the stage call returns (shg_stage_extract queues a copy kernel
+    that reads it): one of a small per-thread ring, each slot guarded by an event recorded after its last use -- a slot is handed
+    out again only once that event has completed, and a slot that has to grow is kept until then.  -> (buffer, done(stream))"""
+    store = _local.__dict__.setdefault('buffers', {})
+    ring = store.setdefault(('ring', name), [])
+    slot = None
+    for entry in ring:
+        if entry[1] is None or entry[1].query():
+            slot = entry
+            break
+    if slot is None and len(ring) >= 4:
+        slot = ring[0]
+        slot[1].synchronize()
+    if slot is None:
+        slot = [None, None]
+        ring.append(slot)
+    if slot[0] is None or slot[0].numel() < nbytes:
+        slot[0] = torch.empty(max(int(nbytes), 1), dtype=torch.uint8).pin_memory()      # (the slot's event has completed: nobody reads the old one)
+    slot[1] = None
+
+    def done():
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        slot[1] = ev
+    return slot[0], done
+
+
 _size_cache = {}
 
 
@@ -114,12 +142,16 @@ def extract(stack, fit, shifts, n_cols=None, k_offset=0, flip_x=False, out=None,
         raise ValueError('out must be a [S, ih, n_cols] view with unit column stride')
     need = _sizes('extract', lib.shg_stage_extract_workspace_bytes, h, w, s)
     ws = _scratch('extract', need, dev)
-    pin = _scratch('extract', need, pinned=True)
+    # the stage returns with its copy kernel still to read the staging area: a slot of its own until that kernel has run
+    pin, staged = _staging_slot('extract', need)
     mm_store = torch.empty(s * 130, dtype=torch.int32, device=dev) if want_minmax else None      # 64 slots x 2 per plane, then {min, max}
-    _lib.check(lib.shg_stage_extract(stack.data_ptr(), n, h, w, bpp, ops.frame_stride(stack), _p(fit), _p(sh), s, out.data_ptr(),
-                                     out.stride(1), out.stride(0), n_cols, int(k_offset), int(bool(flip_x)),
-                                     None if mm_store is None else mm_store.data_ptr(), ws.data_ptr(), ws.numel(),
-                                     pin.data_ptr(), pin.numel(), ops._stream()), 'shg_stage_extract')
+    try:
+        _lib.check(lib.shg_stage_extract(stack.data_ptr(), n, h, w, bpp, ops.frame_stride(stack), _p(fit), _p(sh), s, out.data_ptr(),
+                                         out.stride(1), out.stride(0), n_cols, int(k_offset), int(bool(flip_x)),
+                                         None if mm_store is None else mm_store.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         pin.data_ptr(), pin.numel(), ops._stream()), 'shg_stage_extract')
+    finally:
+        staged()
     return (out, mm_store[s * 128:].view(s, 2)) if want_minmax else out
 
 
@@ -204,8 +236,11 @@ def process_frames(frames, transversalium=None, crop=None, disc=None, clip_limit
     crop_w, sx0, dx0, ncopy = (int(v) for v in crop) if crop is not None else (0, 0, 0, 0)
     out_w = crop_w if crop_w > 0 else w
     out_pitch = (out_w + 63) // 64 * 64
-    store = torch.empty((k, 5, h, out_pitch), dtype=torch.uint16, device=dev)
-    views = [[store[i, j, :, :out_w] for i in range(k)] for j in range(5)]
+    # what solex_process returns (protus, cc) apart from what only the file writers look at (final, cl1, hc): a caller that
+    # keeps the results of a batch keeps two images per disk alive, not five
+    store = torch.empty((k, 3, h, out_pitch), dtype=torch.uint16, device=dev)
+    kept = torch.empty((k, 2, h, out_pitch), dtype=torch.uint16, device=dev)
+    views = [[store[i, j, :, :out_w] for i in range(k)] for j in range(3)] + [[kept[i, j, :, :out_w] for i in range(k)] for j in range(2)]
     detrans, detrans_pitch, detrans_arr = None, 0, None
     if keep_detrans and transversalium is not None:
         detrans_pitch = (w + 63) // 64 * 64

@@ -258,6 +258,59 @@ def test_two_step_is_the_numpy_fit_bit_for_bit(seed):
     assert tuple(center) == tuple(wc) and (width, height) == (ww, wh) and one_ulp(ph, wp)
 
 
+@pytest.fixture
+def without_numpys_blas():
+    """The host whose NumPy is not a pip wheel: nothing bound, the library on its built-in routines."""
+    lib.shg_host_bind_blas(None, None, None, None, None)
+    lib.shg_host_bind_lapack(None)
+    assert lib.shg_host_blas_bound() == 0 and lib.shg_host_lapack_bound() == 0
+    yield
+    _lib._bind_numpy_lapack()
+    assert lib.shg_host_blas_bound() == 1 and lib.shg_host_lapack_bound() == 1
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_the_builtin_routines_carry_the_control_plane_when_numpys_are_not_found(seed, without_numpys_blas):
+    """No OpenBLAS of a NumPy wheel to bind (conda / MKL / a distribution's NumPy): the limb geometry, the warp geometry and
+    the line fit still work, on the library's own plain-loop algebra and Householder least squares, and agree with NumPy's
+    to rounding (not bit for bit: _lib warns about that at import)."""
+    from oracle import limb_oracle
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(40, 3000))
+    t = rng.uniform(0, 2 * np.pi, n)
+    a, b = rng.uniform(100, 2900), rng.uniform(100, 2900)
+    phi = rng.uniform(-0.7, 0.7)
+    cy, cx = rng.uniform(300, 3200), rng.uniform(300, 3200)
+    r = cy + a * np.cos(t) * np.cos(phi) - b * np.sin(t) * np.sin(phi) + rng.normal(0, 0.7, n)
+    c = cx + a * np.cos(t) * np.sin(phi) + b * np.sin(t) * np.cos(phi) + rng.normal(0, 0.7, n)
+    pts = np.stack([np.rint(r / 4) * 4, np.rint(c / 4) * 4], axis=1)
+    pts[:n // 20] += rng.normal(0, 30, (n // 20, 2))
+    got = hostmath.two_step(pts)
+    want = limb_oracle.two_step(pts)
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-9)
+    np.testing.assert_allclose([got[1], got[2], got[3]], [want[1], want[2], want[3]], rtol=1e-8, atol=1e-11)
+    np.testing.assert_array_equal(pts[got[4].astype(bool)], want[4])
+    g = hostmath.warp_geometry(want[2], want[3], 2000, 1800)
+    inv, theta = hostmath.correction_matrix(want[2], want[3])
+    stretch = np.array([[np.cos(want[2]), np.sin(want[2])], [-np.sin(want[2]), np.cos(want[2])]]) @ np.diag([want[3], 1.0]) @ \
+        np.array([[np.cos(want[2]), -np.sin(want[2])], [np.sin(want[2]), np.cos(want[2])]])
+    th = np.arctan(stretch[1, 0] / stretch[0, 0])
+    corr = np.array([[np.cos(th), np.sin(th)], [-np.sin(th), np.cos(th)]]) @ stretch
+    corr[1, 0] = 0
+    corr /= corr[1, 1]
+    np.testing.assert_allclose(inv, np.linalg.inv(corr), rtol=1e-12, atol=1e-15)
+    assert abs(theta - th) < 1e-14 and g['out_h'] == 2000
+    # the line fit on the Householder least squares
+    y = np.arange(60, 1900)
+    trace = 98.0 + 2e-3 * (y - 1000) + 6e-6 * (y - 1000) ** 2 + rng.normal(0, 0.4, y.size)
+    tb = np.rint(trace).astype(np.int32) - 12
+    ts = np.rint(trace + rng.normal(0, 0.3, y.size)).astype(np.int32)
+    full_b, full_s = np.zeros(2000, np.int32), np.zeros(2000, np.int32)
+    full_b[60:1900], full_s[60:1900] = tb, ts
+    p, fit, mask = hostmath.line_fit(full_b, full_s, 2000, 60, 1900)
+    assert mask.sum() > 1500 and abs(np.polyval(p[::-1], 1000.0) - 98.0) < 0.5
+
+
 def test_ellipse_fit_recovers_an_analytic_ellipse():
     t = np.linspace(0, 2 * np.pi, 721)[:-1]
     a, b, phi, cy, cx = 800.0, 640.0, 0.2, 1000.0, 1100.0

@@ -151,6 +151,26 @@ def test_extract_stage_equals_the_kernel_entry_point_and_the_oracle(ops, orc, n,
     np.testing.assert_array_equal(got, want[:, :, ::-1] if flip else want)
 
 
+def test_back_to_back_extract_stages_do_not_share_a_staging_area(ops, orc):
+    """shg_stage_extract returns while its copy kernel has yet to read the pinned staging area: two calls in a row with
+    DIFFERENT fits (nothing in between that waits for the stream) must each sample their own columns."""
+    from solex_ser_recon_en_amd import stages
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 65536, (600, 40, 800)).astype(np.uint16)
+    stack = dev(frames)
+    ih, iw = 800, 40
+    y = np.arange(ih)
+    fits = []
+    for off in (9.3, 21.7, 14.1, 27.9, 11.2, 18.8):
+        curve = off + 0.004 * y
+        fits.append(np.stack([np.floor(curve), curve - np.floor(curve), y.astype(float), curve], axis=1))
+    torch.cuda.synchronize()
+    outs = [stages.extract(stack, f, [3, 0]) for f in fits]              # queued back to back
+    for f, out in zip(fits, outs):
+        want = np.stack(orc.extract_columns(orc.SerReader(frames), f, [3, 0]))
+        np.testing.assert_array_equal(host(out), want)
+
+
 def test_stage_refuses_a_staging_area_the_gpu_cannot_address(ops):
     """The stage composites store host-bound results straight into the staging area and read their plans from it: it has to
     be page-locked, GPU-mapped memory.  Pageable memory is refused with the reason, nothing is launched."""
