@@ -14,6 +14,10 @@ mode"): the logic around the primitive is then pinned byte for byte, the
 primitive itself is not (it is marked UNPINNED in oracle/shg_oracle.py).
 
 Only inputs and expected outputs are stored; no reference source is copied.
+
+SHG_PIN_REAL=1 (tools/pin_cv2.py, for an interpreter that HAS opencv-python and lsq-ellipse): nothing of cv2 / ellipse is stubbed
+or shimmed -- the reference then runs on the real cv2.blur / createCLAHE / circle / filter2D and LsqEllipse (only cv2.imwrite is
+intercepted, to capture the arrays it is handed).  SHG_GOLDEN_OUT / SHG_REFERENCE redirect the output folder / the reference.
 """
 import io
 import os
@@ -25,19 +29,22 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-GOLD = os.path.join(REPO, 'tests', 'golden')
-REF = '/root/reference'
+GOLD = os.environ.get('SHG_GOLDEN_OUT') or os.path.join(REPO, 'tests', 'golden')
+REF = os.environ.get('SHG_REFERENCE') or '/root/reference'
+REAL = os.environ.get('SHG_PIN_REAL') == '1'        # the real opencv-python / lsq-ellipse instead of this repo's restatements
 
-for _n in ('cv2', 'FreeSimpleGUI', 'ellipse', 'skimage.data._fetchers'):
+for _n in ('FreeSimpleGUI', 'skimage.data._fetchers') + (() if REAL else ('cv2', 'ellipse')):
     sys.modules[_n] = types.ModuleType(_n)
-sys.modules['ellipse'].LsqEllipse = object
+if not REAL:
+    sys.modules['ellipse'].LsqEllipse = object
 sys.path.insert(0, REF)
 sys.path.insert(0, REPO)
 sys.path.insert(0, HERE)
 
 import shg_oracle as orc                                  # noqa: E402  (shim primitives only)
 import limb_oracle as limb                                # noqa: E402  (LsqEllipse shim only)
-sys.modules['ellipse'].LsqEllipse = limb.LsqEllipse       # bound by `from ellipse import LsqEllipse`
+if not REAL:
+    sys.modules['ellipse'].LsqEllipse = limb.LsqEllipse   # bound by `from ellipse import LsqEllipse`
 from solex_ser_recon_en_amd import synth                  # noqa: E402  (input generator only)
 
 import cv2                                                # noqa: E402  (the stub)
@@ -65,6 +72,9 @@ def tmp_ser(frames):
 
 
 def install_blur_shim():
+    if REAL:
+        return
+
     def blur(img, ksize):
         kw, kh = ksize
         if img.dtype == np.uint16:
@@ -322,9 +332,10 @@ def g14_pipeline():
         def apply(self, img):
             return orc.clahe(img, self.clip, self.tiles)
 
-    cv2.createCLAHE = lambda clipLimit, tileGridSize: _Clahe(clipLimit, tileGridSize)
-    cv2.circle = lambda img, center, r, color, thickness: orc.filled_circle(img, center[0], center[1], r, color)
-    cv2.IMWRITE_PNG_COMPRESSION = 16
+    if not REAL:
+        cv2.createCLAHE = lambda clipLimit, tileGridSize: _Clahe(clipLimit, tileGridSize)
+        cv2.circle = lambda img, center, r, color, thickness: orc.filled_circle(img, center[0], center[1], r, color)
+        cv2.IMWRITE_PNG_COMPRESSION = 16
 
     def imwrite(path, img, params=None):
         captured[os.path.basename(path)] = np.array(img)
@@ -332,7 +343,8 @@ def g14_pipeline():
     cv2.imwrite = imwrite
     cv2.destroyAllWindows = lambda: None
     from scipy import ndimage
-    cv2.filter2D = lambda src, ddepth, kernel: ndimage.correlate(src, kernel, mode='mirror')      # scenarios F, G (see g15_stubborn)
+    if not REAL:
+        cv2.filter2D = lambda src, ddepth, kernel: ndimage.correlate(src, kernel, mode='mirror')      # scenarios F, G (see g15_stubborn)
 
     base = {'shift': [0], 'flag_display': False, 'ratio_fixe': None, 'slant_fix': None, 'save_fit': False,
             'clahe_only': False, 'protus_only': False, 'disk_display': True, 'delta_radius': 0,
@@ -457,7 +469,8 @@ def g15_stubborn():
     stored in the source type).  Pins the spurious-row logic, the row replacement, fix_edge_effect and the taper;
     cv2's own DFT rounding stays unpinned.  Two inputs: uint16 (float32 filters) and a float64 image."""
     from scipy import ndimage
-    cv2.filter2D = lambda src, ddepth, kernel: ndimage.correlate(src, kernel, mode='mirror')
+    if not REAL:
+        cv2.filter2D = lambda src, ddepth, kernel: ndimage.correlate(src, kernel, mode='mirror')
     out = {}
     rng = np.random.default_rng(15)
     h, w = 300, 330
