@@ -181,6 +181,28 @@ __device__ __forceinline__ uint16_t rescale1(double px, double lo, double span) 
     return (uint16_t)(int)v;
 }
 
+// The six rescale bounds of image_process (solex_util.py:535-546) from the five order statistics the contrast stage left on
+// the device, formed where they are used -- the products kernel no longer waits for the host to do this arithmetic (a stream
+// synchronisation, a wake-up and a launch in the middle of every scan).  s = {frame: two order statistics of the 99.9999th
+// percentile, cl1: two of the 10th percentile, cl1 max}; NumPy's _lerp.  -> false where rescale_brightness's assert fails
+// (the kernel then writes nothing and the host, which sees the same numbers, reports it).
+struct StatsSource { const double* stats5; double g_bright, g_dark; double* mirror5; };
+__device__ __forceinline__ double lerp_np(double a, double b, double gamma) {
+    const double diff = b - a;
+    return gamma >= 0.5 ? b - diff * (1 - gamma) : a + diff * gamma;
+}
+__device__ __forceinline__ bool bounds_from_stats(const StatsSource& src, int disk, Bounds6& b) {
+    const double* s = src.stats5 + 5 * disk;
+    const double bright = lerp_np(s[0], s[1], src.g_bright);                 // basically the same as max
+    const double dark_clahe = lerp_np(s[2], s[3], src.g_dark);
+    const double bright_clahe = (double)(int64_t)s[4];
+    b.lo[0] = bright * 0.25; b.span[0] = bright - b.lo[0];
+    b.lo[1] = 0.0;           b.span[1] = bright * 0.18 - 0.0;
+    b.lo[2] = dark_clahe;    b.span[2] = bright_clahe - dark_clahe;
+    return 65535 >= bright && bright > bright * 0.25 && 65535 >= bright * 0.18 && bright * 0.18 > 0 && 65535 >= bright_clahe &&
+           bright_clahe > dark_clahe;
+}
+
 // rescale1 without the division for all but a handful of pixels.  t = 65535 * (px - lo) is rounded as the reference
 // rounds it; q = t * (1 / span) is within 2^-50 * 65535 < 1e-10 of the correctly rounded t / span, so unless q sits that
 // close to a whole number both truncate to the same integer (and clamp alike beyond 0 / 65535).  The rare pixel near a
@@ -206,7 +228,7 @@ __device__ __forceinline__ uint32_t rescale1_fast(double px, double lo, double s
 __global__ __launch_bounds__(256) void k_products8(shg::PtrBatch frames, int64_t frame_pitch,
                                                    shg::PtrBatch cl1s, int64_t cl1_pitch, int64_t w, BoundsBatch bb,
                                                    shg::PtrBatch hcs, shg::PtrBatch protuss, shg::PtrBatch ccs,
-                                                   int64_t dst_pitch, int64_t x0, int64_t y0, int64_t r) {
+                                                   int64_t dst_pitch, int64_t x0, int64_t y0, int64_t r, StatsSource stats) {
     const int64_t x = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
     const int64_t y = blockIdx.y;
     if (x >= w) return;
@@ -215,7 +237,12 @@ __global__ __launch_bounds__(256) void k_products8(shg::PtrBatch frames, int64_t
     uint16_t* __restrict__ hc = hcs.at<uint16_t>(blockIdx.z);
     uint16_t* __restrict__ protus = protuss.at<uint16_t>(blockIdx.z);
     uint16_t* __restrict__ cc = ccs.at<uint16_t>(blockIdx.z);
-    const Bounds6& b = bb.v[blockIdx.z];
+    Bounds6 b = bb.v[blockIdx.z];
+    if (stats.stats5) {
+        const bool ok = bounds_from_stats(stats, blockIdx.z, b);
+        if (stats.mirror5 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 5) stats.mirror5[5 * blockIdx.z + threadIdx.x] = stats.stats5[5 * blockIdx.z + threadIdx.x];
+        if (!ok) return;
+    }
     const double i0 = 1.0 / b.span[0], i1 = 1.0 / b.span[1], i2 = 1.0 / b.span[2];
     // the disc's span on this row: [x0 - half, x0 + half] (cv2.circle(frame_protus, (x0, y0), r, 80, -1))
     int64_t d_lo = 1, d_hi = 0;
@@ -267,7 +294,7 @@ __global__ __launch_bounds__(256) void k_products8(shg::PtrBatch frames, int64_t
 __global__ __launch_bounds__(256) void k_products(shg::PtrBatch frames, int64_t frame_pitch,
                                                   shg::PtrBatch cl1s, int64_t cl1_pitch, int64_t w, BoundsBatch bb,
                                                   shg::PtrBatch hcs, shg::PtrBatch protuss, shg::PtrBatch ccs,
-                                                  int64_t dst_pitch, int64_t x0, int64_t y0, int64_t r) {
+                                                  int64_t dst_pitch, int64_t x0, int64_t y0, int64_t r, StatsSource stats) {
     const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t y = blockIdx.y;
     if (x >= w) return;
@@ -276,7 +303,12 @@ __global__ __launch_bounds__(256) void k_products(shg::PtrBatch frames, int64_t 
     uint16_t* __restrict__ hc = hcs.at<uint16_t>(blockIdx.z);
     uint16_t* __restrict__ protus = protuss.at<uint16_t>(blockIdx.z);
     uint16_t* __restrict__ cc = ccs.at<uint16_t>(blockIdx.z);
-    const Bounds6& b = bb.v[blockIdx.z];
+    Bounds6 b = bb.v[blockIdx.z];
+    if (stats.stats5) {
+        const bool ok = bounds_from_stats(stats, blockIdx.z, b);
+        if (stats.mirror5 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 5) stats.mirror5[5 * blockIdx.z + threadIdx.x] = stats.stats5[5 * blockIdx.z + threadIdx.x];
+        if (!ok) return;
+    }
     const double f = (double)frame[y * frame_pitch + x];
     const double c = (double)cl1[y * cl1_pitch + x];
     hc[y * dst_pitch + x] = rescale1(f, b.lo[0], b.span[0]);
@@ -299,12 +331,14 @@ extern "C" int shg_contrast_products_u16(const uint16_t* frame, int64_t frame_pi
                                         disc_y0, disc_r, stream);
 }
 
-// k disks of one shape in one launch (per kProductsBatch): host_lo_hi6 is [k][6]
+// k disks of one shape in one launch (per kProductsBatch): host_lo_hi6 is [k][6] -- or NULL, and the bounds are formed on the
+// device from stats5 [k][5] (device; the order statistics shg_contrast_stats_u16 leaves) with the _lerp weights g_bright /
+// g_dark; mirror5 (may be NULL, e.g. GPU-mapped host memory): where the kernel also leaves those statistics for the host.
 int shg::contrast_products_batch(const uint16_t* const* host_frames, int64_t frame_pitch, const uint16_t* const* host_cl1, int64_t cl1_pitch,
                                  int64_t k, int64_t h, int64_t w, const double* host_lo_hi6, uint16_t* const* host_hc,
                                  uint16_t* const* host_protus, uint16_t* const* host_cc, int64_t dst_pitch, int64_t disc_x0, int64_t disc_y0,
-                                 int64_t disc_r, shg_stream_t stream) {
-    SHG_REQUIRE(host_frames && host_cl1 && host_lo_hi6 && host_hc && host_protus && host_cc && k > 0, SHG_E_ARG, "shg_contrast_products_u16: null pointer");
+                                 int64_t disc_r, shg_stream_t stream, const double* stats5, double g_bright, double g_dark, double* mirror5) {
+    SHG_REQUIRE(host_frames && host_cl1 && (host_lo_hi6 || stats5) && host_hc && host_protus && host_cc && k > 0, SHG_E_ARG, "shg_contrast_products_u16: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && frame_pitch >= w && cl1_pitch >= w && dst_pitch >= w, SHG_E_ARG, "shg_contrast_products_u16: bad image size");
     SHG_REQUIRE(h < 65536, SHG_E_UNSUPPORTED, "shg_contrast_products_u16: more than 65535 rows");
     SHG_REQUIRE(disc_r < 32768, SHG_E_UNSUPPORTED, "shg_contrast_products_u16: radius %lld out of range", (long long)disc_r);
@@ -313,7 +347,7 @@ int shg::contrast_products_batch(const uint16_t* const* host_frames, int64_t fra
         SHG_REQUIRE(host_frames[d] && host_cl1[d] && host_hc[d] && host_protus[d] && host_cc[d], SHG_E_ARG, "shg_contrast_products_u16: null image");
         ptrs |= reinterpret_cast<uintptr_t>(host_frames[d]) | reinterpret_cast<uintptr_t>(host_cl1[d]) | reinterpret_cast<uintptr_t>(host_hc[d]) |
                 reinterpret_cast<uintptr_t>(host_protus[d]) | reinterpret_cast<uintptr_t>(host_cc[d]);
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < 3 && host_lo_hi6; ++i) {
             const double lo = host_lo_hi6[6 * d + 2 * i], hi = host_lo_hi6[6 * d + 2 * i + 1];
             SHG_REQUIRE(65535.0 >= hi && hi > lo, SHG_E_ARG, "shg_contrast_products_u16: need sat >= hi > lo (got lo=%g hi=%g)", lo, hi);   // assert, solex_util.py:521
         }
@@ -323,21 +357,21 @@ int shg::contrast_products_batch(const uint16_t* const* host_frames, int64_t fra
     SHG_PROF("products", st);
     for (int64_t i0 = 0; i0 < k; i0 += kProductsBatch) {
         const int m = (int)std::min<int64_t>(kProductsBatch, k - i0);
-        BoundsBatch bb;
-        for (int d = 0; d < m; ++d)
+        BoundsBatch bb = {};
+        for (int d = 0; d < m && host_lo_hi6; ++d)
             for (int i = 0; i < 3; ++i) {
                 bb.v[d].lo[i] = host_lo_hi6[6 * (i0 + d) + 2 * i];
                 bb.v[d].span[i] = host_lo_hi6[6 * (i0 + d) + 2 * i + 1] - bb.v[d].lo[i];
             }
-        for (int d = m; d < kProductsBatch; ++d) bb.v[d] = bb.v[0];
+        const StatsSource src = {stats5 ? stats5 + 5 * i0 : nullptr, g_bright, g_dark, mirror5 ? mirror5 + 5 * i0 : nullptr};
         const shg::PtrBatch f = shg::make_batch(host_frames, (int)i0, m), c = shg::make_batch(host_cl1, (int)i0, m), hc = shg::make_batch(host_hc, (int)i0, m),
                             pr = shg::make_batch(host_protus, (int)i0, m), cc = shg::make_batch(host_cc, (int)i0, m);
         if (vec) {
             dim3 grid((unsigned)((w + 8 * 256 - 1) / (8 * 256)), (unsigned)h, (unsigned)m);
-            k_products8<<<grid, 256, 0, st>>>(f, frame_pitch, c, cl1_pitch, w, bb, hc, pr, cc, dst_pitch, disc_x0, disc_y0, disc_r > 0 ? disc_r : 0);
+            k_products8<<<grid, 256, 0, st>>>(f, frame_pitch, c, cl1_pitch, w, bb, hc, pr, cc, dst_pitch, disc_x0, disc_y0, disc_r > 0 ? disc_r : 0, src);
         } else {
             dim3 grid((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)m);
-            k_products<<<grid, 256, 0, st>>>(f, frame_pitch, c, cl1_pitch, w, bb, hc, pr, cc, dst_pitch, disc_x0, disc_y0, disc_r > 0 ? disc_r : 0);
+            k_products<<<grid, 256, 0, st>>>(f, frame_pitch, c, cl1_pitch, w, bb, hc, pr, cc, dst_pitch, disc_x0, disc_y0, disc_r > 0 ? disc_r : 0, src);
         }
         if (int e = shg::check_launch("k_products")) return e;
     }

@@ -82,7 +82,8 @@ int crop_pad_batch(const uint16_t* const* host_srcs, int64_t k, int64_t h, int64
                    int64_t dst_pitch, int64_t sx0, int64_t dx0, int64_t n, int32_t fill, shg_stream_t stream);
 int contrast_products_batch(const uint16_t* const* host_frames, int64_t frame_pitch, const uint16_t* const* host_cl1, int64_t cl1_pitch,
                             int64_t k, int64_t h, int64_t w, const double* host_lo_hi6, uint16_t* const* host_hc, uint16_t* const* host_protus,
-                            uint16_t* const* host_cc, int64_t dst_pitch, int64_t disc_x0, int64_t disc_y0, int64_t disc_r, shg_stream_t stream);
+                            uint16_t* const* host_cc, int64_t dst_pitch, int64_t disc_x0, int64_t disc_y0, int64_t disc_r, shg_stream_t stream,
+                            const double* stats5 = nullptr, double g_bright = 0.0, double g_dark = 0.0, double* mirror5 = nullptr);
 int warp_rows_batch(const uint16_t* const* host_srcs, int64_t k, int64_t h, int64_t w, int64_t src_pitch, const double* host_h3,
                     uint16_t* const* host_dsts, int64_t out_h, int64_t out_w, int64_t dst_pitch, const uint32_t* const* host_minmax2,
                     shg_stream_t stream);

@@ -554,7 +554,6 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
     SHG_REQUIRE(h_xa && h_xb && h_stats && h_interior && h_factors && h_out5 && h_taps, SHG_E_WORKSPACE, "shg_stage_process_frames: pinned staging area too small");
     Staging stg;
     STAGE_TRY(map_staging(host_pinned, &stg, "shg_stage_process_frames"));
-    out5 = stg.on_device(h_out5);                                                             // order statistics: only the host reads them
 
     // ---- correct_transversalium2 (solex_util.py:383-516) ----
     std::vector<const uint16_t*> cur((size_t)k);
@@ -637,8 +636,12 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
     ranks_cl1[2] = n_px - 1;                                                                  // np.max
     STAGE_TRY(shg::contrast_stats_batch(host_final, k, h, out_w, out_pitch, clip_limit, tiles, host_cl1, out_pitch, ranks_frame, ranks_cl1, out5, cs_ws,
                                         cs_bytes, stream));
+    // The three rescales and the disc follow without a word from the host: the kernel forms the six bounds from the order
+    // statistics where they lie (and leaves a copy where the host reads them).  What the host still owes the reference is
+    // rescale_brightness's assert (solex_util.py:521): checked once the products kernel has run.
+    STAGE_TRY(shg::contrast_products_batch(host_final, out_pitch, host_cl1, out_pitch, k, h, out_w, nullptr, host_hc, host_protus, host_cc, out_pitch,
+                                           disc_x0, disc_y0, disc_r, stream, out5, g_bright, g_dark, stg.on_device(h_out5)));
     STAGE_HIP(hipStreamSynchronize(st), "shg_stage_process_frames");
-    std::vector<double> lo_hi((size_t)k * 6);
     for (int64_t i = 0; i < k; ++i) {
         const double* s = h_out5 + i * 5;
         const double bright = shg_host_lerp(s[0], s[1], g_bright);                            // basically the same as max
@@ -649,9 +652,6 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
             shg::set_error("rescale_brightness: assert sat >= hi > lo (bright %g, clahe %g .. %g)", bright, dark_clahe, bright_clahe);
             return SHG_E_ASSERT;
         }
-        const double v[6] = {bright * 0.25, bright, 0.0, bright * 0.18, dark_clahe, bright_clahe};
-        memcpy(&lo_hi[(size_t)i * 6], v, sizeof(v));
     }
-    return shg::contrast_products_batch(host_final, out_pitch, host_cl1, out_pitch, k, h, out_w, lo_hi.data(), host_hc, host_protus, host_cc, out_pitch,
-                                        disc_x0, disc_y0, disc_r, stream);
+    return 0;
 }

@@ -1,4 +1,6 @@
-python -m pytest tests/test_pipeline_gpu.py -x -q -m gpu -k "two_ranks" 2>&1 | tail -5
-SHG_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 6 --warmup 2 --mode sharded --no-e2e --no-cpu-baseline --no-extra --repeats 2 2>/dev/null | tail -1 | python3 -c "
+python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+for i in 1 2; do python3 bench.py --steps 20 --warmup 5 --no-e2e --no-cpu-baseline --no-extra 2>/dev/null | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('2 ranks on one GPU (gloo), sharded series: ms/step', d['ms_per_step'], d['repeats']['ms_per_step'])"
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print('C2: ms/step %.3f' % d['ms_per_step'], d['repeats']['ms_per_step'], 'passA in-flight %.3f frac %.3f kernels %.3f' % (r['avg_launch_ms'], r['frac'], d['kernel_ms_per_step']))"; done
+python3 tools/host_budget.py 80 4 | head -8
