@@ -223,20 +223,33 @@ __device__ __forceinline__ uint32_t rescale1_fast(double px, double lo, double s
 }
 
 // Eight pixels per lane: 16-byte loads of frame and cl1, 16-byte stores of the three products (rows 16-byte aligned,
-// pitches multiples of 8; a row's last, partial vector goes pixel by pixel).
-// grid (x, rows, disks)
+// pitches multiples of 8; a row's last, partial vector goes pixel by pixel).  A lane takes the same eight columns of PROD_ROWS
+// rows, their loads issued before the first use (what took k_warp_rows from 227 to 144 us over 21 disks did nothing here).
+// grid (x, ceil(rows / PROD_ROWS), disks)
+constexpr int PROD_ROWS = 1;            // (4 rows per lane, loads hoisted: 160 us per 16-disk launch against 140 -- the extra live registers cost more than the requests in flight bring)
 __global__ __launch_bounds__(256) void k_products8(shg::PtrBatch frames, int64_t frame_pitch,
-                                                   shg::PtrBatch cl1s, int64_t cl1_pitch, int64_t w, BoundsBatch bb,
+                                                   shg::PtrBatch cl1s, int64_t cl1_pitch, int64_t h, int64_t w, BoundsBatch bb,
                                                    shg::PtrBatch hcs, shg::PtrBatch protuss, shg::PtrBatch ccs,
                                                    int64_t dst_pitch, int64_t x0, int64_t y0, int64_t r, StatsSource stats) {
     const int64_t x = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
-    const int64_t y = blockIdx.y;
+    const int64_t ya = (int64_t)blockIdx.y * PROD_ROWS;
     if (x >= w) return;
     const uint16_t* __restrict__ frame = frames.at<const uint16_t>(blockIdx.z);
     const uint16_t* __restrict__ cl1 = cl1s.at<const uint16_t>(blockIdx.z);
     uint16_t* __restrict__ hc = hcs.at<uint16_t>(blockIdx.z);
     uint16_t* __restrict__ protus = protuss.at<uint16_t>(blockIdx.z);
     uint16_t* __restrict__ cc = ccs.at<uint16_t>(blockIdx.z);
+    const bool full = x + 8 <= w;
+    // the rows' pixels first (a row beyond the image re-reads the last one), then the bounds: both are waited for once
+    uint4 qf[PROD_ROWS], qc[PROD_ROWS];
+    if (full) {
+#pragma unroll
+        for (int rr = 0; rr < PROD_ROWS; ++rr) {
+            const int64_t y = ya + rr < h ? ya + rr : h - 1;
+            qf[rr] = *reinterpret_cast<const uint4*>(frame + y * frame_pitch + x);
+            qc[rr] = *reinterpret_cast<const uint4*>(cl1 + y * cl1_pitch + x);
+        }
+    }
     Bounds6 b = bb.v[blockIdx.z];
     if (stats.stats5) {
         const bool ok = bounds_from_stats(stats, blockIdx.z, b);
@@ -244,49 +257,52 @@ __global__ __launch_bounds__(256) void k_products8(shg::PtrBatch frames, int64_t
         if (!ok) return;
     }
     const double i0 = 1.0 / b.span[0], i1 = 1.0 / b.span[1], i2 = 1.0 / b.span[2];
-    // the disc's span on this row: [x0 - half, x0 + half] (cv2.circle(frame_protus, (x0, y0), r, 80, -1))
-    int64_t d_lo = 1, d_hi = 0;
-    if (r > 0) {
-        const int64_t ady = y > y0 ? y - y0 : y0 - y;
-        if (ady <= r) {
-            const int64_t half = isqrt64(r * r - ady * ady);
-            d_lo = x0 - half;
-            d_hi = x0 + half;
-        }
-    }
-    if (x + 8 <= w) {
-        const uint4 qf = *reinterpret_cast<const uint4*>(frame + y * frame_pitch + x);
-        const uint4 qc = *reinterpret_cast<const uint4*>(cl1 + y * cl1_pitch + x);
-        const uint32_t fw[4] = {qf.x, qf.y, qf.z, qf.w}, cw[4] = {qc.x, qc.y, qc.z, qc.w};
-        uint32_t oh[4], op[4], oc[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint32_t h2[2], p2[2], c2[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const double f = (double)((fw[j] >> (16 * e)) & 0xffffu);
-                const double c = (double)((cw[j] >> (16 * e)) & 0xffffu);
-                const int64_t xi = x + 2 * j + e;
-                h2[e] = rescale1_fast(f, b.lo[0], b.span[0], i0);
-                p2[e] = (xi >= d_lo && xi <= d_hi) ? 80u : rescale1_fast(f, b.lo[1], b.span[1], i1);
-                c2[e] = rescale1_fast(c, b.lo[2], b.span[2], i2);
+    for (int rr = 0; rr < PROD_ROWS; ++rr) {
+        const int64_t y = ya + rr;
+        if (y >= h) break;
+        // the disc's span on this row: [x0 - half, x0 + half] (cv2.circle(frame_protus, (x0, y0), r, 80, -1))
+        int64_t d_lo = 1, d_hi = 0;
+        if (r > 0) {
+            const int64_t ady = y > y0 ? y - y0 : y0 - y;
+            if (ady <= r) {
+                const int64_t half = isqrt64(r * r - ady * ady);
+                d_lo = x0 - half;
+                d_hi = x0 + half;
             }
-            oh[j] = h2[0] | (h2[1] << 16);
-            op[j] = p2[0] | (p2[1] << 16);
-            oc[j] = c2[0] | (c2[1] << 16);
         }
-        // the products are final: nobody on the GPU reads them again, so they bypass the caches (frame and cl1 stay)
-        typedef unsigned int __attribute__((ext_vector_type(4))) u32x4;
-        __builtin_nontemporal_store((u32x4){oh[0], oh[1], oh[2], oh[3]}, reinterpret_cast<u32x4*>(hc + y * dst_pitch + x));
-        __builtin_nontemporal_store((u32x4){op[0], op[1], op[2], op[3]}, reinterpret_cast<u32x4*>(protus + y * dst_pitch + x));
-        __builtin_nontemporal_store((u32x4){oc[0], oc[1], oc[2], oc[3]}, reinterpret_cast<u32x4*>(cc + y * dst_pitch + x));
-    } else {
-        for (int64_t xi = x; xi < w; ++xi) {
-            const double f = (double)frame[y * frame_pitch + xi];
-            const double c = (double)cl1[y * cl1_pitch + xi];
-            hc[y * dst_pitch + xi] = (uint16_t)rescale1_fast(f, b.lo[0], b.span[0], i0);
-            protus[y * dst_pitch + xi] = (xi >= d_lo && xi <= d_hi) ? (uint16_t)80 : (uint16_t)rescale1_fast(f, b.lo[1], b.span[1], i1);
-            cc[y * dst_pitch + xi] = (uint16_t)rescale1_fast(c, b.lo[2], b.span[2], i2);
+        if (full) {
+            const uint32_t fw[4] = {qf[rr].x, qf[rr].y, qf[rr].z, qf[rr].w}, cw[4] = {qc[rr].x, qc[rr].y, qc[rr].z, qc[rr].w};
+            uint32_t oh[4], op[4], oc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t h2[2], p2[2], c2[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const double f = (double)((fw[j] >> (16 * e)) & 0xffffu);
+                    const double c = (double)((cw[j] >> (16 * e)) & 0xffffu);
+                    const int64_t xi = x + 2 * j + e;
+                    h2[e] = rescale1_fast(f, b.lo[0], b.span[0], i0);
+                    p2[e] = (xi >= d_lo && xi <= d_hi) ? 80u : rescale1_fast(f, b.lo[1], b.span[1], i1);
+                    c2[e] = rescale1_fast(c, b.lo[2], b.span[2], i2);
+                }
+                oh[j] = h2[0] | (h2[1] << 16);
+                op[j] = p2[0] | (p2[1] << 16);
+                oc[j] = c2[0] | (c2[1] << 16);
+            }
+            // the products are final: nobody on the GPU reads them again, so they bypass the caches (frame and cl1 stay)
+            typedef unsigned int __attribute__((ext_vector_type(4))) u32x4;
+            __builtin_nontemporal_store((u32x4){oh[0], oh[1], oh[2], oh[3]}, reinterpret_cast<u32x4*>(hc + y * dst_pitch + x));
+            __builtin_nontemporal_store((u32x4){op[0], op[1], op[2], op[3]}, reinterpret_cast<u32x4*>(protus + y * dst_pitch + x));
+            __builtin_nontemporal_store((u32x4){oc[0], oc[1], oc[2], oc[3]}, reinterpret_cast<u32x4*>(cc + y * dst_pitch + x));
+        } else {
+            for (int64_t xi = x; xi < w; ++xi) {
+                const double f = (double)frame[y * frame_pitch + xi];
+                const double c = (double)cl1[y * cl1_pitch + xi];
+                hc[y * dst_pitch + xi] = (uint16_t)rescale1_fast(f, b.lo[0], b.span[0], i0);
+                protus[y * dst_pitch + xi] = (xi >= d_lo && xi <= d_hi) ? (uint16_t)80 : (uint16_t)rescale1_fast(f, b.lo[1], b.span[1], i1);
+                cc[y * dst_pitch + xi] = (uint16_t)rescale1_fast(c, b.lo[2], b.span[2], i2);
+            }
         }
     }
 }
@@ -367,8 +383,8 @@ int shg::contrast_products_batch(const uint16_t* const* host_frames, int64_t fra
         const shg::PtrBatch f = shg::make_batch(host_frames, (int)i0, m), c = shg::make_batch(host_cl1, (int)i0, m), hc = shg::make_batch(host_hc, (int)i0, m),
                             pr = shg::make_batch(host_protus, (int)i0, m), cc = shg::make_batch(host_cc, (int)i0, m);
         if (vec) {
-            dim3 grid((unsigned)((w + 8 * 256 - 1) / (8 * 256)), (unsigned)h, (unsigned)m);
-            k_products8<<<grid, 256, 0, st>>>(f, frame_pitch, c, cl1_pitch, w, bb, hc, pr, cc, dst_pitch, disc_x0, disc_y0, disc_r > 0 ? disc_r : 0, src);
+            dim3 grid((unsigned)((w + 8 * 256 - 1) / (8 * 256)), (unsigned)((h + PROD_ROWS - 1) / PROD_ROWS), (unsigned)m);
+            k_products8<<<grid, 256, 0, st>>>(f, frame_pitch, c, cl1_pitch, h, w, bb, hc, pr, cc, dst_pitch, disc_x0, disc_y0, disc_r > 0 ? disc_r : 0, src);
         } else {
             dim3 grid((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)m);
             k_products<<<grid, 256, 0, st>>>(f, frame_pitch, c, cl1_pitch, w, bb, hc, pr, cc, dst_pitch, disc_x0, disc_y0, disc_r > 0 ? disc_r : 0, src);

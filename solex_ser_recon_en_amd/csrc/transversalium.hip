@@ -350,36 +350,52 @@ __global__ __launch_bounds__(256) void k_scale_rows(shg::PtrBatch imgs, int64_t 
 }
 
 // The same with eight pixels per lane (rows 16-byte aligned, pitches multiples of 8; a row's last, partial vector goes
-// pixel by pixel).
-// grid (x, rows, disks): blockIdx.z picks source, destination and the disk's h factors
-__global__ __launch_bounds__(256) void k_scale_rows8(shg::PtrBatch imgs, int64_t w, int64_t pitch,
+// pixel by pixel) and SCALE_ROWS rows per lane, their loads issued before the first use (one row per workgroup: one request
+// in flight per wave, 2.8 TB/s).
+// grid (x, ceil(rows / SCALE_ROWS), disks): blockIdx.z picks source, destination and the disk's h factors
+constexpr int SCALE_ROWS = 4;
+__global__ __launch_bounds__(256) void k_scale_rows8(shg::PtrBatch imgs, int64_t h, int64_t w, int64_t pitch,
                                                      const double* __restrict__ c, const double* __restrict__ row_factor,
                                                      shg::PtrBatch dsts, int64_t dst_pitch) {
     const int64_t x = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
-    const int64_t y = blockIdx.y;
+    const int64_t ya = (int64_t)blockIdx.y * SCALE_ROWS;
     if (x >= w) return;
     const uint16_t* __restrict__ img = imgs.at<const uint16_t>(blockIdx.z);
     uint16_t* __restrict__ dst = dsts.at<uint16_t>(blockIdx.z);
-    c += (int64_t)blockIdx.z * gridDim.y;
-    const double cy = c[y], fy = row_factor ? row_factor[y] : 1.0;
+    c += (int64_t)blockIdx.z * h;
     const bool factored = row_factor != nullptr;
-    auto one = [&](uint32_t px) {
-        double v = (double)px;
-        if (factored) v = v * fy;
-        v = v * cy;
-        v = v > 65535.0 ? 65535.0 : v;
-        return (uint32_t)(int)v;
-    };
-    if (x + 8 <= w) {
-        const uint4 q = *reinterpret_cast<const uint4*>(img + y * pitch + x);
-        uint4 o;
-        o.x = one(q.x & 0xffffu) | (one(q.x >> 16) << 16);
-        o.y = one(q.y & 0xffffu) | (one(q.y >> 16) << 16);
-        o.z = one(q.z & 0xffffu) | (one(q.z >> 16) << 16);
-        o.w = one(q.w & 0xffffu) | (one(q.w >> 16) << 16);
-        *reinterpret_cast<uint4*>(dst + y * dst_pitch + x) = o;
-    } else {
-        for (int64_t i = x; i < w; ++i) dst[y * dst_pitch + i] = (uint16_t)one(img[y * pitch + i]);
+    const bool full = x + 8 <= w;
+    uint4 q[SCALE_ROWS];
+    double cy[SCALE_ROWS], fy[SCALE_ROWS];
+#pragma unroll
+    for (int rr = 0; rr < SCALE_ROWS; ++rr) {
+        const int64_t y = ya + rr < h ? ya + rr : h - 1;
+        if (full) q[rr] = *reinterpret_cast<const uint4*>(img + y * pitch + x);
+        cy[rr] = c[y];
+        fy[rr] = factored ? row_factor[y] : 1.0;
+    }
+#pragma unroll
+    for (int rr = 0; rr < SCALE_ROWS; ++rr) {
+        const int64_t y = ya + rr;
+        if (y >= h) break;
+        const double cyr = cy[rr], fyr = fy[rr];
+        auto one = [&](uint32_t px) {
+            double v = (double)px;
+            if (factored) v = v * fyr;
+            v = v * cyr;
+            v = v > 65535.0 ? 65535.0 : v;
+            return (uint32_t)(int)v;
+        };
+        if (full) {
+            uint4 o;
+            o.x = one(q[rr].x & 0xffffu) | (one(q[rr].x >> 16) << 16);
+            o.y = one(q[rr].y & 0xffffu) | (one(q[rr].y >> 16) << 16);
+            o.z = one(q[rr].z & 0xffffu) | (one(q[rr].z >> 16) << 16);
+            o.w = one(q[rr].w & 0xffffu) | (one(q[rr].w >> 16) << 16);
+            *reinterpret_cast<uint4*>(dst + y * dst_pitch + x) = o;
+        } else {
+            for (int64_t i = x; i < w; ++i) dst[y * dst_pitch + i] = (uint16_t)one(img[y * pitch + i]);
+        }
     }
 }
 
@@ -579,8 +595,8 @@ int shg::scale_rows_batch(const uint16_t* const* host_imgs, int64_t k, int64_t h
         const int m = (int)std::min<int64_t>(shg::kMaxBatch, k - i0);
         const shg::PtrBatch src = shg::make_batch(host_imgs, (int)i0, m), dst = shg::make_batch(host_dsts, (int)i0, m);
         if (vec) {                                       // eight pixels per lane: 16-byte loads and stores
-            dim3 grid((unsigned)((w + 8 * 256 - 1) / (8 * 256)), (unsigned)h, (unsigned)m);
-            k_scale_rows8<<<grid, 256, 0, st>>>(src, w, pitch, c + i0 * h, row_factor, dst, dst_pitch);
+            dim3 grid((unsigned)((w + 8 * 256 - 1) / (8 * 256)), (unsigned)((h + SCALE_ROWS - 1) / SCALE_ROWS), (unsigned)m);
+            k_scale_rows8<<<grid, 256, 0, st>>>(src, h, w, pitch, c + i0 * h, row_factor, dst, dst_pitch);
         } else {
             dim3 grid((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)m);
             k_scale_rows<<<grid, 256, 0, st>>>(src, w, pitch, c + i0 * h, row_factor, dst, dst_pitch);

@@ -57,8 +57,9 @@ __global__ __launch_bounds__(256) void k_minmax(const uint16_t* __restrict__ src
 
 constexpr int kWarpBatch = 16;                     // disks per launch (their transform rows travel by value)
 struct WarpRows { double h[kWarpBatch][3]; };
+constexpr int WARP_ROWS = 4;                       // output rows per lane: their 2 x WARP_ROWS loads are issued before the first use
 
-// grid (x, rows, disks): blockIdx.z picks source, destination, transform row and extrema
+// grid (x, ceil(rows / WARP_ROWS), disks): blockIdx.z picks source, destination, transform row and extrema
 __global__ __launch_bounds__(256) void k_warp_rows(shg::PtrBatch srcs, int64_t h, int64_t w, int64_t pitch,
                                                    WarpRows rows, shg::PtrBatch dsts,
                                                    int64_t out_h, int64_t out_w, int64_t dst_pitch,
@@ -67,27 +68,43 @@ __global__ __launch_bounds__(256) void k_warp_rows(shg::PtrBatch srcs, int64_t h
     uint16_t* __restrict__ dst = dsts.at<uint16_t>(blockIdx.z);
     const uint32_t* __restrict__ mm = mms.at<const uint32_t>(blockIdx.z);
     const double h00 = rows.h[blockIdx.z][0], h01 = rows.h[blockIdx.z][1], h02 = rows.h[blockIdx.z][2];
-    const uint32_t mn = mm[0], mx = mm[1];
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t r = blockIdx.y;
+    const int c = (int)(blockIdx.x * 256 + threadIdx.x);
+    const int ra = (int)blockIdx.y * WARP_ROWS;
     if (c >= out_w) return;
     constexpr double inv = 1.0 / 65536.0;
+    // both samples of every row are read unconditionally from clamped positions and replaced by cval afterwards where they
+    // fall outside the image: no branch (and no wait) between the loads
+    double dc[WARP_ROWS];
+    uint32_t v0[WARP_ROWS], v1[WARP_ROWS];
+    bool in0[WARP_ROWS], in1[WARP_ROWS];
+    const double wd = (double)w;
+#pragma unroll
+    for (int rr = 0; rr < WARP_ROWS; ++rr) {
+        const int r = ra + rr;
+        const double x = h00 * (double)c + h01 * (double)r + h02;
+        const double x0 = floor(x), x1 = ceil(x);
+        dc[rr] = x - x0;
+        const bool row_ok = r < h;                                // (r < out_h is checked at the store)
+        in0[rr] = row_ok && x0 >= 0.0 && x0 < wd;
+        in1[rr] = row_ok && x1 >= 0.0 && x1 < wd;
+        const uint16_t* row = src + (int64_t)(row_ok ? r : 0) * pitch;
+        v0[rr] = row[in0[rr] ? (int)x0 : 0];
+        v1[rr] = row[in1[rr] ? (int)x1 : 0];
+    }
+    const uint32_t mn = mm[0], mx = mm[1];
     const double cval = (double)src[0] * inv;                 // cval = image[0, 0]
-    const double x = h00 * (double)c + h01 * (double)r + h02;
-    const double x0 = floor(x), x1 = ceil(x);
-    const double dc = x - x0;
-    const int64_t i0 = (int64_t)x0, i1 = (int64_t)x1;
-    // both samples are read unconditionally from clamped positions and replaced by cval afterwards where they fall
-    // outside the image: no branch (and no wait) between the two loads
-    const uint16_t* row = src + (r < h ? r : 0) * pitch;
-    const bool in0 = r < h && i0 >= 0 && i0 < w, in1 = r < h && i1 >= 0 && i1 < w;
-    const double s0 = (double)row[in0 ? i0 : 0] * inv, s1 = (double)row[in1 ? i1 : 0] * inv;
-    const double left = in0 ? s0 : cval, right = in1 ? s1 : cval;
-    double v = (1.0 - dc) * left + dc * right;
     const double lo = (double)mn * inv, hi = (double)mx * inv;
-    v = v < lo ? lo : v;                                       // np.clip(warped, image.min(), image.max())
-    v = v > hi ? hi : v;
-    dst[r * dst_pitch + c] = (uint16_t)(int)(65536.0 * v);     // (2**16 * img).astype(uint16)
+#pragma unroll
+    for (int rr = 0; rr < WARP_ROWS; ++rr) {
+        const int r = ra + rr;
+        if (r >= out_h) break;
+        const double s0 = (double)v0[rr] * inv, s1 = (double)v1[rr] * inv;
+        const double left = in0[rr] ? s0 : cval, right = in1[rr] ? s1 : cval;
+        double v = (1.0 - dc[rr]) * left + dc[rr] * right;
+        v = v < lo ? lo : v;                                       // np.clip(warped, image.min(), image.max())
+        v = v > hi ? hi : v;
+        dst[(int64_t)r * dst_pitch + c] = (uint16_t)(int)(65536.0 * v);     // (2**16 * img).astype(uint16)
+    }
 }
 
 }  // namespace
@@ -124,7 +141,7 @@ int shg::warp_rows_batch(const uint16_t* const* host_srcs, int64_t k, int64_t h,
     SHG_REQUIRE(host_srcs && host_h3 && host_dsts && host_minmax2 && k > 0, SHG_E_ARG, "shg_warp_rows_minmax_u16: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && out_h > 0 && out_w > 0, SHG_E_ARG, "shg_warp_rows_minmax_u16: empty image");
     SHG_REQUIRE(src_pitch >= w && dst_pitch >= out_w, SHG_E_ARG, "shg_warp_rows_minmax_u16: pitch smaller than width");
-    SHG_REQUIRE(out_h < 65536, SHG_E_UNSUPPORTED, "shg_warp_rows_minmax_u16: more than 65535 rows");
+    SHG_REQUIRE(out_h < 65536 && out_w < (1ll << 30) && w < (1ll << 30) && h < (1ll << 30), SHG_E_UNSUPPORTED, "shg_warp_rows_minmax_u16: image too large");
     for (int64_t i = 0; i < k; ++i) SHG_REQUIRE(host_srcs[i] && host_dsts[i] && host_minmax2[i], SHG_E_ARG, "shg_warp_rows_minmax_u16: null image");
     hipStream_t st = shg::as_stream(stream);
     SHG_PROF("warp", st);
@@ -133,7 +150,7 @@ int shg::warp_rows_batch(const uint16_t* const* host_srcs, int64_t k, int64_t h,
         WarpRows rows = {};
         for (int d = 0; d < m; ++d)
             for (int j = 0; j < 3; ++j) rows.h[d][j] = host_h3[3 * (i0 + d) + j];
-        dim3 grid((unsigned)((out_w + 255) / 256), (unsigned)out_h, (unsigned)m);
+        dim3 grid((unsigned)((out_w + 255) / 256), (unsigned)((out_h + WARP_ROWS - 1) / WARP_ROWS), (unsigned)m);
         k_warp_rows<<<grid, 256, 0, st>>>(shg::make_batch(host_srcs, (int)i0, m), h, w, src_pitch, rows, shg::make_batch(host_dsts, (int)i0, m), out_h,
                                           out_w, dst_pitch, shg::make_batch(host_minmax2, (int)i0, m));
         if (int e = shg::check_launch("k_warp_rows")) return e;
