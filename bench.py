@@ -500,7 +500,7 @@ def sharded_c3_leg(args, world, rank, options, backend):
             with contextlib.redirect_stdout(io.StringIO()):
                 Solex_recon.solex_do_work([(path, options()) for _ in range(k)], True, distribute='frames' if world > 1 else 'none')
             torch.cuda.synchronize()
-        go(1)
+        go(args.c3_scans)                               # (as many as are timed: the allocator then holds a block for every stack in flight)
         if world > 1:
             td.barrier()
         t0 = time.perf_counter()

@@ -99,11 +99,21 @@ class _Decoder:
         _Service.named('shg-decode-%s' % self.device).jobs.put(self._run)
 
     def _run(self):
-        i = 0
         try:
             import torch
             torch.cuda.set_device(self.device)
             bind_thread('io', self.device)                   # the reader threads inherit it: off the scan workers' cores
+            queued = []                                      # files whose chunks are with the upload service, oldest first
+
+            def land(j):
+                rdr = self.out[j][0]
+                try:
+                    if rdr is not None and not hasattr(self.tasks[j][0], 'device_stack'):
+                        rdr.device_stack(device=self.device)            # waits for the last chunk; raises what a chunk raised
+                except BaseException as e:      # noqa: BLE001 -- re-raised when this file's turn comes
+                    self.out[j] = (None, e)
+                self.ready[j].set()
+
             for i, (file, _) in enumerate(self.tasks):
                 self.slots.acquire()
                 if self.stop:
@@ -116,13 +126,17 @@ class _Decoder:
                         if self.frame_range is not None:
                             _check_shardable(rdr)
                             rdr.frame_range = self.frame_range(int(rdr.FrameCount))
-                        rdr.device_stack(device=self.device)
+                        rdr.begin_device_stack(device=self.device)      # queue its chunks behind the previous file's: the link stays busy
                         self.out[i] = (rdr, None)
                     except BaseException as e:      # noqa: BLE001 -- re-raised when this file's turn comes
                         self.out[i] = (None, e)
-                self.ready[i].set()
+                queued.append(i)
+                if len(queued) > 1:
+                    land(queued.pop(0))
+            while queued:
+                land(queued.pop(0))
         except BaseException as e:      # noqa: BLE001 -- whatever stops this thread must not leave a scan waiting for its file
-            for j in range(i, len(self.tasks)):
+            for j in range(len(self.tasks)):
                 if not self.ready[j].is_set():
                     self.out[j] = (None, e)
                     self.ready[j].set()

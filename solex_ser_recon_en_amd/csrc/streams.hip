@@ -21,12 +21,15 @@ std::mutex g_lane_mu;                         // guards g_lanes, and keeps one s
 hipStream_t g_lanes[kMaxDevices] = {};
 struct LaneEvents {
     hipEvent_t ev[kMaxDevices] = {};
+    hipEvent_t before[kMaxDevices] = {};
     ~LaneEvents() {
         for (hipEvent_t e : ev)
             if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : before)
+            if (e) (void)hipEventDestroy(e);
     }
 };
-thread_local LaneEvents t_events;             // one event per (thread, device): a thread has one pass A pending at most
+thread_local LaneEvents t_events;             // a pair of events per (thread, device): a thread has one pass A pending at most
 }  // namespace
 
 hipStream_t frame_pass_lane(int device) {
@@ -41,13 +44,21 @@ int on_frame_pass_lane(hipStream_t st, int (*launch)(hipStream_t, void*), void* 
     hipStream_t lane = frame_pass_lane(device);
     if (!lane || lane == st) return launch(st, arg);
     hipEvent_t& ev = t_events.ev[device];
-    if (!ev) {
-        hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-        if (e != hipSuccess) { ev = nullptr; set_error("frame-pass lane: %s", hipGetErrorString(e)); return (int)e; }
+    hipEvent_t& before = t_events.before[device];
+    if (!ev || !before) {
+        hipError_t e = ev ? hipSuccess : hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e == hipSuccess && !before) e = hipEventCreateWithFlags(&before, hipEventDisableTiming);
+        if (e != hipSuccess) { set_error("frame-pass lane: %s", hipGetErrorString(e)); return (int)e; }
     }
     hipError_t e;
     {
         std::lock_guard<std::mutex> lk(g_lane_mu);
+        // the pass reads what the caller's stream has produced so far (a stack a kernel has only just written, a workspace
+        // the previous scan's last kernel still uses): the lane waits for that point of `st` -- in the scan pool, where a
+        // worker synchronises its stream after every scan, there is nothing to wait for
+        e = hipEventRecord(before, st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(lane, before, 0);
+        if (e != hipSuccess) { set_error("frame-pass lane: %s", hipGetErrorString(e)); return (int)e; }
         if (int le = launch(lane, arg)) return le;
         e = hipEventRecord(ev, lane);
     }

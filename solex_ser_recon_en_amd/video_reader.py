@@ -43,6 +43,105 @@ def _return_pinned_pair(pair):
         _pinned_free.append(pair)
 
 
+class _UploadJob:
+    """The chunks of one file on their way to HBM: done when the last copy has landed (or a chunk failed)."""
+
+    def __init__(self, n_chunks):
+        self.left = n_chunks
+        self.errors = []
+        self.lock = threading.Lock()
+        self.done = threading.Event()
+        if n_chunks <= 0:
+            self.done.set()
+
+    def chunk_done(self, error=None):
+        with self.lock:
+            if error is not None:
+                self.errors.append(error)
+            self.left -= 1
+            if self.left <= 0:
+                self.done.set()
+
+
+class _Uploader:
+    """File -> pinned host -> HBM for one device, as a standing service: `readers` long-lived threads, each with two pinned
+    staging buffers and a copy stream of its own, take (file, offset, bytes, destination) chunks from one queue -- of whichever
+    file is being decoded, and of the next one as soon as its chunks are queued, so the link does not idle across a file
+    boundary (before: eight threads, eight streams and sixteen buffer leases per file, and a drain at every file's end).
+    A chunk is one preadv() of whole frames into pinned memory (no interpreter lock) and one asynchronous 2-D hipMemcpy into
+    the (8 KiB-pitched) frames of the stack."""
+
+    _all = {}
+    _guard = threading.Lock()
+
+    def __init__(self, device, readers, chunk_bytes):
+        import queue
+        self.device, self.chunk_bytes = device, chunk_bytes
+        self.jobs = queue.SimpleQueue()
+        self.threads = [threading.Thread(target=self._reader, args=(i,), name='shg-upload-%s-%d' % (device, i), daemon=True)
+                        for i in range(readers)]
+        for t in self.threads:
+            t.start()
+
+    @classmethod
+    def of(cls, device, readers, chunk_bytes):
+        key = (str(device), int(readers), int(chunk_bytes))
+        with cls._guard:
+            up = cls._all.get(key)
+            if up is None or not all(t.is_alive() for t in up.threads):
+                up = cls._all[key] = cls(device, readers, chunk_bytes)
+            return up
+
+    def _reader(self, tid):
+        from . import _lib
+        from .device import bind_thread
+        torch.cuda.set_device(self.device)
+        bind_thread('io', self.device)                       # off the scan workers' cores (device.cpu_plan)
+        stream = torch.cuda.Stream(device=self.device)
+        bufs = [torch.empty(self.chunk_bytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        pending = [None, None]                               # per buffer: (event of its copy, job) still in flight
+        slot = 0
+
+        def settle(i):
+            if pending[i] is not None:
+                ev, job = pending[i]
+                pending[i] = None
+                try:
+                    ev.synchronize()
+                    job.chunk_done()
+                except BaseException as e:      # noqa: BLE001
+                    job.chunk_done(e)
+
+        while True:
+            if self.jobs.empty():                            # nothing queued: what is in flight lands before we sleep
+                settle(0)
+                settle(1)
+            path, offset, nbytes, dst, dst_pitch, frame_bytes, m, ready, job = self.jobs.get()
+            settle(slot)                                     # this buffer's previous copy has landed
+            try:
+                view = bufs[slot][:nbytes]
+                mv = memoryview(view.numpy())
+                fd = os.open(path, os.O_RDONLY)
+                try:
+                    got = 0
+                    while got < nbytes:
+                        r = os.preadv(fd, [mv[got:]], offset + got)
+                        if r <= 0:
+                            raise Exception('error input file ' + str(path) + ': short read')
+                        got += r
+                finally:
+                    os.close(fd)
+                if ready is not None:
+                    stream.wait_event(ready)                 # the stack may be a recycled block: its allocating stream drains first
+                _lib.check(_lib.lib.shg_upload_frames(dst, dst_pitch, view.data_ptr(), frame_bytes, m, stream.cuda_stream), 'shg_upload_frames')
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                pending[slot] = (ev, job)
+                slot ^= 1
+            except BaseException as e:      # noqa: BLE001 -- reported to whoever waits for the file
+                job.chunk_done(e)
+
+
 class video_reader:
     def __init__(self, file, buffer_size=25, frame_range=None):
         self.file = file
@@ -50,6 +149,7 @@ class video_reader:
         upper = str(file).upper()
         self._mm = None
         self._stack = None
+        self._upload = None
         if upper.endswith('.AVI'):                              # video_reader.py:20-23, 68-80
             from .avi_io import AviIndex
             self.SER_flag, self.AVI_flag = False, True
@@ -121,17 +221,34 @@ class video_reader:
     def device_stack(self, device=None, chunk_bytes=16 << 20, readers=None):
         """Frames [k0:k1) of the file as one tensor [n, Height, Width] in HBM (file layout).
 
-        `readers` threads (default min(8, cpus)) each own two pinned staging buffers and a copy
-        stream: preadv() of whole frames into pinned memory (GIL released), one asynchronous 2-D hipMemcpy
-        into the (8 KiB-pitched) frames of the stack, next chunk.  One thread tops out at the page-cache memcpy rate (~12 GB/s
-        measured); several saturate the PCIe link (tools/sweep_decode.py: 8 readers x 16 MB chunks 50 GB/s; 32 MB 47.7, 64 MB
-        42.6, 4 MB 45.8; 4 readers 33; more than 8 readers no faster)."""
+        The device's upload service (_Uploader: `readers` threads, default min(8, cpus), each with two pinned staging buffers
+        and a copy stream) takes the file in chunks of whole frames: preadv() into pinned memory (no interpreter lock), one
+        asynchronous 2-D hipMemcpy into the (8 KiB-pitched) frames of the stack, next chunk.  One thread tops out at the
+        page-cache memcpy rate (~12 GB/s measured); several saturate the PCIe link (tools/sweep_decode.py: 8 readers x 16 MB
+        chunks 50 GB/s; 32 MB 47.7, 64 MB 42.6, 4 MB 45.8; 4 readers 33; more than 8 readers no faster).
+        begin_device_stack() only queues the chunks: a caller that decodes a series of files queues the next file before it
+        waits for this one, and the link stays busy across the boundary."""
         if self._stack is not None:
             return self._stack
+        self.begin_device_stack(device, chunk_bytes, readers)
+        if self._upload is None:
+            return self._stack
+        stack, job = self._upload
+        job.done.wait()
+        self._upload = None
+        if job.errors:
+            raise job.errors[0]
+        self._stack = stack
+        return stack
+
+    def begin_device_stack(self, device=None, chunk_bytes=16 << 20, readers=None):
+        if self._stack is not None or getattr(self, '_upload', None) is not None:
+            return
+        self._upload = None
         device = device or default_device()
         if self.AVI_flag:
             self._stack = self._avi_device_stack(device, chunk_bytes)
-            return self._stack
+            return
         k0, k1 = self.frame_range
         n = k1 - k0
         h, w, b = int(self.Height), int(self.Width), self.infilebytes
@@ -140,81 +257,27 @@ class video_reader:
         frame_bytes = h * w * b
         if os.path.getsize(self.file) < SER_HEADER_BYTES + int(self.FrameCount) * frame_bytes:
             raise Exception('error input file ' + str(self.file) + ': shorter than its header says')
-        from . import _lib, ops
+        from . import ops
         dt = torch.uint16 if b == 2 else torch.uint8
         stack = ops.padded_stack(n, h, w, dt, device)                  # frame pitch rounded up to 8 KiB
         pitch_bytes = stack.stride(0) * b if n > 1 else frame_bytes
         base_ptr = stack.data_ptr()
         base = SER_HEADER_BYTES + k0 * frame_bytes
         chunk_frames = max(1, chunk_bytes // frame_bytes)
+        chunk_cap = max(chunk_bytes, frame_bytes)
         n_chunks = (n + chunk_frames - 1) // chunk_frames
-        readers = max(1, min(readers or min(8, os.cpu_count() or 1), n_chunks))
-        counter = itertools.count()
-        errors = []
-        streams = [torch.cuda.Stream(device=device) for _ in range(readers)]
+        readers = max(1, readers or min(8, os.cpu_count() or 1))
+        up = _Uploader.of(device, readers, chunk_cap)
         # the stack may be a block the caching allocator recycled from the previous file: kernels queued on the allocating
         # stream may still read it, so no upload starts before that stream has drained up to here
-        alloc_stream = torch.cuda.current_stream(device)
-        for st in streams:
-            st.wait_stream(alloc_stream)
-
-        def work(tid):
-            try:
-                torch.cuda.set_device(device)
-                bufs = _lease_pinned_pair(chunk_frames * frame_bytes)
-                events = [None, None]
-                fd = os.open(self.file, os.O_RDONLY)
-                try:
-                    slot = 0
-                    while True:
-                        c = next(counter)
-                        if c >= n_chunks:
-                            break
-                        f0 = c * chunk_frames
-                        m = min(chunk_frames, n - f0)
-                        nbytes = m * frame_bytes
-                        if events[slot] is not None:
-                            events[slot].synchronize()                  # this buffer's previous copy has landed
-                        view = bufs[slot][:nbytes]
-                        mv = memoryview(view.numpy())
-                        got = 0
-                        while got < nbytes:
-                            r = os.preadv(fd, [mv[got:]], base + f0 * frame_bytes + got)
-                            if r <= 0:
-                                raise Exception('error input file ' + str(self.file) + ': short read')
-                            got += r
-                        # dense frames in pinned memory -> pitched frames in HBM: one asynchronous 2-D hipMemcpy
-                        _lib.check(_lib.lib.shg_upload_frames(base_ptr + f0 * pitch_bytes, pitch_bytes, view.data_ptr(), frame_bytes, m,
-                                                              streams[tid].cuda_stream), 'shg_upload_frames')
-                        ev = torch.cuda.Event()
-                        ev.record(streams[tid])
-                        events[slot] = ev
-                        slot ^= 1
-                    for ev in events:
-                        if ev is not None:
-                            ev.synchronize()
-                finally:
-                    os.close(fd)
-                    for ev in events:
-                        if ev is not None:
-                            ev.synchronize()
-                    _return_pinned_pair(bufs)
-            except BaseException as e:      # noqa: BLE001 -- re-raised on the caller's thread
-                errors.append(e)
-
-        threads = [threading.Thread(target=work, args=(i,), name='shg-decode-%d' % i) for i in range(readers)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        if errors:
-            raise errors[0]
-        cur = torch.cuda.current_stream(device)
-        for st in streams:
-            cur.wait_stream(st)
-        self._stack = stack
-        return stack
-
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(device))
+        job = _UploadJob(n_chunks)
+        for c in range(n_chunks):
+            f0 = c * chunk_frames
+            m = min(chunk_frames, n - f0)
+            up.jobs.put((self.file, base + f0 * frame_bytes, m * frame_bytes, base_ptr + f0 * pitch_bytes, pitch_bytes, frame_bytes, m, ready, job))
+        self._upload = (stack, job)
 
     def _avi_device_stack(self, device, chunk_bytes):
         """Frames [k0:k1) of an uncompressed AVI as the uint8 [n, Height, Width] stack: chunk payloads go to HBM as

@@ -151,6 +151,25 @@ def test_extract_stage_equals_the_kernel_entry_point_and_the_oracle(ops, orc, n,
     np.testing.assert_array_equal(got, want[:, :, ::-1] if flip else want)
 
 
+def test_pass_a_in_the_lane_waits_for_the_stack_its_caller_is_still_writing(ops):
+    """With a frame-pass lane set, pass A runs on another stream than its caller's: it must still see a stack that the caller's
+    stream has only queued the writing of (no synchronisation in between)."""
+    from solex_ser_recon_en_amd import Solex_recon
+    Solex_recon._ensure_lane(torch.device('cuda', torch.cuda.current_device()))
+    for trial in range(4):
+        base = torch.randint(0, 60000, (1500, 64, 512), dtype=torch.int32, device='cuda')
+        torch.cuda.synchronize()
+        work = base
+        for _ in range(6):                                                # a queue of elementwise kernels the stack depends on
+            work = (work * 3 + 7) % 60001
+        stack = work.to(torch.int16).view(torch.uint16)
+        mean, mx = ops.accumulate_mean_max(stack)                         # queued right behind them
+        torch.cuda.synchronize()
+        mean2, mx2 = ops.accumulate_mean_max(stack)
+        torch.cuda.synchronize()
+        assert torch.equal(mean.view(torch.int16), mean2.view(torch.int16)) and torch.equal(mx.view(torch.int16), mx2.view(torch.int16))
+
+
 def test_back_to_back_extract_stages_do_not_share_a_staging_area(ops, orc):
     """shg_stage_extract returns while its copy kernel has yet to read the pinned staging area: two calls in a row with
     DIFFERENT fits (nothing in between that waits for the stream) must each sample their own columns."""
