@@ -227,8 +227,9 @@ extern "C" int shg_host_detect_bord(const double* host_row_means, int64_t n, int
     SHG_HOST_TIME("host detect_bord");
     SHG_REQUIRE(host_row_means && lb && ub && n > 0, SHG_E_ARG, "shg_host_detect_bord: bad argument");
     std::vector<double> s(host_row_means, host_row_means + n);
-    std::sort(s.begin(), s.end());
-    const double med = (n & 1) ? s[n / 2] : (s[n / 2 - 1] + s[n / 2]) / 2.0;      // np.median
+    std::nth_element(s.begin(), s.begin() + n / 2, s.end());                        // (a full sort of 2000 values took 47 us per scan)
+    const double upper = s[n / 2];
+    const double med = (n & 1) ? upper : (*std::max_element(s.begin(), s.begin() + n / 2) + upper) / 2.0;      // np.median
     const double thr = med / 5;
     int64_t first = 0, last = n - 1;                    // np.argmax of an all-False mask is 0: lb = 0, ub = n - 1
     for (int64_t i = 0; i < n; ++i) if (host_row_means[i] > thr) { first = i; break; }
