@@ -576,6 +576,17 @@ int shg_host_set_savgol_taps(shg_savgol_taps_fn fn);
 typedef struct shg_pool shg_pool;
 int shg_pool_create(const shg_stream_t* streams, int n_workers, const int32_t* host_cpus, int n_cpus, shg_pool** out);
 int shg_pool_submit(shg_pool* pool, const shg_scan_request* req, shg_scan_result* res, int64_t* ticket);
+/* The same, naming the stream the stack was produced on (0 = the null stream).  With a frame-pass lane set, the scan's pass A
+ * (solex_util.py:174-188) is launched on the lane right here, behind what that stream holds now, and the worker that later runs
+ * the scan finds it there: the lane does not idle while every worker is still in the chain of an earlier scan. */
+int shg_pool_submit_after(shg_pool* pool, const shg_scan_request* req, shg_scan_result* res, shg_stream_t after, int64_t* ticket);
+/* The pieces shg_pool_submit_after is made of (a caller with a queue of its own): start pass A of a request / of a stack ahead
+ * of shg_scan_file / shg_accumulate_mean_max with the same arguments (*launched = 0: no lane, nothing done), and wait for and
+ * drop a pass that nobody came to use. */
+int shg_scan_prelaunch(const shg_scan_request* req, shg_stream_t after, int* launched);
+int shg_pass_a_prelaunch(const void* stack, int64_t n_frames, int64_t height, int64_t width, int bytes_per_px,
+                         int64_t frame_stride_px, void* workspace, size_t workspace_bytes, shg_stream_t after, int* launched);
+int shg_pass_a_forget(const void* workspace);
 int shg_pool_poll(shg_pool* pool, int64_t ticket);
 int shg_pool_wait(shg_pool* pool, int64_t ticket, int* scan_status, char* error_buf, size_t error_cap);
 int shg_pool_destroy(shg_pool* pool);

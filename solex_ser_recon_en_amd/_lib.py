@@ -161,6 +161,10 @@ SIGNATURES = {
     'shg_host_set_savgol_taps': (c_int, [P]),
     'shg_pool_create': (c_int, [P, c_int, P, c_int, ctypes.POINTER(c_void_p)]),
     'shg_pool_submit': (c_int, [P, ctypes.POINTER(ScanRequest), ctypes.POINTER(ScanResult), ctypes.POINTER(c_int64)]),
+    'shg_pool_submit_after': (c_int, [P, ctypes.POINTER(ScanRequest), ctypes.POINTER(ScanResult), P, ctypes.POINTER(c_int64)]),
+    'shg_scan_prelaunch': (c_int, [ctypes.POINTER(ScanRequest), P, ctypes.POINTER(c_int)]),
+    'shg_pass_a_prelaunch': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int64, P, c_size_t, P, ctypes.POINTER(c_int)]),
+    'shg_pass_a_forget': (c_int, [P]),
     'shg_pool_poll': (c_int, [P, c_int64]),
     'shg_pool_wait': (c_int, [P, c_int64, ctypes.POINTER(c_int), ctypes.c_char_p, c_size_t]),
     'shg_pool_destroy': (c_int, [P]),

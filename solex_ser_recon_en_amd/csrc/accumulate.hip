@@ -10,6 +10,8 @@
 // independent, so any split / any rank sharding gives identical bits).
 #include <math.h>
 #include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
 #include "shg_common.h"
 
 namespace {
@@ -443,6 +445,81 @@ int launch_pass_a(hipStream_t st, void* arg) {
 }
 }  // namespace
 
+// A pass launched ahead of its scan (shg_pass_a_prelaunch), keyed by the workspace its partials went to.
+namespace {
+struct Ahead {
+    PassA a;
+    hipEvent_t done;
+};
+std::mutex g_ahead_mu;
+std::unordered_map<const void*, Ahead> g_ahead;
+
+bool same_pass(const PassA& x, const PassA& y) {
+    return x.stack == y.stack && x.n_frames == y.n_frames && x.height == y.height && x.width == y.width && x.bytes_per_px == y.bytes_per_px &&
+           x.frame_stride_px == y.frame_stride_px && x.workspace == y.workspace;
+}
+
+// -> true when a pass into `workspace` had been launched ahead; it has finished when this returns (whatever it was a pass over:
+// a pass that is not ours still writes to our workspace, so it is waited for all the same) and *same says whether it is the
+// pass `want` asks for, with its plan and partials copied into `want`.
+bool take_ahead(PassA* want, bool* same, int* status) {
+    Ahead got;
+    {
+        std::lock_guard<std::mutex> lk(g_ahead_mu);
+        auto it = g_ahead.find(want->workspace);
+        if (it == g_ahead.end()) return false;
+        got = it->second;
+        g_ahead.erase(it);
+    }
+    hipError_t e;
+    {
+        SHG_HOST_TIME("lane wait (queue + pass A)");
+        e = hipEventSynchronize(got.done);
+    }
+    (void)hipEventDestroy(got.done);
+    *status = 0;
+    if (e != hipSuccess) { shg::set_error("frame-pass lane: %s", hipGetErrorString(e)); *status = (int)e; }
+    *same = same_pass(got.a, *want) && got.a.workspace_bytes <= want->workspace_bytes;
+    if (*same) { want->p = got.a.p; want->psum = got.a.psum; want->pmax = got.a.pmax; }
+    return true;
+}
+}  // namespace
+
+// Start pass A of a scan that has not begun yet (the scan pool does, for the scans in its queue: pool.hip).  The lane then
+// never idles between the scans' passes while a worker is still busy with the chain of an earlier scan -- the pass is the one
+// kernel of a scan that is bound by the device, and it is what the rate of a batch is bound by.  shg_accumulate_mean_max with the
+// same arguments later finds the pass here, waits for it and only finalises.  Needs a lane (-> *launched = 0 without one).
+extern "C" int shg_pass_a_prelaunch(const void* stack, int64_t n_frames, int64_t height, int64_t width, int bytes_per_px,
+                                    int64_t frame_stride_px, void* workspace, size_t workspace_bytes, shg_stream_t after, int* launched) {
+    SHG_REQUIRE(launched, SHG_E_ARG, "shg_pass_a_prelaunch: null pointer");
+    *launched = 0;
+    PassA a{stack, n_frames, height, width, bytes_per_px, frame_stride_px, workspace, workspace_bytes, Plan{}, nullptr, nullptr};
+    {   // a pass somebody started into this workspace and never used: let it finish before this one writes there
+        bool same = false;
+        int status = 0;
+        PassA old = a;
+        if (take_ahead(&old, &same, &status) && status) return status;
+    }
+    hipEvent_t done = nullptr;
+    const int r = shg::prelaunch_on_lane(shg::as_stream(after), launch_pass_a, &a, &done);
+    if (r == 1) return 0;                                      // no lane: the scan launches its pass itself
+    if (r != 0) return r;
+    std::lock_guard<std::mutex> lk(g_ahead_mu);
+    g_ahead[workspace] = Ahead{a, done};
+    *launched = 1;
+    return 0;
+}
+
+// Wait for and drop a pass launched ahead into `workspace` that no scan came to use (a scan that failed before its first stage).
+extern "C" int shg_pass_a_forget(const void* workspace) {
+    PassA a{};
+    a.workspace = const_cast<void*>(workspace);
+    bool same = false;
+    int status = 0;
+    (void)take_ahead(&a, &same, &status);
+    return status;
+}
+
 // Pass A goes through the frame-pass lane when the process has one (streams.hip): the passes of all scans in flight run
 // one after the other there instead of halving each other's bandwidth.  Only the pass itself: its partials live in the
 // caller's workspace, which no other stream touches, while mean_out / max_out may be memory the caller's stream has
@@ -452,7 +529,12 @@ extern "C" int shg_accumulate_mean_max(const void* stack, int64_t n_frames, int6
                                        size_t workspace_bytes, shg_stream_t stream) {
     SHG_REQUIRE(mean_out && max_out, SHG_E_ARG, "shg_accumulate_mean_max: null pointer");
     PassA a{stack, n_frames, height, width, bytes_per_px, frame_stride_px, workspace, workspace_bytes, Plan{}, nullptr, nullptr};
-    if (int e = shg::on_frame_pass_lane(shg::as_stream(stream), launch_pass_a, &a)) return e;
+    bool same = false;
+    int status = 0;
+    const bool ahead = take_ahead(&a, &same, &status);
+    if (ahead && status) return status;
+    if (!(ahead && same))
+        if (int e = shg::on_frame_pass_lane(shg::as_stream(stream), launch_pass_a, &a)) return e;
     return launch_finalize(FromPartials{a.psum, a.pmax, a.p.nsplit, a.p.npix}, n_frames, height, width, bytes_per_px, mean_out, max_out, shg::as_stream(stream));
 }
 

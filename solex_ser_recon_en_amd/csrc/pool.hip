@@ -7,6 +7,7 @@
 // (measured before: four interpreter threads making the same calls spent 0.4 ms per scan waiting for each other's lock,
 // tools/host_budget.py).  The pool owns no memory: every buffer travels in the request.
 #include <sched.h>
+#include <stdlib.h>
 #include <string.h>
 #include <condition_variable>
 #include <deque>
@@ -29,6 +30,7 @@ struct shg_pool {
         shg_scan_result* rs;
         int status = 0;
         bool done = false;
+        bool ahead = false;                                   // its pass A is on the lane already
         std::string error;
     };
     std::deque<int64_t> queue;
@@ -62,6 +64,7 @@ void pool_worker(shg_pool* p, int k) {
         int status = shg_scan_file(job.rq, job.rs, reinterpret_cast<shg_stream_t>(st));
         std::string err;
         if (status != 0) err = shg_last_error_string();
+        if (job.ahead) (void)shg_pass_a_forget(job.rq->workspace);   // a scan that failed before it got to its pass
         // the caller may look at every output as soon as the ticket is done: the scan's last kernels have run by then
         hipError_t e = hipStreamSynchronize(st);
         if (status == 0 && e != hipSuccess) { status = (int)e; err = std::string("scan pool: ") + hipGetErrorString(e); }
@@ -103,7 +106,18 @@ extern "C" int shg_pool_create(const shg_stream_t* streams, int n_workers, const
 }
 
 extern "C" int shg_pool_submit(shg_pool* p, const shg_scan_request* rq, shg_scan_result* rs, int64_t* ticket) {
+    return shg_pool_submit_after(p, rq, rs, nullptr, ticket);
+}
+
+// The scan's pass A starts now, in submission order on the lane, behind what `after` (the stream the stack was produced on; 0 =
+// the null stream) holds at this moment: the workers are usually all busy with the chains of earlier scans, and a lane that
+// waited for one of them to get to this scan would idle.  SHG_PASS_AHEAD=0 turns that off.
+extern "C" int shg_pool_submit_after(shg_pool* p, const shg_scan_request* rq, shg_scan_result* rs, shg_stream_t after, int64_t* ticket) {
     SHG_REQUIRE(p && rq && rs && ticket, SHG_E_ARG, "shg_pool_submit: null pointer");
+    static const bool pass_ahead = [] { const char* v = getenv("SHG_PASS_AHEAD"); return !(v && v[0] == '0'); }();
+    int ahead = 0;
+    if (pass_ahead)
+        if (int e = shg_scan_prelaunch(rq, after, &ahead)) return e;
     {
         std::lock_guard<std::mutex> lk(p->mu);
         SHG_REQUIRE(!p->stop, SHG_E_RUNTIME, "shg_pool_submit: the pool is shutting down");
@@ -111,6 +125,7 @@ extern "C" int shg_pool_submit(shg_pool* p, const shg_scan_request* rq, shg_scan
         shg_pool::Job j;
         j.rq = rq;
         j.rs = rs;
+        j.ahead = ahead != 0;
         p->jobs[*ticket] = j;
         p->queue.push_back(*ticket);
     }

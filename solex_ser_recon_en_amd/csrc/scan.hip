@@ -156,6 +156,23 @@ extern "C" size_t shg_scan_host_bytes(const shg_scan_request* rq) {
     return r.mean_pin + r.extract_pin + r.limb_pin + r.process_pin + kAlign;
 }
 
+// Pass A of a scan that will run later (the scan pool calls this when the scan is submitted): launched on the device's frame-pass
+// lane now, found there by the scan's first stage.  Nothing happens -- and nothing is wrong -- without a lane, for a resumed scan,
+// or for a request shg_scan_file is going to refuse.
+extern "C" int shg_scan_prelaunch(const shg_scan_request* rq, shg_stream_t after, int* launched) {
+    SHG_REQUIRE(rq && launched, SHG_E_ARG, "shg_scan_prelaunch: null pointer");
+    *launched = 0;
+    if (rq->struct_bytes != sizeof(shg_scan_request) || rq->start_phase != 0 || !rq->stack || !rq->workspace || rq->n_frames <= 0 ||
+        rq->height <= 0 || rq->width <= 0 || rq->n_shifts <= 0 || (rq->bytes_per_px != 1 && rq->bytes_per_px != 2))
+        return 0;
+    const Regions rg = regions(rq);
+    const size_t acc = shg_accumulate_workspace_bytes(rq->n_frames, rq->height, rq->width, rq->bytes_per_px);
+    if (rq->workspace_bytes < rg.mean_ws || acc == 0 || acc > rg.mean_ws) return 0;
+    // the partials are the first thing shg_stage_mean_fit takes from its workspace, which is the first region of the scan's
+    return shg_pass_a_prelaunch(rq->stack, rq->n_frames, rq->height, rq->width, rq->bytes_per_px, rq->frame_stride_px, rq->workspace, acc, after,
+                                launched);
+}
+
 extern "C" int shg_scan_file(const shg_scan_request* rq, shg_scan_result* rs, shg_stream_t stream) {
     SHG_HOST_TIME("scan_file");
     SHG_REQUIRE(rq && rs, SHG_E_ARG, "shg_scan_file: null pointer");

@@ -74,6 +74,40 @@ int on_frame_pass_lane(hipStream_t st, int (*launch)(hipStream_t, void*), void* 
     if (e != hipSuccess) { set_error("frame-pass lane: %s", hipGetErrorString(e)); return (int)e; }
     return 0;
 }
+
+// Launch on the lane without anybody waiting for it here: the pass of a scan that is still queued (shg_pass_a_prelaunch).  The lane
+// first waits for what `after` has queued so far (the stack's producer, if it is still running); *done gets an event recorded
+// behind the launch (the caller owns it).  -> 1 when there is no lane (nothing launched), 0 launched, else an error.
+int prelaunch_on_lane(hipStream_t after, int (*launch)(hipStream_t, void*), void* arg, hipEvent_t* done) {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return 1;
+    hipStream_t lane = frame_pass_lane(device);
+    if (!lane) return 1;
+    hipEvent_t before = nullptr, ev = nullptr;
+    hipError_t e = hipEventCreateWithFlags(&before, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_lane_mu);
+        e = hipEventRecord(before, after);
+        if (e == hipSuccess) e = hipStreamWaitEvent(lane, before, 0);
+        if (e == hipSuccess) {
+            if (int le = launch(lane, arg)) {
+                (void)hipEventDestroy(before);
+                (void)hipEventDestroy(ev);
+                return le;
+            }
+            e = hipEventRecord(ev, lane);
+        }
+    }
+    if (before) (void)hipEventDestroy(before);               // (destroying a recorded event is fine: the wait has been queued)
+    if (e != hipSuccess) {
+        if (ev) (void)hipEventDestroy(ev);
+        set_error("frame-pass lane: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    *done = ev;
+    return 0;
+}
 }  // namespace shg
 
 extern "C" int shg_device_cu_count(int* out) {

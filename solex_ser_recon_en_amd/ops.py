@@ -4,6 +4,8 @@ PyTorch is plumbing here: it owns device memory and the current HIP stream; ever
 computation below happens in libshg_hip.so.  All tensors must live on the GPU; a
 CPU tensor raises (there is no CPU path).
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -104,6 +106,19 @@ def accumulate_mean_max(stack, workspace=None):
     _lib.check(lib.shg_accumulate_mean_max(stack.data_ptr(), n, h, w, bpp, frame_stride(stack), mean.data_ptr(), mout.data_ptr(),
                                            workspace.data_ptr(), workspace.numel(), _stream()), 'shg_accumulate_mean_max')
     return mean, mout
+
+
+def pass_a_prelaunch(stack, workspace):
+    """Start pass A of `stack` on the device's frame-pass lane now, behind what the current stream holds (shg_pass_a_prelaunch);
+    accumulate_mean_max(stack, workspace) later finds it there.  -> False when the device has no lane (nothing was launched)."""
+    n, h, w, bpp = stack_geometry(stack)
+    need = lib.shg_accumulate_workspace_bytes(n, h, w, bpp)
+    if workspace.numel() < need:
+        raise ValueError('pass_a_prelaunch: workspace of %d bytes, %d needed' % (workspace.numel(), need))
+    launched = ctypes.c_int()
+    _lib.check(lib.shg_pass_a_prelaunch(stack.data_ptr(), n, h, w, bpp, frame_stride(stack), workspace.data_ptr(), workspace.numel(),
+                                        _stream(), ctypes.byref(launched)), 'shg_pass_a_prelaunch')
+    return bool(launched.value)
 
 
 def finalize_mean_max(total, mx, n_total, height, width, bpp):

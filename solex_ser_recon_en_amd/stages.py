@@ -471,7 +471,10 @@ class ScanCall:
     def submit(self, pool):
         self.pool = pool
         ticket = ctypes.c_int64()
-        _lib.check(lib.shg_pool_submit(pool, ctypes.byref(self.rq), ctypes.byref(self.rs), ctypes.byref(ticket)), 'shg_pool_submit')
+        # the stack is whatever this thread's current stream has produced by now: the scan's pass A goes onto the lane behind that
+        after = torch.cuda.current_stream(self.stack.device).cuda_stream
+        _lib.check(lib.shg_pool_submit_after(pool, ctypes.byref(self.rq), ctypes.byref(self.rs), after, ctypes.byref(ticket)),
+                   'shg_pool_submit')
         self.ticket = ticket.value
         return self
 

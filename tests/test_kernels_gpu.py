@@ -170,6 +170,44 @@ def test_pass_a_in_the_lane_waits_for_the_stack_its_caller_is_still_writing(ops)
         assert torch.equal(mean.view(torch.int16), mean2.view(torch.int16)) and torch.equal(mx.view(torch.int16), mx2.view(torch.int16))
 
 
+def test_pass_a_launched_ahead_is_found_by_its_scan_and_by_nobody_else(ops):
+    """shg_pass_a_prelaunch starts the pass on the lane; accumulate_mean_max with the same stack and workspace only finalises
+    it, one with another stack waits for the stray pass and runs its own; shg_pass_a_forget drops a pass nobody came for."""
+    from solex_ser_recon_en_amd import Solex_recon, _lib
+    Solex_recon._ensure_lane(torch.device('cuda', torch.cuda.current_device()))
+    g = torch.Generator(device='cuda').manual_seed(11)
+    a = torch.randint(0, 65536, (700, 48, 640), dtype=torch.int32, device='cuda', generator=g).to(torch.uint16)
+    b = torch.randint(0, 65536, (700, 48, 640), dtype=torch.int32, device='cuda', generator=g).to(torch.uint16)
+    want_a, want_b = ops.accumulate_mean_max(a), ops.accumulate_mean_max(b)
+    ws = torch.empty(_lib.lib.shg_accumulate_workspace_bytes(700, 48, 640, 2), dtype=torch.uint8, device='cuda')
+    torch.cuda.synchronize()
+
+    def same(x, y):
+        return all(torch.equal(p.view(torch.int16), q.view(torch.int16)) for p, q in zip(x, y))
+    _lib.profile_enable(True, only=['accumulate'])
+    _lib.profile_reset()
+    try:
+        assert ops.pass_a_prelaunch(a, ws)
+        got = ops.accumulate_mean_max(a, ws)                              # the pass launched ahead: no second launch
+        torch.cuda.synchronize()
+        assert same(got, want_a)
+        assert ops.pass_a_prelaunch(a, ws)
+        got = ops.accumulate_mean_max(b, ws)                              # another stack: waits for the stray pass, runs its own
+        torch.cuda.synchronize()
+        assert same(got, want_b)
+        launches = _lib.profile_get('accumulate')[1]
+    finally:
+        _lib.profile_enable(False)
+    assert launches == 3
+    assert ops.pass_a_prelaunch(b, ws)
+    ws.zero_()                                                            # (queued behind nothing: the pass may still be writing)
+    assert _lib.lib.shg_pass_a_forget(ws.data_ptr()) == 0
+    torch.cuda.synchronize()
+    got = ops.accumulate_mean_max(a, ws)
+    torch.cuda.synchronize()
+    assert same(got, want_a)
+
+
 def test_back_to_back_extract_stages_do_not_share_a_staging_area(ops, orc):
     """shg_stage_extract returns while its copy kernel has yet to read the pinned staging area: two calls in a row with
     DIFFERENT fits (nothing in between that waits for the stream) must each sample their own columns."""

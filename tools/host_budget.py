@@ -31,12 +31,35 @@ def batch(n, workers):
     torch.cuda.synchronize()
 
 
+# the ONE interpreter thread that feeds the native pool: what it spends per scan preparing, submitting and finishing (waiting apart)
+main_thread = {}
+
+
+def clocked(cls, name, tag):
+    inner = getattr(cls, name)
+
+    def outer(*a, **kw):
+        t = time.perf_counter()
+        try:
+            return inner(*a, **kw)
+        finally:
+            main_thread[tag] = main_thread.get(tag, 0.0) + time.perf_counter() - t
+    setattr(cls, name, outer)
+
+
+from solex_ser_recon_en_amd import stages as _stages  # noqa: E402
+clocked(Solex_recon._OneCall, '__init__', 'prepare (_OneCall.__init__)')
+clocked(Solex_recon._OneCall, 'submit', 'submit')
+clocked(Solex_recon._OneCall, 'finish', 'finish, waiting included')
+clocked(_stages.ScanCall, 'wait', 'waiting for the pool (ScanCall.wait)')
+
 import gc  # noqa: E402
 for workers in ([int(sys.argv[2])] if len(sys.argv) > 2 else [1, 4]):
     batch(8, workers)
     gc.collect()
     gc.freeze()
     _lib.lib.shg_host_timing_enable(1)
+    main_thread.clear()
     t0 = time.perf_counter()
     batch(steps, workers)
     wall = time.perf_counter() - t0
@@ -50,5 +73,12 @@ for workers in ([int(sys.argv[2])] if len(sys.argv) > 2 else [1, 4]):
         rows.append((tag, float(sec), int(calls)))
     for tag, sec, calls in sorted(rows, key=lambda r: -r[1]):
         print('  %-58s %8.1f us per scan  (%5.2f calls, %7.1f us each)' % (tag, sec / steps * 1e6, calls / steps, sec / calls * 1e6))
+    if main_thread:
+        print('  -- the feeding thread, per scan:')
+        for tag, sec in sorted(main_thread.items(), key=lambda kv: -kv[1]):
+            print('     %-55s %8.1f us' % (tag, sec / steps * 1e6))
+        busy = sum(v for k, v in main_thread.items() if 'wait' not in k) + main_thread.get('finish, waiting included', 0.0) \
+            - main_thread.get('waiting for the pool (ScanCall.wait)', 0.0)
+        print('     %-55s %8.1f us of %.1f us per scan' % ('busy (everything but waiting)', busy / steps * 1e6, wall / steps * 1e6))
     scan = dict((t, s) for t, s, _ in rows).get('scan_file', 0.0)
     print('  outside shg_scan_file (interpreter, allocation, waiting for a task): %.1f us per scan' % ((wall * workers - scan) / steps * 1e6))
