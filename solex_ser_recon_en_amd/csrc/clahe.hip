@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void k_clahe_interp(const T* __restrict__ img,
 // of its LUT reads: four 2-byte gathers per pixel, each lane of each one in a cache line of its own (neighbouring
 // pixels differ by more than the 32 values a line holds), 16.8 M line requests per image, 18 us.  Value-major, a
 // pixel's four entries share a line; with the reference's 2 x 2 grid they are one aligned 8-byte word.
-// PX pixels per lane (4: rows 8-byte aligned, one 8-byte load and store); a workgroup takes `rows` image rows.
+// PX pixels per lane (4: rows 8-byte aligned, one 8-byte load and store); a workgroup takes `rows` rounds of 256 lanes.
 // COUNT: also the first pass of the order statistics that follow (np.percentile(cl1, 10), np.max(cl1)) -- the histogram
 // of the high bytes of the pixels it has just produced, in sel_hist's slot layout (k_select16_pass, pass 0): the values
 // are in registers here, which saves that pass its read of the image.
@@ -483,11 +483,18 @@ __global__ __launch_bounds__(256) void k_clahe_interp_vm(shg::PtrBatch imgs, int
         for (int i = threadIdx.x; i < 256 * COPIES; i += 256) lh[i] = 0;
         __syncthreads();
     }
-    const int64_t x0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * PX;
+    // lanes are dealt (row, vector) pairs in one flat sequence, `rows` rounds of 256 per workgroup: with an (x, y) grid a width
+    // just past a multiple of 256 * PX pixels (2096 at C2) leaves every third workgroup with a dozen lanes to do
+    const uint32_t nv = (uint32_t)((w + PX - 1) / PX);
     const int ntiles = tiles * tiles;
-    const int n = x0 < w ? (int)min((int64_t)PX, w - x0) : 0;
     const int copy = threadIdx.x & (COPIES - 1);
-    for (int64_t y = (int64_t)blockIdx.y * rows; y < min(h, ((int64_t)blockIdx.y + 1) * rows) && n > 0; ++y) {
+    for (int it = 0; it < rows; ++it) {
+        const uint32_t flat = (blockIdx.x * (uint32_t)rows + (uint32_t)it) * 256u + threadIdx.x;
+        const uint32_t yy = flat / nv;
+        const int64_t y = yy;
+        if (y >= h) break;
+        const int64_t x0 = (int64_t)(flat - yy * nv) * PX;
+        const int n = (int)min((int64_t)PX, w - x0);
         const float tyf = (float)(int)y * inv_th - 0.5f;
         int ty1 = (int)floorf(tyf);
         int ty2 = ty1 + 1;
@@ -558,7 +565,7 @@ __global__ __launch_bounds__(256) void k_clahe_interp_vm(shg::PtrBatch imgs, int
         uint32_t c = 0;
 #pragma unroll
         for (int k = 0; k < COPIES; ++k) c += lh[threadIdx.x * COPIES + k];
-        const unsigned slot = (blockIdx.y * gridDim.x + blockIdx.x) % SEL_SLOTS;
+        const unsigned slot = blockIdx.x % SEL_SLOTS;
         if (c) atomicAdd(&sel_hist[(int64_t)slot * sel_stride + threadIdx.x], c);
     }
 }
@@ -852,16 +859,20 @@ inline bool launch_interp16(const Disks& d, int64_t h, int64_t w, int64_t pitch,
         return false;
     }
     const bool vec = d.aligned(7) && pitch % 4 == 0 && dst_pitch % 4 == 0;
+    auto blocks = [&](int px, int rounds) {              // workgroups for the flat (row, vector) sequence
+        const int64_t lanes = ((w + px - 1) / px) * h;
+        return (unsigned)((lanes + 256 * (int64_t)rounds - 1) / (256 * (int64_t)rounds));
+    };
     if (vec && sel_hist) {
-        const int rows = 4;                              // per workgroup: amortises the histogram's zeroing and flush
-        k_clahe_interp_vm<4, true><<<dim3((unsigned)((w + 1023) / 1024), (unsigned)((h + rows - 1) / rows), nz), 256, 0, st>>>(
+        const int rows = 4;                              // rounds per workgroup: amortises the histogram's zeroing and flush
+        k_clahe_interp_vm<4, true><<<dim3(blocks(4, rows), 1u, nz), 256, 0, st>>>(
             d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, rows, sel_hist, sel_stride, d.zs);
         return true;
     }
     if (vec) {
-        k_clahe_interp_vm<4, false><<<dim3((unsigned)((w + 1023) / 1024), (unsigned)h, nz), 256, 0, st>>>(d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, 1, nullptr, 0, d.zs);
+        k_clahe_interp_vm<4, false><<<dim3(blocks(4, 1), 1u, nz), 256, 0, st>>>(d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, 1, nullptr, 0, d.zs);
     } else {
-        k_clahe_interp_vm<1, false><<<dim3((unsigned)((w + 255) / 256), (unsigned)h, nz), 256, 0, st>>>(d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, 1, nullptr, 0, d.zs);
+        k_clahe_interp_vm<1, false><<<dim3(blocks(1, 1), 1u, nz), 256, 0, st>>>(d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, 1, nullptr, 0, d.zs);
     }
     return false;
 }

@@ -225,15 +225,20 @@ __device__ __forceinline__ uint32_t rescale1_fast(double px, double lo, double s
 // Eight pixels per lane: 16-byte loads of frame and cl1, 16-byte stores of the three products (rows 16-byte aligned,
 // pitches multiples of 8; a row's last, partial vector goes pixel by pixel).  A lane takes the same eight columns of PROD_ROWS
 // rows, their loads issued before the first use (what took k_warp_rows from 227 to 144 us over 21 disks did nothing here).
-// grid (x, ceil(rows / PROD_ROWS), disks)
+// grid (ceil(vectors per row * row groups / 256), 1, disks)
 constexpr int PROD_ROWS = 1;            // (4 rows per lane, loads hoisted: 160 us per 16-disk launch against 140 -- the extra live registers cost more than the requests in flight bring)
 __global__ __launch_bounds__(256) void k_products8(shg::PtrBatch frames, int64_t frame_pitch,
                                                    shg::PtrBatch cl1s, int64_t cl1_pitch, int64_t h, int64_t w, BoundsBatch bb,
                                                    shg::PtrBatch hcs, shg::PtrBatch protuss, shg::PtrBatch ccs,
                                                    int64_t dst_pitch, int64_t x0, int64_t y0, int64_t r, StatsSource stats) {
-    const int64_t x = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
-    const int64_t ya = (int64_t)blockIdx.y * PROD_ROWS;
-    if (x >= w) return;
+    // lanes are dealt (row group, vector) pairs in one flat sequence: a width just past a multiple of 2048 pixels (2096 at C2)
+    // would leave every second workgroup of a (x, y) grid with half a dozen lanes to do
+    const uint32_t nv = (uint32_t)((w + 7) / 8);
+    const uint32_t flat = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t yg = flat / nv;
+    const int64_t x = (int64_t)(flat - yg * nv) * 8;
+    const int64_t ya = (int64_t)yg * PROD_ROWS;
+    if (ya >= h) return;
     const uint16_t* __restrict__ frame = frames.at<const uint16_t>(blockIdx.z);
     const uint16_t* __restrict__ cl1 = cl1s.at<const uint16_t>(blockIdx.z);
     uint16_t* __restrict__ hc = hcs.at<uint16_t>(blockIdx.z);
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(256) void k_products8(shg::PtrBatch frames, int64_t
     Bounds6 b = bb.v[blockIdx.z];
     if (stats.stats5) {
         const bool ok = bounds_from_stats(stats, blockIdx.z, b);
-        if (stats.mirror5 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 5) stats.mirror5[5 * blockIdx.z + threadIdx.x] = stats.stats5[5 * blockIdx.z + threadIdx.x];
+        if (stats.mirror5 && blockIdx.x == 0 && threadIdx.x < 5) stats.mirror5[5 * blockIdx.z + threadIdx.x] = stats.stats5[5 * blockIdx.z + threadIdx.x];
         if (!ok) return;
     }
     const double i0 = 1.0 / b.span[0], i1 = 1.0 / b.span[1], i2 = 1.0 / b.span[2];
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(256) void k_products(shg::PtrBatch frames, int64_t 
     Bounds6 b = bb.v[blockIdx.z];
     if (stats.stats5) {
         const bool ok = bounds_from_stats(stats, blockIdx.z, b);
-        if (stats.mirror5 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 5) stats.mirror5[5 * blockIdx.z + threadIdx.x] = stats.stats5[5 * blockIdx.z + threadIdx.x];
+        if (stats.mirror5 && blockIdx.x == 0 && threadIdx.x < 5) stats.mirror5[5 * blockIdx.z + threadIdx.x] = stats.stats5[5 * blockIdx.z + threadIdx.x];
         if (!ok) return;
     }
     const double f = (double)frame[y * frame_pitch + x];
@@ -383,7 +388,8 @@ int shg::contrast_products_batch(const uint16_t* const* host_frames, int64_t fra
         const shg::PtrBatch f = shg::make_batch(host_frames, (int)i0, m), c = shg::make_batch(host_cl1, (int)i0, m), hc = shg::make_batch(host_hc, (int)i0, m),
                             pr = shg::make_batch(host_protus, (int)i0, m), cc = shg::make_batch(host_cc, (int)i0, m);
         if (vec) {
-            dim3 grid((unsigned)((w + 8 * 256 - 1) / (8 * 256)), (unsigned)((h + PROD_ROWS - 1) / PROD_ROWS), (unsigned)m);
+            const int64_t lanes = ((w + 7) / 8) * ((h + PROD_ROWS - 1) / PROD_ROWS);
+            dim3 grid((unsigned)((lanes + 255) / 256), 1u, (unsigned)m);
             k_products8<<<grid, 256, 0, st>>>(f, frame_pitch, c, cl1_pitch, h, w, bb, hc, pr, cc, dst_pitch, disc_x0, disc_y0, disc_r > 0 ? disc_r : 0, src);
         } else {
             dim3 grid((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)m);

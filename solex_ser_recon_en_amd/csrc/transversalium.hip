@@ -352,14 +352,19 @@ __global__ __launch_bounds__(256) void k_scale_rows(shg::PtrBatch imgs, int64_t 
 // The same with eight pixels per lane (rows 16-byte aligned, pitches multiples of 8; a row's last, partial vector goes
 // pixel by pixel) and SCALE_ROWS rows per lane, their loads issued before the first use (one row per workgroup: one request
 // in flight per wave, 2.8 TB/s).
-// grid (x, ceil(rows / SCALE_ROWS), disks): blockIdx.z picks source, destination and the disk's h factors
+// grid (ceil(vectors per row * row groups / 256), 1, disks): blockIdx.z picks source, destination and the disk's h factors
 constexpr int SCALE_ROWS = 4;
 __global__ __launch_bounds__(256) void k_scale_rows8(shg::PtrBatch imgs, int64_t h, int64_t w, int64_t pitch,
                                                      const double* __restrict__ c, const double* __restrict__ row_factor,
                                                      shg::PtrBatch dsts, int64_t dst_pitch) {
-    const int64_t x = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
-    const int64_t ya = (int64_t)blockIdx.y * SCALE_ROWS;
-    if (x >= w) return;
+    // lanes are dealt (row group, vector) pairs in one flat sequence (an (x, y) grid wastes every second workgroup on a width
+    // just past a multiple of 2048 pixels: 2096 at C2)
+    const uint32_t nv = (uint32_t)((w + 7) / 8);
+    const uint32_t flat = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t yg = flat / nv;
+    const int64_t x = (int64_t)(flat - yg * nv) * 8;
+    const int64_t ya = (int64_t)yg * SCALE_ROWS;
+    if (ya >= h) return;
     const uint16_t* __restrict__ img = imgs.at<const uint16_t>(blockIdx.z);
     uint16_t* __restrict__ dst = dsts.at<uint16_t>(blockIdx.z);
     c += (int64_t)blockIdx.z * h;
@@ -595,7 +600,8 @@ int shg::scale_rows_batch(const uint16_t* const* host_imgs, int64_t k, int64_t h
         const int m = (int)std::min<int64_t>(shg::kMaxBatch, k - i0);
         const shg::PtrBatch src = shg::make_batch(host_imgs, (int)i0, m), dst = shg::make_batch(host_dsts, (int)i0, m);
         if (vec) {                                       // eight pixels per lane: 16-byte loads and stores
-            dim3 grid((unsigned)((w + 8 * 256 - 1) / (8 * 256)), (unsigned)((h + SCALE_ROWS - 1) / SCALE_ROWS), (unsigned)m);
+            const int64_t lanes = ((w + 7) / 8) * ((h + SCALE_ROWS - 1) / SCALE_ROWS);
+            dim3 grid((unsigned)((lanes + 255) / 256), 1u, (unsigned)m);
             k_scale_rows8<<<grid, 256, 0, st>>>(src, h, w, pitch, c + i0 * h, row_factor, dst, dst_pitch);
         } else {
             dim3 grid((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)m);
