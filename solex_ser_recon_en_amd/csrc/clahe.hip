@@ -92,42 +92,77 @@ __global__ __launch_bounds__(1024) void k_tile_hist16(const uint16_t* __restrict
 // (k_hist_ranks) and, per 2048 bins, the clipped total and the clipped-off excess, so that the LUT no longer has to be
 // built by one workgroup per tile (k_tile_lut16_blocks: 32 workgroups per tile instead of one).
 __global__ __launch_bounds__(1024) void k_tile_hist16_slices(shg::PtrBatch imgs, int64_t h, int64_t w, int64_t pitch,
-                                                             int tiles, int64_t th, int64_t tw, uint32_t* __restrict__ part, size_t zs) {
+                                                             int tiles, int64_t th, int64_t tw, uint32_t* __restrict__ part, size_t zs,
+                                                             int slice_rows, int vec) {
     extern __shared__ uint32_t lh[];   // HIST16/2 dwords, two u16 counters each
     const uint16_t* __restrict__ img = imgs.at<const uint16_t>(blockIdx.z);
     part = zdisk(part, zs);
     const int tile = blockIdx.y;
     const int64_t ty = tile / tiles, tx = tile % tiles;
     const int64_t area = th * tw;
-    const int64_t p0 = (int64_t)blockIdx.x * SLICE_PX;
-    const int64_t p1 = p0 + SLICE_PX < area ? p0 + SLICE_PX : area;
+    // a slice is a run of whole tile rows (slice_rows of them: fewer than 65536 pixels, so that a u16 counter cannot wrap)
+    const int ya = (int)blockIdx.x * slice_rows;
+    const int yb = min((int)th, ya + slice_rows) - 1;
     for (int i = threadIdx.x; i < HIST16 / 8; i += 1024) reinterpret_cast<uint4*>(lh)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int twi = (int)tw;
-        const int ya = (int)(p0 / tw), yb = (int)((p1 - 1) / tw);
-        const int xs_first = (int)(p0 - (int64_t)ya * tw), xe_last = (int)(p1 - (int64_t)yb * tw);
-        for (int yy = ya + wave; yy <= yb; yy += 16) {
-            const int xs = yy == ya ? xs_first : 0, xe = yy == yb ? xe_last : twi;
-            int64_t y = ty * th + yy;
-            if (y >= h) y = shg::reflect101(y, h);
-            const uint16_t* row = img + y * pitch;
-            const int64_t xbase = tx * tw;
-            // eight loads in flight per lane before the first count: one load per trip left this kernel waiting on memory
-            // latency 33 times over (20 us)
-            for (int x0 = xs + lane; x0 < xe; x0 += 64 * 8) {
-                uint32_t v[8];
+        const int64_t xbase = tx * tw;
+        auto count = [&](uint32_t v) { atomicAdd(&lh[v >> 1], (v & 1) ? 0x10000u : 1u); };
+        if (vec) {
+            // rows of 16-byte vectors, none reflected: a wave takes two rows a round (its share of a 65535-pixel slice is four),
+            // three vectors of each per lane, all six loads in flight before the first count -- pixel by pixel the wave waited
+            // for memory a dozen times per slice, which is what this kernel's time was
+            const int nvr = twi / 8;
+            for (int yy = ya + wave; yy <= yb; yy += 32) {
+                const bool two = yy + 16 <= yb;
+                int64_t y0 = ty * th + yy, y1 = ty * th + (two ? yy + 16 : yy);
+                if (y0 >= h) y0 = shg::reflect101(y0, h);
+                if (y1 >= h) y1 = shg::reflect101(y1, h);
+                const uint4* r0 = reinterpret_cast<const uint4*>(img + y0 * pitch + xbase);
+                const uint4* r1 = reinterpret_cast<const uint4*>(img + y1 * pitch + xbase);
+                for (int v0 = lane; v0 < nvr; v0 += 64 * 3) {
+                    uint4 q[2][3];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int xx = x0 + 64 * u;
-                    int64_t x = xbase + (xx < xe ? xx : xs);
-                    if (x >= w) x = shg::reflect101(x, w);
-                    v[u] = row[x];
+                    for (int u = 0; u < 3; ++u) {
+                        const int vi = v0 + 64 * u < nvr ? v0 + 64 * u : v0;
+                        q[0][u] = r0[vi];
+                        q[1][u] = r1[vi];
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        if (rr == 1 && !two) break;
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) {
+                            if (v0 + 64 * u >= nvr) break;
+                            const uint32_t d[4] = {q[rr][u].x, q[rr][u].y, q[rr][u].z, q[rr][u].w};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { count(d[j] & 0xffffu); count(d[j] >> 16); }
+                        }
+                    }
                 }
+            }
+        } else {
+            for (int yy = ya + wave; yy <= yb; yy += 16) {
+                int64_t y = ty * th + yy;
+                if (y >= h) y = shg::reflect101(y, h);
+                const uint16_t* row = img + y * pitch;
+                // eight loads in flight per lane before the first count: one load per trip left this kernel waiting on memory
+                // latency 33 times over (20 us)
+                for (int x0 = lane; x0 < twi; x0 += 64 * 8) {
+                    uint32_t v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (x0 + 64 * u < xe) atomicAdd(&lh[v[u] >> 1], (v[u] & 1) ? 0x10000u : 1u);
+                    for (int u = 0; u < 8; ++u) {
+                        const int xx = x0 + 64 * u;
+                        int64_t x = xbase + (xx < twi ? xx : 0);
+                        if (x >= w) x = shg::reflect101(x, w);
+                        v[u] = row[x];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (x0 + 64 * u < twi) count(v[u]);
+                }
             }
         }
     }
@@ -888,6 +923,14 @@ inline void tile_geometry(int64_t h, int64_t w, int tiles, int64_t* th, int64_t*
     *tw = we / tiles;
 }
 
+// a tile's slices are runs of whole rows holding at most slice_px pixels (a tile row longer than that: one row a slice --
+// the u16 counters of such a slice can wrap, and clahe_impl keeps those images off this path)
+inline int64_t slice_rows_of(int64_t tw, int64_t slice_px) { return tw >= slice_px ? 1 : slice_px / tw; }
+inline int64_t slice_count(int64_t th, int64_t tw, int64_t slice_px) {
+    const int64_t rows = slice_rows_of(tw, slice_px);
+    return (th + rows - 1) / rows;
+}
+
 // extra workspace of the atomics-free 16-bit path, after the [hist | lut] block: slice histograms, chunk sums, se
 struct FastLayout { size_t part, chunk, se, total; int64_t slices; };
 inline FastLayout fast_layout(int64_t h, int64_t w, int tiles) {
@@ -895,7 +938,7 @@ inline FastLayout fast_layout(int64_t h, int64_t w, int tiles) {
     tile_geometry(h, w, tiles, &th, &tw);
     FastLayout f;
     const size_t ntiles = (size_t)tiles * tiles;
-    f.slices = (th * tw + SLICE_PX - 1) / SLICE_PX;
+    f.slices = slice_count(th, tw, SLICE_PX);
     f.part = 0;
     f.chunk = ntiles * (size_t)f.slices * (HIST16 / 2) * sizeof(uint32_t);
     f.se = f.chunk + ntiles * 1024 * sizeof(uint32_t);
@@ -947,7 +990,7 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
     uint16_t* lut = reinterpret_cast<uint16_t*>(hist + (size_t)ntiles * hist_size);
     const float inv_tw = 1.0f / (float)tw, inv_th = 1.0f / (float)th;
     dim3 igrid((unsigned)((w + 255) / 256), (unsigned)h);
-    if (bytes_per_px == 2 && clip > 0 && clip <= 65535 && workspace_bytes >= shg_clahe_workspace_bytes_for(h, w, tiles, 2)) {
+    if (bytes_per_px == 2 && clip > 0 && clip <= 65535 && tw <= 65535 && workspace_bytes >= shg_clahe_workspace_bytes_for(h, w, tiles, 2)) {
         // no atomics, no memset: slice histograms stored whole, one reduction, the LUT by 32 workgroups per tile
         ensure_lds_attr();
         const FastLayout f = fast_layout(h, w, tiles);
@@ -957,9 +1000,17 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
         int32_t* se = reinterpret_cast<int32_t*>(extra + f.se);
         { SHG_PROF("clahe_hist", st);
           const unsigned nz = (unsigned)dset.n;
-          k_tile_hist16_slices<<<dim3((unsigned)f.slices, (unsigned)ntiles, nz), 1024, HIST16 * 2, st>>>(dset.src, h, w, pitch, tiles, th, tw, part, dset.zs);
+          // One image: 32768-pixel slices spread a tile over enough workgroups to fill the chip.  A stack of disks fills it
+          // anyway: the largest slice a u16 counter allows halves the slice histograms written here and read back by the
+          // reduction (the layout's f.slices is the upper bound the workspace was sized for).
+          static const int64_t big = [] { const char* v = getenv("SHG_CLAHE_SLICE_PX"); return v ? (int64_t)atoi(v) : (int64_t)65535; }();
+          const int64_t slice_px = (dset.n >= 4 && big > SLICE_PX && big <= 65535) ? big : SLICE_PX;
+          const int64_t slice_rows = slice_rows_of(tw, slice_px), slices = slice_count(th, tw, slice_px);
+          const int vec = w % tiles == 0 && tw % 8 == 0 && pitch % 8 == 0 && dset.aligned(15);
+          k_tile_hist16_slices<<<dim3((unsigned)slices, (unsigned)ntiles, nz), 1024, HIST16 * 2, st>>>(dset.src, h, w, pitch, tiles, th, tw, part, dset.zs,
+                                                                                                    (int)slice_rows, vec);
           if (int e = shg::check_launch("k_tile_hist16_slices")) return e;
-          k_hist_reduce<<<dim3(32, (unsigned)ntiles, nz), 1024, 0, st>>>(part, (int)f.slices, clip, hist, chunk_tile, se, dset.zs); }
+          k_hist_reduce<<<dim3(32, (unsigned)ntiles, nz), 1024, 0, st>>>(part, (int)slices, clip, hist, chunk_tile, se, dset.zs); }
         if (int e = shg::check_launch("k_hist_reduce")) return e;
         { SHG_PROF("clahe_lut", st); k_tile_lut16_blocks<<<dim3(32, (unsigned)ntiles, (unsigned)dset.n), 1024, 0, st>>>(hist, se, clip, lut_scale, lut, dset.zs); }
         if (int e = shg::check_launch("k_tile_lut16_blocks")) return e;
@@ -1058,7 +1109,12 @@ int select_u16_impl(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, co
     }
     // ~8192 pixels per workgroup, at most 1024 workgroups, whole rows each
     // (measured, tools/bench_select.py: 2048 / 4096 / 8192 / 16384 pixels per workgroup -> 92 / 58 / 45 / 44 us for two ranks)
-    int64_t want = (h * w + 8191) / 8192;
+    // Several disks in one launch: the chip is full with ~2048 workgroups in all, and a workgroup's share then grows with the
+    // number of disks (the replay, zeroing and flush around the pixel loop are paid per workgroup).
+    static const int64_t wg_target = [] { const char* v = getenv("SHG_SELECT_WGS"); return v ? (int64_t)atoi(v) : (int64_t)2048; }();
+    int64_t per_wg = 8192;
+    if (dset.n > 1 && h * w * dset.n / per_wg > wg_target) per_wg = h * w * dset.n / wg_target;
+    int64_t want = (h * w + per_wg - 1) / per_wg;
     want = want < 1 ? 1 : (want > 1024 ? 1024 : want);
     const unsigned blocks = (unsigned)(h < want ? h : want);
     uintptr_t bits = 0;

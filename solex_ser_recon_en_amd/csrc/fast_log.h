@@ -1,0 +1,60 @@
+// log(x) for x positive, finite and normal: the algorithm of fdlibm's __ieee754_log (error below 1 ulp) with its polynomials in
+// fused multiply-adds, in ~40 float64 instructions where the device library's log takes ~85 (it carries the result in two
+// doubles).  The row-pair statistic of the transversalium correction (solex_util.py:383-395) takes a logarithm per pixel pair
+// and is bound by exactly these instructions.  np.log, the device library and this agree to the last bit or differ in it, as
+// any two correctly working libm's do; DESIGN.md section 4 says what that means for parity.
+// Plain C++ so that tests/ can compile the same text with the host compiler and put it next to logl.
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define SHG_FASTLOG_FN __host__ __device__ __forceinline__
+#else
+#define SHG_FASTLOG_FN inline
+#endif
+
+namespace shg {
+
+// n / d for normal operands whose quotient is normal: reciprocal, two Newton steps, one correction of the quotient
+SHG_FASTLOG_FN double div_normal(double n, double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(d);
+#else
+    double y = 1.0 / d;
+#endif
+    double e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
+    const double q = n * y;
+    const double r = fma(-d, q, n);
+    return fma(r, y, q);
+}
+
+SHG_FASTLOG_FN double log_normal(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double m = __builtin_amdgcn_frexp_mant(x);           // [0.5, 1)
+    int k = __builtin_amdgcn_frexp_exp(x);
+#else
+    int k;
+    double m = frexp(x, &k);
+#endif
+    const bool low = m < 0.70710678118654752440;         // x = 2^k (1 + f), sqrt(2)/2 <= 1 + f < sqrt(2)
+    m = low ? m + m : m;
+    k = low ? k - 1 : k;
+    const double f = m - 1.0;
+    const double s = div_normal(f, 2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return fma(dk, ln2_hi, -((hfsq - fma(s, hfsq + R, dk * ln2_lo)) - f));
+}
+
+}  // namespace shg

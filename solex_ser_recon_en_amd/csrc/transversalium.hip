@@ -17,6 +17,7 @@
 #include <math.h>
 #include <algorithm>
 #include "shg_common.h"
+#include "fast_log.h"
 
 namespace {
 
@@ -279,7 +280,9 @@ __global__ __launch_bounds__(NT) void k_rowpair_stats(shg::PtrBatch imgs, int64_
     {
         bool odd = false;
         for (int i = threadIdx.x; i < n; i += NT) {
-            const double x = log(((double)r1[i] * f1) / ((double)r0[i] * f0));        // np.log(strip1 / strip0)
+            const double q = ((double)r1[i] * f1) / ((double)r0[i] * f0);              // np.log(strip1 / strip0)
+            // (zero pixels make 0, inf or NaN quotients: those go through the library's log, which knows what to return)
+            const double x = (q >= 2.2250738585072014e-308 && q <= 1.7976931348623157e308) ? shg::log_normal(q) : log(q);
             if (x != x) sc.bad = 1;
             odd = odd || !(fabs(x) <= 1.7976931348623157e308);
             keys[i] = f64_key(x);

@@ -4,6 +4,7 @@ These functions take host pointers only, so the whole file runs without a GPU.  
 BIT-IDENTICAL to NumPy's (the raw disks are exact only if `fit` is).  tests/numpy_ref.py holds the NumPy / SciPy
 statements the C++ is compared with."""
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -460,3 +461,21 @@ def test_percentile_plan(n, q):
     rng = np.random.default_rng(0)
     a, b = sorted(rng.random(2))
     assert lib.shg_host_lerp(a, b, gamma) == order_stats.lerp_order_stats(n, q)[2](a, b)
+
+
+def test_fast_log_stays_below_one_ulp(tmp_path):
+    """csrc/fast_log.h (the logarithm of k_rowpair_stats) compiled with the host compiler: below 1 ulp against logl over the
+    quotients of 16-bit pixel pairs and over random normal doubles, exact for 1, and equal to the host libm's log in all but a
+    few percent of the cases (where the two differ in the last bit, as two libm's do)."""
+    import shutil
+    import subprocess
+    gxx = shutil.which('g++')
+    if gxx is None:
+        pytest.skip('no g++')
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / 'fast_log_check')
+    subprocess.run([gxx, '-O2', '-ffp-contract=off', '-I', os.path.join(here, '..', 'solex_ser_recon_en_amd', 'csrc'),
+                    os.path.join(here, 'c_abi', 'fast_log_check.cpp'), '-o', exe], check=True)
+    pairs, every, differ = (float(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split())
+    assert pairs < 1.0 and every < 1.0, (pairs, every)
+    assert differ < 0.08, differ
