@@ -71,17 +71,20 @@ __global__ __launch_bounds__(256) void k_warp_rows(shg::PtrBatch srcs, int64_t h
     const int c = (int)(blockIdx.x * 256 + threadIdx.x);
     const int ra = (int)blockIdx.y * WARP_ROWS;
     if (c >= out_w) return;
-    constexpr double inv = 1.0 / 65536.0;
-    // both samples of every row are read unconditionally from clamped positions and replaced by cval afterwards where they
-    // fall outside the image: no branch (and no wait) between the loads
+    // The reference works on img / 65536 and stores (2**16 * warped).astype(uint16).  Scaling by a power of two is exact and
+    // commutes with every rounding below, so the blend, the clip and the truncation run on the raw sample values: the same
+    // results with three float64 multiplications less per pixel (this kernel is bound by its float64 instructions).
+    // Both samples of every row are read unconditionally from clamped positions and replaced by cval afterwards where they
+    // fall outside the image: no branch (and no wait) between the loads.
     double dc[WARP_ROWS];
     uint32_t v0[WARP_ROWS], v1[WARP_ROWS];
     bool in0[WARP_ROWS], in1[WARP_ROWS];
     const double wd = (double)w;
+    const double xc = h00 * (double)c;
 #pragma unroll
     for (int rr = 0; rr < WARP_ROWS; ++rr) {
         const int r = ra + rr;
-        const double x = h00 * (double)c + h01 * (double)r + h02;
+        const double x = xc + h01 * (double)r + h02;
         const double x0 = floor(x), x1 = ceil(x);
         dc[rr] = x - x0;
         const bool row_ok = r < h;                                // (r < out_h is checked at the store)
@@ -91,19 +94,16 @@ __global__ __launch_bounds__(256) void k_warp_rows(shg::PtrBatch srcs, int64_t h
         v0[rr] = row[in0[rr] ? (int)x0 : 0];
         v1[rr] = row[in1[rr] ? (int)x1 : 0];
     }
-    const uint32_t mn = mm[0], mx = mm[1];
-    const double cval = (double)src[0] * inv;                 // cval = image[0, 0]
-    const double lo = (double)mn * inv, hi = (double)mx * inv;
+    const double cval = (double)src[0];                       // cval = image[0, 0]
+    const double lo = (double)mm[0], hi = (double)mm[1];
 #pragma unroll
     for (int rr = 0; rr < WARP_ROWS; ++rr) {
         const int r = ra + rr;
         if (r >= out_h) break;
-        const double s0 = (double)v0[rr] * inv, s1 = (double)v1[rr] * inv;
-        const double left = in0[rr] ? s0 : cval, right = in1[rr] ? s1 : cval;
+        const double left = in0[rr] ? (double)v0[rr] : cval, right = in1[rr] ? (double)v1[rr] : cval;
         double v = (1.0 - dc[rr]) * left + dc[rr] * right;
-        v = v < lo ? lo : v;                                       // np.clip(warped, image.min(), image.max())
-        v = v > hi ? hi : v;
-        dst[(int64_t)r * dst_pitch + c] = (uint16_t)(int)(65536.0 * v);     // (2**16 * img).astype(uint16)
+        v = fmin(fmax(v, lo), hi);                                 // np.clip(warped, image.min(), image.max()): no NaN can get here
+        dst[(int64_t)r * dst_pitch + c] = (uint16_t)(int)v;        // (2**16 * img).astype(uint16)
     }
 }
 
