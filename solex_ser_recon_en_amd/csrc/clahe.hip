@@ -99,7 +99,6 @@ __global__ __launch_bounds__(1024) void k_tile_hist16_slices(shg::PtrBatch imgs,
     part = zdisk(part, zs);
     const int tile = blockIdx.y;
     const int64_t ty = tile / tiles, tx = tile % tiles;
-    const int64_t area = th * tw;
     // a slice is a run of whole tile rows (slice_rows of them: fewer than 65536 pixels, so that a u16 counter cannot wrap)
     const int ya = (int)blockIdx.x * slice_rows;
     const int yb = min((int)th, ya + slice_rows) - 1;
@@ -716,6 +715,13 @@ __global__ __launch_bounds__(1024) void k_select16_pass(shg::PtrBatch imgs, int6
     int his[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) his[r] = (pass == 1 && r < n_ranks) ? his_s[r] : -1;
+    // the ranks' high bytes, four to a word (a spare byte repeats the first rank's)
+    uint32_t wanted0 = 0, wanted1 = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        wanted0 |= (uint32_t)((r < n_ranks ? his[r] : his[0]) & 0xff) << (8 * r);
+        wanted1 |= (uint32_t)((4 + r < n_ranks ? his[4 + r] : his[0]) & 0xff) << (8 * r);
+    }
     const int copy0 = threadIdx.x & (SEL_COPIES0 - 1), copy1 = threadIdx.x & (SEL_COPIES1 - 1);
     auto count = [&](uint32_t v) {
         if (pass == 0) {
@@ -749,6 +755,29 @@ __global__ __launch_bounds__(1024) void k_select16_pass(shg::PtrBatch imgs, int6
             for (int u = 0; u < 4; ++u) {
                 if (!ok[u]) continue;
                 const uint32_t d[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+                if (pass == 1) {
+                    // Pass 1 counts only the pixels whose high byte is one of the ranks': a fraction of a percent each.  A pair of
+                    // pixels is tested without a branch -- is a byte of `wanted` (the ranks' high bytes, four to a word) equal to
+                    // a pixel's high byte: the zero-byte test on wanted ^ (byte * 0x01010101) -- and only a pair that has one goes
+                    // through count().  (A compare and a branch per pixel and rank made the pass issue bound: 2100 scalar and 1500
+                    // vector instructions per wave; a wave always holds some lane with a match, so testing whole vectors first
+                    // saves nothing.)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        uint32_t any = 0;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const uint32_t rep = ((d[j] >> (8 + 16 * e)) & 0xffu) * 0x01010101u;
+                            const uint32_t x0 = wanted0 ^ rep, x1 = wanted1 ^ rep;
+                            any |= ((x0 - 0x01010101u) & ~x0) | ((x1 - 0x01010101u) & ~x1);
+                        }
+                        if (any & 0x80808080u) {
+                            count(d[j] & 0xffffu);
+                            count(d[j] >> 16);
+                        }
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     count(d[j] & 0xffffu);
