@@ -428,6 +428,21 @@ def extra_leg(what, pool, shifts, steps, warmup, workers, run_scans, barrier, _l
                        'frac_uncontended': round(bytes_b / (ext_ms / ext_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ext_n else None}}
 
 
+def _write_near_gpu(write):
+    """tmpfs pages live on the NUMA node of the cpu that first touches them.  A writer that happens to run on the far socket leaves
+    the whole file there and every read of the decode leg crosses the socket link (measured on the 2 x 64-core box: 35 GB/s into
+    the GPU instead of 52).  The file stands in for one the page cache holds next to its reader, so it is written from the
+    cpus the decode readers run on."""
+    from solex_ser_recon_en_amd import device
+    import torch
+    old = device.bind_thread('io', torch.device('cuda', torch.cuda.current_device()))
+    try:
+        write()
+    finally:
+        if old is not None:
+            os.sched_setaffinity(0, old)
+
+
 def _write_scan(path, n, width, height, bits, rank, world):
     """Rank 0 writes the synthetic SER file (generated on its GPU), everyone waits for it."""
     import torch
@@ -437,7 +452,7 @@ def _write_scan(path, n, width, height, bits, rank, world):
         frames = synth.synth_frames_torch(n, width, height, bits, seed=0)
         host = ops.stack_to_host(frames)
         del frames
-        synth.write_ser(path, host)
+        _write_near_gpu(lambda: synth.write_ser(path, host))
         del host
     if world > 1:
         td.barrier()
@@ -454,7 +469,7 @@ def e2e_leg(args, world, rank, stack, n_local, options, workers):
     path = shared_path('shg_bench_e2e.ser', stack.shape[0] * frame_bytes, rank, world)
     try:
         if rank == 0:
-            synth.write_ser(path, ops.stack_to_host(stack))
+            _write_near_gpu(lambda: synth.write_ser(path, ops.stack_to_host(stack)))
         if world > 1:
             td.barrier()
         size = os.path.getsize(path)
