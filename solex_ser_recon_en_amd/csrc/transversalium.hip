@@ -45,6 +45,7 @@ struct Scratch {
     unsigned long long kmin, kmax;
     uint32_t n_cand;
     double red[4];
+    double vfound[2];            // bucket select: the two values found
     int bad, nonfinite;
 };
 
@@ -134,18 +135,19 @@ __device__ __forceinline__ void select2(KeyFn key, int n, int64_t rank_lo, int64
 // bucket is <= every key of the next one and the bucket holding a rank is found by a prefix sum; its keys (a few
 // dozen of ~2000 for real rows) are ranked against each other.  A crowded bucket is bucketed again between its own
 // extrema.  Returns false (block-uniform) when it gives up: the caller then runs select2.
-template <typename KeyFn>
-__device__ __forceinline__ bool select2_buckets(KeyFn key, int n, int64_t rank_lo, int64_t rank_hi, double lo, double hi,
-                                                Scratch& sc, uint64_t& out_lo, uint64_t& out_hi) {
+template <typename ValFn>
+__device__ __forceinline__ bool select2_buckets(ValFn val, int n, int64_t rank_lo, int64_t rank_hi, double lo, double hi,
+                                                Scratch& sc, double& out_lo, double& out_hi) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t* hist = &sc.hist[0][0];
-    uint32_t below = 0;                                 // keys smaller than kmin
-    uint64_t kmin = 0, kmax = ~0ull;                    // the keys still in play (all of them at first)
+    double* cand = reinterpret_cast<double*>(sc.cand);
+    uint32_t below = 0;                                 // values smaller than wlo
+    double wlo = 0.0, whi = 0.0;                        // the values still in play, from the second level on (all of them at first)
     for (int level = 0; level < 4; ++level) {
         if (level > 0) {
-            if (kmin == kmax) { out_lo = out_hi = kmin; return true; }
-            lo = key_f64(kmin);
-            hi = key_f64(kmax);
+            if (wlo == whi) { out_lo = out_hi = wlo; return true; }
+            lo = wlo;
+            hi = whi;
         }
         // [lo, hi] only has to spread the keys: values beyond it fall into the end buckets, which keeps the map monotone.
         // The caller passes the bulk of the distribution (mean +- 3 sigma) rather than the extrema: with the range set by
@@ -153,17 +155,19 @@ __device__ __forceinline__ bool select2_buckets(KeyFn key, int n, int64_t rank_l
         // 51 for the radix select; profiles/).
         const double inv = (double)NB / (hi - lo);
         if (!(inv > 0.0) || inv > 1.7e308) return false;
-        auto bucket = [&](uint64_t k) {
-            const double t = (key_f64(k) - lo) * inv;
-            return t >= (double)(NB - 1) ? NB - 1 : (t > 0.0 ? (int)t : 0);
+        auto bucket = [&](double v) {                    // (the sweeps read the values as they are: no sort keys made and unmade)
+            int b = (int)((v - lo) * inv);               // toward zero, saturating (v_cvt_i32_f64): still monotone
+            b = b < 0 ? 0 : b;
+            return b > NB - 1 ? NB - 1 : b;
         };
+        auto in_play = [&](double v) { return level == 0 || (v >= wlo && v <= whi); };
         hist[tid] = 0;
         hist[tid + 256] = 0;
         if (tid == 0) sc.n_cand = 0;
         __syncthreads();
         for (int i = tid; i < n; i += NT) {
-            const uint64_t k = key(i);
-            if (k >= kmin && k <= kmax) atomicAdd(&hist[bucket(k)], 1u);
+            const double v = val(i);
+            if (in_play(v)) atomicAdd(&hist[bucket(v)], 1u);
         }
         __syncthreads();
         // prefix sum over the buckets, two per thread
@@ -192,42 +196,42 @@ __device__ __forceinline__ bool select2_buckets(KeyFn key, int n, int64_t rank_l
         if (cnt <= (uint32_t)CAP) {
             // adjacent ranks: the buckets between b0 and b1 are empty, so the candidates are consecutive in rank
             for (int i = tid; i < n; i += NT) {
-                const uint64_t k = key(i);
-                if (k >= kmin && k <= kmax) {
-                    const int b = bucket(k);
-                    if (b == b0 || b == b1) sc.cand[atomicAdd(&sc.n_cand, 1u)] = k;
+                const double v = val(i);
+                if (in_play(v)) {
+                    const int b = bucket(v);
+                    if (b == b0 || b == b1) cand[atomicAdd(&sc.n_cand, 1u)] = v;
                 }
             }
             __syncthreads();
             const int m = (int)sc.n_cand;
             if (tid < m) {
-                const uint64_t mine = sc.cand[tid];
+                const double mine = cand[tid];      // (-0.0 and +0.0 tie here and have different keys in select2: same correction)
                 uint32_t r = base;
                 for (int j = 0; j < m; ++j) {
-                    const uint64_t o = sc.cand[j];
+                    const double o = cand[j];
                     r += (o < mine || (o == mine && j < tid)) ? 1u : 0u;
                 }
-                if (r == (uint32_t)rank_lo) sc.found[0] = mine;
-                if (r == (uint32_t)rank_hi) sc.found[1] = mine;
+                if (r == (uint32_t)rank_lo) sc.vfound[0] = mine;
+                if (r == (uint32_t)rank_hi) sc.vfound[1] = mine;
             }
             __syncthreads();
-            out_lo = sc.found[0];
-            out_hi = sc.found[1];
+            out_lo = sc.vfound[0];
+            out_hi = sc.vfound[1];
             __syncthreads();
             return true;
         }
         if (b0 != b1) return false;                     // a crowded bucket next to the one with the other rank: rare enough
         if (tid == 0) { sc.kmin = ~0ull; sc.kmax = 0ull; }
         __syncthreads();
-        uint64_t mn = ~0ull, mx = 0ull;
+        uint64_t mn = ~0ull, mx = 0ull;                 // (extrema through the keys: 64-bit atomics order them)
         for (int i = tid; i < n; i += NT) {
-            const uint64_t k = key(i);
-            if (k >= kmin && k <= kmax && bucket(k) == b0) { mn = k < mn ? k : mn; mx = k > mx ? k : mx; }
+            const double v = val(i);
+            if (in_play(v) && bucket(v) == b0) { const uint64_t k = f64_key(v); mn = k < mn ? k : mn; mx = k > mx ? k : mx; }
         }
         if (mn <= mx) { atomicMin(&sc.kmin, (unsigned long long)mn); atomicMax(&sc.kmax, (unsigned long long)mx); }
         __syncthreads();
-        kmin = sc.kmin;
-        kmax = sc.kmax;
+        wlo = key_f64(sc.kmin);
+        whi = key_f64(sc.kmax);
         below = base;
         __syncthreads();
     }
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(NT) void k_rowpair_stats(shg::PtrBatch imgs, int64_
                                                       const int32_t* __restrict__ xa, const int32_t* __restrict__ xb,
                                                       const double* __restrict__ row_factor, double* __restrict__ out,
                                                       double* __restrict__ mirror, int64_t out_stride) {
-    extern __shared__ uint64_t keys[];   // [n]
+    extern __shared__ double vals[];     // [n]: the log-ratios of the chord
     __shared__ Scratch sc;
     const uint16_t* __restrict__ img = imgs.at<const uint16_t>(blockIdx.z);
     out += (int64_t)blockIdx.z * out_stride;
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(NT) void k_rowpair_stats(shg::PtrBatch imgs, int64_
             const double x = (q >= 2.2250738585072014e-308 && q <= 1.7976931348623157e308) ? shg::log_normal(q) : log(q);
             if (x != x) sc.bad = 1;
             odd = odd || !(fabs(x) <= 1.7976931348623157e308);
-            keys[i] = f64_key(x);
+            vals[i] = x;
             sum1 += x;
             sum2 += x * x;
         }
@@ -304,14 +308,20 @@ __global__ __launch_bounds__(NT) void k_rowpair_stats(shg::PtrBatch imgs, int64_
     const double sigma = var > 0.0 ? sqrt(var) : 0.0;
     // np.median: the middle order statistic, or the mean of the two middle ones
     const int64_t lo = (n & 1) ? (n >> 1) : (n >> 1) - 1, hi = n >> 1;
-    uint64_t ka, kb;
-    auto row_key = [&](int i) { return keys[i]; };
-    if (!(finite && select2_buckets(row_key, n, lo, hi, mean - 3.0 * sigma, mean + 3.0 * sigma, sc, ka, kb)))
-        select2(row_key, n, lo, hi, sc, ka, kb);
-    const double med = (n & 1) ? key_f64(ka) : (key_f64(ka) + key_f64(kb)) / 2.0;
+    double va, vb;
+    auto general = [&](auto key) {                 // the radix select, over sort keys made on the fly
+        uint64_t ka, kb;
+        select2(key, n, lo, hi, sc, ka, kb);
+        va = key_f64(ka);
+        vb = key_f64(kb);
+    };
+    auto row_val = [&](int i) { return vals[i]; };
+    if (!(finite && select2_buckets(row_val, n, lo, hi, mean - 3.0 * sigma, mean + 3.0 * sigma, sc, va, vb)))
+        general([&](int i) { return f64_key(vals[i]); });
+    const double med = (n & 1) ? va : (va + vb) / 2.0;
     if (!finite) {                       // (finite values and a finite median cannot make a NaN)
         for (int i = threadIdx.x; i < n; i += NT) {
-            const double dv = fabs(key_f64(keys[i]) - med);             // inf - inf or a NaN median -> NaN
+            const double dv = fabs(vals[i] - med);                      // inf - inf or a NaN median -> NaN
             if (dv != dv) sc.bad = 1;
         }
         __syncthreads();
@@ -320,15 +330,19 @@ __global__ __launch_bounds__(NT) void k_rowpair_stats(shg::PtrBatch imgs, int64_
             return;
         }
     }
-    // |x - med| >= 0: its bit pattern is already order preserving
-    auto dev_key = [&](int i) { return f64_key(fabs(key_f64(keys[i]) - med)); };
-    if (!(finite && select2_buckets(dev_key, n, lo, hi, 0.0, 2.0 * sigma, sc, ka, kb))) select2(dev_key, n, lo, hi, sc, ka, kb);
-    const double mdev = (n & 1) ? key_f64(ka) : (key_f64(ka) + key_f64(kb)) / 2.0;
+    auto dev_val = [&](int i) { return fabs(vals[i] - med); };
+    if (!(finite && select2_buckets(dev_val, n, lo, hi, 0.0, 2.0 * sigma, sc, va, vb)))
+        general([&](int i) { return f64_key(fabs(vals[i] - med)); });    // |x - med| >= 0: its bit pattern is already order preserving
+    const double mdev = (n & 1) ? va : (va + vb) / 2.0;
+    // `dev / mdev < 2` as `dev < 2 * mdev`: the rounded quotient is below 2 exactly when the true one is below 2 - 2^-53, and no
+    // double lies in [2 mdev (1 - 2^-54), 2 mdev) -- the two tests agree for every pair of doubles (infinities and NaN included),
+    // and the sweep has no division.
+    const double twice = 2.0 * mdev;
     double s = 0.0, cnt = 0.0;
     for (int i = threadIdx.x; i < n; i += NT) {
-        const double x = key_f64(keys[i]);
+        const double x = vals[i];
         const double dev = fabs(x - med);
-        const bool keep = (mdev != 0.0) ? (dev / mdev < 2.0) : true;   // s = d/mdev if mdev else zeros; data[s < m] (NaN < 2 is false)
+        const bool keep = (mdev != 0.0) ? (dev < twice) : true;        // s = d/mdev if mdev else zeros; data[s < 2] (see above)
         if (keep) { s += x; cnt += 1.0; }
     }
     s = block_sum(s, sc.red);
@@ -551,7 +565,7 @@ int shg::rowpair_stats_batch(const uint16_t* const* host_imgs, int64_t k, int64_
         }
         return 0;
     }
-    const size_t lds_bytes = (size_t)w * sizeof(uint64_t);
+    const size_t lds_bytes = (size_t)w * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowpair_stats), hipFuncAttributeMaxDynamicSharedMemorySize, MAXN * 8);
