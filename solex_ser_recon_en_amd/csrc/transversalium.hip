@@ -248,7 +248,7 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 }
 
 // grid (rows, 1, disks): blockIdx.z picks the image and its slice (out_stride doubles apart) of out / mirror
-__global__ __launch_bounds__(NT) void k_rowpair_stats(shg::PtrBatch imgs, int64_t pitch, int64_t y1,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8))) void k_rowpair_stats(shg::PtrBatch imgs, int64_t pitch, int64_t y1,
                                                       const int32_t* __restrict__ xa, const int32_t* __restrict__ xb,
                                                       const double* __restrict__ row_factor, double* __restrict__ out,
                                                       double* __restrict__ mirror, int64_t out_stride) {
