@@ -419,10 +419,11 @@ def test_clahe_matches_oracle(ops, orc, h, w, tiles, dtype):
 
 
 @pytest.mark.parametrize('h,w,tiles,clip_limit', [(1100, 1000, 2, 0.8), (1100, 1000, 2, 40.0), (901, 1203, 2, 3.0), (640, 960, 4, 8.0),
-                                                  (1100, 1000, 2, 0.0)])
+                                                  (1100, 1000, 2, 0.0), (1100, 1008, 2, 0.8), (700, 1056, 3, 2.0)])
 def test_clahe_paths_agree_with_the_oracle_on_several_slices_per_tile(ops, orc, h, w, tiles, clip_limit):
     """Tiles of more than one 32768-pixel slice, clip limits from 1 count to hundreds (batch and residual redistribution
-    both at work), a padded (reflected) tile grid, no clipping at all: slice histograms + block-wise LUT, the atomics path
+    both at work), a padded (reflected) tile grid, no clipping at all, tile rows that are whole 16-byte vectors (the slice
+    histogram's vector loads: widths 1008 and 1056) and ones that are not: slice histograms + block-wise LUT, the atomics path
     and the oracle agree bit for bit.  A solar-like image: a bright disc with limb darkening on a near-constant sky."""
     rng = np.random.default_rng(17)
     yy, xx = np.mgrid[0:h, 0:w]
