@@ -505,7 +505,8 @@ template <int PX, bool COUNT>
 __global__ __launch_bounds__(256) void k_clahe_interp_vm(shg::PtrBatch imgs, int64_t h, int64_t w, int64_t pitch,
                                                          int tiles, float inv_tw, float inv_th,
                                                          const uint16_t* __restrict__ lut, shg::PtrBatch dsts, int64_t dst_pitch,
-                                                         int rows, uint32_t* __restrict__ sel_hist, int sel_stride, size_t zs) {
+                                                         int rows, uint32_t* __restrict__ sel_hist, int sel_stride, size_t zs,
+                                                         int tiled, uint32_t tiles_x) {
     constexpr int HIST = 65536;
     constexpr int COPIES = 8;                            // interleaved copies of each bin: a row's pixels crowd a few bins
     __shared__ uint32_t lh[COUNT ? 256 * COPIES : 1];
@@ -523,11 +524,28 @@ __global__ __launch_bounds__(256) void k_clahe_interp_vm(shg::PtrBatch imgs, int
     const int ntiles = tiles * tiles;
     const int copy = threadIdx.x & (COPIES - 1);
     for (int it = 0; it < rows; ++it) {
-        const uint32_t flat = (blockIdx.x * (uint32_t)rows + (uint32_t)it) * 256u + threadIdx.x;
-        const uint32_t yy = flat / nv;
+        uint32_t yy;
+        int64_t x0;
+        if (tiled) {
+            // a wave takes 16 pixels x 16 rows, the four waves of a workgroup sit side by side (128 bytes of every row): the
+            // pixels of a wave -- and of the wave that follows it on the CU -- are neighbours in both directions, so the window
+            // of the LUT they read is a fifth of what 256 pixels along one row span, and more of its lines are still in L1
+            const uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+            const uint32_t lw = (uint32_t)tiled & 0xffu, wx = ((uint32_t)tiled >> 8) & 0xffu;     // log2 of lanes across a wave, waves across
+            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+            const uint32_t lx = lane & ((1u << lw) - 1u), ly = lane >> lw;
+            const uint32_t wvx = wave & ((1u << wx) - 1u), wvy = wave >> wx;
+            const uint32_t wave_rows = 64u >> lw, wg_rows = wave_rows * (4u >> wx);
+            x0 = ((int64_t)bx * ((1u << lw) << wx) + (wvx << lw) + lx) * PX;
+            yy = (by * (uint32_t)rows + (uint32_t)it) * wg_rows + wvy * wave_rows + ly;
+            if (x0 >= w) break;
+        } else {
+            const uint32_t flat = (blockIdx.x * (uint32_t)rows + (uint32_t)it) * 256u + threadIdx.x;
+            yy = flat / nv;
+            x0 = (int64_t)(flat - yy * nv) * PX;
+        }
         const int64_t y = yy;
         if (y >= h) break;
-        const int64_t x0 = (int64_t)(flat - yy * nv) * PX;
         const int n = (int)min((int64_t)PX, w - x0);
         const float tyf = (float)(int)y * inv_th - 0.5f;
         int ty1 = (int)floorf(tyf);
@@ -927,16 +945,27 @@ inline bool launch_interp16(const Disks& d, int64_t h, int64_t w, int64_t pitch,
         const int64_t lanes = ((w + px - 1) / px) * h;
         return (unsigned)((lanes + 256 * (int64_t)rounds - 1) / (256 * (int64_t)rounds));
     };
+    static const bool tiled_ok = [] { const char* v = getenv("SHG_INTERP_TILED"); return !(v && v[0] == '0'); }();
     if (vec && sel_hist) {
         const int rows = 4;                              // rounds per workgroup: amortises the histogram's zeroing and flush
+        if (tiled_ok) {
+            // 4 lanes x 16 rows per wave, 4 waves across: 64 pixels x 16 rows a round (measured over 21 disks: 243 us; 2 waves
+            // across 242, one 270; 2 lanes x 32 rows 262-384; 8 lanes x 8 rows 246-253; the flat sequence 300)
+            const int lw = 2, wx = 2;
+            const int64_t wg_px = (int64_t)4 << (lw + wx), wg_rows = (int64_t)(64 >> lw) * (4 >> wx);
+            const uint32_t tx = (uint32_t)((w + wg_px - 1) / wg_px), ty = (uint32_t)((h + wg_rows * rows - 1) / (wg_rows * rows));
+            k_clahe_interp_vm<4, true><<<dim3(tx * ty, 1u, nz), 256, 0, st>>>(
+                d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, rows, sel_hist, sel_stride, d.zs, 0x10000 | lw | (wx << 8), tx);
+            return true;
+        }
         k_clahe_interp_vm<4, true><<<dim3(blocks(4, rows), 1u, nz), 256, 0, st>>>(
-            d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, rows, sel_hist, sel_stride, d.zs);
+            d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, rows, sel_hist, sel_stride, d.zs, 0, 1u);
         return true;
     }
     if (vec) {
-        k_clahe_interp_vm<4, false><<<dim3(blocks(4, 1), 1u, nz), 256, 0, st>>>(d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, 1, nullptr, 0, d.zs);
+        k_clahe_interp_vm<4, false><<<dim3(blocks(4, 1), 1u, nz), 256, 0, st>>>(d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, 1, nullptr, 0, d.zs, 0, 1u);
     } else {
-        k_clahe_interp_vm<1, false><<<dim3(blocks(1, 1), 1u, nz), 256, 0, st>>>(d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, 1, nullptr, 0, d.zs);
+        k_clahe_interp_vm<1, false><<<dim3(blocks(1, 1), 1u, nz), 256, 0, st>>>(d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, 1, nullptr, 0, d.zs, 0, 1u);
     }
     return false;
 }
