@@ -6,7 +6,7 @@ C=${@:-SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTI
 O=$R/gpurun_out/pmc_kernel
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/sq -- python3 $R/tools/step_loop.py 3 -10,-9,-8,-7,-6,-5,-4,-3,-2,-1,0,1,2,3,4,5,6,7,8,9,10 > /dev/null 2>&1
+timeout 150 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/sq -- python3 $R/tools/step_loop.py 3 -10,-9,-8,-7,-6,-5,-4,-3,-2,-1,0,1,2,3,4,5,6,7,8,9,10 > /dev/null 2>&1
 cd $R
 python3 - "$K" <<'PY'
 import csv, glob, sys, collections
