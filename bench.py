@@ -226,11 +226,15 @@ def main():
 
     # serial pass: one scan at a time, every entry point bracketed by events -> uncontended kernel durations
     serial_steps = max(3, min(10, args.steps))
+    run_scans(2, 1, results=True)           # the first scans that hand their images back allocate host arrays and pinned areas: not timed
+    torch.cuda.synchronize()
     _lib.profile_reset()
     _lib.profile_enable(True)
     barrier()
     t_serial = time.perf_counter()
-    out = run_scans(serial_steps, 1, results=True)
+    out = []
+    for i in range(serial_steps):           # one call per scan: nothing of the next scan (its pass A, launched when it is queued) runs beside this one
+        out += run_scans(1, 1, results=True, first=i)
     torch.cuda.synchronize()
     t_serial = time.perf_counter() - t_serial
     _lib.profile_enable(False)
@@ -406,9 +410,13 @@ def extra_leg(what, pool, shifts, steps, warmup, workers, run_scans, barrier, _l
         td.all_reduce(t, op=td.ReduceOp.MAX)
         times = [float(v) for v in t.tolist()]
     dt = sorted(times)[1]
+    for i in range(2):                      # the one-worker pool's first scans of this shape allocate their arenas: not timed
+        run_scans(1, 1, shifts=shifts, pool=pool, first=i)
+    torch.cuda.synchronize()
     _lib.profile_reset()
     _lib.profile_enable(True)
-    run_scans(3, 1, shifts=shifts, pool=pool)
+    for i in range(3):                      # one call per scan, as in the main serial pass
+        run_scans(1, 1, shifts=shifts, pool=pool, first=i)
     torch.cuda.synchronize()
     _lib.profile_enable(False)
     acc_ms, acc_n = _lib.profile_get('accumulate')
@@ -422,6 +430,9 @@ def extra_leg(what, pool, shifts, steps, warmup, workers, run_scans, barrier, _l
     return {'workload': what, 'value': round(n * steps * world / dt, 1), 'unit': 'frames/s', 'ms_per_step': round(dt / steps * 1e3, 3),
             'steps': steps, 'regions_ms_per_step': [round(t / steps * 1e3, 3) for t in times], 'disks_per_scan': len(shifts),
             'kernel_ms_per_step': round(all_ms / 3, 4),
+            'kernel_time_how': 'event-bracketed entry points of one scan, one scan at a time; an entry point that launches once per 16 disks '
+                               'has its host work between the launches inside the bracket -- the kernels alone are in '
+                               'profiles/*_step_kernel_table_c4.txt (rocprofv3)',
             'pass_a': {'avg_launch_ms': round(acc_ms / acc_n, 5) if acc_n else None, 'algorithmic_bytes': bytes_a,
                        'frac_uncontended': round(bytes_a / (acc_ms / acc_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if acc_n else None},
             'pass_b': {'avg_launch_us': round(ext_ms / ext_n * 1e3, 2) if ext_n else None, 'algorithmic_bytes': bytes_b,
