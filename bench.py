@@ -397,7 +397,9 @@ def extra_leg(what, pool, shifts, steps, warmup, workers, run_scans, barrier, _l
     import torch.distributed as td
     n, h, w = pool[0].shape
     bpp = pool[0].element_size()
-    run_scans(warmup, workers, shifts=shifts, pool=pool)
+    # every slot of the pool (workers + 2 scans in flight) sizes its arenas and leases its pinned areas on its first scans of a new
+    # shape: two rounds through all of them before anything is timed
+    run_scans(max(warmup, 2 * (workers + 2)), workers, shifts=shifts, pool=pool)
     times = []
     for r in range(3):
         barrier()
