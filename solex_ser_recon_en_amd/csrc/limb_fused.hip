@@ -24,6 +24,17 @@
 
 namespace {
 
+// "Everything this workgroup has added to the shared histograms has been performed": what a workgroup says before it counts
+// itself done.  Its results are device-scope atomics (performed at the memory side, read back by the last workgroup with
+// device-scope loads), so all that is needed is that every lane's atomics have been acknowledged (vmcnt) before lane 0 bumps the
+// counter.  An acq_rel fetch_add at agent scope says the same and more: on this multi-XCD part it also writes back and
+// invalidates the XCD's whole L2 (buffer_wbl2 / buffer_inv sc1), once per workgroup, under every kernel running beside it.
+__device__ __forceinline__ void published() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+
 constexpr int TH = 16, TW = 64;              // output tile of both tiled kernels (1024 threads, a pixel each)
 constexpr int MAXR = 16;
 struct GaussW { double w[2 * MAXR + 1]; int radius; };
@@ -272,9 +283,9 @@ __global__ __launch_bounds__(256) void k_limb_select1(const uint32_t* __restrict
     }
     __syncthreads();
     flush_hist(lds, bits1, lc, hist1 + ((size_t)pair << bits1), coarse1 + pair * 256, threadIdx.x, 256);
-    __syncthreads();
+    published();
     if (threadIdx.x == 0)
-        last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1;
+        last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1;
     __syncthreads();
     if (!last) return;
     {   // wave q takes pair q: both digits, then the value
@@ -368,8 +379,8 @@ __global__ __launch_bounds__(256) void k_limb_flood_hist(const uint32_t* __restr
     }
     __syncthreads();
     if (threadIdx.x < 20 && lc[threadIdx.x]) atomicAdd(&counts[threadIdx.x], lc[threadIdx.x]);
-    __syncthreads();                                  // (the counts are device-scope atomics: ordered before the release below)
-    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    published();
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
     if (!last) return;
     if (threadIdx.x < 20) {
