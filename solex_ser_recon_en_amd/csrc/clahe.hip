@@ -174,8 +174,14 @@ __global__ __launch_bounds__(1024) void k_tile_hist16_slices(shg::PtrBatch imgs,
 // hist [tile][65536] u32; chunk_tile [tile][1024] (64-bin sums); se [tile][32][2] = clipped total, excess per 2048 bins.
 __global__ __launch_bounds__(1024) void k_hist_reduce(const uint32_t* __restrict__ part, int slices, int clip,
                                                       uint32_t* __restrict__ hist, uint32_t* __restrict__ chunk_tile,
-                                                      int32_t* __restrict__ se, size_t zs) {
+                                                      int32_t* __restrict__ se, size_t zs, uint32_t* __restrict__ sel_zero, int sel_words) {
     __shared__ int wsum[2][16];
+    // the slot histograms of the selects that follow the blend (which adds to them): zeroed here, by the disk's first workgroup, instead
+    // of by a memset launch of their own (every launch is an L2 write-back and invalidate under the other scans' kernels)
+    if (sel_zero && blockIdx.x == 0 && blockIdx.y == 0) {
+        uint32_t* z = zdisk(sel_zero, zs);
+        for (int i = threadIdx.x; i < sel_words; i += 1024) z[i] = 0;
+    }
     part = zdisk(part, zs);
     hist = zdisk(hist, zs);
     chunk_tile = zdisk(chunk_tile, zs);
@@ -1019,7 +1025,8 @@ namespace {
 // workspace at `workspace + i * disks->zs`; only the atomics-free 16-bit path takes more than one.
 int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_per_px, double clip_limit, int tiles,
                void* dst, int64_t dst_pitch, void* workspace, size_t workspace_bytes, shg_stream_t stream, const uint32_t** chunk_tile_out,
-               uint32_t* sel_hist, int sel_stride, bool* sel_pass0_done, const Disks* disks = nullptr) {
+               uint32_t* sel_hist, int sel_stride, bool* sel_pass0_done, const Disks* disks = nullptr, bool* sel_zeroed = nullptr) {
+    if (sel_zeroed) *sel_zeroed = false;                 // -> true when the histogram reduction has zeroed sel_hist (the caller asked by passing it)
     if (chunk_tile_out) *chunk_tile_out = nullptr;
     if (sel_pass0_done) *sel_pass0_done = false;
     SHG_REQUIRE(img && dst && workspace, SHG_E_ARG, "shg_clahe: null pointer");
@@ -1068,7 +1075,10 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
           k_tile_hist16_slices<<<dim3((unsigned)slices, (unsigned)ntiles, nz), 1024, HIST16 * 2, st>>>(dset.src, h, w, pitch, tiles, th, tw, part, dset.zs,
                                                                                                     (int)slice_rows, vec);
           if (int e = shg::check_launch("k_tile_hist16_slices")) return e;
-          k_hist_reduce<<<dim3(32, (unsigned)ntiles, nz), 1024, 0, st>>>(part, (int)slices, clip, hist, chunk_tile, se, dset.zs); }
+          const bool zero_sel = sel_hist && sel_zeroed;
+          k_hist_reduce<<<dim3(32, (unsigned)ntiles, nz), 1024, 0, st>>>(part, (int)slices, clip, hist, chunk_tile, se, dset.zs, zero_sel ? sel_hist : nullptr,
+                                                                          zero_sel ? SEL_SLOTS * sel_stride : 0);
+          if (zero_sel) *sel_zeroed = true; }
         if (int e = shg::check_launch("k_hist_reduce")) return e;
         { SHG_PROF("clahe_lut", st); k_tile_lut16_blocks<<<dim3(32, (unsigned)ntiles, (unsigned)dset.n), 1024, 0, st>>>(hist, se, clip, lut_scale, lut, dset.zs); }
         if (int e = shg::check_launch("k_tile_lut16_blocks")) return e;
@@ -1108,7 +1118,15 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
         { SHG_PROF("clahe_interp", st); k_clahe_interp<uint8_t, 256><<<igrid, 256, 0, st>>>(static_cast<const uint8_t*>(img), h, w, pitch, tiles, inv_tw, inv_th, lut,
                                                             static_cast<uint8_t*>(dst), dst_pitch); }
     }
-    return shg::check_launch("k_clahe_interp");
+    if (int e = shg::check_launch("k_clahe_interp")) return e;
+    if (sel_hist && sel_zeroed) {                        // nothing has counted into sel_hist on this path: zero it the plain way
+        if (hipError_t e = hipMemsetAsync(sel_hist, 0, (size_t)SEL_SLOTS * sel_stride * sizeof(uint32_t), st)) {
+            shg::set_error("shg_clahe: memset: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        *sel_zeroed = true;
+    }
+    return 0;
 }
 }  // namespace
 
@@ -1229,15 +1247,14 @@ extern "C" int shg_contrast_stats_u16(const uint16_t* frame, int64_t h, int64_t 
     // When the tile grid divides the image, CLAHE's tile histograms (still at the head of its workspace) add up to the
     // histogram of the frame: np.percentile(frame, q)'s two order statistics are read off them (k_chunk_sums, k_hist_ranks)
     // instead of selecting over the image again (two passes of k_select16_pass).
-    // the select on the CLAHE image (3 ranks): its histograms are zeroed up front so that the interpolation kernel can count
+    // the select on the CLAHE image (3 ranks): its histograms are zero before the interpolation kernel, which counts
     // the first pass while the pixels are in its registers
     uint32_t* sel3 = reinterpret_cast<uint32_t*>(ws + c + s2);
-    {
-        hipError_t e = hipMemsetAsync(sel3, 0, (size_t)SEL_SLOTS * (1 + 3) * 256 * sizeof(uint32_t), shg::as_stream(stream));
-        if (e != hipSuccess) { shg::set_error("shg_contrast_stats_u16: %s", hipGetErrorString(e)); return (int)e; }
-    }
-    bool pass0_done = false;
-    if (int e = clahe_impl(frame, h, w, pitch, 2, clip_limit, tiles, cl1, cl1_pitch, ws, c, stream, &chunk_tile, sel3, (1 + 3) * 256, &pass0_done)) return e;
+    bool pass0_done = false, sel_zeroed = false;         // (zeroed by CLAHE's histogram reduction on the way, or by a memset where that does not run)
+    if (int e = clahe_impl(frame, h, w, pitch, 2, clip_limit, tiles, cl1, cl1_pitch, ws, c, stream, &chunk_tile, sel3, (1 + 3) * 256, &pass0_done, nullptr,
+                           &sel_zeroed))
+        return e;
+    SHG_REQUIRE(sel_zeroed, SHG_E_RUNTIME, "shg_contrast_stats_u16: the select histograms were not zeroed");
     if (h % tiles == 0 && w % tiles == 0) {
         const size_t s3r = (shg_select_u16_workspace_bytes(3) + 255) / 256 * 256;
         uint32_t* chunk_sums = reinterpret_cast<uint32_t*>(ws + c + s2 + s3r);
@@ -1306,16 +1323,12 @@ int shg::contrast_stats_batch(const uint16_t* const* host_frames, int64_t k, int
         }
         // the selects on the CLAHE images: their slot histograms zeroed up front, every disk's in its own area
         uint32_t* sel3 = reinterpret_cast<uint32_t*>(ws + c + s2);
-        if (hipError_t e = hipMemset2DAsync(sel3, per, 0, (size_t)SEL_SLOTS * (1 + 3) * 256 * sizeof(uint32_t), (size_t)m, st)) {
-            shg::set_error("shg_contrast_stats_u16: %s", hipGetErrorString(e));
-            return (int)e;
-        }
         const uint32_t* chunk_tile = nullptr;
-        bool pass0_done = false;
+        bool pass0_done = false, sel_zeroed = false;
         if (int e = clahe_impl(host_frames[i0], h, w, pitch, 2, clip_limit, tiles, host_cl1[i0], cl1_pitch, ws, c, stream, &chunk_tile, sel3, (1 + 3) * 256,
-                               &pass0_done, &d))
+                               &pass0_done, &d, &sel_zeroed))
             return e;
-        SHG_REQUIRE(chunk_tile, SHG_E_RUNTIME, "shg_contrast_stats_u16: the batched path did not take the slice histograms");
+        SHG_REQUIRE(chunk_tile && sel_zeroed, SHG_E_RUNTIME, "shg_contrast_stats_u16: the batched path did not take the slice histograms");
         {
             SHG_PROF("hist_ranks", st);
             k_hist_ranks<<<dim3(2u, 1u, (unsigned)m), 1024, 0, st>>>(reinterpret_cast<const uint32_t*>(ws), chunk_tile, tiles * tiles, tiles * tiles, ranks,
