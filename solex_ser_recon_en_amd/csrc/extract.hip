@@ -17,6 +17,10 @@
 #include <stdlib.h>
 #include "shg_common.h"
 
+namespace shg {
+thread_local bool t_minmax_slots_zeroed = false;
+}
+
 namespace {
 
 constexpr int TY = 64;        // slit rows per workgroup (= lanes of a wave)
@@ -340,6 +344,8 @@ extern "C" int shg_extract_columns_minmax(const void* stack, int64_t n_frames, i
                                           int bytes_per_px, int64_t frame_stride_px, const int32_t* ind_l, const double* lw, const double* rw,
                                           int n_shifts, uint16_t* disks, int64_t row_pitch, int64_t plane_stride,
                                           int64_t n_cols, int64_t k_offset, int flip_x, uint32_t* minmax_slots, shg_stream_t stream) {
+    const bool slots_zeroed = shg::t_minmax_slots_zeroed;        // (first thing: whatever this call returns, the hint is spent)
+    shg::t_minmax_slots_zeroed = false;
     SHG_REQUIRE(stack && ind_l && lw && rw && disks, SHG_E_ARG, "shg_extract_columns: null pointer");
     SHG_REQUIRE(n_frames > 0 && height > 0 && width > 0 && n_shifts > 0, SHG_E_ARG, "shg_extract_columns: empty input");
     SHG_REQUIRE(bytes_per_px == 1 || bytes_per_px == 2, SHG_E_ARG, "shg_extract_columns: bytes_per_px must be 1 or 2");
@@ -376,7 +382,7 @@ extern "C" int shg_extract_columns_minmax(const void* stack, int64_t n_frames, i
     // instantiation 14 / 13 / 14 / 14 us for batch 2 / 4 / 8 / 16 (16 us with the four-shift one)
     const int batch2 = 4;
     const int batch = batch_env > 0 ? batch_env : (n_shifts > SC_MAX ? 8 : (n_shifts <= 2 ? batch2 : 4));
-    if (minmax_slots) {
+    if (minmax_slots && !slots_zeroed) {
         if (hipError_t e = hipMemsetAsync(minmax_slots, 0, (size_t)n_shifts * 64 * 2 * sizeof(uint32_t), st)) {
             shg::set_error("shg_extract_columns: memset: %s", hipGetErrorString(e));
             return (int)e;
@@ -422,6 +428,8 @@ extern "C" int shg_extract_columns_dense(const void* stack, int64_t n_frames, in
                                          const double* rw, const int32_t* host_shifts, int n_shifts, uint16_t* disks, int64_t row_pitch,
                                          int64_t plane_stride, int64_t n_cols, int64_t k_offset, int flip_x, uint32_t* minmax_slots,
                                          shg_stream_t stream) {
+    const bool slots_zeroed = shg::t_minmax_slots_zeroed;        // (first thing: whatever this call returns, the hint is spent)
+    shg::t_minmax_slots_zeroed = false;
     SHG_REQUIRE(stack && ind_l && base_col && lw && rw && host_shifts && disks, SHG_E_ARG, "shg_extract_columns_dense: null pointer");
     SHG_REQUIRE(n_frames > 0 && height > 0 && width > 0, SHG_E_ARG, "shg_extract_columns_dense: empty input");
     SHG_REQUIRE(shg_extract_dense_fits(host_shifts, n_shifts), SHG_E_UNSUPPORTED, "shg_extract_columns_dense: the shifts are not 3..%d consecutive integers", DS_MAX);
@@ -440,7 +448,7 @@ extern "C" int shg_extract_columns_dense(const void* stack, int64_t n_frames, in
     PlaneOfOffset po = {};
     for (int i = 0; i < n_shifts; ++i) po.v[host_shifts[i] - lo] = i;
     hipStream_t st = shg::as_stream(stream);
-    if (minmax_slots) {
+    if (minmax_slots && !slots_zeroed) {
         if (hipError_t e = hipMemsetAsync(minmax_slots, 0, (size_t)n_shifts * 64 * 2 * sizeof(uint32_t), st)) {
             shg::set_error("shg_extract_columns_dense: memset: %s", hipGetErrorString(e));
             return (int)e;

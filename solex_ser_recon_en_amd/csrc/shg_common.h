@@ -31,6 +31,10 @@ inline hipStream_t as_stream(shg_stream_t s) { return reinterpret_cast<hipStream
 // The frame-pass lane (streams.hip): launch(stream, arg) runs on the current device's lane when one is set -- `st` then
 // waits for it through an event -- and on `st` itself otherwise.
 int on_frame_pass_lane(hipStream_t st, int (*launch)(hipStream_t, void*), void* arg);
+
+// Set by a stage that has already cleared the extrema's slots (stages.hip: in the launch that uploads the plan); the extraction entry point
+// this thread calls next then skips its memset, and resets the flag.
+extern thread_local bool t_minmax_slots_zeroed;
 // The same launch with nobody waiting: after what `after` holds so far, *done recorded behind it (the caller's to destroy).
 // -> 1 when the device has no lane (nothing launched), 0 when launched, another value on error.
 int prelaunch_on_lane(hipStream_t after, int (*launch)(hipStream_t, void*), void* arg, hipEvent_t* done);

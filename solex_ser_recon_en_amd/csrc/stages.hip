@@ -65,6 +65,14 @@ __global__ __launch_bounds__(256) void k_words(uint32_t* __restrict__ dst, const
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
+// the same, and `zero_words` words at `zero` cleared on the way (a scratch area the next kernel accumulates into: one launch instead of a
+// copy and a memset -- every launch is an L2 write-back and invalidate under the other scans' kernels)
+__global__ __launch_bounds__(256) void k_words_zero(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t n_words,
+                                                    uint32_t* __restrict__ zero, size_t zero_words) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < zero_words; i += (size_t)gridDim.x * 256) zero[i] = 0;
+}
+
 // comp = [m | idx[n] | root[n]] on the device -> the same layout in the staging area, only the m entries in use.
 __global__ __launch_bounds__(256) void k_edge_list(const int32_t* __restrict__ comp, int64_t n, int32_t* __restrict__ dst) {
     const int64_t m = comp[0];
@@ -240,7 +248,15 @@ extern "C" int shg_stage_extract(const void* stack, int64_t n_frames, int64_t he
     Staging stg;
     STAGE_TRY(map_staging(host_pinned, &stg, "shg_stage_extract"));
     const char* end = dense ? reinterpret_cast<const char*>(h_base + ih) : reinterpret_cast<const char*>(h_w2 + 2 * ih);
-    STAGE_TRY(move_words(ind_l, stg.on_device(h_ind), (size_t)(end - reinterpret_cast<const char*>(h_ind)), st));
+    if (minmax_slots) {                                  // the plan goes up and the extrema's slots are cleared in one launch
+        const size_t n_words = ((size_t)(end - reinterpret_cast<const char*>(h_ind)) + 3) / 4, zero_words = (size_t)n_shifts * 130;
+        const unsigned blocks = (unsigned)std::min<size_t>((std::max(n_words, zero_words) + 255) / 256, 64);
+        k_words_zero<<<blocks, 256, 0, st>>>(reinterpret_cast<uint32_t*>(ind_l), reinterpret_cast<const uint32_t*>(stg.on_device(h_ind)), n_words, minmax_slots, zero_words);
+        STAGE_TRY(shg::check_launch("k_words_zero"));
+        shg::t_minmax_slots_zeroed = true;               // (read and reset by the extraction entry point this thread calls next)
+    } else {
+        STAGE_TRY(move_words(ind_l, stg.on_device(h_ind), (size_t)(end - reinterpret_cast<const char*>(h_ind)), st));
+    }
     if (dense)
         return shg_extract_columns_dense(stack, n_frames, height, width, bytes_per_px, frame_stride_px, ind_l, base, w2, w2 + ih, host_shifts, n_shifts,
                                          disks, row_pitch, plane_stride, n_cols, k_offset, flip_x, minmax_slots, stream);
