@@ -623,6 +623,36 @@ def test_row_factor_paths_match_float_image(ops, orc, golden):
     np.testing.assert_array_equal(host(ops.scale_rows_u16(dev(img), np.ones(img.shape[0]), rf)), np.minimum(fimg, 65535).astype(np.uint16))
 
 
+@pytest.mark.parametrize('h,w', [(7, 5), (9, 8), (33, 17), (64, 2049), (50, 2096), (5, 4100), (130, 1023)])
+def test_row_kernels_on_widths_around_their_vector_and_workgroup_sizes(ops, h, w):
+    """k_scale_rows8, k_products8 and the CLAHE blend deal their lanes from one flat (row, vector) sequence: widths below a vector,
+    just past a multiple of a workgroup's span (2049, 2096, 4100), one short of it (1023), row counts that are not multiples of
+    the rows a lane takes -- against plain NumPy, pixel for pixel, padding columns untouched."""
+    rng = np.random.default_rng(h * 10007 + w)
+    img = rng.integers(0, 65536, (h, w)).astype(np.uint16)
+    c = 0.5 + rng.random(h)
+    want = np.minimum(img.astype(np.float64) * c[:, None], 65535.0).astype(np.uint16)       # (img.T * c).T, saturate, truncate
+    np.testing.assert_array_equal(host(ops.scale_rows_u16(dev(img), c)), want)
+
+    cl1 = rng.integers(0, 65536, (h, w)).astype(np.uint16)
+    lo_hi6 = [9000.0, 61000.0, 0.0, 11000.0, 3000.5, 64000.0]
+
+    def rescale(a, lo, hi):                                      # rescale_brightness, solex_util.py:519-524
+        v = 65535.0 * (a.astype(np.float64) - lo) / (hi - lo)
+        return np.clip(v, 0, 65535).astype(np.uint16)
+    disc = (w // 2, h // 2, max(1, min(h, w) // 3))
+    hc, protus, cc = (host(t) for t in ops.contrast_products_u16(dev(img), dev(cl1), lo_hi6, disc))
+    np.testing.assert_array_equal(hc, rescale(img, lo_hi6[0], lo_hi6[1]))
+    np.testing.assert_array_equal(cc, rescale(cl1, lo_hi6[4], lo_hi6[5]))
+    want_p = rescale(img, lo_hi6[2], lo_hi6[3])
+    yy, xx = np.mgrid[0:h, 0:w]
+    ady = np.abs(yy - disc[1])
+    half = np.floor(np.sqrt(np.maximum(disc[2] ** 2 - ady.astype(np.float64) ** 2, 0)) + 1e-9).astype(np.int64)
+    inside = (ady <= disc[2]) & (np.abs(xx - disc[0]) <= half)
+    want_p[inside] = 80                                          # cv2.circle(frame_protus, centre, r, 80, -1)
+    np.testing.assert_array_equal(protus, want_p)
+
+
 @pytest.mark.parametrize('h,w', [(70, 90), (1, 1), (333, 1027), (2000, 64)])
 def test_select_u16_is_exact(ops, h, w):
     rng = np.random.default_rng(h + w)
