@@ -653,6 +653,31 @@ def test_row_kernels_on_widths_around_their_vector_and_workgroup_sizes(ops, h, w
     np.testing.assert_array_equal(protus, want_p)
 
 
+@pytest.mark.parametrize('h,w,tiles', [(96, 104, 2), (130, 200, 2), (257, 2096, 2), (1000, 1048, 2), (90, 120, 3), (77, 50, 2)])
+def test_contrast_stats_is_clahe_plus_the_order_statistics(ops, orc, h, w, tiles):
+    """shg_contrast_stats_u16 (the first half of image_process in one call): the blend that lays its lanes out in 16 x 16 tiles and counts the
+    first select pass on the way, the select histograms zeroed by CLAHE's histogram reduction, the percentiles read off the tile
+    histograms or selected -- cl1 equals the oracle's CLAHE and the five statistics are NumPy's order statistics, on shapes that do
+    and do not divide into tiles / vectors / workgroup spans."""
+    from solex_ser_recon_en_amd.order_stats import lerp_order_stats
+    rng = np.random.default_rng(h * 31 + w)
+    yy, xx = np.mgrid[0:h, 0:w]
+    r = np.hypot(yy - h / 2, xx - w / 2) / (0.45 * min(h, w))
+    disc = np.where(r < 1, 0.3 + 0.6 * np.sqrt(np.clip(1 - r * r, 0, 1)), 0.02)
+    img = np.clip((disc + 0.01 * rng.standard_normal((h, w))) * 65535, 0, 65535).astype(np.uint16)
+    n = h * w
+    f_lo, f_hi, _ = lerp_order_stats(n, 99.9999)
+    c_lo, c_hi, _ = lerp_order_stats(n, 10)
+    out5 = torch.zeros(5, dtype=torch.float64, device='cuda')
+    for small in (False, True):
+        out5.zero_()
+        cl1 = host(ops.contrast_stats_u16(dev(img), [f_lo, f_hi], [c_lo, c_hi, n - 1], out5, 0.8, tiles, small_workspace=small))
+        want = orc.clahe(img, 0.8, tiles)
+        np.testing.assert_array_equal(cl1, want)
+        fs, cs = np.sort(img.ravel()), np.sort(want.ravel())
+        np.testing.assert_array_equal(host(out5), np.array([fs[f_lo], fs[f_hi], cs[c_lo], cs[c_hi], cs[n - 1]], dtype=np.float64))
+
+
 @pytest.mark.parametrize('h,w', [(70, 90), (1, 1), (333, 1027), (2000, 64)])
 def test_select_u16_is_exact(ops, h, w):
     rng = np.random.default_rng(h + w)
