@@ -482,6 +482,14 @@ def _scan_batch_native(tasks, decoder, n_workers, scan_here, collected):
         while inflight:
             finish_oldest()
     finally:
+        # whatever ends this loop early (an interrupt in the feeding thread): the pool's threads still read the requests and
+        # write into the buffers of the scans in flight -- those stay alive until the pool has let go of them
+        while inflight:
+            _, call = inflight.popleft()
+            try:
+                call.call.wait()
+            except BaseException:       # noqa: BLE001 -- the first error is the one that is raised
+                pass
         if previous is not None:
             os.sched_setaffinity(0, previous)
     if errors:
@@ -628,6 +636,8 @@ class _OneCall:
             hdr['NAXIS1'] = rdr.iw
             if options['save_fit'] or plots or (phase >= 3 and not r['limb_fitted'] and requested[0] and '_nolog' not in options):
                 disk_list = [DeviceImage(r['disks'][i], minmax=r['extrema'][i]) for i in range(len(shifts))]
+            if options.get('_keep_raw'):                    # tests and bench.py's parity legs: the raw disks of a one-call scan
+                options['_raw_disks'] = [DeviceImage(r['disks'][i]) for i in range(len(shifts))]
             for i, disk in enumerate(disk_list):
                 if options['save_fit'] and requested[i]:
                     outputs.submit(write_fits, output_path(basefich0 + '_shift=' + str(shifts[i]) + '_raw.fits', options), disk, hdr)

@@ -115,12 +115,20 @@ extern "C" int shg_pool_submit(shg_pool* p, const shg_scan_request* rq, shg_scan
 extern "C" int shg_pool_submit_after(shg_pool* p, const shg_scan_request* rq, shg_scan_result* rs, shg_stream_t after, int64_t* ticket) {
     SHG_REQUIRE(p && rq && rs && ticket, SHG_E_ARG, "shg_pool_submit: null pointer");
     static const bool pass_ahead = [] { const char* v = getenv("SHG_PASS_AHEAD"); return !(v && v[0] == '0'); }();
+    {
+        std::lock_guard<std::mutex> lk(p->mu);                // before anything is launched for a scan nobody will run
+        SHG_REQUIRE(!p->stop, SHG_E_RUNTIME, "shg_pool_submit: the pool is shutting down");
+    }
     int ahead = 0;
     if (pass_ahead)
         if (int e = shg_scan_prelaunch(rq, after, &ahead)) return e;
     {
         std::lock_guard<std::mutex> lk(p->mu);
-        SHG_REQUIRE(!p->stop, SHG_E_RUNTIME, "shg_pool_submit: the pool is shutting down");
+        if (p->stop) {                                        // (shut down between the two locks: the pass on the lane is waited for and dropped)
+            if (ahead) (void)shg_pass_a_forget(rq->workspace);
+            shg::set_error("shg_pool_submit: the pool is shutting down");
+            return SHG_E_RUNTIME;
+        }
         *ticket = p->next_ticket++;
         shg_pool::Job j;
         j.rq = rq;

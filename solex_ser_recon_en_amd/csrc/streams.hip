@@ -129,6 +129,10 @@ extern "C" int shg_stream_create(int priority, const uint32_t* host_cu_mask, int
         bool any = false;
         for (int i = 0; i < n_mask_words; ++i) any = any || host_cu_mask[i] != 0;
         SHG_REQUIRE(any, SHG_E_ARG, "shg_stream_create: empty CU mask");
+        // (There is no non-blocking variant of this call: a CU-masked stream synchronises implicitly with the null stream, which
+        // the thread that feeds a scan pool and torch use by default.  The SHG_CHAIN_CUS / SHG_CHAIN_CU_MASK experiment knobs
+        // therefore serialise the chains against whatever that stream holds: fine for the sweep they exist for, which found no
+        // mask that pays -- tools/sweep_lane.sh -- but not a way to run production scans.)
         e = hipExtStreamCreateWithCUMask(&st, (uint32_t)n_mask_words, host_cu_mask);
     } else {
         int least = 0, greatest = 0;                              // numerically: greatest priority <= least priority

@@ -239,8 +239,13 @@ __device__ __forceinline__ bool select2_buckets(ValFn val, int n, int64_t rank_l
 }
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
+    // The butterflies' lane addresses are formed anew in every call: hoisted out as common subexpressions they stay live
+    // across the whole kernel, and under k_rowpair_stats' 64-register cap four of them were spilled to scratch (16 bytes
+    // written and read back per lane, 60 MB per 21-disk launch).  The empty asm hides the lane number from that hoisting.
+    int self = threadIdx.x & 63;
+    asm volatile("" : "+v"(self));
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl(v, self ^ d);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -566,11 +571,9 @@ int shg::rowpair_stats_batch(const uint16_t* const* host_imgs, int64_t k, int64_
         return 0;
     }
     const size_t lds_bytes = (size_t)w * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowpair_stats), hipFuncAttributeMaxDynamicSharedMemorySize, MAXN * 8);
-        attr_set = true;
-    }
+    static const bool attr_set =                         // (a function-local static: initialised once, also with several pool threads here)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowpair_stats), hipFuncAttributeMaxDynamicSharedMemorySize, MAXN * 8) == hipSuccess;
+    (void)attr_set;
     SHG_PROF("rowpair_stats", st);
     for (int64_t i0 = 0; i0 < k; i0 += shg::kMaxBatch) {
         const int m = (int)std::min<int64_t>(shg::kMaxBatch, k - i0);

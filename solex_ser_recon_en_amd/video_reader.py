@@ -63,20 +63,116 @@ class _UploadJob:
                 self.done.set()
 
 
+def _direct_mode():
+    """SHG_READ_DIRECT = 0 (never), 1 (whenever the file system takes O_DIRECT), auto (default: O_DIRECT for files that are
+    not in the page cache)."""
+    v = os.environ.get('SHG_READ_DIRECT', 'auto').strip().lower()
+    return v if v in ('0', '1') else 'auto'
+
+
+_DIRECT_ALIGN = 4096                     # O_DIRECT wants offset, length and address on the device's logical block size
+
+
+def _page_cache_share(fd, offset, nbytes):
+    """Share of [offset, offset + nbytes) of the file that the page cache holds (mincore over a mapping nobody touches), or
+    1.0 when that cannot be asked: a cached file is read through the cache at memcpy speed, a cold one is better read
+    straight into pinned memory."""
+    import ctypes
+    import mmap
+    try:
+        libc = ctypes.CDLL(None, use_errno=True)
+        libc.mmap.restype = ctypes.c_void_p
+        libc.mmap.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long]
+        libc.munmap.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        libc.mincore.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        page = mmap.PAGESIZE
+        lo = offset // page * page
+        length = offset + nbytes - lo
+        addr = libc.mmap(None, length, mmap.PROT_READ, mmap.MAP_SHARED, fd, lo)
+        if addr is None or addr == ctypes.c_void_p(-1).value:
+            return 1.0
+        try:
+            n_pages = (length + page - 1) // page
+            vec = (ctypes.c_ubyte * n_pages)()
+            if libc.mincore(addr, length, vec) != 0:
+                return 1.0
+            return sum(b & 1 for b in vec) / float(n_pages)
+        finally:
+            libc.munmap(addr, length)
+    except (OSError, ValueError, AttributeError):
+        return 1.0
+
+
+class _FileHandles:
+    """The descriptors a reader thread holds for the file it is working through: the buffered one and, where the file system
+    takes it and the file is cold, an O_DIRECT one (file -> pinned buffer by DMA, no copy through the page cache)."""
+
+    def __init__(self):
+        self.path, self.fd, self.dfd = None, -1, -1
+
+    def open(self, path, offset, nbytes):
+        if path == self.path:
+            return
+        self.close()
+        self.fd = os.open(path, os.O_RDONLY)
+        self.path = path
+        mode = _direct_mode()
+        if mode != '0' and hasattr(os, 'O_DIRECT'):
+            try:
+                if mode == '1' or _page_cache_share(self.fd, offset, min(nbytes, 4 << 20)) < 0.5:
+                    self.dfd = os.open(path, os.O_RDONLY | os.O_DIRECT)
+            except OSError:                                  # tmpfs and friends: EINVAL
+                self.dfd = -1
+
+    def close(self):
+        for fd in (self.fd, self.dfd):
+            if fd >= 0:
+                os.close(fd)
+        self.path, self.fd, self.dfd = None, -1, -1
+
+
+def _read_chunk(handles, mv, offset, nbytes):
+    """[offset, offset + nbytes) of the file into the pinned buffer behind `mv` (page-aligned, _DIRECT_ALIGN bytes longer than
+    the largest chunk).  -> the position of the first wanted byte in the buffer.  O_DIRECT reads the enclosing aligned span (the
+    SER header is 178 bytes: no frame starts on a block); a short or refused direct read falls back to the buffered one."""
+    if handles.dfd >= 0:
+        lo = offset // _DIRECT_ALIGN * _DIRECT_ALIGN
+        span = (offset + nbytes - lo + _DIRECT_ALIGN - 1) // _DIRECT_ALIGN * _DIRECT_ALIGN
+        try:
+            got = 0
+            while got < offset + nbytes - lo:
+                r = os.preadv(handles.dfd, [mv[got:span]], lo + got)
+                if r <= 0 or (r % _DIRECT_ALIGN and got + r < offset + nbytes - lo):
+                    raise OSError('short direct read')
+                got += r
+            return offset - lo
+        except OSError:
+            os.close(handles.dfd)
+            handles.dfd = -1
+    got = 0
+    while got < nbytes:
+        r = os.preadv(handles.fd, [mv[got:nbytes]], offset + got)
+        if r <= 0:
+            raise Exception('error input file ' + str(handles.path) + ': short read')
+        got += r
+    return 0
+
+
 class _Uploader:
     """File -> pinned host -> HBM for one device, as a standing service: `readers` long-lived threads, each with two pinned
     staging buffers and a copy stream of its own, take (file, offset, bytes, destination) chunks from one queue -- of whichever
     file is being decoded, and of the next one as soon as its chunks are queued, so the link does not idle across a file
     boundary (before: eight threads, eight streams and sixteen buffer leases per file, and a drain at every file's end).
-    A chunk is one preadv() of whole frames into pinned memory (no interpreter lock) and one asynchronous 2-D hipMemcpy into
-    the (8 KiB-pitched) frames of the stack."""
+    A chunk is one preadv() of whole frames into pinned memory (no interpreter lock; O_DIRECT for a file the page cache does
+    not hold, see _read_chunk) and one asynchronous 2-D hipMemcpy into the (8 KiB-pitched) frames of the stack.  One service
+    per (device, readers): a reader's buffers grow when a file with larger chunks comes along."""
 
     _all = {}
     _guard = threading.Lock()
 
-    def __init__(self, device, readers, chunk_bytes):
+    def __init__(self, device, readers):
         import queue
-        self.device, self.chunk_bytes = device, chunk_bytes
+        self.device = device
         self.jobs = queue.SimpleQueue()
         self.threads = [threading.Thread(target=self._reader, args=(i,), name='shg-upload-%s-%d' % (device, i), daemon=True)
                         for i in range(readers)]
@@ -84,22 +180,24 @@ class _Uploader:
             t.start()
 
     @classmethod
-    def of(cls, device, readers, chunk_bytes):
-        key = (str(device), int(readers), int(chunk_bytes))
+    def of(cls, device, readers):
+        key = (str(device), int(readers))
         with cls._guard:
             up = cls._all.get(key)
             if up is None or not all(t.is_alive() for t in up.threads):
-                up = cls._all[key] = cls(device, readers, chunk_bytes)
+                up = cls._all[key] = cls(device, readers)
             return up
 
     def _reader(self, tid):
+        import queue
         from . import _lib
         from .device import bind_thread
         torch.cuda.set_device(self.device)
         bind_thread('io', self.device)                       # off the scan workers' cores (device.cpu_plan)
         stream = torch.cuda.Stream(device=self.device)
-        bufs = [torch.empty(self.chunk_bytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        bufs = [None, None]
         pending = [None, None]                               # per buffer: (event of its copy, job) still in flight
+        handles = _FileHandles()
         slot = 0
 
         def settle(i):
@@ -113,27 +211,28 @@ class _Uploader:
                     job.chunk_done(e)
 
         while True:
-            if self.jobs.empty():                            # nothing queued: what is in flight lands before we sleep
+            # One atomic fetch: "is the queue empty?" followed by a blocking get() let another reader take the last chunk in
+            # between, and this one then slept with a copy in flight whose chunk_done() nobody would ever call.
+            try:
+                item = self.jobs.get_nowait()
+            except queue.Empty:                              # nothing queued: what is in flight lands before we sleep
                 settle(0)
                 settle(1)
-            path, offset, nbytes, dst, dst_pitch, frame_bytes, m, ready, job = self.jobs.get()
+                handles.close()
+                item = self.jobs.get()
+            path, offset, nbytes, dst, dst_pitch, frame_bytes, m, ready, job = item
             settle(slot)                                     # this buffer's previous copy has landed
             try:
-                view = bufs[slot][:nbytes]
-                mv = memoryview(view.numpy())
-                fd = os.open(path, os.O_RDONLY)
-                try:
-                    got = 0
-                    while got < nbytes:
-                        r = os.preadv(fd, [mv[got:]], offset + got)
-                        if r <= 0:
-                            raise Exception('error input file ' + str(path) + ': short read')
-                        got += r
-                finally:
-                    os.close(fd)
+                need = nbytes + 2 * _DIRECT_ALIGN
+                if bufs[slot] is None or bufs[slot].numel() < need:
+                    bufs[slot] = None
+                    bufs[slot] = torch.empty(need, dtype=torch.uint8).pin_memory()
+                view = bufs[slot]
+                handles.open(path, offset, nbytes)
+                skip = _read_chunk(handles, memoryview(view.numpy()), offset, nbytes)
                 if ready is not None:
                     stream.wait_event(ready)                 # the stack may be a recycled block: its allocating stream drains first
-                _lib.check(_lib.lib.shg_upload_frames(dst, dst_pitch, view.data_ptr(), frame_bytes, m, stream.cuda_stream), 'shg_upload_frames')
+                _lib.check(_lib.lib.shg_upload_frames(dst, dst_pitch, view.data_ptr() + skip, frame_bytes, m, stream.cuda_stream), 'shg_upload_frames')
                 ev = torch.cuda.Event()
                 ev.record(stream)
                 pending[slot] = (ev, job)
@@ -264,10 +363,9 @@ class video_reader:
         base_ptr = stack.data_ptr()
         base = SER_HEADER_BYTES + k0 * frame_bytes
         chunk_frames = max(1, chunk_bytes // frame_bytes)
-        chunk_cap = max(chunk_bytes, frame_bytes)
         n_chunks = (n + chunk_frames - 1) // chunk_frames
         readers = max(1, readers or min(8, os.cpu_count() or 1))
-        up = _Uploader.of(device, readers, chunk_cap)
+        up = _Uploader.of(device, readers)
         # the stack may be a block the caching allocator recycled from the previous file: kernels queued on the allocating
         # stream may still read it, so no upload starts before that stream has drained up to here
         ready = torch.cuda.Event()

@@ -1,0 +1,173 @@
+"""BASELINE's configurations at full size through the route bench.py times and the CLI takes by default: solex_do_work with
+several files in flight -- one shg_scan_file call per file (csrc/scan.hip) made by the native scan pool (csrc/pool.hip), pass A on
+the frame-pass lane and launched when the scan is queued (csrc/streams.hip).  tests/test_fullsize_gpu.py holds the same
+configurations against the oracle on the stage-by-stage route; here every raw disk and every product of the pooled route is
+held bit for bit against that route, and the oracle (oracle/pipeline_oracle.py) checks the pooled route directly.
+Reference loop body: Solex_recon.py:33-42 (Pool), :105-133 (the disks of a file)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from solex_ser_recon_en_amd import SHG_MAIN, Solex_recon, ops, outputs, synth
+    return SHG_MAIN, Solex_recon, ops, outputs, synth
+
+
+def run_batch(pkg, stacks, extra, pooled, monkeypatch):
+    """-> per file: (options, raw disks as arrays, [(cc, protus), ...] as arrays)"""
+    SHG_MAIN, Solex_recon, ops, outputs, synth = pkg
+    from solex_ser_recon_en_amd.video_reader import array_reader
+    monkeypatch.setenv('SHG_SCAN_CALL', '1' if pooled else '0')
+    tasks = []
+    for st in stacks:
+        opts = SHG_MAIN.default_options()
+        opts.update(extra, _nolog=True, _keep_raw=True)
+        tasks.append((array_reader(st), opts))
+    if pooled:
+        res = Solex_recon.solex_do_work(tasks, True, distribute='none', return_results=True, workers=4)
+        disks = [[np.asarray(d) for d in opts['_raw_disks']] for _, opts in tasks]
+    else:                                                   # one file at a time, one C call per stage
+        res, disks = [], []
+        for rdr, opts in tasks:
+            disk_list, bounds, hdr = Solex_recon.solex_read(rdr, opts)
+            disks.append([np.asarray(d) for d in disk_list])
+            res.append(Solex_recon.solex_process(opts, disk_list, bounds, hdr))
+    outputs.flush()
+    torch.cuda.synchronize()
+    out = []
+    for (_, opts), dk, per_file in zip(tasks, disks, res):
+        out.append((opts, dk, [(np.asarray(cc), np.asarray(pr)) for cc, pr in per_file]))
+    return out
+
+
+def same_as_stage_route(pooled, staged):
+    assert len(pooled) == len(staged)
+    for (po_, pd, pr), (so, sd, sr) in zip(pooled, staged):
+        for key in ('shift', 'shift_requested', 'ratio_fixe', 'slant_fix'):
+            assert po_[key] == so[key], key
+        assert len(pd) == len(sd) and len(pr) == len(sr)
+        for a, b in zip(pd, sd):
+            np.testing.assert_array_equal(a, b)
+        for (cc1, p1), (cc2, p2) in zip(pr, sr):
+            np.testing.assert_array_equal(cc1, cc2)
+            np.testing.assert_array_equal(p1, p2)
+
+
+def against_the_oracle(host_frames, extra, got, probe, max_flips):
+    from oracle import pipeline_oracle as po
+    opts, disks, results = got
+    with np.errstate(all='ignore'):
+        want = po.run(host_frames, dict(extra, shift=list(probe)))
+    for shift, ref in zip(want['read']['shifts'], want['read']['disks']):
+        np.testing.assert_array_equal(disks[opts['shift'].index(shift)], ref)                  # raw disks: bit exact
+    np.testing.assert_allclose(opts['ratio_fixe'], want['geometry']['ratio'], rtol=1e-9)
+    requested = [s for s in opts['shift'] if s in opts['shift_requested']]
+    for shift in probe:
+        cc, protus = results[requested.index(shift)]
+        for img, ref in ((cc, want['results'][shift]['cc']), (protus, want['results'][shift]['protus'])):
+            d = np.abs(img.astype(np.int64) - ref.astype(np.int64))
+            assert d.max() <= 1 and np.count_nonzero(d) <= max_flips, (shift, d.max(), np.count_nonzero(d))
+
+
+def test_c2_through_the_pool(pkg, monkeypatch):
+    """BASELINE configs[1] (2000 frames of 2000 x 200, 16 bit, one shift): six different scans in flight in the native pool.
+    All six against the stage route bit for bit, the first and the last against the oracle."""
+    SHG_MAIN, Solex_recon, ops, outputs, synth = pkg
+    stacks = [synth.synth_frames_torch(2000, 2000, 200, 16, seed=20 + i) for i in range(6)]
+    pooled = run_batch(pkg, stacks, {}, True, monkeypatch)
+    staged = run_batch(pkg, stacks, {}, False, monkeypatch)
+    same_as_stage_route(pooled, staged)
+    for i in (0, 5):
+        against_the_oracle(ops.stack_to_host(stacks[i]), {}, pooled[i], [0], 8)
+
+
+def test_c4_through_the_pool(pkg, monkeypatch):
+    """BASELINE configs[3] (-w -10:10:1: 21 requested disks, shg_scan_file's warps in two launches of 16 + 5): six different
+    scans in flight.  All 21 disks and 42 products of every scan against the stage route bit for bit; shifts -10, 0, +10 of
+    the first scan against the oracle."""
+    SHG_MAIN, Solex_recon, ops, outputs, synth = pkg
+    extra = {'shift': list(range(-10, 11))}
+    stacks = [synth.synth_frames_torch(2000, 2000, 200, 16, seed=30 + i) for i in range(6)]
+    pooled = run_batch(pkg, stacks, extra, True, monkeypatch)
+    assert all(len(r) == 21 and len(d) == 21 for _, d, r in pooled)
+    staged = run_batch(pkg, stacks, extra, False, monkeypatch)
+    same_as_stage_route(pooled, staged)
+    against_the_oracle(ops.stack_to_host(stacks[0]), {}, pooled[0], [-10, 0, 10], 8)
+
+
+def test_c5_files_through_the_pool(pkg, monkeypatch):
+    """BASELINE configs[4]'s file shape (2560 x 256, 16 bit), the first 1000 frames of six different files in flight (the
+    whole 4000-frame file runs in test_fullsize_gpu.py): stage route bit for bit, the first file against the oracle."""
+    SHG_MAIN, Solex_recon, ops, outputs, synth = pkg
+    stacks = [synth.synth_frames_torch(1000, 2560, 256, 16, seed=40 + i) for i in range(6)]
+    pooled = run_batch(pkg, stacks, {}, True, monkeypatch)
+    staged = run_batch(pkg, stacks, {}, False, monkeypatch)
+    same_as_stage_route(pooled, staged)
+    against_the_oracle(ops.stack_to_host(stacks[0]), {}, pooled[0], [0], 16)
+
+
+def test_upload_service_with_more_readers_than_chunks(pkg, tmp_path):
+    """Many one-chunk files through eight readers: a reader that found the queue non-empty, lost the last chunk to another
+    reader and then slept with a copy in flight never reported its chunk (the wait for the file hung).  300 files, each must land."""
+    import threading
+    SHG_MAIN, Solex_recon, ops, outputs, synth = pkg
+    from solex_ser_recon_en_amd.video_reader import video_reader
+    frames = synth.synth_frames_numpy(6, 96, 24, 16, seed=1)
+    path = str(tmp_path / 'tiny.ser')
+    synth.write_ser(path, frames)
+    failed = []
+
+    def work():
+        try:
+            for _ in range(300):
+                rdr = video_reader(path)
+                rdr.begin_device_stack(chunk_bytes=3 * 96 * 24 * 2, readers=8)     # two chunks, eight readers
+                stack, job = rdr._upload
+                if not job.done.wait(timeout=20):
+                    failed.append('a chunk was never reported')
+                    return
+                if job.errors:
+                    failed.append(repr(job.errors[0]))
+                    return
+            got = ops.stack_to_host(rdr.device_stack())
+            if not np.array_equal(got, frames):
+                failed.append('frames differ')
+        except BaseException as e:      # noqa: BLE001
+            failed.append(repr(e))
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(120)
+    assert not t.is_alive() and not failed, failed
+
+
+@pytest.mark.parametrize('mode', ['0', '1', 'auto'])
+def test_direct_reads_give_the_same_stack(pkg, tmp_path, monkeypatch, mode):
+    """SHG_READ_DIRECT: O_DIRECT reads of the enclosing 4 KiB-aligned span into the pinned buffer (the SER header is 178 bytes:
+    no frame starts on a block) against buffered reads: the same frames in HBM (g1's decode), also for chunks that end at the
+    end of the file, also where the file system refuses O_DIRECT (the buffered read takes over)."""
+    import os
+    SHG_MAIN, Solex_recon, ops, outputs, synth = pkg
+    from solex_ser_recon_en_amd import video_reader as vr
+    frames = synth.synth_frames_numpy(37, 200, 50, 16, seed=2)
+    for where in (str(tmp_path), '/dev/shm'):
+        path = os.path.join(where, 'direct_%s_%d.ser' % (mode, os.getpid()))
+        try:
+            synth.write_ser(path, frames)
+            fd = os.open(path, os.O_RDONLY)
+            os.fsync(fd)
+            os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)          # cold, where the file system can forget it
+            os.close(fd)
+            monkeypatch.setenv('SHG_READ_DIRECT', mode)
+            got = ops.stack_to_host(vr.video_reader(path).device_stack(chunk_bytes=5 * 200 * 50 * 2))
+            np.testing.assert_array_equal(got, frames)
+            part = ops.stack_to_host(vr.video_reader(path, frame_range=(30, 37)).device_stack(chunk_bytes=4 * 200 * 50 * 2))
+            np.testing.assert_array_equal(part, frames[30:37])
+        finally:
+            if os.path.exists(path):
+                os.unlink(path)

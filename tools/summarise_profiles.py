@@ -5,6 +5,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -47,8 +48,9 @@ def pmc(suffix):
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             n = r['Kernel_Name']
-            if 'k_' in n and 'anonymous' in n:
-                acc[n.split('::')[-1].split('(')[0]].append(float(r['Counter_Value']))
+            m = re.search(r'\bk_[a-z0-9_]+', n)             # the kernel's own name: an argument type such as shg::PtrBatch also holds '::'
+            if m and 'anonymous' in n:
+                acc[m.group(0)].append(float(r['Counter_Value']))
         for k, v in sorted(acc.items()):
             out.setdefault(k, {})[which.upper() + '_SIZE_KB_mean'] = round(sum(v) / len(v), 1)
             out[k][which.upper() + '_SIZE_launches'] = len(v)
