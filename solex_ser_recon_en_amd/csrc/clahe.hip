@@ -27,6 +27,7 @@ constexpr int HIST16 = 65536;
 // the same 256 addresses queue up behind each other in the memory-side atomic units; readers add the copies up.
 constexpr int SEL_SLOTS = 8;
 constexpr int SLICE_PX = 32768;        // pixels per workgroup (< 65536 so that u16 counters cannot wrap)
+constexpr int kFusedMaxSliceRows = 2048;   // k_tile_hist16_slices<true> keeps a slice's row factors in LDS behind the histogram
 
 // pixel (ty, tx, i) -> source coordinates with the bottom/right REFLECT_101 extension
 template <typename T>
@@ -91,10 +92,30 @@ __global__ __launch_bounds__(1024) void k_tile_hist16(const uint16_t* __restrict
 // reads every bin anyway, also leaves what the next steps need: the 64-bin chunk sums the percentiles start from
 // (k_hist_ranks) and, per 2048 bins, the clipped total and the clipped-off excess, so that the LUT no longer has to be
 // built by one workgroup per tile (k_tile_lut16_blocks: 32 workgroups per tile instead of one).
+// FUSED: the image whose histograms are taken does not exist yet -- it is made here, on the way, from the frame before it in
+// single_image_process (Solex_recon.py:149-171): the circularised frame times its row factor (correct_transversalium2's last
+// line, solex_util.py:515-516: saturate, truncate) through the crop / pad block (new[:, dx0:dx0+n] = img[:, sx0:sx0+n], the rest
+// img[0, 0]).  The workgroup stores the pixels it has just formed into imgs (the "uncontrasted" image) and counts them: one
+// read of the frame instead of k_scale_rows8's read + write, k_crop_pad's read + write and this kernel's read, and two launches
+// less per scan.  Only on a tile grid that divides the image (no reflected border: every pixel is some tile's exactly once).
+struct FusedSrc {
+    shg::PtrBatch raw;               // the frames before the row scaling, [h][raw_pitch]
+    int64_t raw_pitch;
+    const double* c;                 // [disk][h] row factors, or NULL (no transversalium correction: a plain crop / copy)
+    int64_t sx0, dx0, ncopy;
+};
+
+__device__ __forceinline__ uint32_t scale_px(uint32_t px, double cy) {        // k_scale_rows: img * c[y], saturate, truncate
+    double v = (double)px * cy;
+    v = v > 65535.0 ? 65535.0 : v;
+    return (uint32_t)(int)v;
+}
+
+template <bool FUSED>
 __global__ __launch_bounds__(1024) void k_tile_hist16_slices(shg::PtrBatch imgs, int64_t h, int64_t w, int64_t pitch,
                                                              int tiles, int64_t th, int64_t tw, uint32_t* __restrict__ part, size_t zs,
-                                                             int slice_rows, int vec) {
-    extern __shared__ uint32_t lh[];   // HIST16/2 dwords, two u16 counters each
+                                                             int slice_rows, int vec, FusedSrc fs) {
+    extern __shared__ uint32_t lh[];   // HIST16/2 dwords, two u16 counters each; FUSED: then slice_rows doubles (the rows' factors)
     const uint16_t* __restrict__ img = imgs.at<const uint16_t>(blockIdx.z);
     part = zdisk(part, zs);
     const int tile = blockIdx.y;
@@ -103,6 +124,20 @@ __global__ __launch_bounds__(1024) void k_tile_hist16_slices(shg::PtrBatch imgs,
     const int ya = (int)blockIdx.x * slice_rows;
     const int yb = min((int)th, ya + slice_rows) - 1;
     for (int i = threadIdx.x; i < HIST16 / 8; i += 1024) reinterpret_cast<uint4*>(lh)[i] = make_uint4(0, 0, 0, 0);
+    double* cf = reinterpret_cast<double*>(lh + HIST16 / 2);
+    const uint16_t* __restrict__ raw = nullptr;
+    uint16_t* __restrict__ fin = nullptr;
+    __shared__ uint32_t fill_s;
+    const bool scaled = FUSED && fs.c != nullptr;
+    if (FUSED) {
+        raw = fs.raw.at<const uint16_t>(blockIdx.z);
+        fin = imgs.at<uint16_t>(blockIdx.z);
+        // the factors of this slice's rows (they may live in the host's staging area: one trip for all of them, here) and the
+        // value of the padding columns
+        const double* c = scaled ? fs.c + (int64_t)blockIdx.z * h : nullptr;
+        for (int i = threadIdx.x; i <= yb - ya; i += 1024) cf[i] = scaled ? c[ty * th + ya + i] : 1.0;
+        if (threadIdx.x == 0) fill_s = scaled ? scale_px(raw[0], c[0]) : (uint32_t)raw[0];
+    }
     __syncthreads();
     {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -113,14 +148,18 @@ __global__ __launch_bounds__(1024) void k_tile_hist16_slices(shg::PtrBatch imgs,
             // rows of 16-byte vectors, none reflected: a wave takes two rows a round (its share of a 65535-pixel slice is four),
             // three vectors of each per lane, all six loads in flight before the first count -- pixel by pixel the wave waited
             // for memory a dozen times per slice, which is what this kernel's time was
+            // (FUSED with vec: no crop -- the frame's columns are the image's)
             const int nvr = twi / 8;
             for (int yy = ya + wave; yy <= yb; yy += 32) {
                 const bool two = yy + 16 <= yb;
                 int64_t y0 = ty * th + yy, y1 = ty * th + (two ? yy + 16 : yy);
-                if (y0 >= h) y0 = shg::reflect101(y0, h);
-                if (y1 >= h) y1 = shg::reflect101(y1, h);
-                const uint4* r0 = reinterpret_cast<const uint4*>(img + y0 * pitch + xbase);
-                const uint4* r1 = reinterpret_cast<const uint4*>(img + y1 * pitch + xbase);
+                if (!FUSED) {
+                    if (y0 >= h) y0 = shg::reflect101(y0, h);
+                    if (y1 >= h) y1 = shg::reflect101(y1, h);
+                }
+                const uint4* r0 = reinterpret_cast<const uint4*>((FUSED ? raw + y0 * fs.raw_pitch : img + y0 * pitch) + xbase);
+                const uint4* r1 = reinterpret_cast<const uint4*>((FUSED ? raw + y1 * fs.raw_pitch : img + y1 * pitch) + xbase);
+                const double c0 = FUSED ? cf[yy - ya] : 1.0, c1 = FUSED ? cf[(two ? yy + 16 : yy) - ya] : 1.0;
                 for (int v0 = lane; v0 < nvr; v0 += 64 * 3) {
                     uint4 q[2][3];
 #pragma unroll
@@ -135,7 +174,16 @@ __global__ __launch_bounds__(1024) void k_tile_hist16_slices(shg::PtrBatch imgs,
 #pragma unroll
                         for (int u = 0; u < 3; ++u) {
                             if (v0 + 64 * u >= nvr) break;
-                            const uint32_t d[4] = {q[rr][u].x, q[rr][u].y, q[rr][u].z, q[rr][u].w};
+                            uint32_t d[4] = {q[rr][u].x, q[rr][u].y, q[rr][u].z, q[rr][u].w};
+                            if (FUSED) {
+                                if (scaled) {
+                                    const double cy = rr ? c1 : c0;
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) d[j] = scale_px(d[j] & 0xffffu, cy) | (scale_px(d[j] >> 16, cy) << 16);
+                                }
+                                uint4* dst = reinterpret_cast<uint4*>(fin + (rr ? y1 : y0) * pitch + xbase);
+                                dst[v0 + 64 * u] = make_uint4(d[0], d[1], d[2], d[3]);
+                            }
 #pragma unroll
                             for (int j = 0; j < 4; ++j) { count(d[j] & 0xffffu); count(d[j] >> 16); }
                         }
@@ -145,22 +193,37 @@ __global__ __launch_bounds__(1024) void k_tile_hist16_slices(shg::PtrBatch imgs,
         } else {
             for (int yy = ya + wave; yy <= yb; yy += 16) {
                 int64_t y = ty * th + yy;
-                if (y >= h) y = shg::reflect101(y, h);
-                const uint16_t* row = img + y * pitch;
+                if (!FUSED && y >= h) y = shg::reflect101(y, h);
+                const uint16_t* row = FUSED ? raw + y * fs.raw_pitch : img + y * pitch;
+                const double cy = FUSED ? cf[yy - ya] : 1.0;
+                const uint32_t fill = FUSED ? fill_s : 0u;
                 // eight loads in flight per lane before the first count: one load per trip left this kernel waiting on memory
                 // latency 33 times over (20 us)
                 for (int x0 = lane; x0 < twi; x0 += 64 * 8) {
                     uint32_t v[8];
+                    bool inside[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int xx = x0 + 64 * u;
                         int64_t x = xbase + (xx < twi ? xx : 0);
-                        if (x >= w) x = shg::reflect101(x, w);
-                        v[u] = row[x];
+                        if (FUSED) {
+                            const int64_t j = x - fs.dx0;                      // the crop / pad block: column x of the image <- column sx0 + j of the frame
+                            inside[u] = j >= 0 && j < fs.ncopy;
+                            v[u] = row[inside[u] ? fs.sx0 + j : 0];
+                        } else {
+                            if (x >= w) x = shg::reflect101(x, w);
+                            v[u] = row[x];
+                        }
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (x0 + 64 * u < twi) count(v[u]);
+                    for (int u = 0; u < 8; ++u) {
+                        if (x0 + 64 * u >= twi) continue;
+                        if (FUSED) {
+                            v[u] = inside[u] ? (scaled ? scale_px(v[u], cy) : v[u]) : fill;
+                            fin[y * pitch + xbase + x0 + 64 * u] = (uint16_t)v[u];
+                        }
+                        count(v[u]);
+                    }
                 }
             }
         }
@@ -899,7 +962,9 @@ void ensure_lds_attr() {
     static bool done = false;
     if (!done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16_slices), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16_slices<false>), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16_slices<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  HIST16 * 2 + kFusedMaxSliceRows * 8);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_image_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_lut16_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (HIST16 + HIST16 / 64) * 2);
@@ -922,6 +987,8 @@ struct Disks {
     shg::PtrBatch src, dst;
     int n;
     size_t zs;
+    bool fused = false;              // src is still to be made, from `from` (k_tile_hist16_slices<true>)
+    FusedSrc from = {};
     bool aligned(unsigned mask) const {
         uintptr_t bits = 0;
         for (int i = 0; i < n; ++i) bits |= reinterpret_cast<uintptr_t>(src.p[i]) | reinterpret_cast<uintptr_t>(dst.p[i]);
@@ -929,7 +996,9 @@ struct Disks {
     }
 };
 inline Disks one_disk(const void* src, void* dst) {
-    Disks d = {};
+    Disks d;
+    d.src = {};
+    d.dst = {};
     d.src.p[0] = src;
     d.dst.p[0] = dst ? dst : src;
     d.n = 1;
@@ -1071,9 +1140,18 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
           static const int64_t big = [] { const char* v = getenv("SHG_CLAHE_SLICE_PX"); return v ? (int64_t)atoi(v) : (int64_t)65535; }();
           const int64_t slice_px = (dset.n >= 4 && big > SLICE_PX && big <= 65535) ? big : SLICE_PX;
           const int64_t slice_rows = slice_rows_of(tw, slice_px), slices = slice_count(th, tw, slice_px);
-          const int vec = w % tiles == 0 && tw % 8 == 0 && pitch % 8 == 0 && dset.aligned(15);
-          k_tile_hist16_slices<<<dim3((unsigned)slices, (unsigned)ntiles, nz), 1024, HIST16 * 2, st>>>(dset.src, h, w, pitch, tiles, th, tw, part, dset.zs,
-                                                                                                    (int)slice_rows, vec);
+          int vec = w % tiles == 0 && tw % 8 == 0 && pitch % 8 == 0 && dset.aligned(15);
+          if (dset.fused) {
+              SHG_REQUIRE(h % tiles == 0 && w % tiles == 0 && slice_rows <= kFusedMaxSliceRows, SHG_E_ARG, "shg_clahe: the fused histogram needs a tile grid that divides the image");
+              uintptr_t bits = 0;
+              for (int i = 0; i < dset.n; ++i) bits |= reinterpret_cast<uintptr_t>(dset.from.raw.p[i]);
+              vec = vec && (bits & 15) == 0 && dset.from.raw_pitch % 8 == 0 && dset.from.sx0 == 0 && dset.from.dx0 == 0 && dset.from.ncopy == w;
+              k_tile_hist16_slices<true><<<dim3((unsigned)slices, (unsigned)ntiles, nz), 1024, HIST16 * 2 + (size_t)slice_rows * 8, st>>>(
+                  dset.src, h, w, pitch, tiles, th, tw, part, dset.zs, (int)slice_rows, vec, dset.from);
+          } else {
+              k_tile_hist16_slices<false><<<dim3((unsigned)slices, (unsigned)ntiles, nz), 1024, HIST16 * 2, st>>>(dset.src, h, w, pitch, tiles, th, tw, part, dset.zs,
+                                                                                                               (int)slice_rows, vec, FusedSrc{});
+          }
           if (int e = shg::check_launch("k_tile_hist16_slices")) return e;
           const bool zero_sel = sel_hist && sel_zeroed;
           k_hist_reduce<<<dim3(32, (unsigned)ntiles, nz), 1024, 0, st>>>(part, (int)slices, clip, hist, chunk_tile, se, dset.zs, zero_sel ? sel_hist : nullptr,
@@ -1088,7 +1166,7 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
         if (chunk_tile_out) *chunk_tile_out = chunk_tile;
         return shg::check_launch("k_clahe_interp");
     }
-    SHG_REQUIRE(dset.n == 1, SHG_E_UNSUPPORTED, "shg_clahe: several disks per launch need the roomy 16-bit workspace");
+    SHG_REQUIRE(dset.n == 1 && !dset.fused, SHG_E_UNSUPPORTED, "shg_clahe: several disks per launch need the roomy 16-bit workspace");
     if (hipError_t e = hipMemsetAsync(hist, 0, (size_t)ntiles * hist_size * sizeof(uint32_t), st)) {
         shg::set_error("shg_clahe: memset: %s", hipGetErrorString(e));
         return (int)e;
@@ -1281,20 +1359,32 @@ extern "C" int shg_contrast_stats_u16(const uint16_t* frame, int64_t h, int64_t 
 // workspace: k areas of shg_contrast_stats_workspace_bytes_for(h, w, tiles) bytes.  The batched launches need the atomics-free
 // CLAHE path (clip limit within the u16 range) and a tile grid that divides the image (percentiles read off the tile
 // histograms); anything else goes disk by disk through shg_contrast_stats_u16 -- same results either way.
+// Whether contrast_stats_batch takes its batched route (one launch per kernel for all disks, the slice histograms, the percentiles
+// read off them) for images of this shape -- the route that can also MAKE the images on its way (FrameSource).
+bool shg::contrast_stats_batches(int64_t h, int64_t w, int tiles, double clip_limit) {
+    if (!(tiles >= 1 && tiles <= 16 && h > 0 && w > 0 && h < 65536 && h % tiles == 0 && w % tiles == 0 && clip_limit > 0.0)) return false;
+    int64_t th, tw;
+    tile_geometry(h, w, tiles, &th, &tw);
+    if (th * tw >= (1ll << 31) || tw > 65535) return false;
+    const int clip = (int)(clip_limit * (double)(th * tw) / HIST16);
+    return clip <= 65535 && slice_rows_of(tw, 65535) <= kFusedMaxSliceRows;
+}
+
 int shg::contrast_stats_batch(const uint16_t* const* host_frames, int64_t k, int64_t h, int64_t w, int64_t pitch, double clip_limit, int tiles,
                               uint16_t* const* host_cl1, int64_t cl1_pitch, const int64_t* ranks_frame2, const int64_t* ranks_cl13, double* out5,
-                              void* workspace, size_t workspace_bytes, shg_stream_t stream) {
+                              void* workspace, size_t workspace_bytes, shg_stream_t stream, const FrameSource* from) {
     SHG_REQUIRE(host_frames && host_cl1 && ranks_frame2 && ranks_cl13 && out5 && workspace && k > 0, SHG_E_ARG, "shg_contrast_stats_u16: null pointer");
     SHG_REQUIRE(h > 0 && w > 0, SHG_E_ARG, "shg_contrast_stats_u16: empty image");
     const size_t per = shg_contrast_stats_workspace_bytes_for(h, w, tiles);
     SHG_REQUIRE(per != 0, SHG_E_WORKSPACE, "shg_contrast_stats_u16: bad tile count");
-    bool batched = k > 1 && workspace_bytes >= (size_t)k * per && tiles >= 1 && tiles <= 16 && h % tiles == 0 && w % tiles == 0 && clip_limit > 0.0;
+    bool batched = (k > 1 || from) && workspace_bytes >= (size_t)k * per && tiles >= 1 && tiles <= 16 && h % tiles == 0 && w % tiles == 0 && clip_limit > 0.0;
     if (batched) {
         int64_t th, tw;
         tile_geometry(h, w, tiles, &th, &tw);
         const int clip = (int)(clip_limit * (double)(th * tw) / HIST16);
         batched = clip <= 65535;                                   // (clip = max(clip, 1) >= 1)
     }
+    SHG_REQUIRE(batched || !from, SHG_E_ARG, "shg_contrast_stats_u16: a frame source needs the batched route (contrast_stats_batches)");
     if (!batched) {
         const size_t each = workspace_bytes >= (size_t)k * per ? per : 0;       // every disk its own area if there is room, else one after the other in the same
         for (int64_t i = 0; i < k; ++i)
@@ -1313,13 +1403,24 @@ int shg::contrast_stats_batch(const uint16_t* const* host_frames, int64_t k, int
     for (int64_t i0 = 0; i0 < k; i0 += shg::kMaxBatch) {
         const int m = (int)std::min<int64_t>(shg::kMaxBatch, k - i0);
         char* ws = static_cast<char*>(workspace) + (size_t)i0 * per;
-        Disks d = {};
+        Disks d;
+        d.src = {};
+        d.dst = {};
         d.n = m;
         d.zs = per;
         for (int i = 0; i < m; ++i) {
             SHG_REQUIRE(host_frames[i0 + i] && host_cl1[i0 + i], SHG_E_ARG, "shg_contrast_stats_u16: null image");
             d.src.p[i] = host_frames[i0 + i];
             d.dst.p[i] = host_cl1[i0 + i];
+            if (from) d.from.raw.p[i] = from->host_raw[i0 + i];
+        }
+        if (from) {
+            d.fused = true;
+            d.from.raw_pitch = from->raw_pitch;
+            d.from.c = from->factors ? from->factors + i0 * h : nullptr;
+            d.from.sx0 = from->sx0;
+            d.from.dx0 = from->dx0;
+            d.from.ncopy = from->ncopy;
         }
         // the selects on the CLAHE images: their slot histograms zeroed up front, every disk's in its own area
         uint32_t* sel3 = reinterpret_cast<uint32_t*>(ws + c + s2);

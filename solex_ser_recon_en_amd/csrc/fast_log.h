@@ -57,4 +57,48 @@ SHG_FASTLOG_FN double log_normal(double x) {
     return fma(dk, ln2_hi, -((hfsq - fma(s, hfsq + R, dk * ln2_lo)) - f));
 }
 
+// log(fl(a / b)) for two 16-bit pixel values a, b >= 1 (np.log(strip1 / strip0), solex_util.py:393): the quotient correctly
+// rounded, then the algorithm above -- with ONE reciprocal for both divisions (a / b, and f / (2 + f) inside the logarithm) where
+// the compiler's a / b and div_normal spend two reciprocals, four Newton steps and the scale / fix-up instructions of a general
+// IEEE division.
+//   * z ~ 1 / (b (a + b)) (both factors exact: below 2^33), two Newton steps; then 1 / b ~ z (a + b) and 1 / (a + b) ~ z b;
+//   * q = fl(a / b) EXACTLY: q0 = a y, r = a - b q0 (one fma: exact), q = fl(q0 + r y).  y is within a few ulp of 1 / b, so
+//     q0 + r y is within 2^-50 ulp of a / b, and a quotient of integers below 2^16 that is not a double lies at least 2^-17 ulp
+//     from every rounding boundary (|a / b - m| = |a 2^j - b (2 k + 1)| / (b 2^j) >= 1 / (b 2^j)): the rounding cannot differ;
+//   * sqrt(2) / 2 <= q < sqrt(2) (neighbouring rows of a sunlit disk: always, but for a handful of pixels): k = 0, f = q - 1,
+//     d = fl(2 + f), and 1 / d ~ b / (a + b) = b (z b) to a few ulp -- one Newton step and the same quotient correction give
+//     s = f / d as div_normal does.  Any other q: log_normal(q).
+SHG_FASTLOG_FN double log_ratio_u16(unsigned a_px, unsigned b_px) {
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    const double a = (double)a_px, b = (double)b_px;
+    const double t = a + b, p = b * t;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double z = __builtin_amdgcn_rcp(p);
+#else
+    double z = 1.0 / p;
+#endif
+    double e = fma(-p, z, 1.0);
+    z = fma(z, e, z);
+    e = fma(-p, z, 1.0);
+    z = fma(z, e, z);
+    const double u = z * b;                              // ~ 1 / (a + b)
+    const double y = z * t;                              // ~ 1 / b
+    const double q0 = a * y;
+    const double q = fma(fma(-b, q0, a), y, q0);         // fl(a / b)
+    if (!(q >= 0.70710678118654752440 && q < 1.41421356237309504880)) return log_normal(q);
+    const double f = q - 1.0, d = 2.0 + f;
+    double v = b * u;                                    // ~ 1 / (q + 1)
+    v = fma(v, fma(-d, v, 1.0), v);
+    const double s0 = f * v;
+    const double s = fma(fma(-d, s0, f), v, s0);
+    const double zz = s * s, w = zz * zz;
+    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+    const double t2 = zz * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    return -((hfsq - s * (hfsq + R)) - f);               // (log_normal's last line with k = 0)
+}
+
 }  // namespace shg

@@ -94,9 +94,19 @@ int contrast_products_batch(const uint16_t* const* host_frames, int64_t frame_pi
 int warp_rows_batch(const uint16_t* const* host_srcs, int64_t k, int64_t h, int64_t w, int64_t src_pitch, const double* host_h3,
                     uint16_t* const* host_dsts, int64_t out_h, int64_t out_w, int64_t dst_pitch, const uint32_t* const* host_minmax2,
                     shg_stream_t stream);
+// from (may be NULL): host_frames do not exist yet -- the CLAHE histogram kernel makes them on its way from the frames before
+// them in single_image_process: host_raw[i][y][sx0 + j] * factors[i][y] (saturated, truncated; factors NULL: as they are) ->
+// host_frames[i][y][dx0 + j] for j < ncopy, host_raw[i][0][0] (scaled) elsewhere.  Only where contrast_stats_batches() says so.
+struct FrameSource {
+    const uint16_t* const* host_raw;
+    int64_t raw_pitch;
+    const double* factors;           // device-readable [k][h], or NULL
+    int64_t sx0, dx0, ncopy;
+};
+bool contrast_stats_batches(int64_t h, int64_t w, int tiles, double clip_limit);
 int contrast_stats_batch(const uint16_t* const* host_frames, int64_t k, int64_t h, int64_t w, int64_t pitch, double clip_limit, int tiles,
                          uint16_t* const* host_cl1, int64_t cl1_pitch, const int64_t* ranks_frame2, const int64_t* ranks_cl13, double* out5,
-                         void* workspace, size_t workspace_bytes, shg_stream_t stream);
+                         void* workspace, size_t workspace_bytes, shg_stream_t stream, const FrameSource* from = nullptr);
 
 constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kCUs = 256;          // MI355X

@@ -550,7 +550,13 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
     double* factors = dev.take<double>((size_t)k * h);
     const size_t tpitch = ((size_t)w + 63) / 64 * 64;
     std::vector<uint16_t*> scaled((size_t)k, nullptr);
-    const bool need_tmp = transversalium && crop_w > 0 && !host_detrans;
+    // The row scaling and the crop / pad block ride on CLAHE's histogram kernel (k_tile_hist16_slices<true>: it forms the pixels of
+    // the image it counts) wherever the contrast stage takes its batched route and nobody wants the scaled frame itself
+    // (save_fit's _detransversaliumed.fits): two launches and two image passes less per disk.  SHG_FUSE_SCALE=0: the separate kernels.
+    const char* fuse_env = getenv("SHG_FUSE_SCALE");            // (asked per call: the tests run both ways in one process)
+    const bool fuse_on = !(fuse_env && fuse_env[0] == '0');
+    const bool fuse = fuse_on && !host_detrans && shg::contrast_stats_batches(h, crop_w > 0 ? crop_w : w, tiles, clip_limit) && pitch >= w;
+    const bool need_tmp = transversalium && crop_w > 0 && !host_detrans && !fuse;
     if (need_tmp)
         for (int64_t i = 0; i < k; ++i) scaled[i] = dev.take<uint16_t>((size_t)h * tpitch);
     const size_t cs_each = up(shg_contrast_stats_workspace_bytes_for(h, out_w, tiles));      // one area per disk: all disks go through a kernel together
@@ -623,6 +629,7 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
         // k_scale_rows reads one factor per workgroup: straight from the staging area (a copy kernel first: 3.8 us for the launch,
         // 2.8 us saved in the reader)
         factors = stg.on_device(h_factors);
+      if (!fuse) {
         std::vector<uint16_t*> dsts((size_t)k);
         int64_t dpitch = out_pitch;
         for (int64_t i = 0; i < k; ++i) {
@@ -634,9 +641,12 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
         }
         cur_pitch = dpitch;
         STAGE_TRY(shg::scale_rows_batch(host_frames, k, h, w, pitch, factors, nullptr, dsts.data(), dpitch, stream));
+      }
     }
     // ---- crop / pad (Solex_recon.py:155-171) ----
-    if (crop_w > 0) {
+    if (fuse) {
+        // (done by the histogram kernel below)
+    } else if (crop_w > 0) {
         STAGE_TRY(shg::crop_pad_batch(cur.data(), k, h, w, cur_pitch, host_final, crop_w, out_pitch, sx0, dx0, ncopy, -1, stream));
     } else if (cur[0] != host_final[0]) {
         // no transversalium into host_final and no crop: the frame itself is the image to contrast; copy it (a crop of
@@ -650,8 +660,9 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
     STAGE_TRY(shg_host_percentile_plan(n_px, 99.9999, &ranks_frame[0], &ranks_frame[1], &g_bright));
     STAGE_TRY(shg_host_percentile_plan(n_px, 10.0, &ranks_cl1[0], &ranks_cl1[1], &g_dark));
     ranks_cl1[2] = n_px - 1;                                                                  // np.max
+    shg::FrameSource from = {host_frames, pitch, transversalium ? factors : nullptr, crop_w > 0 ? sx0 : 0, crop_w > 0 ? dx0 : 0, crop_w > 0 ? ncopy : w};
     STAGE_TRY(shg::contrast_stats_batch(host_final, k, h, out_w, out_pitch, clip_limit, tiles, host_cl1, out_pitch, ranks_frame, ranks_cl1, out5, cs_ws,
-                                        cs_bytes, stream));
+                                        cs_bytes, stream, fuse ? &from : nullptr));
     // The three rescales and the disc follow without a word from the host: the kernel forms the six bounds from the order
     // statistics where they lie (and leaves a copy where the host reads them).  What the host still owes the reference is
     // rescale_brightness's assert (solex_util.py:521): checked once the products kernel has run.

@@ -60,6 +60,21 @@ __device__ __forceinline__ void hist_add(uint32_t* hist, bool valid, uint32_t di
     if (valid && digit != d0) atomicAdd(&hist[digit], 1u);
 }
 
+// Inclusive prefix sum across the wave.  The lane number is hidden from the optimiser (see block_sum): the six source-lane
+// addresses and their comparisons, hoisted out of this function as loop invariants, otherwise sit in registers from the first
+// select to the last.
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_scan(T v) {
+    int self = threadIdx.x & 63;
+    asm volatile("" : "+v"(self));
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const T o = __shfl(v, self - d);
+        if (self >= d) v += o;
+    }
+    return v;
+}
+
 // The two order statistics rank_lo <= rank_hi (0-based) of key(i), i < n, for the whole workgroup.
 template <typename KeyFn>
 __device__ __forceinline__ void select2(KeyFn key, int n, int64_t rank_lo, int64_t rank_hi, Scratch& sc, uint64_t& out_lo,
@@ -87,13 +102,8 @@ __device__ __forceinline__ void select2(KeyFn key, int n, int64_t rank_lo, int64
         int64_t c[2], incl[2];
         c[0] = sc.hist[0][tid];
         c[1] = same ? c[0] : sc.hist[1][tid];
-        incl[0] = c[0];
-        incl[1] = c[1];
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int64_t o0 = __shfl_up(incl[0], d), o1 = __shfl_up(incl[1], d);
-            if (lane >= d) { incl[0] += o0; incl[1] += o1; }
-        }
+        incl[0] = wave_inclusive_scan(c[0]);
+        incl[1] = wave_inclusive_scan(c[1]);
         if (lane == 63) { sc.wave_tot[0][wave] = incl[0]; sc.wave_tot[1][wave] = incl[1]; }
         __syncthreads();
         for (int i = 0; i < wave; ++i) { incl[0] += sc.wave_tot[0][i]; incl[1] += sc.wave_tot[1][i]; }
@@ -172,12 +182,7 @@ __device__ __forceinline__ bool select2_buckets(ValFn val, int n, int64_t rank_l
         __syncthreads();
         // prefix sum over the buckets, two per thread
         const uint32_t c0 = hist[2 * tid], c1 = hist[2 * tid + 1];
-        uint32_t incl = c0 + c1;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
+        uint32_t incl = wave_inclusive_scan(c0 + c1);
         if (lane == 63) sc.wave_tot[0][wave] = incl;
         __syncthreads();
         for (int i = 0; i < wave; ++i) incl += (uint32_t)sc.wave_tot[0][i];
@@ -286,7 +291,37 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8))) void k_
     // a de-vignetted frame is the float64 image img * row_factor[y] (removeVignette, solex_util.py:654)
     const double f1 = row_factor ? row_factor[y] : 1.0, f0 = row_factor ? row_factor[y - 1] : 1.0;
     double sum1 = 0.0, sum2 = 0.0;       // only steer the bucket select (where the bulk of the row lies): any rounding will do
-    {
+    if (!row_factor) {
+        // Plain 16-bit rows (every scan but a de-vignetted one): log_ratio_u16 -- one reciprocal serves the quotient and the
+        // logarithm's own division -- for pixel pairs without a zero; four pairs' loads in flight before the first is used.
+        bool odd = false;
+        for (int i0 = threadIdx.x; i0 < n; i0 += 4 * NT) {
+            uint32_t a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * NT < n ? i0 + u * NT : i0;
+                a[u] = r1[i];
+                b[u] = r0[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * NT;
+                if (i >= n) break;
+                double x;
+                if (a[u] != 0 && b[u] != 0) {
+                    x = shg::log_ratio_u16(a[u], b[u]);
+                } else {                 // a zero pixel: 0, inf or NaN quotient -- the library's log knows what to return
+                    x = log((double)a[u] / (double)b[u]);
+                    if (x != x) sc.bad = 1;
+                    odd = odd || !(fabs(x) <= 1.7976931348623157e308);
+                }
+                vals[i] = x;
+                sum1 += x;
+                sum2 += x * x;
+            }
+        }
+        if (odd) sc.nonfinite = 1;
+    } else {
         bool odd = false;
         for (int i = threadIdx.x; i < n; i += NT) {
             const double q = ((double)r1[i] * f1) / ((double)r0[i] * f0);              // np.log(strip1 / strip0)

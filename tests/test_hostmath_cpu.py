@@ -476,6 +476,9 @@ def test_fast_log_stays_below_one_ulp(tmp_path):
     exe = str(tmp_path / 'fast_log_check')
     subprocess.run([gxx, '-O2', '-ffp-contract=off', '-I', os.path.join(here, '..', 'solex_ser_recon_en_amd', 'csrc'),
                     os.path.join(here, 'c_abi', 'fast_log_check.cpp'), '-o', exe], check=True)
-    pairs, every, differ = (float(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split())
+    pairs, every, differ, ratio, ratio_differs = (float(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split())
     assert pairs < 1.0 and every < 1.0, (pairs, every)
     assert differ < 0.08, differ
+    # log_ratio_u16(a, b) (one reciprocal for the quotient and for the logarithm's own division): below 1 ulp too, and the very
+    # double log_normal(a / b) gives, but for a few pairs in a million
+    assert ratio < 1.0 and ratio_differs < 1e-4, (ratio, ratio_differs)

@@ -1000,3 +1000,53 @@ def test_fused_limb_kernels_equal_the_separate_ones(ops, h, w, seed):
         np.testing.assert_array_equal(idx[keep], want_idx)
         np.testing.assert_array_equal(root[keep], want_root)
         assert len(want_idx) > 0
+
+
+@pytest.mark.parametrize('shape,crop,trans,k', [((200, 304), None, True, 1), ((200, 304), (256, 24, 0, 256), True, 3),
+                                                ((202, 310), (400, 0, 45, 310), True, 2), ((200, 304), None, False, 2),
+                                                ((198, 306), (198, 54, 0, 198), False, 1), ((2000, 2096), None, True, 2),
+                                                ((2000, 2096), (2000, 48, 0, 2000), True, 1), ((201, 304), None, True, 1)])
+def test_scaling_and_crop_fused_into_the_histogram_kernel(shape, crop, trans, k, monkeypatch):
+    """shg_stage_process_frames forms the image CLAHE works on inside the CLAHE histogram kernel (k_tile_hist16_slices<true>: frame x
+    row factor, saturate, truncate, crop / pad; Solex_recon.py:149-171, solex_util.py:515-516) where the tile grid divides the
+    image.  Every product equals the separate kernels' (SHG_FUSE_SCALE=0: k_scale_rows8, k_crop_pad, then the histograms) bit for bit:
+    vector and pixel paths, crops that pad on either side, several disks, no transversalium (a plain copy), and a shape the grid
+    does not divide (201 rows: not fused either way)."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from solex_ser_recon_en_amd import solex_util, stages
+    h, w = shape
+    rng = np.random.default_rng(h * 31 + w)
+    yy, xx = np.mgrid[0:h, 0:w]
+    frames = []
+    for i in range(k):
+        r = np.hypot((yy - h / 2) / (0.45 * h), (xx - w / 2) / (0.45 * w))
+        img = np.where(r < 1, 52000.0 * (0.4 + 0.6 * np.sqrt(np.clip(1 - r * r, 0, 1))), 900.0) * (1 + 0.02 * np.sin(yy / 3.0 + i))
+        img = np.clip(img + rng.normal(0, 300, img.shape), 1, 65535).astype(np.uint16)
+        img[0, 0] = 777 + i                                  # the padding value is img[0, 0] (times its row's factor)
+        frames.append(torch.from_numpy(img.view(np.int16)).cuda().view(torch.uint16))
+    pitch = (w + 63) // 64 * 64
+    store = torch.zeros((k, h, pitch), dtype=torch.uint16, device='cuda')
+    views = []
+    for i, f in enumerate(frames):
+        store[i, :, :w] = f
+        views.append(store[i, :, :w])
+    transv = None
+    if trans:
+        window = min(61, (int(0.8 * h) // 2) * 2 - 1)
+        transv = dict(circle=(w / 2.0, h / 2.0, 0.4 * h), borders=[0.0, 0.05 * h, w - 1.0, 0.95 * h], taps=solex_util.savgol_taps(window), window=window)
+
+    def run(fused):
+        monkeypatch.setenv('SHG_FUSE_SCALE', '1' if fused else '0')
+        res = stages.process_frames(views, transv, crop, (w // 2, h // 2, int(0.3 * h)))
+        torch.cuda.synchronize()
+        return {name: [np.asarray(t.cpu().view(torch.int16).numpy()).view(np.uint16).copy() for t in res[name]]
+                for name in ('final', 'cl1', 'hc', 'protus', 'cc')}, None if res['factors'] is None else res['factors'].copy()
+    a, fa = run(True)
+    b, fb = run(False)
+    if trans:
+        np.testing.assert_array_equal(fa, fb)
+    for name in a:
+        for x, y in zip(a[name], b[name]):
+            assert x.shape == (h, crop[0] if crop else w)
+            np.testing.assert_array_equal(x, y, err_msg=name)
