@@ -208,9 +208,16 @@ def main():
     gc.collect()
     gc.freeze()
     _lib.profile_reset()
-    _lib.profile_enable(True, only=('accumulate', 'extract'))
+    _lib.profile_enable(True, only=('accumulate',))       # (pass A runs on the lane; the chains' kernels share dispatches with other scans' -- csrc/launch.h -- and have no launch of their own to bracket)
+    comb0 = Solex_recon.combiner_stats()
     region_s = timed_regions(args.steps, max(1, args.repeats))
+    comb1 = Solex_recon.combiner_stats()
     _lib.profile_enable(False)
+    combiner = {k: comb1[k] - comb0[k] for k in comb1}
+    combiner['launches_per_dispatch'] = round(combiner['launches_recorded'] / combiner['dispatches'], 2) if combiner['dispatches'] else None
+    combiner['dispatches_per_scan'] = round(combiner['dispatches'] / (args.steps * len(region_s)), 2)
+    combiner['what'] = ('kernel launches the scans of the timed regions recorded, and the dispatches that carried them: the same kernel of '
+                        'the scans in flight shares a dispatch (csrc/launch.h, csrc/combine.hip); pass A and its finalising kernel run on the lane')
     elapsed = sorted(region_s)[len(region_s) // 2]                       # the median region is the one quoted
 
     # ---- roofline of the dominant kernel (pass A: sum/max over the stack), live HIP events --------
@@ -384,7 +391,7 @@ def main():
             'kernel_time_how': 'sum of the HIP-event-bracketed durations of all %d library entry points of one scan, serial pass '
                                '(%.3f ms wall per scan there); gpu_busy_frac = that / ms_per_step' % (
                                    all_n // serial_steps, t_serial / serial_steps * 1e3),
-            'roofline': roofline, 'cpu_baseline': cpu, 'e2e': e2e, 'sharded_c3': c3, 'c4': c4, 'c5_file': c5,
+            'combiner': combiner, 'roofline': roofline, 'cpu_baseline': cpu, 'e2e': e2e, 'sharded_c3': c3, 'c4': c4, 'c5_file': c5,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -438,6 +438,19 @@ def _native_pool(device, n_workers):
     return pool
 
 
+def combiner_stats():
+    """What the launch combiners of this process's native pools have done so far (csrc/launch.h): kernel launches the scans
+    recorded, dispatches made for them, flushes -- summed over the pools."""
+    import ctypes
+    from ._lib import check, lib
+    total = [0, 0, 0]
+    for pool in _native_pools.values():
+        out = (ctypes.c_uint64 * 3)()
+        check(lib.shg_pool_combiner_stats(pool, out), 'shg_pool_combiner_stats')
+        total = [a + int(b) for a, b in zip(total, out)]
+    return {'launches_recorded': total[0], 'dispatches': total[1], 'flushes': total[2]}
+
+
 def _scan_batch_native(tasks, decoder, n_workers, scan_here, collected):
     """The files of a batch through the native scan pool: this ONE thread prepares each scan (buffers, options), submits it
     and, when its turn comes, turns what the pool computed into log lines, files and results -- in file order.  Up to

@@ -278,8 +278,21 @@ struct FromPartials {
 // mean = sum // n (== trunc(float64(sum)/n) for sums < 2^53, solex_util.py:188), x256 for 8-bit
 // (video_reader.py:121-122), rotated: out[y][x] = in[x][W-1-y] when W > H (video_reader.py:119-120).
 template <typename Src>
-__global__ __launch_bounds__(256) void k_finalize(Src in, uint64_t n_total, int64_t height, int64_t width, int scale,
-                                                  uint16_t* __restrict__ mean_out, uint16_t* __restrict__ max_out) {
+struct FinalizeArgs {
+    Src in;
+    uint64_t n_total;
+    int64_t height, width;
+    int scale;
+    uint16_t *mean_out, *max_out;
+};
+
+SHG_MERGEABLE_T(SHG_TPL(template <typename Src>), SHG_TPL(<Src>), k_finalize, FinalizeArgs<Src>, __launch_bounds__(256)) {
+    const Src in = kargs.in;
+    const uint64_t n_total = kargs.n_total;
+    const int64_t height = kargs.height, width = kargs.width;
+    const int scale = kargs.scale;
+    uint16_t* __restrict__ mean_out = kargs.mean_out;
+    uint16_t* __restrict__ max_out = kargs.max_out;
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= height * width) return;
     int64_t src;
@@ -300,9 +313,13 @@ __global__ __launch_bounds__(256) void k_finalize(Src in, uint64_t n_total, int6
 // The rotated case through a 32 x 32 LDS tile: the plain kernel reads `sum` along file columns (one 8-byte value per 16 KB
 // of addresses: 15.6 MB fetched for a 4 MB input at C2, PMC round 1).  Here a workgroup reads 32 file rows x 32 file
 // columns row-wise (256-byte runs) and writes 32 output rows x 32 output columns row-wise.
-template <typename Src>
-__global__ __launch_bounds__(256) void k_finalize_rot(Src in, uint64_t n_total, int64_t height, int64_t width, int scale,
-                                                      uint16_t* __restrict__ mean_out, uint16_t* __restrict__ max_out) {
+SHG_MERGEABLE_T(SHG_TPL(template <typename Src>), SHG_TPL(<Src>), k_finalize_rot, FinalizeArgs<Src>, __launch_bounds__(256)) {
+    const Src in = kargs.in;
+    const uint64_t n_total = kargs.n_total;
+    const int64_t height = kargs.height, width = kargs.width;
+    const int scale = kargs.scale;
+    uint16_t* __restrict__ mean_out = kargs.mean_out;
+    uint16_t* __restrict__ max_out = kargs.max_out;
     __shared__ uint16_t tm[32][33], tx[32][33];
     const int64_t fx0 = (int64_t)blockIdx.x * 32;          // file column block  (slit rows y = W-1-fx, descending)
     const int64_t fy0 = (int64_t)blockIdx.y * 32;          // file row block     (spectral columns x = fy)
@@ -403,13 +420,12 @@ template <typename Src>
 int launch_finalize(Src in, int64_t n_total, int64_t height, int64_t width, int bytes_per_px, uint16_t* mean_out, uint16_t* max_out, hipStream_t st) {
     SHG_PROF("finalize", st);
     const int scale = bytes_per_px == 1 ? 256 : 1;
+    const FinalizeArgs<Src> fa{in, (uint64_t)n_total, height, width, scale, mean_out, max_out};
     if (width > height) {
         dim3 grid((unsigned)((width + 31) / 32), (unsigned)((height + 31) / 32));
-        k_finalize_rot<Src><<<grid, 256, 0, st>>>(in, (uint64_t)n_total, height, width, scale, mean_out, max_out);
-    } else {
-        k_finalize<Src><<<(unsigned)((height * width + 255) / 256), 256, 0, st>>>(in, (uint64_t)n_total, height, width, scale, mean_out, max_out);
+        return SHG_LAUNCH_T(k_finalize_rot, <Src>, grid, dim3(256), 0, st, fa);
     }
-    return shg::check_launch("k_finalize");
+    return SHG_LAUNCH_T(k_finalize, <Src>, dim3((unsigned)((height * width + 255) / 256)), dim3(256), 0, st, fa);
 }
 }  // namespace
 
@@ -422,6 +438,7 @@ extern "C" int shg_accumulate_sum_max(const void* stack, int64_t n_frames, int64
     uint16_t* pmax;
     if (int e = accumulate_partials(stack, n_frames, height, width, bytes_per_px, frame_stride_px, workspace, workspace_bytes, stream, &p, &psum, &pmax)) return e;
     hipStream_t st = shg::as_stream(stream);
+    SHG_DIRECT(st);
     { SHG_PROF("reduce_partials", st); k_reduce_partials<<<(unsigned)((p.npix + 255) / 256), 256, 0, st>>>(psum, pmax, p.nsplit, p.npix, sum_out, max_out); }
     return shg::check_launch("k_reduce_partials");
 }
@@ -474,7 +491,9 @@ bool take_ahead(PassA* want, bool* same, int* status) {
     hipError_t e;
     {
         SHG_HOST_TIME("lane wait (queue + pass A)");
+        shg::pool_wait_begin();                              // (a pool thread: the other scans' recorded launches need not wait for this one)
         e = hipEventSynchronize(got.done);
+        shg::pool_wait_end();
     }
     (void)hipEventDestroy(got.done);
     *status = 0;

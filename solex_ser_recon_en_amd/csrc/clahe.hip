@@ -18,8 +18,8 @@ namespace {
 // A launch over several disks (blockIdx.z): every disk has a workspace of its own, `zs` bytes after the previous one, so a
 // pointer into the first disk's workspace becomes the disk's by adding blockIdx.z * zs bytes.
 template <typename T>
-__device__ __forceinline__ T* zdisk(T* p, size_t zs) {
-    return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(p)) + (size_t)blockIdx.z * zs);
+__device__ __forceinline__ T* zdisk(T* p, size_t zs, uint32_t z) {
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(p)) + (size_t)z * zs);
 }
 
 constexpr int HIST16 = 65536;
@@ -111,13 +111,27 @@ __device__ __forceinline__ uint32_t scale_px(uint32_t px, double cy) {        //
     return (uint32_t)(int)v;
 }
 
-template <bool FUSED>
-__global__ __launch_bounds__(1024) void k_tile_hist16_slices(shg::PtrBatch imgs, int64_t h, int64_t w, int64_t pitch,
-                                                             int tiles, int64_t th, int64_t tw, uint32_t* __restrict__ part, size_t zs,
-                                                             int slice_rows, int vec, FusedSrc fs) {
+struct HistSlicesArgs {
+    shg::PtrBatch imgs;
+    int64_t h, w, pitch;
+    int tiles;
+    int64_t th, tw;
+    uint32_t* part;
+    size_t zs;
+    int slice_rows, vec;
+    FusedSrc fs;
+};
+
+SHG_MERGEABLE_T(SHG_TPL(template <bool FUSED>), SHG_TPL(<FUSED>), k_tile_hist16_slices, HistSlicesArgs, __launch_bounds__(1024)) {
+    const shg::PtrBatch& imgs = kargs.imgs;
+    const int64_t h = kargs.h, w = kargs.w, pitch = kargs.pitch, th = kargs.th, tw = kargs.tw;
+    const int tiles = kargs.tiles, slice_rows = kargs.slice_rows, vec = kargs.vec;
+    uint32_t* __restrict__ part = kargs.part;
+    const size_t zs = kargs.zs;
+    const FusedSrc& fs = kargs.fs;
     extern __shared__ uint32_t lh[];   // HIST16/2 dwords, two u16 counters each; FUSED: then slice_rows doubles (the rows' factors)
     const uint16_t* __restrict__ img = imgs.at<const uint16_t>(blockIdx.z);
-    part = zdisk(part, zs);
+    part = zdisk(part, zs, blockIdx.z);
     const int tile = blockIdx.y;
     const int64_t ty = tile / tiles, tx = tile % tiles;
     // a slice is a run of whole tile rows (slice_rows of them: fewer than 65536 pixels, so that a u16 counter cannot wrap)
@@ -235,20 +249,35 @@ __global__ __launch_bounds__(1024) void k_tile_hist16_slices(shg::PtrBatch imgs,
 
 // grid (32, ntiles) x 1024 threads: lane d of the tile owns the counter pair d = bins 2d, 2d + 1.
 // hist [tile][65536] u32; chunk_tile [tile][1024] (64-bin sums); se [tile][32][2] = clipped total, excess per 2048 bins.
-__global__ __launch_bounds__(1024) void k_hist_reduce(const uint32_t* __restrict__ part, int slices, int clip,
-                                                      uint32_t* __restrict__ hist, uint32_t* __restrict__ chunk_tile,
-                                                      int32_t* __restrict__ se, size_t zs, uint32_t* __restrict__ sel_zero, int sel_words) {
+struct HistReduceArgs {
+    const uint32_t* part;
+    int slices, clip;
+    uint32_t *hist, *chunk_tile;
+    int32_t* se;
+    size_t zs;
+    uint32_t* sel_zero;
+    int sel_words;
+};
+
+SHG_MERGEABLE(k_hist_reduce, HistReduceArgs, __launch_bounds__(1024)) {
+    const uint32_t* __restrict__ part = kargs.part;
+    const int slices = kargs.slices, clip = kargs.clip, sel_words = kargs.sel_words;
+    uint32_t* __restrict__ hist = kargs.hist;
+    uint32_t* __restrict__ chunk_tile = kargs.chunk_tile;
+    int32_t* __restrict__ se = kargs.se;
+    const size_t zs = kargs.zs;
+    uint32_t* __restrict__ sel_zero = kargs.sel_zero;
     __shared__ int wsum[2][16];
     // the slot histograms of the selects that follow the blend (which adds to them): zeroed here, by the disk's first workgroup, instead
     // of by a memset launch of their own (every launch is an L2 write-back and invalidate under the other scans' kernels)
     if (sel_zero && blockIdx.x == 0 && blockIdx.y == 0) {
-        uint32_t* z = zdisk(sel_zero, zs);
+        uint32_t* z = zdisk(sel_zero, zs, blockIdx.z);
         for (int i = threadIdx.x; i < sel_words; i += 1024) z[i] = 0;
     }
-    part = zdisk(part, zs);
-    hist = zdisk(hist, zs);
-    chunk_tile = zdisk(chunk_tile, zs);
-    se = zdisk(se, zs);
+    part = zdisk(part, zs, blockIdx.z);
+    hist = zdisk(hist, zs, blockIdx.z);
+    chunk_tile = zdisk(chunk_tile, zs, blockIdx.z);
+    se = zdisk(se, zs, blockIdx.z);
     const int tile = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d = blockIdx.x * 1024 + tid;
     const uint32_t* p = part + (int64_t)tile * slices * (HIST16 / 2) + d;
@@ -287,13 +316,27 @@ __global__ __launch_bounds__(1024) void k_hist_reduce(const uint32_t* __restrict
 // The tile LUT (clip, redistribute, prefix sum, scale: as k_tile_lut16_lds) by 32 workgroups per tile, 2048 bins each:
 // the counts before a workgroup's first bin are the clipped totals of the workgroups before it, plus what the
 // redistribution adds there -- `batch` per bin and one more for the bins 0, step, 2 step, ... below residual * step.
-__global__ __launch_bounds__(1024) void k_tile_lut16_blocks(const uint32_t* __restrict__ hist, const int32_t* __restrict__ se, int clip,
-                                                            float lut_scale, uint16_t* __restrict__ lut, size_t zs) {
+struct LutBlocksArgs {
+    const uint32_t* hist;
+    const int32_t* se;
+    int clip;
+    float lut_scale;
+    uint16_t* lut;
+    size_t zs;
+};
+
+SHG_MERGEABLE(k_tile_lut16_blocks, LutBlocksArgs, __launch_bounds__(1024)) {
+    const uint32_t* __restrict__ hist = kargs.hist;
+    const int32_t* __restrict__ se = kargs.se;
+    const int clip = kargs.clip;
+    const float lut_scale = kargs.lut_scale;
+    uint16_t* __restrict__ lut = kargs.lut;
+    const size_t zs = kargs.zs;
     constexpr int HIST = 65536;
     __shared__ int s_before, s_excess;
-    hist = zdisk(hist, zs);
-    se = zdisk(se, zs);
-    lut = zdisk(lut, zs);
+    hist = zdisk(hist, zs, blockIdx.z);
+    se = zdisk(se, zs, blockIdx.z);
+    lut = zdisk(lut, zs, blockIdx.z);
     __shared__ int wsum[16];
     const int tile = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (wave == 0) {
@@ -570,19 +613,39 @@ __global__ __launch_bounds__(256) void k_clahe_interp(const T* __restrict__ img,
 // COUNT: also the first pass of the order statistics that follow (np.percentile(cl1, 10), np.max(cl1)) -- the histogram
 // of the high bytes of the pixels it has just produced, in sel_hist's slot layout (k_select16_pass, pass 0): the values
 // are in registers here, which saves that pass its read of the image.
-template <int PX, bool COUNT>
-__global__ __launch_bounds__(256) void k_clahe_interp_vm(shg::PtrBatch imgs, int64_t h, int64_t w, int64_t pitch,
-                                                         int tiles, float inv_tw, float inv_th,
-                                                         const uint16_t* __restrict__ lut, shg::PtrBatch dsts, int64_t dst_pitch,
-                                                         int rows, uint32_t* __restrict__ sel_hist, int sel_stride, size_t zs,
-                                                         int tiled, uint32_t tiles_x) {
+struct InterpVmArgs {
+    shg::PtrBatch imgs;
+    int64_t h, w, pitch;
+    int tiles;
+    float inv_tw, inv_th;
+    const uint16_t* lut;
+    shg::PtrBatch dsts;
+    int64_t dst_pitch;
+    int rows;
+    uint32_t* sel_hist;
+    int sel_stride;
+    size_t zs;
+    int tiled;
+    uint32_t tiles_x;
+};
+
+SHG_MERGEABLE_T(SHG_TPL(template <int PX, bool COUNT>), SHG_TPL(<PX, COUNT>), k_clahe_interp_vm, InterpVmArgs, __launch_bounds__(256)) {
+    const shg::PtrBatch& imgs = kargs.imgs;
+    const shg::PtrBatch& dsts = kargs.dsts;
+    const int64_t h = kargs.h, w = kargs.w, pitch = kargs.pitch, dst_pitch = kargs.dst_pitch;
+    const int tiles = kargs.tiles, rows = kargs.rows, sel_stride = kargs.sel_stride, tiled = kargs.tiled;
+    const float inv_tw = kargs.inv_tw, inv_th = kargs.inv_th;
+    const uint16_t* __restrict__ lut = kargs.lut;
+    uint32_t* __restrict__ sel_hist = kargs.sel_hist;
+    const size_t zs = kargs.zs;
+    const uint32_t tiles_x = kargs.tiles_x;
     constexpr int HIST = 65536;
     constexpr int COPIES = 8;                            // interleaved copies of each bin: a row's pixels crowd a few bins
     __shared__ uint32_t lh[COUNT ? 256 * COPIES : 1];
     const uint16_t* __restrict__ img = imgs.at<const uint16_t>(blockIdx.z);
     uint16_t* __restrict__ dst = dsts.at<uint16_t>(blockIdx.z);
-    lut = zdisk(lut, zs);
-    if (COUNT) sel_hist = zdisk(sel_hist, zs);
+    lut = zdisk(lut, zs, blockIdx.z);
+    if (COUNT) sel_hist = zdisk(sel_hist, zs, blockIdx.z);
     if (COUNT) {
         for (int i = threadIdx.x; i < 256 * COPIES; i += 256) lh[i] = 0;
         __syncthreads();
@@ -766,12 +829,27 @@ constexpr int SEL_COPIES0 = 16, SEL_COPIES1 = 4;
 
 struct Ranks8 { int64_t v[8]; };            // the requested ranks travel as a kernel argument: no host-to-device copy per call
 
-__global__ __launch_bounds__(1024) void k_select16_pass(shg::PtrBatch imgs, int64_t h, int64_t w, int64_t pitch, int pass,
-                                                       Ranks8 ranks, int n_ranks, uint32_t* __restrict__ hist,
-                                                       int vec_ok, size_t zs) {
+struct SelectPassArgs {
+    shg::PtrBatch imgs;
+    int64_t h, w, pitch;
+    int pass;
+    Ranks8 ranks;
+    int n_ranks;
+    uint32_t* hist;
+    int vec_ok;
+    size_t zs;
+};
+
+SHG_MERGEABLE(k_select16_pass, SelectPassArgs, __launch_bounds__(1024)) {
+    const shg::PtrBatch& imgs = kargs.imgs;
+    const int64_t h = kargs.h, w = kargs.w, pitch = kargs.pitch;
+    const int pass = kargs.pass, n_ranks = kargs.n_ranks, vec_ok = kargs.vec_ok;
+    const Ranks8& ranks = kargs.ranks;
+    uint32_t* __restrict__ hist = kargs.hist;
+    const size_t zs = kargs.zs;
     __shared__ uint32_t lh[8 * 256 * SEL_COPIES1];        // pass 0: [bin][16 copies]; pass 1: [rank][bin][4 copies]
     const uint16_t* __restrict__ img = imgs.at<const uint16_t>(blockIdx.z);
-    hist = zdisk(hist, zs);
+    hist = zdisk(hist, zs, blockIdx.z);
     __shared__ int his_s[8];
     if (pass == 1) {
         // replay pass 0's choice for every rank: ONE scan of the shared high-byte histogram (a scan per rank was a third of
@@ -897,9 +975,21 @@ __global__ __launch_bounds__(1024) void k_select16_pass(shg::PtrBatch imgs, int6
 }
 
 // grid (n_ranks), 256 threads
-__global__ __launch_bounds__(256) void k_select16_final(Ranks8 ranks, const uint32_t* __restrict__ hist,
-                                                        double* __restrict__ out, size_t zs, int out_zstride) {
-    hist = zdisk(hist, zs);
+struct SelectFinalArgs {
+    Ranks8 ranks;
+    const uint32_t* hist;
+    double* out;
+    size_t zs;
+    int out_zstride;
+};
+
+SHG_MERGEABLE(k_select16_final, SelectFinalArgs, __launch_bounds__(256)) {
+    const Ranks8& ranks = kargs.ranks;
+    const uint32_t* __restrict__ hist = kargs.hist;
+    double* __restrict__ out = kargs.out;
+    const size_t zs = kargs.zs;
+    const int out_zstride = kargs.out_zstride;
+    hist = zdisk(hist, zs, blockIdx.z);
     out += (int64_t)blockIdx.z * out_zstride;
     int hi, lo;
     int64_t below, below2;
@@ -922,12 +1012,25 @@ __global__ __launch_bounds__(1024) void k_chunk_sums(const uint32_t* __restrict_
 // Order statistics of the image whose per-tile histograms CLAHE has just built (valid when the tile grid divides the
 // image: no reflected padding in the histograms).  One workgroup per rank: lane t takes the t-th run of 64 bins from the
 // chunk sums of k_chunk_sums, a workgroup scan finds the run that holds the rank, one wave scans its 64 bins.
-__global__ __launch_bounds__(1024) void k_hist_ranks(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ chunk_sums,
-                                                     int chunk_sets, int ntiles, Ranks8 ranks, double* __restrict__ out, size_t zs,
-                                                     int out_zstride) {
+struct HistRanksArgs {
+    const uint32_t *hist, *chunk_sums;
+    int chunk_sets, ntiles;
+    Ranks8 ranks;
+    double* out;
+    size_t zs;
+    int out_zstride;
+};
+
+SHG_MERGEABLE(k_hist_ranks, HistRanksArgs, __launch_bounds__(1024)) {
+    const uint32_t* __restrict__ hist = kargs.hist;
+    const uint32_t* __restrict__ chunk_sums = kargs.chunk_sums;
+    const int chunk_sets = kargs.chunk_sets, ntiles = kargs.ntiles, out_zstride = kargs.out_zstride;
+    const Ranks8& ranks = kargs.ranks;
+    double* __restrict__ out = kargs.out;
+    const size_t zs = kargs.zs;
     __shared__ int64_t wtot[16];
-    hist = zdisk(hist, zs);
-    chunk_sums = zdisk(chunk_sums, zs);
+    hist = zdisk(hist, zs, blockIdx.z);
+    chunk_sums = zdisk(chunk_sums, zs, blockIdx.z);
     out += (int64_t)blockIdx.z * out_zstride;
     __shared__ int64_t pick[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -959,17 +1062,20 @@ __global__ __launch_bounds__(1024) void k_hist_ranks(const uint32_t* __restrict_
 }
 
 void ensure_lds_attr() {
-    static bool done = false;
-    if (!done) {
+    static const bool done = [] {                        // (a function-local static: once, also with several pool threads here)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16_slices<false>), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16_slices_multi<false>), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16_slices<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  HIST16 * 2 + kFusedMaxSliceRows * 8);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16_slices_multi<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   HIST16 * 2 + kFusedMaxSliceRows * 8);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_image_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_lut16_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (HIST16 + HIST16 / 64) * 2);
-        done = true;
-    }
+        return true;
+    }();
+    (void)done;
 }
 
 }  // namespace
@@ -1006,14 +1112,16 @@ inline Disks one_disk(const void* src, void* dst) {
     return d;
 }
 
-inline bool launch_interp16(const Disks& d, int64_t h, int64_t w, int64_t pitch, int tiles, float inv_tw, float inv_th,
-                            const uint16_t* lut, bool value_major, int64_t dst_pitch, uint32_t* sel_hist, int sel_stride,
-                            hipStream_t st) {
+inline int launch_interp16(const Disks& d, int64_t h, int64_t w, int64_t pitch, int tiles, float inv_tw, float inv_th,
+                           const uint16_t* lut, bool value_major, int64_t dst_pitch, uint32_t* sel_hist, int sel_stride,
+                           hipStream_t st, bool* counted) {
+    *counted = false;
     const unsigned nz = (unsigned)d.n;
     if (!value_major) {                                  // (single image only: the caller checked)
+        SHG_DIRECT(st);
         k_clahe_interp<uint16_t, HIST16><<<dim3((unsigned)((w + 255) / 256), (unsigned)h), 256, 0, st>>>(
             static_cast<const uint16_t*>(d.src.p[0]), h, w, pitch, tiles, inv_tw, inv_th, lut, static_cast<uint16_t*>(const_cast<void*>(d.dst.p[0])), dst_pitch);
-        return false;
+        return shg::check_launch("k_clahe_interp");
     }
     const bool vec = d.aligned(7) && pitch % 4 == 0 && dst_pitch % 4 == 0;
     auto blocks = [&](int px, int rounds) {              // workgroups for the flat (row, vector) sequence
@@ -1021,28 +1129,27 @@ inline bool launch_interp16(const Disks& d, int64_t h, int64_t w, int64_t pitch,
         return (unsigned)((lanes + 256 * (int64_t)rounds - 1) / (256 * (int64_t)rounds));
     };
     static const bool tiled_ok = [] { const char* v = getenv("SHG_INTERP_TILED"); return !(v && v[0] == '0'); }();
+    InterpVmArgs a{d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, 1, nullptr, 0, d.zs, 0, 1u};
     if (vec && sel_hist) {
         const int rows = 4;                              // rounds per workgroup: amortises the histogram's zeroing and flush
+        a.rows = rows;
+        a.sel_hist = sel_hist;
+        a.sel_stride = sel_stride;
+        *counted = true;
         if (tiled_ok) {
             // 4 lanes x 16 rows per wave, 4 waves across: 64 pixels x 16 rows a round (measured over 21 disks: 243 us; 2 waves
             // across 242, one 270; 2 lanes x 32 rows 262-384; 8 lanes x 8 rows 246-253; the flat sequence 300)
             const int lw = 2, wx = 2;
             const int64_t wg_px = (int64_t)4 << (lw + wx), wg_rows = (int64_t)(64 >> lw) * (4 >> wx);
             const uint32_t tx = (uint32_t)((w + wg_px - 1) / wg_px), ty = (uint32_t)((h + wg_rows * rows - 1) / (wg_rows * rows));
-            k_clahe_interp_vm<4, true><<<dim3(tx * ty, 1u, nz), 256, 0, st>>>(
-                d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, rows, sel_hist, sel_stride, d.zs, 0x10000 | lw | (wx << 8), tx);
-            return true;
+            a.tiled = 0x10000 | lw | (wx << 8);
+            a.tiles_x = tx;
+            return SHG_LAUNCH_T(k_clahe_interp_vm, SHG_TPL(<4, true>), dim3(tx * ty, 1u, nz), dim3(256), 0, st, a);
         }
-        k_clahe_interp_vm<4, true><<<dim3(blocks(4, rows), 1u, nz), 256, 0, st>>>(
-            d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, rows, sel_hist, sel_stride, d.zs, 0, 1u);
-        return true;
+        return SHG_LAUNCH_T(k_clahe_interp_vm, SHG_TPL(<4, true>), dim3(blocks(4, rows), 1u, nz), dim3(256), 0, st, a);
     }
-    if (vec) {
-        k_clahe_interp_vm<4, false><<<dim3(blocks(4, 1), 1u, nz), 256, 0, st>>>(d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, 1, nullptr, 0, d.zs, 0, 1u);
-    } else {
-        k_clahe_interp_vm<1, false><<<dim3(blocks(1, 1), 1u, nz), 256, 0, st>>>(d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, 1, nullptr, 0, d.zs, 0, 1u);
-    }
-    return false;
+    if (vec) return SHG_LAUNCH_T(k_clahe_interp_vm, SHG_TPL(<4, false>), dim3(blocks(4, 1), 1u, nz), dim3(256), 0, st, a);
+    return SHG_LAUNCH_T(k_clahe_interp_vm, SHG_TPL(<1, false>), dim3(blocks(1, 1), 1u, nz), dim3(256), 0, st, a);
 }
 
 // tile geometry as OpenCV pads it (copyMakeBorder(0, t - h%t, 0, t - w%t, REFLECT_101), clahe.cpp)
@@ -1146,27 +1253,30 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
               uintptr_t bits = 0;
               for (int i = 0; i < dset.n; ++i) bits |= reinterpret_cast<uintptr_t>(dset.from.raw.p[i]);
               vec = vec && (bits & 15) == 0 && dset.from.raw_pitch % 8 == 0 && dset.from.sx0 == 0 && dset.from.dx0 == 0 && dset.from.ncopy == w;
-              k_tile_hist16_slices<true><<<dim3((unsigned)slices, (unsigned)ntiles, nz), 1024, HIST16 * 2 + (size_t)slice_rows * 8, st>>>(
-                  dset.src, h, w, pitch, tiles, th, tw, part, dset.zs, (int)slice_rows, vec, dset.from);
+              if (int e = SHG_LAUNCH_T(k_tile_hist16_slices, <true>, dim3((unsigned)slices, (unsigned)ntiles, nz), dim3(1024), HIST16 * 2 + (size_t)slice_rows * 8, st,
+                                       HistSlicesArgs{dset.src, h, w, pitch, tiles, th, tw, part, dset.zs, (int)slice_rows, vec, dset.from}))
+                  return e;
           } else {
-              k_tile_hist16_slices<false><<<dim3((unsigned)slices, (unsigned)ntiles, nz), 1024, HIST16 * 2, st>>>(dset.src, h, w, pitch, tiles, th, tw, part, dset.zs,
-                                                                                                               (int)slice_rows, vec, FusedSrc{});
+              if (int e = SHG_LAUNCH_T(k_tile_hist16_slices, <false>, dim3((unsigned)slices, (unsigned)ntiles, nz), dim3(1024), HIST16 * 2, st,
+                                       HistSlicesArgs{dset.src, h, w, pitch, tiles, th, tw, part, dset.zs, (int)slice_rows, vec, FusedSrc{}}))
+                  return e;
           }
-          if (int e = shg::check_launch("k_tile_hist16_slices")) return e;
           const bool zero_sel = sel_hist && sel_zeroed;
-          k_hist_reduce<<<dim3(32, (unsigned)ntiles, nz), 1024, 0, st>>>(part, (int)slices, clip, hist, chunk_tile, se, dset.zs, zero_sel ? sel_hist : nullptr,
-                                                                          zero_sel ? SEL_SLOTS * sel_stride : 0);
+          if (int e = SHG_LAUNCH(k_hist_reduce, dim3(32, (unsigned)ntiles, nz), dim3(1024), 0, st,
+                                 HistReduceArgs{part, (int)slices, clip, hist, chunk_tile, se, dset.zs, zero_sel ? sel_hist : nullptr, zero_sel ? SEL_SLOTS * sel_stride : 0}))
+              return e;
           if (zero_sel) *sel_zeroed = true; }
-        if (int e = shg::check_launch("k_hist_reduce")) return e;
-        { SHG_PROF("clahe_lut", st); k_tile_lut16_blocks<<<dim3(32, (unsigned)ntiles, (unsigned)dset.n), 1024, 0, st>>>(hist, se, clip, lut_scale, lut, dset.zs); }
-        if (int e = shg::check_launch("k_tile_lut16_blocks")) return e;
+        { SHG_PROF("clahe_lut", st);
+          if (int e = SHG_LAUNCH(k_tile_lut16_blocks, dim3(32, (unsigned)ntiles, (unsigned)dset.n), dim3(1024), 0, st, LutBlocksArgs{hist, se, clip, lut_scale, lut, dset.zs})) return e; }
         { SHG_PROF("clahe_interp", st);
-          const bool counted = launch_interp16(dset, h, w, pitch, tiles, inv_tw, inv_th, lut, true, dst_pitch, sel_hist, sel_stride, st);
+          bool counted = false;
+          if (int e = launch_interp16(dset, h, w, pitch, tiles, inv_tw, inv_th, lut, true, dst_pitch, sel_hist, sel_stride, st, &counted)) return e;
           if (sel_pass0_done) *sel_pass0_done = counted; }
         if (chunk_tile_out) *chunk_tile_out = chunk_tile;
-        return shg::check_launch("k_clahe_interp");
+        return 0;
     }
     SHG_REQUIRE(dset.n == 1 && !dset.fused, SHG_E_UNSUPPORTED, "shg_clahe: several disks per launch need the roomy 16-bit workspace");
+    SHG_DIRECT(st);                                      // (the launches below go to `st` the plain way)
     if (hipError_t e = hipMemsetAsync(hist, 0, (size_t)ntiles * hist_size * sizeof(uint32_t), st)) {
         shg::set_error("shg_clahe: memset: %s", hipGetErrorString(e));
         return (int)e;
@@ -1184,7 +1294,9 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
             k_tile_lut<HIST16><<<ntiles, 1024, 0, st>>>(hist, clip, lut_scale, lut);
         }
         if (int e = shg::check_launch("k_tile_lut")) return e;
-        { SHG_PROF("clahe_interp", st); launch_interp16(dset, h, w, pitch, tiles, inv_tw, inv_th, lut, false, dst_pitch, nullptr, 0, st); }
+        { SHG_PROF("clahe_interp", st);
+          bool counted = false;
+          if (int e = launch_interp16(dset, h, w, pitch, tiles, inv_tw, inv_th, lut, false, dst_pitch, nullptr, 0, st, &counted)) return e; }
     } else {
         int64_t hb = (area + 4095) / 4096;
         if (hb > 256) hb = 256;
@@ -1198,6 +1310,7 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
     }
     if (int e = shg::check_launch("k_clahe_interp")) return e;
     if (sel_hist && sel_zeroed) {                        // nothing has counted into sel_hist on this path: zero it the plain way
+        SHG_DIRECT(st);
         if (hipError_t e = hipMemsetAsync(sel_hist, 0, (size_t)SEL_SLOTS * sel_stride * sizeof(uint32_t), st)) {
             shg::set_error("shg_clahe: memset: %s", hipGetErrorString(e));
             return (int)e;
@@ -1218,6 +1331,7 @@ extern "C" int shg_hist(const void* img, int64_t h, int64_t w, int64_t pitch, in
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w, SHG_E_ARG, "shg_hist: bad image size");
     SHG_REQUIRE(bytes_per_px == 1 || bytes_per_px == 2, SHG_E_ARG, "shg_hist: bytes_per_px must be 1 or 2");
     hipStream_t st = shg::as_stream(stream);
+    SHG_DIRECT(st);
     const int hist_size = bytes_per_px == 1 ? 256 : HIST16;
     if (hipError_t e = hipMemsetAsync(hist, 0, (size_t)hist_size * sizeof(uint32_t), st)) {
         shg::set_error("shg_hist: memset: %s", hipGetErrorString(e));
@@ -1258,6 +1372,7 @@ int select_u16_impl(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, co
     Ranks8 ranks = {};
     for (int i = 0; i < n_ranks; ++i) ranks.v[i] = host_ranks[i];
     if (!zeroed) {
+        SHG_DIRECT(st);
         hipError_t e = hipMemsetAsync(hist, 0, (size_t)SEL_SLOTS * (1 + n_ranks) * 256 * sizeof(uint32_t), st);
         if (e != hipSuccess) { shg::set_error("shg_select_u16: %s", hipGetErrorString(e)); return (int)e; }
     }
@@ -1279,11 +1394,11 @@ int select_u16_impl(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, co
     for (int pass = pass0_done ? 1 : 0; pass < 2; ++pass) {
         // 512 threads: the zeroing / replay / flush around the pixel loop is shared by twice the waves (256 / 512 / 1024
         // threads: 44.7 / 40.6 / 40.3 us for two ranks, tools/bench_select.py)
-        k_select16_pass<<<dim3(blocks, 1u, (unsigned)dset.n), 512, 0, st>>>(dset.src, h, w, pitch, pass, ranks, n_ranks, hist, vec_ok, dset.zs);
-        if (int err = shg::check_launch("k_select16_pass")) return err;
+        if (int err = SHG_LAUNCH(k_select16_pass, dim3(blocks, 1u, (unsigned)dset.n), dim3(512), 0, st,
+                                 SelectPassArgs{dset.src, h, w, pitch, pass, ranks, n_ranks, hist, vec_ok, dset.zs}))
+            return err;
     }
-    k_select16_final<<<dim3((unsigned)n_ranks, 1u, (unsigned)dset.n), 256, 0, st>>>(ranks, hist, out, dset.zs, out_zstride);
-    return shg::check_launch("k_select16_final");
+    return SHG_LAUNCH(k_select16_final, dim3((unsigned)n_ranks, 1u, (unsigned)dset.n), dim3(256), 0, st, SelectFinalArgs{ranks, hist, out, dset.zs, out_zstride});
 }
 }  // namespace
 
@@ -1344,12 +1459,17 @@ extern "C" int shg_contrast_stats_u16(const uint16_t* frame, int64_t h, int64_t 
         hipStream_t st = shg::as_stream(stream);
         SHG_PROF("hist_ranks", st);
         if (chunk_tile) {                                // left by k_hist_reduce, one set per tile
-            k_hist_ranks<<<2, 1024, 0, st>>>(reinterpret_cast<const uint32_t*>(ws), chunk_tile, tiles * tiles, tiles * tiles, ranks, out5, 0, 0);
+            if (int e = SHG_LAUNCH(k_hist_ranks, dim3(2), dim3(1024), 0, st,
+                                   HistRanksArgs{reinterpret_cast<const uint32_t*>(ws), chunk_tile, tiles * tiles, tiles * tiles, ranks, out5, 0, 0}))
+                return e;
         } else {
+            SHG_DIRECT(st);
             k_chunk_sums<<<64, 1024, 0, st>>>(reinterpret_cast<const uint32_t*>(ws), tiles * tiles, chunk_sums);
-            k_hist_ranks<<<2, 1024, 0, st>>>(reinterpret_cast<const uint32_t*>(ws), chunk_sums, 1, tiles * tiles, ranks, out5, 0, 0);
+            if (int e = shg::check_launch("k_chunk_sums")) return e;
+            if (int e = SHG_LAUNCH(k_hist_ranks, dim3(2), dim3(1024), 0, st,
+                                   HistRanksArgs{reinterpret_cast<const uint32_t*>(ws), chunk_sums, 1, tiles * tiles, ranks, out5, 0, 0}))
+                return e;
         }
-        if (int e = shg::check_launch("k_hist_ranks")) return e;
     } else if (int e = shg_select_u16(frame, h, w, pitch, ranks_frame2, 2, out5, ws + c, s2, stream)) return e;
     return select_u16_impl(cl1, h, w, cl1_pitch, ranks_cl13, 3, out5 + 2, sel3, shg_select_u16_workspace_bytes(3), stream, true, pass0_done);
 }
@@ -1432,9 +1552,9 @@ int shg::contrast_stats_batch(const uint16_t* const* host_frames, int64_t k, int
         SHG_REQUIRE(chunk_tile && sel_zeroed, SHG_E_RUNTIME, "shg_contrast_stats_u16: the batched path did not take the slice histograms");
         {
             SHG_PROF("hist_ranks", st);
-            k_hist_ranks<<<dim3(2u, 1u, (unsigned)m), 1024, 0, st>>>(reinterpret_cast<const uint32_t*>(ws), chunk_tile, tiles * tiles, tiles * tiles, ranks,
-                                                                      out5 + 5 * i0, per, 5);
-            if (int e = shg::check_launch("k_hist_ranks")) return e;
+            if (int e = SHG_LAUNCH(k_hist_ranks, dim3(2u, 1u, (unsigned)m), dim3(1024), 0, st,
+                                   HistRanksArgs{reinterpret_cast<const uint32_t*>(ws), chunk_tile, tiles * tiles, tiles * tiles, ranks, out5 + 5 * i0, per, 5}))
+                return e;
         }
         Disks dc = d;
         dc.src = d.dst;                                            // the selects read the CLAHE images

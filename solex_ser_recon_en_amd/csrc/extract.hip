@@ -28,13 +28,29 @@ constexpr int TK = 64;        // output columns (frames) per workgroup
 constexpr int TKP = TK + 2;   // padded LDS row stride (33 dwords: odd)
 constexpr int SC_MAX = 4;     // shifts per workgroup (2 when the scan has only the two implicit shifts: half the registers)
 
-template <typename T, bool ROT, int BATCH, int SC>
-__global__ __launch_bounds__(256) void k_extract(const T* __restrict__ stack, int n_frames, int64_t height, int64_t width, int64_t fstride,
-                                                 const int32_t* __restrict__ ind_l, const double* __restrict__ lw,
-                                                 const double* __restrict__ rw, int n_shifts,
-                                                 uint16_t* __restrict__ disks, int64_t row_pitch, int64_t plane_stride,
-                                                 int64_t n_cols, int64_t k_offset, int flip_x, int vec_store,
-                                                 uint32_t* __restrict__ mm) {
+struct ExtractArgs {
+    const void* stack;
+    int n_frames;
+    int64_t height, width, fstride;
+    const int32_t* ind_l;
+    const double *lw, *rw;
+    int n_shifts;
+    uint16_t* disks;
+    int64_t row_pitch, plane_stride, n_cols, k_offset;
+    int flip_x, vec_store;
+    uint32_t* mm;
+};
+
+SHG_MERGEABLE_T(SHG_TPL(template <typename T, bool ROT, int BATCH, int SC>), SHG_TPL(<T, ROT, BATCH, SC>), k_extract, ExtractArgs, __launch_bounds__(256)) {
+    const T* __restrict__ stack = static_cast<const T*>(kargs.stack);
+    const int n_frames = kargs.n_frames, n_shifts = kargs.n_shifts, flip_x = kargs.flip_x, vec_store = kargs.vec_store;
+    const int64_t height = kargs.height, width = kargs.width, fstride = kargs.fstride, row_pitch = kargs.row_pitch, plane_stride = kargs.plane_stride,
+                  n_cols = kargs.n_cols, k_offset = kargs.k_offset;
+    const int32_t* __restrict__ ind_l = kargs.ind_l;
+    const double* __restrict__ lw = kargs.lw;
+    const double* __restrict__ rw = kargs.rw;
+    uint16_t* __restrict__ disks = kargs.disks;
+    uint32_t* __restrict__ mm = kargs.mm;
     __shared__ uint16_t tile[SC][TY][TKP];
     const int64_t ih = ROT ? width : height;
     const int lane = threadIdx.x & 63;
@@ -319,7 +335,14 @@ __global__ __launch_bounds__(64 * NW) void k_extract_dense(const T* __restrict__
 }
 
 // fold the 64 slots of every plane: out[s] = {min, max}
-__global__ void k_fold_minmax(const uint32_t* __restrict__ slots, uint32_t* __restrict__ out) {
+struct FoldMinmaxArgs {
+    const uint32_t* slots;
+    uint32_t* out;
+};
+
+SHG_MERGEABLE(k_fold_minmax, FoldMinmaxArgs, __launch_bounds__(64)) {
+    const uint32_t* __restrict__ slots = kargs.slots;
+    uint32_t* __restrict__ out = kargs.out;
     uint32_t a = slots[((int64_t)blockIdx.x * 64 + threadIdx.x) * 2], b = slots[((int64_t)blockIdx.x * 64 + threadIdx.x) * 2 + 1];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -365,17 +388,17 @@ extern "C" int shg_extract_columns_minmax(const void* stack, int64_t n_frames, i
     dim3 grid((unsigned)((n_cols + TK - 1) / TK), (unsigned)((ih + TY - 1) / TY), (unsigned)((n_shifts + sc - 1) / sc));
     hipStream_t st = shg::as_stream(stream);
     const int n = (int)n_frames;
-#define SHG_LAUNCH_BS(T, ROT, B, SCV)                                                                                         \
-    k_extract<T, ROT, B, SCV><<<grid, 256, 0, st>>>(static_cast<const T*>(stack), n, height, width, fstride, ind_l, lw, rw, n_shifts, \
-                                               disks, row_pitch, plane_stride, n_cols, k_offset, flip_x, vec_store, minmax_slots)
-#define SHG_LAUNCH_B(T, ROT, B) do { if (sc == 2) SHG_LAUNCH_BS(T, ROT, B, 2); else SHG_LAUNCH_BS(T, ROT, B, 4); } while (0)
-#define SHG_LAUNCH(T, ROT)                                                 \
+    const ExtractArgs xa{stack, n, height, width, fstride, ind_l, lw, rw, n_shifts, disks, row_pitch, plane_stride, n_cols, k_offset, flip_x, vec_store, minmax_slots};
+    int launch_status = 0;
+#define EXT_LAUNCH_BS(T, ROT, B, SCV) launch_status = SHG_LAUNCH_T(k_extract, SHG_TPL(<T, ROT, B, SCV>), grid, dim3(256), 0, st, xa)
+#define EXT_LAUNCH_B(T, ROT, B) do { if (sc == 2) EXT_LAUNCH_BS(T, ROT, B, 2); else EXT_LAUNCH_BS(T, ROT, B, 4); } while (0)
+#define EXT_LAUNCH(T, ROT)                                                 \
     switch (batch) {                                                       \
-        case 1: SHG_LAUNCH_B(T, ROT, 1); break;                            \
-        case 2: SHG_LAUNCH_B(T, ROT, 2); break;                            \
-        case 8: SHG_LAUNCH_B(T, ROT, 8); break;                            \
-        case 16: SHG_LAUNCH_B(T, ROT, 16); break;                          \
-        default: SHG_LAUNCH_B(T, ROT, 4); break;                           \
+        case 1: EXT_LAUNCH_B(T, ROT, 1); break;                            \
+        case 2: EXT_LAUNCH_B(T, ROT, 2); break;                            \
+        case 8: EXT_LAUNCH_B(T, ROT, 8); break;                            \
+        case 16: EXT_LAUNCH_B(T, ROT, 16); break;                          \
+        default: EXT_LAUNCH_B(T, ROT, 4); break;                           \
     }
     static const int batch_env = [] { const char* e = getenv("SHG_EXT_BATCH"); return e ? atoi(e) : 0; }();   // tuning override
     // measured at C2 (tools/sweep_extract.sh), batch 1 / 2 / 4 / 8 / 16: S=21 124 / 104 / 104 / 95 / 124 us; S=2 with the two-shift
@@ -383,6 +406,7 @@ extern "C" int shg_extract_columns_minmax(const void* stack, int64_t n_frames, i
     const int batch2 = 4;
     const int batch = batch_env > 0 ? batch_env : (n_shifts > SC_MAX ? 8 : (n_shifts <= 2 ? batch2 : 4));
     if (minmax_slots && !slots_zeroed) {
+        SHG_DIRECT(st);
         if (hipError_t e = hipMemsetAsync(minmax_slots, 0, (size_t)n_shifts * 64 * 2 * sizeof(uint32_t), st)) {
             shg::set_error("shg_extract_columns: memset: %s", hipGetErrorString(e));
             return (int)e;
@@ -391,19 +415,17 @@ extern "C" int shg_extract_columns_minmax(const void* stack, int64_t n_frames, i
     {
         SHG_PROF("extract", st);
         if (bytes_per_px == 2) {
-            if (rot) SHG_LAUNCH(uint16_t, true) else SHG_LAUNCH(uint16_t, false)
+            if (rot) EXT_LAUNCH(uint16_t, true) else EXT_LAUNCH(uint16_t, false)
         } else {
-            if (rot) SHG_LAUNCH(uint8_t, true) else SHG_LAUNCH(uint8_t, false)
+            if (rot) EXT_LAUNCH(uint8_t, true) else EXT_LAUNCH(uint8_t, false)
         }
     }
-#undef SHG_LAUNCH_B
-#undef SHG_LAUNCH_BS
-#undef SHG_LAUNCH
-    if (int e = shg::check_launch("k_extract")) return e;
-    if (minmax_slots) {
-        k_fold_minmax<<<(unsigned)n_shifts, 64, 0, st>>>(minmax_slots, minmax_slots + (int64_t)n_shifts * 64 * 2);
-        return shg::check_launch("k_fold_minmax");
-    }
+#undef EXT_LAUNCH_B
+#undef EXT_LAUNCH_BS
+#undef EXT_LAUNCH
+    if (launch_status) return launch_status;
+    if (minmax_slots)
+        return SHG_LAUNCH(k_fold_minmax, dim3((unsigned)n_shifts), dim3(64), 0, st, FoldMinmaxArgs{minmax_slots, minmax_slots + (int64_t)n_shifts * 64 * 2});
     return 0;
 }
 
@@ -448,6 +470,7 @@ extern "C" int shg_extract_columns_dense(const void* stack, int64_t n_frames, in
     PlaneOfOffset po = {};
     for (int i = 0; i < n_shifts; ++i) po.v[host_shifts[i] - lo] = i;
     hipStream_t st = shg::as_stream(stream);
+    SHG_DIRECT(st);                                          // (this kernel launches the plain way: launch.h)
     if (minmax_slots && !slots_zeroed) {
         if (hipError_t e = hipMemsetAsync(minmax_slots, 0, (size_t)n_shifts * 64 * 2 * sizeof(uint32_t), st)) {
             shg::set_error("shg_extract_columns_dense: memset: %s", hipGetErrorString(e));
@@ -487,9 +510,7 @@ extern "C" int shg_extract_columns_dense(const void* stack, int64_t n_frames, in
 #undef SHG_DENSE_S
 #undef SHG_DENSE
     if (int e = shg::check_launch("k_extract_dense")) return e;
-    if (minmax_slots) {
-        k_fold_minmax<<<(unsigned)n_shifts, 64, 0, st>>>(minmax_slots, minmax_slots + (int64_t)n_shifts * 64 * 2);
-        return shg::check_launch("k_fold_minmax");
-    }
+    if (minmax_slots)
+        return SHG_LAUNCH(k_fold_minmax, dim3((unsigned)n_shifts), dim3(64), 0, st, FoldMinmaxArgs{minmax_slots, minmax_slots + (int64_t)n_shifts * 64 * 2});
     return 0;
 }

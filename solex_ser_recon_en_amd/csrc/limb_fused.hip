@@ -119,9 +119,31 @@ __device__ __forceinline__ int refl101(int i, int n) {           // BORDER_REFLE
 // chain of dependent accesses, and several workgroups per CU hide each other's.  LDS: S[RH][RW] u32 | H[RH][BT] u32.
 constexpr int BT = 16;
 constexpr int NT1 = 1024;                    // the canny tile kernel: one pixel of the 16 x 64 tile per thread
-__global__ __launch_bounds__(256) void k_limb_blur(const uint16_t* __restrict__ img, int h, int w, int64_t pitch, int sh, int sw, int k,
-                                                   int vec4, uint32_t* __restrict__ keysk, uint32_t* __restrict__ keys5,
-                                                   unsigned long long* __restrict__ acc) {
+// (a memset's worth of zeroes as a kernel, so that it can share a dispatch with the other scans' like every launch of the stage)
+struct ZeroWordsArgs {
+    uint32_t* dst;
+    size_t n_words;
+};
+SHG_MERGEABLE(k_zero_words, ZeroWordsArgs, __launch_bounds__(256)) {
+    uint32_t* __restrict__ dst = kargs.dst;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < kargs.n_words; i += (size_t)gridDim.x * 256) dst[i] = 0;
+}
+
+struct LimbBlurArgs {
+    const uint16_t* img;
+    int h, w;
+    int64_t pitch;
+    int sh, sw, k, vec4;
+    uint32_t *keysk, *keys5;
+    unsigned long long* acc;
+};
+SHG_MERGEABLE(k_limb_blur, LimbBlurArgs, __launch_bounds__(256)) {
+    const uint16_t* __restrict__ img = kargs.img;
+    const int h = kargs.h, w = kargs.w, sh = kargs.sh, sw = kargs.sw, k = kargs.k, vec4 = kargs.vec4;
+    const int64_t pitch = kargs.pitch;
+    uint32_t* __restrict__ keysk = kargs.keysk;
+    uint32_t* __restrict__ keys5 = kargs.keys5;
+    unsigned long long* __restrict__ acc = kargs.acc;
     __shared__ uint32_t S[(BT + KMAX) * (BT + KMAX)];
     __shared__ uint32_t H[(BT + KMAX) * BT];
     __shared__ unsigned long long wsum[4];
@@ -239,8 +261,19 @@ __device__ __forceinline__ void wave_pick(const uint32_t* __restrict__ fine, con
 struct Ranks4 { int64_t rank[4]; int array[4]; double scale[4]; };       // array: 0 = blur(k), 1 = blur(5)
 
 // ---- K2: first radix pass: the histogram of the window sums' high digit, one per distinct array.  grid (blocks, arrays) -----------
-__global__ __launch_bounds__(256) void k_limb_select0(const uint32_t* __restrict__ keysk, const uint32_t* __restrict__ keys5, int64_t n,
-                                                      int bits0, int bits1, uint32_t* __restrict__ hist0, uint32_t* __restrict__ coarse0) {
+struct LimbSelect0Args {
+    const uint32_t *keysk, *keys5;
+    int64_t n;
+    int bits0, bits1;
+    uint32_t *hist0, *coarse0;
+};
+SHG_MERGEABLE(k_limb_select0, LimbSelect0Args, __launch_bounds__(256)) {
+    const uint32_t* __restrict__ keysk = kargs.keysk;
+    const uint32_t* __restrict__ keys5 = kargs.keys5;
+    const int64_t n = kargs.n;
+    const int bits0 = kargs.bits0, bits1 = kargs.bits1;
+    uint32_t* __restrict__ hist0 = kargs.hist0;
+    uint32_t* __restrict__ coarse0 = kargs.coarse0;
     extern __shared__ uint32_t lds[];
     __shared__ uint32_t lc[256];
     const int a = blockIdx.y;
@@ -263,11 +296,32 @@ __global__ __launch_bounds__(256) void k_limb_select0(const uint32_t* __restrict
 
 // ---- K3: second radix pass, grid (blocks, 4 pairs); the last workgroup through forms the four order statistics
 // ((key * 2^-20) * scale: the blur's own arithmetic) and very_bright = np.percentile(blurred, 99) by NumPy's _lerp ---------------
-__global__ __launch_bounds__(256) void k_limb_select1(const uint32_t* __restrict__ keysk, const uint32_t* __restrict__ keys5, int64_t n,
-                                                      Ranks4 p, int bits0, int bits1, const uint32_t* __restrict__ hist0,
-                                                      const uint32_t* __restrict__ coarse0, uint32_t* __restrict__ hist1,
-                                                      uint32_t* __restrict__ coarse1, double gamma, uint32_t* __restrict__ done,
-                                                      unsigned long long* __restrict__ acc, double* __restrict__ out4) {
+struct LimbSelect1Args {
+    const uint32_t *keysk, *keys5;
+    int64_t n;
+    Ranks4 p;
+    int bits0, bits1;
+    const uint32_t *hist0, *coarse0;
+    uint32_t *hist1, *coarse1;
+    double gamma;
+    uint32_t* done;
+    unsigned long long* acc;
+    double* out4;
+};
+SHG_MERGEABLE(k_limb_select1, LimbSelect1Args, __launch_bounds__(256)) {
+    const uint32_t* __restrict__ keysk = kargs.keysk;
+    const uint32_t* __restrict__ keys5 = kargs.keys5;
+    const int64_t n = kargs.n;
+    const Ranks4& p = kargs.p;
+    const int bits0 = kargs.bits0, bits1 = kargs.bits1;
+    const uint32_t* __restrict__ hist0 = kargs.hist0;
+    const uint32_t* __restrict__ coarse0 = kargs.coarse0;
+    uint32_t* __restrict__ hist1 = kargs.hist1;
+    uint32_t* __restrict__ coarse1 = kargs.coarse1;
+    const double gamma = kargs.gamma;
+    uint32_t* __restrict__ done = kargs.done;
+    unsigned long long* __restrict__ acc = kargs.acc;
+    double* __restrict__ out4 = kargs.out4;
     extern __shared__ uint32_t lds[];
     __shared__ uint32_t lc[256];
     __shared__ int last;
@@ -325,8 +379,17 @@ __device__ __forceinline__ double key_f64(uint64_t k) {
 }
 
 // ---- K3: min / max of blurred[blurred < very_bright] ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_limb_flood_minmax(const uint32_t* __restrict__ keysk, int64_t n, double scale_k,
-                                                           unsigned long long* __restrict__ acc) {
+struct LimbFloodMinmaxArgs {
+    const uint32_t* keysk;
+    int64_t n;
+    double scale_k;
+    unsigned long long* acc;
+};
+SHG_MERGEABLE(k_limb_flood_minmax, LimbFloodMinmaxArgs, __launch_bounds__(256)) {
+    const uint32_t* __restrict__ keysk = kargs.keysk;
+    const int64_t n = kargs.n;
+    const double scale_k = kargs.scale_k;
+    unsigned long long* __restrict__ acc = kargs.acc;
     const double very_bright = __longlong_as_double((long long)acc[3]);
     unsigned long long lo = ~0ull, hi = 0ull;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -356,9 +419,24 @@ __global__ __launch_bounds__(256) void k_limb_flood_minmax(const uint32_t* __res
 
 // ---- K4: np.histogram(data, 20) over data = blurred[blurred < very_bright]; the last workgroup to finish stores the stage's
 // numbers where the host reads them: packed[0..3] order statistics, [4] sum(image), [5] min, [6] max, then 20 uint32 counts ---
-__global__ __launch_bounds__(256) void k_limb_flood_hist(const uint32_t* __restrict__ keysk, int64_t n, double scale_k,
-                                                         const unsigned long long* __restrict__ acc, const double* __restrict__ out4,
-                                                         uint32_t* __restrict__ counts, uint32_t* __restrict__ done, double* __restrict__ packed) {
+struct LimbFloodHistArgs {
+    const uint32_t* keysk;
+    int64_t n;
+    double scale_k;
+    const unsigned long long* acc;
+    const double* out4;
+    uint32_t *counts, *done;
+    double* packed;
+};
+SHG_MERGEABLE(k_limb_flood_hist, LimbFloodHistArgs, __launch_bounds__(256)) {
+    const uint32_t* __restrict__ keysk = kargs.keysk;
+    const int64_t n = kargs.n;
+    const double scale_k = kargs.scale_k;
+    const unsigned long long* __restrict__ acc = kargs.acc;
+    const double* __restrict__ out4 = kargs.out4;
+    uint32_t* __restrict__ counts = kargs.counts;
+    uint32_t* __restrict__ done = kargs.done;
+    double* __restrict__ packed = kargs.packed;
     const double very_bright = __longlong_as_double((long long)acc[3]);
     __shared__ double edges[21];
     __shared__ uint32_t lc[20];
@@ -451,9 +529,24 @@ __device__ __forceinline__ void lds_union(int* lab, int a, int b) {
 
 // Dynamic LDS (bytes): F u8 [(TH+4+2R)][(TW+4+2R)] | gv f64 [TH+4] | V f64 [(TH+4)][(TW+4+2R)] | Sm f64 [(TH+4)][(TW+4)] |
 // I, J, M f64 [(TH+2)][(TW+2)] each | lab int [TH*TW]
-__global__ __launch_bounds__(NT1) void k_limb_canny_tile(const uint32_t* __restrict__ keysk, int h, int w, double scale_k, double flood_thresh,
-                                                         GaussW g, double low, double high, uint8_t* __restrict__ mask, int* __restrict__ L,
-                                                         int* __restrict__ row_counts, int tiles_x) {
+struct LimbCannyArgs {
+    const uint32_t* keysk;
+    int h, w;
+    double scale_k, flood_thresh;
+    GaussW g;
+    double low, high;
+    uint8_t* mask;
+    int *L, *row_counts;
+    int tiles_x;
+};
+SHG_MERGEABLE(k_limb_canny_tile, LimbCannyArgs, __launch_bounds__(NT1)) {
+    const uint32_t* __restrict__ keysk = kargs.keysk;
+    const int h = kargs.h, w = kargs.w, tiles_x = kargs.tiles_x;
+    const double scale_k = kargs.scale_k, flood_thresh = kargs.flood_thresh, low = kargs.low, high = kargs.high;
+    const GaussW& g = kargs.g;
+    uint8_t* __restrict__ mask = kargs.mask;
+    int* __restrict__ L = kargs.L;
+    int* __restrict__ row_counts = kargs.row_counts;
     extern __shared__ double lds_d[];
     const int R = g.radius;
     const int FW = TW + 4 + 2 * R, FH = TH + 4 + 2 * R, VW = FW, VH = TH + 4, SW = TW + 4, MW = TW + 2, MH = TH + 2;
@@ -616,7 +709,15 @@ __device__ __forceinline__ void g_union(int* L, int a, int b) {
 }
 
 // one thread per pixel of a tile's first row (blockIdx.y = 0: tile row, x), first or last column (blockIdx.y = 1: column line, y)
-__global__ __launch_bounds__(256) void k_limb_border_merge(const uint8_t* __restrict__ mask, int h, int w, int* __restrict__ L) {
+struct LimbBorderArgs {
+    const uint8_t* mask;
+    int h, w;
+    int* L;
+};
+SHG_MERGEABLE(k_limb_border_merge, LimbBorderArgs, __launch_bounds__(256)) {
+    const uint8_t* __restrict__ mask = kargs.mask;
+    const int h = kargs.h, w = kargs.w;
+    int* __restrict__ L = kargs.L;
     const int j = blockIdx.x * 256 + threadIdx.x;
     int y, x;
     if (blockIdx.y == 0) {
@@ -644,8 +745,20 @@ __global__ __launch_bounds__(256) void k_limb_border_merge(const uint8_t* __rest
 
 // ---- K7: every low pixel in raster order with its component's root, the high bit in bit 30 of the root: comp = [m | idx[n] | root[n]]
 // grid: h rows.
-__global__ __launch_bounds__(256) void k_limb_emit(const uint8_t* __restrict__ mask, const int* __restrict__ L, int h, int w,
-                                                   const int* __restrict__ row_counts, int tiles_x, int n, int* __restrict__ comp) {
+struct LimbEmitArgs {
+    const uint8_t* mask;
+    const int* L;
+    int h, w;
+    const int* row_counts;
+    int tiles_x, n;
+    int* comp;
+};
+SHG_MERGEABLE(k_limb_emit, LimbEmitArgs, __launch_bounds__(256)) {
+    const uint8_t* __restrict__ mask = kargs.mask;
+    const int* __restrict__ L = kargs.L;
+    const int h = kargs.h, w = kargs.w, tiles_x = kargs.tiles_x, n = kargs.n;
+    const int* __restrict__ row_counts = kargs.row_counts;
+    int* __restrict__ comp = kargs.comp;
     __shared__ int wave_cnt[4];
     __shared__ int base;
     __shared__ int part[4];
@@ -730,31 +843,31 @@ extern "C" int shg_limb_prepare(const uint16_t* img, int64_t h, int64_t w, int64
     uint32_t *keysk = ws + lay.keysk, *keys5 = k == 5 ? keysk : ws + lay.keys5;
     double* out4 = reinterpret_cast<double*>(acc + 4 + 3 * FLOOD_SLOTS);
     SHG_PROF("limb_prepare", st);
-    if (hipError_t e = hipMemsetAsync(ws, 0, lay.zero_words * 4, st)) { shg::set_error("shg_limb_prepare: %s", hipGetErrorString(e)); return (int)e; }
+    if (int e = SHG_LAUNCH(k_zero_words, dim3((unsigned)std::min<size_t>((lay.zero_words + 255) / 256, 64)), dim3(256), 0, st, ZeroWordsArgs{ws, lay.zero_words})) return e;
     Ranks4 p;
     const double scale_k = 1.0 / ((double)k * (double)k), scale_5 = 1.0 / 25.0;
     for (int i = 0; i < 4; ++i) { p.rank[i] = host_ranks4[i]; p.array[i] = (i < 2 && k != 5) ? 1 : 0; p.scale[i] = (i < 2) ? scale_5 : scale_k; }
     dim3 grid1((unsigned)((sw + BT - 1) / BT), (unsigned)((sh + BT - 1) / BT));
     const int vec4 = (reinterpret_cast<uintptr_t>(img) & 7) == 0 && pitch % 4 == 0;
-    k_limb_blur<<<grid1, 256, 0, st>>>(img, (int)h, (int)w, pitch, (int)sh, (int)sw, k, vec4, keysk, keys5, acc);
-    if (int e = shg::check_launch("k_limb_blur")) return e;
+    if (int e = SHG_LAUNCH(k_limb_blur, grid1, dim3(256), 0, st, LimbBlurArgs{img, (int)h, (int)w, pitch, (int)sh, (int)sw, k, vec4, keysk, keys5, acc})) return e;
     static const bool lds_ok = [] {                             // a 2^14-bin histogram is the default 64 KB of dynamic LDS, to the byte
         return hipFuncSetAttribute(reinterpret_cast<const void*>(k_limb_select0), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void*>(k_limb_select1), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+               hipFuncSetAttribute(reinterpret_cast<const void*>(k_limb_select1), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(k_limb_select0_multi), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(k_limb_select1_multi), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
     }();
     if (!lds_ok) (void)hipGetLastError();
     int64_t blocks = (n + 2047) / 2048;
     if (blocks > 256) blocks = 256;
-    k_limb_select0<<<dim3((unsigned)blocks, k == 5 ? 1u : 2u), 256, ((size_t)1 << lay.bits0) * 4, st>>>(keysk, keys5, n, lay.bits0, lay.bits1, hist0, coarse0);
-    if (int e = shg::check_launch("k_limb_select0")) return e;
-    k_limb_select1<<<dim3((unsigned)blocks, 4u), 256, ((size_t)1 << lay.bits1) * 4, st>>>(keysk, keys5, n, p, lay.bits0, lay.bits1, hist0, coarse0, hist1,
-                                                                                          coarse1, gamma99, done, acc, out4);
-    if (int e = shg::check_launch("k_limb_select1")) return e;
-    k_limb_flood_minmax<<<(unsigned)blocks, 256, 0, st>>>(keysk, n, scale_k, acc);
-    if (int e = shg::check_launch("k_limb_flood_minmax")) return e;
-    k_limb_flood_hist<<<(unsigned)blocks, 256, 0, st>>>(keysk, n, scale_k, acc, out4, counts, done + 1, packed);
+    if (int e = SHG_LAUNCH(k_limb_select0, dim3((unsigned)blocks, k == 5 ? 1u : 2u), dim3(256), ((size_t)1 << lay.bits0) * 4, st,
+                           LimbSelect0Args{keysk, keys5, n, lay.bits0, lay.bits1, hist0, coarse0}))
+        return e;
+    if (int e = SHG_LAUNCH(k_limb_select1, dim3((unsigned)blocks, 4u), dim3(256), ((size_t)1 << lay.bits1) * 4, st,
+                           LimbSelect1Args{keysk, keys5, n, p, lay.bits0, lay.bits1, hist0, coarse0, hist1, coarse1, gamma99, done, acc, out4}))
+        return e;
+    if (int e = SHG_LAUNCH(k_limb_flood_minmax, dim3((unsigned)blocks), dim3(256), 0, st, LimbFloodMinmaxArgs{keysk, n, scale_k, acc})) return e;
     *keys_out = keysk;
-    return shg::check_launch("k_limb_flood_hist");
+    return SHG_LAUNCH(k_limb_flood_hist, dim3((unsigned)blocks), dim3(256), 0, st, LimbFloodHistArgs{keysk, n, scale_k, acc, out4, counts, done + 1, packed});
 }
 
 extern "C" size_t shg_limb_edges_workspace_bytes(int64_t sh, int64_t sw) {
@@ -785,16 +898,16 @@ extern "C" int shg_limb_edges(const uint32_t* keys, int64_t sh, int64_t sw, int 
     hipStream_t st = shg::as_stream(stream);
     SHG_PROF("limb_edges", st);
     dim3 grid((unsigned)tiles_x, (unsigned)((sh + TH - 1) / TH));
-    static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_limb_canny_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_limb_canny_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                               hipFuncSetAttribute(reinterpret_cast<const void*>(k_limb_canny_tile_multi), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
     if (!lds_ok) (void)hipGetLastError();
-    k_limb_canny_tile<<<grid, NT1, canny_tile_lds(radius), st>>>(keys, (int)sh, (int)sw, 1.0 / ((double)k * (double)k), flood_thresh, g, low, high,
-                                                                 mask, L, row_counts, tiles_x);
-    if (int e = shg::check_launch("k_limb_canny_tile")) return e;
+    if (int e = SHG_LAUNCH(k_limb_canny_tile, grid, dim3(NT1), canny_tile_lds(radius), st,
+                           LimbCannyArgs{keys, (int)sh, (int)sw, 1.0 / ((double)k * (double)k), flood_thresh, g, low, high, mask, L, row_counts, tiles_x}))
+        return e;
     {
         const int64_t tops = ((sh + TH - 1) / TH) * sw, sides = 2 * (int64_t)tiles_x * sh;
-        k_limb_border_merge<<<dim3((unsigned)((std::max(tops, sides) + 255) / 256), 2u), 256, 0, st>>>(mask, (int)sh, (int)sw, L);
+        if (int e = SHG_LAUNCH(k_limb_border_merge, dim3((unsigned)((std::max(tops, sides) + 255) / 256), 2u), dim3(256), 0, st, LimbBorderArgs{mask, (int)sh, (int)sw, L}))
+            return e;
     }
-    if (int e = shg::check_launch("k_limb_border_merge")) return e;
-    k_limb_emit<<<(unsigned)sh, 256, 0, st>>>(mask, L, (int)sh, (int)sw, row_counts, tiles_x, (int)n, comp);
-    return shg::check_launch("k_limb_emit");
+    return SHG_LAUNCH(k_limb_emit, dim3((unsigned)sh), dim3(256), 0, st, LimbEmitArgs{mask, L, (int)sh, (int)sw, row_counts, tiles_x, (int)n, comp});
 }

@@ -114,6 +114,7 @@ int shg::crop_pad_batch(const uint16_t* const* host_srcs, int64_t k, int64_t h, 
     for (int64_t i0 = 0; i0 < k; i0 += shg::kMaxBatch) {
         const int m = (int)std::min<int64_t>(shg::kMaxBatch, k - i0);
         dim3 grid((unsigned)((nw + 255) / 256), (unsigned)h, (unsigned)m);
+        SHG_DIRECT(st);
         k_crop_pad<<<grid, 256, 0, st>>>(shg::make_batch(host_srcs, (int)i0, m), pitch, shg::make_batch(host_dsts, (int)i0, m), nw, dst_pitch, sx0, dx0, n,
                                          (uint16_t)(fill < 0 ? 0 : fill), fill < 0 ? 1 : 0);
         if (int e = shg::check_launch("k_crop_pad")) return e;
@@ -128,6 +129,7 @@ extern "C" int shg_rescale_u16(const uint16_t* img, int64_t h, int64_t w, int64_
     SHG_REQUIRE(65535.0 >= hi && hi > lo, SHG_E_ARG, "shg_rescale_u16: need sat >= hi > lo (got lo=%g hi=%g)", lo, hi);   // assert, solex_util.py:521
     SHG_REQUIRE(h < 65536, SHG_E_UNSUPPORTED, "shg_rescale_u16: more than 65535 rows");
     dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
+    SHG_DIRECT(shg::as_stream(stream));
     { SHG_PROF("rescale", shg::as_stream(stream)); k_rescale<<<grid, 256, 0, shg::as_stream(stream)>>>(img, w, pitch, 65535.0 * alpha, lo, hi - lo, dst, dst_pitch); }
     return shg::check_launch("k_rescale");
 }
@@ -139,6 +141,7 @@ extern "C" int shg_rescale_u8(const uint8_t* img, int64_t h, int64_t w, int64_t 
     SHG_REQUIRE(255.0 >= hi && hi > lo, SHG_E_ARG, "shg_rescale_u8: need sat >= hi > lo (got lo=%g hi=%g)", lo, hi);
     SHG_REQUIRE(h < 65536, SHG_E_UNSUPPORTED, "shg_rescale_u8: more than 65535 rows");
     dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
+    SHG_DIRECT(shg::as_stream(stream));
     { SHG_PROF("rescale", shg::as_stream(stream)); k_rescale_u8<<<grid, 256, 0, shg::as_stream(stream)>>>(img, w, pitch, 255.0 * alpha, lo, hi - lo, dst, dst_pitch); }
     return shg::check_launch("k_rescale_u8");
 }
@@ -151,6 +154,7 @@ extern "C" int shg_fill_disc_u16(uint16_t* img, int64_t h, int64_t w, int64_t pi
     SHG_REQUIRE(r >= 0 && r < 32768, SHG_E_UNSUPPORTED, "shg_fill_disc_u16: radius %lld out of range", (long long)r);
     hipStream_t st = shg::as_stream(stream);
     dim3 grid((unsigned)((2 * r + 1 + 255) / 256), (unsigned)(2 * r + 1));
+    SHG_DIRECT(st);
     { SHG_PROF("fill_disc", st); k_fill_disc<<<grid, 256, 0, st>>>(img, h, w, pitch, x0, y0, r, value); }
     return shg::check_launch("k_fill_disc");
 }
@@ -161,6 +165,7 @@ extern "C" int shg_downscale_mean_u16(const uint16_t* img, int64_t h, int64_t w,
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w && factor >= 1 && factor <= 64, SHG_E_ARG, "shg_downscale_mean_u16: bad size");
     const int64_t oh = (h + factor - 1) / factor, ow = (w + factor - 1) / factor;
     SHG_REQUIRE(oh * ow < (1ll << 31), SHG_E_UNSUPPORTED, "shg_downscale_mean_u16: image too large");
+    SHG_DIRECT(shg::as_stream(stream));
     { SHG_PROF("downscale", shg::as_stream(stream)); k_downscale_mean<<<(unsigned)((oh * ow + 255) / 256), 256, 0, shg::as_stream(stream)>>>(
           img, h, w, pitch, factor, oh, ow, (reinterpret_cast<uintptr_t>(img) & 7) == 0 && pitch % 4 == 0, dst); }
     return shg::check_launch("k_downscale_mean");
@@ -171,7 +176,8 @@ extern "C" int shg_downscale_mean_u16(const uint16_t* img, int64_t h, int64_t w,
 // went back over protus for the disc).  Same arithmetic per pixel as k_rescale / k_fill_disc.
 namespace {
 struct Bounds6 { double lo[3], span[3]; };
-constexpr int kProductsBatch = 16;                  // disks per launch of the products kernels (their bounds travel by value)
+constexpr int kProductsBatch = 8;                   // disks per launch of the products kernels (their bounds and five pointer tables travel by value)
+using ProdPtrs = shg::PtrBatchN<kProductsBatch>;
 struct BoundsBatch { Bounds6 v[kProductsBatch]; };
 
 __device__ __forceinline__ uint16_t rescale1(double px, double lo, double span) {
@@ -227,10 +233,27 @@ __device__ __forceinline__ uint32_t rescale1_fast(double px, double lo, double s
 // rows, their loads issued before the first use (what took k_warp_rows from 227 to 144 us over 21 disks did nothing here).
 // grid (ceil(vectors per row * row groups / 256), 1, disks)
 constexpr int PROD_ROWS = 1;            // (4 rows per lane, loads hoisted: 160 us per 16-disk launch against 140 -- the extra live registers cost more than the requests in flight bring)
-__global__ __launch_bounds__(256) void k_products8(shg::PtrBatch frames, int64_t frame_pitch,
-                                                   shg::PtrBatch cl1s, int64_t cl1_pitch, int64_t h, int64_t w, BoundsBatch bb,
-                                                   shg::PtrBatch hcs, shg::PtrBatch protuss, shg::PtrBatch ccs,
-                                                   int64_t dst_pitch, int64_t x0, int64_t y0, int64_t r, StatsSource stats) {
+struct ProductsArgs {
+    ProdPtrs frames;
+    int64_t frame_pitch;
+    ProdPtrs cl1s;
+    int64_t cl1_pitch, h, w;
+    BoundsBatch bb;
+    ProdPtrs hcs, protuss, ccs;
+    int64_t dst_pitch, x0, y0, r;
+    StatsSource stats;
+};
+
+SHG_MERGEABLE(k_products8, ProductsArgs, __launch_bounds__(256)) {
+    const ProdPtrs& frames = kargs.frames;
+    const ProdPtrs& cl1s = kargs.cl1s;
+    const ProdPtrs& hcs = kargs.hcs;
+    const ProdPtrs& protuss = kargs.protuss;
+    const ProdPtrs& ccs = kargs.ccs;
+    const int64_t frame_pitch = kargs.frame_pitch, cl1_pitch = kargs.cl1_pitch, h = kargs.h, w = kargs.w, dst_pitch = kargs.dst_pitch,
+                  x0 = kargs.x0, y0 = kargs.y0, r = kargs.r;
+    const BoundsBatch& bb = kargs.bb;
+    const StatsSource& stats = kargs.stats;
     // lanes are dealt (row group, vector) pairs in one flat sequence: a width just past a multiple of 2048 pixels (2096 at C2)
     // would leave every second workgroup of a (x, y) grid with half a dozen lanes to do
     const uint32_t nv = (uint32_t)((w + 7) / 8);
@@ -312,9 +335,9 @@ __global__ __launch_bounds__(256) void k_products8(shg::PtrBatch frames, int64_t
     }
 }
 
-__global__ __launch_bounds__(256) void k_products(shg::PtrBatch frames, int64_t frame_pitch,
-                                                  shg::PtrBatch cl1s, int64_t cl1_pitch, int64_t w, BoundsBatch bb,
-                                                  shg::PtrBatch hcs, shg::PtrBatch protuss, shg::PtrBatch ccs,
+__global__ __launch_bounds__(256) void k_products(ProdPtrs frames, int64_t frame_pitch,
+                                                  ProdPtrs cl1s, int64_t cl1_pitch, int64_t w, BoundsBatch bb,
+                                                  ProdPtrs hcs, ProdPtrs protuss, ProdPtrs ccs,
                                                   int64_t dst_pitch, int64_t x0, int64_t y0, int64_t r, StatsSource stats) {
     const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t y = blockIdx.y;
@@ -385,17 +408,21 @@ int shg::contrast_products_batch(const uint16_t* const* host_frames, int64_t fra
                 bb.v[d].span[i] = host_lo_hi6[6 * (i0 + d) + 2 * i + 1] - bb.v[d].lo[i];
             }
         const StatsSource src = {stats5 ? stats5 + 5 * i0 : nullptr, g_bright, g_dark, mirror5 ? mirror5 + 5 * i0 : nullptr};
-        const shg::PtrBatch f = shg::make_batch(host_frames, (int)i0, m), c = shg::make_batch(host_cl1, (int)i0, m), hc = shg::make_batch(host_hc, (int)i0, m),
-                            pr = shg::make_batch(host_protus, (int)i0, m), cc = shg::make_batch(host_cc, (int)i0, m);
+        const ProdPtrs f = shg::make_batch_n<kProductsBatch>(host_frames, (int)i0, m), c = shg::make_batch_n<kProductsBatch>(host_cl1, (int)i0, m),
+                       hc = shg::make_batch_n<kProductsBatch>(host_hc, (int)i0, m), pr = shg::make_batch_n<kProductsBatch>(host_protus, (int)i0, m),
+                       cc = shg::make_batch_n<kProductsBatch>(host_cc, (int)i0, m);
         if (vec) {
             const int64_t lanes = ((w + 7) / 8) * ((h + PROD_ROWS - 1) / PROD_ROWS);
             dim3 grid((unsigned)((lanes + 255) / 256), 1u, (unsigned)m);
-            k_products8<<<grid, 256, 0, st>>>(f, frame_pitch, c, cl1_pitch, h, w, bb, hc, pr, cc, dst_pitch, disc_x0, disc_y0, disc_r > 0 ? disc_r : 0, src);
+            if (int e = SHG_LAUNCH(k_products8, grid, dim3(256), 0, st,
+                                   ProductsArgs{f, frame_pitch, c, cl1_pitch, h, w, bb, hc, pr, cc, dst_pitch, disc_x0, disc_y0, disc_r > 0 ? disc_r : 0, src}))
+                return e;
         } else {
             dim3 grid((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)m);
+            SHG_DIRECT(st);
             k_products<<<grid, 256, 0, st>>>(f, frame_pitch, c, cl1_pitch, w, bb, hc, pr, cc, dst_pitch, disc_x0, disc_y0, disc_r > 0 ? disc_r : 0, src);
+            if (int e = shg::check_launch("k_products")) return e;
         }
-        if (int e = shg::check_launch("k_products")) return e;
     }
     return 0;
 }

@@ -18,6 +18,10 @@ inline int check_launch(const char* what) {
     return 0;
 }
 
+}  // namespace shg
+#include "launch.h"
+namespace shg {
+
 #define SHG_REQUIRE(cond, code, ...)            \
     do {                                        \
         if (!(cond)) {                          \
@@ -66,17 +70,23 @@ struct HostScope {
 // The images of one launch over several disks of a file (a Doppler stack: Solex_recon.py:105-133 loops over the shifts):
 // blockIdx.z picks the disk, the kernel its pointers from this by-value table.  At most kMaxBatch disks per launch.
 constexpr int kMaxBatch = 32;
-struct PtrBatch {
-    const void* p[kMaxBatch];
+template <int N>
+struct PtrBatchN {
+    const void* p[N];
     template <typename T>
     __device__ __forceinline__ T* at(int i) const { return static_cast<T*>(const_cast<void*>(p[i])); }
 };
-template <typename T>
-inline PtrBatch make_batch(T* const* host_ptrs, int first, int count) {
-    PtrBatch b = {};
-    for (int i = 0; i < count && i < kMaxBatch; ++i) b.p[i] = host_ptrs[first + i];
+using PtrBatch = PtrBatchN<kMaxBatch>;
+// (a kernel that takes several tables, or other per-disk arguments by value, takes fewer disks per launch and narrower tables: the
+// argument block of a dispatch shared by several scans -- launch.h -- holds one such set per scan)
+template <int N, typename T>
+inline PtrBatchN<N> make_batch_n(T* const* host_ptrs, int first, int count) {
+    PtrBatchN<N> b = {};
+    for (int i = 0; i < count && i < N; ++i) b.p[i] = host_ptrs[first + i];
     return b;
 }
+template <typename T>
+inline PtrBatch make_batch(T* const* host_ptrs, int first, int count) { return make_batch_n<kMaxBatch>(host_ptrs, first, count); }
 
 // One launch per kernel for the k disks of a file (host arrays of device pointers; any k, cut into launches of kMaxBatch):
 // the per-disk stages of shg_stage_process_frames and the warps of shg_scan_file.  The single-image entry points of the C ABI
@@ -107,6 +117,13 @@ bool contrast_stats_batches(int64_t h, int64_t w, int tiles, double clip_limit);
 int contrast_stats_batch(const uint16_t* const* host_frames, int64_t k, int64_t h, int64_t w, int64_t pitch, double clip_limit, int tiles,
                          uint16_t* const* host_cl1, int64_t cl1_pitch, const int64_t* ranks_frame2, const int64_t* ranks_cl13, double* out5,
                          void* workspace, size_t workspace_bytes, shg_stream_t stream, const FrameSource* from = nullptr);
+
+// The launch combiner of a scan pool (combine.hip; launch.h says what it is for)
+Combiner* combiner_create();
+void combiner_destroy(Combiner* c);
+int combiner_enter(Combiner* c, Recorder* rec, hipStream_t own);
+void combiner_leave(Combiner* c);
+void combiner_stats(Combiner* c, unsigned long long* out3);
 
 constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kCUs = 256;          // MI355X

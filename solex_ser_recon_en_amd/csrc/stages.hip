@@ -43,14 +43,12 @@ struct Arena {
         if (int e_ = (expr)) return e_; \
     } while (0)
 
-#define STAGE_HIP(expr, who)                                               \
+// "The host needs what this stage has launched so far": hipStreamSynchronize -- or, on a thread of a scan pool, the point where
+// the scan's recorded launches go to the device together with the other scans' (launch.h).
+#define STAGE_SYNC(st, who)                                                \
     do {                                                                   \
-        SHG_HOST_TIME("sync " #expr);                                      \
-        hipError_t he_ = (expr);                                           \
-        if (he_ != hipSuccess) {                                           \
-            shg::set_error("%s: %s", who, hipGetErrorString(he_));         \
-            return (int)he_;                                               \
-        }                                                                  \
+        SHG_HOST_TIME("sync");                                             \
+        if (int se_ = shg::stream_sync(st, who)) return se_;               \
     } while (0)
 
 // ---- host <-> device without the copy engines ---------------------------------------------------------------
@@ -61,14 +59,27 @@ struct Arena {
 // result only the host reads stores it straight into the staging area; everything else crosses with one small
 // kernel of ours (k_words), which also lets the device decide how much to send (k_edge_list).  Visibility follows the
 // stream: host writes before the launch are seen by the kernel, kernel stores are seen after hipStreamSynchronize.
-__global__ __launch_bounds__(256) void k_words(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t n_words) {
+struct WordsArgs {
+    uint32_t* dst;
+    const uint32_t* src;
+    size_t n_words;
+    uint32_t* zero;
+    size_t zero_words;
+};
+SHG_MERGEABLE(k_words, WordsArgs, __launch_bounds__(256)) {
+    uint32_t* __restrict__ dst = kargs.dst;
+    const uint32_t* __restrict__ src = kargs.src;
+    const size_t n_words = kargs.n_words;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
 // the same, and `zero_words` words at `zero` cleared on the way (a scratch area the next kernel accumulates into: one launch instead of a
 // copy and a memset -- every launch is an L2 write-back and invalidate under the other scans' kernels)
-__global__ __launch_bounds__(256) void k_words_zero(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t n_words,
-                                                    uint32_t* __restrict__ zero, size_t zero_words) {
+SHG_MERGEABLE(k_words_zero, WordsArgs, __launch_bounds__(256)) {
+    uint32_t* __restrict__ dst = kargs.dst;
+    const uint32_t* __restrict__ src = kargs.src;
+    const size_t n_words = kargs.n_words, zero_words = kargs.zero_words;
+    uint32_t* __restrict__ zero = kargs.zero;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (size_t)gridDim.x * 256) dst[i] = src[i];
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < zero_words; i += (size_t)gridDim.x * 256) zero[i] = 0;
 }
@@ -87,8 +98,7 @@ inline int move_words(void* dst, const void* src, size_t bytes, hipStream_t st) 
     const size_t n_words = (bytes + 3) / 4;                      // arena slots are 256-byte aligned and padded
     if (n_words == 0) return 0;
     const unsigned blocks = (unsigned)std::min<size_t>((n_words + 255) / 256, 64);
-    k_words<<<blocks, 256, 0, st>>>(static_cast<uint32_t*>(dst), static_cast<const uint32_t*>(src), n_words);
-    return shg::check_launch("k_words");
+    return SHG_LAUNCH(k_words, dim3(blocks), dim3(256), 0, st, WordsArgs{static_cast<uint32_t*>(dst), static_cast<const uint32_t*>(src), n_words, nullptr, 0});
 }
 
 // The staging area as the GPU addresses it (the same address under unified addressing).
@@ -177,7 +187,7 @@ extern "C" int shg_stage_mean_fit(const void* stack, int64_t n_frames, int64_t h
         STAGE_TRY(shg_box_blur_u16(max_out, ih, iw, 5, 5, blur, tmp, stream));
         STAGE_TRY(shg_row_mean_u16(blur, ih, iw, row_means, stream));
     }
-    STAGE_HIP(hipStreamSynchronize(st), "shg_stage_mean_fit");
+    STAGE_SYNC(st, "shg_stage_mean_fit");
     int64_t y1, y2;
     STAGE_TRY(shg_host_detect_bord(h_means, ih, &y1, &y2));
     const int64_t clip = (int64_t)((double)(y2 - y1) * 0.05);                                 // :224-226
@@ -195,7 +205,7 @@ extern "C" int shg_stage_mean_fit(const void* stack, int64_t n_frames, int64_t h
         STAGE_TRY(shg_row_argmin_u16(blur, ih, iw, lo, hi, traces, stream));
         STAGE_TRY(shg_row_argmin_u16(mean_out, ih, iw, 0, iw, traces + ih, stream));
     }
-    STAGE_HIP(hipStreamSynchronize(st), "shg_stage_mean_fit");
+    STAGE_SYNC(st, "shg_stage_mean_fit");
     if (host_trace_sharp) memcpy(host_trace_sharp, h_traces + ih, (size_t)ih * 4);
     return shg_host_line_fit(h_traces, h_traces + ih, ih, y1, y2, (int32_t)lo, host_p4, host_fit, host_mask_good);
 }
@@ -251,8 +261,8 @@ extern "C" int shg_stage_extract(const void* stack, int64_t n_frames, int64_t he
     if (minmax_slots) {                                  // the plan goes up and the extrema's slots are cleared in one launch
         const size_t n_words = ((size_t)(end - reinterpret_cast<const char*>(h_ind)) + 3) / 4, zero_words = (size_t)n_shifts * 130;
         const unsigned blocks = (unsigned)std::min<size_t>((std::max(n_words, zero_words) + 255) / 256, 64);
-        k_words_zero<<<blocks, 256, 0, st>>>(reinterpret_cast<uint32_t*>(ind_l), reinterpret_cast<const uint32_t*>(stg.on_device(h_ind)), n_words, minmax_slots, zero_words);
-        STAGE_TRY(shg::check_launch("k_words_zero"));
+        STAGE_TRY(SHG_LAUNCH(k_words_zero, dim3(blocks), dim3(256), 0, st,
+                             WordsArgs{reinterpret_cast<uint32_t*>(ind_l), reinterpret_cast<const uint32_t*>(stg.on_device(h_ind)), n_words, minmax_slots, zero_words}));
         shg::t_minmax_slots_zeroed = true;               // (read and reset by the extraction entry point this thread calls next)
     } else {
         STAGE_TRY(move_words(ind_l, stg.on_device(h_ind), (size_t)(end - reinterpret_cast<const char*>(h_ind)), st));
@@ -347,7 +357,7 @@ extern "C" int shg_stage_limb_points(const uint16_t* disk, int64_t h, int64_t w,
         STAGE_TRY(shg_host_percentile_plan(n, 99.0, &ranks[2], &ranks[3], &gamma99));          // np.percentile(blurred, 99) (:165)
         const uint32_t* keys = nullptr;
         STAGE_TRY(shg_limb_prepare(disk, h, w, pitch, k, ranks, gamma99, stg.on_device(h_packed), &keys, prep_ws, prep_bytes, stream));
-        STAGE_HIP(hipStreamSynchronize(st), "shg_stage_limb_points");
+        STAGE_SYNC(st, "shg_stage_limb_points");
         const double median5 = (n & 1) ? h_packed[0] : (h_packed[0] + h_packed[1]) / 2;
         const double low = median5 / 10, high = low * 1.5;                                   // :241-243
         int64_t counts64[20];
@@ -364,7 +374,7 @@ extern "C" int shg_stage_limb_points(const uint16_t* disk, int64_t h, int64_t w,
             const double sigma = 2.0 - 0.5 * rung;
             const int radius = (int)(4.0 * sigma + 0.5);
             STAGE_TRY(shg_limb_edges(keys, sh, sw, k, thresh3, taps, radius, low, high, stg.on_device(h_comp), edge_ws, edge_bytes, stream));
-            STAGE_HIP(hipStreamSynchronize(st), "shg_stage_limb_points");
+            STAGE_SYNC(st, "shg_stage_limb_points");
             const int64_t m_low = h_comp[0];
             SHG_REQUIRE(m_low >= 0 && m_low <= n, SHG_E_RUNTIME, "shg_stage_limb_points: %lld edge pixels in an image of %lld", (long long)m_low, (long long)n);
             m = keep_strong_components(idx, root, m_low, n);
@@ -435,7 +445,7 @@ extern "C" int shg_stage_limb_points(const uint16_t* disk, int64_t h, int64_t w,
     }
     STAGE_TRY(shg_flood_stats_lerp_f64(small, blurred, n, packed + 2, gamma99, packed + 4, counts, flood_ws, stream));
     STAGE_TRY(move_words(stg.on_device(h_packed), packed, 8 * 8 + 20 * 4, st));
-    STAGE_HIP(hipStreamSynchronize(st), "shg_stage_limb_points");
+    STAGE_SYNC(st, "shg_stage_limb_points");
     const double median5 = (n & 1) ? h_packed[0] : (h_packed[0] + h_packed[1]) / 2;
     const double low = median5 / 10, high = low * 1.5;                                       // :241-243
     int64_t counts64[20];
@@ -452,9 +462,10 @@ extern "C" int shg_stage_limb_points(const uint16_t* disk, int64_t h, int64_t w,
         const int radius = (int)(4.0 * sigma + 0.5);
         STAGE_TRY(shg_canny_masks_f64(blurred, sh, sw, thresh3, taps, radius, low, high, low_mask, high_mask, canny_ws, canny_bytes, stream));
         STAGE_TRY(shg_edge_components(low_mask, high_mask, sh, sw, comp + 1, comp + 1 + n, comp, cc_ws, cc_bytes, stream));
+        SHG_DIRECT(st);
         k_edge_list<<<16, 256, 0, st>>>(comp, n, stg.on_device(h_comp));                      // the device knows how many: one trip
         STAGE_TRY(shg::check_launch("k_edge_list"));
-        STAGE_HIP(hipStreamSynchronize(st), "shg_stage_limb_points");
+        STAGE_SYNC(st, "shg_stage_limb_points");
         m = h_comp[0];
         SHG_REQUIRE(m >= 0 && m <= n, SHG_E_RUNTIME, "shg_stage_limb_points: %lld edge pixels in an image of %lld", (long long)m, (long long)n);
         if (m > 0) break;
@@ -614,7 +625,7 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
                 STAGE_TRY(shg_correlate1d_rows_f64(stats, k, n, taps_d, radius, sym ? 1 : (anti ? -1 : 0), stg.on_device(h_interior), stream));
                 use_interior = h_interior;
             }
-            STAGE_HIP(hipStreamSynchronize(st), "shg_stage_process_frames");
+            STAGE_SYNC(st, "shg_stage_process_frames");
         } else {
             for (int64_t i = 0; i < k; ++i) h_stats[i] = 0.0;                                 // y_ratios_r = [0], :386
         }
@@ -668,7 +679,7 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
     // rescale_brightness's assert (solex_util.py:521): checked once the products kernel has run.
     STAGE_TRY(shg::contrast_products_batch(host_final, out_pitch, host_cl1, out_pitch, k, h, out_w, nullptr, host_hc, host_protus, host_cc, out_pitch,
                                            disc_x0, disc_y0, disc_r, stream, out5, g_bright, g_dark, stg.on_device(h_out5)));
-    STAGE_HIP(hipStreamSynchronize(st), "shg_stage_process_frames");
+    STAGE_SYNC(st, "shg_stage_process_frames");
     for (int64_t i = 0; i < k; ++i) {
         const double* s = h_out5 + i * 5;
         const double bright = shg_host_lerp(s[0], s[1], g_bright);                            // basically the same as max

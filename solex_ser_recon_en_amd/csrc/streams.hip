@@ -69,7 +69,13 @@ int on_frame_pass_lane(hipStream_t st, int (*launch)(hipStream_t, void*), void* 
     static const bool host_wait = [] { const char* v = getenv("SHG_LANE_WAIT"); return !(v && v[0] == 's'); }();
     if (e == hipSuccess) {
         SHG_HOST_TIME("lane wait (queue + pass A)");
-        e = host_wait ? hipEventSynchronize(ev) : hipStreamWaitEvent(st, ev, 0);
+        if (host_wait || shg::t_rec) {                       // (a pool thread's later launches go through the combiner's streams, not `st`)
+            shg::pool_wait_begin();
+            e = hipEventSynchronize(ev);
+            shg::pool_wait_end();
+        } else {
+            e = hipStreamWaitEvent(st, ev, 0);
+        }
     }
     if (e != hipSuccess) { set_error("frame-pass lane: %s", hipGetErrorString(e)); return (int)e; }
     return 0;

@@ -44,7 +44,7 @@ struct Scratch {
     unsigned long long cand[CAP];
     unsigned long long kmin, kmax;
     uint32_t n_cand;
-    double red[4];
+    double red[8];
     double vfound[2];            // bucket select: the two values found
     int bad, nonfinite;
 };
@@ -257,11 +257,40 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// two sums in one round of barriers (red: 8 doubles)
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* red) {
+    int self = threadIdx.x & 63;
+    asm volatile("" : "+v"(self));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        a += __shfl(a, self ^ d);
+        b += __shfl(b, self ^ d);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = b; }
+    __syncthreads();
+    a = (red[0] + red[1]) + (red[2] + red[3]);
+    b = (red[4] + red[5]) + (red[6] + red[7]);
+}
+
 // grid (rows, 1, disks): blockIdx.z picks the image and its slice (out_stride doubles apart) of out / mirror
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8))) void k_rowpair_stats(shg::PtrBatch imgs, int64_t pitch, int64_t y1,
-                                                      const int32_t* __restrict__ xa, const int32_t* __restrict__ xb,
-                                                      const double* __restrict__ row_factor, double* __restrict__ out,
-                                                      double* __restrict__ mirror, int64_t out_stride) {
+struct RowpairArgs {
+    shg::PtrBatch imgs;
+    int64_t pitch, y1;
+    const int32_t *xa, *xb;
+    const double* row_factor;
+    double *out, *mirror;
+    int64_t out_stride;
+};
+
+SHG_MERGEABLE(k_rowpair_stats, RowpairArgs, __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8)))) {
+    const shg::PtrBatch& imgs = kargs.imgs;
+    const int64_t pitch = kargs.pitch, y1 = kargs.y1, out_stride = kargs.out_stride;
+    const int32_t* __restrict__ xa = kargs.xa;
+    const int32_t* __restrict__ xb = kargs.xb;
+    const double* __restrict__ row_factor = kargs.row_factor;
+    double* __restrict__ out = kargs.out;
+    double* __restrict__ mirror = kargs.mirror;
     extern __shared__ double vals[];     // [n]: the log-ratios of the chord
     __shared__ Scratch sc;
     const uint16_t* __restrict__ img = imgs.at<const uint16_t>(blockIdx.z);
@@ -335,8 +364,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8))) void k_
         }
         if (odd) sc.nonfinite = 1;
     }
-    sum1 = block_sum(sum1, sc.red);
-    sum2 = block_sum(sum2, sc.red);
+    block_sum2(sum1, sum2, sc.red);
     __syncthreads();
     if (sc.bad) {
         emit(__builtin_nan(""));
@@ -385,8 +413,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8))) void k_
         const bool keep = (mdev != 0.0) ? (dev < twice) : true;        // s = d/mdev if mdev else zeros; data[s < 2] (see above)
         if (keep) { s += x; cnt += 1.0; }
     }
-    s = block_sum(s, sc.red);
-    cnt = block_sum(cnt, sc.red);
+    block_sum2(s, cnt, sc.red);
     emit(s / cnt);
 }
 
@@ -471,8 +498,20 @@ __global__ __launch_bounds__(256) void k_scale_rows8(shg::PtrBatch imgs, int64_t
 // predicated global loads a single 1800-sample row took 30 us: one request in flight per lane).
 constexpr int CORR_MAXR = 1024;
 
-__global__ __launch_bounds__(256) void k_correlate1d_rows(const double* __restrict__ src, int64_t n, const double* __restrict__ weights,
-                                                          int radius, int symmetric, double* __restrict__ dst) {
+struct CorrelateArgs {
+    const double* src;
+    int64_t n;
+    const double* weights;
+    int radius, symmetric;
+    double* dst;
+};
+
+SHG_MERGEABLE(k_correlate1d_rows, CorrelateArgs, __launch_bounds__(256)) {
+    const double* __restrict__ src = kargs.src;
+    const int64_t n = kargs.n;
+    const double* __restrict__ weights = kargs.weights;
+    const int radius = kargs.radius, symmetric = kargs.symmetric;
+    double* __restrict__ dst = kargs.dst;
     extern __shared__ double corr_lds[];                 // [256 + 2R] samples, then [2R + 1] weights
     double* xs = corr_lds;
     double* ws = corr_lds + 256 + 2 * radius;
@@ -565,6 +604,7 @@ extern "C" int shg_line_order_stats_u16(const uint16_t* img, int64_t h, int64_t 
                 "shg_line_order_stats_u16: ranks [%lld, %lld] outside a line of %lld", (long long)rank_lo, (long long)rank_hi, (long long)n);
     hipStream_t st = shg::as_stream(stream);
     SHG_PROF("line_order_stats", st);
+    SHG_DIRECT(st);
     k_line_order_stats<<<(unsigned)lines, NT, 0, st>>>(img, pitch, (int)n, axis == 0 ? 1 : pitch, axis == 0 ? pitch : 1, (int)rank_lo,
                                                       (int)rank_hi, out_lo, out_hi);
     return shg::check_launch("k_line_order_stats");
@@ -597,6 +637,7 @@ int shg::rowpair_stats_batch(const uint16_t* const* host_imgs, int64_t k, int64_
     hipStream_t st = shg::as_stream(stream);
     const int64_t rows = y2 - y1 - 1, n = y2 - y1;
     if (rows <= 0) {                                     // a single row: its statistic is the leading 0 (the kernel writes it otherwise)
+        SHG_DIRECT(st);
         hipError_t e = hipMemsetAsync(out, 0, (size_t)k * sizeof(double), st);
         if (e == hipSuccess && out_mirror) e = hipMemsetAsync(out_mirror, 0, (size_t)k * sizeof(double), st);
         if (e != hipSuccess) {
@@ -607,14 +648,15 @@ int shg::rowpair_stats_batch(const uint16_t* const* host_imgs, int64_t k, int64_
     }
     const size_t lds_bytes = (size_t)w * sizeof(double);
     static const bool attr_set =                         // (a function-local static: initialised once, also with several pool threads here)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowpair_stats), hipFuncAttributeMaxDynamicSharedMemorySize, MAXN * 8) == hipSuccess;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowpair_stats), hipFuncAttributeMaxDynamicSharedMemorySize, MAXN * 8) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowpair_stats_multi), hipFuncAttributeMaxDynamicSharedMemorySize, MAXN * 8) == hipSuccess;
     (void)attr_set;
     SHG_PROF("rowpair_stats", st);
     for (int64_t i0 = 0; i0 < k; i0 += shg::kMaxBatch) {
         const int m = (int)std::min<int64_t>(shg::kMaxBatch, k - i0);
-        k_rowpair_stats<<<dim3((unsigned)rows, 1u, (unsigned)m), NT, lds_bytes, st>>>(shg::make_batch(host_imgs, (int)i0, m), pitch, y1, xa, xb, row_factor,
-                                                                                     out + i0 * n, out_mirror ? out_mirror + i0 * n : nullptr, n);
-        if (int e = shg::check_launch("k_rowpair_stats")) return e;
+        if (int e = SHG_LAUNCH(k_rowpair_stats, dim3((unsigned)rows, 1u, (unsigned)m), dim3(NT), lds_bytes, st,
+                               RowpairArgs{shg::make_batch(host_imgs, (int)i0, m), pitch, y1, xa, xb, row_factor, out + i0 * n, out_mirror ? out_mirror + i0 * n : nullptr, n}))
+            return e;
     }
     return 0;
 }
@@ -627,8 +669,11 @@ extern "C" int shg_correlate1d_rows_f64(const double* src, int64_t k, int64_t n,
     hipStream_t st = shg::as_stream(stream);
     const size_t lds = (size_t)(256 + 4 * radius + 1) * sizeof(double);
     SHG_PROF("correlate1d_rows", st);
-    k_correlate1d_rows<<<dim3((unsigned)((n + 255) / 256), (unsigned)k), 256, lds, st>>>(src, n, weights, radius, symmetric > 0 ? 1 : (symmetric < 0 ? -1 : 0), dst);
-    return shg::check_launch("k_correlate1d_rows");
+    static const bool attr_set = hipFuncSetAttribute(reinterpret_cast<const void*>(k_correlate1d_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 4 * CORR_MAXR + 1) * 8) == hipSuccess &&
+                                 hipFuncSetAttribute(reinterpret_cast<const void*>(k_correlate1d_rows_multi), hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 4 * CORR_MAXR + 1) * 8) == hipSuccess;
+    (void)attr_set;
+    return SHG_LAUNCH(k_correlate1d_rows, dim3((unsigned)((n + 255) / 256), (unsigned)k), dim3(256), lds, st,
+                      CorrelateArgs{src, n, weights, radius, symmetric > 0 ? 1 : (symmetric < 0 ? -1 : 0), dst});
 }
 
 extern "C" int shg_scale_rows_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, const double* c,
@@ -654,6 +699,7 @@ int shg::scale_rows_batch(const uint16_t* const* host_imgs, int64_t k, int64_t h
     for (int64_t i0 = 0; i0 < k; i0 += shg::kMaxBatch) {
         const int m = (int)std::min<int64_t>(shg::kMaxBatch, k - i0);
         const shg::PtrBatch src = shg::make_batch(host_imgs, (int)i0, m), dst = shg::make_batch(host_dsts, (int)i0, m);
+        SHG_DIRECT(st);
         if (vec) {                                       // eight pixels per lane: 16-byte loads and stores
             const int64_t lanes = ((w + 7) / 8) * ((h + SCALE_ROWS - 1) / SCALE_ROWS);
             dim3 grid((unsigned)((lanes + 255) / 256), 1u, (unsigned)m);

@@ -60,10 +60,22 @@ struct WarpRows { double h[kWarpBatch][3]; };
 constexpr int WARP_ROWS = 4;                       // output rows per lane: their 2 x WARP_ROWS loads are issued before the first use
 
 // grid (x, ceil(rows / WARP_ROWS), disks): blockIdx.z picks source, destination, transform row and extrema
-__global__ __launch_bounds__(256) void k_warp_rows(shg::PtrBatch srcs, int64_t h, int64_t w, int64_t pitch,
-                                                   WarpRows rows, shg::PtrBatch dsts,
-                                                   int64_t out_h, int64_t out_w, int64_t dst_pitch,
-                                                   shg::PtrBatch mms) {
+using WarpPtrs = shg::PtrBatchN<kWarpBatch>;
+struct WarpArgs {
+    WarpPtrs srcs;
+    int64_t h, w, pitch;
+    WarpRows rows;
+    WarpPtrs dsts;
+    int64_t out_h, out_w, dst_pitch;
+    WarpPtrs mms;
+};
+
+SHG_MERGEABLE(k_warp_rows, WarpArgs, __launch_bounds__(256)) {
+    const WarpPtrs& srcs = kargs.srcs;
+    const WarpPtrs& dsts = kargs.dsts;
+    const WarpPtrs& mms = kargs.mms;
+    const int64_t h = kargs.h, w = kargs.w, pitch = kargs.pitch, out_h = kargs.out_h, out_w = kargs.out_w, dst_pitch = kargs.dst_pitch;
+    const WarpRows& rows = kargs.rows;
     const uint16_t* __restrict__ src = srcs.at<const uint16_t>(blockIdx.z);
     uint16_t* __restrict__ dst = dsts.at<uint16_t>(blockIdx.z);
     const uint32_t* __restrict__ mm = mms.at<const uint32_t>(blockIdx.z);
@@ -117,6 +129,7 @@ extern "C" int shg_warp_rows_u16(const uint16_t* src, int64_t h, int64_t w, int6
     SHG_REQUIRE(src_pitch >= w && dst_pitch >= out_w, SHG_E_ARG, "shg_warp_rows_u16: pitch smaller than width");
     SHG_REQUIRE(out_h < 65536, SHG_E_UNSUPPORTED, "shg_warp_rows_u16: more than 65535 rows");
     hipStream_t st = shg::as_stream(stream);
+    SHG_DIRECT(st);
     { SHG_PROF("minmax", st); k_minmax_init<<<1, 1, 0, st>>>(minmax); }
     int64_t blocks = h < 256 ? h : 256;
     { SHG_PROF("minmax", st); k_minmax<<<(unsigned)blocks, 256, 0, st>>>(src, h, w, src_pitch, minmax); }
@@ -151,9 +164,10 @@ int shg::warp_rows_batch(const uint16_t* const* host_srcs, int64_t k, int64_t h,
         for (int d = 0; d < m; ++d)
             for (int j = 0; j < 3; ++j) rows.h[d][j] = host_h3[3 * (i0 + d) + j];
         dim3 grid((unsigned)((out_w + 255) / 256), (unsigned)((out_h + WARP_ROWS - 1) / WARP_ROWS), (unsigned)m);
-        k_warp_rows<<<grid, 256, 0, st>>>(shg::make_batch(host_srcs, (int)i0, m), h, w, src_pitch, rows, shg::make_batch(host_dsts, (int)i0, m), out_h,
-                                          out_w, dst_pitch, shg::make_batch(host_minmax2, (int)i0, m));
-        if (int e = shg::check_launch("k_warp_rows")) return e;
+        if (int e = SHG_LAUNCH(k_warp_rows, grid, dim3(256), 0, st,
+                               WarpArgs{shg::make_batch_n<kWarpBatch>(host_srcs, (int)i0, m), h, w, src_pitch, rows, shg::make_batch_n<kWarpBatch>(host_dsts, (int)i0, m),
+                                        out_h, out_w, dst_pitch, shg::make_batch_n<kWarpBatch>(host_minmax2, (int)i0, m)}))
+            return e;
     }
     return 0;
 }
