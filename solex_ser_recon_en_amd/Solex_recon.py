@@ -460,7 +460,14 @@ def _scan_batch_native(tasks, decoder, n_workers, scan_here, collected):
     a batch halts on an unsuitable file, as result.get() makes the reference's (Solex_recon.py:42)."""
     import collections
     pool = _native_pool(decoder.device, n_workers)
-    depth = n_workers + 2
+    # scans handed to the pool at once: the workers' own, and enough queued behind them (their pass A already on the lane) that the
+    # lane never waits for a worker to come free
+    try:
+        depth = int(os.environ.get('SHG_POOL_DEPTH', '0'))
+    except ValueError:
+        depth = 0
+    if depth <= 0:
+        depth = n_workers + 8
     inflight = collections.deque()
     errors = []
     previous = bind_thread('scan', decoder.device)

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <mutex>
 #include <unordered_map>
+#include <algorithm>
 #include "shg_common.h"
 
 namespace {
@@ -29,7 +30,7 @@ struct Plan {
 // Launch-shape overrides for the tuning sweeps in tools/ (SHG_ACC_*).  Read once per process: the plan is made on every
 // launch and must not go through getenv each time.
 struct Tuning {
-    int inflight_kib, nsplit, unroll, xcd, nt;
+    int inflight_kib, nsplit, unroll, xcd, nt, lds_kib;
 };
 
 const Tuning& tuning() {
@@ -39,7 +40,7 @@ const Tuning& tuning() {
             return (s && *s) ? atoi(s) : dflt;
         };
         return Tuning{env_int("SHG_ACC_INFLIGHT_KIB", 7168), env_int("SHG_ACC_NSPLIT", 0), env_int("SHG_ACC_UNROLL", 0),
-                      env_int("SHG_ACC_XCD", 0), env_int("SHG_ACC_NT", 1)};
+                      env_int("SHG_ACC_XCD", 0), env_int("SHG_ACC_NT", 1), env_int("SHG_ACC_LDS_KIB", 0)};
     }();
     return t;
 }
@@ -356,7 +357,13 @@ void launch_vec(const Plan& p, const void* stack, int n, uint32_t* psum, uint16_
         grid = dim3((unsigned)(8 * ((nblk + xcd_per - 1) / xcd_per)), 1u);
     }
     const u32x4* s = static_cast<const u32x4*>(stack);
-#define SHG_ACC_LAUNCH(U) { SHG_PROF("accumulate", st); k_accumulate_vec<BPP, U, NT><<<grid, 256, 0, st>>>(s, p.vecs, p.stride_vecs, n, p.frames_per_split, psum, pmax, p.npix, p.nsplit, xcd_per); }
+    // SHG_ACC_LDS_KIB (tuning experiment): unused dynamic LDS per workgroup, which caps the workgroups a CU holds at once -- with more,
+    // shorter workgroups than the device can hold (a larger nsplit) the hardware then hands them out as earlier ones finish: CUs
+    // that the other scans' kernels keep busy simply take fewer of them
+    const size_t pad_lds = (size_t)std::min(std::max(tuning().lds_kib, 0), 160) * 1024;
+#define SHG_ACC_LAUNCH(U) { SHG_PROF("accumulate", st);                                                                                    \
+        if (pad_lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_accumulate_vec<BPP, U, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds); \
+        k_accumulate_vec<BPP, U, NT><<<grid, 256, pad_lds, st>>>(s, p.vecs, p.stride_vecs, n, p.frames_per_split, psum, pmax, p.npix, p.nsplit, xcd_per); }
     switch (p.unroll) {
         case 2: SHG_ACC_LAUNCH(2) break;
         case 4: SHG_ACC_LAUNCH(4) break;

@@ -1,15 +1,21 @@
-// The launch combiner of a scan pool (launch.h says why): scans in flight record their kernel launches; when every one of them is
-// waiting -- for its results, or for its pass A on the lane -- whatever has been recorded goes to the device, the same kernel of
-// different scans as ONE dispatch.
+// The launch combiner of a scan pool (launch.h says why): scans in flight record their kernel launches instead of making them,
+// and the same kernel of several scans goes to the device as ONE dispatch.
 //
-// The rule "flush when every busy thread waits" needs no tuning and costs a lone scan nothing (its own wait is the moment); under
-// load it puts the scans of a pool in step with each other: W scans advance one segment (the launches between two host decisions)
-// per round, and a segment of W scans is launched as often as a segment of one.  A thread that has waited SHG_COMBINE_WAIT_US
-// (default 60) for the others flushes what there is: a long host computation of one scan (the line fit: 150 us) does not hold the
-// others' kernels back for longer than that.
+// Two things make scans meet at the same kernel:
+//   * the gate -- scans reach their chains one pass A apart (a quarter of a millisecond); a scan whose pass has finished waits
+//     until `group` of them stand together (SHG_COMBINE_GROUP, default 4), for SHG_COMBINE_GATE_US (default 120) at most, and not
+//     at all when no other scan is running.  The scans released together are a COHORT;
+//   * the cohort's rhythm -- a cohort's launches are flushed when every scan of it that is still running has reached a point where
+//     it needs its results (stream_sync): the k-th launch of each, merged position by position, on one of the combiner's
+//     streams; the scans wake together, do their host work side by side (each on its pool thread) and meet again at the next
+//     point.  A scan that has waited SHG_COMBINE_WAIT_US (default 150) for the others flushes what the cohort has: one slow host
+//     computation does not hold the others' kernels back for longer than that.
+// Cohorts are independent of each other (own pending list, the streams taken in turn), a lone scan is a cohort of one and is
+// flushed the moment it waits: the combiner costs it a mutex.
 #include <stdlib.h>
 #include <chrono>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include "shg_common.h"
 
@@ -17,14 +23,22 @@ namespace shg {
 
 thread_local Recorder* t_rec = nullptr;
 
+struct Cohort {
+    int members = 0;                          // scans of the cohort that are still running
+    std::vector<Recorder*> pending;           // those that have posted their launches and wait
+};
+
 struct Combiner {
     std::mutex mu;
     std::condition_variable cv;
-    int busy = 0, waiting = 0;
-    std::vector<Recorder*> pending;
-    hipStream_t streams[2] = {nullptr, nullptr};
+    static constexpr int kStreams = 4;
+    hipStream_t streams[kStreams] = {};
     int turn = 0;
-    long wait_us = 60;
+    long wait_us = 150;
+    int on_lane = 0, group = 4, busy = 0;
+    std::vector<Recorder*> at_gate;
+    unsigned long long gate_generation = 0;
+    long gate_us = 120, gate_hard_us = 4000;  // a scan waits at the gate for the scans still on the lane (4 ms at most), gate_us when there are none
     // statistics (shg_pool_combiner_stats): launches recorded, dispatches made, flushes
     unsigned long long n_recorded = 0, n_dispatches = 0, n_flushes = 0;
 };
@@ -39,13 +53,14 @@ void fail(Recorder* r, int code) {
     }
 }
 
-// mu held.  Everything pending goes to one of the combiner's streams, merged position by position.
-void flush_locked(Combiner* c) {
-    if (c->pending.empty()) return;
+// mu held.  What the cohort's waiting scans have recorded goes to one of the combiner's streams, merged position by position.
+void flush_locked(Combiner* c, Cohort* co) {
+    if (co->pending.empty()) return;
     ++c->n_flushes;
     hipStream_t st = c->streams[c->turn];
-    c->turn ^= 1;
-    const size_t np = c->pending.size();
+    c->turn = (c->turn + 1) % Combiner::kStreams;
+    std::vector<Recorder*>& pend = co->pending;
+    const size_t np = pend.size();
     std::vector<size_t> cursor(np, 0);
     const LaunchRec* group[kMaxMerge];
     const unsigned char* gargs[kMaxMerge];
@@ -53,13 +68,13 @@ void flush_locked(Combiner* c) {
     for (;;) {
         size_t first = np;
         for (size_t p = 0; p < np; ++p)
-            if (c->pending[p]->error == 0 && cursor[p] < c->pending[p]->recs.size()) { first = p; break; }
+            if (pend[p]->error == 0 && cursor[p] < pend[p]->recs.size()) { first = p; break; }
         if (first == np) break;
-        const LaunchRec& head = c->pending[first]->recs[cursor[first]];
+        const LaunchRec& head = pend[first]->recs[cursor[first]];
         int n = 0;
         uint64_t blocks = 0;
         for (size_t p = first; p < np && n < head.cap && n < kMaxMerge; ++p) {
-            Recorder* r = c->pending[p];
+            Recorder* r = pend[p];
             if (r->error != 0 || cursor[p] >= r->recs.size()) continue;
             const LaunchRec& q = r->recs[cursor[p]];
             if (q.single != head.single || q.block.x != head.block.x || q.block.y != head.block.y || q.block.z != head.block.z) continue;
@@ -74,7 +89,7 @@ void flush_locked(Combiner* c) {
         ++c->n_dispatches;
         const int e = head.flush(group, gargs, n, st);
         for (int i = 0; i < n; ++i) {
-            Recorder* r = c->pending[members[i]];
+            Recorder* r = pend[members[i]];
             if (e != 0) fail(r, e);
             if (++cursor[members[i]] == r->recs.size() && r->error == 0) {
                 const hipError_t he = hipEventRecord(r->ev, st);
@@ -82,46 +97,59 @@ void flush_locked(Combiner* c) {
             }
         }
     }
-    for (Recorder* r : c->pending) {
+    for (Recorder* r : pend) {
         r->recs.clear();
         r->blob.clear();
         r->flushed = true;
     }
-    c->pending.clear();
+    pend.clear();
     c->cv.notify_all();
 }
 
-// The calling pool thread stops launching until leave_wait(): its recorded launches (if any) are posted.
-void enter_wait(Recorder* r, std::unique_lock<std::mutex>& lk) {
-    Combiner* c = r->comb;
-    r->posted = !r->recs.empty();
-    if (r->posted) {
-        r->flushed = false;
-        c->pending.push_back(r);
+void open_gate(Combiner* c) {
+    if (!c->at_gate.empty()) {
+        std::shared_ptr<Cohort> co = std::make_shared<Cohort>();
+        co->members = (int)c->at_gate.size();
+        for (Recorder* r : c->at_gate) r->cohort = co;
+        c->at_gate.clear();
     }
-    ++c->waiting;
-    if (c->waiting >= c->busy) flush_locked(c);
+    ++c->gate_generation;
+    c->cv.notify_all();
 }
 
-int leave_wait(Recorder* r, std::unique_lock<std::mutex>& lk) {
+// mu held.  Post the scan's recorded launches to its cohort, flush when the cohort is complete, wait for the device.
+int post_and_wait(Recorder* r, std::unique_lock<std::mutex>& lk) {
     Combiner* c = r->comb;
-    if (r->posted) {
-        while (!r->flushed) {
-            if (c->cv.wait_for(lk, std::chrono::microseconds(c->wait_us)) == std::cv_status::timeout && !r->flushed) flush_locked(c);
-        }
+    c->n_recorded += r->recs.size();
+    if (r->recs.empty()) {
+        const int err = r->error;
+        if (err != 0) set_error("%s", r->error_text);
+        r->error = 0;
+        return err;
+    }
+    Cohort* co = r->cohort.get();
+    r->flushed = false;
+    co->pending.push_back(r);
+    {
+        SHG_HOST_TIME("combiner: waiting for the cohort, flush");
+        if ((int)co->pending.size() >= co->members) flush_locked(c, co);
+        while (!r->flushed)
+            if (c->cv.wait_for(lk, std::chrono::microseconds(c->wait_us)) == std::cv_status::timeout && !r->flushed) flush_locked(c, co);
     }
     int err = r->error;
-    if (r->posted && err == 0) {
+    if (err == 0) {
         lk.unlock();
-        const hipError_t he = hipEventSynchronize(r->ev);        // (the others' flushes do not need this thread)
+        hipError_t he;
+        {
+            SHG_HOST_TIME("combiner: waiting for the device");
+            he = hipEventSynchronize(r->ev);
+        }
         lk.lock();
         if (he != hipSuccess) { set_error("launch combiner: %s", hipGetErrorString(he)); err = (int)he; }
-    } else if (err != 0) {
+    } else {
         set_error("%s", r->error_text);
     }
-    r->posted = false;
     r->error = 0;
-    --c->waiting;
     return err;
 }
 
@@ -154,24 +182,44 @@ int stream_sync(hipStream_t st, const char* who) {
         if (he != hipSuccess) { set_error("%s: %s", who, hipGetErrorString(he)); return (int)he; }
     }
     std::unique_lock<std::mutex> lk(r->comb->mu);
-    r->comb->n_recorded += r->recs.size();
-    enter_wait(r, lk);
-    return leave_wait(r, lk);
+    return post_and_wait(r, lk);
 }
 
+// Around a pool thread's wait for its pass A on the lane.  What it has recorded (normally nothing) goes out first; when the pass has
+// finished the scan stands at the gate.
 void pool_wait_begin() {
     Recorder* r = t_rec;
     if (!r) return;
     std::unique_lock<std::mutex> lk(r->comb->mu);
-    r->comb->n_recorded += r->recs.size();
-    enter_wait(r, lk);
+    const int err = post_and_wait(r, lk);
+    if (err != 0) fail(r, err);                              // (surfaces at the scan's next stream_sync)
+    ++r->comb->on_lane;
 }
 
 void pool_wait_end() {
     Recorder* r = t_rec;
     if (!r) return;
-    std::unique_lock<std::mutex> lk(r->comb->mu);
-    (void)leave_wait(r, lk);                                 // (an error of a recorded launch surfaces at the scan's next stream_sync: kept below)
+    Combiner* c = r->comb;
+    std::unique_lock<std::mutex> lk(c->mu);
+    --c->on_lane;
+    if (c->group <= 1) return;
+    // leave the cohort this scan has been in so far (a cohort of its own since it began: nothing is pending there)
+    if (r->cohort) --r->cohort->members;
+    r->cohort.reset();
+    SHG_HOST_TIME("gate (waiting for the cohort to form)");
+    const unsigned long long mine = c->gate_generation;
+    c->at_gate.push_back(r);
+    // Enough of them, or nobody else in the pool is running a scan (a lone file: nothing to wait for): go.  Otherwise wait for the
+    // scans whose pass is still on the lane (they arrive one pass apart); with none there, give stragglers gate_us -- scans that
+    // became free together (a cohort that has just finished) arrive within microseconds of each other.
+    if ((int)c->at_gate.size() >= c->group || (int)c->at_gate.size() >= c->busy) open_gate(c);
+    const auto t0 = std::chrono::steady_clock::now();
+    while (c->gate_generation == mine) {
+        c->cv.wait_for(lk, std::chrono::microseconds(c->gate_us));
+        if (c->gate_generation != mine) break;
+        const long waited = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+        if ((c->on_lane == 0 && waited >= c->gate_us) || waited >= c->gate_hard_us) open_gate(c);
+    }
 }
 
 int direct_launches_follow(hipStream_t st) {
@@ -198,6 +246,14 @@ Combiner* combiner_create() {
         const long us = atol(v);
         if (us > 0) c->wait_us = us;
     }
+    if (const char* v = getenv("SHG_COMBINE_GROUP")) {
+        const int g = atoi(v);
+        if (g >= 1 && g <= 64) c->group = g;
+    }
+    if (const char* v = getenv("SHG_COMBINE_GATE_US")) {
+        const long us = atol(v);
+        if (us > 0) c->gate_us = us;
+    }
     return c;
 }
 
@@ -218,8 +274,10 @@ int combiner_enter(Combiner* c, Recorder* rec, hipStream_t own) {
     rec->own = own;
     rec->recs.clear();
     rec->blob.clear();
-    rec->posted = rec->flushed = rec->direct = false;
+    rec->flushed = rec->direct = false;
     rec->error = 0;
+    rec->cohort = std::make_shared<Cohort>();                // alone until the gate puts it with others
+    rec->cohort->members = 1;
     {
         std::lock_guard<std::mutex> lk(c->mu);
         ++c->busy;
@@ -229,10 +287,18 @@ int combiner_enter(Combiner* c, Recorder* rec, hipStream_t own) {
 }
 
 void combiner_leave(Combiner* c) {
+    Recorder* r = t_rec;
     t_rec = nullptr;
+    if (!r) return;
     std::unique_lock<std::mutex> lk(c->mu);
     --c->busy;
-    if (c->waiting >= c->busy) flush_locked(c);             // the others may have been waiting for this thread alone
+    if (!c->at_gate.empty() && (int)c->at_gate.size() >= c->busy) open_gate(c);       // (those at the gate were waiting for this scan alone)
+    if (r->cohort) {
+        Cohort* co = r->cohort.get();
+        --co->members;
+        if (co->members > 0 && (int)co->pending.size() >= co->members) flush_locked(c, co);     // the others were waiting for this scan alone
+        r->cohort.reset();
+    }
 }
 
 void combiner_stats(Combiner* c, unsigned long long* out3) {

@@ -21,6 +21,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <functional>
+#include <memory>
 #include <vector>
 
 namespace shg {
@@ -90,13 +91,15 @@ struct LaunchRec {
 };
 
 // What one scan has launched since it last waited for the device.
+struct Cohort;
 struct Recorder {
     std::vector<LaunchRec> recs;
     std::vector<unsigned char> blob;
     Combiner* comb = nullptr;
+    std::shared_ptr<Cohort> cohort;           // the scans this one moves in step with (combine.hip)
     hipStream_t own = nullptr;                // the scan worker's own stream: where code that launches directly still launches
     hipEvent_t ev = nullptr;                  // recorded behind the scan's last launch of a flush
-    bool posted = false, flushed = false, direct = false;
+    bool flushed = false, direct = false;
     int error = 0;
     char error_text[256] = {0};
 };

@@ -282,8 +282,8 @@ inline int64_t small_dim(int64_t v) { return (v + kFactor - 1) / kFactor; }
 // The fused kernels of limb_fused.hip (8 launches) take the stage when the blur window fits their tile; SHG_LIMB_FUSED=0
 // keeps the one-kernel-per-call chain of limb.hip (23 launches), which also serves the larger windows.
 inline bool limb_fused(int64_t sh, int64_t sw, int k) {
-    static const bool enabled = [] { const char* v = getenv("SHG_LIMB_FUSED"); return !(v && v[0] == '0'); }();
-    return enabled && k > 0 && shg_limb_fused_fits(sh, sw, k);
+    const char* v = getenv("SHG_LIMB_FUSED");                // (asked per call: the tests run both chains in one process)
+    return !(v && v[0] == '0') && k > 0 && shg_limb_fused_fits(sh, sw, k);
 }
 
 // skimage's hysteresis on the emitted LOW-mask pixels (limb_fused.hip: bit 30 of root = the pixel is in the HIGH mask): keep

@@ -56,9 +56,14 @@ int on_frame_pass_lane(hipStream_t st, int (*launch)(hipStream_t, void*), void* 
         // the pass reads what the caller's stream has produced so far (a stack a kernel has only just written, a workspace
         // the previous scan's last kernel still uses): the lane waits for that point of `st` -- in the scan pool, where a
         // worker synchronises its stream after every scan, there is nothing to wait for
-        e = hipEventRecord(before, st);
-        if (e == hipSuccess) e = hipStreamWaitEvent(lane, before, 0);
-        if (e != hipSuccess) { set_error("frame-pass lane: %s", hipGetErrorString(e)); return (int)e; }
+        // (a stream with nothing pending -- the usual case -- needs no barrier on the lane: every packet between two passes
+        // there is a few microseconds in which the lane, the one thing the rate of a batch is bound by, does nothing)
+        if (hipStreamQuery(st) != hipSuccess) {
+            (void)hipGetLastError();
+            e = hipEventRecord(before, st);
+            if (e == hipSuccess) e = hipStreamWaitEvent(lane, before, 0);
+            if (e != hipSuccess) { set_error("frame-pass lane: %s", hipGetErrorString(e)); return (int)e; }
+        }
         if (int le = launch(lane, arg)) return le;
         e = hipEventRecord(ev, lane);
     }
@@ -90,12 +95,16 @@ int prelaunch_on_lane(hipStream_t after, int (*launch)(hipStream_t, void*), void
     hipStream_t lane = frame_pass_lane(device);
     if (!lane) return 1;
     hipEvent_t before = nullptr, ev = nullptr;
-    hipError_t e = hipEventCreateWithFlags(&before, hipEventDisableTiming);
+    const bool idle = hipStreamQuery(after) == hipSuccess;    // nothing pending there: no barrier on the lane (see on_frame_pass_lane)
+    if (!idle) (void)hipGetLastError();
+    hipError_t e = idle ? hipSuccess : hipEventCreateWithFlags(&before, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e == hipSuccess) {
         std::lock_guard<std::mutex> lk(g_lane_mu);
-        e = hipEventRecord(before, after);
-        if (e == hipSuccess) e = hipStreamWaitEvent(lane, before, 0);
+        if (!idle) {
+            e = hipEventRecord(before, after);
+            if (e == hipSuccess) e = hipStreamWaitEvent(lane, before, 0);
+        }
         if (e == hipSuccess) {
             if (int le = launch(lane, arg)) {
                 (void)hipEventDestroy(before);

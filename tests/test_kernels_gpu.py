@@ -1050,3 +1050,71 @@ def test_scaling_and_crop_fused_into_the_histogram_kernel(shape, crop, trans, k,
         for x, y in zip(a[name], b[name]):
             assert x.shape == (h, crop[0] if crop else w)
             np.testing.assert_array_equal(x, y, err_msg=name)
+
+
+def test_limb_stage_under_load_equals_the_separate_kernels(ops, monkeypatch):
+    """The fused limb kernels find their last workgroup with a RELAXED agent-scope counter behind `s_waitcnt vmcnt(0)` + barrier
+    (limb_fused.hip, published()): correct because gfx950 performs agent-scope atomics at the memory side and acknowledges them
+    afterwards -- an assumption about this part, not a promise of the memory model, so it is held here under the load it has to
+    survive: four streams run 2000 limb stages between them on four different disks while a fifth keeps pass A (1.6 GB of
+    non-temporal reads per launch) going; every one of the 2000 results -- geometry, limb points, kept points -- equals what the
+    one-kernel-per-call chain of limb.hip (SHG_LIMB_FUSED=0, acq_rel-free as well but without any last-workgroup logic) gives
+    for that disk, bit for bit."""
+    import threading
+    from solex_ser_recon_en_amd import stages, synth
+    shapes = [(2000, 2000, 11), (2000, 1777, 12), (1603, 2100, 13), (2404, 1500, 14)]
+    disks = [torch.from_numpy(_limb_disk(h, w, seed)).cuda() for h, w, seed in shapes]
+    monkeypatch.setenv('SHG_LIMB_FUSED', '0')
+    want = [stages.limb_fit(d, want_points=True) for d in disks]
+    monkeypatch.setenv('SHG_LIMB_FUSED', '1')
+    stack = synth.synth_frames_torch(2000, 2000, 200, 16, seed=3, padded=True)
+    torch.cuda.synchronize()
+    stop = threading.Event()
+    failures = []
+
+    def frame_pass():
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                ws = None
+                while not stop.is_set():
+                    for _ in range(4):
+                        ops.accumulate_sum_max(stack, ws)
+                    st.synchronize()
+        except BaseException as e:      # noqa: BLE001
+            failures.append('pass A: %r' % (e,))
+
+    def same(a, b):
+        if isinstance(a, np.ndarray):
+            return a.shape == b.shape and np.array_equal(a, b)
+        if isinstance(a, (list, tuple)):
+            return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+        return a == b
+
+    def limb_worker(t):
+        try:
+            torch.cuda.set_device(0)
+            stages.use_buffers({})
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for i in range(500):
+                    j = (t + i) % len(disks)
+                    got = stages.limb_fit(disks[j], want_points=True)
+                    for key, ref in want[j].items():
+                        if not same(got[key], ref):
+                            failures.append('stream %d, stage %d, disk %d: %s differs' % (t, i, j, key))
+                            return
+        except BaseException as e:      # noqa: BLE001
+            failures.append('stream %d: %r' % (t, e))
+
+    bg = threading.Thread(target=frame_pass)
+    bg.start()
+    workers = [threading.Thread(target=limb_worker, args=(t,)) for t in range(4)]
+    for w_ in workers:
+        w_.start()
+    for w_ in workers:
+        w_.join()
+    stop.set()
+    bg.join()
+    torch.cuda.synchronize()
+    assert not failures, failures[:5]

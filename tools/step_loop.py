@@ -20,5 +20,7 @@ for _ in range(steps):
     opts = SHG_MAIN.default_options()
     opts.update(_nolog=True, shift=list(shifts))
     with contextlib.redirect_stdout(io.StringIO()):
-        Solex_recon.solex_do_work([(array_reader(stack), opts)], True, return_results=True)
+        res = Solex_recon.solex_do_work([(array_reader(stack), opts)], True, return_results=True)
 torch.cuda.synchronize()
+# what tools/roofline_table.py needs: N W H bits S k out_w
+print(n, w, h, bits, len(dict.fromkeys([10, 0] + list(shifts))), len(shifts), res[0][0][0].shape[1])

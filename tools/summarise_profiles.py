@@ -37,7 +37,7 @@ shutil.copy(newest(os.path.join(go, tag + '_trace_w1', '*', '*_kernel_stats.csv'
 for name in ('bench', 'bench_driver_flags', 'bench_w1', 'bench_under_rocprof', 'bench_w1_under_rocprof', 'bench_c1', 'bench_c3_one_gpu', 'bench_c4',
              'bench_c5_per_gpu', 'bench_u8', 'bench_n500'):
     copy(os.path.join(go, '%s_%s.json' % (tag, name)), '%s_%s.json' % (tag, name))
-for name in ('step_kernel_table', 'step_kernel_table_c4', 'step_kernel_table_c5'):
+for name in ('step_kernel_table_c2', 'step_kernel_table_c4', 'step_kernel_table_c5'):
     copy(os.path.join(go, '%s_%s.txt' % (tag, name)), '%s_%s.txt' % (tag, name))
 
 
@@ -63,8 +63,11 @@ def traffic_of(table, prefix):
     return int(2 * a['FETCH_SIZE_KB_mean'] * 1024 + a['WRITE_SIZE_KB_mean'] * 1024)
 
 
+for f in glob.glob(os.path.join(go, tag + '_profiles', '*')):
+    shutil.copy(f, os.path.join(pr, os.path.basename(f)))
+
 traffic = {}
-for suffix, key, what in (('', '2000x2000x200x16', 'bench.py --workers 1'), ('_c4', None, 'step_loop C4'), ('_c5', '4000x2560x256x16', 'step_loop C5')):
+for suffix, key, what in (('', '2000x2000x200x16', 'bench.py --workers 1'), ('_c2', None, 'step_loop C2'), ('_c4', None, 'step_loop C4'), ('_c5', '4000x2560x256x16', 'step_loop C5')):
     try:
         table = pmc(suffix)
     except ValueError:
@@ -94,7 +97,7 @@ for name in ('bench', 'bench_driver_flags', 'bench_w1', 'bench_c1', 'bench_c3_on
             say('   e2e', d['e2e']['value'], 'f/s', d['e2e']['host_to_device_GBps_per_gpu'], 'GB/s;  c3', d['sharded_c3']['value'], 'f/s', d['sharded_c3']['ms_per_scan'], 'ms/scan')
         if d.get('cpu_baseline'):
             say('   cpu', d['cpu_baseline']['value'], d['cpu_baseline'].get('parity_vs_gpu'))
-for name in ('step_kernel_table', 'step_kernel_table_c4', 'step_kernel_table_c5'):
+for name in ('step_kernel_table_c2', 'step_kernel_table_c4', 'step_kernel_table_c5'):
     f = os.path.join(pr, '%s_%s.txt' % (tag, name))
     if os.path.exists(f):
         say(name, open(f).read().strip().splitlines()[-1])
