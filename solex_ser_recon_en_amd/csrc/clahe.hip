@@ -1245,7 +1245,8 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
           // anyway: the largest slice a u16 counter allows halves the slice histograms written here and read back by the
           // reduction (the layout's f.slices is the upper bound the workspace was sized for).
           static const int64_t big = [] { const char* v = getenv("SHG_CLAHE_SLICE_PX"); return v ? (int64_t)atoi(v) : (int64_t)65535; }();
-          const int64_t slice_px = (dset.n >= 4 && big > SLICE_PX && big <= 65535) ? big : SLICE_PX;
+          static const int big_from = [] { const char* v = getenv("SHG_CLAHE_BIG_FROM"); return v ? atoi(v) : 4; }();      // disks per launch from which the big slices are taken
+          const int64_t slice_px = (dset.n >= big_from && big > SLICE_PX && big <= 65535) ? big : SLICE_PX;
           const int64_t slice_rows = slice_rows_of(tw, slice_px), slices = slice_count(th, tw, slice_px);
           int vec = w % tiles == 0 && tw % 8 == 0 && pitch % 8 == 0 && dset.aligned(15);
           if (dset.fused) {

@@ -7,6 +7,7 @@ arguments: a per-thread device workspace and pinned staging areas (a scan worker
 so buffers are never shared between streams), grown on demand and reused from file to file.
 """
 import ctypes
+import os
 import threading
 
 import numpy as np
@@ -168,7 +169,8 @@ def _canny_ladder_taps():
 def _limb_call(fn, disk, extra):
     ptr, h, w, pitch = ops._img(disk, 'disk', torch.uint16)
     dev = disk.device
-    ws = _scratch('limb', _sizes('limb_ws', lib.shg_stage_limb_points_workspace_bytes, h, w), dev)
+    # (the answer depends on which limb kernels the library takes: SHG_LIMB_FUSED, asked per call)
+    ws = _scratch('limb', _sizes('limb_ws' + os.environ.get('SHG_LIMB_FUSED', '1')[:1], lib.shg_stage_limb_points_workspace_bytes, h, w), dev)
     pin = _scratch('limb', _sizes('limb_pin', lib.shg_stage_limb_points_host_bytes, h, w), pinned=True)
     full = (-(-h // 4)) * (-(-w // 4))
     cap = min(full, 1 << 16)
