@@ -171,3 +171,46 @@ def test_direct_reads_give_the_same_stack(pkg, tmp_path, monkeypatch, mode):
         finally:
             if os.path.exists(path):
                 os.unlink(path)
+
+
+def test_launch_combiner_gives_the_serial_products(pkg, monkeypatch):
+    """SHG_COMBINE=1: the scans a native pool has in flight record their kernel launches and the same kernel of several scans
+    goes to the device as ONE dispatch (csrc/launch.h, csrc/combine.hip: 27 mergeable kernels, cohorts of scans released together
+    by a gate).  Files of different shapes, depths and options -- so that merged dispatches hold sub-launches with different grids,
+    LDS sizes and argument blocks, and some scans take branches that launch the plain way (SHG_DIRECT) -- must come out exactly as
+    one scan at a time does; and the combiner must really have merged something."""
+    SHG_MAIN, Solex_recon, ops, outputs, synth = pkg
+    from solex_ser_recon_en_amd.video_reader import array_reader
+    specs = [(600, 640, 48, 16, 3, {}), (520, 600, 40, 16, 4, {'shift': [-2, 0, 3]}), (600, 640, 48, 8, 5, {'flip_x': True}),
+             (560, 48, 640, 16, 6, {'crop_width_square': True}), (600, 640, 48, 16, 7, {'transversalium': False}),
+             (600, 640, 48, 16, 8, {'fixed_width': 500, 'img_rotate': 90}), (640, 700, 56, 16, 9, {'ratio_fixe': 1.0}),
+             (600, 640, 48, 16, 10, {}), (600, 640, 48, 16, 11, {'shift': list(range(-4, 5))}), (600, 640, 48, 16, 12, {}),
+             (580, 640, 48, 16, 13, {}), (600, 660, 48, 16, 14, {})]
+    stacks = [synth.synth_frames_torch(n, w, h, bits, seed=seed) for n, w, h, bits, seed, _ in specs]
+
+    def run(workers):
+        tasks = []
+        for st, spec in zip(stacks, specs):
+            opts = SHG_MAIN.default_options()
+            opts.update(spec[5], _nolog=True, _keep_raw=True)
+            tasks.append((array_reader(st), opts))
+        res = Solex_recon.solex_do_work(tasks, True, distribute='none', return_results=True, workers=workers)
+        outputs.flush()
+        torch.cuda.synchronize()
+        return [([np.asarray(d) for d in o['_raw_disks']], [(np.asarray(cc), np.asarray(pr)) for cc, pr in per], o['ratio_fixe'])
+                for (_, o), per in zip(tasks, res)]
+    serial = run(1)
+    monkeypatch.setenv('SHG_COMBINE', '1')
+    monkeypatch.setenv('SHG_COMBINE_GROUP', '3')
+    before = Solex_recon.combiner_stats()
+    merged = run(7)                                          # (a pool size no other test uses: its combiner is made with this environment)
+    after = Solex_recon.combiner_stats()
+    recorded, dispatches = after['launches_recorded'] - before['launches_recorded'], after['dispatches'] - before['dispatches']
+    assert recorded > 20 * len(specs) and dispatches < 0.8 * recorded, (recorded, dispatches)
+    for (d1, r1, q1), (d2, r2, q2) in zip(serial, merged):
+        assert q1 == q2 and len(d1) == len(d2) and len(r1) == len(r2)
+        for a, b in zip(d1, d2):
+            np.testing.assert_array_equal(a, b)
+        for (c1, p1), (c2, p2) in zip(r1, r2):
+            np.testing.assert_array_equal(c1, c2)
+            np.testing.assert_array_equal(p1, p2)
