@@ -217,7 +217,7 @@ def main():
     combiner['launches_per_dispatch'] = round(combiner['launches_recorded'] / combiner['dispatches'], 2) if combiner['dispatches'] else None
     combiner['dispatches_per_scan'] = round(combiner['dispatches'] / (args.steps * len(region_s)), 2)
     combiner['what'] = ('kernel launches the scans of the timed regions recorded, and the dispatches that carried them: the same kernel of '
-                        'the scans in flight shares a dispatch (csrc/launch.h, csrc/combine.hip); pass A and its finalising kernel run on the lane')
+                        'the scans in flight shares a dispatch (csrc/launch.h, csrc/combine.hip; SHG_COMBINE=1, off by default: all zero then); pass A runs on the lane')
     elapsed = sorted(region_s)[len(region_s) // 2]                       # the median region is the one quoted
 
     # ---- roofline of the dominant kernel (pass A: sum/max over the stack), live HIP events --------

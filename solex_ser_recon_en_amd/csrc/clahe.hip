@@ -316,6 +316,43 @@ SHG_MERGEABLE(k_hist_reduce, HistReduceArgs, __launch_bounds__(1024)) {
 // The tile LUT (clip, redistribute, prefix sum, scale: as k_tile_lut16_lds) by 32 workgroups per tile, 2048 bins each:
 // the counts before a workgroup's first bin are the clipped totals of the workgroups before it, plus what the
 // redistribution adds there -- `batch` per bin and one more for the bins 0, step, 2 step, ... below residual * step.
+struct Ranks8 { int64_t v[8]; };            // the requested ranks travel as a kernel argument: no host-to-device copy per call
+
+// One order statistic of the image whose per-tile histograms CLAHE has built (valid when the tile grid divides the image: no
+// reflected padding in the histograms), by one workgroup of 1024: lane t takes the t-th run of 64 bins from the chunk sums, a
+// workgroup scan finds the run that holds the rank, one wave scans its 64 bins.  (k_hist_ranks, and the extra workgroups of
+// k_tile_lut16_blocks.)
+__device__ __forceinline__ void hist_rank_job(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ chunk_sums, int chunk_sets, int ntiles,
+                                              int64_t rank, double* __restrict__ out) {
+    __shared__ int64_t wtot[16];
+    __shared__ int64_t pick[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int64_t local = 0;
+    for (int k = 0; k < chunk_sets; ++k) local += chunk_sums[k * 1024 + tid];     // one set (k_chunk_sums) or one per tile (k_hist_reduce)
+    int64_t incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    for (int i = 0; i < wave; ++i) incl += wtot[i];
+    if (incl - local <= rank && rank < incl) { pick[0] = tid; pick[1] = incl - local; }
+    __syncthreads();
+    if (wave != 0) return;
+    const int64_t chunk = pick[0], below = pick[1];
+    int64_t c = 0;
+    for (int t = 0; t < ntiles; ++t) c += hist[(int64_t)t * HIST16 + chunk * 64 + lane];
+    int64_t inc2 = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t o = __shfl_up(inc2, d);
+        if (lane >= d) inc2 += o;
+    }
+    if (below + inc2 - c <= rank && rank < below + inc2) *out = (double)(chunk * 64 + lane);
+}
+
 struct LutBlocksArgs {
     const uint32_t* hist;
     const int32_t* se;
@@ -323,6 +360,14 @@ struct LutBlocksArgs {
     float lut_scale;
     uint16_t* lut;
     size_t zs;
+    // the frame's order statistics read off the same histograms by n_ranks extra workgroups (blockIdx.x = 32 + rank index,
+    // blockIdx.y = 0) instead of a launch of k_hist_ranks: they depend on nothing the LUT does
+    int n_ranks;
+    int64_t rank[2];
+    const uint32_t* chunk_sums;
+    int chunk_sets;
+    double* ranks_out;
+    int ranks_zstride;
 };
 
 SHG_MERGEABLE(k_tile_lut16_blocks, LutBlocksArgs, __launch_bounds__(1024)) {
@@ -335,6 +380,13 @@ SHG_MERGEABLE(k_tile_lut16_blocks, LutBlocksArgs, __launch_bounds__(1024)) {
     constexpr int HIST = 65536;
     __shared__ int s_before, s_excess;
     hist = zdisk(hist, zs, blockIdx.z);
+    if (blockIdx.x >= 32) {
+        const int r = (int)blockIdx.x - 32;
+        if (blockIdx.y == 0 && r < kargs.n_ranks)
+            hist_rank_job(hist, zdisk(kargs.chunk_sums, zs, blockIdx.z), kargs.chunk_sets, (int)gridDim.y, kargs.rank[r],
+                          kargs.ranks_out + (int64_t)blockIdx.z * kargs.ranks_zstride + r);
+        return;
+    }
     se = zdisk(se, zs, blockIdx.z);
     lut = zdisk(lut, zs, blockIdx.z);
     __shared__ int wsum[16];
@@ -827,7 +879,6 @@ __device__ __forceinline__ void pick_digit(const uint32_t* __restrict__ hist, in
 // of equal keys inside a lane's eight pixels (the divergent bookkeeping costs more than the atomics it saves).
 constexpr int SEL_COPIES0 = 16, SEL_COPIES1 = 4;
 
-struct Ranks8 { int64_t v[8]; };            // the requested ranks travel as a kernel argument: no host-to-device copy per call
 
 struct SelectPassArgs {
     shg::PtrBatch imgs;
@@ -1028,37 +1079,10 @@ SHG_MERGEABLE(k_hist_ranks, HistRanksArgs, __launch_bounds__(1024)) {
     const Ranks8& ranks = kargs.ranks;
     double* __restrict__ out = kargs.out;
     const size_t zs = kargs.zs;
-    __shared__ int64_t wtot[16];
     hist = zdisk(hist, zs, blockIdx.z);
     chunk_sums = zdisk(chunk_sums, zs, blockIdx.z);
     out += (int64_t)blockIdx.z * out_zstride;
-    __shared__ int64_t pick[2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t rank = ranks.v[blockIdx.x];
-    int64_t local = 0;
-    for (int k = 0; k < chunk_sets; ++k) local += chunk_sums[k * 1024 + tid];     // one set (k_chunk_sums) or one per tile (k_hist_reduce)
-    int64_t incl = local;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int64_t o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
-    if (lane == 63) wtot[wave] = incl;
-    __syncthreads();
-    for (int i = 0; i < wave; ++i) incl += wtot[i];
-    if (incl - local <= rank && rank < incl) { pick[0] = tid; pick[1] = incl - local; }
-    __syncthreads();
-    if (wave != 0) return;
-    const int64_t chunk = pick[0], below = pick[1];
-    int64_t c = 0;
-    for (int t = 0; t < ntiles; ++t) c += hist[(int64_t)t * HIST16 + chunk * 64 + lane];
-    int64_t inc2 = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int64_t o = __shfl_up(inc2, d);
-        if (lane >= d) inc2 += o;
-    }
-    if (below + inc2 - c <= rank && rank < below + inc2) out[blockIdx.x] = (double)(chunk * 64 + lane);
+    hist_rank_job(hist, chunk_sums, chunk_sets, ntiles, ranks.v[blockIdx.x], out + blockIdx.x);
 }
 
 void ensure_lds_attr() {
@@ -1089,6 +1113,11 @@ extern "C" size_t shg_clahe_workspace_bytes(int tiles, int bytes_per_px) {
 namespace {
 // sel_hist (may be NULL): the zeroed slot histograms of the select that follows on dst; the kernel then counts its first pass
 // The disks of one launch: their images, where their results go, how many, and the byte distance between their workspaces.
+struct RanksJob {                                        // two order statistics of every disk's frame -> out[disk * out_zstride + {0, 1}]
+    int64_t rank[2];
+    double* out;
+    int out_zstride;
+};
 struct Disks {
     shg::PtrBatch src, dst;
     int n;
@@ -1201,7 +1230,9 @@ namespace {
 // workspace at `workspace + i * disks->zs`; only the atomics-free 16-bit path takes more than one.
 int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_per_px, double clip_limit, int tiles,
                void* dst, int64_t dst_pitch, void* workspace, size_t workspace_bytes, shg_stream_t stream, const uint32_t** chunk_tile_out,
-               uint32_t* sel_hist, int sel_stride, bool* sel_pass0_done, const Disks* disks = nullptr, bool* sel_zeroed = nullptr) {
+               uint32_t* sel_hist, int sel_stride, bool* sel_pass0_done, const Disks* disks = nullptr, bool* sel_zeroed = nullptr,
+               const RanksJob* ranks_job = nullptr, bool* ranks_done = nullptr) {
+    if (ranks_done) *ranks_done = false;
     if (sel_zeroed) *sel_zeroed = false;                 // -> true when the histogram reduction has zeroed sel_hist (the caller asked by passing it)
     if (chunk_tile_out) *chunk_tile_out = nullptr;
     if (sel_pass0_done) *sel_pass0_done = false;
@@ -1268,7 +1299,18 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
               return e;
           if (zero_sel) *sel_zeroed = true; }
         { SHG_PROF("clahe_lut", st);
-          if (int e = SHG_LAUNCH(k_tile_lut16_blocks, dim3(32, (unsigned)ntiles, (unsigned)dset.n), dim3(1024), 0, st, LutBlocksArgs{hist, se, clip, lut_scale, lut, dset.zs})) return e; }
+          LutBlocksArgs la{hist, se, clip, lut_scale, lut, dset.zs, 0, {0, 0}, nullptr, 0, nullptr, 0};
+          if (ranks_job && ranks_done) {                     // the frame's order statistics ride along (two more workgroups per disk)
+              la.n_ranks = 2;
+              la.rank[0] = ranks_job->rank[0];
+              la.rank[1] = ranks_job->rank[1];
+              la.chunk_sums = chunk_tile;
+              la.chunk_sets = ntiles;
+              la.ranks_out = ranks_job->out;
+              la.ranks_zstride = ranks_job->out_zstride;
+              *ranks_done = true;
+          }
+          if (int e = SHG_LAUNCH(k_tile_lut16_blocks, dim3(32u + (unsigned)la.n_ranks, (unsigned)ntiles, (unsigned)dset.n), dim3(1024), 0, st, la)) return e; }
         { SHG_PROF("clahe_interp", st);
           bool counted = false;
           if (int e = launch_interp16(dset, h, w, pitch, tiles, inv_tw, inv_th, lut, true, dst_pitch, sel_hist, sel_stride, st, &counted)) return e;
@@ -1547,11 +1589,13 @@ int shg::contrast_stats_batch(const uint16_t* const* host_frames, int64_t k, int
         uint32_t* sel3 = reinterpret_cast<uint32_t*>(ws + c + s2);
         const uint32_t* chunk_tile = nullptr;
         bool pass0_done = false, sel_zeroed = false;
+        const RanksJob job{{ranks.v[0], ranks.v[1]}, out5 + 5 * i0, 5};
+        bool ranks_done = false;
         if (int e = clahe_impl(host_frames[i0], h, w, pitch, 2, clip_limit, tiles, host_cl1[i0], cl1_pitch, ws, c, stream, &chunk_tile, sel3, (1 + 3) * 256,
-                               &pass0_done, &d, &sel_zeroed))
+                               &pass0_done, &d, &sel_zeroed, &job, &ranks_done))
             return e;
         SHG_REQUIRE(chunk_tile && sel_zeroed, SHG_E_RUNTIME, "shg_contrast_stats_u16: the batched path did not take the slice histograms");
-        {
+        if (!ranks_done) {
             SHG_PROF("hist_ranks", st);
             if (int e = SHG_LAUNCH(k_hist_ranks, dim3(2u, 1u, (unsigned)m), dim3(1024), 0, st,
                                    HistRanksArgs{reinterpret_cast<const uint32_t*>(ws), chunk_tile, tiles * tiles, tiles * tiles, ranks, out5 + 5 * i0, per, 5}))

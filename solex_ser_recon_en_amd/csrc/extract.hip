@@ -15,10 +15,14 @@
 // Arithmetic is float64 with separately rounded products (compile with
 // -ffp-contract=off) and a truncating store, to be bit-exact with NumPy.
 #include <stdlib.h>
+#include <algorithm>
 #include "shg_common.h"
 
 namespace shg {
 thread_local bool t_minmax_slots_zeroed = false;
+thread_local void* t_zero_with_fold = nullptr;
+thread_local size_t t_zero_with_fold_words = 0;
+thread_local void* t_prezeroed = nullptr;
 }
 
 namespace {
@@ -338,11 +342,20 @@ __global__ __launch_bounds__(64 * NW) void k_extract_dense(const T* __restrict__
 struct FoldMinmaxArgs {
     const uint32_t* slots;
     uint32_t* out;
+    int n_planes;                    // workgroups beyond these clear `zero` (shg::t_zero_with_fold)
+    uint32_t* zero;
+    size_t zero_words;
 };
 
 SHG_MERGEABLE(k_fold_minmax, FoldMinmaxArgs, __launch_bounds__(64)) {
     const uint32_t* __restrict__ slots = kargs.slots;
     uint32_t* __restrict__ out = kargs.out;
+    if ((int)blockIdx.x >= kargs.n_planes) {
+        uint32_t* __restrict__ z = kargs.zero;
+        const size_t stride = (size_t)(gridDim.x - kargs.n_planes) * 64;
+        for (size_t i = (size_t)(blockIdx.x - kargs.n_planes) * 64 + threadIdx.x; i < kargs.zero_words; i += stride) z[i] = 0;
+        return;
+    }
     uint32_t a = slots[((int64_t)blockIdx.x * 64 + threadIdx.x) * 2], b = slots[((int64_t)blockIdx.x * 64 + threadIdx.x) * 2 + 1];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -351,6 +364,22 @@ SHG_MERGEABLE(k_fold_minmax, FoldMinmaxArgs, __launch_bounds__(64)) {
         b = ob > b ? ob : b;
     }
     if (threadIdx.x == 0) { out[blockIdx.x * 2] = 0xffffu - a; out[blockIdx.x * 2 + 1] = b; }
+}
+
+// k_fold_minmax, and with it the clearing of the area the next stage asked for (shg::t_zero_with_fold)
+int launch_fold(uint32_t* minmax_slots, int n_shifts, hipStream_t st) {
+    FoldMinmaxArgs fa{minmax_slots, minmax_slots + (int64_t)n_shifts * 64 * 2, n_shifts, nullptr, 0};
+    unsigned extra = 0;
+    if (shg::t_zero_with_fold && shg::t_zero_with_fold_words > 0) {
+        fa.zero = static_cast<uint32_t*>(shg::t_zero_with_fold);
+        fa.zero_words = shg::t_zero_with_fold_words;
+        extra = (unsigned)std::min<size_t>((fa.zero_words + 1023) / 1024, 64);
+    }
+    const int e = SHG_LAUNCH(k_fold_minmax, dim3((unsigned)n_shifts + extra), dim3(64), 0, st, fa);
+    if (e == 0 && extra) shg::t_prezeroed = shg::t_zero_with_fold;
+    shg::t_zero_with_fold = nullptr;
+    shg::t_zero_with_fold_words = 0;
+    return e;
 }
 
 }  // namespace
@@ -424,8 +453,7 @@ extern "C" int shg_extract_columns_minmax(const void* stack, int64_t n_frames, i
 #undef EXT_LAUNCH_BS
 #undef EXT_LAUNCH
     if (launch_status) return launch_status;
-    if (minmax_slots)
-        return SHG_LAUNCH(k_fold_minmax, dim3((unsigned)n_shifts), dim3(64), 0, st, FoldMinmaxArgs{minmax_slots, minmax_slots + (int64_t)n_shifts * 64 * 2});
+    if (minmax_slots) return launch_fold(minmax_slots, n_shifts, st);
     return 0;
 }
 
@@ -510,7 +538,6 @@ extern "C" int shg_extract_columns_dense(const void* stack, int64_t n_frames, in
 #undef SHG_DENSE_S
 #undef SHG_DENSE
     if (int e = shg::check_launch("k_extract_dense")) return e;
-    if (minmax_slots)
-        return SHG_LAUNCH(k_fold_minmax, dim3((unsigned)n_shifts), dim3(64), 0, st, FoldMinmaxArgs{minmax_slots, minmax_slots + (int64_t)n_shifts * 64 * 2});
+    if (minmax_slots) return launch_fold(minmax_slots, n_shifts, st);
     return 0;
 }

@@ -812,6 +812,15 @@ extern "C" int shg_limb_fused_fits(int64_t sh, int64_t sw, int k) {
     return sh > 2 && sw > 2 && sh * sw < (1ll << 30) && k >= 1 && k <= KMAX;
 }
 
+// words at the head of shg_limb_prepare's workspace that it zeroes for the disk [h][w] (the block-mean image is h/4 x w/4, the blur
+// window int(0.01 * h/4)); 0 when the fused kernels do not take that image
+size_t shg::limb_prepare_zero_words(int64_t h, int64_t w) {
+    const int64_t sh = (h + 3) / 4, sw = (w + 3) / 4;
+    const int k = (int)((double)sh * 0.01);
+    if (!shg_limb_fused_fits(sh, sw, k)) return 0;
+    return prep_layout(sh, sw, k).zero_words;
+}
+
 extern "C" size_t shg_limb_prepare_workspace_bytes(int64_t sh, int64_t sw, int k) {
     if (!shg_limb_fused_fits(sh, sw, k)) return 0;
     return prep_layout(sh, sw, k).total_words * 4;
@@ -843,7 +852,11 @@ extern "C" int shg_limb_prepare(const uint16_t* img, int64_t h, int64_t w, int64
     uint32_t *keysk = ws + lay.keysk, *keys5 = k == 5 ? keysk : ws + lay.keys5;
     double* out4 = reinterpret_cast<double*>(acc + 4 + 3 * FLOOD_SLOTS);
     SHG_PROF("limb_prepare", st);
-    if (int e = SHG_LAUNCH(k_zero_words, dim3((unsigned)std::min<size_t>((lay.zero_words + 255) / 256, 64)), dim3(256), 0, st, ZeroWordsArgs{ws, lay.zero_words})) return e;
+    if (shg::t_prezeroed == workspace) {                       // the extraction's last launch has cleared them on its way (shg_scan_file)
+        shg::t_prezeroed = nullptr;
+    } else if (int e = SHG_LAUNCH(k_zero_words, dim3((unsigned)std::min<size_t>((lay.zero_words + 255) / 256, 64)), dim3(256), 0, st, ZeroWordsArgs{ws, lay.zero_words})) {
+        return e;
+    }
     Ranks4 p;
     const double scale_k = 1.0 / ((double)k * (double)k), scale_5 = 1.0 / 25.0;
     for (int i = 0; i < 4; ++i) { p.rank[i] = host_ranks4[i]; p.array[i] = (i < 2 && k != 5) ? 1 : 0; p.scale[i] = (i < 2) ? scale_5 : scale_k; }

@@ -216,9 +216,16 @@ extern "C" int shg_scan_file(const shg_scan_request* rq, shg_scan_result* rs, sh
         rs->y1 = y12[0];
         rs->y2 = y12[1];
         rs->phase_done = 1;
-        SCAN_TRY(shg_stage_extract(rq->stack, rq->n_frames, rq->height, rq->width, rq->bytes_per_px, rq->frame_stride_px, rq->host_fit,
-                                   rq->host_shifts, S, rq->disks, rq->disk_pitch, rq->disk_plane_stride, n_cols, 0, rq->flip_x,
-                                   rq->minmax_slots, extract_ws, rg.extract_ws, extract_pin, rg.extract_pin, stream));
+        if (limb) {                                            // the limb stage's accumulators are cleared by the extraction's last launch
+            shg::t_zero_with_fold = limb_ws;
+            shg::t_zero_with_fold_words = shg::limb_prepare_zero_words(ih, n_cols);
+        }
+        const int extract_status = shg_stage_extract(rq->stack, rq->n_frames, rq->height, rq->width, rq->bytes_per_px, rq->frame_stride_px, rq->host_fit,
+                                                     rq->host_shifts, S, rq->disks, rq->disk_pitch, rq->disk_plane_stride, n_cols, 0, rq->flip_x,
+                                                     rq->minmax_slots, extract_ws, rg.extract_ws, extract_pin, rg.extract_pin, stream);
+        shg::t_zero_with_fold = nullptr;                       // (whatever happened: the request does not outlive this call)
+        shg::t_zero_with_fold_words = 0;
+        if (extract_status) { shg::t_prezeroed = nullptr; return extract_status; }
         rs->phase_done = 2;
         // ---- solex_process: the geometry (Solex_recon.py:104-122) ----
         bool later_disks = false;                              // a requested disk other than the first goes through correct_image with
@@ -226,8 +233,10 @@ extern "C" int shg_scan_file(const shg_scan_request* rq, shg_scan_result* rs, sh
         double mat3[9], inv[4], origin[2], det;
         if (limb) {
             int64_t dims[2];
-            SCAN_TRY(shg_stage_limb_fit(rq->disks, ih, n_cols, rq->disk_pitch, rq->host_gauss_taps, rq->host_points, rq->host_flags, rq->points_cap,
-                                        rs->counts3, rs->geom16, dims, rq->host_outline200, limb_ws, rg.limb_ws, limb_pin, rg.limb_pin, stream));
+            const int limb_status = shg_stage_limb_fit(rq->disks, ih, n_cols, rq->disk_pitch, rq->host_gauss_taps, rq->host_points, rq->host_flags, rq->points_cap,
+                                                       rs->counts3, rs->geom16, dims, rq->host_outline200, limb_ws, rg.limb_ws, limb_pin, rg.limb_pin, stream);
+            shg::t_prezeroed = nullptr;                        // (spent by shg_limb_prepare, or never looked at: the other limb kernels)
+            if (limb_status) return limb_status;
             const double* g = rs->geom16;
             rs->limb_fitted = 1;
             rs->phi = g[3];
@@ -255,6 +264,7 @@ extern "C" int shg_scan_file(const shg_scan_request* rq, shg_scan_result* rs, sh
             memcpy(rs->h_rest, mat3, 3 * sizeof(double));
             rs->theta_rest = rs->theta_first;
             rs->circle3[0] = rs->circle3[1] = rs->circle3[2] = -1;
+            shg::t_prezeroed = nullptr;
         }
         rs->phase_done = 3;
     } else {

@@ -39,6 +39,14 @@ int on_frame_pass_lane(hipStream_t st, int (*launch)(hipStream_t, void*), void* 
 // Set by a stage that has already cleared the extrema's slots (stages.hip: in the launch that uploads the plan); the extraction entry point
 // this thread calls next then skips its memset, and resets the flag.
 extern thread_local bool t_minmax_slots_zeroed;
+// A scratch area the NEXT stage accumulates into, cleared by the extraction's last (tiny) launch instead of by a launch of its own
+// (every launch of a scan costs the frame pass running beside it about a microsecond): shg_scan_file names the limb stage's
+// accumulators here before it calls the extraction, k_fold_minmax clears them on its way and the pointer moves to t_prezeroed,
+// where shg_limb_prepare finds it (and skips its own zeroing) or shg_scan_file drops it.
+extern thread_local void* t_zero_with_fold;
+extern thread_local size_t t_zero_with_fold_words;
+extern thread_local void* t_prezeroed;
+size_t limb_prepare_zero_words(int64_t h, int64_t w);          // words shg_limb_prepare zeroes for an [h][w] disk (0: not the fused path's)
 // The same launch with nobody waiting: after what `after` holds so far, *done recorded behind it (the caller's to destroy).
 // -> 1 when the device has no lane (nothing launched), 0 when launched, another value on error.
 int prelaunch_on_lane(hipStream_t after, int (*launch)(hipStream_t, void*), void* arg, hipEvent_t* done);

@@ -361,3 +361,42 @@ def test_folder_argument_expands_to_its_scans(tmp_path):
         (tmp_path / name).write_bytes(b'x')
     (tmp_path / 'sub.ser').mkdir()
     assert [os.path.basename(f) for f in SHG_MAIN.scans_in(str(tmp_path))] == ['a.SER', 'b.ser', 'c.avi']
+
+
+def test_upload_reader_direct_and_buffered_reads_agree(tmp_path, monkeypatch):
+    """video_reader's chunk reader (file -> the upload service's pinned buffer): the O_DIRECT path reads the enclosing 4 KiB-aligned
+    span (the SER header is 178 bytes: no frame starts on a block) and reports where the wanted bytes begin; a chunk that ends at
+    the end of the file, a file system that refuses O_DIRECT and SHG_READ_DIRECT=0 all give the very bytes the buffered read gives."""
+    import mmap
+    from solex_ser_recon_en_amd import video_reader as vr
+    data = os.urandom(3 * (1 << 20) + 12345)
+    path = str(tmp_path / 'blob.ser')
+    with open(path, 'wb') as f:
+        f.write(data)
+        f.flush()
+        os.fsync(f.fileno())
+    buf = mmap.mmap(-1, (1 << 20) + 2 * vr._DIRECT_ALIGN)     # page-aligned, like a pinned buffer
+    mv = memoryview(buf)
+    try:
+        for mode in ('0', '1', 'auto'):
+            monkeypatch.setenv('SHG_READ_DIRECT', mode)
+            fd = os.open(path, os.O_RDONLY)
+            os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)  # cold where the file system can forget it
+            os.close(fd)
+            h = vr._FileHandles()
+            for offset, n in ((178, 1 << 20), (178 + (1 << 20), 1 << 20), (len(data) - 70001, 70001), (4096, 8192), (0, 1)):
+                h.open(path, offset, n)
+                if mode == '0':
+                    assert h.dfd < 0
+                skip = vr._read_chunk(h, mv, offset, n)
+                assert 0 <= skip < vr._DIRECT_ALIGN and bytes(mv[skip:skip + n]) == data[offset:offset + n], (mode, offset, n)
+            h.close()
+            assert h.fd < 0 and h.dfd < 0
+        share = vr._page_cache_share
+        fd = os.open(path, os.O_RDONLY)
+        os.pread(fd, 1 << 20, 0)
+        assert 0.0 <= share(fd, 0, 1 << 20) <= 1.0 and share(-1, 0, 4096) == 1.0      # (a descriptor that cannot be mapped: "cached")
+        os.close(fd)
+    finally:
+        mv.release()
+        buf.close()
