@@ -226,7 +226,14 @@ def solex_do_work(tasks, flag_command_line=False, distribute='auto', return_resu
                     os.sched_setaffinity(0, previous)
         elif native:
             _ensure_lane(decoder.device)
-            _scan_batch_native(tasks, decoder, n_workers, scan, collected if return_results else None)
+            if os.environ.get('SHG_CHAIN_CUS') or os.environ.get('SHG_CHAIN_CU_MASK'):
+                # CU-masked streams are BLOCKING streams (there is no other kind): they synchronise with the legacy null stream, so
+                # this thread -- whose current stream every scan's pass A is launched behind -- must not sit on that one
+                import torch
+                with torch.cuda.stream(_feeder_stream(decoder.device)):
+                    _scan_batch_native(tasks, decoder, n_workers, scan, collected if return_results else None)
+            else:
+                _scan_batch_native(tasks, decoder, n_workers, scan, collected if return_results else None)
         else:
             _ensure_lane(decoder.device)
             _scan_pool(scan, len(tasks), n_workers, decoder.device)
@@ -310,6 +317,18 @@ def _ensure_lane(device):
             with torch.cuda.device(device):
                 check(lib.shg_frame_pass_lane_set(lane.cuda_stream), 'shg_frame_pass_lane_set')
     return lane
+
+
+_feeders = {}
+
+
+def _feeder_stream(device):
+    import torch
+    with _contexts_lock:
+        st = _feeders.get(str(device))
+        if st is None:
+            st = _feeders[str(device)] = torch.cuda.Stream(device=device)
+    return st
 
 
 def _worker_context(device, k):
