@@ -213,6 +213,7 @@ def main():
     region_s = timed_regions(args.steps, max(1, args.repeats))
     comb1 = Solex_recon.combiner_stats()
     _lib.profile_enable(False)
+    lane = lane_timeline(_lib, len(region_s))
     combiner = {k: comb1[k] - comb0[k] for k in comb1}
     combiner['launches_per_dispatch'] = round(combiner['launches_recorded'] / combiner['dispatches'], 2) if combiner['dispatches'] else None
     combiner['dispatches_per_scan'] = round(combiner['dispatches'] / (args.steps * len(region_s)), 2)
@@ -289,6 +290,7 @@ def main():
                 'frame_walk_ceiling': {'value': round(walk, 1), 'unit': 'GB/s', 'frac_of_it': round(ach1 / walk, 4) if walk else None,
                                        'how': 'the same XOR-only kernel with pass A\'s addresses (a lane walks the frame axis), best of 8 '
                                               '(splits x unroll) = %s' % (walk_shape,)},
+                'lane': lane,
                 'secondary': {'kernel': 'k_extract (pass B)', 'algorithmic_bytes_per_launch': bytes_b,
                               'avg_launch_ms': round(ext_ms / ext_n, 5) if ext_n else None,
                               'achieved': round(bytes_b / (ext_ms / ext_n * 1e-3) / 1e9, 1) if ext_n else None,
@@ -397,6 +399,32 @@ def main():
     if world > 1:
         td.barrier()
         td.destroy_process_group()
+
+
+def lane_timeline(_lib, n_regions):
+    """The frame-pass lane over the timed regions, from the same HIP events as roofline.achieved (shg_profile_dump): the idle gap
+    between consecutive passes and how busy the lane is from a region's first pass to its last.  The step is the lane's period
+    (DESIGN.md section 5): pass A beside the other scans' kernels + this gap + a region's fill and drain."""
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), 'shg_bench_lane_%d.csv' % os.getpid())
+    try:
+        _lib.check(_lib.lib.shg_profile_dump(path.encode()), 'shg_profile_dump')
+        spans = sorted((float(r[2]), float(r[3])) for r in (ln.split(',') for ln in open(path).read().splitlines()[1:]) if r[0] == 'accumulate')
+    except Exception as e:      # noqa: BLE001
+        return {'error': repr(e)}
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
+    if len(spans) < 2:
+        return None
+    gaps = sorted(spans[i + 1][0] - spans[i][1] for i in range(len(spans) - 1))
+    inner = gaps[:len(gaps) - (n_regions - 1)] if n_regions > 1 else gaps        # (the n_regions - 1 longest gaps are the region boundaries)
+    busy = sum(b - a for a, b in spans)
+    span = (spans[-1][1] - spans[0][0]) - sum(gaps[len(inner):])
+    return {'passes': len(spans), 'gap_ms_median': round(inner[len(inner) // 2], 4), 'gap_ms_mean': round(sum(inner) / len(inner), 4),
+            'busy_frac': round(busy / span, 4) if span > 0 else None,
+            'how': 'idle time between consecutive pass A launches on the lane and the share of the time from a region\'s first pass '
+                   'to its last that a pass was running (region boundaries taken out)'}
 
 
 def extra_leg(what, pool, shifts, steps, warmup, workers, run_scans, barrier, _lib, world):
