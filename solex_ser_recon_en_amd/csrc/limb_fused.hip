@@ -1,12 +1,13 @@
-// The limb stage in nine launches instead of twenty-three (ellipse_to_circle.py:148-291, 299-302).
+// The limb stage in seven launches instead of twenty-three (ellipse_to_circle.py:148-291, 299-302).
 //
 // limb.hip holds one kernel per NumPy / OpenCV / scikit-image call of get_flood_image and get_edge_list: on the
 // quarter-size image (250 k pixels at C2) every one of them is a 3-15 us launch, 119 us of a scan's 310 us chain.  Here the
 // same arithmetic -- bit for bit: the tests hold each fused kernel against its limb.hip counterparts -- goes through LDS
 // tiles:
-//   shg_limb_prepare   memset | block mean + cv2.blur (k and 5) | first radix pass | second radix pass (its last workgroup forms the
-//                      order statistics) | flood min / max | flood histogram (its last workgroup stores the stage's 30 numbers
-//                      where the host reads them)
+//   shg_limb_prepare   (accumulators cleared by the extraction's last launch, or by k_zero_words) | block mean + cv2.blur (k and 5) +
+//                      the image's smallest blurred value | first radix pass | second radix pass (its last workgroup forms the
+//                      order statistics, very_bright and, from them, the flood's min / max) | flood histogram (its last
+//                      workgroup stores the stage's 30 numbers where the host reads them)
 //   shg_limb_edges     Gaussian (both axes) + Sobel + magnitude + non-maximum suppression + tile-local union-find |
 //                      union across tile borders | raster-ordered emission straight into the host's staging area
 // What makes the fusion exact rather than approximate:
@@ -51,6 +52,15 @@ constexpr int FLOOD_SLOTS = 9;
 constexpr int KMAX = 16;                     // largest cv2.blur window the fused path takes (int(0.01 * rows / 4): scans up to 6799 slit rows)
 constexpr double kUnit = 9.5367431640625e-07;        // 2^-20
 
+__device__ __forceinline__ uint64_t f64_key(double v) {          // monotone map double -> uint64
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_f64(uint64_t k) {
+    const uint64_t b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
 // ---- workspace layout of shg_limb_prepare (all 32-bit words unless noted) -------------------------------------------
 struct PrepLayout {
     int bits0, bits1;                        // high / low digit of a window sum: two radix passes
@@ -76,7 +86,8 @@ PrepLayout prep_layout(int64_t sh, int64_t sw, int k) {
     L.hist1 = off; off += (size_t)4 << L.bits1;
     L.coarse0 = off; off += 2 * 256;
     L.coarse1 = off; off += 4 * 256;
-    L.acc = off; off += 2 * (4 + 3 * FLOOD_SLOTS + 4);         // u64 each: very_bright, the slots, then the four order statistics
+    L.acc = off; off += 2 * (4 + 3 * FLOOD_SLOTS + 4 + FLOOD_SLOTS);     // u64 each: very_bright, the slots, the four order statistics, then the
+                                                                         // complemented keys of blur k's smallest values (k_limb_blur, one per slot)
     L.counts = off; off += 20;
     L.done = off; off += 4;                                     // [0]: workgroups of the second radix pass that are through, [1]: of the histogram
     L.zero_words = off;                                         // everything up to here is zeroed by the call
@@ -147,12 +158,13 @@ SHG_MERGEABLE(k_limb_blur, LimbBlurArgs, __launch_bounds__(256)) {
     __shared__ uint32_t S[(BT + KMAX) * (BT + KMAX)];
     __shared__ uint32_t H[(BT + KMAX) * BT];
     __shared__ unsigned long long wsum[4];
+    __shared__ uint32_t wmin[4];
     const int hl = max(k / 2, 2), hr = max(k - 1 - k / 2, 2);           // halo of the union of the two windows
     const int RH = BT + hl + hr, RW = RH;
     const int x0 = blockIdx.x * BT, y0 = blockIdx.y * BT;
     const int tid = threadIdx.x;
-    // (the call zeroes the accumulators; minima start from the largest key)
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid < FLOOD_SLOTS) acc[5 + 3 * tid] = ~0ull;
+    // (the call zeroes the accumulators; k_limb_select1's last workgroup writes the flood slots' minima and maxima)
+    uint32_t my_min = 0xffffffffu;                                       // this pixel's window sum of blur k
     // block means of the region, BORDER_REFLECT_101 on the quarter-size image (cv2.blur's border)
     unsigned long long own = 0;
     for (int e = tid; e < RH * RW; e += 256) {
@@ -201,11 +213,24 @@ SHG_MERGEABLE(k_limb_blur, LimbBlurArgs, __launch_bounds__(256)) {
             uint32_t s = 0;
             for (int j = 0; j < kw; ++j) s += H[(r_lo + y + j) * BT + x];
             keys[(int64_t)(y0 + y) * sw + x0 + x] = s;
+            if (a == 0) my_min = s;
         }
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = __shfl_xor(my_min, d);
+        my_min = o < my_min ? o : my_min;
+    }
+    if ((tid & 63) == 0) wmin[tid >> 6] = my_min;
+    __syncthreads();
     if (tid == 0) {
+        const int slot = (blockIdx.y * gridDim.x + blockIdx.x) % FLOOD_SLOTS;
         const unsigned long long t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (t) atomicAdd(&acc[4 + 3 * ((blockIdx.y * gridDim.x + blockIdx.x) % FLOOD_SLOTS)], t);
+        if (t) atomicAdd(&acc[4 + 3 * slot], t);
+        // the smallest blurred value of the image: what min(blurred[blurred < very_bright]) is, once very_bright is known
+        // (k_limb_select1).  Kept as the complement of its order-preserving key, so that zeroed memory is the neutral start.
+        const uint32_t m = min(min(wmin[0], wmin[1]), min(wmin[2], wmin[3]));
+        if (m != 0xffffffffu) atomicMax(&acc[4 + 3 * FLOOD_SLOTS + 4 + slot], ~f64_key(((double)m * kUnit) * (1.0 / ((double)k * (double)k))));
     }
 }
 
@@ -361,59 +386,44 @@ SHG_MERGEABLE(k_limb_select1, LimbSelect1Args, __launch_bounds__(256)) {
         if ((threadIdx.x & 63) == 0) val[q] = ((double)key * kUnit) * p.scale[q];
     }
     __syncthreads();
+    __shared__ double vb_s;
+    __shared__ int scan_s;
+    __shared__ unsigned long long wmax[4];
     if (threadIdx.x == 0) {
         const double a = val[2], b = val[3], diff = b - a;
         const double very_bright = gamma >= 0.5 ? b - diff * (1.0 - gamma) : a + diff * gamma;
         out4[0] = val[0]; out4[1] = val[1]; out4[2] = a; out4[3] = b;
         acc[3] = (unsigned long long)__double_as_longlong(very_bright);
+        vb_s = very_bright;
+        scan_s = !(a < very_bright);
     }
-}
-
-__device__ __forceinline__ uint64_t f64_key(double v) {
-    const uint64_t b = (uint64_t)__double_as_longlong(v);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double key_f64(uint64_t k) {
-    const uint64_t b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
-    return __longlong_as_double((long long)b);
-}
-
-// ---- K3: min / max of blurred[blurred < very_bright] ---------------------------------------------------------------------------
-struct LimbFloodMinmaxArgs {
-    const uint32_t* keysk;
-    int64_t n;
-    double scale_k;
-    unsigned long long* acc;
-};
-SHG_MERGEABLE(k_limb_flood_minmax, LimbFloodMinmaxArgs, __launch_bounds__(256)) {
-    const uint32_t* __restrict__ keysk = kargs.keysk;
-    const int64_t n = kargs.n;
-    const double scale_k = kargs.scale_k;
-    unsigned long long* __restrict__ acc = kargs.acc;
-    const double very_bright = __longlong_as_double((long long)acc[3]);
-    unsigned long long lo = ~0ull, hi = 0ull;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const double bl = ((double)keysk[i] * kUnit) * scale_k;
-        if (bl < very_bright) {
-            const uint64_t kk = f64_key(bl);
-            lo = kk < lo ? kk : lo;
-            hi = kk > hi ? kk : hi;
-        }
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned long long ol = __shfl_xor(lo, d), oh = __shfl_xor(hi, d);
-        lo = ol < lo ? ol : lo;
-        hi = oh > hi ? oh : hi;
-    }
-    __shared__ unsigned long long wlo[4], whi[4];
-    if ((threadIdx.x & 63) == 0) { wlo[threadIdx.x >> 6] = lo; whi[threadIdx.x >> 6] = hi; }
     __syncthreads();
+    // min / max of blurred[blurred < very_bright] (ellipse_to_circle.py:166-169) without another pass over the image: the minimum is
+    // the image's smallest value (k_limb_blur left it) if that lies below very_bright; the maximum is the lower of the two order
+    // statistics very_bright was interpolated between -- a < very_bright <= b, and no value lies between two consecutive order
+    // statistics -- unless the two coincide (very_bright == a: a tie at the 99th percentile, a few scans in a hundred), and
+    // then this workgroup looks the image over for the largest value below it.
+    const double very_bright = vb_s;
+    unsigned long long hi = 0ull;
+    if (scan_s) {
+        const uint32_t* __restrict__ vk = p.array[2] ? keys5 : keysk;
+        for (int64_t i = threadIdx.x; i < n; i += 256) {
+            const double bl = ((double)vk[i] * kUnit) * p.scale[2];
+            if (bl < very_bright) { const unsigned long long kk = f64_key(bl); hi = kk > hi ? kk : hi; }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(hi, d); hi = o > hi ? o : hi; }
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = hi;
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        for (int i = 1; i < 4; ++i) { lo = wlo[i] < lo ? wlo[i] : lo; hi = whi[i] > hi ? whi[i] : hi; }
-        unsigned long long* slot = acc + 4 + 3 * (blockIdx.x % FLOOD_SLOTS);
-        atomicMin(&slot[1], lo);
-        atomicMax(&slot[2], hi);
+        if (scan_s) { hi = wmax[0]; for (int i = 1; i < 4; ++i) hi = wmax[i] > hi ? wmax[i] : hi; }
+        else hi = f64_key(val[2]);
+        unsigned long long inv = 0ull;
+        for (int s = 0; s < FLOOD_SLOTS; ++s) { const unsigned long long v = acc[4 + 3 * FLOOD_SLOTS + 4 + s]; inv = v > inv ? v : inv; }
+        unsigned long long lo = ~inv;                            // the key of the smallest value
+        if (inv == 0ull || !(key_f64(lo) < very_bright)) { lo = ~0ull; hi = 0ull; }      // nothing below very_bright
+        for (int s = 0; s < FLOOD_SLOTS; ++s) { acc[5 + 3 * s] = s == 0 ? lo : ~0ull; acc[6 + 3 * s] = s == 0 ? hi : 0ull; }
     }
 }
 
@@ -878,7 +888,6 @@ extern "C" int shg_limb_prepare(const uint16_t* img, int64_t h, int64_t w, int64
     if (int e = SHG_LAUNCH(k_limb_select1, dim3((unsigned)blocks, 4u), dim3(256), ((size_t)1 << lay.bits1) * 4, st,
                            LimbSelect1Args{keysk, keys5, n, p, lay.bits0, lay.bits1, hist0, coarse0, hist1, coarse1, gamma99, done, acc, out4}))
         return e;
-    if (int e = SHG_LAUNCH(k_limb_flood_minmax, dim3((unsigned)blocks), dim3(256), 0, st, LimbFloodMinmaxArgs{keysk, n, scale_k, acc})) return e;
     *keys_out = keysk;
     return SHG_LAUNCH(k_limb_flood_hist, dim3((unsigned)blocks), dim3(256), 0, st, LimbFloodHistArgs{keysk, n, scale_k, acc, out4, counts, done + 1, packed});
 }

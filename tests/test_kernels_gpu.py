@@ -950,16 +950,21 @@ def _limb_disk(h, w, seed):
     r2 = ((xx - 0.52 * w) / (0.40 * w)) ** 2 + ((yy - 0.49 * h) / (0.43 * h)) ** 2
     img = np.where(r2 < 1, 9000 + 30000 * np.sqrt(np.clip(1 - r2, 0, 1)), 900.0)
     img = img + rng.normal(0, 250, img.shape)
-    img[rng.integers(0, h, 40), rng.integers(0, w, 40)] = 65535
+    if seed >= 100:                                          # a flat top: the 99th percentile of the blurred image is a tie
+        img = np.minimum(img, 30000.0)
+    else:
+        img[rng.integers(0, h, 40), rng.integers(0, w, 40)] = 65535
     return np.clip(img, 0, 65535).astype(np.uint16)
 
 
-@pytest.mark.parametrize('h,w,seed', [(2000, 2000, 1), (1203, 997, 2), (3204, 1601, 3), (6400, 800, 4), (420, 640, 5)])
+@pytest.mark.parametrize('h,w,seed', [(2000, 2000, 1), (1203, 997, 2), (3204, 1601, 3), (6400, 800, 4), (420, 640, 5), (2000, 2000, 101), (1203, 997, 102)])
 def test_fused_limb_kernels_equal_the_separate_ones(ops, h, w, seed):
     """shg_limb_prepare == downscale + cv2.blur (k and 5) + the two selects + the flood statistics, and shg_limb_edges ==
     canny masks + hysteresis labelling, value for value: same window sums, same order statistics, same sum / min / max /
     histogram, same edge pixels with the same roots -- for blur windows 5, 3, 8, 16 and 1, images whose sides are not
-    multiples of 4 or of the tile, and every rung of canny's retry ladder."""
+    multiples of 4 or of the tile, and every rung of canny's retry ladder.  Seeds >= 100: a disk with a flat top, so that the two
+    order statistics the 99th percentile is interpolated between coincide -- the case in which the fused path has to look the image
+    over for the largest value below very_bright instead of taking the lower order statistic."""
 
     disk = torch.from_numpy(_limb_disk(h, w, seed)).cuda()
     sh, sw = -(-h // 4), -(-w // 4)
