@@ -96,7 +96,7 @@ def _page_cache_share(fd, offset, nbytes):
             vec = (ctypes.c_ubyte * n_pages)()
             if libc.mincore(addr, length, vec) != 0:
                 return 1.0
-            return sum(b & 1 for b in vec) / float(n_pages)
+            return float(np.count_nonzero(np.frombuffer(vec, dtype=np.uint8) & 1)) / float(n_pages)
         finally:
             libc.munmap(addr, length)
     except (OSError, ValueError, AttributeError):
@@ -119,7 +119,7 @@ class _FileHandles:
         mode = _direct_mode()
         if mode != '0' and hasattr(os, 'O_DIRECT'):
             try:
-                if mode == '1' or _page_cache_share(self.fd, offset, min(nbytes, 4 << 20)) < 0.5:
+                if mode == '1' or _page_cache_share(self.fd, offset, min(nbytes, 1 << 20)) < 0.5:       # (a sample: 256 pages, a few microseconds)
                     self.dfd = os.open(path, os.O_RDONLY | os.O_DIRECT)
             except OSError:                                  # tmpfs and friends: EINVAL
                 self.dfd = -1
