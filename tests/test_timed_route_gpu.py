@@ -215,3 +215,46 @@ def test_launch_combiner_gives_the_serial_products(pkg, monkeypatch):
         for (c1, p1), (c2, p2) in zip(r1, r2):
             np.testing.assert_array_equal(c1, c2)
             np.testing.assert_array_equal(p1, p2)
+
+
+def test_launch_combiner_survives_scans_that_fail(pkg, monkeypatch):
+    """Scans that fail in the middle of their chains (noise only: the line fit; a tiny disk: the limb fit) among good ones, with the
+    launch combiner on: a failing scan leaves its cohort (the others must not wait for it), the batch raises what the serial order
+    raises, and the pool goes on to give the serial products for the next batch."""
+    SHG_MAIN, Solex_recon, ops, outputs, synth = pkg
+    from solex_ser_recon_en_amd.video_reader import array_reader
+    good = [synth.synth_frames_torch(500, 520, 40, 16, seed=50 + i) for i in range(5)]
+    noise = torch.from_numpy(np.random.default_rng(0).integers(0, 3000, (400, 32, 400)).astype(np.int16)).cuda().view(torch.uint16)
+    tiny = torch.from_numpy(synth.synth_frames_numpy(400, 400, 32, 16, seed=1, scene=dict(ax=20.0, ay=20.0)).view(np.int16)).cuda().view(torch.uint16)
+
+    def run(stacks, workers):
+        tasks = []
+        for st in stacks:
+            opts = SHG_MAIN.default_options()
+            opts.update(_nolog=True)
+            tasks.append((array_reader(st), opts))
+        try:
+            res = Solex_recon.solex_do_work(tasks, True, distribute='none', return_results=True, workers=workers)
+            err = None
+        except Exception as e:      # noqa: BLE001
+            res, err = None, e
+        outputs.flush()
+        torch.cuda.synchronize()
+        return res, err
+    mixed = [good[0], good[1], noise, good[2], tiny, good[3], good[4]]
+    _, want_err = run(mixed, 1)
+    assert want_err is not None
+    serial, err = run(good, 1)
+    assert err is None
+    monkeypatch.setenv('SHG_COMBINE', '1')
+    monkeypatch.setenv('SHG_COMBINE_GROUP', '3')
+    monkeypatch.setenv('SHG_COMBINE_GATE_US', '3000')
+    for _ in range(3):
+        _, got_err = run(mixed, 5)                           # (a pool size no other test uses)
+        assert type(got_err) is type(want_err) and str(got_err) == str(want_err), (got_err, want_err)
+        merged, err = run(good, 5)
+        assert err is None
+        for a, b in zip(serial, merged):
+            for (c1, p1), (c2, p2) in zip(a, b):
+                np.testing.assert_array_equal(np.asarray(c1), np.asarray(c2))
+                np.testing.assert_array_equal(np.asarray(p1), np.asarray(p2))
