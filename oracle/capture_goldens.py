@@ -495,7 +495,32 @@ def g15_stubborn():
     save('g15_stubborn', **out)
 
 
-ALL = dict(G6=g6_vignette, G13=g13_limb, G14=g14_pipeline, G1=g1_mean_max, G2=g2_extract, G3=g3_warp, G4=g4_transversalium, G5=g5_rescale,
+def g16_ellipse_skimage():
+    """An INDEPENDENT implementation of the ellipse fit the reference takes from lsq-ellipse (absent here: restated in
+    oracle/limb_oracle.py from Halir & Flusser 1998): scikit-image 0.18.3's skimage.measure.EllipseModel, which implements the
+    same published method with its own numerics and its own conversion to centre / axes / angle.  Noisy partial ellipses of the
+    shapes a solar limb takes; the fixture holds the points and EllipseModel's (xc, yc, a, b, theta)."""
+    from skimage.measure import EllipseModel
+    rng = np.random.default_rng(16)
+    out = {}
+    cases = [(1010.0, 995.0, 840.0, 880.0, 0.03, 0.4, 2 * np.pi, 900), (523.0, 480.7, 400.0, 310.0, -0.6, 0.8, 2 * np.pi, 500),
+             (2000.0, 1280.0, 1680.0, 1120.0, 0.9, 1.5, 1.4 * np.pi, 1200), (300.0, 310.0, 250.0, 251.0, 0.2, 0.3, 2 * np.pi, 300),
+             (1500.0, 700.0, 500.0, 1300.0, 0.1, 2.0, 1.7 * np.pi, 800), (640.0, 512.0, 420.0, 390.0, -1.2, 0.5, 2 * np.pi, 64)]
+    for i, (xc, yc, a, b, theta, noise, arc, n) in enumerate(cases):
+        t = np.sort(rng.uniform(0.3, 0.3 + arc, n))
+        x = xc + a * np.cos(t) * np.cos(theta) - b * np.sin(t) * np.sin(theta) + noise * rng.standard_normal(n)
+        y = yc + a * np.cos(t) * np.sin(theta) + b * np.sin(t) * np.cos(theta) + noise * rng.standard_normal(n)
+        pts = np.c_[x, y]
+        model = EllipseModel()
+        assert model.estimate(pts)
+        out['points%d' % i] = pts
+        out['params%d' % i] = np.array(model.params, dtype=np.float64)          # xc, yc, a, b, theta
+        out['truth%d' % i] = np.array([xc, yc, a, b, theta])
+    out['n_cases'] = np.array(len(cases))
+    save('g16_ellipse_skimage', **out)
+
+
+ALL = dict(G16=g16_ellipse_skimage, G6=g6_vignette, G13=g13_limb, G14=g14_pipeline, G1=g1_mean_max, G2=g2_extract, G3=g3_warp, G4=g4_transversalium, G5=g5_rescale,
            G7=g7_matrix, G8=g8_fit_shim, G9=g9_fits, G10=g10_cli, G11=g11_crop, G12=g12_shift_order, G15=g15_stubborn)
 
 if __name__ == '__main__':

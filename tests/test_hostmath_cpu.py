@@ -482,3 +482,36 @@ def test_fast_log_stays_below_one_ulp(tmp_path):
     # log_ratio_u16(a, b) (one reciprocal for the quotient and for the logarithm's own division): below 1 ulp too, and the very
     # double log_normal(a / b) gives, but for a few pairs in a million
     assert ratio < 1.0 and ratio_differs < 1e-4, (ratio, ratio_differs)
+
+
+def test_ellipse_fit_agrees_with_scikit_images_independent_implementation(golden):
+    """lsq-ellipse (the reference's `from ellipse import LsqEllipse`, ellipse_to_circle.py:53-59) is absent from /root/reference
+    and from this image, so the fit is a restatement of Halir & Flusser's direct least squares -- which nothing but itself pinned.
+    g16 holds the same published method as scikit-image 0.18.3 implements it (skimage.measure.EllipseModel: its own scaling,
+    eigen-solve and conversion to centre / axes / angle), captured under the interpreter that has it, on noisy, partly open
+    ellipses of the shapes a limb takes: the oracle's LsqEllipse and the C++ control plane's fit (hostmath.fit_ellipse, what every
+    scan runs) must describe the same ellipse -- centre, both semi-axes and the major axis' direction."""
+    from oracle import limb_oracle as limb
+    g = golden('g16_ellipse_skimage')
+
+    def canonical(xc, yc, a, b, theta):
+        if a < b:
+            a, b, theta = b, a, theta + np.pi / 2
+        return np.array([xc, yc, a, b]), float(np.mod(theta, np.pi))
+
+    for i in range(int(g['n_cases'])):
+        pts = g['points%d' % i]
+        want, want_angle = canonical(*g['params%d' % i])
+        fits = []
+        center, width, height, phi = limb.LsqEllipse().fit(pts).as_parameters()
+        fits.append((float(center[0]), float(center[1]), float(np.real(width)), float(np.real(height)), float(np.real(phi))))
+        c2, w2, h2, p2 = hostmath.fit_ellipse(pts)
+        fits.append((float(c2[0]), float(c2[1]), float(w2), float(h2), float(p2)))
+        for got in fits:
+            vals, angle = canonical(*got)
+            np.testing.assert_allclose(vals, want, rtol=1e-11, atol=0)              # (measured: 1e-15 .. 7e-14)
+            roundness = (want[2] - want[3]) / want[2]                 # a nearly round ellipse has no direction to speak of
+            d = abs(angle - want_angle)
+            assert min(d, np.pi - d) < 1e-11 / max(roundness, 1e-3), (i, angle, want_angle)     # (measured: 2e-14 .. 2e-12)
+        # and the two of this repo agree far more closely with each other than with a third party's numerics
+        np.testing.assert_allclose(fits[0][:4], fits[1][:4], rtol=1e-11)

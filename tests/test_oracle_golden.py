@@ -267,3 +267,23 @@ def test_row_box_sums_known_answers():
     s = orc.row_box_sums_reflect101(a, 3)
     np.testing.assert_array_equal(s[0], [1 + 0 + 1, 0 + 1 + 2, 1 + 2 + 3, 2 + 3 + 4, 3 + 4 + 5, 4 + 5 + 4])   # gfedcb|abcdefgh|gfedcba
     np.testing.assert_array_equal(orc.row_box_sums_reflect101(np.ones((3, 9)), 7), np.full((3, 9), 7.0))
+
+
+@pytest.mark.parametrize('kw,kh', [(5, 5), (25, 17), (25, 16), (3, 1), (7, 7), (9, 13)])
+def test_box_blur_restatement_against_scipys_uniform_filter(kw, kh):
+    """cv2.blur is absent here (parity unpinned); its restatement -- exact integer window sums with BORDER_REFLECT_101, OpenCV's
+    float32 / double scaling, round half to even -- is held against an independent implementation of the same box filter:
+    scipy.ndimage.uniform_filter (mode='mirror' is REFLECT_101; the window sizes the path uses: 5 x 5, 25 x h/100, k x k).
+    OpenCV scales a window sum in float32 where it vectorises (24 bits for sums of up to 2.8e7), SciPy averages in float64: equal
+    on all but a thousandth of the pixels (measured: 0 for the small windows, 22 of 33 127 for 25 x 17), never more than one grey
+    level apart, and equal everywhere on a constant image."""
+    from scipy import ndimage
+    rng = np.random.default_rng(kw * 100 + kh)
+    yy, xx = np.mgrid[0:211, 0:157]
+    img = np.clip(20000 + 15000 * np.sin(yy / 17.0) * np.cos(xx / 23.0) + rng.normal(0, 900, yy.shape), 0, 65535).astype(np.uint16)
+    got = orc.box_blur_u16(img, kw, kh).astype(np.int64)
+    ref = np.rint(ndimage.uniform_filter(img.astype(np.float64), size=(kh, kw), mode='mirror')).astype(np.int64)
+    d = np.abs(got - ref)
+    assert d.max() <= 1 and np.count_nonzero(d) <= d.size // 1000, (d.max(), np.count_nonzero(d))
+    flat = np.full((40, 50), 12345, dtype=np.uint16)
+    np.testing.assert_array_equal(orc.box_blur_u16(flat, kw, kh), flat)
