@@ -39,10 +39,8 @@ try:
         dt = time.perf_counter() - t0
         ok = torch.equal(dev.view(torch.int16), stack.view(torch.int16))
         print('SHG_READ_DIRECT=%-4s %.1f MB cold from %s in %.1f ms -> %.2f GB/s  (frames identical: %s)' % (mode, size / 1e6, where, dt * 1e3, size / dt / 1e9, ok))
-    os.environ['SHG_READ_DIRECT'] = 'auto'
-    rdr = video_reader(path)                                    # warm now (the buffered pass above filled the cache? no: auto read direct) -- read once buffered
     os.environ['SHG_READ_DIRECT'] = '0'
-    video_reader(path).device_stack()
+    video_reader(path).device_stack()                          # one buffered read: the page cache holds the file now
     os.environ['SHG_READ_DIRECT'] = 'auto'
     t0 = time.perf_counter()
     video_reader(path).device_stack()
