@@ -29,7 +29,8 @@ def timeit(fn, iters=30, warmup=5):
     return t[len(t) // 2], t[0]
 
 
-SHAPES = ((2000, 2000, 200, 16), (4000, 2560, 256, 16), (2000, 200, 2000, 16), (2000, 2000, 200, 8))
+# (the fifth: C2 / C4 with file rows of 4096 bytes -- what padding the rows of a 2000-px file to 128 bytes would give pass B: every 128-byte run on a line)
+SHAPES = ((2000, 2000, 200, 16), (4000, 2560, 256, 16), (2000, 200, 2000, 16), (2000, 2000, 200, 8), (2000, 2048, 200, 16))
 for (n, w, h, bits) in (SHAPES if len(sys.argv) < 2 else [SHAPES[int(sys.argv[1])]]):
     stack = synth.synth_frames_torch(n, w, h, bits, seed=0, padded=True)
     ih, iw = max(w, h), min(w, h)

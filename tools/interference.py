@@ -58,6 +58,22 @@ workloads = {
     'select on cl1 (2 passes)': lambda: ops.select_u16(cl1, ranks),
     'products': lambda: ops.contrast_products_u16(frame, cl1, [0, 60000, 0, 50000, 1000, 60000], disc),
 }
+# plain streaming kernels of the same sizes (PyTorch's own): is it what the chain's kernels do, or that anything runs at all?
+_a16 = torch.zeros(8 << 20, dtype=torch.int16, device=dev)
+_b16 = torch.ones(8 << 20, dtype=torch.int16, device=dev)
+_a1g = torch.zeros(256 << 20, dtype=torch.int16, device=dev)
+_b1g = torch.ones(256 << 20, dtype=torch.int16, device=dev)
+workloads.update({
+    'torch: copy 16 MB -> 16 MB': lambda: _a16.copy_(_b16),
+    'torch: fill 16 MB': lambda: _a16.fill_(3),
+    'torch: sum of 16 MB': lambda: _b16.sum(),
+    'torch: copy 512 MB -> 512 MB': lambda: _a1g.copy_(_b1g),
+    'torch: fill 512 MB': lambda: _a1g.fill_(3),
+    'torch: sum of 512 MB': lambda: _b1g.sum(),
+})
+if os.environ.get('SHG_INTERFERENCE_ONLY'):
+    keep = os.environ['SHG_INTERFERENCE_ONLY'].split(',')
+    workloads = {k: v for k, v in workloads.items() if v is None or any(t in k for t in keep)}
 
 ws = torch.empty(_lib.lib.shg_accumulate_workspace_bytes(2000, 200, 2000, 2), dtype=torch.uint8, device=dev)
 lane = torch.cuda.Stream(device=dev, priority=-1)
