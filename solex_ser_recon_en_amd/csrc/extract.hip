@@ -58,7 +58,9 @@ SHG_MERGEABLE_T(SHG_TPL(template <typename T, bool ROT, int BATCH, int SC>), SHG
     __shared__ uint16_t tile[SC][TY][TKP];
     const int64_t ih = ROT ? width : height;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    // (the wave's number through readfirstlane: the compiler does not know threadIdx.x >> 6 is the same in all lanes, and without it
+    // every frame's index, range test and 64-bit base address below are per-lane VALU work -- 7 of the kernel's 24 instructions per sample)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t c0 = (int64_t)blockIdx.x * TK;           // first output column of this workgroup
     const int64_t y = (int64_t)blockIdx.y * TY + lane;
     const int s0 = blockIdx.z * SC;
@@ -75,11 +77,16 @@ SHG_MERGEABLE_T(SHG_TPL(template <typename T, bool ROT, int BATCH, int SC>), SHG
 #pragma unroll
     for (int s = 0; s < SC; ++s) il[s] = ind_l[(int64_t)(s0 + min(s, ns - 1)) * ih + yc];
 
-    // element offset of the left sample inside a frame, and the distance to the right one
-    int64_t off[SC];
+    // element offsets of the left and the right sample inside a frame (32 bits: a frame is far below 4 G samples; with the frame's
+    // base address in scalar registers the loads need no address arithmetic of their own)
+    // BYTE offsets: `scalar base + 32-bit lane offset` is an addressing mode of the load (a scaled element index is not: its doubling could overflow)
+    uint32_t off[SC], offr[SC];
     const int64_t step = ROT ? width : 1;
 #pragma unroll
-    for (int s = 0; s < SC; ++s) off[s] = ROT ? (int64_t)il[s] * width + (width - 1 - yc) : yc * width + il[s];
+    for (int s = 0; s < SC; ++s) {
+        off[s] = (uint32_t)((ROT ? (int64_t)il[s] * width + (width - 1 - yc) : yc * width + il[s]) * (int64_t)sizeof(T));
+        offr[s] = off[s] + (uint32_t)(step * (int64_t)sizeof(T));
+    }
 
     __shared__ uint32_t wred[4][SC][2];
     uint32_t vlo[SC], vhi[SC];
@@ -96,11 +103,11 @@ SHG_MERGEABLE_T(SHG_TPL(template <typename T, bool ROT, int BATCH, int SC>), SHG
             const int64_t col = c0 + cc;
             const int64_t k = (flip_x ? (n_cols - 1 - col) : col) - k_offset;   // wave-uniform
             ok[i] = cc < TK && col < n_cols && k >= 0 && k < n_frames;
-            const T* f = stack + (ok[i] ? k : 0) * fstride;
+            const char* f = reinterpret_cast<const char*>(stack + (ok[i] ? k : 0) * fstride);
 #pragma unroll
             for (int s = 0; s < SC; ++s) {
-                lv[i][s] = f[off[s]];
-                rv[i][s] = f[off[s] + step];
+                lv[i][s] = *reinterpret_cast<const T*>(f + off[s]);
+                rv[i][s] = *reinterpret_cast<const T*>(f + offr[s]);
             }
         }
 #pragma unroll
@@ -113,7 +120,7 @@ SHG_MERGEABLE_T(SHG_TPL(template <typename T, bool ROT, int BATCH, int SC>), SHG
                     const double l = (double)((int)lv[i][s] * scale);
                     const double r = (double)((int)rv[i][s] * scale);
                     const double v = l * wl + r * wr;
-                    const uint32_t q = (uint32_t)(uint16_t)(int)v;
+                    const uint32_t q = (uint32_t)(int)v;     // 0 <= v < 65536: a blend of two 16-bit samples with weights in [0, 1] (no mask needed)
                     tile[s][lane][cc] = (uint16_t)q;
                     vlo[s] = q < vlo[s] ? q : vlo[s];
                     vhi[s] = q > vhi[s] ? q : vhi[s];
