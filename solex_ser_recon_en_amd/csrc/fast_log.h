@@ -15,6 +15,19 @@
 
 namespace shg {
 
+// a * b + K for a constant K.  On the device the constant sits in scalar registers and the multiply-add names three sources and a
+// separate destination: the compiler's own choice for fma(a, b, K) is the two-operand v_fmac_f64, which first copies K into the
+// destination (one v_mov_b64 per term of the polynomials below: 8 of the 36 instructions of a logarithm near 1).
+SHG_FASTLOG_FN double fma_const(double a, double b, double K) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(K));
+    return r;
+#else
+    return fma(a, b, K);
+#endif
+}
+
 // n / d for normal operands whose quotient is normal: reciprocal, two Newton steps, one correction of the quotient
 SHG_FASTLOG_FN double div_normal(double n, double d) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -49,8 +62,8 @@ SHG_FASTLOG_FN double log_normal(double x) {
     const double f = m - 1.0;
     const double s = div_normal(f, 2.0 + f);
     const double z = s * s, w = z * z;
-    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
-    const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double t1 = w * fma_const(w, fma_const(w, Lg6, Lg4), Lg2);
+    const double t2 = z * fma_const(w, fma_const(w, fma_const(w, Lg7, Lg5), Lg3), Lg1);
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
     const double dk = (double)k;
@@ -61,10 +74,13 @@ SHG_FASTLOG_FN double log_normal(double x) {
 // rounded, then the algorithm above -- with ONE reciprocal for both divisions (a / b, and f / (2 + f) inside the logarithm) where
 // the compiler's a / b and div_normal spend two reciprocals, four Newton steps and the scale / fix-up instructions of a general
 // IEEE division.
-//   * z ~ 1 / (b (a + b)) (both factors exact: below 2^33), two Newton steps; then 1 / b ~ z (a + b) and 1 / (a + b) ~ z b;
-//   * q = fl(a / b) EXACTLY: q0 = a y, r = a - b q0 (one fma: exact), q = fl(q0 + r y).  y is within a few ulp of 1 / b, so
-//     q0 + r y is within 2^-50 ulp of a / b, and a quotient of integers below 2^16 that is not a double lies at least 2^-17 ulp
-//     from every rounding boundary (|a / b - m| = |a 2^j - b (2 k + 1)| / (b 2^j) >= 1 / (b 2^j)): the rounding cannot differ;
+//   * z ~ 1 / (b (a + b)) (both factors exact: below 2^33), ONE Newton step on the hardware's reciprocal (v_rcp_f64: relative
+//     error <= 2^-23, so 2^-45 after the step); then 1 / b ~ y = z (a + b) and 1 / (a + b) ~ u = z b, both to 2^-45;
+//   * q = fl(a / b) EXACTLY: q0 = a y, r = a - b q0 (one fma; exact: the difference spans < 40 bits), q = fl(q0 + r y).
+//     q0 + r y = a / b + (r / b) e with |e| <= 2^-45 and |r / b| <= 2^-44 a / b: within 2^-36 ulp of a / b, and a quotient of
+//     integers below 2^16 that is not a double lies at least 2^-17 ulp from every rounding boundary
+//     (|a / b - m| = |a 2^j - b (2 k + 1)| / (b 2^j) >= 1 / (b 2^j)): the rounding cannot differ.  (tests/c_abi/fast_log_check.cpp
+//     runs this text with a reciprocal that is wrong by up to 2^-22 and compares q's logarithm with that of the compiler's a / b.)
 //   * sqrt(2) / 2 <= q < sqrt(2) (neighbouring rows of a sunlit disk: always, but for a handful of pixels): k = 0, f = q - 1,
 //     d = fl(2 + f), and 1 / d ~ b / (a + b) = b (z b) to a few ulp -- one Newton step and the same quotient correction give
 //     s = f / d as div_normal does.  Any other q: log_normal(q).
@@ -76,13 +92,12 @@ SHG_FASTLOG_FN double log_ratio_u16(unsigned a_px, unsigned b_px) {
     const double t = a + b, p = b * t;
 #if defined(__HIP_DEVICE_COMPILE__)
     double z = __builtin_amdgcn_rcp(p);
+#elif defined(SHG_FASTLOG_TEST_RCP)
+    double z = SHG_FASTLOG_TEST_RCP(p);                  // the host check's stand-in for the hardware's 2^-23 reciprocal
 #else
     double z = 1.0 / p;
 #endif
-    double e = fma(-p, z, 1.0);
-    z = fma(z, e, z);
-    e = fma(-p, z, 1.0);
-    z = fma(z, e, z);
+    z = fma(z, fma(-p, z, 1.0), z);
     const double u = z * b;                              // ~ 1 / (a + b)
     const double y = z * t;                              // ~ 1 / b
     const double q0 = a * y;
@@ -94,11 +109,11 @@ SHG_FASTLOG_FN double log_ratio_u16(unsigned a_px, unsigned b_px) {
     const double s0 = f * v;
     const double s = fma(fma(-d, s0, f), v, s0);
     const double zz = s * s, w = zz * zz;
-    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
-    const double t2 = zz * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double t1 = w * fma_const(w, fma_const(w, Lg6, Lg4), Lg2);
+    const double t2 = zz * fma_const(w, fma_const(w, fma_const(w, Lg7, Lg5), Lg3), Lg1);
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
-    return -((hfsq - s * (hfsq + R)) - f);               // (log_normal's last line with k = 0)
+    return f - (hfsq - s * (hfsq + R));                  // (log_normal's last line with k = 0: -(x - f) = f - x to the bit)
 }
 
 }  // namespace shg

@@ -4,6 +4,16 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+// log_ratio_u16's reciprocal here: the exact one made wrong by up to 2^-22 (the device's v_rcp_f64 is good to 2^-23), the error's
+// sign and size varying with the operand -- the exactness of the quotient inside must not depend on the reciprocal's last 30 bits
+static inline double coarse_rcp(double p) {
+    uint64_t b;
+    memcpy(&b, &p, 8);
+    b = (b ^ (b >> 29)) * 0x9e3779b97f4a7c15ull;
+    const double k = (double)(int64_t)(b >> 11) / 9007199254740992.0 * 2.0 - 1.0;      // in [-1, 1)
+    return (1.0 / p) * (1.0 + k * 2.384185791015625e-07);
+}
+#define SHG_FASTLOG_TEST_RCP(p) coarse_rcp(p)
 #include "fast_log.h"
 
 static double ulp_err(double got, long double want) {
