@@ -739,7 +739,11 @@ SHG_MERGEABLE_T(SHG_TPL(template <int PX, bool COUNT>), SHG_TPL(<PX, COUNT>), k_
         ty1 = max(ty1, 0);
         ty2 = min(ty2, tiles - 1);
         uint32_t px[PX];
-        if (PX == 4 && n == 4) {
+        if (PX == 8 && n == 8) {
+            const uint4 q = *reinterpret_cast<const uint4*>(img + y * pitch + x0);
+            px[0] = q.x & 0xffffu; px[1 % PX] = q.x >> 16; px[2 % PX] = q.y & 0xffffu; px[3 % PX] = q.y >> 16;
+            px[4 % PX] = q.z & 0xffffu; px[5 % PX] = q.z >> 16; px[6 % PX] = q.w & 0xffffu; px[7 % PX] = q.w >> 16;
+        } else if (PX == 4 && n == 4) {
             const uint2 q = *reinterpret_cast<const uint2*>(img + y * pitch + x0);
             px[0] = q.x & 0xffffu; px[1 % PX] = q.x >> 16; px[2 % PX] = q.y & 0xffffu; px[3 % PX] = q.y >> 16;
         } else {
@@ -775,7 +779,10 @@ SHG_MERGEABLE_T(SHG_TPL(template <int PX, bool COUNT>), SHG_TPL(<PX, COUNT>), k_
             const int r = __float2int_rn(res);
             out[j] = (uint32_t)(r < 0 ? 0 : (r > HIST - 1 ? HIST - 1 : r));
         }
-        if (PX == 4 && n == 4) {
+        if (PX == 8 && n == 8) {
+            *reinterpret_cast<uint4*>(dst + y * dst_pitch + x0) = make_uint4(out[0] | (out[1 % PX] << 16), out[2 % PX] | (out[3 % PX] << 16),
+                                                                             out[4 % PX] | (out[5 % PX] << 16), out[6 % PX] | (out[7 % PX] << 16));
+        } else if (PX == 4 && n == 4) {
             *reinterpret_cast<uint2*>(dst + y * dst_pitch + x0) = make_uint2(out[0] | (out[1 % PX] << 16), out[2 % PX] | (out[3 % PX] << 16));
         } else {
 #pragma unroll
@@ -1168,11 +1175,18 @@ inline int launch_interp16(const Disks& d, int64_t h, int64_t w, int64_t pitch, 
         if (tiled_ok) {
             // 4 lanes x 16 rows per wave, 4 waves across: 64 pixels x 16 rows a round (measured over 21 disks: 243 us; 2 waves
             // across 242, one 270; 2 lanes x 32 rows 262-384; 8 lanes x 8 rows 246-253; the flat sequence 300)
-            const int lw = 2, wx = 2;
-            const int64_t wg_px = (int64_t)4 << (lw + wx), wg_rows = (int64_t)(64 >> lw) * (4 >> wx);
+            // Eight pixels a lane (16-byte loads and stores) from four disks up: 222 us against 243 over 21 disks -- and 17.5 against 13.7 us
+            // on one, where the launch is too small to fill the device.  (SHG_INTERP_SHAPE = lw | wx << 4 | (8 px) << 8: tools' sweeps;
+            // halving the kernel's L2 requests this way does not change what it costs a pass A beside it, profiles/r04_sweeps.txt.)
+            static const int shape = [] { const char* v = getenv("SHG_INTERP_SHAPE"); return v ? atoi(v) : 0; }();
+            const int lw = shape ? (shape & 15) : 2, wx = shape ? ((shape >> 4) & 15) : 2;
+            const bool px8 = (shape ? ((shape >> 8) & 1) != 0 : nz >= 4) && d.aligned(15) && pitch % 8 == 0 && dst_pitch % 8 == 0;
+            const int pxn = px8 ? 8 : 4;
+            const int64_t wg_px = (int64_t)pxn << (lw + wx), wg_rows = (int64_t)(64 >> lw) * (4 >> wx);
             const uint32_t tx = (uint32_t)((w + wg_px - 1) / wg_px), ty = (uint32_t)((h + wg_rows * rows - 1) / (wg_rows * rows));
             a.tiled = 0x10000 | lw | (wx << 8);
             a.tiles_x = tx;
+            if (px8) return SHG_LAUNCH_T(k_clahe_interp_vm, SHG_TPL(<8, true>), dim3(tx * ty, 1u, nz), dim3(256), 0, st, a);
             return SHG_LAUNCH_T(k_clahe_interp_vm, SHG_TPL(<4, true>), dim3(tx * ty, 1u, nz), dim3(256), 0, st, a);
         }
         return SHG_LAUNCH_T(k_clahe_interp_vm, SHG_TPL(<4, true>), dim3(blocks(4, rows), 1u, nz), dim3(256), 0, st, a);

@@ -63,6 +63,12 @@ _a16 = torch.zeros(8 << 20, dtype=torch.int16, device=dev)
 _b16 = torch.ones(8 << 20, dtype=torch.int16, device=dev)
 _a1g = torch.zeros(256 << 20, dtype=torch.int16, device=dev)
 _b1g = torch.ones(256 << 20, dtype=torch.int16, device=dev)
+_m64 = torch.rand(1024, 1024, dtype=torch.float64, device=dev)
+_m64o = torch.empty_like(_m64)
+_m32 = torch.rand(2048, 2048, dtype=torch.float32, device=dev)
+_m32o = torch.empty_like(_m32)
+_v32 = torch.rand(1 << 20, dtype=torch.float32, device=dev)
+_v32o = torch.empty_like(_v32)
 workloads.update({
     'torch: copy 16 MB -> 16 MB': lambda: _a16.copy_(_b16),
     'torch: fill 16 MB': lambda: _a16.fill_(3),
@@ -70,6 +76,10 @@ workloads.update({
     'torch: copy 512 MB -> 512 MB': lambda: _a1g.copy_(_b1g),
     'torch: fill 512 MB': lambda: _a1g.fill_(3),
     'torch: sum of 512 MB': lambda: _b1g.sum(),
+    # compute-bound co-runners whose operands stay in L2: is it memory traffic at all?
+    'torch: fp64 matmul 1024^3': lambda: torch.mm(_m64, _m64, out=_m64o),
+    'torch: fp32 matmul 2048^3': lambda: torch.mm(_m32, _m32, out=_m32o),
+    'torch: sin of 1 M floats': lambda: torch.sin(_v32, out=_v32o),
 })
 if os.environ.get('SHG_INTERFERENCE_ONLY'):
     keep = os.environ['SHG_INTERFERENCE_ONLY'].split(',')
