@@ -30,7 +30,7 @@ struct Plan {
 // Launch-shape overrides for the tuning sweeps in tools/ (SHG_ACC_*).  Read once per process: the plan is made on every
 // launch and must not go through getenv each time.
 struct Tuning {
-    int inflight_kib, nsplit, unroll, xcd, nt, lds_kib, prio;
+    int inflight_kib, nsplit, unroll, xcd, nt, lds_kib, prio, interleave;
 };
 
 const Tuning& tuning() {
@@ -40,7 +40,8 @@ const Tuning& tuning() {
             return (s && *s) ? atoi(s) : dflt;
         };
         return Tuning{env_int("SHG_ACC_INFLIGHT_KIB", 7168), env_int("SHG_ACC_NSPLIT", 0), env_int("SHG_ACC_UNROLL", 0),
-                      env_int("SHG_ACC_XCD", 0), env_int("SHG_ACC_NT", 1), env_int("SHG_ACC_LDS_KIB", 0), env_int("SHG_ACC_PRIO", 1)};
+                      env_int("SHG_ACC_XCD", 0), env_int("SHG_ACC_NT", 1), env_int("SHG_ACC_LDS_KIB", 0), env_int("SHG_ACC_PRIO", 1),
+                      env_int("SHG_ACC_INTERLEAVE", 0)};
     }();
     return t;
 }
@@ -181,7 +182,7 @@ template <int BPP, int UNROLL, bool NT>
 __global__ __launch_bounds__(256) void k_accumulate_vec(const u32x4* __restrict__ stack, int64_t vecs, int64_t fstride,
                                                         int n_frames, int frames_per_split,
                                                         uint32_t* __restrict__ psum, uint16_t* __restrict__ pmax,
-                                                        int64_t npix, int nsplit, int xcd_per_split, int prio) {
+                                                        int64_t npix, int nsplit, int xcd_per_split, int prio, int interleave) {
     // Column block and frame split of this workgroup.  Plain mapping: (blockIdx.x, blockIdx.y).  XCD-aware mapping
     // (1-D grid): workgroups b and b + 8 share an XCD under round-robin dispatch, so giving the XCDs with
     // (b % 8) / xcd_per_split == s split s keeps every XCD on one frame range (tried for TLB / DRAM-page locality).
@@ -197,23 +198,27 @@ __global__ __launch_bounds__(256) void k_accumulate_vec(const u32x4* __restrict_
     if (v >= vecs) return;
     // this kernel's waves ahead of the other scans' at the CU's issue arbiter (SHG_ACC_PRIO=0: not; measured 0.379-0.381 against 0.387-0.390 ms per step)
     if (prio > 0) __builtin_amdgcn_s_setprio(3);
-    const int k0 = split * frames_per_split;
-    const int k1 = min(n_frames, k0 + frames_per_split);
+    // A split is a range of consecutive frames -- or (interleave, a tuning experiment) every nsplit-th frame: then all workgroups read
+    // the same few frames at any moment however many splits there are, instead of nsplit regions of the stack far apart.
+    const int kstep = interleave ? nsplit : 1;
+    const int k0 = interleave ? split : split * frames_per_split;
+    const int k1 = interleave ? n_frames : min(n_frames, k0 + frames_per_split);
+    const int64_t fs = fstride * kstep;
     Acc<BPP> acc;
     acc.init();
     const u32x4* p = stack + (int64_t)k0 * fstride + v;
     int k = k0;
-    for (; k + UNROLL <= k1; k += UNROLL) {
+    for (; k + (UNROLL - 1) * kstep < k1; k += UNROLL * kstep) {
         u32x4 r[UNROLL];
 #pragma unroll
-        for (int j = 0; j < UNROLL; ++j) r[j] = NT ? __builtin_nontemporal_load(p + (int64_t)j * fstride) : p[(int64_t)j * fstride];
-        p += (int64_t)UNROLL * fstride;
+        for (int j = 0; j < UNROLL; ++j) r[j] = NT ? __builtin_nontemporal_load(p + (int64_t)j * fs) : p[(int64_t)j * fs];
+        p += (int64_t)UNROLL * fs;
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) acc.add(r[j]);
     }
-    for (; k < k1; ++k) {
+    for (; k < k1; k += kstep) {
         acc.add(NT ? __builtin_nontemporal_load(p) : *p);
-        p += fstride;
+        p += fs;
     }
     const int64_t pix = v * Acc<BPP>::PX;
     acc.store(psum + (int64_t)split * npix + pix, pmax + (int64_t)split * npix + pix);
@@ -365,7 +370,7 @@ void launch_vec(const Plan& p, const void* stack, int n, uint32_t* psum, uint16_
     const size_t pad_lds = (size_t)std::min(std::max(tuning().lds_kib, 0), 160) * 1024;
 #define SHG_ACC_LAUNCH(U) { SHG_PROF("accumulate", st);                                                                                    \
         if (pad_lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_accumulate_vec<BPP, U, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds); \
-        k_accumulate_vec<BPP, U, NT><<<grid, 256, pad_lds, st>>>(s, p.vecs, p.stride_vecs, n, p.frames_per_split, psum, pmax, p.npix, p.nsplit, xcd_per, tuning().prio); }
+        k_accumulate_vec<BPP, U, NT><<<grid, 256, pad_lds, st>>>(s, p.vecs, p.stride_vecs, n, p.frames_per_split, psum, pmax, p.npix, p.nsplit, xcd_per, tuning().prio, tuning().interleave); }
     switch (p.unroll) {
         case 2: SHG_ACC_LAUNCH(2) break;
         case 4: SHG_ACC_LAUNCH(4) break;
