@@ -1178,7 +1178,8 @@ inline int launch_interp16(const Disks& d, int64_t h, int64_t w, int64_t pitch, 
             // Eight pixels a lane (16-byte loads and stores) from four disks up: 222 us against 243 over 21 disks -- and 17.5 against 13.7 us
             // on one, where the launch is too small to fill the device.  (SHG_INTERP_SHAPE = lw | wx << 4 | (8 px) << 8: tools' sweeps;
             // halving the kernel's L2 requests this way does not change what it costs a pass A beside it, profiles/r04_sweeps.txt.)
-            static const int shape = [] { const char* v = getenv("SHG_INTERP_SHAPE"); return v ? atoi(v) : 0; }();
+            const char* shape_env = getenv("SHG_INTERP_SHAPE");      // (read per call: a test compares the two lane widths in one process)
+            const int shape = shape_env ? atoi(shape_env) : 0;
             const int lw = shape ? (shape & 15) : 2, wx = shape ? ((shape >> 4) & 15) : 2;
             const bool px8 = (shape ? ((shape >> 8) & 1) != 0 : nz >= 4) && d.aligned(15) && pitch % 8 == 0 && dst_pitch % 8 == 0;
             const int pxn = px8 ? 8 : 4;

@@ -1007,6 +1007,43 @@ def test_fused_limb_kernels_equal_the_separate_ones(ops, h, w, seed):
         assert len(want_idx) > 0
 
 
+@pytest.mark.parametrize('shape', [(200, 304), (202, 310), (64, 2096)])
+def test_blend_with_eight_pixel_lanes_equals_four_pixel_lanes(shape, monkeypatch):
+    """From four disks up the CLAHE blend (k_clahe_interp_vm, clahe_apply.py:243-256's interpolation) gives a lane eight pixels --
+    16-byte loads and stores -- instead of four.  Same products bit for bit as with four-pixel lanes (SHG_INTERP_SHAPE=34: the
+    single-disk shape), on a width that is a multiple of eight, one that is not (a row's last vector goes pixel by pixel), and a
+    full-width one."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from solex_ser_recon_en_amd import stages
+    h, w = shape
+    k = 5
+    rng = np.random.default_rng(h * 7 + w)
+    yy, xx = np.mgrid[0:h, 0:w]
+    pitch = (w + 63) // 64 * 64
+    store = torch.zeros((k, h, pitch), dtype=torch.uint16, device='cuda')
+    views = []
+    for i in range(k):
+        r = np.hypot((yy - h / 2) / (0.45 * h), (xx - w / 2) / (0.45 * w))
+        img = np.where(r < 1, 50000.0 * (0.4 + 0.6 * np.sqrt(np.clip(1 - r * r, 0, 1))), 800.0 + 40 * i)
+        img = np.clip(img + rng.normal(0, 400, img.shape), 1, 65535).astype(np.uint16)
+        store[i, :, :w] = torch.from_numpy(img.view(np.int16)).cuda().view(torch.uint16)
+        views.append(store[i, :, :w])
+
+    def run(shape_env):
+        if shape_env is None:
+            monkeypatch.delenv('SHG_INTERP_SHAPE', raising=False)
+        else:
+            monkeypatch.setenv('SHG_INTERP_SHAPE', shape_env)
+        res = stages.process_frames(views, None, None, (w // 2, h // 2, int(0.3 * h)))
+        torch.cuda.synchronize()
+        return {name: [np.asarray(t.cpu().view(torch.int16).numpy()).view(np.uint16).copy() for t in res[name]] for name in ('cl1', 'hc', 'protus', 'cc')}
+    wide, narrow = run(None), run('34')
+    for name in wide:
+        for x, y in zip(wide[name], narrow[name]):
+            np.testing.assert_array_equal(x, y, err_msg=name)
+
+
 @pytest.mark.parametrize('shape,crop,trans,k', [((200, 304), None, True, 1), ((200, 304), (256, 24, 0, 256), True, 3),
                                                 ((202, 310), (400, 0, 45, 310), True, 2), ((200, 304), None, False, 2),
                                                 ((198, 306), (198, 54, 0, 198), False, 1), ((2000, 2096), None, True, 2),
