@@ -75,7 +75,7 @@ SHG_FASTLOG_FN double log_normal(double x) {
 // the compiler's a / b and div_normal spend two reciprocals, four Newton steps and the scale / fix-up instructions of a general
 // IEEE division.
 //   * z ~ 1 / (b (a + b)) (both factors exact: below 2^33), ONE Newton step on the hardware's reciprocal (v_rcp_f64: relative
-//     error <= 2^-23, so 2^-45 after the step); then 1 / b ~ y = z (a + b) and 1 / (a + b) ~ u = z b, both to 2^-45;
+//     error <= 2^-23 by its description, 2^-24.4 measured on gfx950 -- tools/probes/rcp_f64_error.hip -- so 2^-45 after the step); then 1 / b ~ y = z (a + b) and 1 / (a + b) ~ u = z b, both to 2^-45;
 //   * q = fl(a / b) EXACTLY: q0 = a y, r = a - b q0 (one fma; exact: the difference spans < 40 bits), q = fl(q0 + r y).
 //     q0 + r y = a / b + (r / b) e with |e| <= 2^-45 and |r / b| <= 2^-44 a / b: within 2^-36 ulp of a / b, and a quotient of
 //     integers below 2^16 that is not a double lies at least 2^-17 ulp from every rounding boundary
