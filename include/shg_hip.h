@@ -19,8 +19,7 @@
  *    (shg_frame_pass_lane_set: one stream handle per device, set once) and a pair of events per (thread, device) that
  *    uses it; (3) the registry of passes launched ahead of their scans (shg_pass_a_prelaunch: workspace address ->
  *    launch plan + event, an entry lives from the prelaunch to the scan's first stage or shg_pass_a_forget); (4) every
- *    shg_pool: its threads, its queue and job map, and -- unless SHG_COMBINE=0 -- its launch combiner (two streams,
- *    an event per thread, the launches recorded since the threads last waited; csrc/launch.h); (5) function-local
+ *    shg_pool: its threads, its queue and job map; (5) function-local
  *    one-time settings of kernel attributes (dynamic LDS sizes) and cached environment knobs (SHG_*); (6) the BLAS /
  *    LAPACK entry points and callbacks the host control plane was given (shg_host_set_*);
  *  - return value: 0 = OK, >0 = hipError_t, <0 = SHG_E_* argument error; the
@@ -40,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SHG_ABI_VERSION 14
+#define SHG_ABI_VERSION 15
 
 #define SHG_E_ARG        (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SHG_E_WORKSPACE  (-2)   /* workspace too small                                 */
@@ -600,11 +599,6 @@ int shg_pass_a_forget(const void* workspace);
 int shg_pool_poll(shg_pool* pool, int64_t ticket);
 int shg_pool_wait(shg_pool* pool, int64_t ticket, int* scan_status, char* error_buf, size_t error_cap);
 int shg_pool_destroy(shg_pool* pool);
-/* A pool with more than one worker merges launches: its scans are independent and each is a chain of ~26 small kernels, so
- * the SAME kernel of the scans in flight is sent to the device as ONE dispatch whenever every busy worker waits for the device
- * anyway (csrc/launch.h, csrc/combine.hip; results are those of separate launches bit for bit; SHG_COMBINE=0 turns it off).
- * out3 = kernel launches the scans have recorded so far, dispatches made for them, flushes. */
-int shg_pool_combiner_stats(shg_pool* pool, uint64_t* out3);
 
 /* ==== streams of a scan worker pool ==============================================================
  * The reference post-processes up to four files at once (Pool(4), Solex_recon.py:30-42).  Scans in flight share one

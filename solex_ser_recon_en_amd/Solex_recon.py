@@ -350,13 +350,14 @@ def _worker_context(device, k):
 
 def _sharded_series(tasks, decoder, collected):
     """Several scans, each sharded over the ranks: this thread reads them one after the other (decode, pass A, all-reduce,
-    extraction, all-reduce of the mosaic -- every collective here, in file order, on every rank), and what has no collective
-    in it, rank 0's post-processing of a finished mosaic, runs behind on a second thread with a stream of its own.  So while
-    rank 0 fits the limb and contrasts scan k, all ranks are already decoding and reducing scan k + 1 (before: every rank but
-    the first idled through rank 0's tail, Solex_recon.py:33-42 has no counterpart -- the reference never shards a scan).
-    A Doppler stack (several requested disks) deals its disks to all ranks and agrees on the limb fit: collectives inside
-    solex_process, so such a scan is post-processed here, in line.  Before every scan the ranks ask each other whether anyone
-    has failed (dist.any_failed): a failure stops all of them together."""
+    extraction, reduction of the mosaic -- every collective here, in file order, on every rank), and what has no collective
+    in it, the post-processing of a finished mosaic, runs behind on a second thread with a stream of its own ON THE SCAN'S OWNER:
+    scan k belongs to rank k mod G (dist.scan_owner), the mosaic is reduced to that rank only, and it alone writes the scan's
+    files and log.  So while one rank fits the limb and contrasts scan k, all ranks are already decoding and reducing scan k + 1,
+    whose tail then runs on the next rank: G tails at once, the reference's Pool over files (Solex_recon.py:26-44) spread over
+    the GPUs.  A Doppler stack (several requested disks) deals its disks to all ranks and agrees on the limb fit: collectives
+    inside solex_process, so such a scan is all-reduced and post-processed here, in line.  Before every scan the ranks ask each
+    other whether anyone has failed (dist.any_failed): a failure stops all of them together."""
     import torch
     device = decoder.device
     post = _Service.named('shg-post-%s' % device)
@@ -399,17 +400,19 @@ def _sharded_series(tasks, decoder, collected):
             try:
                 print('file %s is processing' % file)
                 options['_shard_frames'] = True
+                n_requested = len(set(options['shift']))
+                if n_requested == 1:
+                    options['_owner'] = options['_mosaic_to'] = dist.scan_owner(i)
                 rdr = decoder.get(i)
                 _check_shardable(rdr)
                 disk_list, bounds, hdr = solex_read(rdr, options)
                 _release_stack(rdr)
-                n_requested = sum(1 for s in options['shift'] if s in options['shift_requested'])
                 if n_requested > 1:
                     options['_deal_disks'] = True           # every rank post-processes its share: collectives inside
                     res = solex_process(options, disk_list, bounds, hdr)
                     if collected is not None:
                         collected[i] = res
-                elif dist.rank() == 0:
+                elif dist.rank() == options['_owner']:
                     slots.acquire()
                     ready = torch.cuda.Event()
                     ready.record(torch.cuda.current_stream(device))
@@ -455,19 +458,6 @@ def _native_pool(device, n_workers):
             check(lib.shg_pool_create(arr, n_workers, carr, len(cpus), ctypes.byref(out)), 'shg_pool_create')
         pool = _native_pools[key] = out
     return pool
-
-
-def combiner_stats():
-    """What the launch combiners of this process's native pools have done so far (csrc/launch.h): kernel launches the scans
-    recorded, dispatches made for them, flushes -- summed over the pools."""
-    import ctypes
-    from ._lib import check, lib
-    total = [0, 0, 0]
-    for pool in _native_pools.values():
-        out = (ctypes.c_uint64 * 3)()
-        check(lib.shg_pool_combiner_stats(pool, out), 'shg_pool_combiner_stats')
-        total = [a + int(b) for a, b in zip(total, out)]
-    return {'launches_recorded': total[0], 'dispatches': total[1], 'flushes': total[2]}
 
 
 def _scan_batch_native(tasks, decoder, n_workers, scan_here, collected):
@@ -731,7 +721,8 @@ class _OneCall:
 
 
 def _writes_files(options):
-    return not (options.get('_shard_frames') and dist.rank() != 0)
+    """Of a frame-sharded scan only its owner writes (rank 0; in a series of sharded scans rank k mod G for scan k)."""
+    return not (options.get('_shard_frames') and dist.rank() != options.get('_owner', 0))
 
 
 def solex_read(file, options):
@@ -755,7 +746,8 @@ def solex_read(file, options):
     with timing.stage('mean_max+line_fit'):
         mean_img, fit, backup_y1, backup_y2 = compute_mean_return_fit(rdr, wopts, hdr, iw, ih, basefich0)
     with timing.stage('extract'):
-        disks, extrema = extract_disks(rdr, fit, options['shift'], flip_x=bool(options['flip_x']), want_minmax=True)     # flip fused (:74-76)
+        disks, extrema = extract_disks(rdr, fit, options['shift'], flip_x=bool(options['flip_x']), want_minmax=True,     # flip fused (:74-76)
+                                       owner=options.get('_mosaic_to'))
     hdr['NAXIS1'] = iw          # as the reference (:65); the FITS writer takes NAXIS* from the data anyway
 
     disk_list = [DeviceImage(disks[i], minmax=None if extrema is None else extrema[i]) for i in range(disks.shape[0])]

@@ -168,7 +168,6 @@ SIGNATURES = {
     'shg_pool_poll': (c_int, [P, c_int64]),
     'shg_pool_wait': (c_int, [P, c_int64, ctypes.POINTER(c_int), ctypes.c_char_p, c_size_t]),
     'shg_pool_destroy': (c_int, [P]),
-    'shg_pool_combiner_stats': (c_int, [P, P]),
     'shg_device_cu_count': (c_int, [ctypes.POINTER(c_int)]),
     'shg_stream_create': (c_int, [c_int, P, c_int, ctypes.POINTER(c_void_p)]),
     'shg_stream_destroy': (c_int, [P]),
@@ -202,7 +201,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 if lib.shg_abi_version() != ABI_VERSION:
     raise ImportError('libshg_hip.so ABI %d != expected %d: rebuild it' % (lib.shg_abi_version(), ABI_VERSION))
 

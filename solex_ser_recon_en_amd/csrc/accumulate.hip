@@ -294,7 +294,7 @@ struct FinalizeArgs {
     uint16_t *mean_out, *max_out;
 };
 
-SHG_MERGEABLE_T(SHG_TPL(template <typename Src>), SHG_TPL(<Src>), k_finalize, FinalizeArgs<Src>, __launch_bounds__(256)) {
+template <typename Src> __global__ __launch_bounds__(256) void k_finalize(const FinalizeArgs<Src> kargs) {
     const Src in = kargs.in;
     const uint64_t n_total = kargs.n_total;
     const int64_t height = kargs.height, width = kargs.width;
@@ -321,7 +321,7 @@ SHG_MERGEABLE_T(SHG_TPL(template <typename Src>), SHG_TPL(<Src>), k_finalize, Fi
 // The rotated case through a 32 x 32 LDS tile: the plain kernel reads `sum` along file columns (one 8-byte value per 16 KB
 // of addresses: 15.6 MB fetched for a 4 MB input at C2, PMC round 1).  Here a workgroup reads 32 file rows x 32 file
 // columns row-wise (256-byte runs) and writes 32 output rows x 32 output columns row-wise.
-SHG_MERGEABLE_T(SHG_TPL(template <typename Src>), SHG_TPL(<Src>), k_finalize_rot, FinalizeArgs<Src>, __launch_bounds__(256)) {
+template <typename Src> __global__ __launch_bounds__(256) void k_finalize_rot(const FinalizeArgs<Src> kargs) {
     const Src in = kargs.in;
     const uint64_t n_total = kargs.n_total;
     const int64_t height = kargs.height, width = kargs.width;
@@ -437,9 +437,9 @@ int launch_finalize(Src in, int64_t n_total, int64_t height, int64_t width, int 
     const FinalizeArgs<Src> fa{in, (uint64_t)n_total, height, width, scale, mean_out, max_out};
     if (width > height) {
         dim3 grid((unsigned)((width + 31) / 32), (unsigned)((height + 31) / 32));
-        return SHG_LAUNCH_T(k_finalize_rot, <Src>, grid, dim3(256), 0, st, fa);
+        return shg::launch(k_finalize_rot<Src>, grid, dim3(256), 0, st, fa, "k_finalize_rot");
     }
-    return SHG_LAUNCH_T(k_finalize, <Src>, dim3((unsigned)((height * width + 255) / 256)), dim3(256), 0, st, fa);
+    return shg::launch(k_finalize<Src>, dim3((unsigned)((height * width + 255) / 256)), dim3(256), 0, st, fa, "k_finalize");
 }
 }  // namespace
 
@@ -452,7 +452,6 @@ extern "C" int shg_accumulate_sum_max(const void* stack, int64_t n_frames, int64
     uint16_t* pmax;
     if (int e = accumulate_partials(stack, n_frames, height, width, bytes_per_px, frame_stride_px, workspace, workspace_bytes, stream, &p, &psum, &pmax)) return e;
     hipStream_t st = shg::as_stream(stream);
-    SHG_DIRECT(st);
     { SHG_PROF("reduce_partials", st); k_reduce_partials<<<(unsigned)((p.npix + 255) / 256), 256, 0, st>>>(psum, pmax, p.nsplit, p.npix, sum_out, max_out); }
     return shg::check_launch("k_reduce_partials");
 }
@@ -505,9 +504,7 @@ bool take_ahead(PassA* want, bool* same, int* status) {
     hipError_t e;
     {
         SHG_HOST_TIME("lane wait (queue + pass A)");
-        shg::pool_wait_begin();                              // (a pool thread: the other scans' recorded launches need not wait for this one)
         e = hipEventSynchronize(got.done);
-        shg::pool_wait_end();
     }
     (void)hipEventDestroy(got.done);
     *status = 0;

@@ -122,7 +122,7 @@ struct HistSlicesArgs {
     FusedSrc fs;
 };
 
-SHG_MERGEABLE_T(SHG_TPL(template <bool FUSED>), SHG_TPL(<FUSED>), k_tile_hist16_slices, HistSlicesArgs, __launch_bounds__(1024)) {
+template <bool FUSED> __global__ __launch_bounds__(1024) void k_tile_hist16_slices(const HistSlicesArgs kargs) {
     const shg::PtrBatch& imgs = kargs.imgs;
     const int64_t h = kargs.h, w = kargs.w, pitch = kargs.pitch, th = kargs.th, tw = kargs.tw;
     const int tiles = kargs.tiles, slice_rows = kargs.slice_rows, vec = kargs.vec;
@@ -259,7 +259,7 @@ struct HistReduceArgs {
     int sel_words;
 };
 
-SHG_MERGEABLE(k_hist_reduce, HistReduceArgs, __launch_bounds__(1024)) {
+__global__ __launch_bounds__(1024) void k_hist_reduce(const HistReduceArgs kargs) {
     const uint32_t* __restrict__ part = kargs.part;
     const int slices = kargs.slices, clip = kargs.clip, sel_words = kargs.sel_words;
     uint32_t* __restrict__ hist = kargs.hist;
@@ -370,7 +370,7 @@ struct LutBlocksArgs {
     int ranks_zstride;
 };
 
-SHG_MERGEABLE(k_tile_lut16_blocks, LutBlocksArgs, __launch_bounds__(1024)) {
+__global__ __launch_bounds__(1024) void k_tile_lut16_blocks(const LutBlocksArgs kargs) {
     const uint32_t* __restrict__ hist = kargs.hist;
     const int32_t* __restrict__ se = kargs.se;
     const int clip = kargs.clip;
@@ -681,7 +681,7 @@ struct InterpVmArgs {
     uint32_t tiles_x;
 };
 
-SHG_MERGEABLE_T(SHG_TPL(template <int PX, bool COUNT>), SHG_TPL(<PX, COUNT>), k_clahe_interp_vm, InterpVmArgs, __launch_bounds__(256)) {
+template <int PX, bool COUNT> __global__ __launch_bounds__(256) void k_clahe_interp_vm(const InterpVmArgs kargs) {
     const shg::PtrBatch& imgs = kargs.imgs;
     const shg::PtrBatch& dsts = kargs.dsts;
     const int64_t h = kargs.h, w = kargs.w, pitch = kargs.pitch, dst_pitch = kargs.dst_pitch;
@@ -898,7 +898,7 @@ struct SelectPassArgs {
     size_t zs;
 };
 
-SHG_MERGEABLE(k_select16_pass, SelectPassArgs, __launch_bounds__(1024)) {
+__global__ __launch_bounds__(1024) void k_select16_pass(const SelectPassArgs kargs) {
     const shg::PtrBatch& imgs = kargs.imgs;
     const int64_t h = kargs.h, w = kargs.w, pitch = kargs.pitch;
     const int pass = kargs.pass, n_ranks = kargs.n_ranks, vec_ok = kargs.vec_ok;
@@ -1041,7 +1041,7 @@ struct SelectFinalArgs {
     int out_zstride;
 };
 
-SHG_MERGEABLE(k_select16_final, SelectFinalArgs, __launch_bounds__(256)) {
+__global__ __launch_bounds__(256) void k_select16_final(const SelectFinalArgs kargs) {
     const Ranks8& ranks = kargs.ranks;
     const uint32_t* __restrict__ hist = kargs.hist;
     double* __restrict__ out = kargs.out;
@@ -1079,7 +1079,7 @@ struct HistRanksArgs {
     int out_zstride;
 };
 
-SHG_MERGEABLE(k_hist_ranks, HistRanksArgs, __launch_bounds__(1024)) {
+__global__ __launch_bounds__(1024) void k_hist_ranks(const HistRanksArgs kargs) {
     const uint32_t* __restrict__ hist = kargs.hist;
     const uint32_t* __restrict__ chunk_sums = kargs.chunk_sums;
     const int chunk_sets = kargs.chunk_sets, ntiles = kargs.ntiles, out_zstride = kargs.out_zstride;
@@ -1096,10 +1096,7 @@ void ensure_lds_attr() {
     static const bool done = [] {                        // (a function-local static: once, also with several pool threads here)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16_slices<false>), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16_slices_multi<false>), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16_slices<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  HIST16 * 2 + kFusedMaxSliceRows * 8);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16_slices_multi<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   HIST16 * 2 + kFusedMaxSliceRows * 8);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_image_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_lut16_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1154,7 +1151,6 @@ inline int launch_interp16(const Disks& d, int64_t h, int64_t w, int64_t pitch, 
     *counted = false;
     const unsigned nz = (unsigned)d.n;
     if (!value_major) {                                  // (single image only: the caller checked)
-        SHG_DIRECT(st);
         k_clahe_interp<uint16_t, HIST16><<<dim3((unsigned)((w + 255) / 256), (unsigned)h), 256, 0, st>>>(
             static_cast<const uint16_t*>(d.src.p[0]), h, w, pitch, tiles, inv_tw, inv_th, lut, static_cast<uint16_t*>(const_cast<void*>(d.dst.p[0])), dst_pitch);
         return shg::check_launch("k_clahe_interp");
@@ -1187,13 +1183,13 @@ inline int launch_interp16(const Disks& d, int64_t h, int64_t w, int64_t pitch, 
             const uint32_t tx = (uint32_t)((w + wg_px - 1) / wg_px), ty = (uint32_t)((h + wg_rows * rows - 1) / (wg_rows * rows));
             a.tiled = 0x10000 | lw | (wx << 8);
             a.tiles_x = tx;
-            if (px8) return SHG_LAUNCH_T(k_clahe_interp_vm, SHG_TPL(<8, true>), dim3(tx * ty, 1u, nz), dim3(256), 0, st, a);
-            return SHG_LAUNCH_T(k_clahe_interp_vm, SHG_TPL(<4, true>), dim3(tx * ty, 1u, nz), dim3(256), 0, st, a);
+            if (px8) return shg::launch(k_clahe_interp_vm<8, true>, dim3(tx * ty, 1u, nz), dim3(256), 0, st, a, "k_clahe_interp_vm");
+            return shg::launch(k_clahe_interp_vm<4, true>, dim3(tx * ty, 1u, nz), dim3(256), 0, st, a, "k_clahe_interp_vm");
         }
-        return SHG_LAUNCH_T(k_clahe_interp_vm, SHG_TPL(<4, true>), dim3(blocks(4, rows), 1u, nz), dim3(256), 0, st, a);
+        return shg::launch(k_clahe_interp_vm<4, true>, dim3(blocks(4, rows), 1u, nz), dim3(256), 0, st, a, "k_clahe_interp_vm");
     }
-    if (vec) return SHG_LAUNCH_T(k_clahe_interp_vm, SHG_TPL(<4, false>), dim3(blocks(4, 1), 1u, nz), dim3(256), 0, st, a);
-    return SHG_LAUNCH_T(k_clahe_interp_vm, SHG_TPL(<1, false>), dim3(blocks(1, 1), 1u, nz), dim3(256), 0, st, a);
+    if (vec) return shg::launch(k_clahe_interp_vm<4, false>, dim3(blocks(4, 1), 1u, nz), dim3(256), 0, st, a, "k_clahe_interp_vm");
+    return shg::launch(k_clahe_interp_vm<1, false>, dim3(blocks(1, 1), 1u, nz), dim3(256), 0, st, a, "k_clahe_interp_vm");
 }
 
 // tile geometry as OpenCV pads it (copyMakeBorder(0, t - h%t, 0, t - w%t, REFLECT_101), clahe.cpp)
@@ -1300,17 +1296,17 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
               uintptr_t bits = 0;
               for (int i = 0; i < dset.n; ++i) bits |= reinterpret_cast<uintptr_t>(dset.from.raw.p[i]);
               vec = vec && (bits & 15) == 0 && dset.from.raw_pitch % 8 == 0 && dset.from.sx0 == 0 && dset.from.dx0 == 0 && dset.from.ncopy == w;
-              if (int e = SHG_LAUNCH_T(k_tile_hist16_slices, <true>, dim3((unsigned)slices, (unsigned)ntiles, nz), dim3(1024), HIST16 * 2 + (size_t)slice_rows * 8, st,
-                                       HistSlicesArgs{dset.src, h, w, pitch, tiles, th, tw, part, dset.zs, (int)slice_rows, vec, dset.from}))
+              if (int e = shg::launch(k_tile_hist16_slices<true>, dim3((unsigned)slices, (unsigned)ntiles, nz), dim3(1024), HIST16 * 2 + (size_t)slice_rows * 8, st,
+                                       HistSlicesArgs{dset.src, h, w, pitch, tiles, th, tw, part, dset.zs, (int)slice_rows, vec, dset.from}, "k_tile_hist16_slices"))
                   return e;
           } else {
-              if (int e = SHG_LAUNCH_T(k_tile_hist16_slices, <false>, dim3((unsigned)slices, (unsigned)ntiles, nz), dim3(1024), HIST16 * 2, st,
-                                       HistSlicesArgs{dset.src, h, w, pitch, tiles, th, tw, part, dset.zs, (int)slice_rows, vec, FusedSrc{}}))
+              if (int e = shg::launch(k_tile_hist16_slices<false>, dim3((unsigned)slices, (unsigned)ntiles, nz), dim3(1024), HIST16 * 2, st,
+                                       HistSlicesArgs{dset.src, h, w, pitch, tiles, th, tw, part, dset.zs, (int)slice_rows, vec, FusedSrc{}}, "k_tile_hist16_slices"))
                   return e;
           }
           const bool zero_sel = sel_hist && sel_zeroed;
-          if (int e = SHG_LAUNCH(k_hist_reduce, dim3(32, (unsigned)ntiles, nz), dim3(1024), 0, st,
-                                 HistReduceArgs{part, (int)slices, clip, hist, chunk_tile, se, dset.zs, zero_sel ? sel_hist : nullptr, zero_sel ? SEL_SLOTS * sel_stride : 0}))
+          if (int e = shg::launch(k_hist_reduce, dim3(32, (unsigned)ntiles, nz), dim3(1024), 0, st,
+                                 HistReduceArgs{part, (int)slices, clip, hist, chunk_tile, se, dset.zs, zero_sel ? sel_hist : nullptr, zero_sel ? SEL_SLOTS * sel_stride : 0}, "k_hist_reduce"))
               return e;
           if (zero_sel) *sel_zeroed = true; }
         { SHG_PROF("clahe_lut", st);
@@ -1325,7 +1321,7 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
               la.ranks_zstride = ranks_job->out_zstride;
               *ranks_done = true;
           }
-          if (int e = SHG_LAUNCH(k_tile_lut16_blocks, dim3(32u + (unsigned)la.n_ranks, (unsigned)ntiles, (unsigned)dset.n), dim3(1024), 0, st, la)) return e; }
+          if (int e = shg::launch(k_tile_lut16_blocks, dim3(32u + (unsigned)la.n_ranks, (unsigned)ntiles, (unsigned)dset.n), dim3(1024), 0, st, la, "k_tile_lut16_blocks")) return e; }
         { SHG_PROF("clahe_interp", st);
           bool counted = false;
           if (int e = launch_interp16(dset, h, w, pitch, tiles, inv_tw, inv_th, lut, true, dst_pitch, sel_hist, sel_stride, st, &counted)) return e;
@@ -1334,7 +1330,6 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
         return 0;
     }
     SHG_REQUIRE(dset.n == 1 && !dset.fused, SHG_E_UNSUPPORTED, "shg_clahe: several disks per launch need the roomy 16-bit workspace");
-    SHG_DIRECT(st);                                      // (the launches below go to `st` the plain way)
     if (hipError_t e = hipMemsetAsync(hist, 0, (size_t)ntiles * hist_size * sizeof(uint32_t), st)) {
         shg::set_error("shg_clahe: memset: %s", hipGetErrorString(e));
         return (int)e;
@@ -1368,7 +1363,6 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
     }
     if (int e = shg::check_launch("k_clahe_interp")) return e;
     if (sel_hist && sel_zeroed) {                        // nothing has counted into sel_hist on this path: zero it the plain way
-        SHG_DIRECT(st);
         if (hipError_t e = hipMemsetAsync(sel_hist, 0, (size_t)SEL_SLOTS * sel_stride * sizeof(uint32_t), st)) {
             shg::set_error("shg_clahe: memset: %s", hipGetErrorString(e));
             return (int)e;
@@ -1389,7 +1383,6 @@ extern "C" int shg_hist(const void* img, int64_t h, int64_t w, int64_t pitch, in
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w, SHG_E_ARG, "shg_hist: bad image size");
     SHG_REQUIRE(bytes_per_px == 1 || bytes_per_px == 2, SHG_E_ARG, "shg_hist: bytes_per_px must be 1 or 2");
     hipStream_t st = shg::as_stream(stream);
-    SHG_DIRECT(st);
     const int hist_size = bytes_per_px == 1 ? 256 : HIST16;
     if (hipError_t e = hipMemsetAsync(hist, 0, (size_t)hist_size * sizeof(uint32_t), st)) {
         shg::set_error("shg_hist: memset: %s", hipGetErrorString(e));
@@ -1430,7 +1423,6 @@ int select_u16_impl(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, co
     Ranks8 ranks = {};
     for (int i = 0; i < n_ranks; ++i) ranks.v[i] = host_ranks[i];
     if (!zeroed) {
-        SHG_DIRECT(st);
         hipError_t e = hipMemsetAsync(hist, 0, (size_t)SEL_SLOTS * (1 + n_ranks) * 256 * sizeof(uint32_t), st);
         if (e != hipSuccess) { shg::set_error("shg_select_u16: %s", hipGetErrorString(e)); return (int)e; }
     }
@@ -1452,11 +1444,11 @@ int select_u16_impl(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, co
     for (int pass = pass0_done ? 1 : 0; pass < 2; ++pass) {
         // 512 threads: the zeroing / replay / flush around the pixel loop is shared by twice the waves (256 / 512 / 1024
         // threads: 44.7 / 40.6 / 40.3 us for two ranks, tools/bench_select.py)
-        if (int err = SHG_LAUNCH(k_select16_pass, dim3(blocks, 1u, (unsigned)dset.n), dim3(512), 0, st,
-                                 SelectPassArgs{dset.src, h, w, pitch, pass, ranks, n_ranks, hist, vec_ok, dset.zs}))
+        if (int err = shg::launch(k_select16_pass, dim3(blocks, 1u, (unsigned)dset.n), dim3(512), 0, st,
+                                 SelectPassArgs{dset.src, h, w, pitch, pass, ranks, n_ranks, hist, vec_ok, dset.zs}, "k_select16_pass"))
             return err;
     }
-    return SHG_LAUNCH(k_select16_final, dim3((unsigned)n_ranks, 1u, (unsigned)dset.n), dim3(256), 0, st, SelectFinalArgs{ranks, hist, out, dset.zs, out_zstride});
+    return shg::launch(k_select16_final, dim3((unsigned)n_ranks, 1u, (unsigned)dset.n), dim3(256), 0, st, SelectFinalArgs{ranks, hist, out, dset.zs, out_zstride}, "k_select16_final");
 }
 }  // namespace
 
@@ -1517,15 +1509,14 @@ extern "C" int shg_contrast_stats_u16(const uint16_t* frame, int64_t h, int64_t 
         hipStream_t st = shg::as_stream(stream);
         SHG_PROF("hist_ranks", st);
         if (chunk_tile) {                                // left by k_hist_reduce, one set per tile
-            if (int e = SHG_LAUNCH(k_hist_ranks, dim3(2), dim3(1024), 0, st,
-                                   HistRanksArgs{reinterpret_cast<const uint32_t*>(ws), chunk_tile, tiles * tiles, tiles * tiles, ranks, out5, 0, 0}))
+            if (int e = shg::launch(k_hist_ranks, dim3(2), dim3(1024), 0, st,
+                                   HistRanksArgs{reinterpret_cast<const uint32_t*>(ws), chunk_tile, tiles * tiles, tiles * tiles, ranks, out5, 0, 0}, "k_hist_ranks"))
                 return e;
         } else {
-            SHG_DIRECT(st);
             k_chunk_sums<<<64, 1024, 0, st>>>(reinterpret_cast<const uint32_t*>(ws), tiles * tiles, chunk_sums);
             if (int e = shg::check_launch("k_chunk_sums")) return e;
-            if (int e = SHG_LAUNCH(k_hist_ranks, dim3(2), dim3(1024), 0, st,
-                                   HistRanksArgs{reinterpret_cast<const uint32_t*>(ws), chunk_sums, 1, tiles * tiles, ranks, out5, 0, 0}))
+            if (int e = shg::launch(k_hist_ranks, dim3(2), dim3(1024), 0, st,
+                                   HistRanksArgs{reinterpret_cast<const uint32_t*>(ws), chunk_sums, 1, tiles * tiles, ranks, out5, 0, 0}, "k_hist_ranks"))
                 return e;
         }
     } else if (int e = shg_select_u16(frame, h, w, pitch, ranks_frame2, 2, out5, ws + c, s2, stream)) return e;
@@ -1612,8 +1603,8 @@ int shg::contrast_stats_batch(const uint16_t* const* host_frames, int64_t k, int
         SHG_REQUIRE(chunk_tile && sel_zeroed, SHG_E_RUNTIME, "shg_contrast_stats_u16: the batched path did not take the slice histograms");
         if (!ranks_done) {
             SHG_PROF("hist_ranks", st);
-            if (int e = SHG_LAUNCH(k_hist_ranks, dim3(2u, 1u, (unsigned)m), dim3(1024), 0, st,
-                                   HistRanksArgs{reinterpret_cast<const uint32_t*>(ws), chunk_tile, tiles * tiles, tiles * tiles, ranks, out5 + 5 * i0, per, 5}))
+            if (int e = shg::launch(k_hist_ranks, dim3(2u, 1u, (unsigned)m), dim3(1024), 0, st,
+                                   HistRanksArgs{reinterpret_cast<const uint32_t*>(ws), chunk_tile, tiles * tiles, tiles * tiles, ranks, out5 + 5 * i0, per, 5}, "k_hist_ranks"))
                 return e;
         }
         Disks dc = d;

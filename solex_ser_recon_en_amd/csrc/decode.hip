@@ -64,7 +64,6 @@ extern "C" int shg_unpack_dib_frames(const uint8_t* raw, int64_t n_frames, int64
     dim3 grid((unsigned)((height * width + 255) / 256), (unsigned)n_frames);
     hipStream_t st = shg::as_stream(stream);
     SHG_PROF("unpack_dib", st);
-    SHG_DIRECT(st);
     k_unpack_dib<<<grid, 256, 0, st>>>(raw, raw_pitch_bytes, height, width, bits, row_bytes, bottom_up, gray_lut, stack, fstride);
     return shg::check_launch("k_unpack_dib");
 }

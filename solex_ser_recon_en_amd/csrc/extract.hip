@@ -45,7 +45,7 @@ struct ExtractArgs {
     uint32_t* mm;
 };
 
-SHG_MERGEABLE_T(SHG_TPL(template <typename T, bool ROT, int BATCH, int SC>), SHG_TPL(<T, ROT, BATCH, SC>), k_extract, ExtractArgs, __launch_bounds__(256)) {
+template <typename T, bool ROT, int BATCH, int SC> __global__ __launch_bounds__(256) void k_extract(const ExtractArgs kargs) {
     const T* __restrict__ stack = static_cast<const T*>(kargs.stack);
     const int n_frames = kargs.n_frames, n_shifts = kargs.n_shifts, flip_x = kargs.flip_x, vec_store = kargs.vec_store;
     const int64_t height = kargs.height, width = kargs.width, fstride = kargs.fstride, row_pitch = kargs.row_pitch, plane_stride = kargs.plane_stride,
@@ -120,7 +120,7 @@ SHG_MERGEABLE_T(SHG_TPL(template <typename T, bool ROT, int BATCH, int SC>), SHG
                     const double l = (double)((int)lv[i][s] * scale);
                     const double r = (double)((int)rv[i][s] * scale);
                     const double v = l * wl + r * wr;
-                    const uint32_t q = (uint32_t)(int)v;     // 0 <= v < 65536: a blend of two 16-bit samples with weights in [0, 1] (no mask needed)
+                    const uint32_t q = (uint32_t)(int)v & 0xffffu;   // what the stored pixel is (weights outside [0, 1] wrap as the reference's uint16 cast does)
                     tile[s][lane][cc] = (uint16_t)q;
                     vlo[s] = q < vlo[s] ? q : vlo[s];
                     vhi[s] = q > vhi[s] ? q : vhi[s];
@@ -354,7 +354,7 @@ struct FoldMinmaxArgs {
     size_t zero_words;
 };
 
-SHG_MERGEABLE(k_fold_minmax, FoldMinmaxArgs, __launch_bounds__(64)) {
+__global__ __launch_bounds__(64) void k_fold_minmax(const FoldMinmaxArgs kargs) {
     const uint32_t* __restrict__ slots = kargs.slots;
     uint32_t* __restrict__ out = kargs.out;
     if ((int)blockIdx.x >= kargs.n_planes) {
@@ -382,7 +382,7 @@ int launch_fold(uint32_t* minmax_slots, int n_shifts, hipStream_t st) {
         fa.zero_words = shg::t_zero_with_fold_words;
         extra = (unsigned)std::min<size_t>((fa.zero_words + 1023) / 1024, 64);
     }
-    const int e = SHG_LAUNCH(k_fold_minmax, dim3((unsigned)n_shifts + extra), dim3(64), 0, st, fa);
+    const int e = shg::launch(k_fold_minmax, dim3((unsigned)n_shifts + extra), dim3(64), 0, st, fa, "k_fold_minmax");
     if (e == 0 && extra) shg::t_prezeroed = shg::t_zero_with_fold;
     shg::t_zero_with_fold = nullptr;
     shg::t_zero_with_fold_words = 0;
@@ -415,6 +415,9 @@ extern "C" int shg_extract_columns_minmax(const void* stack, int64_t n_frames, i
     SHG_REQUIRE(row_pitch >= n_cols, SHG_E_ARG, "shg_extract_columns: row_pitch < n_cols");
     SHG_REQUIRE((height < width ? height : width) >= 2, SHG_E_ARG, "shg_extract_columns: spectral axis needs >= 2 pixels");
     SHG_REQUIRE(frame_stride_px == 0 || frame_stride_px >= height * width, SHG_E_ARG, "shg_extract_columns: frame stride smaller than a frame");
+    // (the kernel addresses a sample as `frame base + 32-bit byte offset`)
+    SHG_REQUIRE(height * width * bytes_per_px < (1ll << 32), SHG_E_UNSUPPORTED, "shg_extract_columns: a frame of %lld x %lld samples is larger than 4 GiB",
+                (long long)height, (long long)width);
     const int64_t fstride = frame_stride_px > 0 ? frame_stride_px : height * width;
     const bool rot = width > height;
     const int64_t ih = rot ? width : height;
@@ -426,7 +429,7 @@ extern "C" int shg_extract_columns_minmax(const void* stack, int64_t n_frames, i
     const int n = (int)n_frames;
     const ExtractArgs xa{stack, n, height, width, fstride, ind_l, lw, rw, n_shifts, disks, row_pitch, plane_stride, n_cols, k_offset, flip_x, vec_store, minmax_slots};
     int launch_status = 0;
-#define EXT_LAUNCH_BS(T, ROT, B, SCV) launch_status = SHG_LAUNCH_T(k_extract, SHG_TPL(<T, ROT, B, SCV>), grid, dim3(256), 0, st, xa)
+#define EXT_LAUNCH_BS(T, ROT, B, SCV) launch_status = shg::launch(k_extract<T, ROT, B, SCV>, grid, dim3(256), 0, st, xa, "k_extract")
 #define EXT_LAUNCH_B(T, ROT, B) do { if (sc == 2) EXT_LAUNCH_BS(T, ROT, B, 2); else EXT_LAUNCH_BS(T, ROT, B, 4); } while (0)
 #define EXT_LAUNCH(T, ROT)                                                 \
     switch (batch) {                                                       \
@@ -442,7 +445,6 @@ extern "C" int shg_extract_columns_minmax(const void* stack, int64_t n_frames, i
     const int batch2 = 4;
     const int batch = batch_env > 0 ? batch_env : (n_shifts > SC_MAX ? 8 : (n_shifts <= 2 ? batch2 : 4));
     if (minmax_slots && !slots_zeroed) {
-        SHG_DIRECT(st);
         if (hipError_t e = hipMemsetAsync(minmax_slots, 0, (size_t)n_shifts * 64 * 2 * sizeof(uint32_t), st)) {
             shg::set_error("shg_extract_columns: memset: %s", hipGetErrorString(e));
             return (int)e;
@@ -505,7 +507,6 @@ extern "C" int shg_extract_columns_dense(const void* stack, int64_t n_frames, in
     PlaneOfOffset po = {};
     for (int i = 0; i < n_shifts; ++i) po.v[host_shifts[i] - lo] = i;
     hipStream_t st = shg::as_stream(stream);
-    SHG_DIRECT(st);                                          // (this kernel launches the plain way: launch.h)
     if (minmax_slots && !slots_zeroed) {
         if (hipError_t e = hipMemsetAsync(minmax_slots, 0, (size_t)n_shifts * 64 * 2 * sizeof(uint32_t), st)) {
             shg::set_error("shg_extract_columns_dense: memset: %s", hipGetErrorString(e));

@@ -570,10 +570,8 @@ extern "C" int shg_box_blur_f64(const double* src, int64_t h, int64_t w, int k, 
     SHG_REQUIRE(k > 0, SHG_E_ARG, "shg_box_blur_f64: kernel %d must be positive", k);      // cv2.blur raises as well
     hipStream_t st = shg::as_stream(stream);
     const unsigned blocks = (unsigned)((h * w + 255) / 256);
-    SHG_DIRECT(st);
     { SHG_PROF("box_blur_f64", st); k_boxf_rows<<<blocks, 256, 0, st>>>(src, (int)h, (int)w, k, tmp); }
     if (int e = shg::check_launch("k_boxf_rows")) return e;
-    SHG_DIRECT(st);
     { SHG_PROF("box_blur_f64", st); k_boxf_cols<<<blocks, 256, 0, st>>>(tmp, (int)h, (int)w, k, 1.0 / ((double)k * (double)k), dst); }
     return shg::check_launch("k_boxf_cols");
 }
@@ -587,10 +585,8 @@ extern "C" int shg_box_blur_key_f64(const double* src, int64_t h, int64_t w, int
     hipStream_t st = shg::as_stream(stream);
     const unsigned blocks = (unsigned)((h * w + 255) / 256);
     SHG_PROF("box_blur_f64", st);
-    SHG_DIRECT(st);
     k_boxf_rows<<<blocks, 256, 0, st>>>(src, (int)h, (int)w, k, tmp);
     if (int e = shg::check_launch("k_boxf_rows")) return e;
-    SHG_DIRECT(st);
     k_boxf_cols_key<<<blocks, 256, 0, st>>>(tmp, (int)h, (int)w, k, 1.0 / ((double)k * (double)k), dst, keys);
     return shg::check_launch("k_boxf_cols_key");
 }
@@ -616,7 +612,6 @@ extern "C" int shg_select_keys_u32(const uint32_t* const* host_keys, int64_t n, 
     }
     hipStream_t st = shg::as_stream(stream);
     uint32_t* hist = static_cast<uint32_t*>(workspace);
-    SHG_DIRECT(st);
     if (hipError_t e = hipMemsetAsync(hist, 0, shg_select_keys_workspace_bytes(n_pairs), st)) {
         shg::set_error("shg_select_keys_u32: %s", hipGetErrorString(e));
         return (int)e;
@@ -625,11 +620,9 @@ extern "C" int shg_select_keys_u32(const uint32_t* const* host_keys, int64_t n, 
     if (blocks > 256) blocks = 256;
     SHG_PROF("select", st);
     for (int pass = 0; pass < SEL32_PASSES; ++pass) {
-        SHG_DIRECT(st);
         k_select32_pass<<<dim3((unsigned)blocks, (unsigned)n_pairs), 256, 0, st>>>(p, n, pass, hist);
         if (int err = shg::check_launch("k_select32_pass")) return err;
     }
-    SHG_DIRECT(st);
     k_select32_final<<<(unsigned)n_pairs, 256, 0, st>>>(p, hist, out);
     return shg::check_launch("k_select32_final");
 }
@@ -654,16 +647,12 @@ extern "C" int shg_canny_masks_f64(const double* blurred, int64_t h, int64_t w, 
     double *img_v = p, *one_v = p + n, *smoothed = p + 2 * n, *isob = p + 3 * n, *jsob = p + 4 * n, *mag = p + 5 * n;
     hipStream_t st = shg::as_stream(stream);
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    SHG_DIRECT(st);
     { SHG_PROF("canny", st); k_gauss_v2<<<blocks, 256, 0, st>>>(blurred, (int)h, (int)w, flood_thresh, g, img_v, one_v); }
     if (int e = shg::check_launch("k_gauss_v2")) return e;
-    SHG_DIRECT(st);
     { SHG_PROF("canny", st); k_gauss_h2_div<<<blocks, 256, 0, st>>>(img_v, one_v, (int)h, (int)w, g, smoothed); }
     if (int e = shg::check_launch("k_gauss_h2_div")) return e;
-    SHG_DIRECT(st);
     { SHG_PROF("canny", st); k_sobel_mag<<<blocks, 256, 0, st>>>(smoothed, (int)h, (int)w, isob, jsob, mag); }
     if (int e = shg::check_launch("k_sobel_mag")) return e;
-    SHG_DIRECT(st);
     { SHG_PROF("canny", st); k_nms<<<blocks, 256, 0, st>>>(isob, jsob, mag, (int)h, (int)w, low, high, low_mask, high_mask); }
     return shg::check_launch("k_nms");
 }
@@ -694,22 +683,17 @@ extern "C" int shg_select_multi_f64(const double* const* host_arrays, int64_t n,
     int64_t* ranks = reinterpret_cast<int64_t*>(hist + (size_t)n_ranks * 8 * 256);
     const double** arrays = reinterpret_cast<const double**>(ranks + n_ranks);
     for (int i = 0; i < n_ranks; ++i) SHG_REQUIRE(host_arrays[i], SHG_E_ARG, "shg_select_f64: null array");
-    SHG_DIRECT(st);
     hipError_t e = hipMemsetAsync(hist, 0, (size_t)n_ranks * 8 * 256 * sizeof(uint32_t), st);
-    SHG_DIRECT(st);
     if (e == hipSuccess) e = hipMemcpyAsync(ranks, host_ranks, n_ranks * sizeof(int64_t), hipMemcpyHostToDevice, st);
-    SHG_DIRECT(st);
     if (e == hipSuccess) e = hipMemcpyAsync(arrays, host_arrays, n_ranks * sizeof(void*), hipMemcpyHostToDevice, st);
     if (e != hipSuccess) { shg::set_error("shg_select_f64: %s", hipGetErrorString(e)); return (int)e; }
     int64_t blocks = (n + 2047) / 2048;
     if (blocks > 256) blocks = 256;
     SHG_PROF("select", st);
     for (int pass = 0; pass < 8; ++pass) {
-        SHG_DIRECT(st);
         k_select_pass<<<dim3((unsigned)blocks, (unsigned)n_ranks), 256, 0, st>>>(arrays, n, pass, ranks, hist);
         if (int err = shg::check_launch("k_select_pass")) return err;
     }
-    SHG_DIRECT(st);
     k_select_final<<<(unsigned)n_ranks, 256, 0, st>>>(ranks, hist, out);
     return shg::check_launch("k_select_final");
 }
@@ -723,12 +707,9 @@ static int flood_stats(const double* image, const double* blurred, int64_t n, co
     int64_t blocks = (n + 2047) / 2048;
     if (blocks > 256) blocks = 256;
     SHG_PROF("flood_stats", st);
-    SHG_DIRECT(st);
     k_flood_init<<<1, 64, 0, st>>>(acc, counts, order_stats, gamma, very_bright);
-    SHG_DIRECT(st);
     k_flood_minmax<<<(unsigned)blocks, 256, 0, st>>>(image, blurred, n, acc);
     if (int err = shg::check_launch("k_flood_minmax")) return err;
-    SHG_DIRECT(st);
     k_flood_hist<<<(unsigned)blocks, 256, 0, st>>>(blurred, n, acc, stats, counts);
     return shg::check_launch("k_flood_hist");
 }
@@ -764,17 +745,11 @@ extern "C" int shg_edge_components(const uint8_t* low_mask, const uint8_t* high_
     int* offsets = counts + h;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     SHG_PROF("edge_components", st);
-    SHG_DIRECT(st);
     k_ccl_init<<<blocks, 256, 0, st>>>(low_mask, n, L, flag);
-    SHG_DIRECT(st);
     k_ccl_merge<<<blocks, 256, 0, st>>>(low_mask, (int)h, (int)w, L);
-    SHG_DIRECT(st);
     k_ccl_flatten<<<blocks, 256, 0, st>>>(low_mask, high_mask, n, L, flag);
-    SHG_DIRECT(st);
     k_ccl_emit<<<(unsigned)h, 256, 0, st>>>(L, flag, (int)w, 0, counts, offsets, out_idx, out_root);
-    SHG_DIRECT(st);
     k_ccl_scan<<<1, 256, 0, st>>>(counts, (int)h, offsets, out_count);
-    SHG_DIRECT(st);
     k_ccl_emit<<<(unsigned)h, 256, 0, st>>>(L, flag, (int)w, 1, counts, offsets, out_idx, out_root);
     return shg::check_launch("k_ccl");
 }

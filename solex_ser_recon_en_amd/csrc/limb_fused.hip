@@ -135,7 +135,7 @@ struct ZeroWordsArgs {
     uint32_t* dst;
     size_t n_words;
 };
-SHG_MERGEABLE(k_zero_words, ZeroWordsArgs, __launch_bounds__(256)) {
+__global__ __launch_bounds__(256) void k_zero_words(const ZeroWordsArgs kargs) {
     uint32_t* __restrict__ dst = kargs.dst;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < kargs.n_words; i += (size_t)gridDim.x * 256) dst[i] = 0;
 }
@@ -148,7 +148,7 @@ struct LimbBlurArgs {
     uint32_t *keysk, *keys5;
     unsigned long long* acc;
 };
-SHG_MERGEABLE(k_limb_blur, LimbBlurArgs, __launch_bounds__(256)) {
+__global__ __launch_bounds__(256) void k_limb_blur(const LimbBlurArgs kargs) {
     const uint16_t* __restrict__ img = kargs.img;
     const int h = kargs.h, w = kargs.w, sh = kargs.sh, sw = kargs.sw, k = kargs.k, vec4 = kargs.vec4;
     const int64_t pitch = kargs.pitch;
@@ -292,7 +292,7 @@ struct LimbSelect0Args {
     int bits0, bits1;
     uint32_t *hist0, *coarse0;
 };
-SHG_MERGEABLE(k_limb_select0, LimbSelect0Args, __launch_bounds__(256)) {
+__global__ __launch_bounds__(256) void k_limb_select0(const LimbSelect0Args kargs) {
     const uint32_t* __restrict__ keysk = kargs.keysk;
     const uint32_t* __restrict__ keys5 = kargs.keys5;
     const int64_t n = kargs.n;
@@ -333,7 +333,7 @@ struct LimbSelect1Args {
     unsigned long long* acc;
     double* out4;
 };
-SHG_MERGEABLE(k_limb_select1, LimbSelect1Args, __launch_bounds__(256)) {
+__global__ __launch_bounds__(256) void k_limb_select1(const LimbSelect1Args kargs) {
     const uint32_t* __restrict__ keysk = kargs.keysk;
     const uint32_t* __restrict__ keys5 = kargs.keys5;
     const int64_t n = kargs.n;
@@ -438,7 +438,7 @@ struct LimbFloodHistArgs {
     uint32_t *counts, *done;
     double* packed;
 };
-SHG_MERGEABLE(k_limb_flood_hist, LimbFloodHistArgs, __launch_bounds__(256)) {
+__global__ __launch_bounds__(256) void k_limb_flood_hist(const LimbFloodHistArgs kargs) {
     const uint32_t* __restrict__ keysk = kargs.keysk;
     const int64_t n = kargs.n;
     const double scale_k = kargs.scale_k;
@@ -549,7 +549,7 @@ struct LimbCannyArgs {
     int *L, *row_counts;
     int tiles_x;
 };
-SHG_MERGEABLE(k_limb_canny_tile, LimbCannyArgs, __launch_bounds__(NT1)) {
+__global__ __launch_bounds__(NT1) void k_limb_canny_tile(const LimbCannyArgs kargs) {
     const uint32_t* __restrict__ keysk = kargs.keysk;
     const int h = kargs.h, w = kargs.w, tiles_x = kargs.tiles_x;
     const double scale_k = kargs.scale_k, flood_thresh = kargs.flood_thresh, low = kargs.low, high = kargs.high;
@@ -724,7 +724,7 @@ struct LimbBorderArgs {
     int h, w;
     int* L;
 };
-SHG_MERGEABLE(k_limb_border_merge, LimbBorderArgs, __launch_bounds__(256)) {
+__global__ __launch_bounds__(256) void k_limb_border_merge(const LimbBorderArgs kargs) {
     const uint8_t* __restrict__ mask = kargs.mask;
     const int h = kargs.h, w = kargs.w;
     int* __restrict__ L = kargs.L;
@@ -763,7 +763,7 @@ struct LimbEmitArgs {
     int tiles_x, n;
     int* comp;
 };
-SHG_MERGEABLE(k_limb_emit, LimbEmitArgs, __launch_bounds__(256)) {
+__global__ __launch_bounds__(256) void k_limb_emit(const LimbEmitArgs kargs) {
     const uint8_t* __restrict__ mask = kargs.mask;
     const int* __restrict__ L = kargs.L;
     const int h = kargs.h, w = kargs.w, tiles_x = kargs.tiles_x, n = kargs.n;
@@ -864,7 +864,7 @@ extern "C" int shg_limb_prepare(const uint16_t* img, int64_t h, int64_t w, int64
     SHG_PROF("limb_prepare", st);
     if (shg::t_prezeroed == workspace) {                       // the extraction's last launch has cleared them on its way (shg_scan_file)
         shg::t_prezeroed = nullptr;
-    } else if (int e = SHG_LAUNCH(k_zero_words, dim3((unsigned)std::min<size_t>((lay.zero_words + 255) / 256, 64)), dim3(256), 0, st, ZeroWordsArgs{ws, lay.zero_words})) {
+    } else if (int e = shg::launch(k_zero_words, dim3((unsigned)std::min<size_t>((lay.zero_words + 255) / 256, 64)), dim3(256), 0, st, ZeroWordsArgs{ws, lay.zero_words}, "k_zero_words")) {
         return e;
     }
     Ranks4 p;
@@ -872,24 +872,22 @@ extern "C" int shg_limb_prepare(const uint16_t* img, int64_t h, int64_t w, int64
     for (int i = 0; i < 4; ++i) { p.rank[i] = host_ranks4[i]; p.array[i] = (i < 2 && k != 5) ? 1 : 0; p.scale[i] = (i < 2) ? scale_5 : scale_k; }
     dim3 grid1((unsigned)((sw + BT - 1) / BT), (unsigned)((sh + BT - 1) / BT));
     const int vec4 = (reinterpret_cast<uintptr_t>(img) & 7) == 0 && pitch % 4 == 0;
-    if (int e = SHG_LAUNCH(k_limb_blur, grid1, dim3(256), 0, st, LimbBlurArgs{img, (int)h, (int)w, pitch, (int)sh, (int)sw, k, vec4, keysk, keys5, acc})) return e;
+    if (int e = shg::launch(k_limb_blur, grid1, dim3(256), 0, st, LimbBlurArgs{img, (int)h, (int)w, pitch, (int)sh, (int)sw, k, vec4, keysk, keys5, acc}, "k_limb_blur")) return e;
     static const bool lds_ok = [] {                             // a 2^14-bin histogram is the default 64 KB of dynamic LDS, to the byte
         return hipFuncSetAttribute(reinterpret_cast<const void*>(k_limb_select0), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void*>(k_limb_select1), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void*>(k_limb_select0_multi), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void*>(k_limb_select1_multi), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+               hipFuncSetAttribute(reinterpret_cast<const void*>(k_limb_select1), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
     }();
     if (!lds_ok) (void)hipGetLastError();
     int64_t blocks = (n + 2047) / 2048;
     if (blocks > 256) blocks = 256;
-    if (int e = SHG_LAUNCH(k_limb_select0, dim3((unsigned)blocks, k == 5 ? 1u : 2u), dim3(256), ((size_t)1 << lay.bits0) * 4, st,
-                           LimbSelect0Args{keysk, keys5, n, lay.bits0, lay.bits1, hist0, coarse0}))
+    if (int e = shg::launch(k_limb_select0, dim3((unsigned)blocks, k == 5 ? 1u : 2u), dim3(256), ((size_t)1 << lay.bits0) * 4, st,
+                           LimbSelect0Args{keysk, keys5, n, lay.bits0, lay.bits1, hist0, coarse0}, "k_limb_select0"))
         return e;
-    if (int e = SHG_LAUNCH(k_limb_select1, dim3((unsigned)blocks, 4u), dim3(256), ((size_t)1 << lay.bits1) * 4, st,
-                           LimbSelect1Args{keysk, keys5, n, p, lay.bits0, lay.bits1, hist0, coarse0, hist1, coarse1, gamma99, done, acc, out4}))
+    if (int e = shg::launch(k_limb_select1, dim3((unsigned)blocks, 4u), dim3(256), ((size_t)1 << lay.bits1) * 4, st,
+                           LimbSelect1Args{keysk, keys5, n, p, lay.bits0, lay.bits1, hist0, coarse0, hist1, coarse1, gamma99, done, acc, out4}, "k_limb_select1"))
         return e;
     *keys_out = keysk;
-    return SHG_LAUNCH(k_limb_flood_hist, dim3((unsigned)blocks), dim3(256), 0, st, LimbFloodHistArgs{keysk, n, scale_k, acc, out4, counts, done + 1, packed});
+    return shg::launch(k_limb_flood_hist, dim3((unsigned)blocks), dim3(256), 0, st, LimbFloodHistArgs{keysk, n, scale_k, acc, out4, counts, done + 1, packed}, "k_limb_flood_hist");
 }
 
 extern "C" size_t shg_limb_edges_workspace_bytes(int64_t sh, int64_t sw) {
@@ -920,16 +918,15 @@ extern "C" int shg_limb_edges(const uint32_t* keys, int64_t sh, int64_t sw, int 
     hipStream_t st = shg::as_stream(stream);
     SHG_PROF("limb_edges", st);
     dim3 grid((unsigned)tiles_x, (unsigned)((sh + TH - 1) / TH));
-    static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_limb_canny_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-                               hipFuncSetAttribute(reinterpret_cast<const void*>(k_limb_canny_tile_multi), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_limb_canny_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
     if (!lds_ok) (void)hipGetLastError();
-    if (int e = SHG_LAUNCH(k_limb_canny_tile, grid, dim3(NT1), canny_tile_lds(radius), st,
-                           LimbCannyArgs{keys, (int)sh, (int)sw, 1.0 / ((double)k * (double)k), flood_thresh, g, low, high, mask, L, row_counts, tiles_x}))
+    if (int e = shg::launch(k_limb_canny_tile, grid, dim3(NT1), canny_tile_lds(radius), st,
+                           LimbCannyArgs{keys, (int)sh, (int)sw, 1.0 / ((double)k * (double)k), flood_thresh, g, low, high, mask, L, row_counts, tiles_x}, "k_limb_canny_tile"))
         return e;
     {
         const int64_t tops = ((sh + TH - 1) / TH) * sw, sides = 2 * (int64_t)tiles_x * sh;
-        if (int e = SHG_LAUNCH(k_limb_border_merge, dim3((unsigned)((std::max(tops, sides) + 255) / 256), 2u), dim3(256), 0, st, LimbBorderArgs{mask, (int)sh, (int)sw, L}))
+        if (int e = shg::launch(k_limb_border_merge, dim3((unsigned)((std::max(tops, sides) + 255) / 256), 2u), dim3(256), 0, st, LimbBorderArgs{mask, (int)sh, (int)sw, L}, "k_limb_border_merge"))
             return e;
     }
-    return SHG_LAUNCH(k_limb_emit, dim3((unsigned)sh), dim3(256), 0, st, LimbEmitArgs{mask, L, (int)sh, (int)sw, row_counts, tiles_x, (int)n, comp});
+    return shg::launch(k_limb_emit, dim3((unsigned)sh), dim3(256), 0, st, LimbEmitArgs{mask, L, (int)sh, (int)sw, row_counts, tiles_x, (int)n, comp}, "k_limb_emit");
 }

@@ -88,7 +88,6 @@ extern "C" int shg_box_blur_u16(const uint16_t* src, int64_t h, int64_t w, int k
     SHG_REQUIRE((int64_t)kw * kh <= 32768, SHG_E_UNSUPPORTED, "shg_box_blur_u16: window %d x %d overflows int32 sums", kw, kh);
     hipStream_t st = shg::as_stream(stream);
     const unsigned blocks = (unsigned)((h * w + 255) / 256);
-    SHG_DIRECT(st);
     { SHG_PROF("box_blur", st); k_box_rows<<<blocks, 256, 0, st>>>(src, h, w, kw, tmp); }
     if (int e = shg::check_launch("k_box_rows")) return e;
     { SHG_PROF("box_blur", st); k_box_cols<<<blocks, 256, 0, st>>>(tmp, h, w, kh, 1.0 / ((double)kw * (double)kh), dst); }
@@ -100,7 +99,6 @@ extern "C" int shg_row_argmin_u16(const uint16_t* img, int64_t h, int64_t w, int
     SHG_REQUIRE(img && out, SHG_E_ARG, "shg_row_argmin_u16: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && x0 >= 0 && x1 <= w && x0 < x1, SHG_E_ARG,
                 "shg_row_argmin_u16: empty column range [%lld, %lld) of %lld", (long long)x0, (long long)x1, (long long)w);
-    SHG_DIRECT(shg::as_stream(stream));
     { SHG_PROF("row_argmin", shg::as_stream(stream)); k_row_argmin<<<(unsigned)((h + 3) / 4), 256, 0, shg::as_stream(stream)>>>(img, h, w, x0, x1, out); }
     return shg::check_launch("k_row_argmin");
 }
@@ -108,7 +106,6 @@ extern "C" int shg_row_argmin_u16(const uint16_t* img, int64_t h, int64_t w, int
 extern "C" int shg_row_mean_u16(const uint16_t* img, int64_t h, int64_t w, double* out, shg_stream_t stream) {
     SHG_REQUIRE(img && out, SHG_E_ARG, "shg_row_mean_u16: null pointer");
     SHG_REQUIRE(h > 0 && w > 0, SHG_E_ARG, "shg_row_mean_u16: empty image");
-    SHG_DIRECT(shg::as_stream(stream));
     { SHG_PROF("row_mean", shg::as_stream(stream)); k_row_mean<<<(unsigned)((h + 3) / 4), 256, 0, shg::as_stream(stream)>>>(img, h, w, out); }
     return shg::check_launch("k_row_mean");
 }
@@ -147,7 +144,7 @@ struct BlurReduceArgs {
     int32_t *arg_blur, *arg_sharp;
 };
 
-SHG_MERGEABLE_T(SHG_TPL(template <int MODE>), SHG_TPL(<MODE>), k_blur_reduce, BlurReduceArgs, __launch_bounds__(256)) {
+template <int MODE> __global__ __launch_bounds__(256) void k_blur_reduce(const BlurReduceArgs kargs) {
     const uint16_t* __restrict__ src = kargs.src;
     const int h = kargs.h, w = kargs.w, kw = kargs.kw, kh = kargs.kh, x0 = kargs.x0, x1 = kargs.x1;
     const double scale = kargs.scale;
@@ -262,12 +259,11 @@ extern "C" int shg_blur_row_mean_u16(const uint16_t* src, int64_t h, int64_t w, 
     SHG_REQUIRE(h < (1ll << 30), SHG_E_UNSUPPORTED, "shg_blur_row_mean_u16: %lld rows", (long long)h);
     SHG_REQUIRE(shg_blur_fits_fused(w, kh), SHG_E_UNSUPPORTED, "shg_blur_row_mean_u16: %lld columns x %d rows do not fit the LDS tile", (long long)w, kh);
     hipStream_t st = shg::as_stream(stream);
-    static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_reduce<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlurReduceMaxLds) == hipSuccess &&
-                             hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_reduce_multi<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlurReduceMaxLds) == hipSuccess;
+    static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_reduce<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlurReduceMaxLds) == hipSuccess;
     (void)attr;
     SHG_PROF("blur_row_mean", st);
-    return SHG_LAUNCH_T(k_blur_reduce, <0>, dim3((unsigned)((h + FROWS - 1) / FROWS)), dim3(256), blur_reduce_lds(w, kh), st,
-                        BlurReduceArgs{src, (int)h, (int)w, kw, kh, 1.0 / ((double)kw * (double)kh), 0, (int)w, out, nullptr, nullptr});
+    return shg::launch(k_blur_reduce<0>, dim3((unsigned)((h + FROWS - 1) / FROWS)), dim3(256), blur_reduce_lds(w, kh), st,
+                        BlurReduceArgs{src, (int)h, (int)w, kw, kh, 1.0 / ((double)kw * (double)kh), 0, (int)w, out, nullptr, nullptr}, "k_blur_reduce");
 }
 
 extern "C" int shg_blur_argmin_u16(const uint16_t* src, int64_t h, int64_t w, int kw, int kh, int64_t x0, int64_t x1,
@@ -280,10 +276,9 @@ extern "C" int shg_blur_argmin_u16(const uint16_t* src, int64_t h, int64_t w, in
     SHG_REQUIRE(h < (1ll << 30), SHG_E_UNSUPPORTED, "shg_blur_argmin_u16: %lld rows", (long long)h);
     SHG_REQUIRE(shg_blur_fits_fused(w, kh), SHG_E_UNSUPPORTED, "shg_blur_argmin_u16: %lld columns x %d rows do not fit the LDS tile", (long long)w, kh);
     hipStream_t st = shg::as_stream(stream);
-    static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_reduce<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlurReduceMaxLds) == hipSuccess &&
-                             hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_reduce_multi<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlurReduceMaxLds) == hipSuccess;
+    static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_reduce<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBlurReduceMaxLds) == hipSuccess;
     (void)attr;
     SHG_PROF("blur_argmin", st);
-    return SHG_LAUNCH_T(k_blur_reduce, <1>, dim3((unsigned)((h + FROWS - 1) / FROWS)), dim3(256), blur_reduce_lds(w, kh), st,
-                        BlurReduceArgs{src, (int)h, (int)w, kw, kh, 1.0 / ((double)kw * (double)kh), (int)x0, (int)x1, nullptr, out_blur, out_sharp});
+    return shg::launch(k_blur_reduce<1>, dim3((unsigned)((h + FROWS - 1) / FROWS)), dim3(256), blur_reduce_lds(w, kh), st,
+                        BlurReduceArgs{src, (int)h, (int)w, kw, kh, 1.0 / ((double)kw * (double)kh), (int)x0, (int)x1, nullptr, out_blur, out_sharp}, "k_blur_reduce");
 }

@@ -132,7 +132,6 @@ extern "C" int shg_lin_filter_row_sums(const uint16_t* img, int64_t h, int64_t w
     dim3 grid((unsigned)((w + SEG - 1) / SEG), (unsigned)h);
     hipStream_t st = shg::as_stream(stream);
     SHG_PROF("lin_row_sums", st);
-    SHG_DIRECT(st);
     if (row_factor) k_lin_row_sums<true><<<grid, 256, 0, st>>>(img, w, pitch, row_factor, log_lut, flagged, up, dn, linlen, hl, hf);
     else k_lin_row_sums<false><<<grid, 256, 0, st>>>(img, w, pitch, row_factor, log_lut, flagged, up, dn, linlen, hl, hf);
     return shg::check_launch("k_lin_row_sums");
@@ -148,7 +147,6 @@ extern "C" int shg_lin_filter_apply(const uint16_t* img, int64_t h, int64_t w, i
     dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
     hipStream_t st = shg::as_stream(stream);
     SHG_PROF("lin_apply", st);
-    SHG_DIRECT(st);
     if (row_factor)
         k_lin_apply<true><<<grid, 256, 0, st>>>(img, h, w, pitch, row_factor, hl, hf, linlen, half_width, taper, xa, xb, edge, edge_half, dst, dst_pitch);
     else

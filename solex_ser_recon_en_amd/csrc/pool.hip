@@ -37,7 +37,6 @@ struct shg_pool {
     std::map<int64_t, Job> jobs;
     int64_t next_ticket = 1;
     bool stop = false;
-    shg::Combiner* comb = nullptr;                            // the same kernel of the scans in flight as one dispatch (launch.h); SHG_COMBINE=0: none
 };
 
 namespace {
@@ -51,7 +50,6 @@ void pool_worker(shg_pool* p, int k) {
         (void)sched_setaffinity(0, sizeof(set), &set);
     }
     hipStream_t st = p->streams[(size_t)k];
-    shg::Recorder rec;
     for (;;) {
         int64_t ticket;
         shg_pool::Job job;
@@ -63,15 +61,13 @@ void pool_worker(shg_pool* p, int k) {
             p->queue.pop_front();
             job = p->jobs[ticket];
         }
-        const bool combined = p->comb && shg::combiner_enter(p->comb, &rec, st) == 0;
         int status = shg_scan_file(job.rq, job.rs, reinterpret_cast<shg_stream_t>(st));
         std::string err;
         if (status != 0) err = shg_last_error_string();
         if (job.ahead) (void)shg_pass_a_forget(job.rq->workspace);   // a scan that failed before it got to its pass
         // the caller may look at every output as soon as the ticket is done: the scan's last kernels have run by then
-        const int e = shg::stream_sync(st, "scan pool");
-        if (status == 0 && e != 0) { status = e; err = shg_last_error_string(); }
-        if (combined) shg::combiner_leave(p->comb);
+        const hipError_t e = hipStreamSynchronize(st);
+        if (status == 0 && e != hipSuccess) { status = (int)e; err = std::string("scan pool: ") + hipGetErrorString(e); }
         {
             std::lock_guard<std::mutex> lk(p->mu);
             shg_pool::Job& j = p->jobs[ticket];
@@ -92,12 +88,6 @@ extern "C" int shg_pool_create(const shg_stream_t* streams, int n_workers, const
     if (e != hipSuccess) { delete p; shg::set_error("shg_pool_create: %s", hipGetErrorString(e)); return (int)e; }
     for (int i = 0; i < n_workers; ++i) p->streams.push_back(shg::as_stream(streams[i]));
     for (int i = 0; i < n_cpus; ++i) p->cpus.push_back(host_cpus[i]);
-    {
-        const char* v = getenv("SHG_COMBINE");
-        // Off unless asked for (SHG_COMBINE=1): measured on MI355X it halves the dispatches of a batch (26 -> 10-13 per scan) and
-        // takes 3-4 % off pass A beside the chains, but the cohorts' rhythm costs a short batch as much at its ends
-        if (v && v[0] == '1' && n_workers > 1) p->comb = shg::combiner_create();         // (nullptr if its streams cannot be made: plain launches)
-    }
     try {
         for (int i = 0; i < n_workers; ++i) p->threads.emplace_back(pool_worker, p, i);
     } catch (...) {
@@ -107,7 +97,6 @@ extern "C" int shg_pool_create(const shg_stream_t* streams, int n_workers, const
         }
         p->cv_work.notify_all();
         for (auto& t : p->threads) t.join();
-        shg::combiner_destroy(p->comb);
         delete p;
         shg::set_error("shg_pool_create: cannot start %d threads", n_workers);
         return SHG_E_RUNTIME;
@@ -184,17 +173,7 @@ extern "C" int shg_pool_destroy(shg_pool* p) {
     }
     p->cv_work.notify_all();
     for (auto& t : p->threads) t.join();
-    shg::combiner_destroy(p->comb);
     delete p;
     return 0;
 }
 
-// What the pool's launch combiner has done so far: out3 = kernel launches the scans recorded, dispatches made for them, flushes.
-// All zero for a pool without one (SHG_COMBINE=0, or a single worker).
-extern "C" int shg_pool_combiner_stats(shg_pool* p, uint64_t* out3) {
-    SHG_REQUIRE(p && out3, SHG_E_ARG, "shg_pool_combiner_stats: null pointer");
-    unsigned long long v[3] = {0, 0, 0};
-    if (p->comb) shg::combiner_stats(p->comb, v);
-    for (int i = 0; i < 3; ++i) out3[i] = v[i];
-    return 0;
-}

@@ -114,7 +114,6 @@ int shg::crop_pad_batch(const uint16_t* const* host_srcs, int64_t k, int64_t h, 
     for (int64_t i0 = 0; i0 < k; i0 += shg::kMaxBatch) {
         const int m = (int)std::min<int64_t>(shg::kMaxBatch, k - i0);
         dim3 grid((unsigned)((nw + 255) / 256), (unsigned)h, (unsigned)m);
-        SHG_DIRECT(st);
         k_crop_pad<<<grid, 256, 0, st>>>(shg::make_batch(host_srcs, (int)i0, m), pitch, shg::make_batch(host_dsts, (int)i0, m), nw, dst_pitch, sx0, dx0, n,
                                          (uint16_t)(fill < 0 ? 0 : fill), fill < 0 ? 1 : 0);
         if (int e = shg::check_launch("k_crop_pad")) return e;
@@ -129,7 +128,6 @@ extern "C" int shg_rescale_u16(const uint16_t* img, int64_t h, int64_t w, int64_
     SHG_REQUIRE(65535.0 >= hi && hi > lo, SHG_E_ARG, "shg_rescale_u16: need sat >= hi > lo (got lo=%g hi=%g)", lo, hi);   // assert, solex_util.py:521
     SHG_REQUIRE(h < 65536, SHG_E_UNSUPPORTED, "shg_rescale_u16: more than 65535 rows");
     dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
-    SHG_DIRECT(shg::as_stream(stream));
     { SHG_PROF("rescale", shg::as_stream(stream)); k_rescale<<<grid, 256, 0, shg::as_stream(stream)>>>(img, w, pitch, 65535.0 * alpha, lo, hi - lo, dst, dst_pitch); }
     return shg::check_launch("k_rescale");
 }
@@ -141,7 +139,6 @@ extern "C" int shg_rescale_u8(const uint8_t* img, int64_t h, int64_t w, int64_t 
     SHG_REQUIRE(255.0 >= hi && hi > lo, SHG_E_ARG, "shg_rescale_u8: need sat >= hi > lo (got lo=%g hi=%g)", lo, hi);
     SHG_REQUIRE(h < 65536, SHG_E_UNSUPPORTED, "shg_rescale_u8: more than 65535 rows");
     dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
-    SHG_DIRECT(shg::as_stream(stream));
     { SHG_PROF("rescale", shg::as_stream(stream)); k_rescale_u8<<<grid, 256, 0, shg::as_stream(stream)>>>(img, w, pitch, 255.0 * alpha, lo, hi - lo, dst, dst_pitch); }
     return shg::check_launch("k_rescale_u8");
 }
@@ -154,7 +151,6 @@ extern "C" int shg_fill_disc_u16(uint16_t* img, int64_t h, int64_t w, int64_t pi
     SHG_REQUIRE(r >= 0 && r < 32768, SHG_E_UNSUPPORTED, "shg_fill_disc_u16: radius %lld out of range", (long long)r);
     hipStream_t st = shg::as_stream(stream);
     dim3 grid((unsigned)((2 * r + 1 + 255) / 256), (unsigned)(2 * r + 1));
-    SHG_DIRECT(st);
     { SHG_PROF("fill_disc", st); k_fill_disc<<<grid, 256, 0, st>>>(img, h, w, pitch, x0, y0, r, value); }
     return shg::check_launch("k_fill_disc");
 }
@@ -165,7 +161,6 @@ extern "C" int shg_downscale_mean_u16(const uint16_t* img, int64_t h, int64_t w,
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w && factor >= 1 && factor <= 64, SHG_E_ARG, "shg_downscale_mean_u16: bad size");
     const int64_t oh = (h + factor - 1) / factor, ow = (w + factor - 1) / factor;
     SHG_REQUIRE(oh * ow < (1ll << 31), SHG_E_UNSUPPORTED, "shg_downscale_mean_u16: image too large");
-    SHG_DIRECT(shg::as_stream(stream));
     { SHG_PROF("downscale", shg::as_stream(stream)); k_downscale_mean<<<(unsigned)((oh * ow + 255) / 256), 256, 0, shg::as_stream(stream)>>>(
           img, h, w, pitch, factor, oh, ow, (reinterpret_cast<uintptr_t>(img) & 7) == 0 && pitch % 4 == 0, dst); }
     return shg::check_launch("k_downscale_mean");
@@ -244,7 +239,7 @@ struct ProductsArgs {
     StatsSource stats;
 };
 
-SHG_MERGEABLE(k_products8, ProductsArgs, __launch_bounds__(256)) {
+__global__ __launch_bounds__(256) void k_products8(const ProductsArgs kargs) {
     const ProdPtrs& frames = kargs.frames;
     const ProdPtrs& cl1s = kargs.cl1s;
     const ProdPtrs& hcs = kargs.hcs;
@@ -414,12 +409,11 @@ int shg::contrast_products_batch(const uint16_t* const* host_frames, int64_t fra
         if (vec) {
             const int64_t lanes = ((w + 7) / 8) * ((h + PROD_ROWS - 1) / PROD_ROWS);
             dim3 grid((unsigned)((lanes + 255) / 256), 1u, (unsigned)m);
-            if (int e = SHG_LAUNCH(k_products8, grid, dim3(256), 0, st,
-                                   ProductsArgs{f, frame_pitch, c, cl1_pitch, h, w, bb, hc, pr, cc, dst_pitch, disc_x0, disc_y0, disc_r > 0 ? disc_r : 0, src}))
+            if (int e = shg::launch(k_products8, grid, dim3(256), 0, st,
+                                   ProductsArgs{f, frame_pitch, c, cl1_pitch, h, w, bb, hc, pr, cc, dst_pitch, disc_x0, disc_y0, disc_r > 0 ? disc_r : 0, src}, "k_products8"))
                 return e;
         } else {
             dim3 grid((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)m);
-            SHG_DIRECT(st);
             k_products<<<grid, 256, 0, st>>>(f, frame_pitch, c, cl1_pitch, w, bb, hc, pr, cc, dst_pitch, disc_x0, disc_y0, disc_r > 0 ? disc_r : 0, src);
             if (int e = shg::check_launch("k_products")) return e;
         }

@@ -18,9 +18,15 @@ inline int check_launch(const char* what) {
     return 0;
 }
 
-}  // namespace shg
-#include "launch.h"
-namespace shg {
+
+// One kernel launch with its error check: k(a) on `st`; `a` is the kernel's one trivially copyable argument struct.
+template <typename A>
+struct same_type { using type = A; };
+template <typename A>
+inline int launch(void (*k)(A), dim3 grid, dim3 block, size_t lds, hipStream_t st, const typename same_type<A>::type& a, const char* what) {
+    hipLaunchKernelGGL(k, grid, block, lds, st, a);
+    return check_launch(what);
+}
 
 #define SHG_REQUIRE(cond, code, ...)            \
     do {                                        \
@@ -85,8 +91,7 @@ struct PtrBatchN {
     __device__ __forceinline__ T* at(int i) const { return static_cast<T*>(const_cast<void*>(p[i])); }
 };
 using PtrBatch = PtrBatchN<kMaxBatch>;
-// (a kernel that takes several tables, or other per-disk arguments by value, takes fewer disks per launch and narrower tables: the
-// argument block of a dispatch shared by several scans -- launch.h -- holds one such set per scan)
+// (a kernel that takes several tables, or other per-disk arguments by value, takes narrower tables: 4 KB of kernel arguments in all)
 template <int N, typename T>
 inline PtrBatchN<N> make_batch_n(T* const* host_ptrs, int first, int count) {
     PtrBatchN<N> b = {};
@@ -125,13 +130,6 @@ bool contrast_stats_batches(int64_t h, int64_t w, int tiles, double clip_limit);
 int contrast_stats_batch(const uint16_t* const* host_frames, int64_t k, int64_t h, int64_t w, int64_t pitch, double clip_limit, int tiles,
                          uint16_t* const* host_cl1, int64_t cl1_pitch, const int64_t* ranks_frame2, const int64_t* ranks_cl13, double* out5,
                          void* workspace, size_t workspace_bytes, shg_stream_t stream, const FrameSource* from = nullptr);
-
-// The launch combiner of a scan pool (combine.hip; launch.h says what it is for)
-Combiner* combiner_create();
-void combiner_destroy(Combiner* c);
-int combiner_enter(Combiner* c, Recorder* rec, hipStream_t own);
-void combiner_leave(Combiner* c);
-void combiner_stats(Combiner* c, unsigned long long* out3);
 
 constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kCUs = 256;          // MI355X

@@ -43,12 +43,14 @@ struct Arena {
         if (int e_ = (expr)) return e_; \
     } while (0)
 
-// "The host needs what this stage has launched so far": hipStreamSynchronize -- or, on a thread of a scan pool, the point where
-// the scan's recorded launches go to the device together with the other scans' (launch.h).
+// "The host needs what this stage has launched so far."
 #define STAGE_SYNC(st, who)                                                \
     do {                                                                   \
         SHG_HOST_TIME("sync");                                             \
-        if (int se_ = shg::stream_sync(st, who)) return se_;               \
+        if (hipError_t se_ = hipStreamSynchronize(st)) {                   \
+            shg::set_error("%s: %s", who, hipGetErrorString(se_));         \
+            return (int)se_;                                               \
+        }                                                                  \
     } while (0)
 
 // ---- host <-> device without the copy engines ---------------------------------------------------------------
@@ -66,7 +68,7 @@ struct WordsArgs {
     uint32_t* zero;
     size_t zero_words;
 };
-SHG_MERGEABLE(k_words, WordsArgs, __launch_bounds__(256)) {
+__global__ __launch_bounds__(256) void k_words(const WordsArgs kargs) {
     uint32_t* __restrict__ dst = kargs.dst;
     const uint32_t* __restrict__ src = kargs.src;
     const size_t n_words = kargs.n_words;
@@ -75,7 +77,7 @@ SHG_MERGEABLE(k_words, WordsArgs, __launch_bounds__(256)) {
 
 // the same, and `zero_words` words at `zero` cleared on the way (a scratch area the next kernel accumulates into: one launch instead of a
 // copy and a memset -- every launch is an L2 write-back and invalidate under the other scans' kernels)
-SHG_MERGEABLE(k_words_zero, WordsArgs, __launch_bounds__(256)) {
+__global__ __launch_bounds__(256) void k_words_zero(const WordsArgs kargs) {
     uint32_t* __restrict__ dst = kargs.dst;
     const uint32_t* __restrict__ src = kargs.src;
     const size_t n_words = kargs.n_words, zero_words = kargs.zero_words;
@@ -98,7 +100,7 @@ inline int move_words(void* dst, const void* src, size_t bytes, hipStream_t st) 
     const size_t n_words = (bytes + 3) / 4;                      // arena slots are 256-byte aligned and padded
     if (n_words == 0) return 0;
     const unsigned blocks = (unsigned)std::min<size_t>((n_words + 255) / 256, 64);
-    return SHG_LAUNCH(k_words, dim3(blocks), dim3(256), 0, st, WordsArgs{static_cast<uint32_t*>(dst), static_cast<const uint32_t*>(src), n_words, nullptr, 0});
+    return shg::launch(k_words, dim3(blocks), dim3(256), 0, st, WordsArgs{static_cast<uint32_t*>(dst), static_cast<const uint32_t*>(src), n_words, nullptr, 0}, "k_words");
 }
 
 // The staging area as the GPU addresses it (the same address under unified addressing).
@@ -261,8 +263,8 @@ extern "C" int shg_stage_extract(const void* stack, int64_t n_frames, int64_t he
     if (minmax_slots) {                                  // the plan goes up and the extrema's slots are cleared in one launch
         const size_t n_words = ((size_t)(end - reinterpret_cast<const char*>(h_ind)) + 3) / 4, zero_words = (size_t)n_shifts * 130;
         const unsigned blocks = (unsigned)std::min<size_t>((std::max(n_words, zero_words) + 255) / 256, 64);
-        STAGE_TRY(SHG_LAUNCH(k_words_zero, dim3(blocks), dim3(256), 0, st,
-                             WordsArgs{reinterpret_cast<uint32_t*>(ind_l), reinterpret_cast<const uint32_t*>(stg.on_device(h_ind)), n_words, minmax_slots, zero_words}));
+        STAGE_TRY(shg::launch(k_words_zero, dim3(blocks), dim3(256), 0, st,
+                             WordsArgs{reinterpret_cast<uint32_t*>(ind_l), reinterpret_cast<const uint32_t*>(stg.on_device(h_ind)), n_words, minmax_slots, zero_words}, "k_words_zero"));
         shg::t_minmax_slots_zeroed = true;               // (read and reset by the extraction entry point this thread calls next)
     } else {
         STAGE_TRY(move_words(ind_l, stg.on_device(h_ind), (size_t)(end - reinterpret_cast<const char*>(h_ind)), st));
@@ -462,7 +464,6 @@ extern "C" int shg_stage_limb_points(const uint16_t* disk, int64_t h, int64_t w,
         const int radius = (int)(4.0 * sigma + 0.5);
         STAGE_TRY(shg_canny_masks_f64(blurred, sh, sw, thresh3, taps, radius, low, high, low_mask, high_mask, canny_ws, canny_bytes, stream));
         STAGE_TRY(shg_edge_components(low_mask, high_mask, sh, sw, comp + 1, comp + 1 + n, comp, cc_ws, cc_bytes, stream));
-        SHG_DIRECT(st);
         k_edge_list<<<16, 256, 0, st>>>(comp, n, stg.on_device(h_comp));                      // the device knows how many: one trip
         STAGE_TRY(shg::check_launch("k_edge_list"));
         STAGE_SYNC(st, "shg_stage_limb_points");

@@ -74,10 +74,8 @@ int on_frame_pass_lane(hipStream_t st, int (*launch)(hipStream_t, void*), void* 
     static const bool host_wait = [] { const char* v = getenv("SHG_LANE_WAIT"); return !(v && v[0] == 's'); }();
     if (e == hipSuccess) {
         SHG_HOST_TIME("lane wait (queue + pass A)");
-        if (host_wait || shg::t_rec) {                       // (a pool thread's later launches go through the combiner's streams, not `st`)
-            shg::pool_wait_begin();
+        if (host_wait) {
             e = hipEventSynchronize(ev);
-            shg::pool_wait_end();
         } else {
             e = hipStreamWaitEvent(st, ev, 0);
         }
@@ -107,7 +105,7 @@ int prelaunch_on_lane(hipStream_t after, int (*launch)(hipStream_t, void*), void
         }
         if (e == hipSuccess) {
             if (int le = launch(lane, arg)) {
-                (void)hipEventDestroy(before);
+                if (before) (void)hipEventDestroy(before);
                 (void)hipEventDestroy(ev);
                 return le;
             }

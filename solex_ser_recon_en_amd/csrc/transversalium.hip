@@ -283,7 +283,7 @@ struct RowpairArgs {
     int64_t out_stride;
 };
 
-SHG_MERGEABLE(k_rowpair_stats, RowpairArgs, __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8)))) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8))) void k_rowpair_stats(const RowpairArgs kargs) {
     const shg::PtrBatch& imgs = kargs.imgs;
     const int64_t pitch = kargs.pitch, y1 = kargs.y1, out_stride = kargs.out_stride;
     const int32_t* __restrict__ xa = kargs.xa;
@@ -506,7 +506,7 @@ struct CorrelateArgs {
     double* dst;
 };
 
-SHG_MERGEABLE(k_correlate1d_rows, CorrelateArgs, __launch_bounds__(256)) {
+__global__ __launch_bounds__(256) void k_correlate1d_rows(const CorrelateArgs kargs) {
     const double* __restrict__ src = kargs.src;
     const int64_t n = kargs.n;
     const double* __restrict__ weights = kargs.weights;
@@ -604,7 +604,6 @@ extern "C" int shg_line_order_stats_u16(const uint16_t* img, int64_t h, int64_t 
                 "shg_line_order_stats_u16: ranks [%lld, %lld] outside a line of %lld", (long long)rank_lo, (long long)rank_hi, (long long)n);
     hipStream_t st = shg::as_stream(stream);
     SHG_PROF("line_order_stats", st);
-    SHG_DIRECT(st);
     k_line_order_stats<<<(unsigned)lines, NT, 0, st>>>(img, pitch, (int)n, axis == 0 ? 1 : pitch, axis == 0 ? pitch : 1, (int)rank_lo,
                                                       (int)rank_hi, out_lo, out_hi);
     return shg::check_launch("k_line_order_stats");
@@ -637,7 +636,6 @@ int shg::rowpair_stats_batch(const uint16_t* const* host_imgs, int64_t k, int64_
     hipStream_t st = shg::as_stream(stream);
     const int64_t rows = y2 - y1 - 1, n = y2 - y1;
     if (rows <= 0) {                                     // a single row: its statistic is the leading 0 (the kernel writes it otherwise)
-        SHG_DIRECT(st);
         hipError_t e = hipMemsetAsync(out, 0, (size_t)k * sizeof(double), st);
         if (e == hipSuccess && out_mirror) e = hipMemsetAsync(out_mirror, 0, (size_t)k * sizeof(double), st);
         if (e != hipSuccess) {
@@ -648,14 +646,13 @@ int shg::rowpair_stats_batch(const uint16_t* const* host_imgs, int64_t k, int64_
     }
     const size_t lds_bytes = (size_t)w * sizeof(double);
     static const bool attr_set =                         // (a function-local static: initialised once, also with several pool threads here)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowpair_stats), hipFuncAttributeMaxDynamicSharedMemorySize, MAXN * 8) == hipSuccess &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowpair_stats_multi), hipFuncAttributeMaxDynamicSharedMemorySize, MAXN * 8) == hipSuccess;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowpair_stats), hipFuncAttributeMaxDynamicSharedMemorySize, MAXN * 8) == hipSuccess;
     (void)attr_set;
     SHG_PROF("rowpair_stats", st);
     for (int64_t i0 = 0; i0 < k; i0 += shg::kMaxBatch) {
         const int m = (int)std::min<int64_t>(shg::kMaxBatch, k - i0);
-        if (int e = SHG_LAUNCH(k_rowpair_stats, dim3((unsigned)rows, 1u, (unsigned)m), dim3(NT), lds_bytes, st,
-                               RowpairArgs{shg::make_batch(host_imgs, (int)i0, m), pitch, y1, xa, xb, row_factor, out + i0 * n, out_mirror ? out_mirror + i0 * n : nullptr, n}))
+        if (int e = shg::launch(k_rowpair_stats, dim3((unsigned)rows, 1u, (unsigned)m), dim3(NT), lds_bytes, st,
+                               RowpairArgs{shg::make_batch(host_imgs, (int)i0, m), pitch, y1, xa, xb, row_factor, out + i0 * n, out_mirror ? out_mirror + i0 * n : nullptr, n}, "k_rowpair_stats"))
             return e;
     }
     return 0;
@@ -669,11 +666,10 @@ extern "C" int shg_correlate1d_rows_f64(const double* src, int64_t k, int64_t n,
     hipStream_t st = shg::as_stream(stream);
     const size_t lds = (size_t)(256 + 4 * radius + 1) * sizeof(double);
     SHG_PROF("correlate1d_rows", st);
-    static const bool attr_set = hipFuncSetAttribute(reinterpret_cast<const void*>(k_correlate1d_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 4 * CORR_MAXR + 1) * 8) == hipSuccess &&
-                                 hipFuncSetAttribute(reinterpret_cast<const void*>(k_correlate1d_rows_multi), hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 4 * CORR_MAXR + 1) * 8) == hipSuccess;
+    static const bool attr_set = hipFuncSetAttribute(reinterpret_cast<const void*>(k_correlate1d_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (256 + 4 * CORR_MAXR + 1) * 8) == hipSuccess;
     (void)attr_set;
-    return SHG_LAUNCH(k_correlate1d_rows, dim3((unsigned)((n + 255) / 256), (unsigned)k), dim3(256), lds, st,
-                      CorrelateArgs{src, n, weights, radius, symmetric > 0 ? 1 : (symmetric < 0 ? -1 : 0), dst});
+    return shg::launch(k_correlate1d_rows, dim3((unsigned)((n + 255) / 256), (unsigned)k), dim3(256), lds, st,
+                      CorrelateArgs{src, n, weights, radius, symmetric > 0 ? 1 : (symmetric < 0 ? -1 : 0), dst}, "k_correlate1d_rows");
 }
 
 extern "C" int shg_scale_rows_u16(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, const double* c,
@@ -699,7 +695,6 @@ int shg::scale_rows_batch(const uint16_t* const* host_imgs, int64_t k, int64_t h
     for (int64_t i0 = 0; i0 < k; i0 += shg::kMaxBatch) {
         const int m = (int)std::min<int64_t>(shg::kMaxBatch, k - i0);
         const shg::PtrBatch src = shg::make_batch(host_imgs, (int)i0, m), dst = shg::make_batch(host_dsts, (int)i0, m);
-        SHG_DIRECT(st);
         if (vec) {                                       // eight pixels per lane: 16-byte loads and stores
             const int64_t lanes = ((w + 7) / 8) * ((h + SCALE_ROWS - 1) / SCALE_ROWS);
             dim3 grid((unsigned)((lanes + 255) / 256), 1u, (unsigned)m);

@@ -70,7 +70,7 @@ struct WarpArgs {
     WarpPtrs mms;
 };
 
-SHG_MERGEABLE(k_warp_rows, WarpArgs, __launch_bounds__(256)) {
+__global__ __launch_bounds__(256) void k_warp_rows(const WarpArgs kargs) {
     const WarpPtrs& srcs = kargs.srcs;
     const WarpPtrs& dsts = kargs.dsts;
     const WarpPtrs& mms = kargs.mms;
@@ -129,7 +129,6 @@ extern "C" int shg_warp_rows_u16(const uint16_t* src, int64_t h, int64_t w, int6
     SHG_REQUIRE(src_pitch >= w && dst_pitch >= out_w, SHG_E_ARG, "shg_warp_rows_u16: pitch smaller than width");
     SHG_REQUIRE(out_h < 65536, SHG_E_UNSUPPORTED, "shg_warp_rows_u16: more than 65535 rows");
     hipStream_t st = shg::as_stream(stream);
-    SHG_DIRECT(st);
     { SHG_PROF("minmax", st); k_minmax_init<<<1, 1, 0, st>>>(minmax); }
     int64_t blocks = h < 256 ? h : 256;
     { SHG_PROF("minmax", st); k_minmax<<<(unsigned)blocks, 256, 0, st>>>(src, h, w, src_pitch, minmax); }
@@ -164,9 +163,9 @@ int shg::warp_rows_batch(const uint16_t* const* host_srcs, int64_t k, int64_t h,
         for (int d = 0; d < m; ++d)
             for (int j = 0; j < 3; ++j) rows.h[d][j] = host_h3[3 * (i0 + d) + j];
         dim3 grid((unsigned)((out_w + 255) / 256), (unsigned)((out_h + WARP_ROWS - 1) / WARP_ROWS), (unsigned)m);
-        if (int e = SHG_LAUNCH(k_warp_rows, grid, dim3(256), 0, st,
+        if (int e = shg::launch(k_warp_rows, grid, dim3(256), 0, st,
                                WarpArgs{shg::make_batch_n<kWarpBatch>(host_srcs, (int)i0, m), h, w, src_pitch, rows, shg::make_batch_n<kWarpBatch>(host_dsts, (int)i0, m),
-                                        out_h, out_w, dst_pitch, shg::make_batch_n<kWarpBatch>(host_minmax2, (int)i0, m)}))
+                                        out_h, out_w, dst_pitch, shg::make_batch_n<kWarpBatch>(host_minmax2, (int)i0, m)}, "k_warp_rows"))
             return e;
     }
     return 0;

@@ -5,7 +5,9 @@ blocks, RCCL (torch.distributed backend "nccl") over xGMI for the two exchange s
     frame (ih*iw*8 + ih*iw*4 bytes: 1.6 MB + 0.8 MB at 2000x200).  Integer reductions are
     order independent, so every rank count gives bit-identical mean/max images;
   * after pass B  -- all-reduce SUM of the zero-initialised disk mosaic [S, ih, n_total] into
-    which every rank has extracted the columns of its own frames (16 MB at S=2, C3).
+    which every rank has extracted the columns of its own frames (16 MB at S=2, C3); in a series of
+    sharded scans a reduce to the scan's owner (scan k belongs to rank k mod G, scan_owner), who alone
+    post-processes it and writes its files.
 
 Both messages are small: the collectives are latency-bound, the per-link xGMI bandwidth
 does not bind.  Everything after the gather (fit of the limb, warp, transversalium, CLAHE)
@@ -69,8 +71,15 @@ def mosaic_columns(frame_range, n_total, flip_x=False):
     return (n_total - k1, n_total - k0) if flip_x else (k0, k1)
 
 
-def gather_columns(fill, n_shifts, ih, frame_range, n_total, flip_x, device):
-    """The full disks [S, ih, n_total] on every rank from per-rank column blocks, with ONE collective and no
+def scan_owner(index):
+    """The rank that post-processes scan `index` of a series of frame-sharded scans and writes its files: index mod world, so that
+    the tails of consecutive scans (limb fit, warp, transversalium, CLAHE, encoders) run on different GPUs at the same time."""
+    return int(index) % world_size()
+
+
+def gather_columns(fill, n_shifts, ih, frame_range, n_total, flip_x, device, dst=None):
+    """The full disks [S, ih, n_total] on every rank (dst None) or on rank `dst` only (the other ranks get their own partial
+    mosaic back and must not use it) from per-rank column blocks, with ONE collective and no
     re-layout pass: every rank extracts the columns of its own frames straight into a zeroed mosaic
     (`fill(mosaic, k0)` -- shg_extract_columns takes the column offset and the flip), then the mosaic is
     all-reduced with SUM.  Column blocks are disjoint, so every 16-bit cell receives one non-zero contribution:
@@ -84,12 +93,19 @@ def gather_columns(fill, n_shifts, ih, frame_range, n_total, flip_x, device):
     mosaic = torch.zeros((n_shifts, ih, pitch), dtype=torch.uint16, device=device)
     fill(mosaic[:, :, :n_total], int(frame_range[0]))
     words = mosaic.view(torch.int32)
+
+    def exchange(t):
+        if dst is None:
+            td.all_reduce(t, op=td.ReduceOp.SUM)
+        else:
+            td.reduce(t, dst=int(dst), op=td.ReduceOp.SUM)         # half an all-reduce's traffic: only the owner needs the mosaic
     if _staged(words):
         host = words.cpu()
-        td.all_reduce(host, op=td.ReduceOp.SUM)
-        words.copy_(host)
+        exchange(host)
+        if dst is None or rank() == int(dst):
+            words.copy_(host)
     else:
-        td.all_reduce(words, op=td.ReduceOp.SUM)
+        exchange(words)
     return mosaic[:, :, :n_total]
 
 

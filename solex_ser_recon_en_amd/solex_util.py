@@ -115,15 +115,15 @@ def compute_mean_return_fit(vid_rdr, options, hdr, iw, ih, basefich0):
 
 
 # ---- a5: per-frame column extraction (reference solex_util.py:93-144) ---------------------
-def extract_disks(rdr, fit, shifts, flip_x=False, want_minmax=False):
-    """-> uint16 GPU tensor [S, ih, FrameCount]; all ranks hold the full mosaic when sharded.  One stage call
-    (shg_stage_extract): sample columns and weights from `fit` (:113-123), upload, the extraction kernel.
+def extract_disks(rdr, fit, shifts, flip_x=False, want_minmax=False, owner=None):
+    """-> uint16 GPU tensor [S, ih, FrameCount]; when sharded all ranks hold the full mosaic (owner None) or rank `owner`
+    alone does.  One stage call (shg_stage_extract): sample columns and weights from `fit` (:113-123), upload, the extraction kernel.
     want_minmax: -> (disks, extrema slots int32 [S, 2] or None for a sharded scan)."""
     stack = rdr.device_stack()
     n_total = int(rdr.FrameCount)
     if dist.is_sharded(rdr):
         mosaic = dist.gather_columns(lambda out, k0: stages.extract(stack, fit, shifts, n_cols=n_total, k_offset=k0, flip_x=flip_x, out=out),
-                                     len(shifts), int(rdr.ih), rdr.frame_range, n_total, flip_x, stack.device)
+                                     len(shifts), int(rdr.ih), rdr.frame_range, n_total, flip_x, stack.device, dst=owner)
         return (mosaic, None) if want_minmax else mosaic
     return stages.extract(stack, fit, shifts, n_cols=n_total, k_offset=0, flip_x=flip_x, want_minmax=want_minmax)
 

@@ -138,3 +138,54 @@ def test_sharding_protocol_on_every_rank(tmp_path, world):
         report = eval(str(np.load(str(tmp_path / ('report%d.npy' % r)))[0]))      # noqa: S307 -- our own repr
         assert report['refused'] is True and report['dealt_once'] and report['balanced'] and report['agreed'] and report['after'], (r, report)
         assert report['failure'] == ('own' if r == 0 else 'told'), (r, report)
+
+
+def _series_worker(rank, world, port, stacks, fit, shifts, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    td.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        owned = {}
+        for i, frames in enumerate(stacks):                  # a series of sharded scans: the collectives in file order on every rank
+            n = frames.shape[0]
+            k0, k1 = dist.frame_block(n)
+            flip = bool(i & 1)
+            local_disks = np.stack(orc.extract_columns(orc.SerReader(frames, k0, k1), fit, shifts))[:, :, k0:k1]
+
+            def fill(mosaic, k_offset):
+                c0, c1 = dist.mosaic_columns((k0, k1), n, flip)
+                block = local_disks[:, :, ::-1] if flip else local_disks
+                mosaic.view(torch.int16)[:, :, c0:c1] = torch.from_numpy(block.copy().view(np.int16))
+            owner = dist.scan_owner(i)
+            assert owner == i % world
+            full = dist.gather_columns(fill, len(shifts), local_disks.shape[1], (k0, k1), n, flip, torch.device('cpu'), dst=owner)
+            if rank == owner:                                # only the owner may look at the mosaic
+                owned[str(i)] = full.contiguous().view(torch.int16).numpy().view(np.uint16)
+        np.savez(os.path.join(out_dir, 'owned%d.npz' % rank), **owned)
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3, 8])
+def test_series_of_sharded_scans_each_reduced_to_its_owner(tmp_path, world):
+    """Scan k of a series belongs to rank k mod G (Solex_recon._sharded_series): its mosaic is REDUCED to that rank, which alone
+    post-processes it.  Ten scans of different lengths (uneven frame blocks, some fewer frames per rank than others, every second one
+    mirrored): every scan has exactly one owner and the owner's mosaic is the unsharded oracle's, bit for bit."""
+    ih, iw = 96, 40
+    curve = np.linspace(3.2, iw - 5.1, ih)
+    fit = np.stack([np.floor(curve), curve - np.floor(curve), np.arange(ih), curve], axis=1)
+    shifts = [10, 0]
+    stacks = [synth.synth_frames_numpy(17 + 3 * i, ih, iw, 16, seed=20 + i) for i in range(10)]
+    mp.spawn(_series_worker, args=(world, _free_port(), stacks, fit, shifts, str(tmp_path)), nprocs=world, join=True)
+    seen = {}
+    for r in range(world):
+        got = np.load(str(tmp_path / ('owned%d.npz' % r)))
+        for key in got.files:
+            assert key not in seen, 'scan %s has two owners' % key
+            seen[key] = (r, got[key])
+    assert sorted(seen, key=int) == [str(i) for i in range(10)]
+    for i, frames in enumerate(stacks):
+        r, full = seen[str(i)]
+        assert r == i % world
+        want = np.stack(orc.extract_columns(orc.SerReader(frames), fit, shifts))
+        np.testing.assert_array_equal(full, want[:, :, ::-1] if i & 1 else want)

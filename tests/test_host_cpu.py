@@ -400,3 +400,18 @@ def test_upload_reader_direct_and_buffered_reads_agree(tmp_path, monkeypatch):
     finally:
         mv.release()
         buf.close()
+
+
+def test_bench_starts_its_ranks_and_reports_a_rank_that_fails():
+    """bench.py --gpus 2 with no launcher around it starts two rank processes itself (before it imports torch): here, without a
+    GPU, both ranks stop with 'needs a GPU' and bench.py exits non-zero with them, printing no JSON line."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['HIP_VISIBLE_DEVICES'] = ''
+    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=env, cwd=repo, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count('bench.py needs a GPU') == 2, r.stderr[-2000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]

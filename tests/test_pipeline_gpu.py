@@ -794,3 +794,37 @@ def test_one_call_route_fails_like_the_stage_route(pkg, tmp_path, monkeypatch, n
     # (a failure inside the library names the entry point the caller went through: 'shg_stage_mean_fit failed ...')
     assert type(a_err) is type(b_err) and str(a_err).split(' failed ')[-1] == str(b_err).split(' failed ')[-1]
     assert a_log == b_log
+
+
+@pytest.mark.parametrize('mode', ['folder', 'sharded'])
+def test_bench_launches_its_own_ranks(mode):
+    """`python bench.py --gpus 2` with NO launcher around it (no WORLD_SIZE): bench.py starts the two ranks itself, before it
+    touches the GPU, and rank 0 prints the one JSON line.  Both ranks share this GPU over gloo (SHG_DIST_BACKEND); small scans.
+    folder: two scans per rank, no collective on the data path, and the sharded_c3 leg (a file sharded over the ranks) beside it;
+    sharded: the timed scans themselves are sharded.  The line must say what ran -- world size, backend, collectives -- and the
+    sharded products must be those of one rank."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(SHG_DIST_BACKEND='gloo', PYTHONPATH=repo)
+    cmd = [sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--repeats', '2', '--frames', '250',
+           '--width', '640', '--height', '48', '--mode', mode, '--no-extra', '--e2e-files', '2', '--c3-scans', '2', '--c3-frames', '600']
+    r = subprocess.run(cmd, env=env, cwd=repo, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['config']['world_size'] == 2 and line['config']['backend'] == 'gloo'
+    assert line['steps'] == 4 and line['warmup'] == 2 and line['value'] > 0 and line['cpu_baseline'] is None
+    if mode == 'sharded':
+        assert line['scaling'] == 'strong' and line['config']['mode'] == 'sharded' and line['config']['collectives_per_scan'] > 0
+        par = line['parity_vs_one_rank']
+        assert par['images_compared'] == 2 and par['images_that_differ'] == 0, par
+    else:
+        assert line['scaling'] == 'weak' and line['config']['mode'] == 'folder' and line['config']['collectives_per_scan'] == 0
+        c3 = line['sharded_c3']
+        assert c3['world_size'] == 2 and c3['backend'] == 'gloo' and c3['collectives_per_scan'] > 0, c3
+        assert c3['parity_vs_one_rank']['images_compared'] == 2 and c3['parity_vs_one_rank']['images_that_differ'] == 0, c3
+        assert line['e2e']['value'] > 0 and line['value_decode_inclusive'] == line['e2e']['value'] and line['e2e']['h2d_ceiling_GBps'] > 0
