@@ -111,6 +111,24 @@ __device__ __forceinline__ uint32_t scale_px(uint32_t px, double cy) {        //
     return (uint32_t)(int)v;
 }
 
+// The same value with one fused multiply-add instead of a conversion and a multiplication: D = 2^52 + px is exact (the integer sits in
+// the low mantissa bits), D * cy - 2^52 * cy is px * cy exactly, and the fma rounds it once -- as fl((double)px * cy) does.  kc = 2^52 * cy
+// must be finite (rows_factor_for_fma); the conversion to int saturates, so the clamp is an integer minimum.  (The kernel's time was
+// its VALU work: 23 instructions a pixel, the two conversions at a quarter of the rate.)
+__device__ __forceinline__ uint32_t scale_px_fma(uint32_t px, double cy, double kc) {
+    const double d = __hiloint2double(0x43300000, (int)px);
+    const int q = __double2int_rz(__builtin_fma(d, cy, -kc));          // NaN -> 0, out of range -> INT_MAX / INT_MIN
+    return (uint32_t)min(q, 65535);
+}
+// A row factor the fma form cannot take (NaN, or so large that 2^52 * c overflows) replaced by one that gives the same pixels:
+// NaN -> every pixel (int)NaN = 0 = px * 0; huge -> 0 stays 0, everything else saturates = px * 65536; hugely negative alike.
+__device__ __forceinline__ double row_factor_for_fma(double c) {
+    if (c != c) return 0.0;
+    if (c > 0x1p+960) return 65536.0;
+    if (c < -0x1p+960) return -4294967296.0;
+    return c;
+}
+
 struct HistSlicesArgs {
     shg::PtrBatch imgs;
     int64_t h, w, pitch;
@@ -120,9 +138,17 @@ struct HistSlicesArgs {
     size_t zs;
     int slice_rows, vec;
     FusedSrc fs;
+    int clip, chunk_rows;            // BITS < 16 only
 };
 
-template <bool FUSED> __global__ __launch_bounds__(1024) void k_tile_hist16_slices(const HistSlicesArgs kargs) {
+// BITS = 16: a slice is fewer than 65536 pixels and its u16 counters are stored as they are (128 KB a slice).
+// BITS = 8 / 4: SATURATED counters.  All CLAHE does with a tile's histogram is clip it -- min(count, clip), and the clipped-off excess
+// area - sum of min(count, clip) -- and min(a + b, c) = min(min(a, c) + b, c) for counts, so a slice may forget everything above
+// `clip` (12 at 2000 x 2098 px on a 2 x 2 grid, 20 at 2560 x 2675): the workgroup counts `chunk_rows` rows at a time (fewer than
+// 65536 - 255 pixels: the u16 counters cannot wrap), clamps its counters to `clip` between chunks, and stores them as bytes
+// (clip <= 255) or nibbles (clip <= 15): a slice of any length leaves 64 or 32 KB instead of 128 KB per 65535 pixels.
+// The frame's highest order statistics survive the clamping too (hist_rank_top_job).
+template <bool FUSED, int BITS> __global__ __launch_bounds__(1024) void k_tile_hist16_slices(const HistSlicesArgs kargs) {
     const shg::PtrBatch& imgs = kargs.imgs;
     const int64_t h = kargs.h, w = kargs.w, pitch = kargs.pitch, th = kargs.th, tw = kargs.tw;
     const int tiles = kargs.tiles, slice_rows = kargs.slice_rows, vec = kargs.vec;
@@ -149,23 +175,37 @@ template <bool FUSED> __global__ __launch_bounds__(1024) void k_tile_hist16_slic
         // the factors of this slice's rows (they may live in the host's staging area: one trip for all of them, here) and the
         // value of the padding columns
         const double* c = scaled ? fs.c + (int64_t)blockIdx.z * h : nullptr;
-        for (int i = threadIdx.x; i <= yb - ya; i += 1024) cf[i] = scaled ? c[ty * th + ya + i] : 1.0;
+        for (int i = threadIdx.x; i <= yb - ya; i += 1024) cf[i] = scaled ? row_factor_for_fma(c[ty * th + ya + i]) : 1.0;
         if (threadIdx.x == 0) fill_s = scaled ? scale_px(raw[0], c[0]) : (uint32_t)raw[0];
     }
     __syncthreads();
-    {
+    const int chunk_rows = BITS == 16 ? slice_rows : kargs.chunk_rows;
+    const uint32_t clip2 = (uint32_t)kargs.clip;
+    for (int ca = ya; ca <= yb; ca += chunk_rows) {
+        const int cb = min(yb, ca + chunk_rows - 1);
+        if (BITS != 16 && ca != ya) {                        // between chunks: forget what lies above the clip limit
+            __syncthreads();
+            for (int i = threadIdx.x; i < HIST16 / 8; i += 1024) {
+                uint4 q = reinterpret_cast<uint4*>(lh)[i];
+                uint32_t* d = reinterpret_cast<uint32_t*>(&q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[j] = min(d[j] & 0xffffu, clip2) | (min(d[j] >> 16, clip2) << 16);
+                reinterpret_cast<uint4*>(lh)[i] = q;
+            }
+            __syncthreads();
+        }
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int twi = (int)tw;
         const int64_t xbase = tx * tw;
-        auto count = [&](uint32_t v) { atomicAdd(&lh[v >> 1], (v & 1) ? 0x10000u : 1u); };
+        auto count = [&](uint32_t v) { atomicAdd(&lh[v >> 1], 1u << ((v & 1u) << 4)); };
         if (vec) {
             // rows of 16-byte vectors, none reflected: a wave takes two rows a round (its share of a 65535-pixel slice is four),
             // three vectors of each per lane, all six loads in flight before the first count -- pixel by pixel the wave waited
             // for memory a dozen times per slice, which is what this kernel's time was
             // (FUSED with vec: no crop -- the frame's columns are the image's)
             const int nvr = twi / 8;
-            for (int yy = ya + wave; yy <= yb; yy += 32) {
-                const bool two = yy + 16 <= yb;
+            for (int yy = ca + wave; yy <= cb; yy += 32) {
+                const bool two = yy + 16 <= cb;
                 int64_t y0 = ty * th + yy, y1 = ty * th + (two ? yy + 16 : yy);
                 if (!FUSED) {
                     if (y0 >= h) y0 = shg::reflect101(y0, h);
@@ -174,6 +214,7 @@ template <bool FUSED> __global__ __launch_bounds__(1024) void k_tile_hist16_slic
                 const uint4* r0 = reinterpret_cast<const uint4*>((FUSED ? raw + y0 * fs.raw_pitch : img + y0 * pitch) + xbase);
                 const uint4* r1 = reinterpret_cast<const uint4*>((FUSED ? raw + y1 * fs.raw_pitch : img + y1 * pitch) + xbase);
                 const double c0 = FUSED ? cf[yy - ya] : 1.0, c1 = FUSED ? cf[(two ? yy + 16 : yy) - ya] : 1.0;
+                const double k0 = c0 * 0x1p+52, k1 = c1 * 0x1p+52;
                 for (int v0 = lane; v0 < nvr; v0 += 64 * 3) {
                     uint4 q[2][3];
 #pragma unroll
@@ -191,9 +232,9 @@ template <bool FUSED> __global__ __launch_bounds__(1024) void k_tile_hist16_slic
                             uint32_t d[4] = {q[rr][u].x, q[rr][u].y, q[rr][u].z, q[rr][u].w};
                             if (FUSED) {
                                 if (scaled) {
-                                    const double cy = rr ? c1 : c0;
+                                    const double cy = rr ? c1 : c0, kc = rr ? k1 : k0;
 #pragma unroll
-                                    for (int j = 0; j < 4; ++j) d[j] = scale_px(d[j] & 0xffffu, cy) | (scale_px(d[j] >> 16, cy) << 16);
+                                    for (int j = 0; j < 4; ++j) d[j] = (scale_px_fma(d[j] & 0xffffu, cy, kc) & 0xffffu) | (scale_px_fma(d[j] >> 16, cy, kc) << 16);
                                 }
                                 uint4* dst = reinterpret_cast<uint4*>(fin + (rr ? y1 : y0) * pitch + xbase);
                                 dst[v0 + 64 * u] = make_uint4(d[0], d[1], d[2], d[3]);
@@ -205,11 +246,11 @@ template <bool FUSED> __global__ __launch_bounds__(1024) void k_tile_hist16_slic
                 }
             }
         } else {
-            for (int yy = ya + wave; yy <= yb; yy += 16) {
+            for (int yy = ca + wave; yy <= cb; yy += 16) {
                 int64_t y = ty * th + yy;
                 if (!FUSED && y >= h) y = shg::reflect101(y, h);
                 const uint16_t* row = FUSED ? raw + y * fs.raw_pitch : img + y * pitch;
-                const double cy = FUSED ? cf[yy - ya] : 1.0;
+                const double cy = FUSED ? cf[yy - ya] : 1.0, kc = cy * 0x1p+52;
                 const uint32_t fill = FUSED ? fill_s : 0u;
                 // eight loads in flight per lane before the first count: one load per trip left this kernel waiting on memory
                 // latency 33 times over (20 us)
@@ -233,7 +274,7 @@ template <bool FUSED> __global__ __launch_bounds__(1024) void k_tile_hist16_slic
                     for (int u = 0; u < 8; ++u) {
                         if (x0 + 64 * u >= twi) continue;
                         if (FUSED) {
-                            v[u] = inside[u] ? (scaled ? scale_px(v[u], cy) : v[u]) : fill;
+                            v[u] = inside[u] ? (scaled ? scale_px_fma(v[u], cy, kc) & 0xffffu : v[u]) : fill;
                             fin[y * pitch + xbase + x0 + 64 * u] = (uint16_t)v[u];
                         }
                         count(v[u]);
@@ -243,8 +284,28 @@ template <bool FUSED> __global__ __launch_bounds__(1024) void k_tile_hist16_slic
         }
     }
     __syncthreads();
-    uint32_t* out = part + ((int64_t)tile * gridDim.x + blockIdx.x) * (HIST16 / 2);
-    for (int i = threadIdx.x; i < HIST16 / 8; i += 1024) reinterpret_cast<uint4*>(out)[i] = reinterpret_cast<const uint4*>(lh)[i];
+    if (BITS == 16) {
+        uint32_t* out = part + ((int64_t)tile * gridDim.x + blockIdx.x) * (HIST16 / 2);
+        for (int i = threadIdx.x; i < HIST16 / 8; i += 1024) reinterpret_cast<uint4*>(out)[i] = reinterpret_cast<const uint4*>(lh)[i];
+    } else {
+        // Stored word O folds the LDS words O, O + NW, ... (KF of them: NW = 32768 / KF stored words a slice), two fields each -- lanes
+        // walk the LDS and the slice 16 bytes apart (a lane packing KF adjacent LDS quads read them 16 x KF bytes apart: 16 lanes on the
+        // same banks, 7 us of a 19 us kernel).  So bin b sits in word (b / 2) % NW, field 2 * ((b / 2) / NW) + b % 2 (k_hist_reduce_sat).
+        constexpr int KF = 16 / BITS;                        // 4 (nibbles), 2 (bytes)
+        constexpr int NQ = HIST16 / 8 / KF;                  // stored quads a slice
+        uint4* out = reinterpret_cast<uint4*>(part + ((int64_t)tile * gridDim.x + blockIdx.x) * (HIST16 * BITS / 32));
+        for (int q = threadIdx.x; q < NQ; q += 1024) {
+            uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < KF; ++k) {
+                const uint4 v = reinterpret_cast<const uint4*>(lh)[q + NQ * k];
+                const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] |= (min(d[j] & 0xffffu, clip2) | (min(d[j] >> 16, clip2) << BITS)) << (2 * BITS * k);
+            }
+            out[q] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
 }
 
 // grid (32, ntiles) x 1024 threads: lane d of the tile owns the counter pair d = bins 2d, 2d + 1.
@@ -313,6 +374,95 @@ __global__ __launch_bounds__(1024) void k_hist_reduce(const HistReduceArgs kargs
     }
 }
 
+// The saturated slices of a tile added up, clamped again and stored as bytes: hist8 [tile][65536] = min(count, clip); kept512 [tile][128] =
+// the clipped total of every 512 bins (the excess of the tile is its area minus their sum: k_tile_lut16_blocks<true>); chunk_tile
+// [tile][1024] = the clamped counts of every 64 bins (hist_rank_top_job).
+// grid (stored quads / 64, ntiles, disks) x 256 threads: lane l of every wave owns stored quad 64 * blockIdx.x + l -- KF runs of 8
+// consecutive bins, see the packing in k_tile_hist16_slices -- and wave g adds the slices g, g + 4, ...; wave 0 adds the four up.
+template <int BITS> __global__ __launch_bounds__(256) void k_hist_reduce_sat(const HistReduceArgs kargs) {
+    constexpr int KF = 16 / BITS;
+    constexpr int NQ = HIST16 / 8 / KF;
+    constexpr int NA = BITS == 8 ? 8 : 16;                  // 16-bit sums, two to a register
+    const int slices = kargs.slices, sel_words = kargs.sel_words;
+    const uint32_t clip = (uint32_t)kargs.clip;
+    const size_t zs = kargs.zs;
+    __shared__ uint32_t partial[3][NA][64];
+    if (kargs.sel_zero && blockIdx.x == 0 && blockIdx.y == 0) {
+        uint32_t* z = zdisk(kargs.sel_zero, zs, blockIdx.z);
+        for (int i = threadIdx.x; i < sel_words; i += 256) z[i] = 0;
+    }
+    const uint32_t* __restrict__ part = zdisk(kargs.part, zs, blockIdx.z);
+    uint8_t* __restrict__ hist8 = reinterpret_cast<uint8_t*>(zdisk(kargs.hist, zs, blockIdx.z));
+    uint32_t* __restrict__ chunk_tile = zdisk(kargs.chunk_tile, zs, blockIdx.z);
+    int32_t* __restrict__ kept512 = zdisk(kargs.se, zs, blockIdx.z);
+    const int tile = blockIdx.y, lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + lane;
+    const uint4* p = reinterpret_cast<const uint4*>(part + (int64_t)tile * slices * (NQ * 4)) + q;
+    uint32_t acc[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = 0;
+    auto add = [&](const uint4& v) {
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (BITS == 8) {                                 // fields 0, 2 and 1, 3
+                acc[2 * j] += d[j] & 0x00ff00ffu;
+                acc[2 * j + 1] += (d[j] >> 8) & 0x00ff00ffu;
+            } else {                                         // fields i and i + 4
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[4 * j + i] += (d[j] >> (4 * i)) & 0x000f000fu;
+            }
+        }
+    };
+    int s = grp;
+    for (; s + 12 < slices; s += 16) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = p[(int64_t)(s + 4 * u) * NQ];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) add(v[u]);
+    }
+    for (; s < slices; s += 4) add(p[(int64_t)s * NQ]);
+    if (grp != 0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) partial[grp - 1][i][lane] = acc[i];
+    }
+    __syncthreads();
+    if (grp != 0) return;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] += partial[0][i][lane] + partial[1][i][lane] + partial[2][i][lane];
+    // field f of stored word j (f = 2 k + half): bin 8 q + 16384 (8 / KF ... ) -- run k starts at bin 8 q + (HIST16 / KF) k, word j holds its bins 2 j, 2 j + 1
+#pragma unroll
+    for (int k = 0; k < KF; ++k) {
+        uint32_t o[2] = {0, 0};
+        int kept = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int f = 2 * k + half;
+                uint32_t c;
+                if (BITS == 8) c = f < 2 ? (acc[2 * j + f] & 0xffffu) : (acc[2 * j + f - 2] >> 16);           // fields (0, 2) (1, 3)
+                else c = f < 4 ? (acc[4 * j + f] & 0xffffu) : (acc[4 * j + f - 4] >> 16);                    // fields (i, i + 4)
+                const uint32_t m = min(c, clip);
+                kept += (int)m;
+                const int bin8 = 2 * j + half;
+                o[bin8 >> 2] |= m << (8 * (bin8 & 3));
+            }
+        }
+        const int b0 = 8 * q + (HIST16 / KF) * k;
+        *reinterpret_cast<uint2*>(hist8 + (int64_t)tile * HIST16 + b0) = make_uint2(o[0], o[1]);
+        int t = kept;
+        t += __shfl_xor(t, 1);
+        t += __shfl_xor(t, 2);
+        t += __shfl_xor(t, 4);
+        if ((lane & 7) == 0) chunk_tile[tile * 1024 + (b0 >> 6)] = (uint32_t)t;
+#pragma unroll
+        for (int d = 8; d <= 32; d <<= 1) t += __shfl_xor(t, d);
+        if (lane == 0) kept512[tile * 128 + (b0 >> 9)] = t;
+    }
+}
+
 // The tile LUT (clip, redistribute, prefix sum, scale: as k_tile_lut16_lds) by 32 workgroups per tile, 2048 bins each:
 // the counts before a workgroup's first bin are the clipped totals of the workgroups before it, plus what the
 // redistribution adds there -- `batch` per bin and one more for the bins 0, step, 2 step, ... below residual * step.
@@ -353,6 +503,45 @@ __device__ __forceinline__ void hist_rank_job(const uint32_t* __restrict__ hist,
     if (below + inc2 - c <= rank && rank < below + inc2) *out = (double)(chunk * 64 + lane);
 }
 
+// The same order statistic off SATURATED histograms (hist8 [tile][65536] = min(count, clip) and their 64-bin sums, k_hist_reduce_sat):
+// the K-th LARGEST pixel of the image, K <= clip.  Exact: walking down from the top bin, the true count above the answer's bin is
+// below K <= clip, so no (tile, bin) up there was clamped and the clamped sums are the true ones; at the answer's bin the running sum
+// reaches K whether that bin was clamped (a clamped bin alone holds clip >= K) or not.  One workgroup of 1024: lane t takes the 64-bin
+// run 1023 - t, a workgroup scan finds the run that reaches K, wave 0 scans its bins from the top.
+__device__ __forceinline__ void hist_rank_top_job(const uint8_t* __restrict__ hist8, const uint32_t* __restrict__ chunk_tile, int ntiles, int64_t k_top,
+                                                  double* __restrict__ out) {
+    __shared__ int wtot[16];
+    __shared__ int pick[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = 1023 - tid;
+    int local = 0;
+    for (int t = 0; t < ntiles; ++t) local += (int)chunk_tile[t * 1024 + chunk];
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    for (int i = 0; i < wave; ++i) incl += wtot[i];
+    const int K = (int)k_top;
+    if (incl - local < K && K <= incl) { pick[0] = chunk; pick[1] = incl - local; }
+    __syncthreads();
+    if (wave != 0) return;
+    const int ch = pick[0], above = pick[1];
+    const int bin = ch * 64 + 63 - lane;
+    int c = 0;
+    for (int t = 0; t < ntiles; ++t) c += hist8[(int64_t)t * HIST16 + bin];
+    int inc2 = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc2, d);
+        if (lane >= d) inc2 += o;
+    }
+    if (above + inc2 - c < K && K <= above + inc2) *out = (double)bin;
+}
+
 struct LutBlocksArgs {
     const uint32_t* hist;
     const int32_t* se;
@@ -368,9 +557,11 @@ struct LutBlocksArgs {
     int chunk_sets;
     double* ranks_out;
     int ranks_zstride;
+    int tile_area;                   // SAT: the excess of a tile is its area minus its clipped total
 };
 
-__global__ __launch_bounds__(1024) void k_tile_lut16_blocks(const LutBlocksArgs kargs) {
+// SAT: hist is hist8 (k_hist_reduce_sat) and rank[] counts from the top (the rank[r]-th largest pixel, 1 = the maximum)
+template <bool SAT> __global__ __launch_bounds__(1024) void k_tile_lut16_blocks(const LutBlocksArgs kargs) {
     const uint32_t* __restrict__ hist = kargs.hist;
     const int32_t* __restrict__ se = kargs.se;
     const int clip = kargs.clip;
@@ -382,9 +573,11 @@ __global__ __launch_bounds__(1024) void k_tile_lut16_blocks(const LutBlocksArgs 
     hist = zdisk(hist, zs, blockIdx.z);
     if (blockIdx.x >= 32) {
         const int r = (int)blockIdx.x - 32;
-        if (blockIdx.y == 0 && r < kargs.n_ranks)
-            hist_rank_job(hist, zdisk(kargs.chunk_sums, zs, blockIdx.z), kargs.chunk_sets, (int)gridDim.y, kargs.rank[r],
-                          kargs.ranks_out + (int64_t)blockIdx.z * kargs.ranks_zstride + r);
+        if (blockIdx.y == 0 && r < kargs.n_ranks) {
+            double* out = kargs.ranks_out + (int64_t)blockIdx.z * kargs.ranks_zstride + r;
+            if (SAT) hist_rank_top_job(reinterpret_cast<const uint8_t*>(hist), zdisk(kargs.chunk_sums, zs, blockIdx.z), (int)gridDim.y, kargs.rank[r], out);
+            else hist_rank_job(hist, zdisk(kargs.chunk_sums, zs, blockIdx.z), kargs.chunk_sets, (int)gridDim.y, kargs.rank[r], out);
+        }
         return;
     }
     se = zdisk(se, zs, blockIdx.z);
@@ -393,13 +586,17 @@ __global__ __launch_bounds__(1024) void k_tile_lut16_blocks(const LutBlocksArgs 
     const int tile = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (wave == 0) {
         int kept = 0, over = 0;
-        if (lane < 32) {
+        if (SAT) {                                           // se = kept512 [tile][128]: the clipped totals of every 512 bins
+            const int lo = se[tile * 128 + lane], hi = se[tile * 128 + 64 + lane];
+            kept = (lane < 4 * b ? lo : 0) + (64 + lane < 4 * b ? hi : 0);
+            over = lo + hi;
+        } else if (lane < 32) {
             kept = lane < b ? se[(tile * 32 + lane) * 2] : 0;
             over = se[(tile * 32 + lane) * 2 + 1];
         }
 #pragma unroll
         for (int k = 32; k >= 1; k >>= 1) { kept += __shfl_xor(kept, k); over += __shfl_xor(over, k); }
-        if (lane == 0) { s_before = kept; s_excess = over; }
+        if (lane == 0) { s_before = kept; s_excess = SAT ? kargs.tile_area - over : over; }
     }
     __syncthreads();
     const int excess = s_excess;
@@ -408,7 +605,13 @@ __global__ __launch_bounds__(1024) void k_tile_lut16_blocks(const LutBlocksArgs 
     const int step = residual != 0 ? max(HIST / residual, 1) : 1;
     const int64_t limit = (int64_t)residual * step;
     const int first = b * 2048, i0 = first + 2 * tid;
-    const uint2 hh = *reinterpret_cast<const uint2*>(hist + (int64_t)tile * HIST + i0);
+    uint2 hh;
+    if (SAT) {
+        const uint32_t two = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(hist) + (int64_t)tile * HIST + i0);
+        hh = make_uint2(two & 0xffu, two >> 8);
+    } else {
+        hh = *reinterpret_cast<const uint2*>(hist + (int64_t)tile * HIST + i0);
+    }
     int c0 = (int)min(hh.x, (uint32_t)clip) + batch, c1 = (int)min(hh.y, (uint32_t)clip) + batch;
     if (residual != 0) {
         if ((int64_t)i0 < limit && i0 % step == 0) c0 += 1;
@@ -1095,8 +1298,14 @@ __global__ __launch_bounds__(1024) void k_hist_ranks(const HistRanksArgs kargs) 
 void ensure_lds_attr() {
     static const bool done = [] {                        // (a function-local static: once, also with several pool threads here)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16_slices<false>), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16_slices<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16_slices<false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16_slices<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16_slices<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16_slices<true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  HIST16 * 2 + kFusedMaxSliceRows * 8);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16_slices<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  HIST16 * 2 + kFusedMaxSliceRows * 8);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist16_slices<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   HIST16 * 2 + kFusedMaxSliceRows * 8);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_image_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, HIST16 * 2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_lut16_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1222,7 +1431,7 @@ inline FastLayout fast_layout(int64_t h, int64_t w, int tiles) {
     f.part = 0;
     f.chunk = ntiles * (size_t)f.slices * (HIST16 / 2) * sizeof(uint32_t);
     f.se = f.chunk + ntiles * 1024 * sizeof(uint32_t);
-    f.total = f.se + ntiles * 32 * 2 * sizeof(int32_t);
+    f.total = f.se + ntiles * 128 * sizeof(int32_t);         // (32 x 2 for the u16 slices, 128 for the saturated ones)
     return f;
 }
 }  // namespace
@@ -1281,6 +1490,8 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
         uint32_t* part = reinterpret_cast<uint32_t*>(extra + f.part);
         uint32_t* chunk_tile = reinterpret_cast<uint32_t*>(extra + f.chunk);
         int32_t* se = reinterpret_cast<int32_t*>(extra + f.se);
+        bool sat_path = false;
+        int64_t sat_k_top[2] = {0, 0};
         { SHG_PROF("clahe_hist", st);
           const unsigned nz = (unsigned)dset.n;
           // One image: 32768-pixel slices spread a tile over enough workgroups to fill the chip.  A stack of disks fills it
@@ -1288,40 +1499,97 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
           // reduction (the layout's f.slices is the upper bound the workspace was sized for).
           static const int64_t big = [] { const char* v = getenv("SHG_CLAHE_SLICE_PX"); return v ? (int64_t)atoi(v) : (int64_t)65535; }();
           static const int big_from = [] { const char* v = getenv("SHG_CLAHE_BIG_FROM"); return v ? atoi(v) : 4; }();      // disks per launch from which the big slices are taken
-          const int64_t slice_px = (dset.n >= big_from && big > SLICE_PX && big <= 65535) ? big : SLICE_PX;
-          const int64_t slice_rows = slice_rows_of(tw, slice_px), slices = slice_count(th, tw, slice_px);
+          // Saturated counters (k_tile_hist16_slices<., 8 / 4>): whenever the clip limit fits a byte and nobody needs the true counts
+          // -- the frame's order statistics may ride along when they lie within `clip` pixels of the top (np.percentile(frame, 99.9999)
+          // of a 4 Mpx image: the 5th and 6th largest), a caller who wants the chunk sums (shg_contrast_stats_u16) gets the u16 slices.
+          // (read at every call, three getenv: the tests hold one setting against another in one process)
+          const int sat_mode = [] { const char* v = getenv("SHG_CLAHE_SAT"); return v ? atoi(v) : 1; }();         // 0: never; 8: bytes even where nibbles would do
+          const int64_t sat_px = [] { const char* v = getenv("SHG_CLAHE_SAT_PX"); return v && atoi(v) > 0 ? (int64_t)atoi(v) : (int64_t)0; }();      // pixels per slice (0: chosen below)
+          const int64_t n_px = (int64_t)ntiles * area;
+          const bool want_ranks = ranks_job && ranks_done;
+          bool sat = sat_mode != 0 && clip <= 255 && tw <= 65280 && (chunk_tile_out == nullptr || want_ranks);
+          int64_t k_top[2] = {0, 0};
+          if (sat && want_ranks) {
+              for (int r = 0; r < 2; ++r) {
+                  k_top[r] = n_px - ranks_job->rank[r];          // rank (from the bottom, 0-based) -> the k-th largest
+                  sat = sat && h % tiles == 0 && w % tiles == 0 && k_top[r] >= 1 && k_top[r] <= clip;
+              }
+          }
+          const int bits = !sat ? 16 : (clip <= 15 && sat_mode != 8 ? 4 : 8);
+          int64_t slice_px = (dset.n >= big_from && big > SLICE_PX && big <= 65535) ? big : SLICE_PX;
+          if (sat && sat_px) slice_px = sat_px;
+          const int64_t chunk_rows = slice_rows_of(tw, 65280);                    // (sat: rows counted between two clamps of the u16 counters)
+          int64_t slice_rows = slice_rows_of(tw, slice_px), slices = slice_count(th, tw, slice_px);
+          if (sat) {
+              // as many slices as the byte sums of k_hist_reduce_sat hold (256) and the workspace has room for (sized for f.slices u16 slices)
+              const int64_t max_slices = std::min<int64_t>(256, f.slices * (16 / bits));
+              if (!sat_px) {
+                  // A slice may be any length now, and a workgroup has a CU to itself (its histogram is 128 KB of the 160 KB of LDS): the
+                  // launch takes ceil(workgroups / CUs) rounds of one slice each.  The number of slices per tile that makes rounds x
+                  // (pixels of a slice + what zeroing, clamping and storing 64 K counters costs, about 8000 pixels' worth) smallest:
+                  // 63 at one 2000 x 2098 disk (252 workgroups, one round), 3 for a stack of 21 (252 again) -- not the 4 that
+                  // would leave two thirds of the chip idle in a second round.
+                  int64_t best = 1, best_cost = INT64_MAX;
+                  for (int64_t sl = 1; sl <= std::min<int64_t>(max_slices, th); ++sl) {
+                      const int64_t rows = (th + sl - 1) / sl, n_sl = (th + rows - 1) / rows;
+                      if (dset.fused && rows > kFusedMaxSliceRows) continue;
+                      const int64_t wgs = n_sl * ntiles * (int64_t)dset.n, rounds = (wgs + shg::kCUs - 1) / shg::kCUs;
+                      const int64_t cost = rounds * (rows * tw + 8192);
+                      if (cost < best_cost) { best_cost = cost; best = rows; }
+                  }
+                  slice_rows = best;
+              }
+              slices = (th + slice_rows - 1) / slice_rows;
+              if (slices > max_slices) slice_rows = (th + max_slices - 1) / max_slices;
+              if (dset.fused) slice_rows = std::min<int64_t>(slice_rows, kFusedMaxSliceRows);      // (the factors' room in LDS; th < 65536: 32 slices at most)
+              slices = (th + slice_rows - 1) / slice_rows;
+          }
           int vec = w % tiles == 0 && tw % 8 == 0 && pitch % 8 == 0 && dset.aligned(15);
+          const dim3 hgrid((unsigned)slices, (unsigned)ntiles, nz);
           if (dset.fused) {
               SHG_REQUIRE(h % tiles == 0 && w % tiles == 0 && slice_rows <= kFusedMaxSliceRows, SHG_E_ARG, "shg_clahe: the fused histogram needs a tile grid that divides the image");
-              uintptr_t bits = 0;
-              for (int i = 0; i < dset.n; ++i) bits |= reinterpret_cast<uintptr_t>(dset.from.raw.p[i]);
-              vec = vec && (bits & 15) == 0 && dset.from.raw_pitch % 8 == 0 && dset.from.sx0 == 0 && dset.from.dx0 == 0 && dset.from.ncopy == w;
-              if (int e = shg::launch(k_tile_hist16_slices<true>, dim3((unsigned)slices, (unsigned)ntiles, nz), dim3(1024), HIST16 * 2 + (size_t)slice_rows * 8, st,
-                                       HistSlicesArgs{dset.src, h, w, pitch, tiles, th, tw, part, dset.zs, (int)slice_rows, vec, dset.from}, "k_tile_hist16_slices"))
-                  return e;
-          } else {
-              if (int e = shg::launch(k_tile_hist16_slices<false>, dim3((unsigned)slices, (unsigned)ntiles, nz), dim3(1024), HIST16 * 2, st,
-                                       HistSlicesArgs{dset.src, h, w, pitch, tiles, th, tw, part, dset.zs, (int)slice_rows, vec, FusedSrc{}}, "k_tile_hist16_slices"))
-                  return e;
+              uintptr_t abits = 0;
+              for (int i = 0; i < dset.n; ++i) abits |= reinterpret_cast<uintptr_t>(dset.from.raw.p[i]);
+              vec = vec && (abits & 15) == 0 && dset.from.raw_pitch % 8 == 0 && dset.from.sx0 == 0 && dset.from.dx0 == 0 && dset.from.ncopy == w;
           }
+          const HistSlicesArgs ha{dset.src, h, w, pitch, tiles, th, tw, part, dset.zs, (int)slice_rows, vec, dset.fused ? dset.from : FusedSrc{}, clip, (int)chunk_rows};
+          const size_t lds = HIST16 * 2 + (dset.fused ? (size_t)slice_rows * 8 : 0);
+          int e = 0;
+          if (dset.fused) {
+              e = bits == 16 ? shg::launch(k_tile_hist16_slices<true, 16>, hgrid, dim3(1024), lds, st, ha, "k_tile_hist16_slices")
+                  : bits == 8 ? shg::launch(k_tile_hist16_slices<true, 8>, hgrid, dim3(1024), lds, st, ha, "k_tile_hist16_slices")
+                              : shg::launch(k_tile_hist16_slices<true, 4>, hgrid, dim3(1024), lds, st, ha, "k_tile_hist16_slices");
+          } else {
+              e = bits == 16 ? shg::launch(k_tile_hist16_slices<false, 16>, hgrid, dim3(1024), lds, st, ha, "k_tile_hist16_slices")
+                  : bits == 8 ? shg::launch(k_tile_hist16_slices<false, 8>, hgrid, dim3(1024), lds, st, ha, "k_tile_hist16_slices")
+                              : shg::launch(k_tile_hist16_slices<false, 4>, hgrid, dim3(1024), lds, st, ha, "k_tile_hist16_slices");
+          }
+          if (e) return e;
           const bool zero_sel = sel_hist && sel_zeroed;
-          if (int e = shg::launch(k_hist_reduce, dim3(32, (unsigned)ntiles, nz), dim3(1024), 0, st,
-                                 HistReduceArgs{part, (int)slices, clip, hist, chunk_tile, se, dset.zs, zero_sel ? sel_hist : nullptr, zero_sel ? SEL_SLOTS * sel_stride : 0}, "k_hist_reduce"))
-              return e;
+          const HistReduceArgs ra{part, (int)slices, clip, hist, chunk_tile, se, dset.zs, zero_sel ? sel_hist : nullptr, zero_sel ? SEL_SLOTS * sel_stride : 0};
+          e = bits == 16 ? shg::launch(k_hist_reduce, dim3(32, (unsigned)ntiles, nz), dim3(1024), 0, st, ra, "k_hist_reduce")
+              : bits == 8 ? shg::launch(k_hist_reduce_sat<8>, dim3(64, (unsigned)ntiles, nz), dim3(256), 0, st, ra, "k_hist_reduce_sat")
+                          : shg::launch(k_hist_reduce_sat<4>, dim3(32, (unsigned)ntiles, nz), dim3(256), 0, st, ra, "k_hist_reduce_sat");
+          if (e) return e;
+          sat_path = sat;
+          sat_k_top[0] = k_top[0];
+          sat_k_top[1] = k_top[1];
           if (zero_sel) *sel_zeroed = true; }
         { SHG_PROF("clahe_lut", st);
-          LutBlocksArgs la{hist, se, clip, lut_scale, lut, dset.zs, 0, {0, 0}, nullptr, 0, nullptr, 0};
+          LutBlocksArgs la{hist, se, clip, lut_scale, lut, dset.zs, 0, {0, 0}, nullptr, 0, nullptr, 0, (int)area};
           if (ranks_job && ranks_done) {                     // the frame's order statistics ride along (two more workgroups per disk)
               la.n_ranks = 2;
-              la.rank[0] = ranks_job->rank[0];
-              la.rank[1] = ranks_job->rank[1];
+              la.rank[0] = sat_path ? sat_k_top[0] : ranks_job->rank[0];
+              la.rank[1] = sat_path ? sat_k_top[1] : ranks_job->rank[1];
               la.chunk_sums = chunk_tile;
               la.chunk_sets = ntiles;
               la.ranks_out = ranks_job->out;
               la.ranks_zstride = ranks_job->out_zstride;
               *ranks_done = true;
           }
-          if (int e = shg::launch(k_tile_lut16_blocks, dim3(32u + (unsigned)la.n_ranks, (unsigned)ntiles, (unsigned)dset.n), dim3(1024), 0, st, la, "k_tile_lut16_blocks")) return e; }
+          const dim3 lgrid(32u + (unsigned)la.n_ranks, (unsigned)ntiles, (unsigned)dset.n);
+          if (int e = sat_path ? shg::launch(k_tile_lut16_blocks<true>, lgrid, dim3(1024), 0, st, la, "k_tile_lut16_blocks")
+                               : shg::launch(k_tile_lut16_blocks<false>, lgrid, dim3(1024), 0, st, la, "k_tile_lut16_blocks")) return e; }
         { SHG_PROF("clahe_interp", st);
           bool counted = false;
           if (int e = launch_interp16(dset, h, w, pitch, tiles, inv_tw, inv_th, lut, true, dst_pitch, sel_hist, sel_stride, st, &counted)) return e;

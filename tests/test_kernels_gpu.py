@@ -1160,3 +1160,73 @@ def test_limb_stage_under_load_equals_the_separate_kernels(ops, monkeypatch):
     bg.join()
     torch.cuda.synchronize()
     assert not failures, failures[:5]
+
+
+def _solar_image(h, w, seed, flat_top=False, sky=0.01):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    r = np.hypot(yy - h / 2, xx - w / 2) / (0.42 * min(h, w))
+    disc = np.where(r < 1, 0.35 + 0.55 * np.sqrt(np.clip(1 - r * r, 0, 1)), sky)
+    img = np.clip((disc + 0.01 * rng.standard_normal((h, w))) * 65535, 0, 65535).astype(np.uint16)
+    img[r >= 1] = int(sky * 65535)                      # a perfectly flat sky: one bin holds most of every slice (clamped at every level)
+    if flat_top:
+        img[img > 55000] = 65535                         # a burnt-out core: the top order statistics sit in ONE bin with thousands of pixels
+    return img
+
+
+@pytest.mark.parametrize('h,w,tiles,clip_limit', [(2000, 2096, 2, 0.8), (2000, 2098, 2, 0.8), (2560, 2676, 2, 0.8), (1100, 1000, 2, 0.8),
+                                                  (901, 1203, 2, 3.0), (640, 960, 4, 8.0), (700, 1056, 3, 2.0), (1100, 1008, 2, 15.9),
+                                                  (1100, 1008, 2, 16.0), (1100, 1008, 2, 59.5), (1100, 1008, 2, 61.0), (64, 64, 2, 0.8)])
+def test_clahe_saturated_slice_histograms_equal_the_u16_ones(ops, orc, h, w, tiles, clip_limit, monkeypatch):
+    """csrc/clahe.hip, k_tile_hist16_slices<., 8 / 4>: a slice's counters clamped to the clip limit and stored as bytes or nibbles
+    (min(a + b, c) = min(min(a, c) + b, c)) must give the image the whole u16 counters give (SHG_CLAHE_SAT=0), bit for bit, and the
+    oracle's where that is quick: clip limits 12 (nibbles), 20, 15 | 16 (the nibble / byte border), 255 | 261 (byte / u16 border), a grid
+    that does not divide the image (reflected tiles), one-chunk slices and slices of several chunks clamped in between
+    (SHG_CLAHE_SAT_PX = 300 000: four or five chunks of < 65 280 pixels), bytes forced where nibbles would do (SHG_CLAHE_SAT=8).
+    The sky is perfectly flat: one bin takes most of a slice and is clamped at every level."""
+    img = _solar_image(h, w, seed=h + w)
+    d = dev(img)
+    monkeypatch.setenv('SHG_CLAHE_SAT', '0')
+    want = host(ops.clahe(d, clip_limit, tiles))
+    if h * w <= 1_300_000:
+        np.testing.assert_array_equal(want, orc.clahe(img, clip_limit, tiles))
+    for mode, px in (('1', None), ('8', None), ('1', '300000'), ('8', '300000'), ('1', '5000')):
+        monkeypatch.setenv('SHG_CLAHE_SAT', mode)
+        if px is None:
+            monkeypatch.delenv('SHG_CLAHE_SAT_PX', raising=False)
+        else:
+            monkeypatch.setenv('SHG_CLAHE_SAT_PX', px)
+        np.testing.assert_array_equal(host(ops.clahe(d, clip_limit, tiles)), want, err_msg='SHG_CLAHE_SAT=%s px=%s' % (mode, px))
+
+
+@pytest.mark.parametrize('shape,k,flat_top', [((2000, 2096), 1, False), ((2000, 2096), 3, True), ((2560, 2676), 2, False), ((2000, 2098), 5, True),
+                                              ((200, 304), 2, False), ((1000, 1048), 4, True)])
+def test_frame_percentile_off_the_saturated_histograms(shape, k, flat_top, monkeypatch):
+    """shg_stage_process_frames reads np.percentile(frame, 99.9999)'s two order statistics off CLAHE's tile histograms; with clamped
+    counters (k_hist_reduce_sat, hist_rank_top_job) they are found from the TOP, which is exact while they lie within `clip` pixels of
+    it.  Every product -- the contrast bounds depend on those statistics -- must equal the u16-counter route's (SHG_CLAHE_SAT=0):
+    1 to 5 disks (5: the stack's larger slices, several chunks each), a burnt-out core (the statistics inside one bin of thousands of
+    pixels), a 6.8 Mpx image (clip 20, the 7th and 8th largest), a small image (clip 1: the statistics are out of reach, the u16 route
+    must be taken by itself) and a 1 Mpx one (clip 3, the 2nd and 3rd largest)."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from solex_ser_recon_en_amd import stages
+    h, w = shape
+    pitch = (w + 63) // 64 * 64
+    store = torch.zeros((k, h, pitch), dtype=torch.uint16, device='cuda')
+    views = []
+    for i in range(k):
+        store[i, :, :w] = torch.from_numpy(_solar_image(h, w, seed=100 + i, flat_top=flat_top and i % 2 == 0).view(np.int16)).cuda().view(torch.uint16)
+        views.append(store[i, :, :w])
+
+    def run(mode):
+        monkeypatch.setenv('SHG_CLAHE_SAT', mode)
+        res = stages.process_frames(views, None, None, (w // 2, h // 2, int(0.3 * h)))
+        torch.cuda.synchronize()
+        return {name: [np.asarray(t.cpu().view(torch.int16).numpy()).view(np.uint16).copy() for t in res[name]] for name in ('final', 'cl1', 'hc', 'protus', 'cc')}
+    want = run('0')
+    for mode in ('1', '8'):
+        got = run(mode)
+        for name in want:
+            for i, (x, y) in enumerate(zip(got[name], want[name])):
+                np.testing.assert_array_equal(x, y, err_msg='%s[%d] SHG_CLAHE_SAT=%s' % (name, i, mode))
