@@ -16,6 +16,7 @@
 // -ffp-contract=off) and a truncating store, to be bit-exact with NumPy.
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include "shg_common.h"
 
 namespace shg {
@@ -74,6 +75,13 @@ template <typename T, bool ROT, int BATCH, int SC> __global__ __launch_bounds__(
     const int64_t yc = y_ok ? y : ih - 1;
     int il[SC];
     const double wl = lw[yc], wr = rw[yc];
+    // sample * weight with ONE instruction: D = 2^52 + sample is exact (the integer sits in the low mantissa bits), D * w - 2^52 * w is
+    // sample * w exactly, and the fma rounds it once -- the product fl((double)sample * w) the reference forms, without the conversion
+    // (v_cvt_f64_u32 runs at a quarter of the rate: this kernel's time was its float64 instructions, not its gather --
+    // tools/probes/gather_width_probe.hip reads the same bytes in a third of the time).  Needs 2^52 * w finite: any fit's weights
+    // (they lie in [0, 1]); other weights through the C ABI take the plain form, wave by wave.
+    const double kl = wl * 0x1p+52, kr = wr * 0x1p+52;
+    const bool fast = __all(fabs(wl) < 0x1p+900 && fabs(wr) < 0x1p+900) != 0;
 #pragma unroll
     for (int s = 0; s < SC; ++s) il[s] = ind_l[(int64_t)(s0 + min(s, ns - 1)) * ih + yc];
 
@@ -110,23 +118,34 @@ template <typename T, bool ROT, int BATCH, int SC> __global__ __launch_bounds__(
                 rv[i][s] = *reinterpret_cast<const T*>(f + offr[s]);
             }
         }
+        auto blend = [&](auto fast_form) {                   // (the branch on `fast` sits outside the unrolled loops)
 #pragma unroll
-        for (int i = 0; i < BATCH; ++i) {
-            const int cc = cb + 4 * i;
-            if (!ok[i] || !y_ok) continue;
+            for (int i = 0; i < BATCH; ++i) {
+                const int cc = cb + 4 * i;
+                if (!ok[i] || !y_ok) continue;
 #pragma unroll
-            for (int s = 0; s < SC; ++s) {
-                if (s < ns) {
-                    const double l = (double)((int)lv[i][s] * scale);
-                    const double r = (double)((int)rv[i][s] * scale);
-                    const double v = l * wl + r * wr;
-                    const uint32_t q = (uint32_t)(int)v & 0xffffu;   // what the stored pixel is (weights outside [0, 1] wrap as the reference's uint16 cast does)
-                    tile[s][lane][cc] = (uint16_t)q;
-                    vlo[s] = q < vlo[s] ? q : vlo[s];
-                    vhi[s] = q > vhi[s] ? q : vhi[s];
+                for (int s = 0; s < SC; ++s) {
+                    if (s < ns) {
+                        double v;
+                        if (decltype(fast_form)::value) {
+                            const double pl = __builtin_fma(__hiloint2double(0x43300000, (int)lv[i][s] * scale), wl, -kl);
+                            const double pr = __builtin_fma(__hiloint2double(0x43300000, (int)rv[i][s] * scale), wr, -kr);
+                            v = pl + pr;
+                        } else {
+                            const double l = (double)((int)lv[i][s] * scale);
+                            const double r = (double)((int)rv[i][s] * scale);
+                            v = l * wl + r * wr;
+                        }
+                        const uint32_t q = (uint32_t)(int)v & 0xffffu;   // what the stored pixel is (weights outside [0, 1] wrap as the reference's uint16 cast does)
+                        tile[s][lane][cc] = (uint16_t)q;
+                        vlo[s] = q < vlo[s] ? q : vlo[s];
+                        vhi[s] = q > vhi[s] ? q : vhi[s];
+                    }
                 }
             }
-        }
+        };
+        if (fast) blend(std::true_type{});
+        else blend(std::false_type{});
     }
 
     if (mm) {
@@ -423,7 +442,8 @@ extern "C" int shg_extract_columns_minmax(const void* stack, int64_t n_frames, i
     const int64_t ih = rot ? width : height;
     // the tile's 16-byte row segments land on 16-byte boundaries when every row does
     const int vec_store = ((reinterpret_cast<uintptr_t>(disks) & 15) == 0) && (row_pitch % 8 == 0) && (plane_stride % 8 == 0);
-    const int sc = n_shifts <= 2 ? 2 : SC_MAX;
+    static const int sc_env = [] { const char* e = getenv("SHG_EXT_SC"); return e ? atoi(e) : 0; }();           // tuning override: 2 or 4
+    const int sc = n_shifts <= 2 ? 2 : (sc_env == 2 ? 2 : SC_MAX);
     dim3 grid((unsigned)((n_cols + TK - 1) / TK), (unsigned)((ih + TY - 1) / TY), (unsigned)((n_shifts + sc - 1) / sc));
     hipStream_t st = shg::as_stream(stream);
     const int n = (int)n_frames;

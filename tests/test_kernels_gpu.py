@@ -326,6 +326,46 @@ def test_extract_oracle_random(ops, orc, n, h, w, dtype):
     np.testing.assert_array_equal(host(disks), np.stack(want))
 
 
+@pytest.mark.parametrize('h,w,dtype', [(24, 200, np.uint16), (200, 24, np.uint16), (24, 200, np.uint8)])
+def test_extract_with_weights_no_fit_would_give(ops, h, w, dtype):
+    """k_extract forms sample * weight as fma(2^52 + sample, w, -2^52 w) where that is exact (every fit's weights, which lie in [0, 1])
+    and as the plain product where 2^52 w is not finite -- wave by wave.  Weights through the C ABI may be anything: rows with
+    NaN, +-inf, 1e300, negative and > 1 weights, mixed with ordinary rows inside one wave and in waves of their own, must give
+    what NumPy's float64 arithmetic and its uint16 cast give (solex_util.py:128-133: left * lw + right * rw, astype('uint16'))."""
+    rng = np.random.default_rng(21)
+    n = 70
+    full = 256 if dtype == np.uint8 else 65536
+    frames = rng.integers(0, full, (n, h, w)).astype(dtype)
+    frames[:, :3, :3] = 0
+    ih, iw = max(h, w), min(h, w)
+    col = rng.integers(0, iw - 1, (2, ih)).astype(np.int32)
+    lw = rng.random(ih)
+    rw = 1.0 - lw
+    odd = [np.nan, np.inf, -np.inf, 1e300, -1e300, 2.5, -0.75, 1e-320, 0.0, 65536.0]
+    for i, v in enumerate(odd):                           # single odd rows among ordinary ones (one wave holds both kinds)
+        lw[3 + 7 * i] = v
+        rw[5 + 7 * i] = v
+    lw[128:192] = np.resize(odd, 64)                      # a whole wave of them
+    rw[128:192] = np.resize(odd[::-1], 64)
+    disks = host(ops.extract_columns(dev(frames), col, lw, rw))
+    img = np.transpose(frames, (0, 2, 1))[:, ::-1, :] if w > h else frames          # video_reader.py:119-120: rot90 of every frame
+    img = img.astype(np.int64) * (256 if dtype == np.uint8 else 1)
+    rows = np.arange(ih)
+    with np.errstate(all='ignore'):
+        for s in range(2):
+            left = img[:, rows, col[s]].astype(np.float64)
+            right = img[:, rows, col[s] + 1].astype(np.float64)
+            val = left * lw[None, :] + right * rw[None, :]
+            ordinary = np.isfinite(val) & (np.abs(val) < 2.0 ** 31)
+            want = np.where(ordinary, val, 0).astype(np.int64).astype(np.uint16)
+            got = disks[s].T                               # [n, ih]
+            np.testing.assert_array_equal(got[ordinary], want[ordinary])
+            # what a cast of NaN / out-of-range values gives is the hardware's business (v_cvt_i32_f64 saturates, NaN -> 0), but it must
+            # be the same whichever form the wave took: the odd rows inside ordinary waves against the all-odd wave
+            sat = np.where(np.isnan(val), 0, np.clip(np.where(np.isnan(val), 0, val), -2.0 ** 31, 2.0 ** 31 - 1)).astype(np.int64)
+            np.testing.assert_array_equal(got, (sat & 0xffff).astype(np.uint16))
+
+
 # ---- warp ---------------------------------------------------------------------
 def test_warp_golden_bit_exact(ops, golden):
     g = golden('g3_warp')
