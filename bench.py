@@ -339,7 +339,7 @@ def main():
     c4, c5 = None, None
     if not sharded and not args.no_extra and requested_shifts == [0] and (args.frames, args.width, args.height, args.bits) == (2000, 2000, 200, 16):
         c4 = guarded(extra_leg, 'C4: 2000-frame 16-bit SER 2000x200, -w -10:10:1 (21 disks), stack resident', stacks, parse_shift('-10:10:1'),
-                     8, 2, workers, run_scans, barrier, _lib, world)
+                     16, 2, workers, run_scans, barrier, _lib, world)          # (16 scans a region: four rounds of the four scans in flight)
         del stacks[1:]                                                   # the legs below use rank 0's first stack only
         torch.cuda.empty_cache()
 

@@ -43,6 +43,18 @@ __device__ __forceinline__ void published() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 }
+// "I am done": -> whether this workgroup is the last of `total`.  fence: the one-variable fallback for a box where the assumption above
+// does not hold (SHG_LIMB_FENCE=1): the counter is bumped with an acq_rel agent-scope read-modify-write, which is what the memory
+// model asks for (and costs the L2 write-back / invalidate the relaxed form avoids: +10 % on a C2 step, measured in round 4).
+__device__ __forceinline__ bool count_done(uint32_t* done, uint32_t total, int fence) {
+    const uint32_t before = fence ? __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+                                  : __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return before == total - 1;
+}
+inline int limb_fence() {                                    // (read at every call: a test holds one setting against the other in one process)
+    const char* v = getenv("SHG_LIMB_FENCE");
+    return v && v[0] == '1';
+}
 
 
 constexpr int TH = 16, TW = 64;              // output tile of both tiled kernels (1024 threads, a pixel each)
@@ -332,6 +344,7 @@ struct LimbSelect1Args {
     uint32_t* done;
     unsigned long long* acc;
     double* out4;
+    int fence;
 };
 __global__ __launch_bounds__(256) void k_limb_select1(const LimbSelect1Args kargs) {
     const uint32_t* __restrict__ keysk = kargs.keysk;
@@ -372,8 +385,7 @@ __global__ __launch_bounds__(256) void k_limb_select1(const LimbSelect1Args karg
     __syncthreads();
     flush_hist(lds, bits1, lc, hist1 + ((size_t)pair << bits1), coarse1 + pair * 256, threadIdx.x, 256);
     published();
-    if (threadIdx.x == 0)
-        last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1;
+    if (threadIdx.x == 0) last = count_done(done, gridDim.x * gridDim.y, kargs.fence);
     __syncthreads();
     if (!last) return;
     {   // wave q takes pair q: both digits, then the value
@@ -437,6 +449,7 @@ struct LimbFloodHistArgs {
     const double* out4;
     uint32_t *counts, *done;
     double* packed;
+    int fence;
 };
 __global__ __launch_bounds__(256) void k_limb_flood_hist(const LimbFloodHistArgs kargs) {
     const uint32_t* __restrict__ keysk = kargs.keysk;
@@ -477,7 +490,7 @@ __global__ __launch_bounds__(256) void k_limb_flood_hist(const LimbFloodHistArgs
     __syncthreads();
     if (threadIdx.x < 20 && lc[threadIdx.x]) atomicAdd(&counts[threadIdx.x], lc[threadIdx.x]);
     published();
-    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    if (threadIdx.x == 0) last = count_done(done, gridDim.x, kargs.fence);
     __syncthreads();
     if (!last) return;
     if (threadIdx.x < 20) {
@@ -884,10 +897,10 @@ extern "C" int shg_limb_prepare(const uint16_t* img, int64_t h, int64_t w, int64
                            LimbSelect0Args{keysk, keys5, n, lay.bits0, lay.bits1, hist0, coarse0}, "k_limb_select0"))
         return e;
     if (int e = shg::launch(k_limb_select1, dim3((unsigned)blocks, 4u), dim3(256), ((size_t)1 << lay.bits1) * 4, st,
-                           LimbSelect1Args{keysk, keys5, n, p, lay.bits0, lay.bits1, hist0, coarse0, hist1, coarse1, gamma99, done, acc, out4}, "k_limb_select1"))
+                           LimbSelect1Args{keysk, keys5, n, p, lay.bits0, lay.bits1, hist0, coarse0, hist1, coarse1, gamma99, done, acc, out4, limb_fence()}, "k_limb_select1"))
         return e;
     *keys_out = keysk;
-    return shg::launch(k_limb_flood_hist, dim3((unsigned)blocks), dim3(256), 0, st, LimbFloodHistArgs{keysk, n, scale_k, acc, out4, counts, done + 1, packed}, "k_limb_flood_hist");
+    return shg::launch(k_limb_flood_hist, dim3((unsigned)blocks), dim3(256), 0, st, LimbFloodHistArgs{keysk, n, scale_k, acc, out4, counts, done + 1, packed, limb_fence()}, "k_limb_flood_hist");
 }
 
 extern "C" size_t shg_limb_edges_workspace_bytes(int64_t sh, int64_t sw) {

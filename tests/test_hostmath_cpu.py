@@ -420,6 +420,30 @@ def test_chord_bounds(seed):
         hostmath.chord_bounds((1000.0, 1000.0, 10.0), [0, 0, 2000, 0], 900, 1100, w)
 
 
+def test_chord_bounds_roots_near_whole_numbers():
+    """shg_host_chord_bounds takes sqrt and asks libm's pow (Python's ** 0.5) only where the root lies within a few ulp of a whole
+    number, where the two could floor differently.  Circles with whole-number and half-integer centres and radii make every row's
+    radicand a whole number or a multiple of 1/4 -- thousands of exact and nearly exact roots -- and radii one ulp either side of
+    such values put radicands one ulp from perfect squares: every row must give what the reference's expression gives."""
+    rng = np.random.default_rng(3)
+    w = 4000
+    for trial in range(300):
+        r = float(rng.integers(50, 1900)) + (0.5 if trial % 3 == 1 else 0.0)
+        cy = float(rng.integers(1900, 2100)) + (0.5 if trial % 5 == 2 else 0.0)
+        cx = float(rng.integers(1900, 2100))
+        if trial % 7 == 3:
+            r = np.nextafter(r, np.inf if trial % 2 else -np.inf)
+        y1 = math.ceil(cy - r) + 1
+        y2 = math.floor(cy + r) - 1
+        if y2 - y1 < 3:
+            continue
+        xa, xb = hostmath.chord_bounds((cx, cy, float(r)), [0.0, 0, float(w - 1), 0], y1, y2, w)
+        for y in range(y1 + 1, y2):
+            dx = math.floor((float(r) ** 2 - (y - cy) ** 2) ** 0.5)
+            s = slice(math.ceil(max(cx - dx, 0.0)), math.floor(min(cx + dx, float(w - 1)))).indices(w)
+            assert (xa[y - y1], xb[y - y1]) == (s[0], max(s[0], s[1])), (trial, r, cy, y)
+
+
 @pytest.mark.parametrize('k,n,strength', [(1, 1780, 301), (3, 1200, 301), (2, 200, 301), (1, 45, 301), (2, 900, 41)])
 def test_transversalium_factors(k, n, strength):
     from scipy.ndimage import correlate1d

@@ -997,15 +997,18 @@ def _limb_disk(h, w, seed):
     return np.clip(img, 0, 65535).astype(np.uint16)
 
 
+@pytest.mark.parametrize('fence', ['0', '1'])
 @pytest.mark.parametrize('h,w,seed', [(2000, 2000, 1), (1203, 997, 2), (3204, 1601, 3), (6400, 800, 4), (420, 640, 5), (2000, 2000, 101), (1203, 997, 102)])
-def test_fused_limb_kernels_equal_the_separate_ones(ops, h, w, seed):
+def test_fused_limb_kernels_equal_the_separate_ones(ops, h, w, seed, fence, monkeypatch):
     """shg_limb_prepare == downscale + cv2.blur (k and 5) + the two selects + the flood statistics, and shg_limb_edges ==
     canny masks + hysteresis labelling, value for value: same window sums, same order statistics, same sum / min / max /
     histogram, same edge pixels with the same roots -- for blur windows 5, 3, 8, 16 and 1, images whose sides are not
     multiples of 4 or of the tile, and every rung of canny's retry ladder.  Seeds >= 100: a disk with a flat top, so that the two
     order statistics the 99th percentile is interpolated between coincide -- the case in which the fused path has to look the image
-    over for the largest value below very_bright instead of taking the lower order statistic."""
-
+    over for the largest value below very_bright instead of taking the lower order statistic.
+    fence = 1: SHG_LIMB_FENCE=1, the last-workgroup counters bumped with an acq_rel agent-scope read-modify-write (the memory model's
+    own way) instead of the relaxed one behind published(): the fallback must give the same values."""
+    monkeypatch.setenv('SHG_LIMB_FENCE', fence)
     disk = torch.from_numpy(_limb_disk(h, w, seed)).cuda()
     sh, sw = -(-h // 4), -(-w // 4)
     n = sh * sw
