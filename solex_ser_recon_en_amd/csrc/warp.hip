@@ -88,31 +88,39 @@ __global__ __launch_bounds__(256) void k_warp_rows(const WarpArgs kargs) {
     // results with three float64 multiplications less per pixel (this kernel is bound by its float64 instructions).
     // Both samples of every row are read unconditionally from clamped positions and replaced by cval afterwards where they
     // fall outside the image: no branch (and no wait) between the loads.
+    // The kernel is bound by its instruction count (tools/probes/valu_rates.hip: a float64 compare costs 8.9 cycles a wave, a
+    // conversion 7.9, an add 5.6), so what can be decided on integers is: x1 = ceil(x) is x0 + 1 unless x is whole, and "0 <= x0 < w"
+    // is one unsigned compare of the converted x0 (the conversion saturates, so far-away positions stay outside; a transform that
+    // is not finite never gets here: `sane`, uniform over the launch, keeps every sample outside as the float compares would).
+    // A sample outside the image is replaced by cval = image[0, 0] BEFORE it is converted (one 32-bit select instead of two).
     double dc[WARP_ROWS];
     uint32_t v0[WARP_ROWS], v1[WARP_ROWS];
     bool in0[WARP_ROWS], in1[WARP_ROWS];
-    const double wd = (double)w;
+    const bool sane = fabs(h00) < 1e300 && fabs(h01) < 1e300 && fabs(h02) < 1e300;
+    const uint32_t wu = (uint32_t)w;
     const double xc = h00 * (double)c;
 #pragma unroll
     for (int rr = 0; rr < WARP_ROWS; ++rr) {
         const int r = ra + rr;
         const double x = xc + h01 * (double)r + h02;
-        const double x0 = floor(x), x1 = ceil(x);
+        const double x0 = floor(x);
         dc[rr] = x - x0;
-        const bool row_ok = r < h;                                // (r < out_h is checked at the store)
-        in0[rr] = row_ok && x0 >= 0.0 && x0 < wd;
-        in1[rr] = row_ok && x1 >= 0.0 && x1 < wd;
+        const int i0 = __double2int_rz(x0);                       // exact for |x0| < 2^31, saturated beyond
+        const int i1 = dc[rr] != 0.0 ? (i0 == 0x7fffffff ? i0 : i0 + 1) : i0;      // ceil(x)
+        const bool row_ok = sane && r < h;                        // (r < out_h is checked at the store)
+        in0[rr] = row_ok && (uint32_t)i0 < wu;
+        in1[rr] = row_ok && (uint32_t)i1 < wu;
         const uint16_t* row = src + (int64_t)(row_ok ? r : 0) * pitch;
-        v0[rr] = row[in0[rr] ? (int)x0 : 0];
-        v1[rr] = row[in1[rr] ? (int)x1 : 0];
+        v0[rr] = row[in0[rr] ? i0 : 0];
+        v1[rr] = row[in1[rr] ? i1 : 0];
     }
-    const double cval = (double)src[0];                       // cval = image[0, 0]
+    const uint32_t cval = src[0];                             // cval = image[0, 0]
     const double lo = (double)mm[0], hi = (double)mm[1];
 #pragma unroll
     for (int rr = 0; rr < WARP_ROWS; ++rr) {
         const int r = ra + rr;
         if (r >= out_h) break;
-        const double left = in0[rr] ? (double)v0[rr] : cval, right = in1[rr] ? (double)v1[rr] : cval;
+        const double left = (double)(in0[rr] ? v0[rr] : cval), right = (double)(in1[rr] ? v1[rr] : cval);
         double v = (1.0 - dc[rr]) * left + dc[rr] * right;
         v = fmin(fmax(v, lo), hi);                                 // np.clip(warped, image.min(), image.max()): no NaN can get here
         dst[(int64_t)r * dst_pitch + c] = (uint16_t)(int)v;        // (2**16 * img).astype(uint16)
