@@ -40,7 +40,9 @@ def algorithmic(name, c):
         ('k_warp_rows', (k + c['fit_image']) * (D * 2 + P * 2)),
         ('k_rowpair_stats', k * P * 2),
         ('k_scale_rows', k * P * 4), ('k_crop_pad', k * P * 4), ('k_frame_hist', k * (D * 2 + P * 2)),
-        ('k_tile_hist16', k * P * 2), ('k_hist_reduce', k * ((P + 65534) // 65535) * 131072 * 1),
+        ('k_tile_hist16', k * P * 2),
+        ('k_hist_reduce_sat', None),                             # a few MB of clamped slice counters: no algorithmic figure
+        ('k_hist_reduce', k * ((P + 65534) // 65535) * 131072 * 1),
         ('k_clahe_interp', k * P * 4), ('k_select16_pass', k * P * 2), ('k_products', k * P * 10),
     ]
     for prefix, b in table:
