@@ -513,7 +513,7 @@ def extra_leg(what, pool, shifts, steps, warmup, workers, run_scans, barrier, _l
     bpp = pool[0].element_size()
     # every slot of the pool (workers + 2 scans in flight) sizes its arenas and leases its pinned areas on its first scans of a new
     # shape: two rounds through all of them before anything is timed
-    run_scans(max(warmup, 2 * (workers + 2)), workers, shifts=shifts, pool=pool)
+    run_scans(max(warmup, 2 * (workers + 2), steps), workers, shifts=shifts, pool=pool)      # (and a whole region's worth: the feeder's buffers for that many tasks)
     times = []
     for r in range(3):
         barrier()

@@ -26,6 +26,21 @@ constexpr int HIST16 = 65536;
 // Workgroups flush their select histograms into one of SEL_SLOTS copies (blockIdx % SEL_SLOTS): ~500 workgroups adding to
 // the same 256 addresses queue up behind each other in the memory-side atomic units; readers add the copies up.
 constexpr int SEL_SLOTS = 8;
+// The window (contrast stage only).  np.percentile(cl1, 10) needs the low byte's histogram of the pixels whose high byte holds the
+// rank -- a second pass over the image, because which high byte that is is only known after the first.  But it hardly moves from one
+// scan to the next: the blend kernel, which counts the high bytes anyway, also counts the low bytes of the SEL_NW high bytes around
+// last scan's answer (kept in the workspace: SelWin), and np.max(cl1) is an atomic maximum.  When the ranks fall inside the window
+// the second pass returns at once (k_select16_pass: every workgroup sees it after replaying the first pass), otherwise it runs as
+// before; the result is the same either way.  Layout behind the SEL_SLOTS slot histograms of the 3-rank select:
+// [SEL_WIN_SLOTS][SEL_NW][256] counts, then SelWin.
+constexpr int SEL_NW = 8;
+struct SelWin { uint32_t w0_cur, w0_next, max, pad; };     // first high byte of the window now / for the next scan; largest pixel
+constexpr int SEL_WIN_SLOTS = 8;                           // (32 copies: the blend kernel no faster, the final pick 8 us slower)
+constexpr int SEL_WIN_WORDS = SEL_WIN_SLOTS * SEL_NW * 256;
+__device__ __forceinline__ uint32_t sel_window_origin(const SelWin* st) {        // (whatever the workspace held at first: a valid window)
+    const uint32_t w0 = __hip_atomic_load(&st->w0_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return w0 > 256u - SEL_NW ? 256u - SEL_NW : w0;
+}
 constexpr int SLICE_PX = 32768;        // pixels per workgroup (< 65536 so that u16 counters cannot wrap)
 constexpr int kFusedMaxSliceRows = 2048;   // k_tile_hist16_slices<true> keeps a slice's row factors in LDS behind the histogram
 
@@ -318,23 +333,37 @@ struct HistReduceArgs {
     size_t zs;
     uint32_t* sel_zero;
     int sel_words;
+    int sel_window;                  // the window's counts and SelWin follow the sel_words words: cleared / rolled over as well
 };
+// the slot histograms of the selects that follow the blend (which adds to them) zeroed by the reduction's first workgroups instead of
+// by a memset launch of their own (every launch is an L2 write-back and invalidate under the other scans' kernels); with a window:
+// its counts too (workgroup x < SEL_SLOTS takes slot x's), and SelWin moves on: next scan's origin becomes this scan's, the maximum 0
+__device__ __forceinline__ void zero_select_area(const HistReduceArgs& kargs, int nt) {
+    if (!kargs.sel_zero || blockIdx.y != 0) return;
+    uint32_t* z = zdisk(kargs.sel_zero, kargs.zs, blockIdx.z);
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < kargs.sel_words; i += nt) z[i] = 0;
+    if (kargs.sel_window) {
+        uint32_t* win = z + kargs.sel_words;
+        for (int slot = blockIdx.x; slot < SEL_WIN_SLOTS; slot += gridDim.x)
+            for (int i = threadIdx.x; i < SEL_NW * 256; i += nt) win[slot * SEL_NW * 256 + i] = 0;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            SelWin* st = reinterpret_cast<SelWin*>(win + SEL_WIN_WORDS);
+            st->w0_cur = st->w0_next;
+            st->max = 0;
+        }
+    }
+}
 
 __global__ __launch_bounds__(1024) void k_hist_reduce(const HistReduceArgs kargs) {
     const uint32_t* __restrict__ part = kargs.part;
-    const int slices = kargs.slices, clip = kargs.clip, sel_words = kargs.sel_words;
+    const int slices = kargs.slices, clip = kargs.clip;
     uint32_t* __restrict__ hist = kargs.hist;
     uint32_t* __restrict__ chunk_tile = kargs.chunk_tile;
     int32_t* __restrict__ se = kargs.se;
     const size_t zs = kargs.zs;
-    uint32_t* __restrict__ sel_zero = kargs.sel_zero;
     __shared__ int wsum[2][16];
-    // the slot histograms of the selects that follow the blend (which adds to them): zeroed here, by the disk's first workgroup, instead
-    // of by a memset launch of their own (every launch is an L2 write-back and invalidate under the other scans' kernels)
-    if (sel_zero && blockIdx.x == 0 && blockIdx.y == 0) {
-        uint32_t* z = zdisk(sel_zero, zs, blockIdx.z);
-        for (int i = threadIdx.x; i < sel_words; i += 1024) z[i] = 0;
-    }
+    zero_select_area(kargs, 1024);
     part = zdisk(part, zs, blockIdx.z);
     hist = zdisk(hist, zs, blockIdx.z);
     chunk_tile = zdisk(chunk_tile, zs, blockIdx.z);
@@ -383,14 +412,11 @@ template <int BITS> __global__ __launch_bounds__(256) void k_hist_reduce_sat(con
     constexpr int KF = 16 / BITS;
     constexpr int NQ = HIST16 / 8 / KF;
     constexpr int NA = BITS == 8 ? 8 : 16;                  // 16-bit sums, two to a register
-    const int slices = kargs.slices, sel_words = kargs.sel_words;
+    const int slices = kargs.slices;
     const uint32_t clip = (uint32_t)kargs.clip;
     const size_t zs = kargs.zs;
     __shared__ uint32_t partial[3][NA][64];
-    if (kargs.sel_zero && blockIdx.x == 0 && blockIdx.y == 0) {
-        uint32_t* z = zdisk(kargs.sel_zero, zs, blockIdx.z);
-        for (int i = threadIdx.x; i < sel_words; i += 256) z[i] = 0;
-    }
+    zero_select_area(kargs, 256);
     const uint32_t* __restrict__ part = zdisk(kargs.part, zs, blockIdx.z);
     uint8_t* __restrict__ hist8 = reinterpret_cast<uint8_t*>(zdisk(kargs.hist, zs, blockIdx.z));
     uint32_t* __restrict__ chunk_tile = zdisk(kargs.chunk_tile, zs, blockIdx.z);
@@ -902,6 +928,7 @@ struct InterpVmArgs {
     size_t zs;
     int tiled;
     uint32_t tiles_x;
+    int sel_window;                  // COUNT: also the low bytes inside the window and the largest pixel (SelWin behind sel_hist's slots)
 };
 
 template <int PX, bool COUNT> __global__ __launch_bounds__(256) void k_clahe_interp_vm(const InterpVmArgs kargs) {
@@ -917,12 +944,24 @@ template <int PX, bool COUNT> __global__ __launch_bounds__(256) void k_clahe_int
     constexpr int HIST = 65536;
     constexpr int COPIES = 8;                            // interleaved copies of each bin: a row's pixels crowd a few bins
     __shared__ uint32_t lh[COUNT ? 256 * COPIES : 1];
+    __shared__ uint32_t lwin[COUNT ? SEL_NW * 256 : 1];
+    __shared__ uint32_t wmax_s[4];
     const uint16_t* __restrict__ img = imgs.at<const uint16_t>(blockIdx.z);
     uint16_t* __restrict__ dst = dsts.at<uint16_t>(blockIdx.z);
     lut = zdisk(lut, zs, blockIdx.z);
     if (COUNT) sel_hist = zdisk(sel_hist, zs, blockIdx.z);
+    const bool window = COUNT && kargs.sel_window;
+    uint32_t* win = nullptr;
+    SelWin* wstate = nullptr;
+    uint32_t w0 = 0, vmax = 0;
     if (COUNT) {
         for (int i = threadIdx.x; i < 256 * COPIES; i += 256) lh[i] = 0;
+        if (window) {
+            win = sel_hist + (int64_t)SEL_SLOTS * sel_stride;
+            wstate = reinterpret_cast<SelWin*>(win + SEL_WIN_WORDS);
+            w0 = sel_window_origin(wstate);
+            for (int i = threadIdx.x; i < SEL_NW * 256; i += 256) lwin[i] = 0;
+        }
         __syncthreads();
     }
     // lanes are dealt (row, vector) pairs in one flat sequence, `rows` rounds of 256 per workgroup: with an (x, y) grid a width
@@ -1041,15 +1080,54 @@ template <int PX, bool COUNT> __global__ __launch_bounds__(256) void k_clahe_int
                 for (int j = 0; j < PX; ++j)
                     if (j < n) atomicAdd(&lh[(out[j] >> 8) * COPIES + copy], 1u);
             }
+            if (window) {
+                // (the sky is one flat value over most of a wave -- and it is where the 10th percentile lies: 64 x PX additions to one
+                // LDS word would queue up behind each other, so a wave whose pixels are all one value adds them up in one lane)
+                const uint32_t first = __builtin_amdgcn_readfirstlane(out[0]);
+                bool one_value = n == PX;
+#pragma unroll
+                for (int j = 1; j < PX; ++j) one_value = one_value && out[j] == out[0];
+                const unsigned long long act = __ballot(1), eq = __ballot(one_value && out[0] == first);
+                if (eq == act) {
+                    const uint32_t d = (first >> 8) - w0;
+                    if (d < (uint32_t)SEL_NW && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)act) - 1))
+                        atomicAdd(&lwin[d * 256 + (first & 0xffu)], (uint32_t)PX * (uint32_t)__popcll(act));
+                    vmax = first > vmax ? first : vmax;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < PX; ++j) {
+                        if (j < n) {
+                            const uint32_t d = (out[j] >> 8) - w0;
+                            if (d < (uint32_t)SEL_NW) atomicAdd(&lwin[d * 256 + (out[j] & 0xffu)], 1u);
+                            vmax = out[j] > vmax ? out[j] : vmax;
+                        }
+                    }
+                }
+            }
         }
     }
     if (COUNT) {
+        if (window) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(vmax, d); vmax = o > vmax ? o : vmax; }
+            if ((threadIdx.x & 63) == 0) wmax_s[threadIdx.x >> 6] = vmax;
+        }
         __syncthreads();
         uint32_t c = 0;
 #pragma unroll
         for (int k = 0; k < COPIES; ++k) c += lh[threadIdx.x * COPIES + k];
         const unsigned slot = blockIdx.x % SEL_SLOTS;
         if (c) atomicAdd(&sel_hist[(int64_t)slot * sel_stride + threadIdx.x], c);
+        if (window) {
+            for (int i = threadIdx.x; i < SEL_NW * 256; i += 256) {
+                const uint32_t cw = lwin[i];
+                if (cw) atomicAdd(&win[(int64_t)(blockIdx.x % SEL_WIN_SLOTS) * SEL_NW * 256 + i], cw);
+            }
+            if (threadIdx.x == 0) {
+                const uint32_t m = max(max(wmax_s[0], wmax_s[1]), max(wmax_s[2], wmax_s[3]));
+                if (m) atomicMax(&wstate->max, m);
+            }
+        }
     }
 }
 
@@ -1093,13 +1171,14 @@ __global__ __launch_bounds__(256) void k_image_hist8(const uint8_t* __restrict__
 // MSB-first radix select on the 16-bit values: pass 0 histograms the high byte, pass 1 the low byte of the
 // pixels whose high byte was chosen.  hist: [n_ranks][2][256] u32, zeroed.  Every workgroup replays pass 0's
 // choice with a workgroup-wide scan (one bin per thread).
-__device__ __forceinline__ void pick_digit(const uint32_t* __restrict__ hist, int slot_stride, int64_t rank, int& digit, int64_t& below) {
+__device__ __forceinline__ void pick_digit(const uint32_t* __restrict__ hist, int slot_stride, int64_t rank, int& digit, int64_t& below,
+                                           int slots = SEL_SLOTS) {
     __shared__ int64_t wave_tot[16];
     __shared__ int64_t chosen[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int64_t c = 0;                                         // one bin per thread; a wider workgroup's other threads idle
     if (tid < 256)
-        for (int k = 0; k < SEL_SLOTS; ++k) c += hist[(int64_t)k * slot_stride + tid];
+        for (int k = 0; k < slots; ++k) c += hist[(int64_t)k * slot_stride + tid];
     int64_t incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -1136,6 +1215,8 @@ struct SelectPassArgs {
     uint32_t* hist;
     int vec_ok;
     size_t zs;
+    int sel_window;                  // pass 1: ranks inside the blend kernel's window (and the maximum) need no second pass
+    int64_t n_px;
 };
 
 __global__ __launch_bounds__(1024) void k_select16_pass(const SelectPassArgs kargs) {
@@ -1178,6 +1259,14 @@ __global__ __launch_bounds__(1024) void k_select16_pass(const SelectPassArgs kar
     int his[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) his[r] = (pass == 1 && r < n_ranks) ? his_s[r] : -1;
+    if (pass == 1 && kargs.sel_window) {
+        const uint32_t* win = hist + (int64_t)SEL_SLOTS * (1 + n_ranks) * 256;
+        const uint32_t w0 = sel_window_origin(reinterpret_cast<const SelWin*>(win + SEL_WIN_WORDS));
+        bool covered = true;
+        for (int r = 0; r < n_ranks; ++r)
+            covered = covered && (ranks.v[r] == kargs.n_px - 1 || (uint32_t)(his[r] - (int)w0) < (uint32_t)SEL_NW);
+        if (covered) return;                                 // (the same for every workgroup of the disk: they replayed the same histogram)
+    }
     // the ranks' high bytes, four to a word (a spare byte repeats the first rank's)
     uint32_t wanted0 = 0, wanted1 = 0;
 #pragma unroll
@@ -1275,24 +1364,44 @@ __global__ __launch_bounds__(1024) void k_select16_pass(const SelectPassArgs kar
 // grid (n_ranks), 256 threads
 struct SelectFinalArgs {
     Ranks8 ranks;
-    const uint32_t* hist;
+    uint32_t* hist;
     double* out;
     size_t zs;
     int out_zstride;
+    int sel_window;
+    int64_t n_px;
 };
 
 __global__ __launch_bounds__(256) void k_select16_final(const SelectFinalArgs kargs) {
     const Ranks8& ranks = kargs.ranks;
-    const uint32_t* __restrict__ hist = kargs.hist;
+    uint32_t* __restrict__ hist = kargs.hist;
     double* __restrict__ out = kargs.out;
     const size_t zs = kargs.zs;
     const int out_zstride = kargs.out_zstride;
     hist = zdisk(hist, zs, blockIdx.z);
     out += (int64_t)blockIdx.z * out_zstride;
+    const int n_ranks = (int)gridDim.x, stride = (1 + n_ranks) * 256;
     int hi, lo;
     int64_t below, below2;
-    pick_digit(hist, (1 + (int)gridDim.x) * 256, ranks.v[blockIdx.x], hi, below);
-    pick_digit(hist + (1 + blockIdx.x) * 256, (1 + (int)gridDim.x) * 256, ranks.v[blockIdx.x] - below, lo, below2);
+    pick_digit(hist, stride, ranks.v[blockIdx.x], hi, below);
+    if (kargs.sel_window) {
+        uint32_t* win = hist + (int64_t)SEL_SLOTS * stride;
+        SelWin* st = reinterpret_cast<SelWin*>(win + SEL_WIN_WORDS);
+        const uint32_t w0 = sel_window_origin(st);
+        if (blockIdx.x == 0 && threadIdx.x == 0)            // the first rank's high byte in the middle of the next scan's window
+            st->w0_next = (uint32_t)min(max(hi - SEL_NW / 2 + 1, 0), 256 - SEL_NW);
+        if (ranks.v[blockIdx.x] == kargs.n_px - 1) {         // np.max: the blend kernel's atomic maximum
+            if (threadIdx.x == 0) out[blockIdx.x] = (double)__hip_atomic_load(&st->max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        const uint32_t d = (uint32_t)(hi - (int)w0);
+        if (d < (uint32_t)SEL_NW) {                          // the blend kernel has counted this high byte's low bytes (always valid)
+            pick_digit(win + d * 256, SEL_NW * 256, ranks.v[blockIdx.x] - below, lo, below2, SEL_WIN_SLOTS);
+            if (threadIdx.x == 0) out[blockIdx.x] = (double)((hi << 8) | lo);
+            return;
+        }
+    }
+    pick_digit(hist + (1 + blockIdx.x) * 256, stride, ranks.v[blockIdx.x] - below, lo, below2);
     if (threadIdx.x == 0) out[blockIdx.x] = (double)((hi << 8) | lo);
 }
 
@@ -1395,7 +1504,7 @@ inline Disks one_disk(const void* src, void* dst) {
 
 inline int launch_interp16(const Disks& d, int64_t h, int64_t w, int64_t pitch, int tiles, float inv_tw, float inv_th,
                            const uint16_t* lut, bool value_major, int64_t dst_pitch, uint32_t* sel_hist, int sel_stride,
-                           hipStream_t st, bool* counted) {
+                           hipStream_t st, bool* counted, bool sel_window = false) {
     *counted = false;
     const unsigned nz = (unsigned)d.n;
     if (!value_major) {                                  // (single image only: the caller checked)
@@ -1409,12 +1518,13 @@ inline int launch_interp16(const Disks& d, int64_t h, int64_t w, int64_t pitch, 
         return (unsigned)((lanes + 256 * (int64_t)rounds - 1) / (256 * (int64_t)rounds));
     };
     static const bool tiled_ok = [] { const char* v = getenv("SHG_INTERP_TILED"); return !(v && v[0] == '0'); }();
-    InterpVmArgs a{d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, 1, nullptr, 0, d.zs, 0, 1u};
+    InterpVmArgs a{d.src, h, w, pitch, tiles, inv_tw, inv_th, lut, d.dst, dst_pitch, 1, nullptr, 0, d.zs, 0, 1u, 0};
     if (vec && sel_hist) {
         const int rows = 4;                              // rounds per workgroup: amortises the histogram's zeroing and flush
         a.rows = rows;
         a.sel_hist = sel_hist;
         a.sel_stride = sel_stride;
+        a.sel_window = sel_window ? 1 : 0;
         *counted = true;
         if (tiled_ok) {
             // 4 lanes x 16 rows per wave, 4 waves across: 64 pixels x 16 rows a round (measured over 21 disks: 243 us; 2 waves
@@ -1490,7 +1600,11 @@ namespace {
 int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_per_px, double clip_limit, int tiles,
                void* dst, int64_t dst_pitch, void* workspace, size_t workspace_bytes, shg_stream_t stream, const uint32_t** chunk_tile_out,
                uint32_t* sel_hist, int sel_stride, bool* sel_pass0_done, const Disks* disks = nullptr, bool* sel_zeroed = nullptr,
-               const RanksJob* ranks_job = nullptr, bool* ranks_done = nullptr) {
+               const RanksJob* ranks_job = nullptr, bool* ranks_done = nullptr, bool* sel_window = nullptr) {
+    // sel_window (in / out): the caller's sel_hist has the window's room behind its slots (select_window_bytes) and wants it used;
+    // -> false when this call did not take the path that fills it
+    const bool want_window = sel_window && *sel_window;
+    if (sel_window) *sel_window = false;
     if (ranks_done) *ranks_done = false;
     if (sel_zeroed) *sel_zeroed = false;                 // -> true when the histogram reduction has zeroed sel_hist (the caller asked by passing it)
     if (chunk_tile_out) *chunk_tile_out = nullptr;
@@ -1605,7 +1719,8 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
           }
           if (e) return e;
           const bool zero_sel = sel_hist && sel_zeroed;
-          const HistReduceArgs ra{part, (int)slices, clip, hist, chunk_tile, se, dset.zs, zero_sel ? sel_hist : nullptr, zero_sel ? SEL_SLOTS * sel_stride : 0};
+          const bool window = zero_sel && want_window;
+          const HistReduceArgs ra{part, (int)slices, clip, hist, chunk_tile, se, dset.zs, zero_sel ? sel_hist : nullptr, zero_sel ? SEL_SLOTS * sel_stride : 0, window ? 1 : 0};
           e = bits == 16 ? shg::launch(k_hist_reduce, dim3(32, (unsigned)ntiles, nz), dim3(1024), 0, st, ra, "k_hist_reduce")
               : bits == 8 ? shg::launch(k_hist_reduce_sat<8>, dim3(64, (unsigned)ntiles, nz), dim3(256), 0, st, ra, "k_hist_reduce_sat")
                           : shg::launch(k_hist_reduce_sat<4>, dim3(32, (unsigned)ntiles, nz), dim3(256), 0, st, ra, "k_hist_reduce_sat");
@@ -1639,8 +1754,10 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
           if (e) return e; }
         { SHG_PROF("clahe_interp", st);
           bool counted = false;
-          if (int e = launch_interp16(dset, h, w, pitch, tiles, inv_tw, inv_th, lut, true, dst_pitch, sel_hist, sel_stride, st, &counted)) return e;
-          if (sel_pass0_done) *sel_pass0_done = counted; }
+          const bool window = sel_hist && sel_zeroed && want_window;
+          if (int e = launch_interp16(dset, h, w, pitch, tiles, inv_tw, inv_th, lut, true, dst_pitch, sel_hist, sel_stride, st, &counted, window)) return e;
+          if (sel_pass0_done) *sel_pass0_done = counted;
+          if (sel_window) *sel_window = window && counted; }
         if (chunk_tile_out) *chunk_tile_out = chunk_tile;
         return 0;
     }
@@ -1726,7 +1843,7 @@ namespace {
 // results at out + i * out_zstride
 int select_u16_impl(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, const int64_t* host_ranks, int n_ranks,
                     double* out, void* workspace, size_t workspace_bytes, shg_stream_t stream, bool zeroed, bool pass0_done,
-                    const Disks* disks = nullptr, int out_zstride = 0) {
+                    const Disks* disks = nullptr, int out_zstride = 0, bool window = false) {
     const Disks dset = disks ? *disks : one_disk(img, nullptr);
     SHG_REQUIRE(img && host_ranks && out && workspace, SHG_E_ARG, "shg_select_u16: null pointer");
     SHG_REQUIRE(h > 0 && w > 0 && pitch >= w && n_ranks >= 1 && n_ranks <= 8, SHG_E_ARG, "shg_select_u16: bad sizes");
@@ -1760,10 +1877,10 @@ int select_u16_impl(const uint16_t* img, int64_t h, int64_t w, int64_t pitch, co
         // 512 threads: the zeroing / replay / flush around the pixel loop is shared by twice the waves (256 / 512 / 1024
         // threads: 44.7 / 40.6 / 40.3 us for two ranks, tools/bench_select.py)
         if (int err = shg::launch(k_select16_pass, dim3(blocks, 1u, (unsigned)dset.n), dim3(512), 0, st,
-                                 SelectPassArgs{dset.src, h, w, pitch, pass, ranks, n_ranks, hist, vec_ok, dset.zs}, "k_select16_pass"))
+                                 SelectPassArgs{dset.src, h, w, pitch, pass, ranks, n_ranks, hist, vec_ok, dset.zs, window ? 1 : 0, h * w}, "k_select16_pass"))
             return err;
     }
-    return shg::launch(k_select16_final, dim3((unsigned)n_ranks, 1u, (unsigned)dset.n), dim3(256), 0, st, SelectFinalArgs{ranks, hist, out, dset.zs, out_zstride}, "k_select16_final");
+    return shg::launch(k_select16_final, dim3((unsigned)n_ranks, 1u, (unsigned)dset.n), dim3(256), 0, st, SelectFinalArgs{ranks, hist, out, dset.zs, out_zstride, window ? 1 : 0, h * w}, "k_select16_final");
 }
 }  // namespace
 
@@ -1775,8 +1892,22 @@ extern "C" int shg_select_u16(const uint16_t* img, int64_t h, int64_t w, int64_t
 // ---- image_process in two calls (solex_util.py:527-547) -------------------------------------------------------------
 // The contrast stage is a dozen small launches around one host decision (three percentiles -> six rescale bounds).
 // Two composite entry points issue them from C instead of from a dozen ctypes calls: same kernels, same order.
+// the 3-rank select's area of the contrast stage: its slot histograms, then the window's counts and SelWin
+static size_t select3_area_bytes() {
+    return (size_t)SEL_SLOTS * (1 + 3) * 256 * sizeof(uint32_t) + (size_t)SEL_WIN_WORDS * sizeof(uint32_t) + sizeof(SelWin) + 3 * sizeof(int64_t);
+}
+// Measured (tools/ab_tables.sh): over a 21-disk stack the second pass falls from 73 to 14 us and the blend kernel grows from 212 to
+// 240 us (its workgroups flush their window counts with global atomics) -- 30 us gained; for ONE disk 12.7 -> 6.3 us against
+// 12.9 -> 24.8 us -- 6 us lost.  So: from four disks a launch on.  SHG_SELECT_WINDOW=0 / 1: never / always (the tests).
+static bool select_window_wanted(int disks) {                // (read at every call: tests hold one setting against the other)
+    const char* v = getenv("SHG_SELECT_WINDOW");
+    if (v && v[0] == '0') return false;
+    if (v && v[0] == '1') return true;
+    return disks >= 4;
+}
+
 extern "C" size_t shg_contrast_stats_workspace_bytes(int tiles) {
-    const size_t c = shg_clahe_workspace_bytes(tiles, 2), s2 = shg_select_u16_workspace_bytes(2), s3 = shg_select_u16_workspace_bytes(3);
+    const size_t c = shg_clahe_workspace_bytes(tiles, 2), s2 = shg_select_u16_workspace_bytes(2), s3 = select3_area_bytes();
     if (c == 0) return 0;
     const size_t chunks = 1024 * sizeof(uint32_t);           // 64-bin chunk sums of the summed tile histograms
     return ((c + 255) / 256 + (s2 + 255) / 256 + (s3 + 255) / 256 + (chunks + 255) / 256) * 256;
@@ -1809,12 +1940,13 @@ extern "C" int shg_contrast_stats_u16(const uint16_t* frame, int64_t h, int64_t 
     // the first pass while the pixels are in its registers
     uint32_t* sel3 = reinterpret_cast<uint32_t*>(ws + c + s2);
     bool pass0_done = false, sel_zeroed = false;         // (zeroed by CLAHE's histogram reduction on the way, or by a memset where that does not run)
+    bool window = select_window_wanted(1);
     if (int e = clahe_impl(frame, h, w, pitch, 2, clip_limit, tiles, cl1, cl1_pitch, ws, c, stream, &chunk_tile, sel3, (1 + 3) * 256, &pass0_done, nullptr,
-                           &sel_zeroed))
+                           &sel_zeroed, nullptr, nullptr, &window))
         return e;
     SHG_REQUIRE(sel_zeroed, SHG_E_RUNTIME, "shg_contrast_stats_u16: the select histograms were not zeroed");
     if (h % tiles == 0 && w % tiles == 0) {
-        const size_t s3r = (shg_select_u16_workspace_bytes(3) + 255) / 256 * 256;
+        const size_t s3r = (select3_area_bytes() + 255) / 256 * 256;
         uint32_t* chunk_sums = reinterpret_cast<uint32_t*>(ws + c + s2 + s3r);
         Ranks8 ranks = {};
         for (int i = 0; i < 2; ++i) {
@@ -1835,7 +1967,8 @@ extern "C" int shg_contrast_stats_u16(const uint16_t* frame, int64_t h, int64_t 
                 return e;
         }
     } else if (int e = shg_select_u16(frame, h, w, pitch, ranks_frame2, 2, out5, ws + c, s2, stream)) return e;
-    return select_u16_impl(cl1, h, w, cl1_pitch, ranks_cl13, 3, out5 + 2, sel3, shg_select_u16_workspace_bytes(3), stream, true, pass0_done);
+    return select_u16_impl(cl1, h, w, cl1_pitch, ranks_cl13, 3, out5 + 2, sel3, shg_select_u16_workspace_bytes(3), stream, true, pass0_done, nullptr, 0,
+                           window && pass0_done);
 }
 
 // image_process's CLAHE + order statistics for the k disks of a file in one launch per kernel (shg_stage_process_frames; a
@@ -1912,8 +2045,9 @@ int shg::contrast_stats_batch(const uint16_t* const* host_frames, int64_t k, int
         bool pass0_done = false, sel_zeroed = false;
         const RanksJob job{{ranks.v[0], ranks.v[1]}, out5 + 5 * i0, 5};
         bool ranks_done = false;
+        bool window = select_window_wanted(m);
         if (int e = clahe_impl(host_frames[i0], h, w, pitch, 2, clip_limit, tiles, host_cl1[i0], cl1_pitch, ws, c, stream, &chunk_tile, sel3, (1 + 3) * 256,
-                               &pass0_done, &d, &sel_zeroed, &job, &ranks_done))
+                               &pass0_done, &d, &sel_zeroed, &job, &ranks_done, &window))
             return e;
         SHG_REQUIRE(chunk_tile && sel_zeroed, SHG_E_RUNTIME, "shg_contrast_stats_u16: the batched path did not take the slice histograms");
         if (!ranks_done) {
@@ -1925,7 +2059,7 @@ int shg::contrast_stats_batch(const uint16_t* const* host_frames, int64_t k, int
         Disks dc = d;
         dc.src = d.dst;                                            // the selects read the CLAHE images
         if (int e = select_u16_impl(host_cl1[i0], h, w, cl1_pitch, ranks_cl13, 3, out5 + 5 * i0 + 2, sel3, shg_select_u16_workspace_bytes(3), stream, true,
-                                    pass0_done, &dc, 5))
+                                    pass0_done, &dc, 5, window && pass0_done))
             return e;
     }
     return 0;

@@ -1273,3 +1273,42 @@ def test_frame_percentile_off_the_saturated_histograms(shape, k, flat_top, monke
         for name in want:
             for i, (x, y) in enumerate(zip(got[name], want[name])):
                 np.testing.assert_array_equal(x, y, err_msg='%s[%d] SHG_CLAHE_SAT=%s' % (name, i, mode))
+
+
+def test_percentile_window_hits_and_misses_give_the_second_pass_results(monkeypatch):
+    """np.percentile(cl1, 10) and np.max(cl1) without a second pass over cl1 (csrc/clahe.hip, SelWin): the blend kernel counts the low
+    bytes of the eight high bytes around the PREVIOUS scan's answer -- kept in the stage's workspace -- and an atomic maximum; when
+    this scan's ranks fall inside, k_select16_pass returns at once.  A run of scans through one workspace -- the same image again
+    (a hit), a much brighter and a much darker one (misses: the window sits where the last image had its 10th percentile), back
+    again, disks of a stack with different levels in one launch -- must give exactly what SHG_SELECT_WINDOW=0 gives."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from solex_ser_recon_en_amd import stages
+    h, w = 1000, 1048
+    pitch = (w + 63) // 64 * 64
+
+    def images(levels):
+        store = torch.zeros((len(levels), h, pitch), dtype=torch.uint16, device='cuda')
+        views = []
+        for i, (seed, sky, gain) in enumerate(levels):
+            img = _solar_image(h, w, seed=seed, sky=sky).astype(np.float64) * gain
+            store[i, :, :w] = torch.from_numpy(np.clip(img, 0, 65535).astype(np.uint16).view(np.int16)).cuda().view(torch.uint16)
+            views.append(store[i, :, :w])
+        return views
+    series = [images([(1, 0.01, 1.0)]), images([(1, 0.01, 1.0)]), images([(2, 0.30, 1.0)]), images([(3, 0.001, 0.2)]), images([(1, 0.01, 1.0)]),
+              images([(4, 0.01, 1.0), (5, 0.25, 0.9), (6, 0.002, 0.3)]), images([(4, 0.01, 1.0), (5, 0.25, 0.9), (6, 0.002, 0.3)])]
+
+    def run(mode):
+        monkeypatch.setenv('SHG_SELECT_WINDOW', mode)          # (1: also for a single disk)
+        out = []
+        for views in series:
+            res = stages.process_frames(views, None, None, (w // 2, h // 2, int(0.3 * h)))
+            torch.cuda.synchronize()
+            out.append({name: [np.asarray(t.cpu().view(torch.int16).numpy()).view(np.uint16).copy() for t in res[name]] for name in ('cl1', 'hc', 'protus', 'cc')})
+        return out
+    want = run('0')
+    got = run('1')
+    for k, (a, b) in enumerate(zip(got, want)):
+        for name in b:
+            for i, (x, y) in enumerate(zip(a[name], b[name])):
+                np.testing.assert_array_equal(x, y, err_msg='scan %d %s[%d]' % (k, name, i))
