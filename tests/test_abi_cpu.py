@@ -37,10 +37,11 @@ def test_workspace_queries_need_no_gpu():
     assert lib.shg_clahe_workspace_bytes(3, 1) == 9 * 256 * 6
     assert lib.shg_clahe_workspace_bytes(0, 2) == 0
     # the roomier 16-bit layout: [hist | lut], then one 128 KiB slice histogram per run of whole tile rows holding at most 32768
-    # pixels (1000 x 1048 tiles: 31 rows a slice, 33 slices), chunk sums, clipped totals
-    assert lib.shg_clahe_workspace_bytes_for(2000, 2096, 2, 2) == 4 * 65536 * 6 + 4 * 33 * 131072 + 4 * 1024 * 4 + 4 * 32 * 2 * 4
+    # pixels (1000 x 1048 tiles: 31 rows a slice, 33 slices), chunk sums, clipped totals (128 words a tile: one per 512 bins for the
+    # saturated slices, 32 x 2 for the u16 ones)
+    assert lib.shg_clahe_workspace_bytes_for(2000, 2096, 2, 2) == 4 * 65536 * 6 + 4 * 33 * 131072 + 4 * 1024 * 4 + 4 * 128 * 4
     assert lib.shg_clahe_workspace_bytes_for(77, 50, 4, 1) == lib.shg_clahe_workspace_bytes(4, 1)
-    assert lib.shg_contrast_stats_workspace_bytes_for(2000, 2096, 2) == lib.shg_contrast_stats_workspace_bytes(2) + 4 * 33 * 131072 + 4 * 1024 * 4 + 4 * 32 * 2 * 4
+    assert lib.shg_contrast_stats_workspace_bytes_for(2000, 2096, 2) == lib.shg_contrast_stats_workspace_bytes(2) + 4 * 33 * 131072 + 4 * 1024 * 4 + 4 * 128 * 4
 
 
 def test_argument_errors_are_reported_not_thrown():
