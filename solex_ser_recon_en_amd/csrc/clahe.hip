@@ -931,7 +931,10 @@ struct InterpVmArgs {
     int sel_window;                  // COUNT: also the low bytes inside the window and the largest pixel (SelWin behind sel_hist's slots)
 };
 
-template <int PX, bool COUNT> __global__ __launch_bounds__(256) void k_clahe_interp_vm(const InterpVmArgs kargs) {
+// T2: a 2 x 2 tile grid, known at compile time.  With `tiles` a run-time value the four-entry load sat inside a branch per pixel and
+// the compiler waited for each before issuing the next: a lane's PX gathers went one after the other, eight L2 round trips a row
+// (the kernel's 0.18 of the roofline; its instruction count never mattered).  With T2 all PX gathers are issued, then blended.
+template <int PX, bool COUNT, bool T2> __global__ __launch_bounds__(256) void k_clahe_interp_vm(const InterpVmArgs kargs) {
     const shg::PtrBatch& imgs = kargs.imgs;
     const shg::PtrBatch& dsts = kargs.dsts;
     const int64_t h = kargs.h, w = kargs.w, pitch = kargs.pitch, dst_pitch = kargs.dst_pitch;
@@ -1002,6 +1005,16 @@ template <int PX, bool COUNT> __global__ __launch_bounds__(256) void k_clahe_int
         row_step = wg_rows;
         if (x0 < w) column_terms(x0);
     }
+    // (tiled walk, whole vectors: the NEXT round's pixels are asked for as soon as this round's have been unpacked, so that a round is
+    // one round trip -- its gathers -- and not two)
+    const bool ahead = tiled && (PX == 8 || PX == 4) && x0 + PX <= w;
+    auto fetch = [&](uint32_t yy) {
+        if (PX == 8) return *reinterpret_cast<const uint4*>(img + (int64_t)yy * pitch + x0);
+        const uint2 t = *reinterpret_cast<const uint2*>(img + (int64_t)yy * pitch + x0);
+        return make_uint4(t.x, t.y, 0u, 0u);
+    };
+    uint4 qnext = make_uint4(0u, 0u, 0u, 0u);
+    if (ahead && (int64_t)row0 < h) qnext = fetch(row0);
     for (int it = 0; it < rows; ++it) {
         uint32_t yy;
         if (tiled) {
@@ -1024,7 +1037,13 @@ template <int PX, bool COUNT> __global__ __launch_bounds__(256) void k_clahe_int
         ty1 = max(ty1, 0);
         ty2 = min(ty2, tiles - 1);
         uint32_t px[PX];
-        if (PX == 8 && n == 8) {
+        if (ahead) {
+            const uint4 q = qnext;
+            px[0] = q.x & 0xffffu; px[1 % PX] = q.x >> 16; px[2 % PX] = q.y & 0xffffu; px[3 % PX] = q.y >> 16;
+            if (PX == 8) { px[4 % PX] = q.z & 0xffffu; px[5 % PX] = q.z >> 16; px[6 % PX] = q.w & 0xffffu; px[7 % PX] = q.w >> 16; }
+            const uint32_t yn = yy + row_step;
+            if (it + 1 < rows && (int64_t)yn < h) qnext = fetch(yn);
+        } else if (PX == 8 && n == 8) {
             const uint4 q = *reinterpret_cast<const uint4*>(img + y * pitch + x0);
             px[0] = q.x & 0xffffu; px[1 % PX] = q.x >> 16; px[2 % PX] = q.y & 0xffffu; px[3 % PX] = q.y >> 16;
             px[4 % PX] = q.z & 0xffffu; px[5 % PX] = q.z >> 16; px[6 % PX] = q.w & 0xffffu; px[7 % PX] = q.w >> 16;
@@ -1036,19 +1055,22 @@ template <int PX, bool COUNT> __global__ __launch_bounds__(256) void k_clahe_int
             for (int j = 0; j < PX; ++j) px[j] = j < n ? img[y * pitch + x0 + j] : 0;
         }
         uint32_t out[PX];
+        uint2 q4[PX];                                        // T2: the pixel's four entries are one 8-byte load: [tile row 0: columns 0, 1 | tile row 1: columns 0, 1]
+        if (T2) {
+#pragma unroll
+            for (int j = 0; j < PX; ++j) q4[j] = *reinterpret_cast<const uint2*>(lut + (int64_t)px[j] * 4);
+        }
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
-            const uint16_t* e = lut + (int64_t)px[j] * ntiles;
             uint32_t l11, l12, l21, l22;
-            if (tiles == 2) {
-                // the pixel's four entries are one 8-byte load: [tile row 0: columns 0, 1 | tile row 1: columns 0, 1]
-                const uint2 q = *reinterpret_cast<const uint2*>(e);
-                const uint32_t top = ty1 ? q.y : q.x, bot = ty2 ? q.y : q.x;
+            if (T2) {
+                const uint32_t top = ty1 ? q4[j].y : q4[j].x, bot = ty2 ? q4[j].y : q4[j].x;
                 l11 = (top >> (16 * tx1[j])) & 0xffffu;
                 l12 = (top >> (16 * tx2[j])) & 0xffffu;
                 l21 = (bot >> (16 * tx1[j])) & 0xffffu;
                 l22 = (bot >> (16 * tx2[j])) & 0xffffu;
             } else {
+                const uint16_t* e = lut + (int64_t)px[j] * ntiles;
                 l11 = e[ty1 * tiles + tx1[j]];
                 l12 = e[ty1 * tiles + tx2[j]];
                 l21 = e[ty2 * tiles + tx1[j]];
@@ -1541,13 +1563,19 @@ inline int launch_interp16(const Disks& d, int64_t h, int64_t w, int64_t pitch, 
             const uint32_t tx = (uint32_t)((w + wg_px - 1) / wg_px), ty = (uint32_t)((h + wg_rows * rows - 1) / (wg_rows * rows));
             a.tiled = 0x10000 | lw | (wx << 8);
             a.tiles_x = tx;
-            if (px8) return shg::launch(k_clahe_interp_vm<8, true>, dim3(tx * ty, 1u, nz), dim3(256), 0, st, a, "k_clahe_interp_vm");
-            return shg::launch(k_clahe_interp_vm<4, true>, dim3(tx * ty, 1u, nz), dim3(256), 0, st, a, "k_clahe_interp_vm");
+            const dim3 g(tx * ty, 1u, nz);
+            if (tiles == 2) return px8 ? shg::launch(k_clahe_interp_vm<8, true, true>, g, dim3(256), 0, st, a, "k_clahe_interp_vm")
+                                       : shg::launch(k_clahe_interp_vm<4, true, true>, g, dim3(256), 0, st, a, "k_clahe_interp_vm");
+            if (px8) return shg::launch(k_clahe_interp_vm<8, true, false>, g, dim3(256), 0, st, a, "k_clahe_interp_vm");
+            return shg::launch(k_clahe_interp_vm<4, true, false>, g, dim3(256), 0, st, a, "k_clahe_interp_vm");
         }
-        return shg::launch(k_clahe_interp_vm<4, true>, dim3(blocks(4, rows), 1u, nz), dim3(256), 0, st, a, "k_clahe_interp_vm");
+        if (tiles == 2) return shg::launch(k_clahe_interp_vm<4, true, true>, dim3(blocks(4, rows), 1u, nz), dim3(256), 0, st, a, "k_clahe_interp_vm");
+        return shg::launch(k_clahe_interp_vm<4, true, false>, dim3(blocks(4, rows), 1u, nz), dim3(256), 0, st, a, "k_clahe_interp_vm");
     }
-    if (vec) return shg::launch(k_clahe_interp_vm<4, false>, dim3(blocks(4, 1), 1u, nz), dim3(256), 0, st, a, "k_clahe_interp_vm");
-    return shg::launch(k_clahe_interp_vm<1, false>, dim3(blocks(1, 1), 1u, nz), dim3(256), 0, st, a, "k_clahe_interp_vm");
+    if (vec) return tiles == 2 ? shg::launch(k_clahe_interp_vm<4, false, true>, dim3(blocks(4, 1), 1u, nz), dim3(256), 0, st, a, "k_clahe_interp_vm")
+                               : shg::launch(k_clahe_interp_vm<4, false, false>, dim3(blocks(4, 1), 1u, nz), dim3(256), 0, st, a, "k_clahe_interp_vm");
+    return tiles == 2 ? shg::launch(k_clahe_interp_vm<1, false, true>, dim3(blocks(1, 1), 1u, nz), dim3(256), 0, st, a, "k_clahe_interp_vm")
+                      : shg::launch(k_clahe_interp_vm<1, false, false>, dim3(blocks(1, 1), 1u, nz), dim3(256), 0, st, a, "k_clahe_interp_vm");
 }
 
 // tile geometry as OpenCV pads it (copyMakeBorder(0, t - h%t, 0, t - w%t, REFLECT_101), clahe.cpp)
