@@ -548,7 +548,7 @@ def extra_leg(what, pool, shifts, steps, warmup, workers, run_scans, barrier, _l
             'steps': steps, 'regions_ms_per_step': [round(t / steps * 1e3, 3) for t in times], 'disks_per_scan': len(shifts),
             'parity_vs_stage_route': parity,
             'kernel_ms_per_step': round(all_ms / 3, 4),
-            'kernel_time_how': 'event-bracketed entry points of one scan, one scan at a time; an entry point that launches once per 16 disks '
+            'kernel_time_how': 'event-bracketed entry points of one scan, one scan at a time; an entry point that launches once per 24 disks '
                                'has its host work between the launches inside the bracket -- the kernels alone are in '
                                'profiles/*_step_kernel_table_c4.txt (rocprofv3)',
             'pass_a': {'avg_launch_ms': round(acc_ms / acc_n, 5) if acc_n else None, 'algorithmic_bytes': bytes_a,

@@ -541,7 +541,13 @@ __device__ __forceinline__ void hist_rank_top_job(const uint8_t* __restrict__ hi
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunk = 1023 - tid;
     int local = 0;
-    for (int t = 0; t < ntiles; ++t) local += (int)chunk_tile[t * 1024 + chunk];
+    for (int t = 0; t < ntiles; t += 4) {                   // (four tiles' loads issued together: a 2 x 2 grid is one round trip)
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = chunk_tile[min(t + u, ntiles - 1) * 1024 + chunk];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) local += t + u < ntiles ? (int)v[u] : 0;
+    }
     int incl = local;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -558,7 +564,13 @@ __device__ __forceinline__ void hist_rank_top_job(const uint8_t* __restrict__ hi
     const int ch = pick[0], above = pick[1];
     const int bin = ch * 64 + 63 - lane;
     int c = 0;
-    for (int t = 0; t < ntiles; ++t) c += hist8[(int64_t)t * HIST16 + bin];
+    for (int t = 0; t < ntiles; t += 4) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = hist8[(int64_t)min(t + u, ntiles - 1) * HIST16 + bin];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c += t + u < ntiles ? (int)v[u] : 0;
+    }
     int inc2 = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -1193,14 +1205,19 @@ __global__ __launch_bounds__(256) void k_image_hist8(const uint8_t* __restrict__
 // MSB-first radix select on the 16-bit values: pass 0 histograms the high byte, pass 1 the low byte of the
 // pixels whose high byte was chosen.  hist: [n_ranks][2][256] u32, zeroed.  Every workgroup replays pass 0's
 // choice with a workgroup-wide scan (one bin per thread).
-__device__ __forceinline__ void pick_digit(const uint32_t* __restrict__ hist, int slot_stride, int64_t rank, int& digit, int64_t& below,
-                                           int slots = SEL_SLOTS) {
+template <int SLOTS = SEL_SLOTS>                             // (a compile-time count: the copies' loads are issued together, not one after the other)
+__device__ __forceinline__ void pick_digit(const uint32_t* __restrict__ hist, int slot_stride, int64_t rank, int& digit, int64_t& below) {
     __shared__ int64_t wave_tot[16];
     __shared__ int64_t chosen[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int64_t c = 0;                                         // one bin per thread; a wider workgroup's other threads idle
-    if (tid < 256)
-        for (int k = 0; k < slots; ++k) c += hist[(int64_t)k * slot_stride + tid];
+    if (tid < 256) {
+        uint32_t v[SLOTS];
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) v[k] = hist[(int64_t)k * slot_stride + tid];
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) c += v[k];
+    }
     int64_t incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -1259,8 +1276,13 @@ __global__ __launch_bounds__(1024) void k_select16_pass(const SelectPassArgs kar
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         const int stride = (1 + n_ranks) * 256;
         int64_t c = 0;
-        if (tid < 256)
-            for (int k = 0; k < SEL_SLOTS; ++k) c += hist[(int64_t)k * stride + tid];
+        if (tid < 256) {
+            uint32_t v[SEL_SLOTS];
+#pragma unroll
+            for (int k = 0; k < SEL_SLOTS; ++k) v[k] = hist[(int64_t)k * stride + tid];
+#pragma unroll
+            for (int k = 0; k < SEL_SLOTS; ++k) c += v[k];
+        }
         int64_t incl = c;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -1418,7 +1440,7 @@ __global__ __launch_bounds__(256) void k_select16_final(const SelectFinalArgs ka
         }
         const uint32_t d = (uint32_t)(hi - (int)w0);
         if (d < (uint32_t)SEL_NW) {                          // the blend kernel has counted this high byte's low bytes (always valid)
-            pick_digit(win + d * 256, SEL_NW * 256, ranks.v[blockIdx.x] - below, lo, below2, SEL_WIN_SLOTS);
+            pick_digit<SEL_WIN_SLOTS>(win + d * 256, SEL_NW * 256, ranks.v[blockIdx.x] - below, lo, below2);
             if (threadIdx.x == 0) out[blockIdx.x] = (double)((hi << 8) | lo);
             return;
         }

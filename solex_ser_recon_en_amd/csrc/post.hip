@@ -171,7 +171,7 @@ extern "C" int shg_downscale_mean_u16(const uint16_t* img, int64_t h, int64_t w,
 // went back over protus for the disc).  Same arithmetic per pixel as k_rescale / k_fill_disc.
 namespace {
 struct Bounds6 { double lo[3], span[3]; };
-constexpr int kProductsBatch = 8;                   // disks per launch of the products kernels (their bounds and five pointer tables travel by value)
+constexpr int kProductsBatch = 24;                  // disks per launch of the products kernels (their bounds and five pointer tables travel by value: 2.2 KB of the 4 KB of kernel arguments; a 21-disk stack is one launch -- three launches of eight had three tails)
 using ProdPtrs = shg::PtrBatchN<kProductsBatch>;
 struct BoundsBatch { Bounds6 v[kProductsBatch]; };
 

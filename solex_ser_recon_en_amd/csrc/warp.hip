@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_minmax(const uint16_t* __restrict__ src
     }
 }
 
-constexpr int kWarpBatch = 16;                     // disks per launch (their transform rows travel by value)
+constexpr int kWarpBatch = 24;                     // disks per launch (their transform rows travel by value; a 21-disk stack is one launch)
 struct WarpRows { double h[kWarpBatch][3]; };
 constexpr int WARP_ROWS = 4;                       // output rows per lane: their 2 x WARP_ROWS loads are issued before the first use
 

@@ -89,7 +89,7 @@ def test_c2_through_the_pool(pkg, monkeypatch):
 
 
 def test_c4_through_the_pool(pkg, monkeypatch):
-    """BASELINE configs[3] (-w -10:10:1: 21 requested disks, shg_scan_file's warps in two launches of 16 + 5): six different
+    """BASELINE configs[3] (-w -10:10:1: 21 requested disks, one launch per kernel for all 21 disks): six different
     scans in flight.  All 21 disks and 42 products of every scan against the stage route bit for bit; shifts -10, 0, +10 of
     the first scan against the oracle."""
     SHG_MAIN, Solex_recon, ops, outputs, synth = pkg
@@ -111,6 +111,20 @@ def test_c5_files_through_the_pool(pkg, monkeypatch):
     staged = run_batch(pkg, stacks, {}, False, monkeypatch)
     same_as_stage_route(pooled, staged)
     against_the_oracle('C5 pooled, first 1000 frames', ops.stack_to_host(stacks[0]), {}, pooled[0], [0])
+
+
+def test_more_disks_than_a_launch_takes(pkg, monkeypatch):
+    """-w -14:14:1 on a small scan: 29 requested disks, more than the 24 a launch of the warp and products kernels carries (their
+    pointer tables and bounds travel by value) -- the second launch's disks must come out like the first's: pooled route == stage
+    route for every raw disk and product, and three shifts against the oracle."""
+    SHG_MAIN, Solex_recon, ops, outputs, synth = pkg
+    extra = {'shift': list(range(-14, 15))}
+    stacks = [synth.synth_frames_torch(600, 640, 64, 16, seed=70 + i) for i in range(2)]
+    pooled = run_batch(pkg, stacks, extra, True, monkeypatch)
+    assert all(len(r) == 29 for _, _, r in pooled)
+    staged = run_batch(pkg, stacks, extra, False, monkeypatch)
+    same_as_stage_route(pooled, staged)
+    against_the_oracle('29 disks', ops.stack_to_host(stacks[0]), {}, pooled[0], [-14, 0, 14])
 
 
 def test_whole_c5_files_through_the_pool_against_the_oracle(pkg, monkeypatch):
