@@ -514,6 +514,10 @@ def extra_leg(what, pool, shifts, steps, warmup, workers, run_scans, barrier, _l
     # every slot of the pool (workers + 2 scans in flight) sizes its arenas and leases its pinned areas on its first scans of a new
     # shape: two rounds through all of them before anything is timed
     run_scans(max(warmup, 2 * (workers + 2), steps), workers, shifts=shifts, pool=pool)      # (and a whole region's worth: the feeder's buffers for that many tasks)
+    import gc
+    gc.collect()                            # (what the warm-up left behind goes now, not as a full collection inside the first region)
+    gc.freeze()
+    torch.cuda.synchronize()
     times = []
     for r in range(3):
         barrier()
