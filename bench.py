@@ -135,17 +135,21 @@ def launch_ranks(n):
                                       stdout=None if r == 0 else sys.stderr))
     rc = 0
     pending = list(procs)
-    while pending:
-        for pr in list(pending):
-            code = pr.poll()
-            if code is None:
-                continue
-            pending.remove(pr)
-            if code != 0 and rc == 0:
-                rc = code
-                for other in pending:                        # a rank that fails leaves the others in a collective for good
-                    other.terminate()
-        time.sleep(0.05)
+    try:
+        while pending:
+            for pr in list(pending):
+                code = pr.poll()
+                if code is None:
+                    continue
+                pending.remove(pr)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for other in pending:                    # a rank that fails leaves the others in a collective for good
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in pending:                                   # (this process is being stopped: its ranks go with it, by their own PIDs)
+            pr.terminate()
     return rc
 
 
