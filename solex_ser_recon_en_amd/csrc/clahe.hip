@@ -998,6 +998,7 @@ template <int PX, bool COUNT, bool T2> __global__ __launch_bounds__(256) void k_
             xa1[j] = 1.0f - xa[j];
             tx1[j] = max(t1, 0);
             tx2[j] = min(t1 + 1, tiles - 1);
+            if (T2) { tx1[j] *= 16; tx2[j] *= 16; }          // (2 x 2 grid: the entry's bit offset inside its tile row's word)
         }
     };
     int64_t x0 = 0;
@@ -1077,10 +1078,10 @@ template <int PX, bool COUNT, bool T2> __global__ __launch_bounds__(256) void k_
             uint32_t l11, l12, l21, l22;
             if (T2) {
                 const uint32_t top = ty1 ? q4[j].y : q4[j].x, bot = ty2 ? q4[j].y : q4[j].x;
-                l11 = (top >> (16 * tx1[j])) & 0xffffu;
-                l12 = (top >> (16 * tx2[j])) & 0xffffu;
-                l21 = (bot >> (16 * tx1[j])) & 0xffffu;
-                l22 = (bot >> (16 * tx2[j])) & 0xffffu;
+                l11 = (top >> tx1[j]) & 0xffffu;
+                l12 = (top >> tx2[j]) & 0xffffu;
+                l21 = (bot >> tx1[j]) & 0xffffu;
+                l22 = (bot >> tx2[j]) & 0xffffu;
             } else {
                 const uint16_t* e = lut + (int64_t)px[j] * ntiles;
                 l11 = e[ty1 * tiles + tx1[j]];
