@@ -57,7 +57,9 @@ __global__ __launch_bounds__(256) void k_minmax(const uint16_t* __restrict__ src
 
 constexpr int kWarpBatch = 24;                     // disks per launch (their transform rows travel by value; a 21-disk stack is one launch)
 struct WarpRows { double h[kWarpBatch][3]; };
-constexpr int WARP_ROWS = 4;                       // output rows per lane: their 2 x WARP_ROWS loads are issued before the first use
+// Output rows per lane (their 2 x WARP_ROWS loads are issued before the first use).  Every wave pays for its set-up (kernel arguments,
+// the transform row, the extrema) once, so more rows per lane is less work in total -- as long as there are still enough workgroups
+// to fill 256 CUs several times over: 4 rows for a pair of disks, 8 for a Doppler stack (profiles/r05_sweeps.txt).
 
 // grid (x, ceil(rows / WARP_ROWS), disks): blockIdx.z picks source, destination, transform row and extrema
 using WarpPtrs = shg::PtrBatchN<kWarpBatch>;
@@ -70,6 +72,7 @@ struct WarpArgs {
     WarpPtrs mms;
 };
 
+template <int WARP_ROWS>
 __global__ __launch_bounds__(256) void k_warp_rows(const WarpArgs kargs) {
     const WarpPtrs& srcs = kargs.srcs;
     const WarpPtrs& dsts = kargs.dsts;
@@ -127,6 +130,12 @@ __global__ __launch_bounds__(256) void k_warp_rows(const WarpArgs kargs) {
     }
 }
 
+constexpr int64_t kWarpWideAbove = 16384;          // workgroups an 8-rows-a-lane launch must still have
+int warp_rows_forced() {                           // SHG_WARP_ROWS=4|8|16: the A / B switch of the sweep
+    static const int v = [] { const char* e = getenv("SHG_WARP_ROWS"); const int n = e ? atoi(e) : 0; return n == 4 || n == 8 || n == 16 ? n : 0; }();
+    return v;
+}
+
 }  // namespace
 
 extern "C" int shg_warp_rows_u16(const uint16_t* src, int64_t h, int64_t w, int64_t src_pitch, double h00, double h01,
@@ -170,11 +179,18 @@ int shg::warp_rows_batch(const uint16_t* const* host_srcs, int64_t k, int64_t h,
         WarpRows rows = {};
         for (int d = 0; d < m; ++d)
             for (int j = 0; j < 3; ++j) rows.h[d][j] = host_h3[3 * (i0 + d) + j];
-        dim3 grid((unsigned)((out_w + 255) / 256), (unsigned)((out_h + WARP_ROWS - 1) / WARP_ROWS), (unsigned)m);
-        if (int e = shg::launch(k_warp_rows, grid, dim3(256), 0, st,
-                               WarpArgs{shg::make_batch_n<kWarpBatch>(host_srcs, (int)i0, m), h, w, src_pitch, rows, shg::make_batch_n<kWarpBatch>(host_dsts, (int)i0, m),
-                                        out_h, out_w, dst_pitch, shg::make_batch_n<kWarpBatch>(host_minmax2, (int)i0, m)}, "k_warp_rows"))
-            return e;
+        const WarpArgs args{shg::make_batch_n<kWarpBatch>(host_srcs, (int)i0, m), h, w, src_pitch, rows, shg::make_batch_n<kWarpBatch>(host_dsts, (int)i0, m),
+                            out_h, out_w, dst_pitch, shg::make_batch_n<kWarpBatch>(host_minmax2, (int)i0, m)};
+        const int64_t gx = (out_w + 255) / 256;
+        int rows_per_lane = gx * ((out_h + 7) / 8) * m >= kWarpWideAbove ? 8 : 4;
+        if (warp_rows_forced()) rows_per_lane = warp_rows_forced();
+        auto go = [&](auto R) {
+            dim3 grid((unsigned)gx, (unsigned)((out_h + R.value - 1) / R.value), (unsigned)m);
+            return shg::launch(k_warp_rows<R.value>, grid, dim3(256), 0, st, args, "k_warp_rows");
+        };
+        const int e = rows_per_lane == 16 ? go(std::integral_constant<int, 16>{})
+                    : rows_per_lane == 8 ? go(std::integral_constant<int, 8>{}) : go(std::integral_constant<int, 4>{});
+        if (e) return e;
     }
     return 0;
 }
