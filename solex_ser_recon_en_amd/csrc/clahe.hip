@@ -112,7 +112,8 @@ __global__ __launch_bounds__(1024) void k_tile_hist16(const uint16_t* __restrict
 // line, solex_util.py:515-516: saturate, truncate) through the crop / pad block (new[:, dx0:dx0+n] = img[:, sx0:sx0+n], the rest
 // img[0, 0]).  The workgroup stores the pixels it has just formed into imgs (the "uncontrasted" image) and counts them: one
 // read of the frame instead of k_scale_rows8's read + write, k_crop_pad's read + write and this kernel's read, and two launches
-// less per scan.  Only on a tile grid that divides the image (no reflected border: every pixel is some tile's exactly once).
+// less per scan.  (A grid that does not divide the image: the pixels of OpenCV's reflected border are formed a second time, for the
+// count alone.)
 struct FusedSrc {
     shg::PtrBatch raw;               // the frames before the row scaling, [h][raw_pitch]
     int64_t raw_pitch;
@@ -163,6 +164,10 @@ struct HistSlicesArgs {
 // 65536 - 255 pixels: the u16 counters cannot wrap), clamps its counters to `clip` between chunks, and stores them as bytes
 // (clip <= 255) or nibbles (clip <= 15): a slice of any length leaves 64 or 32 KB instead of 128 KB per 65535 pixels.
 // The frame's highest order statistics survive the clamping too (hist_rank_top_job).
+// a coordinate of the reflected border, i in [n, n + tiles): it mirrors once (clahe_impl requires n > tiles) -- without reflect101's
+// 64-bit remainder, which a wave pays for in full when one lane of it is in the border
+__device__ __forceinline__ int64_t mirror101(int64_t i, int64_t n) { return 2 * (n - 1) - i; }
+
 template <bool FUSED, int BITS> __global__ __launch_bounds__(1024) void k_tile_hist16_slices(const HistSlicesArgs kargs) {
     const shg::PtrBatch& imgs = kargs.imgs;
     const int64_t h = kargs.h, w = kargs.w, pitch = kargs.pitch, th = kargs.th, tw = kargs.tw;
@@ -190,7 +195,11 @@ template <bool FUSED, int BITS> __global__ __launch_bounds__(1024) void k_tile_h
         // the factors of this slice's rows (they may live in the host's staging area: one trip for all of them, here) and the
         // value of the padding columns
         const double* c = scaled ? fs.c + (int64_t)blockIdx.z * h : nullptr;
-        for (int i = threadIdx.x; i <= yb - ya; i += 1024) cf[i] = scaled ? row_factor_for_fma(c[ty * th + ya + i]) : 1.0;
+        for (int i = threadIdx.x; i <= yb - ya; i += 1024) {
+            int64_t r = ty * th + ya + i;
+            if (r >= h) r = mirror101(r, h);           // a row of OpenCV's border: the factor of the row it mirrors
+            cf[i] = scaled ? row_factor_for_fma(c[r]) : 1.0;
+        }
         if (threadIdx.x == 0) fill_s = scaled ? scale_px(raw[0], c[0]) : (uint32_t)raw[0];
     }
     __syncthreads();
@@ -214,20 +223,26 @@ template <bool FUSED, int BITS> __global__ __launch_bounds__(1024) void k_tile_h
         const int64_t xbase = tx * tw;
         auto count = [&](uint32_t v) { atomicAdd(&lh[v >> 1], 1u << ((v & 1u) << 4)); };
         if (vec) {
-            // rows of 16-byte vectors, none reflected: a wave takes two rows a round (its share of a 65535-pixel slice is four),
-            // three vectors of each per lane, all six loads in flight before the first count -- pixel by pixel the wave waited
-            // for memory a dozen times per slice, which is what this kernel's time was
-            // (FUSED with vec: no crop -- the frame's columns are the image's)
-            const int nvr = twi / 8;
+            // rows of 16-byte vectors: a wave takes two rows a round (its share of a 65535-pixel slice is four), three vectors of each
+            // per lane, all six loads in flight before the first count -- pixel by pixel the wave waited for memory a dozen times per
+            // slice, which is what this kernel's time was.  (FUSED with vec: no crop -- the frame's columns are the image's.)
+            // The tile's columns of the image are [xa, xb): whole vectors from xa8 to xb8, and up to 7 + 7 pixels before and after them
+            // (a tile 1049 pixels wide starts anywhere) plus the columns of the reflected border, [xb, xbase + tw) -- at most 30 pixels
+            // a row, taken one per lane (lanes 0-31: the first row, 32-63: the second) behind the vectors.
+            const int64_t xa = xbase, xb = min(xbase + tw, w);
+            const int64_t xa8 = (xa + 7) & ~(int64_t)7, xb8 = max(xb & ~(int64_t)7, xa8);
+            const int nvr = (int)((xb8 - xa8) / 8);
+            const int n_head = (int)(min(xa8, xb) - xa), n_tail = (int)(xb - max(xb8, xa + n_head)), n_edge = n_head + n_tail + (int)(xbase + tw - xb);
             for (int yy = ca + wave; yy <= cb; yy += 32) {
                 const bool two = yy + 16 <= cb;
                 int64_t y0 = ty * th + yy, y1 = ty * th + (two ? yy + 16 : yy);
-                if (!FUSED) {
-                    if (y0 >= h) y0 = shg::reflect101(y0, h);
-                    if (y1 >= h) y1 = shg::reflect101(y1, h);
-                }
-                const uint4* r0 = reinterpret_cast<const uint4*>((FUSED ? raw + y0 * fs.raw_pitch : img + y0 * pitch) + xbase);
-                const uint4* r1 = reinterpret_cast<const uint4*>((FUSED ? raw + y1 * fs.raw_pitch : img + y1 * pitch) + xbase);
+                const bool border0 = y0 >= h, border1 = y1 >= h;             // rows of the reflected border: counted, not stored
+                if (border0) y0 = mirror101(y0, h);
+                if (border1) y1 = mirror101(y1, h);
+                const uint16_t* s0 = FUSED ? raw + y0 * fs.raw_pitch : img + y0 * pitch;
+                const uint16_t* s1 = FUSED ? raw + y1 * fs.raw_pitch : img + y1 * pitch;
+                const uint4* r0 = reinterpret_cast<const uint4*>(s0 + xa8);
+                const uint4* r1 = reinterpret_cast<const uint4*>(s1 + xa8);
                 const double c0 = FUSED ? cf[yy - ya] : 1.0, c1 = FUSED ? cf[(two ? yy + 16 : yy) - ya] : 1.0;
                 const double k0 = c0 * 0x1p+52, k1 = c1 * 0x1p+52;
                 for (int v0 = lane; v0 < nvr; v0 += 64 * 3) {
@@ -251,19 +266,38 @@ template <bool FUSED, int BITS> __global__ __launch_bounds__(1024) void k_tile_h
 #pragma unroll
                                     for (int j = 0; j < 4; ++j) d[j] = (scale_px_fma(d[j] & 0xffffu, cy, kc) & 0xffffu) | (scale_px_fma(d[j] >> 16, cy, kc) << 16);
                                 }
-                                uint4* dst = reinterpret_cast<uint4*>(fin + (rr ? y1 : y0) * pitch + xbase);
-                                dst[v0 + 64 * u] = make_uint4(d[0], d[1], d[2], d[3]);
+                                if (!(rr ? border1 : border0)) {
+                                    uint4* dst = reinterpret_cast<uint4*>(fin + (rr ? y1 : y0) * pitch + xa8);
+                                    dst[v0 + 64 * u] = make_uint4(d[0], d[1], d[2], d[3]);
+                                }
                             }
 #pragma unroll
                             for (int j = 0; j < 4; ++j) { count(d[j] & 0xffffu); count(d[j] >> 16); }
                         }
                     }
                 }
+                const int second = lane >> 5, l = lane & 31;
+                if (l < n_edge && (second == 0 || two)) {
+                    const int64_t x = l < n_head ? xa + l : (l < n_head + n_tail ? xb - n_tail + (l - n_head) : xb + (l - n_head - n_tail));
+                    const bool border_col = x >= w;
+                    const int64_t xr = border_col ? mirror101(x, w) : x;
+                    const int64_t y = second ? y1 : y0;
+                    uint32_t v = (second ? s1 : s0)[xr];
+                    if (FUSED) {
+                        if (scaled) v = scale_px_fma(v, second ? c1 : c0, second ? k1 : k0) & 0xffffu;
+                        if (!border_col && !(second ? border1 : border0)) fin[y * pitch + x] = (uint16_t)v;
+                    }
+                    count(v);
+                }
             }
         } else {
             for (int yy = ca + wave; yy <= cb; yy += 16) {
+                // A grid that does not divide the image: OpenCV pads it below and to the right with its mirror image (REFLECT_101) and the
+                // tiles count those pixels too.  They are pixels of the image -- formed here a second time where the image is being made
+                // (FUSED), and counted, but not stored.
                 int64_t y = ty * th + yy;
-                if (!FUSED && y >= h) y = shg::reflect101(y, h);
+                const bool border_row = y >= h;
+                if (border_row) y = mirror101(y, h);
                 const uint16_t* row = FUSED ? raw + y * fs.raw_pitch : img + y * pitch;
                 const double cy = FUSED ? cf[yy - ya] : 1.0, kc = cy * 0x1p+52;
                 const uint32_t fill = FUSED ? fill_s : 0u;
@@ -271,17 +305,18 @@ template <bool FUSED, int BITS> __global__ __launch_bounds__(1024) void k_tile_h
                 // latency 33 times over (20 us)
                 for (int x0 = lane; x0 < twi; x0 += 64 * 8) {
                     uint32_t v[8];
-                    bool inside[8];
+                    bool inside[8], border[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int xx = x0 + 64 * u;
                         int64_t x = xbase + (xx < twi ? xx : 0);
+                        border[u] = border_row || x >= w;
+                        if (x >= w) x = mirror101(x, w);
                         if (FUSED) {
                             const int64_t j = x - fs.dx0;                      // the crop / pad block: column x of the image <- column sx0 + j of the frame
                             inside[u] = j >= 0 && j < fs.ncopy;
                             v[u] = row[inside[u] ? fs.sx0 + j : 0];
                         } else {
-                            if (x >= w) x = shg::reflect101(x, w);
                             v[u] = row[x];
                         }
                     }
@@ -290,7 +325,7 @@ template <bool FUSED, int BITS> __global__ __launch_bounds__(1024) void k_tile_h
                         if (x0 + 64 * u >= twi) continue;
                         if (FUSED) {
                             v[u] = inside[u] ? (scaled ? scale_px_fma(v[u], cy, kc) & 0xffffu : v[u]) : fill;
-                            fin[y * pitch + xbase + x0 + 64 * u] = (uint16_t)v[u];
+                            if (!border[u]) fin[y * pitch + xbase + x0 + 64 * u] = (uint16_t)v[u];
                         }
                         count(v[u]);
                     }
@@ -494,17 +529,66 @@ template <int BITS> __global__ __launch_bounds__(256) void k_hist_reduce_sat(con
 // redistribution adds there -- `batch` per bin and one more for the bins 0, step, 2 step, ... below residual * step.
 struct Ranks8 { int64_t v[8]; };            // the requested ranks travel as a kernel argument: no host-to-device copy per call
 
+// The pixels OpenCV's reflected border adds to the tile histograms when the grid does not divide the image (tile_geometry): rows
+// h .. he - 1 over the padded width, then columns w .. we - 1 of the image's own rows -- a few thousand mirror images of pixels near the
+// bottom and the right edge.  The FRAME's order statistics, read off the same histograms, must leave them out again: the workgroup
+// that finds a rank walks over them twice (their 64-bin runs, then the bins of the run picked) and subtracts.
+struct BorderPx {
+    shg::PtrBatch imgs;              // the finished images (the histogram kernel has run)
+    int64_t h, w, pitch, he, we;     // he == h and we == w: no border
+    __host__ __device__ bool any() const { return he != h || we != w; }
+};
+// (he - h <= tiles < h and we - w <= tiles < w -- clahe_impl requires it -- so a border coordinate mirrors once: 2 (n - 1) - i)
+__device__ __forceinline__ uint32_t border_pixel(const BorderPx& bp, const uint16_t* __restrict__ img, int i, int below, int wide) {
+    int y, x;
+    if (i < below) { y = (int)bp.h + i / (int)bp.we; x = i % (int)bp.we; }
+    else { const int j = i - below; y = j / wide; x = (int)bp.w + j % wide; }
+    if (y >= (int)bp.h) y = 2 * ((int)bp.h - 1) - y;
+    if (x >= (int)bp.w) x = 2 * ((int)bp.w - 1) - x;
+    return img[(int64_t)y * bp.pitch + x];
+}
+// The walk over the border pixels, twice: a thread's first eight (all of them for a border of up to 8 x the workgroup's threads: 6 200
+// of a 2000 x 2097 image on a 2 x 2 grid) are loaded together the first time -- eight dependent round trips otherwise, 10 us of a 15 us
+// kernel -- and kept in registers for the second.
+struct BorderRegs { uint32_t v[8]; };
+template <bool FIRST, typename F>
+__device__ __forceinline__ void for_each_border_pixel(const BorderPx& bp, const uint16_t* __restrict__ img, BorderRegs& regs, F f) {
+    const int below = (int)((bp.he - bp.h) * bp.we), wide = max((int)(bp.we - bp.w), 1), n = below + (int)(bp.h * (bp.we - bp.w));
+    const int nt = (int)blockDim.x, tid = (int)threadIdx.x;
+    if (FIRST) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + u * nt;
+            regs.v[u] = i < n ? border_pixel(bp, img, i, below, wide) : ~0u;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (regs.v[u] != ~0u) f(regs.v[u]);
+    for (int i = tid + 8 * nt; i < n; i += nt) f(border_pixel(bp, img, i, below, wide));
+}
+
 // One order statistic of the image whose per-tile histograms CLAHE has built (valid when the tile grid divides the image: no
 // reflected padding in the histograms), by one workgroup of 1024: lane t takes the t-th run of 64 bins from the chunk sums, a
 // workgroup scan finds the run that holds the rank, one wave scans its 64 bins.  (k_hist_ranks, and the extra workgroups of
 // k_tile_lut16_blocks.)
 __device__ __forceinline__ void hist_rank_job(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ chunk_sums, int chunk_sets, int ntiles,
-                                              int64_t rank, double* __restrict__ out) {
+                                              int64_t rank, double* __restrict__ out, const BorderPx* bp = nullptr, const uint16_t* __restrict__ img = nullptr) {
     __shared__ int64_t wtot[16];
     __shared__ int64_t pick[2];
+    __shared__ int border_n[1024];   // border pixels per 64-bin run, then (the first 64) per bin of the run picked
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool border = bp && bp->any();
+    BorderRegs regs;
     int64_t local = 0;
     for (int k = 0; k < chunk_sets; ++k) local += chunk_sums[k * 1024 + tid];     // one set (k_chunk_sums) or one per tile (k_hist_reduce)
+    if (border) {
+        border_n[tid] = 0;
+        __syncthreads();
+        for_each_border_pixel<true>(*bp, img, regs, [&](uint32_t v) { atomicAdd(&border_n[v >> 6], 1); });
+        __syncthreads();
+        local -= border_n[tid];
+    }
     int64_t incl = local;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -516,9 +600,15 @@ __device__ __forceinline__ void hist_rank_job(const uint32_t* __restrict__ hist,
     for (int i = 0; i < wave; ++i) incl += wtot[i];
     if (incl - local <= rank && rank < incl) { pick[0] = tid; pick[1] = incl - local; }
     __syncthreads();
-    if (wave != 0) return;
     const int64_t chunk = pick[0], below = pick[1];
-    int64_t c = 0;
+    if (border) {
+        if (tid < 64) border_n[tid] = 0;
+        __syncthreads();
+        for_each_border_pixel<false>(*bp, img, regs, [&](uint32_t v) { if ((int64_t)(v >> 6) == chunk) atomicAdd(&border_n[v & 63u], 1); });
+        __syncthreads();
+    }
+    if (wave != 0) return;
+    int64_t c = border ? -(int64_t)border_n[lane] : 0;
     for (int t = 0; t < ntiles; ++t) c += hist[(int64_t)t * HIST16 + chunk * 64 + lane];
     int64_t inc2 = c;
 #pragma unroll
@@ -534,50 +624,97 @@ __device__ __forceinline__ void hist_rank_job(const uint32_t* __restrict__ hist,
 // below K <= clip, so no (tile, bin) up there was clamped and the clamped sums are the true ones; at the answer's bin the running sum
 // reaches K whether that bin was clamped (a clamped bin alone holds clip >= K) or not.  One workgroup of 1024: lane t takes the 64-bin
 // run 1023 - t, a workgroup scan finds the run that reaches K, wave 0 scans its bins from the top.
+//
+// With a reflected border (BorderPx) the clamped counts hold border pixels as well.  Taking them out again is exact as long as no (tile,
+// bin) ABOVE the answer's bin was clamped -- which the walk checks on its way: the clamped sum above the bin it settles on, border pixels
+// included, stays below `clip` (then every count up there is a true one; a clamped bin further up that made the walk pass the true
+// answer by is above the bin it ends on, and seen).  Where it does not -- more than a handful of the frame's very brightest pixels mirrored
+// in the border -- the answer is NaN and the caller selects over the image instead (shg_stage_process_frames).
 __device__ __forceinline__ void hist_rank_top_job(const uint8_t* __restrict__ hist8, const uint32_t* __restrict__ chunk_tile, int ntiles, int64_t k_top,
-                                                  double* __restrict__ out) {
-    __shared__ int wtot[16];
-    __shared__ int pick[2];
+                                                  double* __restrict__ out, int clip = 0, const BorderPx* bp = nullptr, const uint16_t* __restrict__ img = nullptr) {
+    __shared__ int wtot[2][16];
+    __shared__ int pick[3];
+    __shared__ int border_n[1024];   // border pixels per 64-bin run (from the top), then (the first 64) per bin of the run picked
+    __shared__ int first_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool border = bp && bp->any();
+    BorderRegs regs;
     const int chunk = 1023 - tid;
-    int local = 0;
+    int with = 0;                                           // (`with` the border pixels: what the histograms hold)
     for (int t = 0; t < ntiles; t += 4) {                   // (four tiles' loads issued together: a 2 x 2 grid is one round trip)
         uint32_t v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = chunk_tile[min(t + u, ntiles - 1) * 1024 + chunk];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) local += t + u < ntiles ? (int)v[u] : 0;
+        for (int u = 0; u < 4; ++u) with += t + u < ntiles ? (int)v[u] : 0;
     }
-    int incl = local;
+    int local = with;
+    if (border) {
+        border_n[tid] = 0;
+        if (tid == 0) { pick[0] = -1; first_s = 1024; }
+        __syncthreads();
+        for_each_border_pixel<true>(*bp, img, regs, [&](uint32_t v) { atomicAdd(&border_n[1023 - (int)(v >> 6)], 1); });
+        __syncthreads();
+        local -= border_n[tid];
+    }
+    int incl = local, incl_with = with;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
+        const int o = __shfl_up(incl, d), ow = __shfl_up(incl_with, d);
+        if (lane >= d) { incl += o; incl_with += ow; }
     }
-    if (lane == 63) wtot[wave] = incl;
+    if (lane == 63) { wtot[0][wave] = incl; wtot[1][wave] = incl_with; }
     __syncthreads();
-    for (int i = 0; i < wave; ++i) incl += wtot[i];
+    for (int i = 0; i < wave; ++i) { incl += wtot[0][i]; incl_with += wtot[1][i]; }
     const int K = (int)k_top;
-    if (incl - local < K && K <= incl) { pick[0] = chunk; pick[1] = incl - local; }
+    const bool reached = incl - local < K && K <= incl;
+    if (border) {
+        // (sums that clamped bins and the border pixels taken out of them have made non-monotone can reach K in several runs: the
+        // first from the top is the one the argument above is about)
+        if (reached) atomicMin(&first_s, tid);
+        __syncthreads();
+        if (reached && tid == first_s) { pick[0] = chunk; pick[1] = incl - local; pick[2] = incl_with - with; }
+    } else if (reached) { pick[0] = chunk; pick[1] = incl - local; pick[2] = incl_with - with; }
     __syncthreads();
+    const int ch = pick[0], above = pick[1], above_with = pick[2];
+    if (border) {
+        if (ch < 0) {                                       // clamped counts that never reach K
+            if (tid == 0) *out = __builtin_nan("");
+            return;
+        }
+        if (tid < 64) border_n[tid] = 0;
+        __syncthreads();
+        for_each_border_pixel<false>(*bp, img, regs, [&](uint32_t v) { if ((int)(v >> 6) == ch) atomicAdd(&border_n[v & 63u], 1); });
+        __syncthreads();
+    }
     if (wave != 0) return;
-    const int ch = pick[0], above = pick[1];
     const int bin = ch * 64 + 63 - lane;
-    int c = 0;
+    int cw = 0;
     for (int t = 0; t < ntiles; t += 4) {
         uint32_t v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = hist8[(int64_t)min(t + u, ntiles - 1) * HIST16 + bin];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) c += t + u < ntiles ? (int)v[u] : 0;
+        for (int u = 0; u < 4; ++u) cw += t + u < ntiles ? (int)v[u] : 0;
     }
-    int inc2 = c;
+    const int c = border ? cw - border_n[63 - lane] : cw;
+    int inc2 = c, inc2_with = cw;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(inc2, d);
-        if (lane >= d) inc2 += o;
+        const int o = __shfl_up(inc2, d), ow = __shfl_up(inc2_with, d);
+        if (lane >= d) { inc2 += o; inc2_with += ow; }
     }
-    if (above + inc2 - c < K && K <= above + inc2) *out = (double)bin;
+    const bool mine = above + inc2 - c < K && K <= above + inc2;
+    if (!border) {
+        if (mine) *out = (double)bin;
+        return;
+    }
+    const unsigned long long hits = __ballot(mine);
+    if (hits == 0) {
+        if (lane == 0) *out = __builtin_nan("");
+    } else if (lane == __ffsll((long long)hits) - 1) {
+        *out = above_with + inc2_with - cw < clip ? (double)bin : __builtin_nan("");
+    }
 }
 
 struct LutBlocksArgs {
@@ -597,6 +734,7 @@ struct LutBlocksArgs {
     int ranks_zstride;
     int tile_area;                   // SAT: the excess of a tile is its area minus its clipped total
     int ntiles;
+    BorderPx border;                 // the rank workgroups: what the frame's order statistics leave out again
 };
 
 // SAT: hist is hist8 (k_hist_reduce_sat) and rank[] counts from the top (the rank[r]-th largest pixel, 1 = the maximum)
@@ -620,8 +758,9 @@ template <bool SAT, bool ALLT> __global__ __launch_bounds__(1024) void k_tile_lu
         const int r = (int)blockIdx.x - 32;
         if (blockIdx.y == 0 && r < kargs.n_ranks) {
             double* out = kargs.ranks_out + (int64_t)blockIdx.z * kargs.ranks_zstride + r;
-            if (SAT) hist_rank_top_job(reinterpret_cast<const uint8_t*>(hist), zdisk(kargs.chunk_sums, zs, blockIdx.z), ntiles, kargs.rank[r], out);
-            else hist_rank_job(hist, zdisk(kargs.chunk_sums, zs, blockIdx.z), kargs.chunk_sets, ntiles, kargs.rank[r], out);
+            const uint16_t* img = kargs.border.any() ? kargs.border.imgs.at<const uint16_t>(blockIdx.z) : nullptr;
+            if (SAT) hist_rank_top_job(reinterpret_cast<const uint8_t*>(hist), zdisk(kargs.chunk_sums, zs, blockIdx.z), ntiles, kargs.rank[r], out, clip, &kargs.border, img);
+            else hist_rank_job(hist, zdisk(kargs.chunk_sums, zs, blockIdx.z), kargs.chunk_sets, ntiles, kargs.rank[r], out, &kargs.border, img);
         }
         return;
     }
@@ -1709,14 +1848,13 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
           // (read at every call, three getenv: the tests hold one setting against another in one process)
           const int sat_mode = [] { const char* v = getenv("SHG_CLAHE_SAT"); return v ? atoi(v) : 1; }();         // 0: never; 8: bytes even where nibbles would do
           const int64_t sat_px = [] { const char* v = getenv("SHG_CLAHE_SAT_PX"); return v && atoi(v) > 0 ? (int64_t)atoi(v) : (int64_t)0; }();      // pixels per slice (0: chosen below)
-          const int64_t n_px = (int64_t)ntiles * area;
           const bool want_ranks = ranks_job && ranks_done;
           bool sat = sat_mode != 0 && clip <= 255 && tw <= 65280 && (chunk_tile_out == nullptr || want_ranks);
           int64_t k_top[2] = {0, 0};
           if (sat && want_ranks) {
               for (int r = 0; r < 2; ++r) {
-                  k_top[r] = n_px - ranks_job->rank[r];          // rank (from the bottom, 0-based) -> the k-th largest
-                  sat = sat && h % tiles == 0 && w % tiles == 0 && k_top[r] >= 1 && k_top[r] <= clip;
+                  k_top[r] = h * w - ranks_job->rank[r];         // rank (from the bottom, 0-based) -> the k-th largest
+                  sat = sat && k_top[r] >= 1 && k_top[r] <= clip;
               }
           }
           const int bits = !sat ? 16 : (clip <= 15 && sat_mode != 8 ? 4 : 8);
@@ -1748,10 +1886,11 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
               if (dset.fused) slice_rows = std::min<int64_t>(slice_rows, kFusedMaxSliceRows);      // (the factors' room in LDS; th < 65536: 32 slices at most)
               slices = (th + slice_rows - 1) / slice_rows;
           }
-          int vec = w % tiles == 0 && tw % 8 == 0 && pitch % 8 == 0 && dset.aligned(15);
+          // (tw >= 64: the last tile column then holds columns of the image itself, and a row's loose ends fit half a wave)
+          int vec = tw >= 64 && pitch % 8 == 0 && dset.aligned(15);
           const dim3 hgrid((unsigned)slices, (unsigned)ntiles, nz);
           if (dset.fused) {
-              SHG_REQUIRE(h % tiles == 0 && w % tiles == 0 && slice_rows <= kFusedMaxSliceRows, SHG_E_ARG, "shg_clahe: the fused histogram needs a tile grid that divides the image");
+              SHG_REQUIRE(slice_rows <= kFusedMaxSliceRows, SHG_E_ARG, "shg_clahe: the fused histogram's slices hold at most %d rows", kFusedMaxSliceRows);
               uintptr_t abits = 0;
               for (int i = 0; i < dset.n; ++i) abits |= reinterpret_cast<uintptr_t>(dset.from.raw.p[i]);
               vec = vec && (abits & 15) == 0 && dset.from.raw_pitch % 8 == 0 && dset.from.sx0 == 0 && dset.from.dx0 == 0 && dset.from.ncopy == w;
@@ -1781,8 +1920,9 @@ int clahe_impl(const void* img, int64_t h, int64_t w, int64_t pitch, int bytes_p
           sat_k_top[1] = k_top[1];
           if (zero_sel) *sel_zeroed = true; }
         { SHG_PROF("clahe_lut", st);
-          LutBlocksArgs la{hist, se, clip, lut_scale, lut, dset.zs, 0, {0, 0}, nullptr, 0, nullptr, 0, (int)area, ntiles};
+          LutBlocksArgs la{hist, se, clip, lut_scale, lut, dset.zs, 0, {0, 0}, nullptr, 0, nullptr, 0, (int)area, ntiles, BorderPx{{}, h, w, pitch, h, w}};
           if (ranks_job && ranks_done) {                     // the frame's order statistics ride along (two more workgroups per disk)
+              la.border = BorderPx{dset.src, h, w, pitch, th * tiles, tw * tiles};
               la.n_ranks = 2;
               la.rank[0] = sat_path ? sat_k_top[0] : ranks_job->rank[0];
               la.rank[1] = sat_path ? sat_k_top[1] : ranks_job->rank[1];
@@ -2025,12 +2165,21 @@ extern "C" int shg_contrast_stats_u16(const uint16_t* frame, int64_t h, int64_t 
 // image_process's CLAHE + order statistics for the k disks of a file in one launch per kernel (shg_stage_process_frames; a
 // Doppler stack, Solex_recon.py:105-133).  host_frames / host_cl1: device pointers of k images of one shape; out5: [k][5];
 // workspace: k areas of shg_contrast_stats_workspace_bytes_for(h, w, tiles) bytes.  The batched launches need the atomics-free
-// CLAHE path (clip limit within the u16 range) and a tile grid that divides the image (percentiles read off the tile
-// histograms); anything else goes disk by disk through shg_contrast_stats_u16 -- same results either way.
+// CLAHE path (clip limit within the u16 range); anything else goes disk by disk through shg_contrast_stats_u16 -- same results
+// either way.  The frame's percentiles are read off the tile histograms -- on a grid that does not divide the image less the pixels
+// of the reflected border (BorderPx), and there out5[5 i + 0 / 1] may come back NaN: "select over frame i instead" (hist_rank_top_job).
 // Whether contrast_stats_batch takes its batched route (one launch per kernel for all disks, the slice histograms, the percentiles
 // read off them) for images of this shape -- the route that can also MAKE the images on its way (FrameSource).
+// SHG_CONTRAST_BATCH=0 (the tests): every disk through shg_contrast_stats_u16, one after the other -- the route these launches replaced
+static bool contrast_batch_allowed() {                       // (read at every call: the tests hold one setting against the other)
+    const char* v = getenv("SHG_CONTRAST_BATCH");
+    return !(v && v[0] == '0');
+}
+
 bool shg::contrast_stats_batches(int64_t h, int64_t w, int tiles, double clip_limit) {
-    if (!(tiles >= 1 && tiles <= 16 && h > 0 && w > 0 && h < 65536 && h % tiles == 0 && w % tiles == 0 && clip_limit > 0.0)) return false;
+    if (!contrast_batch_allowed()) return false;
+    if (!(tiles >= 1 && tiles <= 16 && h > 0 && w > 0 && h < 65536 && clip_limit > 0.0)) return false;
+    if (!(h % tiles == 0 && w % tiles == 0) && !(h > tiles && w > tiles)) return false;     // (a reflected border needs tiles + 1 pixels to mirror)
     int64_t th, tw;
     tile_geometry(h, w, tiles, &th, &tw);
     if (th * tw >= (1ll << 31) || tw > 65535) return false;
@@ -2045,7 +2194,8 @@ int shg::contrast_stats_batch(const uint16_t* const* host_frames, int64_t k, int
     SHG_REQUIRE(h > 0 && w > 0, SHG_E_ARG, "shg_contrast_stats_u16: empty image");
     const size_t per = shg_contrast_stats_workspace_bytes_for(h, w, tiles);
     SHG_REQUIRE(per != 0, SHG_E_WORKSPACE, "shg_contrast_stats_u16: bad tile count");
-    bool batched = (k > 1 || from) && workspace_bytes >= (size_t)k * per && tiles >= 1 && tiles <= 16 && h % tiles == 0 && w % tiles == 0 && clip_limit > 0.0;
+    bool batched = contrast_batch_allowed() && (k > 1 || from) && workspace_bytes >= (size_t)k * per && tiles >= 1 && tiles <= 16 && clip_limit > 0.0 &&
+                   ((h % tiles == 0 && w % tiles == 0) || (h > tiles && w > tiles));
     if (batched) {
         int64_t th, tw;
         tile_geometry(h, w, tiles, &th, &tw);

@@ -681,6 +681,20 @@ extern "C" int shg_stage_process_frames(const uint16_t* const* host_frames, int6
     STAGE_TRY(shg::contrast_products_batch(host_final, out_pitch, host_cl1, out_pitch, k, h, out_w, nullptr, host_hc, host_protus, host_cc, out_pitch,
                                            disc_x0, disc_y0, disc_r, stream, out5, g_bright, g_dark, stg.on_device(h_out5)));
     STAGE_SYNC(st, "shg_stage_process_frames");
+    // A tile grid that does not divide the image and saturated histograms: the frame's percentile could not be told from the pixels of
+    // the reflected border where more than a handful of the very brightest were mirrored in it (hist_rank_top_job) -- NaN.  Those disks
+    // take the select over the image and their products again.
+    bool again = false;
+    for (int64_t i = 0; i < k; ++i) {
+        const double* s = h_out5 + i * 5;
+        if (s[0] == s[0] && s[1] == s[1]) continue;
+        again = true;
+        SHG_HOST_TIME("frame percentile selected over the image");      // (tests read the count of these)
+        STAGE_TRY(shg_select_u16(host_final[i], h, out_w, out_pitch, ranks_frame, 2, out5 + 5 * i, cs_ws + (size_t)i * cs_each, cs_each, stream));
+        STAGE_TRY(shg::contrast_products_batch(host_final + i, out_pitch, host_cl1 + i, out_pitch, 1, h, out_w, nullptr, host_hc + i, host_protus + i, host_cc + i,
+                                               out_pitch, disc_x0, disc_y0, disc_r, stream, out5 + 5 * i, g_bright, g_dark, stg.on_device(h_out5 + 5 * i)));
+    }
+    if (again) STAGE_SYNC(st, "shg_stage_process_frames");
     for (int64_t i = 0; i < k; ++i) {
         const double* s = h_out5 + i * 5;
         const double bright = shg_host_lerp(s[0], s[1], g_bright);                            // basically the same as max

@@ -1275,6 +1275,76 @@ def test_frame_percentile_off_the_saturated_histograms(shape, k, flat_top, monke
                 np.testing.assert_array_equal(x, y, err_msg='%s[%d] SHG_CLAHE_SAT=%s' % (name, i, mode))
 
 
+@pytest.mark.parametrize('shape,k,crop,trans,streak', [((2000, 2097), 1, None, True, None), ((2000, 2097), 3, None, True, 'row'), ((2001, 2096), 2, None, False, None),
+                                                       ((2001, 2097), 1, None, True, 'column'), ((200, 305), 2, None, True, None),
+                                                       ((1000, 1049), 4, None, False, 'row'), ((2000, 2096), 2, (1999, 48, 0, 1999), True, None),
+                                                       ((600, 1001), 2, (1101, 0, 50, 1001), True, 'column'), ((999, 1203), 5, None, True, None)])
+def test_contrast_stage_on_a_tile_grid_that_does_not_divide_the_image(shape, k, crop, trans, streak, monkeypatch):
+    """cv2.createCLAHE pads an image its tile grid does not divide below and to the right with its mirror image (REFLECT_101; by a whole
+    `tiles` along an axis that does divide when the other does not) and the tiles count those pixels (solex_util.py:532-533).  The
+    batched contrast stage takes such images too (half of all scans: the width of a circularised disk is any number): the histogram
+    kernel counts the border pixels without storing them, and np.percentile(frame, 99.9999)'s order statistics, read off the tile
+    histograms, leave them out again (BorderPx) -- with saturated counters only while that can be told, else the stage selects over
+    the image (a streak of equal, brightest pixels in the row / column the border mirrors forces that).  Every product must equal
+    what the disk-by-disk route gives (SHG_CONTRAST_BATCH=0: shg_contrast_stats_u16, held against the oracle elsewhere), with u16,
+    byte and nibble counters: odd widths, odd heights, both, a crop to an odd width, a small image (clip 1), five disks."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from solex_ser_recon_en_amd import solex_util, stages
+    h, w = shape
+    pitch = (w + 63) // 64 * 64
+    store = torch.zeros((k, h, pitch), dtype=torch.uint16, device='cuda')
+    views = []
+    out_w = crop[0] if crop else w
+    for i in range(k):
+        img = _solar_image(h, w, seed=300 + i)
+        if streak == 'row' and i % 2 == 0:
+            img[h - 2, w // 3:w // 3 + 40] = 65000          # (row h - 2 is the first row of the border)
+        if streak == 'column' and i % 2 == 0:
+            c = (crop[1] + min(crop[3], crop[0] - crop[2]) - 2) if crop else w - 2         # the image's last column but one
+            img[h // 3:h // 3 + 40, c] = 64000
+        store[i, :, :w] = torch.from_numpy(img.view(np.int16)).cuda().view(torch.uint16)
+        views.append(store[i, :, :w])
+    transv = None
+    if trans:
+        window = min(61, (int(0.8 * h) // 2) * 2 - 1)
+        transv = dict(circle=(w / 2.0, h / 2.0, 0.4 * h), borders=[0.0, 0.05 * h, w - 1.0, 0.95 * h], taps=solex_util.savgol_taps(window), window=window)
+
+    def run(batch, sat):
+        monkeypatch.setenv('SHG_CONTRAST_BATCH', batch)
+        monkeypatch.setenv('SHG_CLAHE_SAT', sat)
+        res = stages.process_frames(views, transv, crop, (out_w // 2, h // 2, int(0.3 * h)))
+        torch.cuda.synchronize()
+        return {name: [np.asarray(t.cpu().view(torch.int16).numpy()).view(np.uint16).copy() for t in res[name]] for name in ('final', 'cl1', 'hc', 'protus', 'cc')}
+    def reselected():                                        # how often the stage fell back on the select over the image since enable(1)
+        import ctypes
+        from solex_ser_recon_en_amd import _lib
+        buf = ctypes.create_string_buffer(1 << 14)
+        _lib.lib.shg_host_timing_report(buf, len(buf))
+        return sum(int(line.rsplit(' ', 1)[1]) for line in buf.value.decode().splitlines() if line.startswith('frame percentile selected'))
+    from solex_ser_recon_en_amd import _lib
+    want = run('0', '1')
+    for sat in ('1', '0', '8'):
+        _lib.lib.shg_host_timing_enable(1)
+        try:
+            got = run('1', sat)
+            fell_back = reselected()
+        finally:
+            _lib.lib.shg_host_timing_enable(0)
+        for name in want:
+            for i, (x, y) in enumerate(zip(got[name], want[name])):
+                assert x.shape == (h, out_w)
+                np.testing.assert_array_equal(x, y, err_msg='%s[%d] SHG_CLAHE_SAT=%s' % (name, i, sat))
+        # the streak's 40 equal pixels and their 40 mirror images clamp the top bin: saturated counters cannot tell -- every other disk asks again
+        he, we = (h, out_w) if h % 2 == 0 and out_w % 2 == 0 else (h + 2 - h % 2, out_w + 2 - out_w % 2)
+        clip = max(int(0.8 * (he // 2) * (we // 2) / 65536), 1)
+        k_top = h * out_w - int((h * out_w - 1) * 0.999999)         # the lower of np.percentile's two order statistics, counted from the top
+        if streak == 'row' and sat != '0' and k_top <= clip <= 255:
+            assert fell_back == (k + 1) // 2, (fell_back, clip, k_top)
+        if streak is None:
+            assert fell_back == 0
+
+
 def test_percentile_window_hits_and_misses_give_the_second_pass_results(monkeypatch):
     """np.percentile(cl1, 10) and np.max(cl1) without a second pass over cl1 (csrc/clahe.hip, SelWin): the blend kernel counts the low
     bytes of the eight high bytes around the PREVIOUS scan's answer -- kept in the stage's workspace -- and an atomic maximum; when

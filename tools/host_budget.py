@@ -1,7 +1,7 @@
 """Where does a scan worker's wall clock go?  `steps` scans through `workers` scan workers with the library's host-side
 section timer on (shg_host_timing_*): per scan, the time inside shg_scan_file, inside each stage composite, waiting in each
 stream synchronise and inside each control-plane routine -- and what is left for the interpreter between two calls.
-    python3 tools/host_budget.py [steps] [workers]"""
+    python3 tools/host_budget.py [steps] [workers] [shifts a,b,c]"""
 import contextlib
 import ctypes
 import io
@@ -16,6 +16,7 @@ from solex_ser_recon_en_amd import SHG_MAIN, Solex_recon, _lib, synth  # noqa: E
 from solex_ser_recon_en_amd.video_reader import array_reader  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+shifts = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else [0]
 stacks = [synth.synth_frames_torch(2000, 2000, 200, 16, seed=j, padded=True) for j in range(5)]
 torch.cuda.synchronize()
 
@@ -24,7 +25,7 @@ def batch(n, workers):
     tasks = []
     for i in range(n):
         opts = SHG_MAIN.default_options()
-        opts.update(_nolog=True)
+        opts.update(_nolog=True, shift=list(shifts))
         tasks.append((array_reader(stacks[i % len(stacks)]), opts))
     with contextlib.redirect_stdout(io.StringIO()):
         Solex_recon.solex_do_work(tasks, True, distribute='none', workers=workers)
