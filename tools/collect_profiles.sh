@@ -34,6 +34,23 @@ for cfg in "c2 20 0" "c4 10 $C4" "c5 10 0 4000 2560 256 16"; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch_$name -- python3 $R/tools/step_loop.py 3 "$@" > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_pmc_write_$name -- python3 $R/tools/step_loop.py 3 "$@" > /dev/null 2>&1
 done
+# the same tables for a scan whose circularised disk CLAHE's 2 x 2 grid does NOT divide (2097 px wide: four of the bench's five
+# synthetic scans, tools/step_loop.py), and how the scans in flight share the device (tools/overlap.py over tools/pool_loop.py)
+export SHG_STEP_SEED=1
+for cfg in "c2 20 0" "c4 10 $C4"; do
+  set -- $cfg; name=$1; steps=$2; shift; shift
+  rm -rf /tmp/odd_trace
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/odd_trace -- python3 $R/tools/step_loop.py $steps "$@" > /dev/null 2>&1
+  python3 $R/tools/kernel_table.py /tmp/odd_trace $steps > $P/${TAG}_step_kernel_table_${name}_odd_width.txt
+done
+unset SHG_STEP_SEED
+for cfg in "c2 60 0" "c4 40 $C4"; do
+  set -- $cfg; name=$1; steps=$2; shift; shift
+  rm -rf /tmp/ov_trace
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/ov_trace -- python3 $R/tools/pool_loop.py $steps 4 "$@" > $P/${TAG}_overlap_$name.txt 2> /dev/null
+  python3 $R/tools/overlap.py /tmp/ov_trace $steps >> $P/${TAG}_overlap_$name.txt
+done
+rm -rf /tmp/odd_trace /tmp/ov_trace
 # SQ / LDS counters (one run) and L2 counters (another) of every kernel of a C4 scan -> profiles/<tag>_sq_<kernel>.json
 rm -rf $O/${TAG}_sq_tmp $O/${TAG}_tcc_tmp
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $O/${TAG}_sq_tmp -- python3 $R/tools/step_loop.py 3 $C4 > /dev/null 2>&1
