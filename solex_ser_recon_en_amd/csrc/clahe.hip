@@ -228,7 +228,7 @@ template <bool FUSED, int BITS> __global__ __launch_bounds__(1024) void k_tile_h
             // slice, which is what this kernel's time was.  (FUSED with vec: no crop -- the frame's columns are the image's.)
             // The tile's columns of the image are [xa, xb): whole vectors from xa8 to xb8, and up to 7 + 7 pixels before and after them
             // (a tile 1049 pixels wide starts anywhere) plus the columns of the reflected border, [xb, xbase + tw) -- at most 30 pixels
-            // a row, taken one per lane (lanes 0-31: the first row, 32-63: the second) behind the vectors.
+            // a row, taken one per lane behind the chunk's vectors.
             const int64_t xa = xbase, xb = min(xbase + tw, w);
             const int64_t xa8 = (xa + 7) & ~(int64_t)7, xb8 = max(xb & ~(int64_t)7, xa8);
             const int nvr = (int)((xb8 - xa8) / 8);
@@ -276,19 +276,24 @@ template <bool FUSED, int BITS> __global__ __launch_bounds__(1024) void k_tile_h
                         }
                     }
                 }
-                const int second = lane >> 5, l = lane & 31;
-                if (l < n_edge && (second == 0 || two)) {
-                    const int64_t x = l < n_head ? xa + l : (l < n_head + n_tail ? xb - n_tail + (l - n_head) : xb + (l - n_head - n_tail));
-                    const bool border_col = x >= w;
-                    const int64_t xr = border_col ? mirror101(x, w) : x;
-                    const int64_t y = second ? y1 : y0;
-                    uint32_t v = (second ? s1 : s0)[xr];
-                    if (FUSED) {
-                        if (scaled) v = scale_px_fma(v, second ? c1 : c0, second ? k1 : k0) & 0xffffu;
-                        if (!border_col && !(second ? border1 : border0)) fin[y * pitch + x] = (uint16_t)v;
-                    }
-                    count(v);
+            }
+            // the rows' loose ends, all of the chunk's together: one pixel a lane (behind every pair of rows they cost the whole wave a
+            // pixel's instructions for a handful of lanes: 16 us of 116 over a 21-disk stack)
+            for (int e = threadIdx.x; e < (cb - ca + 1) * n_edge; e += 1024) {
+                const int rr = e / n_edge, l = e - rr * n_edge, yy = ca + rr;
+                int64_t y = ty * th + yy;
+                const bool border_row = y >= h;
+                if (border_row) y = mirror101(y, h);
+                const int64_t x = l < n_head ? xa + l : (l < n_head + n_tail ? xb - n_tail + (l - n_head) : xb + (l - n_head - n_tail));
+                const bool border_col = x >= w;
+                const int64_t xr = border_col ? mirror101(x, w) : x;
+                uint32_t v = (FUSED ? raw + y * fs.raw_pitch : img + y * pitch)[xr];
+                if (FUSED) {
+                    const double cy = cf[yy - ya];
+                    if (scaled) v = scale_px_fma(v, cy, cy * 0x1p+52) & 0xffffu;
+                    if (!border_col && !border_row) fin[y * pitch + x] = (uint16_t)v;
                 }
+                count(v);
             }
         } else {
             for (int yy = ca + wave; yy <= cb; yy += 16) {
