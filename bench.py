@@ -391,9 +391,12 @@ def main():
                 d.max(), np.count_nonzero(d), d.size)
             # ... and the second scan, whose circularised disk is 2097 px wide: a width CLAHE's 2 x 2 grid does not divide (reflected
             # border in the tile histograms) -- the shape four of the five synthetic scans have
-            if len(out) > 1 and len(stacks) > 1 and out[1]:
+            if len(out) > 1 and n_stacks > 1 and out[1]:
+                second = synth.synth_frames_torch(n_scan, args.width, args.height, args.bits, seed=rank * 64 + 1, k0=k0, k1=k0 + n_local,
+                                                  n_total=n_scan, padded=True)         # (stacks[1] again: the legs above freed it)
                 with contextlib.redirect_stdout(io.StringIO()), np.errstate(all='ignore'):
-                    ref1 = po.run(_ops.stack_to_host(stacks[1][:n_cpu]), {'shift': list(requested_shifts)})
+                    ref1 = po.run(_ops.stack_to_host(second[:n_cpu]), {'shift': list(requested_shifts)})
+                del second
                 cc1, want1 = np.asarray(out[1][0][0]), ref1['results'][0]['cc']
                 d1 = np.abs(cc1.astype(np.int64) - want1.astype(np.int64)) if cc1.shape == want1.shape else None
                 cpu['parity_vs_gpu_second_scan'] = 'shape mismatch' if d1 is None else '%d px wide: max |diff| %d LSB, %d of %d px differ' % (
