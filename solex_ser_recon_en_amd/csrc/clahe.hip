@@ -573,8 +573,8 @@ __device__ __forceinline__ void for_each_border_pixel(const BorderPx& bp, const 
     for (int i = tid + 8 * nt; i < n; i += nt) f(border_pixel(bp, img, i, below, wide));
 }
 
-// One order statistic of the image whose per-tile histograms CLAHE has built (valid when the tile grid divides the image: no
-// reflected padding in the histograms), by one workgroup of 1024: lane t takes the t-th run of 64 bins from the chunk sums, a
+// One order statistic of the image whose per-tile histograms CLAHE has built (a grid that does not divide the image: less the pixels
+// of the reflected border, `bp`), by one workgroup of 1024: lane t takes the t-th run of 64 bins from the chunk sums, a
 // workgroup scan finds the run that holds the rank, one wave scans its 64 bins.  (k_hist_ranks, and the extra workgroups of
 // k_tile_lut16_blocks.)
 __device__ __forceinline__ void hist_rank_job(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ chunk_sums, int chunk_sets, int ntiles,

@@ -1093,10 +1093,10 @@ def test_blend_with_eight_pixel_lanes_equals_four_pixel_lanes(shape, monkeypatch
                                                 ((2000, 2096), (2000, 48, 0, 2000), True, 1), ((201, 304), None, True, 1)])
 def test_scaling_and_crop_fused_into_the_histogram_kernel(shape, crop, trans, k, monkeypatch):
     """shg_stage_process_frames forms the image CLAHE works on inside the CLAHE histogram kernel (k_tile_hist16_slices<true>: frame x
-    row factor, saturate, truncate, crop / pad; Solex_recon.py:149-171, solex_util.py:515-516) where the tile grid divides the
-    image.  Every product equals the separate kernels' (SHG_FUSE_SCALE=0: k_scale_rows8, k_crop_pad, then the histograms) bit for bit:
-    vector and pixel paths, crops that pad on either side, several disks, no transversalium (a plain copy), and a shape the grid
-    does not divide (201 rows: not fused either way)."""
+    row factor, saturate, truncate, crop / pad; Solex_recon.py:149-171, solex_util.py:515-516).  Every product equals the separate
+    kernels' (SHG_FUSE_SCALE=0: k_scale_rows8, k_crop_pad, then the histograms) bit for bit: vector and pixel paths, crops that pad
+    on either side, several disks, no transversalium (a plain copy), and a shape the grid does not divide (201 rows: the border's
+    pixels formed a second time for the count)."""
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     from solex_ser_recon_en_amd import solex_util, stages
