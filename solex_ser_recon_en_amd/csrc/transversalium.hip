@@ -140,6 +140,19 @@ __device__ __forceinline__ void select2(KeyFn key, int n, int64_t rank_lo, int64
     out_hi = pref[1];
 }
 
+// body(i) for i = tid, tid + NT, ... < n with the trip count in a scalar register: n / NT whole rounds that every lane takes -- no
+// per-lane index compare, no juggling of the exec mask: three of the eight to ten VALU instructions an element cost in the plain
+// `for (i = tid; i < n; i += NT)` form, and this kernel is bound by its VALU instructions -- and one last round for the lanes below n % NT.
+// (n must be uniform over the workgroup.)
+template <typename F>
+__device__ __forceinline__ void sweep(int n, F body) {
+    const int rounds = __builtin_amdgcn_readfirstlane(n / NT);
+#pragma unroll 2
+    for (int r = 0; r < rounds; ++r) body((int)threadIdx.x + r * NT);
+    const int last = (int)threadIdx.x + rounds * NT;
+    if (last < n) body(last);
+}
+
 // The same two order statistics by bucketing, for keys that are all finite and lie in [kmin, kmax] (the extrema of the
 // set, found by the caller).  x -> min(NB-1, int((x - lo) * NB / (hi - lo))) never decreases with x, so every key of a
 // bucket is <= every key of the next one and the bucket holding a rank is found by a prefix sum; its keys (a few
@@ -175,10 +188,10 @@ __device__ __forceinline__ bool select2_buckets(ValFn val, int n, int64_t rank_l
         hist[tid + 256] = 0;
         if (tid == 0) sc.n_cand = 0;
         __syncthreads();
-        for (int i = tid; i < n; i += NT) {
+        sweep(n, [&](int i) {
             const double v = val(i);
             if (in_play(v)) atomicAdd(&hist[bucket(v)], 1u);
-        }
+        });
         __syncthreads();
         // prefix sum over the buckets, two per thread
         const uint32_t c0 = hist[2 * tid], c1 = hist[2 * tid + 1];
@@ -200,13 +213,13 @@ __device__ __forceinline__ bool select2_buckets(ValFn val, int n, int64_t rank_l
         __syncthreads();                                // pick[] is rewritten by the next level
         if (cnt <= (uint32_t)CAP) {
             // adjacent ranks: the buckets between b0 and b1 are empty, so the candidates are consecutive in rank
-            for (int i = tid; i < n; i += NT) {
+            sweep(n, [&](int i) {
                 const double v = val(i);
                 if (in_play(v)) {
                     const int b = bucket(v);
                     if (b == b0 || b == b1) cand[atomicAdd(&sc.n_cand, 1u)] = v;
                 }
-            }
+            });
             __syncthreads();
             const int m = (int)sc.n_cand;
             if (tid < m) {
@@ -324,29 +337,47 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8))) void k_
         // Plain 16-bit rows (every scan but a de-vignetted one): log_ratio_u16 -- one reciprocal serves the quotient and the
         // logarithm's own division -- for pixel pairs without a zero; four pairs' loads in flight before the first is used.
         bool odd = false;
-        for (int i0 = threadIdx.x; i0 < n; i0 += 4 * NT) {
+        auto one = [&](uint32_t a, uint32_t b, int i) {
+            double x;
+            if (a != 0 && b != 0) {
+                x = shg::log_ratio_u16(a, b);
+            } else {                     // a zero pixel: 0, inf or NaN quotient -- the library's log knows what to return
+                x = log((double)a / (double)b);
+                if (x != x) sc.bad = 1;
+                odd = odd || !(fabs(x) <= 1.7976931348623157e308);
+            }
+            vals[i] = x;
+            sum1 += x;
+            sum2 += x * x;
+        };
+        // whole groups of 4 x NT pairs first (a scalar trip count, no index clamps or per-lane bounds: see sweep()), then the rest
+        const int groups = __builtin_amdgcn_readfirstlane(n / (4 * NT));
+        for (int g = 0; g < groups; ++g) {
+            const int i0 = (int)threadIdx.x + g * 4 * NT;
             uint32_t a[4], b[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * NT < n ? i0 + u * NT : i0;
-                a[u] = r1[i];
-                b[u] = r0[i];
+                a[u] = r1[i0 + u * NT];
+                b[u] = r0[i0 + u * NT];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * NT;
-                if (i >= n) break;
-                double x;
-                if (a[u] != 0 && b[u] != 0) {
-                    x = shg::log_ratio_u16(a[u], b[u]);
-                } else {                 // a zero pixel: 0, inf or NaN quotient -- the library's log knows what to return
-                    x = log((double)a[u] / (double)b[u]);
-                    if (x != x) sc.bad = 1;
-                    odd = odd || !(fabs(x) <= 1.7976931348623157e308);
+            for (int u = 0; u < 4; ++u) one(a[u], b[u], i0 + u * NT);
+        }
+        {
+            const int i0 = (int)threadIdx.x + groups * 4 * NT;
+            if (i0 < n) {
+                uint32_t a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * NT < n ? i0 + u * NT : i0;
+                    a[u] = r1[i];
+                    b[u] = r0[i];
                 }
-                vals[i] = x;
-                sum1 += x;
-                sum2 += x * x;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (i0 + u * NT >= n) break;
+                    one(a[u], b[u], i0 + u * NT);
+                }
             }
         }
         if (odd) sc.nonfinite = 1;
@@ -407,12 +438,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8))) void k_
     // and the sweep has no division.
     const double twice = 2.0 * mdev;
     double s = 0.0, cnt = 0.0;
-    for (int i = threadIdx.x; i < n; i += NT) {
+    sweep(n, [&](int i) {
         const double x = vals[i];
         const double dev = fabs(x - med);
         const bool keep = (mdev != 0.0) ? (dev < twice) : true;        // s = d/mdev if mdev else zeros; data[s < 2] (see above)
         if (keep) { s += x; cnt += 1.0; }
-    }
+    });
     block_sum2(s, cnt, sc.red);
     emit(s / cnt);
 }
