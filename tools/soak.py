@@ -16,7 +16,7 @@ from solex_ser_recon_en_amd.video_reader import array_reader  # noqa: E402
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
-    stack = synth.synth_frames_torch(2000, 2000, 200, 16, seed=0, padded=True)
+    stack = synth.synth_frames_torch(2000, 2000, 200, 16, seed=int(os.environ.get('SHG_STEP_SEED', '1')), padded=True)     # (1: a 2097 px disk, the reflected-border route)
     first = None
     for i in range(steps):
         opts = SHG_MAIN.default_options()
