@@ -364,6 +364,222 @@ __global__ __launch_bounds__(64 * NW) void k_extract_dense(const T* __restrict__
     }
 }
 
+// ---- the same idea for ROTATED files (round 6): the band kernel ------------------------------------------------------------------
+// On a rotated file the S + 1 samples of a (slit row, frame) lie in S + 1 consecutive FILE rows, and the 64 slit rows of a wave in
+// one 128-byte run of each: a frame's whole need is a band of S + 1 file rows.  The general kernel fetches that band as 2 S loads
+// in groups of four PLANES (the plane order of `-w a:b:1` is 10, 0, a .. b: 29 row reads for 22 rows, and blockIdx.z puts the
+// groups' re-reads far apart in time: FETCH 1.49 x the distinct bytes at C4).  Here the shifts are cut into groups of G
+// consecutive VALUES: a lane loads the G + 1 samples of its row once per frame (all of a wave's frames in flight at once) and
+// forms the G values from registers; the groups of one (row block, column block) sit next to each other in dispatch order on
+// one XCD (1-D grid, decoded below), so the one file row two groups share is an L2 hit.  Two neighbouring frames share a lane:
+// their values go to the LDS tile as one dword and into the extrema as one packed minimum / maximum.
+constexpr int BAND_MAX_S = DS_MAX;
+struct BandArgs {
+    const void* stack;
+    int n_frames;
+    int64_t height, width, fstride;
+    const int32_t* ind_l;
+    const int32_t* base_col;
+    const double *lw, *rw;
+    int S;
+    uint16_t* disks;
+    int64_t row_pitch, plane_stride, n_cols, k_offset;
+    int flip_x, vec_store;
+    uint32_t* mm;
+    int nx, ny, ng;                  // column blocks, row blocks, shift groups
+    int dbg;                         // tuning switches (tools/bench_extract.py): 1 no global stores, 2 no global loads
+    uint8_t plane_of[BAND_MAX_S];    // plane of the d-th smallest shift
+};
+typedef unsigned short __attribute__((ext_vector_type(2))) ushort2_t;
+typedef unsigned int __attribute__((ext_vector_type(4))) u32x4_t;   // native vector: nontemporal-storable
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ushort2_t, a), __builtin_bit_cast(ushort2_t, b)));
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(ushort2_t, a), __builtin_bit_cast(ushort2_t, b)));
+}
+
+// G shifts per workgroup, DK frames per workgroup (LDS rows of DK / 2 + 1 dwords), NW waves.  The kernel is bound by instruction
+// issue as much as by memory (with neither loads nor stores the first version took 95 of its 105 us): no branch in the load or
+// blend loops, every tile address `lane base + constant`, the extrema taken on the way out of LDS.
+template <typename T, int G, int DK, int NW, int LOADMODE>
+__global__ __launch_bounds__(64 * NW) void k_extract_band(const BandArgs a) {
+    constexpr int DKW = DK / 2 + 1;
+    constexpr int FPW = DK / NW;           // frames of a wave (even: pairs of neighbours)
+    constexpr int PAIRS = FPW / 2;
+    static_assert(FPW % 2 == 0 && DK % 8 == 0 && 64 % (DK / 8) == 0, "pairs of frames, 16-byte segments");
+    extern __shared__ uint32_t btile[];    // [G][TY][DKW]
+    // workgroup -> (tile, group), without a division: grid (8 ng, nx / 8, ny), x fastest.  Workgroup ids i, i + 8, i + 16, ... run on
+    // one XCD: its consecutive workgroups take the groups of one tile (the file row two groups share is an L2 hit: FETCH 1.02 x the
+    // distinct bytes, 1.35 x with the groups far apart), and the tile a row block further on -- which shares the cache lines a
+    // 128-byte run of a 4000-byte file row straddles -- has the same XCD too.  (The scalar unit is shared by a CU's four SIMDs:
+    // scalar instructions are the dear ones here.)
+    const int g = (int)(blockIdx.x >> 3);
+    const bool rows_first = (a.dbg & 16) != 0;                      // (tuning: grid (8 ng, ny, nx / 8): row blocks before column blocks)
+    const int bx = (int)((rows_first ? blockIdx.z : blockIdx.y) * 8u + (blockIdx.x & 7u)), by = (int)(rows_first ? blockIdx.y : blockIdx.z);
+    if (bx >= a.nx) return;
+    const T* __restrict__ stack = static_cast<const T*>(a.stack);
+    const int n_frames = a.n_frames, flip_x = a.flip_x, S = a.S;
+    const int64_t width = a.width, ih = a.width, iw = a.height, fstride = a.fstride, n_cols = a.n_cols, k_offset = a.k_offset;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t c0 = (int64_t)bx * DK;
+    const int64_t y = (int64_t)by * TY + lane;
+    const bool y_ok = y < ih;
+    const int64_t yc = y_ok ? y : ih - 1;
+    const int g0 = g * G, ns = min(G, S - g0);
+    constexpr int scale = sizeof(T) == 1 ? 256 : 1;
+    const double wl = a.lw[yc], wr = a.rw[yc];
+    const int base = a.base_col[yc];
+    const bool plain = base >= 0 && (int64_t)base + S <= iw - 1;          // columns base .. base + S all lie inside the frame
+    const double kl = wl * 0x1p+52, kr = wr * 0x1p+52;                     // (see k_extract)
+    const bool fast = __all(fabs(wl) < 0x1p+900 && fabs(wr) < 0x1p+900) != 0;
+    // byte offsets of the group's samples inside a frame (`scalar frame base + 32-bit lane offset` is an addressing mode of the load:
+    // no address arithmetic per load); a lane near the frame's edge reads stand-in rows (g0 ..) and is redone below; the rows
+    // beyond a short last group re-read its last row
+    const uint32_t rowb = (uint32_t)(width * (int64_t)sizeof(T));
+    uint32_t voff[G + 1];
+    voff[0] = (uint32_t)((((plain ? (int64_t)base : 0) + g0) * width + (width - 1 - yc)) * (int64_t)sizeof(T));
+#pragma unroll
+    for (int d = 1; d <= G; ++d) voff[d] = voff[0] + (uint32_t)min(d, ns) * rowb;
+
+    // (32-bit words: the load zero-extends, no mask at the use)
+    uint32_t v[FPW][G + 1];
+    // the wave's frames: lane i forms the address of the i-th one (a frame this rank does not hold: frame 0 stands in, its column
+    // is never stored), the loads take it from scalar registers
+    const int ncols32 = (int)n_cols;
+    uint32_t f_lo, f_hi;
+    {
+        const int i = lane < FPW ? lane : 0;
+        const int col = (int)c0 + 2 * (wave + NW * (i >> 1)) + (i & 1);
+        const int k = (flip_x ? (ncols32 - 1 - col) : col) - (int)k_offset;
+        const bool ok = col < ncols32 && (unsigned)k < (unsigned)n_frames;
+        const uint64_t f = (uint64_t)(uint32_t)(ok ? k : 0) * (uint64_t)(fstride * (int64_t)sizeof(T));
+        f_lo = (uint32_t)f;
+        f_hi = (uint32_t)(f >> 32);
+    }
+#pragma unroll
+    for (int i = 0; i < FPW; ++i) {
+        const char* f = reinterpret_cast<const char*>(stack) + (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)f_hi, i) << 32) |
+                                                                (uint32_t)__builtin_amdgcn_readlane((int)f_lo, i));
+#pragma unroll
+        for (int d = 0; d <= G; ++d) {
+            if (LOADMODE == 1) v[i][d] = (uint32_t)(lane * 3 + d + i);
+            else v[i][d] = (uint32_t)*reinterpret_cast<const T*>(f + voff[d]);
+        }
+    }
+
+    uint32_t* const my = btile + lane * DKW + wave;      // tile[d][lane][pair]: + d * TY * DKW + NW * p, constants
+    auto blend = [&](auto fast_form) {
+#pragma unroll
+        for (int p = 0; p < PAIRS; ++p) {
+            uint32_t qv[2][G];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = 2 * p + h;
+                if (LOADMODE == 3) {
+#pragma unroll
+                    for (int d = 0; d < G; ++d) qv[h][d] = v[i][d] + v[i][d + 1];
+                } else if (decltype(fast_form)::value) {
+                    double D[G + 1];
+#pragma unroll
+                    for (int d = 0; d <= G; ++d) D[d] = __hiloint2double(0x43300000, (int)(v[i][d] * scale));
+#pragma unroll
+                    for (int d = 0; d < G; ++d) qv[h][d] = (uint32_t)(int)(__builtin_fma(D[d], wl, -kl) + __builtin_fma(D[d + 1], wr, -kr));
+                } else {
+#pragma unroll
+                    for (int d = 0; d < G; ++d) {
+                        const double l = (double)(int)(v[i][d] * scale);
+                        const double r = (double)(int)(v[i][d + 1] * scale);
+                        qv[h][d] = (uint32_t)(int)(l * wl + r * wr);
+                    }
+                }
+            }
+            // low halves of the two values side by side (weights outside [0, 1] wrap as the reference's uint16 cast does)
+#pragma unroll
+            for (int d = 0; d < G; ++d) my[d * TY * DKW + NW * p] = __builtin_amdgcn_perm(qv[1][d], qv[0][d], 0x05040100u);
+        }
+    };
+    if (fast) blend(std::true_type{});
+    else blend(std::false_type{});
+
+    if (y_ok && !plain) {
+        // the general rule for the rows the clamps touch (solex_util.py:114-119): left sample at the clamped index of every shift,
+        // right one beside it.  This thread wrote the same tile entries above: no barrier between the two.
+        uint16_t* t16 = reinterpret_cast<uint16_t*>(btile);
+        for (int i = 0; i < FPW; ++i) {
+            const int cc = 2 * (wave + NW * (i >> 1)) + (i & 1);
+            const int64_t col = c0 + cc;
+            const int64_t k = (flip_x ? (n_cols - 1 - col) : col) - k_offset;
+            if (!(col < n_cols && k >= 0 && k < n_frames)) continue;
+            const T* f = stack + k * fstride;
+            for (int d = 0; d < ns; ++d) {
+                const int il = a.ind_l[(int64_t)a.plane_of[g0 + d] * ih + yc];
+                const int64_t off = (int64_t)il * width + (width - 1 - yc);
+                const double l = (double)((int)f[off] * scale);
+                const double r = (double)((int)f[off + width] * scale);
+                t16[((size_t)(d * TY + lane) * DKW) * 2 + cc] = (uint16_t)(uint32_t)(int)(l * wl + r * wr);
+            }
+        }
+    }
+    __syncthreads();
+
+    // write-out: one 16-byte segment (8 columns) per lane, DK / 8 lanes per row, a wave per shift; the planes' minimum and maximum
+    // (what the warp clips to, ellipse_to_circle.py:112-114) are taken here, from the values as stored
+    constexpr int SEGS = DK / 8;
+    const int seg = lane % SEGS;
+    const int64_t col = c0 + seg * 8;
+    const int64_t ka = (flip_x ? (n_cols - 1 - col) : col) - k_offset;
+    const int64_t kb = (flip_x ? (n_cols - 1 - (col + 7)) : (col + 7)) - k_offset;
+    const bool whole = a.vec_store && col + 8 <= n_cols && ka >= 0 && ka < n_frames && kb >= 0 && kb < n_frames;
+    const int rows_here = (int)min((int64_t)TY, ih - (int64_t)by * TY);
+    for (int d = wave; d < ns; d += NW) {
+        const int plane = a.plane_of[g0 + d];
+        uint16_t* dst0 = a.disks + (int64_t)plane * a.plane_stride + ((int64_t)by * TY) * a.row_pitch + col;
+        uint32_t lo = 0xffffffffu, hi = 0u;
+        if (whole) {
+#pragma unroll 4
+            for (int r = lane / SEGS; r < rows_here; r += 64 / SEGS) {
+                const uint32_t* s32 = &btile[(d * TY + r) * DKW + seg * 4];
+                const uint4 o = make_uint4(s32[0], s32[1], s32[2], s32[3]);
+                // (nontemporal: the disks do not displace the file rows neighbouring workgroups are about to share from L2 -- 94 -> 80 us)
+                if (a.dbg & 4) *reinterpret_cast<uint4*>(dst0 + r * a.row_pitch) = o;
+                else if (!(a.dbg & 1)) __builtin_nontemporal_store(u32x4_t{o.x, o.y, o.z, o.w}, reinterpret_cast<u32x4_t*>(dst0 + r * a.row_pitch));
+                lo = pk_min_u16(pk_min_u16(lo, o.x), pk_min_u16(pk_min_u16(o.y, o.z), o.w));
+                hi = pk_max_u16(pk_max_u16(hi, o.x), pk_max_u16(pk_max_u16(o.y, o.z), o.w));
+            }
+        } else {
+            for (int r = lane / SEGS; r < rows_here; r += 64 / SEGS) {
+                const uint16_t* src = reinterpret_cast<const uint16_t*>(&btile[(d * TY + r) * DKW + seg * 4]);
+                uint16_t* dst = dst0 + r * a.row_pitch;
+                for (int j = 0; j < 8; ++j) {
+                    const int64_t cj = col + j;
+                    const int64_t kj = (flip_x ? (n_cols - 1 - cj) : cj) - k_offset;
+                    if (cj < n_cols && kj >= 0 && kj < n_frames) {
+                        dst[j] = src[j];
+                        lo = pk_min_u16(lo, src[j] * 0x10001u);
+                        hi = pk_max_u16(hi, src[j] * 0x10001u);
+                    }
+                }
+            }
+        }
+        if (a.mm) {
+#pragma unroll
+            for (int e = 32; e >= 1; e >>= 1) {
+                lo = pk_min_u16(lo, __shfl_xor(lo, e));
+                hi = pk_max_u16(hi, __shfl_xor(hi, e));
+            }
+            const uint32_t l16 = min(lo & 0xffffu, lo >> 16), h16 = max(hi & 0xffffu, hi >> 16);
+            if (lane == 0 && h16 >= l16) {                    // this workgroup stored at least one value of the plane
+                const int slot = (int)((bx * 5u + by * 3u) & 63u);
+                uint32_t* m = a.mm + ((int64_t)plane * 64 + slot) * 2;
+                atomicMax(&m[0], 0xffffu - l16);              // the minimum as the maximum of the complement: both slots start at zero
+                atomicMax(&m[1], h16);
+            }
+        }
+    }
+}
+
 // fold the 64 slots of every plane: out[s] = {min, max}
 struct FoldMinmaxArgs {
     const uint32_t* slots;
@@ -534,6 +750,45 @@ extern "C" int shg_extract_columns_dense(const void* stack, int64_t n_frames, in
         }
     }
     const int n = (int)n_frames;
+    if (rot) {
+        // the band kernel; SHG_EXT_BAND="G,DK,NW[,dbg]" picks another launch shape (tools/bench_extract.py)
+        int G = 4, DK = 64, NW = 4, dbg = 0;
+        if (const char* e = getenv("SHG_EXT_BAND")) sscanf(e, "%d,%d,%d,%d", &G, &DK, &NW, &dbg);
+        BandArgs ba{stack, n, height, width, fstride, ind_l, base_col, lw, rw, n_shifts, disks, row_pitch, plane_stride, n_cols, k_offset, flip_x, vec_store,
+                    minmax_slots, (int)((n_cols + DK - 1) / DK), (int)((ih + TY - 1) / TY), (n_shifts + G - 1) / G, dbg, {}};
+        for (int i = 0; i < n_shifts; ++i) ba.plane_of[host_shifts[i] - lo] = (uint8_t)i;
+        const dim3 grid3 = (dbg & 16) ? dim3(8u * (unsigned)ba.ng, (unsigned)ba.ny, ((unsigned)ba.nx + 7u) / 8u)
+                                      : dim3(8u * (unsigned)ba.ng, ((unsigned)ba.nx + 7u) / 8u, (unsigned)ba.ny);
+        int launch_status = SHG_E_UNSUPPORTED;
+        bool found = false;
+        SHG_PROF("extract", st);
+#define SHG_BAND(T, GV, DKV, NWV)                                                                                                         \
+        if (!found && G == GV && DK == DKV && NW == NWV && bytes_per_px == (int)sizeof(T)) {                                             \
+            found = true;                                                                                                                 \
+            constexpr size_t lds = (size_t)GV * TY * (DKV / 2 + 1) * 4;                                                                   \
+            static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_extract_band<T, GV, DKV, NWV, 0>),           \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;           \
+            if (!ok_) (void)hipGetLastError();                                                                                            \
+            launch_status = shg::launch(k_extract_band<T, GV, DKV, NWV, 0>, grid3, dim3(64 * NWV), lds, st, ba, "k_extract_band"); \
+        }
+        if (dbg & 2) {
+            constexpr size_t lds = (size_t)4 * TY * (64 / 2 + 1) * 4;
+            found = true;
+            launch_status = shg::launch(k_extract_band<uint16_t, 4, 64, 4, 1>, grid3, dim3(256), lds, st, ba, "k_extract_band");
+        }
+        if (dbg & 8) {
+            constexpr size_t lds = (size_t)4 * TY * (64 / 2 + 1) * 4;
+            found = true;
+            launch_status = shg::launch(k_extract_band<uint16_t, 4, 64, 4, 3>, grid3, dim3(256), lds, st, ba, "k_extract_band");
+        }
+        SHG_BAND(uint16_t, 7, 64, 8) SHG_BAND(uint16_t, 4, 64, 4) SHG_BAND(uint16_t, 3, 64, 4) SHG_BAND(uint16_t, 3, 128, 8)
+        SHG_BAND(uint8_t, 4, 64, 4)
+#undef SHG_BAND
+        SHG_REQUIRE(found, SHG_E_UNSUPPORTED, "shg_extract_columns_dense: no band kernel of shape G=%d DK=%d NW=%d", G, DK, NW);
+        if (launch_status) return launch_status;
+        if (minmax_slots) return launch_fold(minmax_slots, n_shifts, st);
+        return 0;
+    }
     // launch shape (tools/bench_extract.py): waves per workgroup x frames per workgroup x frames in flight per wave
     static const int shape = [] { const char* e = getenv("SHG_EXT_DENSE_SHAPE"); return e ? atoi(e) : 0; }();
 #define SHG_DENSE(T, ROT, B, NW, DKV)                                                                                                               \

@@ -246,7 +246,7 @@ extern "C" int shg_stage_extract(const void* stack, int64_t n_frames, int64_t he
     // On rotated files the general kernel stays: its re-reads of shared lines hit L2, it keeps twice the waves per CU
     // (114 VGPRs, 34 KB of LDS against 200 and 48-91 KB) and measures 107 us against 185 (tools/pmc_extract.sh).
     // SHG_EXT_DENSE=0: never, 2: also on rotated files.
-    static const int dense_mode = [] { const char* v = getenv("SHG_EXT_DENSE"); return v ? atoi(v) : 1; }();
+    const int dense_mode = [] { const char* v = getenv("SHG_EXT_DENSE"); return v ? atoi(v) : 1; }();
     const bool dense = dense_mode > 0 && (dense_mode > 1 || height > width) && iw > n_shifts && shg_extract_dense_fits(host_shifts, n_shifts);
     if (dense) {
         int lo = host_shifts[0];
