@@ -156,7 +156,10 @@ int shg_blur_argmin_u16(const uint16_t* src, int64_t h, int64_t w, int kw, int k
  * (np.flip(axis=1), Solex_recon.py:74-76).  ind_l is [n_shifts][ih] int32, already
  * clamped to [0, iw-2] (solex_util.py:114-119); lw, rw are [ih] float64, NOT adjusted
  * for the clamp (solex_util.py:122-123).  disks: n_shifts planes of plane_stride
- * elements, rows of row_pitch elements (row_pitch >= n_cols). */
+ * elements, rows of row_pitch elements (row_pitch >= n_cols).
+ * Rotated files (width > height, the usual SER) take the band kernel (k_extract_band: a group of shifts per workgroup,
+ * every sample loaded once, nontemporal stores); SHG_EXT_GENERAL=1 in the environment keeps the kernel that serves
+ * un-rotated files (k_extract) for them too -- the parity tests hold one against the other. */
 int shg_extract_columns(const void* stack, int64_t n_frames, int64_t height, int64_t width,
                         int bytes_per_px, int64_t frame_stride_px, const int32_t* ind_l, const double* lw, const double* rw,
                         int n_shifts, uint16_t* disks, int64_t row_pitch, int64_t plane_stride,
@@ -174,7 +177,8 @@ int shg_extract_columns_minmax(const void* stack, int64_t n_frames, int64_t heig
 
 /* The same for a Doppler stack whose shifts are consecutive integers in any order (-w a:b:1 with the two implicit shifts inside
  * the range; 3 <= n_shifts <= 24, shg_extract_dense_fits): a lane loads the n_shifts + 1 distinct samples of a (row, frame)
- * once instead of 2 * n_shifts.  host_shifts [n_shifts]: the shift of every plane; base_col [ih]: the column of the smallest
+ * once instead of 2 * n_shifts (rotated files: k_extract_band in groups of up to seven shift values, the file row two groups
+ * share read by neighbouring workgroups of one XCD; un-rotated files: k_extract_dense).  host_shifts [n_shifts]: the shift of every plane; base_col [ih]: the column of the smallest
  * shift before the clamps (fit[:, 0] + min shift); ind_l as above, used for the rows whose line lies within n_shifts columns
  * of the frame's edge.  Bit-identical to shg_extract_columns_minmax. */
 int shg_extract_dense_fits(const int32_t* host_shifts, int n_shifts);

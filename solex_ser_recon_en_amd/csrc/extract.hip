@@ -364,31 +364,45 @@ __global__ __launch_bounds__(64 * NW) void k_extract_dense(const T* __restrict__
     }
 }
 
-// ---- the same idea for ROTATED files (round 6): the band kernel ------------------------------------------------------------------
-// On a rotated file the S + 1 samples of a (slit row, frame) lie in S + 1 consecutive FILE rows, and the 64 slit rows of a wave in
-// one 128-byte run of each: a frame's whole need is a band of S + 1 file rows.  The general kernel fetches that band as 2 S loads
-// in groups of four PLANES (the plane order of `-w a:b:1` is 10, 0, a .. b: 29 row reads for 22 rows, and blockIdx.z puts the
-// groups' re-reads far apart in time: FETCH 1.49 x the distinct bytes at C4).  Here the shifts are cut into groups of G
-// consecutive VALUES: a lane loads the G + 1 samples of its row once per frame (all of a wave's frames in flight at once) and
-// forms the G values from registers; the groups of one (row block, column block) sit next to each other in dispatch order on
-// one XCD (1-D grid, decoded below), so the one file row two groups share is an L2 hit.  Two neighbouring frames share a lane:
-// their values go to the LDS tile as one dword and into the extrema as one packed minimum / maximum.
+// ---- rotated files (Width > Height, the usual SER), round 6: the band kernel --------------------------------------------------------
+// On a rotated file the samples a slit row needs from a frame lie in consecutive FILE rows, and the 64 slit rows of a wave in one
+// 128-byte run of each.  The general kernel above was thought to be bound by the DRAM efficiency of that gather (round 5); taken
+// apart (tools/sweep_band.py: the same launch without its loads, without its stores, without its arithmetic) it was bound by
+// instruction issue -- a branch per load and per value, 64-bit address arithmetic per load, a mask and a move per sample, a scalar
+// prologue of 585 instructions a wave -- and, once that was gone, by its stores displacing from L2 the file rows that neighbouring
+// workgroups share.  What this kernel does about each:
+//  * a group of G shifts per workgroup, every sample loaded once: for a Doppler stack of consecutive shifts (CONSEC) the G + 1 file
+//    rows the group spans (the sample a shift takes on its right is the one the next takes on its left: 24 loads per slit row and
+//    frame at S = 21 instead of 48); for any other list the two rows of each shift;
+//  * all of a wave's loads (FPW frames x R rows <= 64, what one wave can have in flight) issued back to back, no branch: a frame's
+//    address comes from scalar registers (lane i forms the i-th frame's offset, v_readlane hands it over), a row's offset inside
+//    the frame is one lane register shared by all frames -- `scalar base + lane offset` is an addressing mode, no arithmetic per load;
+//  * the groups of one (row block, column block) next to each other in dispatch order on ONE XCD (grid (8 ng, nx / 8, ny), x
+//    fastest: ids i, i + 8, ... share an XCD), so the file row two groups share -- and the cache lines a 128-byte run of a 4000-byte
+//    file row straddles, shared with the row block next door -- are L2 hits: FETCH_SIZE 1.02 x the distinct bytes at C4 (general
+//    kernel: 1.47 x);
+//  * sample x weight as one fma on the double whose low word IS the sample (2^52 + sample; 2^60 + 256 sample for 8-bit files: the
+//    x 256 of video_reader.py:121-122 for free), two neighbouring frames' values packed into one LDS dword with v_perm;
+//  * NONTEMPORAL 16-byte stores of the tile's rows (94 -> 80 us at C4: the disks no longer displace the shared file rows), the
+//    planes' extrema taken on the way out of LDS with packed minima / maxima.
+// C4 (2000 x 2000 x 200, S = 21): 72 us against the general kernel's 97 - 105 (profiles/r06_sweeps.txt has every step, and the
+// shapes and the walk-the-shifts kernel that lost).  What bounds it now is memory: loads alone 41 us, stores alone <= 30, both 71.
 constexpr int BAND_MAX_S = DS_MAX;
+constexpr int BAND_NW = 8;           // waves of a workgroup
 struct BandArgs {
     const void* stack;
     int n_frames;
     int64_t height, width, fstride;
-    const int32_t* ind_l;
-    const int32_t* base_col;
+    const int32_t* ind_l;            // [S][ih] clamped left columns (solex_util.py:114-119)
+    const int32_t* base_col;         // CONSEC: [ih] column of the smallest shift, not clamped
     const double *lw, *rw;
     int S;
     uint16_t* disks;
     int64_t row_pitch, plane_stride, n_cols, k_offset;
     int flip_x, vec_store;
     uint32_t* mm;
-    int nx, ny, ng;                  // column blocks, row blocks, shift groups
-    int dbg;                         // tuning switches (tools/bench_extract.py): 1 no global stores, 2 no global loads
-    uint8_t plane_of[BAND_MAX_S];    // plane of the d-th smallest shift
+    int nx;                          // column blocks (the grid's y is rounded up to eights)
+    uint8_t plane_of[BAND_MAX_S];    // CONSEC: plane of the d-th smallest shift
 };
 typedef unsigned short __attribute__((ext_vector_type(2))) ushort2_t;
 typedef unsigned int __attribute__((ext_vector_type(4))) u32x4_t;   // native vector: nontemporal-storable
@@ -399,54 +413,60 @@ __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(ushort2_t, a), __builtin_bit_cast(ushort2_t, b)));
 }
 
-// G shifts per workgroup, DK frames per workgroup (LDS rows of DK / 2 + 1 dwords), NW waves.  The kernel is bound by instruction
-// issue as much as by memory (with neither loads nor stores the first version took 95 of its 105 us): no branch in the load or
-// blend loops, every tile address `lane base + constant`, the extrema taken on the way out of LDS.
-template <typename T, int G, int DK, int NW, int LOADMODE>
-__global__ __launch_bounds__(64 * NW) void k_extract_band(const BandArgs a) {
-    constexpr int DKW = DK / 2 + 1;
-    constexpr int FPW = DK / NW;           // frames of a wave (even: pairs of neighbours)
+template <typename T, int G, bool CONSEC>
+__global__ __launch_bounds__(64 * BAND_NW) void k_extract_band(const BandArgs a) {
+    constexpr int NW = BAND_NW;
+    constexpr int DKW = TK / 2 + 1;        // dwords of a tile row (odd: the blend's column writes touch every bank)
+    constexpr int FPW = TK / NW;           // frames of a wave: pairs of neighbours
     constexpr int PAIRS = FPW / 2;
-    static_assert(FPW % 2 == 0 && DK % 8 == 0 && 64 % (DK / 8) == 0, "pairs of frames, 16-byte segments");
+    constexpr int R = CONSEC ? G + 1 : 2 * G;     // file rows a group loads per frame
+    static_assert(FPW % 2 == 0 && FPW * R <= 64, "pairs of frames; a wave has at most 64 loads in flight");
     extern __shared__ uint32_t btile[];    // [G][TY][DKW]
-    // workgroup -> (tile, group), without a division: grid (8 ng, nx / 8, ny), x fastest.  Workgroup ids i, i + 8, i + 16, ... run on
-    // one XCD: its consecutive workgroups take the groups of one tile (the file row two groups share is an L2 hit: FETCH 1.02 x the
-    // distinct bytes, 1.35 x with the groups far apart), and the tile a row block further on -- which shares the cache lines a
-    // 128-byte run of a 4000-byte file row straddles -- has the same XCD too.  (The scalar unit is shared by a CU's four SIMDs:
-    // scalar instructions are the dear ones here.)
     const int g = (int)(blockIdx.x >> 3);
-    const bool rows_first = (a.dbg & 16) != 0;                      // (tuning: grid (8 ng, ny, nx / 8): row blocks before column blocks)
-    const int bx = (int)((rows_first ? blockIdx.z : blockIdx.y) * 8u + (blockIdx.x & 7u)), by = (int)(rows_first ? blockIdx.y : blockIdx.z);
+    const int bx = (int)(blockIdx.y * 8u + (blockIdx.x & 7u)), by = (int)blockIdx.z;
     if (bx >= a.nx) return;
     const T* __restrict__ stack = static_cast<const T*>(a.stack);
     const int n_frames = a.n_frames, flip_x = a.flip_x, S = a.S;
     const int64_t width = a.width, ih = a.width, iw = a.height, fstride = a.fstride, n_cols = a.n_cols, k_offset = a.k_offset;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t c0 = (int64_t)bx * DK;
+    const int64_t c0 = (int64_t)bx * TK;
     const int64_t y = (int64_t)by * TY + lane;
     const bool y_ok = y < ih;
     const int64_t yc = y_ok ? y : ih - 1;
     const int g0 = g * G, ns = min(G, S - g0);
-    constexpr int scale = sizeof(T) == 1 ? 256 : 1;
+    constexpr int scale = sizeof(T) == 1 ? 256 : 1;        // video_reader.py:121-122
     const double wl = a.lw[yc], wr = a.rw[yc];
-    const int base = a.base_col[yc];
-    const bool plain = base >= 0 && (int64_t)base + S <= iw - 1;          // columns base .. base + S all lie inside the frame
-    const double kl = wl * 0x1p+52, kr = wr * 0x1p+52;                     // (see k_extract)
+    // sample * weight with ONE instruction (see k_extract): the sample as the low word of the double 2^52 + sample (high word
+    // 0x43300000); an 8-bit file's as the low word of 2^60 + 256 sample (0x43B00000).  Weights that 2^60 w cannot take (never a fit's:
+    // they lie in [0, 1]) get the plain products, workgroup by workgroup.
+    constexpr int HI = sizeof(T) == 1 ? 0x43B00000 : 0x43300000;
+    const double kl = wl * (sizeof(T) == 1 ? 0x1p+60 : 0x1p+52), kr = wr * (sizeof(T) == 1 ? 0x1p+60 : 0x1p+52);
     const bool fast = __all(fabs(wl) < 0x1p+900 && fabs(wr) < 0x1p+900) != 0;
-    // byte offsets of the group's samples inside a frame (`scalar frame base + 32-bit lane offset` is an addressing mode of the load:
-    // no address arithmetic per load); a lane near the frame's edge reads stand-in rows (g0 ..) and is redone below; the rows
-    // beyond a short last group re-read its last row
+    // byte offsets of the group's samples inside a frame.  CONSEC: rows base + g0 .. base + g0 + G; a slit row whose line lies within
+    // S columns of the frame's edge (the clamps of solex_util.py:114-119 bite) reads stand-in rows g0 .. and is redone by the general
+    // rule below.  Otherwise: the clamped left column of each shift and the one beside it.  Shifts beyond a short last group re-read
+    // its last one.
     const uint32_t rowb = (uint32_t)(width * (int64_t)sizeof(T));
-    uint32_t voff[G + 1];
-    voff[0] = (uint32_t)((((plain ? (int64_t)base : 0) + g0) * width + (width - 1 - yc)) * (int64_t)sizeof(T));
+    const uint32_t colb = (uint32_t)((width - 1 - yc) * (int64_t)sizeof(T));
+    uint32_t voff[R];
+    bool plain = true;
+    if (CONSEC) {
+        const int base = a.base_col[yc];
+        plain = base >= 0 && (int64_t)base + S <= iw - 1;           // columns base .. base + S all lie inside the frame
+        voff[0] = (uint32_t)((plain ? base : 0) + g0) * rowb + colb;
 #pragma unroll
-    for (int d = 1; d <= G; ++d) voff[d] = voff[0] + (uint32_t)min(d, ns) * rowb;
+        for (int d = 1; d < R; ++d) voff[d] = voff[0] + (uint32_t)min(d, ns) * rowb;
+    } else {
+#pragma unroll
+        for (int d = 0; d < G; ++d) {
+            voff[2 * d] = (uint32_t)a.ind_l[(int64_t)(g0 + min(d, ns - 1)) * ih + yc] * rowb + colb;
+            voff[2 * d + 1] = voff[2 * d] + rowb;
+        }
+    }
 
-    // (32-bit words: the load zero-extends, no mask at the use)
-    uint32_t v[FPW][G + 1];
-    // the wave's frames: lane i forms the address of the i-th one (a frame this rank does not hold: frame 0 stands in, its column
-    // is never stored), the loads take it from scalar registers
+    // the wave's frames (pairs of neighbours wave, wave + NW, ...): lane i forms the offset of the i-th one (a frame this rank does
+    // not hold: frame 0 stands in, its column is never stored)
     const int ncols32 = (int)n_cols;
     uint32_t f_lo, f_hi;
     {
@@ -458,18 +478,16 @@ __global__ __launch_bounds__(64 * NW) void k_extract_band(const BandArgs a) {
         f_lo = (uint32_t)f;
         f_hi = (uint32_t)(f >> 32);
     }
+    uint32_t v[FPW][R];                    // (32-bit words: the load zero-extends, no mask at the use)
 #pragma unroll
     for (int i = 0; i < FPW; ++i) {
         const char* f = reinterpret_cast<const char*>(stack) + (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)f_hi, i) << 32) |
                                                                 (uint32_t)__builtin_amdgcn_readlane((int)f_lo, i));
 #pragma unroll
-        for (int d = 0; d <= G; ++d) {
-            if (LOADMODE == 1) v[i][d] = (uint32_t)(lane * 3 + d + i);
-            else v[i][d] = (uint32_t)*reinterpret_cast<const T*>(f + voff[d]);
-        }
+        for (int d = 0; d < R; ++d) v[i][d] = (uint32_t)*reinterpret_cast<const T*>(f + voff[d]);
     }
 
-    uint32_t* const my = btile + lane * DKW + wave;      // tile[d][lane][pair]: + d * TY * DKW + NW * p, constants
+    uint32_t* const my = btile + lane * DKW + wave;        // tile[d][lane][pair]: + d * TY * DKW + NW * p, constants
     auto blend = [&](auto fast_form) {
 #pragma unroll
         for (int p = 0; p < PAIRS; ++p) {
@@ -477,22 +495,15 @@ __global__ __launch_bounds__(64 * NW) void k_extract_band(const BandArgs a) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int i = 2 * p + h;
-                if (LOADMODE == 3) {
 #pragma unroll
-                    for (int d = 0; d < G; ++d) qv[h][d] = v[i][d] + v[i][d + 1];
-                } else if (decltype(fast_form)::value) {
-                    double D[G + 1];
-#pragma unroll
-                    for (int d = 0; d <= G; ++d) D[d] = __hiloint2double(0x43300000, (int)(v[i][d] * scale));
-#pragma unroll
-                    for (int d = 0; d < G; ++d) qv[h][d] = (uint32_t)(int)(__builtin_fma(D[d], wl, -kl) + __builtin_fma(D[d + 1], wr, -kr));
-                } else {
-#pragma unroll
-                    for (int d = 0; d < G; ++d) {
-                        const double l = (double)(int)(v[i][d] * scale);
-                        const double r = (double)(int)(v[i][d + 1] * scale);
-                        qv[h][d] = (uint32_t)(int)(l * wl + r * wr);
-                    }
+                for (int d = 0; d < G; ++d) {
+                    const uint32_t xl = v[i][CONSEC ? d : 2 * d], xr = v[i][CONSEC ? d + 1 : 2 * d + 1];
+                    double val;
+                    if (decltype(fast_form)::value)
+                        val = __builtin_fma(__hiloint2double(HI, (int)xl), wl, -kl) + __builtin_fma(__hiloint2double(HI, (int)xr), wr, -kr);
+                    else
+                        val = (double)(int)(xl * scale) * wl + (double)(int)(xr * scale) * wr;
+                    qv[h][d] = (uint32_t)(int)val;
                 }
             }
             // low halves of the two values side by side (weights outside [0, 1] wrap as the reference's uint16 cast does)
@@ -503,9 +514,9 @@ __global__ __launch_bounds__(64 * NW) void k_extract_band(const BandArgs a) {
     if (fast) blend(std::true_type{});
     else blend(std::false_type{});
 
-    if (y_ok && !plain) {
-        // the general rule for the rows the clamps touch (solex_util.py:114-119): left sample at the clamped index of every shift,
-        // right one beside it.  This thread wrote the same tile entries above: no barrier between the two.
+    if (CONSEC && y_ok && !plain) {
+        // the general rule for the rows the clamps touch: left sample at the clamped index of every shift, right one beside it.
+        // This thread wrote the same tile entries above: no barrier between the two.
         uint16_t* t16 = reinterpret_cast<uint16_t*>(btile);
         for (int i = 0; i < FPW; ++i) {
             const int cc = 2 * (wave + NW * (i >> 1)) + (i & 1);
@@ -524,9 +535,9 @@ __global__ __launch_bounds__(64 * NW) void k_extract_band(const BandArgs a) {
     }
     __syncthreads();
 
-    // write-out: one 16-byte segment (8 columns) per lane, DK / 8 lanes per row, a wave per shift; the planes' minimum and maximum
+    // write-out: one 16-byte segment (8 columns) per lane, 8 lanes per row, a wave per shift; the planes' minimum and maximum
     // (what the warp clips to, ellipse_to_circle.py:112-114) are taken here, from the values as stored
-    constexpr int SEGS = DK / 8;
+    constexpr int SEGS = TK / 8;
     const int seg = lane % SEGS;
     const int64_t col = c0 + seg * 8;
     const int64_t ka = (flip_x ? (n_cols - 1 - col) : col) - k_offset;
@@ -534,21 +545,20 @@ __global__ __launch_bounds__(64 * NW) void k_extract_band(const BandArgs a) {
     const bool whole = a.vec_store && col + 8 <= n_cols && ka >= 0 && ka < n_frames && kb >= 0 && kb < n_frames;
     const int rows_here = (int)min((int64_t)TY, ih - (int64_t)by * TY);
     for (int d = wave; d < ns; d += NW) {
-        const int plane = a.plane_of[g0 + d];
+        const int plane = CONSEC ? a.plane_of[g0 + d] : g0 + d;
         uint16_t* dst0 = a.disks + (int64_t)plane * a.plane_stride + ((int64_t)by * TY) * a.row_pitch + col;
         uint32_t lo = 0xffffffffu, hi = 0u;
         if (whole) {
 #pragma unroll 4
             for (int r = lane / SEGS; r < rows_here; r += 64 / SEGS) {
                 const uint32_t* s32 = &btile[(d * TY + r) * DKW + seg * 4];
-                const uint4 o = make_uint4(s32[0], s32[1], s32[2], s32[3]);
-                // (nontemporal: the disks do not displace the file rows neighbouring workgroups are about to share from L2 -- 94 -> 80 us)
-                if (a.dbg & 4) *reinterpret_cast<uint4*>(dst0 + r * a.row_pitch) = o;
-                else if (!(a.dbg & 1)) __builtin_nontemporal_store(u32x4_t{o.x, o.y, o.z, o.w}, reinterpret_cast<u32x4_t*>(dst0 + r * a.row_pitch));
+                const u32x4_t o = {s32[0], s32[1], s32[2], s32[3]};
+                __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t*>(dst0 + r * a.row_pitch));
                 lo = pk_min_u16(pk_min_u16(lo, o.x), pk_min_u16(pk_min_u16(o.y, o.z), o.w));
                 hi = pk_max_u16(pk_max_u16(hi, o.x), pk_max_u16(pk_max_u16(o.y, o.z), o.w));
             }
         } else {
+            // (the tile only holds columns whose frame this rank owns)
             for (int r = lane / SEGS; r < rows_here; r += 64 / SEGS) {
                 const uint16_t* src = reinterpret_cast<const uint16_t*>(&btile[(d * TY + r) * DKW + seg * 4]);
                 uint16_t* dst = dst0 + r * a.row_pitch;
@@ -571,6 +581,7 @@ __global__ __launch_bounds__(64 * NW) void k_extract_band(const BandArgs a) {
             }
             const uint32_t l16 = min(lo & 0xffffu, lo >> 16), h16 = max(hi & 0xffffu, hi >> 16);
             if (lane == 0 && h16 >= l16) {                    // this workgroup stored at least one value of the plane
+                // one atomic pair per wave and plane into one of 64 slots (same-address atomics serialise chip-wide; k_fold_minmax folds them)
                 const int slot = (int)((bx * 5u + by * 3u) & 63u);
                 uint32_t* m = a.mm + ((int64_t)plane * 64 + slot) * 2;
                 atomicMax(&m[0], 0xffffu - l16);              // the minimum as the maximum of the complement: both slots start at zero
@@ -578,6 +589,38 @@ __global__ __launch_bounds__(64 * NW) void k_extract_band(const BandArgs a) {
             }
         }
     }
+}
+
+// one launch of the band kernel: groups of G shifts (CONSEC: 4 .. 7, as few groups as 7 allow, then as even as they come; otherwise 2 or 4)
+template <bool CONSEC>
+int launch_band(const BandArgs& ba, int bytes_per_px, int64_t ih, hipStream_t st) {
+    const int S = ba.S;
+    int G;
+    if (CONSEC) {
+        const int ng7 = (S + 6) / 7;
+        G = std::max(4, (S + ng7 - 1) / ng7);
+    } else {
+        G = S <= 2 ? 2 : 4;
+    }
+    const int ng = (S + G - 1) / G;
+    const dim3 grid(8u * (unsigned)ng, ((unsigned)ba.nx + 7u) / 8u, (unsigned)((ih + TY - 1) / TY));
+    int status = SHG_E_UNSUPPORTED;
+#define SHG_BAND(T, GV)                                                                                                                   \
+    if (G == GV && bytes_per_px == (int)sizeof(T)) {                                                                                      \
+        constexpr size_t lds = (size_t)GV * TY * (TK / 2 + 1) * 4;                                                                        \
+        static const bool ok_ = lds <= 64 * 1024 || hipFuncSetAttribute(reinterpret_cast<const void*>(k_extract_band<T, GV, CONSEC>),    \
+                                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess; \
+        if (!ok_) (void)hipGetLastError();                                                                                                \
+        status = shg::launch(k_extract_band<T, GV, CONSEC>, grid, dim3(64 * BAND_NW), lds, st, ba, "k_extract_band");                     \
+    }
+    if constexpr (CONSEC) {
+        SHG_BAND(uint16_t, 4) SHG_BAND(uint16_t, 5) SHG_BAND(uint16_t, 6) SHG_BAND(uint16_t, 7)
+        SHG_BAND(uint8_t, 4) SHG_BAND(uint8_t, 5) SHG_BAND(uint8_t, 6) SHG_BAND(uint8_t, 7)
+    } else {
+        SHG_BAND(uint16_t, 2) SHG_BAND(uint16_t, 4) SHG_BAND(uint8_t, 2) SHG_BAND(uint8_t, 4)
+    }
+#undef SHG_BAND
+    return status;
 }
 
 // fold the 64 slots of every plane: out[s] = {min, max}
@@ -686,6 +729,19 @@ extern "C" int shg_extract_columns_minmax(const void* stack, int64_t n_frames, i
             return (int)e;
         }
     }
+    // rotated files: the band kernel, groups of two or four shifts in plane order (SHG_EXT_GENERAL=1: the kernel above, for A / B runs)
+    const bool general_only = [] { const char* e = getenv("SHG_EXT_GENERAL"); return e && atoi(e) != 0; }();     // (read per call: tools/sweep_band.py)
+    if (rot && !general_only) {
+        BandArgs ba{stack, n, height, width, fstride, ind_l, nullptr, lw, rw, n_shifts, disks, row_pitch, plane_stride, n_cols, k_offset, flip_x, vec_store,
+                    minmax_slots, (int)((n_cols + TK - 1) / TK), {}};
+        {
+            SHG_PROF("extract", st);
+            launch_status = launch_band<false>(ba, bytes_per_px, ih, st);
+        }
+        if (launch_status) return launch_status;
+        if (minmax_slots) return launch_fold(minmax_slots, n_shifts, st);
+        return 0;
+    }
     {
         SHG_PROF("extract", st);
         if (bytes_per_px == 2) {
@@ -751,40 +807,15 @@ extern "C" int shg_extract_columns_dense(const void* stack, int64_t n_frames, in
     }
     const int n = (int)n_frames;
     if (rot) {
-        // the band kernel; SHG_EXT_BAND="G,DK,NW[,dbg]" picks another launch shape (tools/bench_extract.py)
-        int G = 4, DK = 64, NW = 4, dbg = 0;
-        if (const char* e = getenv("SHG_EXT_BAND")) sscanf(e, "%d,%d,%d,%d", &G, &DK, &NW, &dbg);
+        // the band kernel: every sample once per group of up to seven shifts
         BandArgs ba{stack, n, height, width, fstride, ind_l, base_col, lw, rw, n_shifts, disks, row_pitch, plane_stride, n_cols, k_offset, flip_x, vec_store,
-                    minmax_slots, (int)((n_cols + DK - 1) / DK), (int)((ih + TY - 1) / TY), (n_shifts + G - 1) / G, dbg, {}};
+                    minmax_slots, (int)((n_cols + TK - 1) / TK), {}};
         for (int i = 0; i < n_shifts; ++i) ba.plane_of[host_shifts[i] - lo] = (uint8_t)i;
-        const dim3 grid3 = (dbg & 16) ? dim3(8u * (unsigned)ba.ng, (unsigned)ba.ny, ((unsigned)ba.nx + 7u) / 8u)
-                                      : dim3(8u * (unsigned)ba.ng, ((unsigned)ba.nx + 7u) / 8u, (unsigned)ba.ny);
-        int launch_status = SHG_E_UNSUPPORTED;
-        bool found = false;
-        SHG_PROF("extract", st);
-#define SHG_BAND(T, GV, DKV, NWV)                                                                                                         \
-        if (!found && G == GV && DK == DKV && NW == NWV && bytes_per_px == (int)sizeof(T)) {                                             \
-            found = true;                                                                                                                 \
-            constexpr size_t lds = (size_t)GV * TY * (DKV / 2 + 1) * 4;                                                                   \
-            static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_extract_band<T, GV, DKV, NWV, 0>),           \
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;           \
-            if (!ok_) (void)hipGetLastError();                                                                                            \
-            launch_status = shg::launch(k_extract_band<T, GV, DKV, NWV, 0>, grid3, dim3(64 * NWV), lds, st, ba, "k_extract_band"); \
+        int launch_status;
+        {
+            SHG_PROF("extract", st);
+            launch_status = launch_band<true>(ba, bytes_per_px, ih, st);
         }
-        if (dbg & 2) {
-            constexpr size_t lds = (size_t)4 * TY * (64 / 2 + 1) * 4;
-            found = true;
-            launch_status = shg::launch(k_extract_band<uint16_t, 4, 64, 4, 1>, grid3, dim3(256), lds, st, ba, "k_extract_band");
-        }
-        if (dbg & 8) {
-            constexpr size_t lds = (size_t)4 * TY * (64 / 2 + 1) * 4;
-            found = true;
-            launch_status = shg::launch(k_extract_band<uint16_t, 4, 64, 4, 3>, grid3, dim3(256), lds, st, ba, "k_extract_band");
-        }
-        SHG_BAND(uint16_t, 7, 64, 8) SHG_BAND(uint16_t, 4, 64, 4) SHG_BAND(uint16_t, 3, 64, 4) SHG_BAND(uint16_t, 3, 128, 8)
-        SHG_BAND(uint8_t, 4, 64, 4)
-#undef SHG_BAND
-        SHG_REQUIRE(found, SHG_E_UNSUPPORTED, "shg_extract_columns_dense: no band kernel of shape G=%d DK=%d NW=%d", G, DK, NW);
         if (launch_status) return launch_status;
         if (minmax_slots) return launch_fold(minmax_slots, n_shifts, st);
         return 0;

@@ -241,13 +241,11 @@ extern "C" int shg_stage_extract(const void* stack, int64_t n_frames, int64_t he
     SHG_REQUIRE(ind_l && w2 && base, SHG_E_WORKSPACE, "shg_stage_extract: workspace too small");
     SHG_REQUIRE(h_ind && h_w2 && h_base, SHG_E_WORKSPACE, "shg_stage_extract: pinned staging area too small");
     STAGE_TRY(shg_host_column_plan(host_fit, ih, iw, host_shifts, n_shifts, h_ind, h_w2, h_w2 + ih));
-    // A Doppler stack of consecutive shifts on an UN-ROTATED file (Height > Width: a slit row's samples lie side by side, every
-    // lane in a cache line of its own): every distinct sample once (shg_extract_columns_dense: 335 us against 684 at C4's shape).
-    // On rotated files the general kernel stays: its re-reads of shared lines hit L2, it keeps twice the waves per CU
-    // (114 VGPRs, 34 KB of LDS against 200 and 48-91 KB) and measures 107 us against 185 (tools/pmc_extract.sh).
-    // SHG_EXT_DENSE=0: never, 2: also on rotated files.
+    // A Doppler stack of consecutive shifts: every distinct sample once (shg_extract_columns_dense: the band kernel on rotated files,
+    // 72 us against the general kernel's 97 - 105 at C4's shape; k_extract_dense on un-rotated ones, 335 against 684).
+    // SHG_EXT_DENSE=0: never (read per call: tools/sweep_band.py switches it inside one process).
     const int dense_mode = [] { const char* v = getenv("SHG_EXT_DENSE"); return v ? atoi(v) : 1; }();
-    const bool dense = dense_mode > 0 && (dense_mode > 1 || height > width) && iw > n_shifts && shg_extract_dense_fits(host_shifts, n_shifts);
+    const bool dense = dense_mode > 0 && iw > n_shifts && shg_extract_dense_fits(host_shifts, n_shifts);
     if (dense) {
         int lo = host_shifts[0];
         for (int i = 1; i < n_shifts; ++i) lo = std::min(lo, (int)host_shifts[i]);

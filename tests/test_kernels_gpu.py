@@ -151,6 +151,52 @@ def test_extract_stage_equals_the_kernel_entry_point_and_the_oracle(ops, orc, n,
     np.testing.assert_array_equal(got, want[:, :, ::-1] if flip else want)
 
 
+@pytest.mark.parametrize('n,h,w,bits,shifts,case', [
+    (200, 40, 1000, 16, [10, 0], 'plain'),                           # two shifts, one group of two
+    (200, 40, 1000, 16, [10, 0, -7, 3, 25], 'plain'),                # any list: groups of four in plane order, a short last group
+    (137, 40, 1000, 16, list(range(-10, 11)), 'plain'),              # 21 consecutive: three groups of seven values
+    (137, 40, 1000, 16, [3, 0, 1, 2, -1, -2, -3, 4], 'plain'),       # eight consecutive, unordered: two groups of four
+    (137, 40, 1000, 8, list(range(-4, 5)), 'plain'),                 # nine, 8-bit: two groups of five (the second short)
+    (137, 40, 1000, 16, list(range(-10, 11)), 'shard'),              # a rank's frames inside a wider mosaic, not on a 16-byte boundary
+    (137, 40, 1000, 16, [10, 0], 'shard'),
+    (137, 40, 1000, 16, list(range(-10, 11)), 'wild'),               # weights the single-rounding product cannot take
+    (64, 40, 1000, 8, [10, 0], 'wild'),
+    (90, 30, 333, 16, list(range(-12, 12)), 'edge'),                 # the line within the shift range of both edges: every clamp
+])
+def test_band_kernel_equals_the_general_kernel(ops, monkeypatch, n, h, w, bits, shifts, case):
+    """Rotated files go through k_extract_band (round 6); k_extract, which served them before and still serves un-rotated files,
+    is the independent check: same disks bit for bit -- flipped, sharded into a wider mosaic, with weights outside [0, 1] (the
+    reference's uint16 wrap) and beyond 2^900 (the plain-product path), and with every slit row on the clamps."""
+    from solex_ser_recon_en_amd import hostmath
+    rng = np.random.default_rng(n * 7 + w + len(shifts))
+    frames = rng.integers(0, 256 if bits == 8 else 65536, (n, h, w)).astype(np.uint8 if bits == 8 else np.uint16)
+    ih, iw = w, h
+    y = np.arange(ih)
+    slope = 0.06 if case == 'edge' else 0.01
+    curve = iw / 2 + slope * (y - ih / 2) + 3 * np.sin(y / 40.0)
+    fit = np.stack([np.floor(curve), curve - np.floor(curve), y.astype(float), curve], axis=1)
+    ind_l, lw, rw = hostmath.column_plan(fit, shifts, ih, iw)
+    if case == 'wild':
+        lw = lw.copy()
+        rw = rw.copy()
+        lw[::7] = 1.75                                                # outside [0, 1]: the sum wraps as the uint16 cast does
+        rw[5::11] = -0.5
+        lw[100:164] = 1e280                                           # a whole wave beyond 2^900: plain products (saturating conversion)
+    kw = dict(n_cols=n + 37, k_offset=21) if case == 'shard' else {}
+    stack = dev(frames)
+    consecutive = 3 <= len(shifts) <= 24 and max(shifts) - min(shifts) == len(shifts) - 1
+    for flip in (False, True):
+        monkeypatch.setenv('SHG_EXT_GENERAL', '1')
+        want = host(ops.extract_columns(stack, ind_l, lw, rw, flip_x=flip, **kw))
+        monkeypatch.delenv('SHG_EXT_GENERAL')
+        got = host(ops.extract_columns(stack, ind_l, lw, rw, flip_x=flip, **kw))
+        np.testing.assert_array_equal(got, want)
+        if consecutive and case in ('plain', 'edge'):
+            dense, mm = ops.extract_columns_dense(stack, fit, shifts, flip_x=flip, want_minmax=True)
+            np.testing.assert_array_equal(host(dense), want)
+            assert [tuple(e) for e in mm.cpu().numpy().astype(np.int64)] == [(int(p.min()), int(p.max())) for p in want]
+
+
 def test_pass_a_in_the_lane_waits_for_the_stack_its_caller_is_still_writing(ops):
     """With a frame-pass lane set, pass A runs on another stream than its caller's: it must still see a stack that the caller's
     stream has only queued the writing of (no synchronisation in between)."""
