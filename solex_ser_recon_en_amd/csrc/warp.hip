@@ -5,6 +5,7 @@
 // HBM/L2-bound.  Arithmetic follows scikit-image 0.18.3 (_warp_fast,
 // bilinear_interpolation, _clip_warp_output) in float64, unfused.
 #include <algorithm>
+#include <cmath>
 #include "shg_common.h"
 
 namespace {
@@ -130,6 +131,112 @@ __global__ __launch_bounds__(256) void k_warp_rows(const WarpArgs kargs) {
     }
 }
 
+// ---- eight output pixels a lane (round 6) ---------------------------------------------------------------------------------------
+// k_warp_rows above issues two 2-byte loads and one 2-byte store per output pixel: 24 vector-memory instructions for a wave's 8 rows,
+// each of them 128 bytes -- the kernel was bound by their issue, not by their bytes (0.37 of the HBM roofline at C4).  Here a lane owns 8
+// consecutive columns of one output row: its 16 source samples lie within 24 pixels of the first one (the transform's column step is at
+// most 1.75: the host checks), so it fetches three aligned 16-byte pieces of the source row, parks them in LDS ([word][lane]: the bank is the
+// lane, no conflict whatever word a lane asks for), and reads each pixel's pair of neighbours back with one ds_read2_b32 at an offset of
+// its own; one 16-byte store.  4 vector-memory instructions for 8 pixels a lane instead of 24.  Same float64 arithmetic, unfused --
+// but no more of it than the result needs: the column term as one fma, no test for whole positions, the clip on integers (34
+// instructions a pixel, 13 of them float64).  C4: 115 -> 104 us; without its loads 96, with nontemporal stores 103: what is left is
+// the float64 work itself (profiles/r06_sweeps.txt).
+// Lanes are dealt (row, 8-column vector) pairs in one flat sequence, ITER of them per thread, the next one's pieces asked for before
+// the current one is blended.
+typedef unsigned int __attribute__((ext_vector_type(4))) u32x4_t;
+constexpr int kWarpWords = 13;                     // LDS words per lane: one of margin (the pixel left of the window) + 12 of window
+template <int ITER>
+__global__ __launch_bounds__(256) void k_warp_rows8(const WarpArgs kargs) {
+    __shared__ uint32_t win[4][kWarpWords][64];
+    const int64_t h = kargs.h, w = kargs.w, pitch = kargs.pitch, out_h = kargs.out_h, out_w = kargs.out_w, dst_pitch = kargs.dst_pitch;
+    const uint16_t* __restrict__ src = kargs.srcs.at<const uint16_t>(blockIdx.z);
+    uint16_t* __restrict__ dst = kargs.dsts.at<uint16_t>(blockIdx.z);
+    const uint32_t* __restrict__ mm = kargs.mms.at<const uint32_t>(blockIdx.z);
+    const double h00 = kargs.rows.h[blockIdx.z][0], h01 = kargs.rows.h[blockIdx.z][1], h02 = kargs.rows.h[blockIdx.z][2];
+    const uint32_t nv = (uint32_t)((out_w + 7) / 8), total = nv * (uint32_t)out_h;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t (*const my)[64] = win[wave];
+    const uint32_t cval = src[0];                             // cval = image[0, 0]
+    const int lo_i = (int)mm[0], hi_i = (int)mm[1];
+    const double k00 = h00 * 0x1p+52;
+    const uint32_t wu = (uint32_t)w;
+    const int w_last = (int)w - 1, last_piece = (int)pitch - 8;
+
+    // (row, first column, window start) of the it-th vector of this thread, and its three pieces
+    auto place = [&](int it, int& r, int& c, int& ws) {
+        const uint32_t flat = ((uint32_t)blockIdx.x * ITER + (uint32_t)it) * 256u + threadIdx.x;
+        const uint32_t f = flat < total ? flat : total - 1;
+        r = (int)(f / nv);
+        c = (int)(f - (uint32_t)r * nv) * 8;
+        const double x = h00 * (double)c + h01 * (double)r + h02;
+        const int i0 = __double2int_rz(floor(x));               // saturates far outside
+        ws = min(max(i0, 0), w_last) & ~7;
+        return flat < total;
+    };
+    auto fetch = [&](int r, int ws, u32x4_t (&q)[3]) {
+        const uint16_t* row = src + (int64_t)(r < h ? r : 0) * pitch;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) q[t] = *reinterpret_cast<const u32x4_t*>(row + min(ws + 8 * t, last_piece));   // (a piece past the row: all of it outside the image)
+    };
+    int r, c, ws;
+    bool live = place(0, r, c, ws);
+    u32x4_t q[3];
+    fetch(r, ws, q);
+#pragma unroll 1
+    for (int it = 0; it < ITER; ++it) {
+        if (!__any(live)) break;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            my[1 + 4 * t][lane] = q[t].x;
+            my[2 + 4 * t][lane] = q[t].y;
+            my[3 + 4 * t][lane] = q[t].z;
+            my[4 + 4 * t][lane] = q[t].w;
+        }
+        const int r_now = r, c_now = c, ws_now = ws;
+        const bool live_now = live;
+        if (it + 1 < ITER) {
+            live = place(it + 1, r, c, ws);
+            fetch(r, ws, q);
+        }
+        const uint32_t w_row = r_now < h ? wu : 0u;              // (a row the source does not have: every sample outside)
+        const double hr = h01 * (double)r_now;
+        const int ws2 = ws_now - 2;
+        uint32_t out[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            // h00 * (double)(c + j) with one instruction: 2^52 + (c + j) is the double whose low word is c + j, and (2^52 + n) h00 - 2^52 h00
+            // rounds once, to fl(n h00) (the column step is at most 1.75: 2^52 h00 is exact)
+            const double x = __builtin_fma(__hiloint2double(0x43300000, c_now + j), h00, -k00) + hr + h02;
+            const double x0 = floor(x);
+            const double dc = x - x0;
+            const int i0 = __double2int_rz(x0);                  // saturates far outside: stays outside
+            // the right neighbour is pixel i0 + 1 even where x is whole (the reference takes ceil(x) = i0 there): its weight dc is 0 then,
+            // and 0 x any sample is +0 -- no test for it
+            const bool in0 = (uint32_t)i0 < w_row, in1 = (uint32_t)i0 + 1u < w_row;
+            // the pair (pixel i0, pixel i0 + 1) out of the window: words k, k + 1 shifted by the pixel's parity (a position outside the
+            // window is outside the image: whatever it reads is replaced by cval)
+            const uint32_t off = min((uint32_t)(i0 - ws2), 23u);
+            const uint32_t d0 = my[off >> 1][lane], d1 = my[(off >> 1) + 1][lane];
+            const uint32_t pair = __builtin_amdgcn_alignbit(d1, d0, (off & 1u) * 16u);
+            const double left = (double)(in0 ? (pair & 0xffffu) : cval), right = (double)(in1 ? pair >> 16 : cval);
+            const double v = (1.0 - dc) * left + dc * right;
+            // np.clip(warped, image.min(), image.max()) and the truncation commute (both monotonic, the bounds whole numbers): on integers
+            out[j] = (uint32_t)min(max((int)v, lo_i), hi_i);
+        }
+        if (live_now) {
+            uint16_t* o = dst + (int64_t)r_now * dst_pitch + c_now;
+            if (c_now + 8 <= out_w) {
+                const u32x4_t pk = {out[0] | (out[1] << 16), out[2] | (out[3] << 16), out[4] | (out[5] << 16), out[6] | (out[7] << 16)};
+                *reinterpret_cast<u32x4_t*>(o) = pk;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (c_now + j < out_w) o[j] = (uint16_t)out[j];
+            }
+        }
+    }
+}
+
 constexpr int64_t kWarpWideAbove = 16384;          // workgroups an 8-rows-a-lane launch must still have
 int warp_rows_forced() {                           // SHG_WARP_ROWS=4|8|16: the A / B switch of the sweep
     static const int v = [] { const char* e = getenv("SHG_WARP_ROWS"); const int n = e ? atoi(e) : 0; return n == 4 || n == 8 || n == 16 ? n : 0; }();
@@ -181,6 +288,21 @@ int shg::warp_rows_batch(const uint16_t* const* host_srcs, int64_t k, int64_t h,
             for (int j = 0; j < 3; ++j) rows.h[d][j] = host_h3[3 * (i0 + d) + j];
         const WarpArgs args{shg::make_batch_n<kWarpBatch>(host_srcs, (int)i0, m), h, w, src_pitch, rows, shg::make_batch_n<kWarpBatch>(host_dsts, (int)i0, m),
                             out_h, out_w, dst_pitch, shg::make_batch_n<kWarpBatch>(host_minmax2, (int)i0, m)};
+        // eight pixels a lane where the pieces can be 16-byte loads and stores and the window holds a lane's samples (SHG_WARP_WIDE=0: never)
+        const bool wide_ok = [] { const char* e = getenv("SHG_WARP_WIDE"); return !e || atoi(e) != 0; }();     // (read per call: the parity test switches it)
+        bool wide = wide_ok && src_pitch % 8 == 0 && dst_pitch % 8 == 0 && w >= 8 && src_pitch >= 8 && out_h * ((out_w + 7) / 8) < (1ll << 31);
+        for (int d = 0; d < m && wide; ++d) {
+            const double a00 = rows.h[d][0], a01 = rows.h[d][1], a02 = rows.h[d][2];
+            wide = a00 >= 0.0 && a00 <= 1.75 && std::fabs(a01) < 1e300 && std::fabs(a02) < 1e300 &&
+                   (reinterpret_cast<uintptr_t>(host_srcs[i0 + d]) & 15) == 0 && (reinterpret_cast<uintptr_t>(host_dsts[i0 + d]) & 15) == 0;
+        }
+        if (wide) {
+            constexpr int ITER = 4;
+            const int64_t vecs = out_h * ((out_w + 7) / 8);
+            dim3 grid((unsigned)((vecs + 256 * ITER - 1) / (256 * ITER)), 1u, (unsigned)m);
+            if (int e = shg::launch(k_warp_rows8<ITER>, grid, dim3(256), 0, st, args, "k_warp_rows8")) return e;
+            continue;
+        }
         const int64_t gx = (out_w + 255) / 256;
         int rows_per_lane = gx * ((out_h + 7) / 8) * m >= kWarpWideAbove ? 8 : 4;
         if (warp_rows_forced()) rows_per_lane = warp_rows_forced();

@@ -423,6 +423,30 @@ def test_warp_golden_bit_exact(ops, golden):
         np.testing.assert_array_equal(host(out), want)
 
 
+@pytest.mark.parametrize('h,w,oh,ow,h00,h01,h02', [
+    (300, 517, 300, 517, 1.0, 0.0, 0.0),            # the identity: every position whole (weight 0 on a neighbour that may lie outside)
+    (300, 517, 300, 540, 0.957, 0.013, -9.4),       # a typical correction: off the image on the left, shear
+    (300, 517, 310, 400, 1.31, -0.02, 3.0),         # more output rows than the source has
+    (257, 1003, 257, 1003, 1.0, 0.0, 5.0),          # whole positions, shifted: runs off the right edge
+    (64, 200, 64, 131, 1.75, 0.1, -20.25),          # the widest column step the 24-pixel window takes
+    (64, 200, 64, 131, 1.76, 0.0, 0.0),             # beyond it: the narrow kernel serves
+    (64, 200, 64, 300, 0.31, 0.0, 190.0),           # neighbouring outputs share their samples; most of the row beyond the image
+    (33, 9, 33, 40, 1.0, 0.5, -3.0),                # an image narrower than a piece's stride
+])
+def test_warp_eight_pixels_a_lane_equals_one_pixel_a_lane(ops, monkeypatch, h, w, oh, ow, h00, h01, h02):
+    """k_warp_rows8 (round 6: three 16-byte pieces of the source row per lane, LDS window, one 16-byte store) against k_warp_rows
+    (two 2-byte gathers per pixel), which g3 pins to scikit-image: same pixels on transforms that run off either edge, land on
+    whole positions, squeeze and stretch."""
+    rng = np.random.default_rng(h * 31 + w + ow)
+    img = rng.integers(0, 65536, (h, w)).astype(np.uint16)
+    img[:, :3] = 65535                                                # saturated columns at the edge: the clip's upper bound in play
+    monkeypatch.setenv('SHG_WARP_WIDE', '0')
+    want = host(ops.warp_rows_u16(dev(img), h00, h01, h02, oh, ow))
+    monkeypatch.delenv('SHG_WARP_WIDE')
+    got = host(ops.warp_rows_u16(dev(img), h00, h01, h02, oh, ow))
+    np.testing.assert_array_equal(got, want)
+
+
 # ---- transversalium -------------------------------------------------------------
 def test_transversalium_stats_and_scale(ops, orc, golden):
     import math
