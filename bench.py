@@ -437,9 +437,10 @@ def main():
                        'frames_per_gpu': n_local, 'mode': 'single' if world == 1 else args.mode,
                        'scans_in_flight_per_process': 1 if sharded else min(workers, args.steps),
                        'backend': td.get_backend() if world > 1 else None, 'world_size': world,
-                       'collectives_per_scan': 3 if sharded else 0,
-                       'collectives': 'all_reduce SUM (sum frame) + all_reduce MAX (max frame) after pass A, reduce SUM of the disk mosaic to the '
-                                      'scan\'s owner (scan k -> rank k mod G, which post-processes it) after pass B; plus a one-word failure poll per scan' if sharded else None},
+                       'collectives_per_scan': 2 if sharded else 0,
+                       'collectives': 'all_gather of the packed frame statistics (u32 sums | u16 maxima | failure word) after pass A, reduce SUM of the '
+                                      'disk mosaic to the scan\'s owner (scan k -> rank k mod G, which post-processes it) after pass B; two scans being read '
+                                      'at a time, one failure word at the end of the series' if sharded else None},
             'parity_vs_one_rank': parity_one_rank,
             'repeats': {'n': len(region_s), 'ms_per_step': [round(t / args.steps * 1e3, 4) for t in region_s],
                         'min': round(min(region_s) / args.steps * 1e3, 4), 'median': round(ms_per_step, 4),
@@ -488,10 +489,11 @@ def sharded_parity(sharded_tasks, whole_task, world):
                         differ += int(a.shape != b.shape or not np.array_equal(a, b))
                 out = {'images_compared': images, 'images_that_differ': differ + (len(got[0]) != len(want[0])),
                        'what': '(cc, protus) of one scan sharded over %d ranks vs the same frames on rank 0 alone' % world}
-        td.barrier()
         return out
     except Exception as e:      # noqa: BLE001
         return {'error': repr(e)}
+    finally:
+        td.barrier()            # (whatever happened on this rank: the others are waiting here, and the next collective must line up)
 
 
 def lane_timeline(_lib, n_regions):
@@ -783,11 +785,11 @@ def sharded_c3_leg(args, world, rank, options, backend):
         parity = sharded_parity(lambda: [(path, options()) for _ in range(2)], lambda: (path, options()), world) if world > 1 else None
         return {'value': round(n * args.c3_scans / dt, 1), 'unit': 'frames/s', 'ms_per_scan': round(dt / args.c3_scans * 1e3, 2),
                 'scans': args.c3_scans, 'scaling': 'strong', 'world_size': world, 'backend': td.get_backend() if world > 1 else None,
-                'collectives_per_scan': 3 if world > 1 else 0,
-                'collectives': 'all_reduce SUM (int64 sum frame), all_reduce MAX (max frame), reduce SUM (disk mosaic, disjoint column blocks) to the scan\'s owner' if world > 1 else None,
+                'collectives_per_scan': 2 if world > 1 else 0,
+                'collectives': 'all_gather (packed frame statistics: u32 sums | u16 maxima | failure word), reduce SUM (disk mosaic, disjoint column blocks) to the scan\'s owner' if world > 1 else None,
                 'frames_per_rank': dist.frame_block(n, rank, world)[1] - dist.frame_block(n, rank, world)[0],
                 'parity_vs_one_rank': parity,
-                'what': 'one %d-frame %dx%d 16-bit SER in %s, every rank decodes its own frame block (file -> pinned -> HBM), all-reduce '
+                'what': 'one %d-frame %dx%d 16-bit SER in %s, every rank decodes its own frame block (file -> pinned -> HBM), one all-gather '
                         'after pass A, reduce of the zero-filled disk mosaic after pass B to the scan\'s owner (scan k -> rank k mod G), who '
                         'post-processes it while all ranks read the next scan' % (n, w, h, os.path.dirname(path))}
     finally:

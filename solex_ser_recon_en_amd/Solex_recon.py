@@ -19,10 +19,12 @@ What changed underneath:
     mosaic after extraction, post-processing on the mosaic (rank 0 writes the files).
     Several files (folder mode) are dealt round-robin to ranks instead: no collective.
 """
+import contextlib
 import functools
 import math
 import os
 import queue
+import sys
 import threading
 
 import numpy as np
@@ -168,11 +170,15 @@ def solex_do_work(tasks, flag_command_line=False, distribute='auto', return_resu
       'auto'   one file -> its frames are sharded over the ranks; several files -> file i goes to rank i mod G
       'frames' shard the frames of every file over the ranks (collectives per file)
       'none'   this rank processes exactly the tasks it was given (the caller already dealt the files)
-    return_results: also return the list of solex_process results (one list of (cc, protus) per processed file).
+    return_results: also return the solex_process results, ONE ENTRY PER TASK in task order: a list of (cc, protus) per file this
+      rank post-processed, None for a file whose products another rank holds (a series of frame-sharded single-shift scans: scan k's
+      products exist on rank k mod G only -- dist.scan_owner; a sharded Doppler stack's disks are dealt to all ranks: every rank gets
+      the list of its own).
     workers: scans in flight at once in this process (default SHG_WORKERS or 4, the reference's Pool(4)): each scan
       worker is a thread with its own HIP stream, so the host control plane of one file (polynomial fits, limb
       geometry, Savitzky-Golay trend) overlaps the kernels of the others.  Files are independent, so every product
-      is bit-identical to the serial order.  Frame-sharded scans are collective and stay serial."""
+      is bit-identical to the serial order.  A series of frame-sharded scans is read by two threads and post-processed by a third
+      (_sharded_series); `workers` does not apply to it."""
     tasks = list(tasks)
     if distribute not in ('auto', 'frames', 'none'):
         raise ValueError("distribute must be 'auto', 'frames' or 'none'")
@@ -242,7 +248,7 @@ def solex_do_work(tasks, flag_command_line=False, distribute='auto', return_resu
         outputs.flush()
     if not return_results:
         return None
-    return [c for c in collected if c is not None] if shard_frames else collected
+    return collected
 
 
 def _check_shardable(rdr):
@@ -349,15 +355,17 @@ def _worker_context(device, k):
 
 
 def _sharded_series(tasks, decoder, collected):
-    """Several scans, each sharded over the ranks: this thread reads them one after the other (decode, pass A, all-reduce,
-    extraction, reduction of the mosaic -- every collective here, in file order, on every rank), and what has no collective
-    in it, the post-processing of a finished mosaic, runs behind on a second thread with a stream of its own ON THE SCAN'S OWNER:
-    scan k belongs to rank k mod G (dist.scan_owner), the mosaic is reduced to that rank only, and it alone writes the scan's
-    files and log.  So while one rank fits the limb and contrasts scan k, all ranks are already decoding and reducing scan k + 1,
-    whose tail then runs on the next rank: G tails at once, the reference's Pool over files (Solex_recon.py:26-44) spread over
-    the GPUs.  A Doppler stack (several requested disks) deals its disks to all ranks and agrees on the limb fit: collectives
-    inside solex_process, so such a scan is all-reduced and post-processed here, in line.  Before every scan the ranks ask each
-    other whether anyone has failed (dist.any_failed): a failure stops all of them together."""
+    """Several scans, each sharded over the ranks.  Per scan TWO collectives (dist.py): the all-gather of the frame statistics after
+    pass A -- which also carries every rank's "I have failed" word, so a failure anywhere stops all ranks at the same scan -- and the
+    reduction of the disk mosaic to the scan's owner after pass B.  Three things run at once on every rank:
+      * two READING threads (this one takes the even scans, a service thread the odd ones), each on a stream of its own: while scan
+        k is fitted and extracted, scan k + 1 is already decoded, summed and exchanged.  Their collectives are issued in one order on
+        every rank (dist.Sequencer: statistics of k + 1, then mosaic of k);
+      * what has no collective in it, the post-processing of a finished mosaic, on a third thread ON THE SCAN'S OWNER: scan k belongs
+        to rank k mod G (dist.scan_owner), the mosaic is reduced to that rank only, and it alone writes the scan's files and log --
+        G tails at once, the reference's Pool over files (Solex_recon.py:26-44) spread over the GPUs.
+    A Doppler stack (several requested disks) deals its disks to all ranks and agrees on the limb fit -- collectives inside
+    solex_process -- so a series with such a scan in it is read by ONE thread, that scan all-reduced and post-processed in line."""
     import torch
     device = decoder.device
     post = _Service.named('shg-post-%s' % device)
@@ -366,6 +374,8 @@ def _sharded_series(tasks, decoder, collected):
     pending = []
     errors = []
     lock = threading.Lock()
+    plain = all(len(set(options['shift'])) == 1 for _, options in tasks)
+    two_readers = plain and len(tasks) > 1 and os.environ.get('SHG_SHARD_READERS', '2') != '1'
 
     def post_job(i, options, disk_list, bounds, hdr, ready, done):
         try:
@@ -390,48 +400,74 @@ def _sharded_series(tasks, decoder, collected):
             slots.release()
             done.set()
 
+    def read_scan(i):
+        """Scan i on the calling thread: decode, pass A, exchange 1, fit, pass B, exchange 2; its mosaic to the owner's post-processing."""
+        file, options = tasks[i]
+        print('file %s is processing' % file)
+        options['_shard_frames'] = True
+        n_requested = len(set(options['shift']))
+        if n_requested == 1:
+            options['_owner'] = options['_mosaic_to'] = dist.scan_owner(i)
+        try:
+            rdr = decoder.get(i)
+            _check_shardable(rdr)
+        except BaseException as e:      # noqa: BLE001
+            # this rank cannot read its share: the others are on their way into the exchange after pass A -- join them there with the
+            # failure word set (the header says how large the message is), so that every rank leaves the series together
+            with lock:
+                errors.append((i, e))
+            hdr_only = video_reader(file) if not hasattr(file, 'device_stack') else file
+            p = int(hdr_only.Width) * int(hdr_only.Height)
+            dist.exchange_frame_stats(torch.zeros(p, dtype=torch.int64, device=device), torch.zeros(p, dtype=torch.uint16, device=device),
+                                      failed=True, n_frames=1)
+            raise
+        disk_list, bounds, hdr = solex_read(rdr, options)
+        _release_stack(rdr)
+        if n_requested > 1:
+            options['_deal_disks'] = True                   # every rank post-processes its share: collectives inside
+            res = solex_process(options, disk_list, bounds, hdr)
+            if collected is not None:
+                collected[i] = res
+        elif dist.rank() == options['_owner']:
+            slots.acquire()
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(device))
+            done = threading.Event()
+            with lock:
+                pending.append(done)
+            post.jobs.put(functools.partial(post_job, i, options, disk_list, bounds, hdr, ready, done))
+
+    @contextlib.contextmanager
+    def second_thread():
+        rctx = _worker_context(device, 'read1')
+        torch.cuda.set_device(device)
+        bind_thread('scan', device)
+        stages.use_buffers(rctx['buffers'])
+        with torch.cuda.stream(rctx['stream']):
+            yield
+            rctx['stream'].synchronize()
+
+    def posts_done():
+        while True:
+            with lock:
+                waiting = [d for d in pending if not d.is_set()]
+            if not waiting:
+                return
+            waiting[0].wait()
+
+    def post_failed():
+        with lock:
+            return bool(errors)
     previous = bind_thread('scan', device)
     try:
-        for i, (file, options) in enumerate(tasks):
-            with lock:
-                failed = bool(errors)
-            if dist.any_failed(failed, device):
-                break
-            try:
-                print('file %s is processing' % file)
-                options['_shard_frames'] = True
-                n_requested = len(set(options['shift']))
-                if n_requested == 1:
-                    options['_owner'] = options['_mosaic_to'] = dist.scan_owner(i)
-                rdr = decoder.get(i)
-                _check_shardable(rdr)
-                disk_list, bounds, hdr = solex_read(rdr, options)
-                _release_stack(rdr)
-                if n_requested > 1:
-                    options['_deal_disks'] = True           # every rank post-processes its share: collectives inside
-                    res = solex_process(options, disk_list, bounds, hdr)
-                    if collected is not None:
-                        collected[i] = res
-                elif dist.rank() == options['_owner']:
-                    slots.acquire()
-                    ready = torch.cuda.Event()
-                    ready.record(torch.cuda.current_stream(device))
-                    done = threading.Event()
-                    pending.append(done)
-                    post.jobs.put(functools.partial(post_job, i, options, disk_list, bounds, hdr, ready, done))
-            except BaseException as e:      # noqa: BLE001
-                with lock:
-                    errors.append((i, e))
-        for done in pending:
-            done.wait()
-        with lock:
-            failed = bool(errors)
-        dist.any_failed(failed, device)                     # (keeps the number of collectives equal on every rank)
+        read_errors = dist.run_series(len(tasks), read_scan, two_readers=two_readers, second_thread=second_thread, before_verdict=posts_done,
+                                      device=device, also_failed=post_failed)
     finally:
-        for done in pending:
-            done.wait()
+        posts_done()
         if previous is not None:
             os.sched_setaffinity(0, previous)
+    with lock:
+        errors.extend(e for e in read_errors if not any(e[1] is x[1] for x in errors))
     if errors:
         raise min(errors, key=lambda ie: ie[0])[1]
 

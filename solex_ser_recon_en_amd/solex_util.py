@@ -68,7 +68,7 @@ def compute_mean_max(rdr, options, basefich0):
     n, h, w, bpp = ops.stack_geometry(stack)
     total, mx = ops.accumulate_sum_max(stack)
     if dist.is_sharded(rdr):
-        total, mx = dist.allreduce_sum_max(total, mx)          # integer SUM / MAX: bit-identical to one rank
+        total, mx = dist.exchange_frame_stats(total, mx, n_frames=n)     # integer SUM / MAX: bit-identical to one rank
     mean, mxo = ops.finalize_mean_max(total, mx, int(rdr.FrameCount), h, w, bpp)
     return DeviceImage(mean), DeviceImage(mxo)
 
@@ -96,7 +96,7 @@ def compute_mean_return_fit(vid_rdr, options, hdr, iw, ih, basefich0):
     plots = plots_enabled(options)
     if dist.is_sharded(vid_rdr):
         total, mx = ops.accumulate_sum_max(stack)
-        total, mx = dist.allreduce_sum_max(total, mx)          # integer SUM / MAX: bit-identical to one rank
+        total, mx = dist.exchange_frame_stats(total, mx, n_frames=int(stack.shape[0]))      # integer SUM / MAX: bit-identical to one rank
         res = stages.mean_fit(None, int(vid_rdr.FrameCount), sums=(total, mx), geometry=ops.stack_geometry(stack), want_plot_data=plots)
     else:
         res = stages.mean_fit(stack, int(vid_rdr.FrameCount), want_plot_data=plots)

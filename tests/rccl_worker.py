@@ -1,7 +1,7 @@
 """Run under torch.distributed.run with the default backend (nccl = RCCL): one process per GPU.
 
 Checks what the gloo runs on one GPU cannot: every rank decodes into ITS device (the decoder thread binds itself to the
-caller's GPU), the RCCL branches of dist.allreduce_sum_max / dist.gather_columns run on device buffers, and the products of
+caller's GPU), the RCCL branches of dist.exchange_frame_stats / dist.gather_columns run on device buffers, and the products of
 a sharded scan / a folder of scans equal the single-GPU run.  Usage: rccl_worker.py <out_dir> <scan.ser> [<scan2.ser> ...]"""
 import contextlib
 import io
@@ -38,12 +38,12 @@ def main():
         assert cc.t.device.index == local
         report['sharded_cc'] = np.asarray(cc)
     else:
-        assert res == []
+        assert res == [None]                                  # one entry per task: this rank holds none of the scan's products
     # 2. a Doppler stack: disks dealt to the ranks after the limb fit on rank 0
     with contextlib.redirect_stdout(io.StringIO()):
         res = Solex_recon.solex_do_work([(files[0], options(shift=[-2, 0, 3]))], True, return_results=True)
-    report['doppler_n'] = len(res[0]) if res else 0
-    for i, (cc, protus) in enumerate(res[0] if res else []):
+    report['doppler_n'] = len(res[0]) if res and res[0] else 0
+    for i, (cc, protus) in enumerate(res[0] if res and res[0] else []):
         assert cc.t.device.index == local
         report['doppler_cc_%d' % i] = np.asarray(cc)
     # 3. folder mode: file i -> rank i mod G, no collective; the decoder thread must land on this rank's GPU

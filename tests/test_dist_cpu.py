@@ -50,7 +50,9 @@ def _worker(rank, world, port, frames, fit, shifts, flip, out_dir):
             FrameCount = n
             frame_range = (k0, k1)
         assert dist.is_sharded(R)
-        total, mx = dist.allreduce_sum_max(total, mx)
+        before = dist.counters['collectives']
+        total, mx = dist.exchange_frame_stats(total, mx, n_frames=k1 - k0)
+        assert dist.counters['collectives'] == before + 1          # ONE collective after pass A (rounds 1-5: two)
         # what pass B produces on this rank: the columns of its own frames
         rdr = orc.SerReader(frames, k0, k1)
         disks = orc.extract_columns(rdr, fit, shifts)
@@ -189,3 +191,121 @@ def test_series_of_sharded_scans_each_reduced_to_its_owner(tmp_path, world):
         assert r == i % world
         want = np.stack(orc.extract_columns(orc.SerReader(frames), fit, shifts))
         np.testing.assert_array_equal(full, want[:, :, ::-1] if i & 1 else want)
+
+
+def _pipelined_worker(rank, world, port, stacks, fit, shifts, fail, two_readers, out_dir):
+    """A series through dist.run_series -- the driver Solex_recon._sharded_series runs -- with the GPU work replaced by the oracle's:
+    per scan the exchange after pass A and the reduction of the mosaic to the owner, from TWO reading threads."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    td.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        owned, stats = {}, {}
+
+        def read_scan(i):
+            frames = stacks[i]
+            n = frames.shape[0]
+            k0, k1 = dist.frame_block(n)
+            local = frames[k0:k1]
+            if fail == ('rank', i) and rank == world - 1:
+                # a rank that cannot read its share joins the exchange with the failure word set (what _sharded_series does), then fails
+                p = frames.shape[1] * frames.shape[2]
+                dist.exchange_frame_stats(torch.zeros(p, dtype=torch.int64), torch.zeros(p, dtype=torch.uint16), failed=True, n_frames=1)
+                raise AssertionError('the exchange must not return on the rank that set the word')
+            total = torch.from_numpy(local.astype(np.int64).sum(0).ravel())
+            mx = torch.from_numpy(local.max(0).ravel().copy())
+            total, mx = dist.exchange_frame_stats(total, mx, n_frames=k1 - k0)
+            stats[str(i)] = (total.numpy().copy(), mx.view(torch.int16).numpy().view(np.uint16).copy())
+            if fail == ('all', i):
+                raise ValueError('scan %d: a fit that fails on every rank alike' % i)
+            flip = bool(i & 1)
+            local_disks = np.stack(orc.extract_columns(orc.SerReader(frames, k0, k1), fit, shifts))[:, :, k0:k1]
+
+            def fill(mosaic, k_offset):
+                c0, c1 = dist.mosaic_columns((k0, k1), n, flip)
+                block = local_disks[:, :, ::-1] if flip else local_disks
+                mosaic.view(torch.int16)[:, :, c0:c1] = torch.from_numpy(block.copy().view(np.int16))
+            owner = dist.scan_owner(i)
+            full = dist.gather_columns(fill, len(shifts), local_disks.shape[1], (k0, k1), n, flip, torch.device('cpu'), dst=owner)
+            if rank == owner:
+                owned[str(i)] = full.contiguous().view(torch.int16).numpy().view(np.uint16)
+
+        before = dist.counters['collectives']
+        errors = dist.run_series(len(stacks), read_scan, two_readers=two_readers)
+        np.savez(os.path.join(out_dir, 'owned%d.npz' % rank), **owned)
+        np.savez(os.path.join(out_dir, 'sums%d.npz' % rank), **{k: v[0] for k, v in stats.items()})
+        np.savez(os.path.join(out_dir, 'maxs%d.npz' % rank), **{k: v[1] for k, v in stats.items()})
+        np.save(os.path.join(out_dir, 'verdict%d.npy' % rank),
+                np.array([repr({'collectives': dist.counters['collectives'] - before, 'errors': [(i, type(e).__name__, str(e)) for i, e in errors]})]))
+        # the next collective still works: nobody is stuck in the series
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        td.all_reduce(t)
+        assert int(t.item()) == world * (world + 1) // 2
+    finally:
+        td.destroy_process_group()
+
+
+def _series_inputs(n_scans):
+    ih, iw = 96, 40
+    curve = np.linspace(3.2, iw - 5.1, ih)
+    fit = np.stack([np.floor(curve), curve - np.floor(curve), np.arange(ih), curve], axis=1)
+    return [synth.synth_frames_numpy(17 + 3 * i, ih, iw, 16, seed=40 + i) for i in range(n_scans)], fit, [10, 0]
+
+
+def _verdicts(tmp_path, world):
+    return [eval(str(np.load(str(tmp_path / ('verdict%d.npy' % r)))[0])) for r in range(world)]      # noqa: S307 -- our own repr
+
+
+@pytest.mark.parametrize('world,two_readers', [(2, True), (3, True), (8, True), (2, False)])
+def test_pipelined_series_two_collectives_per_scan_and_one_rank_products(tmp_path, world, two_readers):
+    """The series driver with two scans being read at a time: per scan exactly TWO collectives (the all-gather of the packed frame
+    statistics with the failure word; the reduction of the mosaic to the owner) plus one word at the end of the series; the summed /
+    maximised frames on EVERY rank and the owner's mosaic are the unsharded results bit for bit, whichever thread read the scan."""
+    stacks, fit, shifts = _series_inputs(7)
+    mp.spawn(_pipelined_worker, args=(world, _free_port(), stacks, fit, shifts, None, two_readers, str(tmp_path)), nprocs=world, join=True)
+    for r, v in enumerate(_verdicts(tmp_path, world)):
+        assert v['errors'] == [], (r, v)
+        assert v['collectives'] == 2 * len(stacks) + 1, (r, v)            # collectives_per_scan == 2
+    owners = {}
+    for r in range(world):
+        sums, maxs = np.load(str(tmp_path / ('sums%d.npz' % r))), np.load(str(tmp_path / ('maxs%d.npz' % r)))
+        for i, frames in enumerate(stacks):
+            np.testing.assert_array_equal(sums[str(i)], frames.astype(np.int64).sum(0).ravel())
+            np.testing.assert_array_equal(maxs[str(i)], frames.max(0).ravel())
+        got = np.load(str(tmp_path / ('owned%d.npz' % r)))
+        for key in got.files:
+            assert key not in owners
+            owners[key] = (r, got[key])
+    assert sorted(owners, key=int) == [str(i) for i in range(len(stacks))]
+    for i, frames in enumerate(stacks):
+        r, full = owners[str(i)]
+        assert r == i % world
+        want = np.stack(orc.extract_columns(orc.SerReader(frames), fit, shifts))
+        np.testing.assert_array_equal(full, want[:, :, ::-1] if i & 1 else want)
+
+
+@pytest.mark.parametrize('world,fail', [(2, ('rank', 3)), (3, ('rank', 0)), (8, ('rank', 4)), (3, ('all', 2))])
+def test_pipelined_series_stops_on_every_rank_together(tmp_path, world, fail):
+    """A rank that cannot read its share of scan j sets the failure word in that scan's exchange: EVERY rank leaves the series there
+    (its own error on the failing rank, 'another rank failed' on the others), nobody is left waiting in a collective, and what was
+    reduced before is intact.  A scan that fails on every rank alike (a fit on the all-reduced mean) gives up its mosaic's place in the
+    order; the word then travels in the next exchange."""
+    stacks, fit, shifts = _series_inputs(6)
+    mp.spawn(_pipelined_worker, args=(world, _free_port(), stacks, fit, shifts, fail, True, str(tmp_path)), nprocs=world, join=True)
+    verdicts = _verdicts(tmp_path, world)
+    for r, v in enumerate(verdicts):
+        assert v['errors'], (r, v)                                         # every rank reports a failure
+        if fail[0] == 'rank':
+            assert v['collectives'] <= 2 * len(stacks) + 1
+            if r != world - 1:
+                assert any('another rank failed' in msg for _, _, msg in v['errors']), (r, v)
+        else:
+            assert any('fails on every rank alike' in msg for _, _, msg in v['errors']), (r, v)
+    assert len({v['collectives'] for v in verdicts}) == 1                  # the same collectives on every rank: none waited alone
+    for r in range(world):
+        got = np.load(str(tmp_path / ('owned%d.npz' % r)))
+        for key in got.files:                                              # mosaics reduced before the stop are the oracle's
+            i = int(key)
+            want = np.stack(orc.extract_columns(orc.SerReader(stacks[i]), fit, shifts))
+            np.testing.assert_array_equal(got[key], want[:, :, ::-1] if i & 1 else want)
+            assert fail[0] == 'all' or i < fail[1]

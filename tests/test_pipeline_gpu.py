@@ -5,6 +5,8 @@ import os
 import numpy as np
 import pytest
 
+from tests.conftest import flips
+
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip('torch')
 
@@ -46,9 +48,13 @@ def free_port():
         return s.getsockname()[1]
 
 
-def close_u16(got, want, max_flips=4, lsb=1):
+def close_to_capture(label, got, want, max_flips, lsb):
+    """Against the REFERENCE'S OWN capture of a stubborn-transversalium product (another host's exp / log / float32 filter sums):
+    the one stated allowance of this file.  Everything else is held to the flip counts observed, which are 0 (conftest.flips)."""
     assert got.shape == want.shape
     diff = np.abs(np.asarray(got).astype(np.int64) - np.asarray(want).astype(np.int64))
+    print('PARITY %-60s %9d px  %d differ  max %d LSB (capture of another host: <= %d px, <= %d LSB allowed)' % (
+        label, diff.size, np.count_nonzero(diff), diff.max(), max_flips, lsb))
     assert diff.max() <= lsb and np.count_nonzero(diff) <= max_flips, (diff.max(), np.count_nonzero(diff))
 
 
@@ -74,10 +80,10 @@ def test_solex_read_process_vs_oracle_and_reference(pkg, scan, tag):
         np.testing.assert_allclose(opts['slant_fix'], np.degrees(want['geometry']['phi']), rtol=1e-6, atol=1e-9)
     for shift, (cc, protus) in zip(requested, results):
         ref = want['results'][shift]
-        # float stages (warp f64, transversalium f64 + device log, CLAHE f32) against the oracle on this host: <= 1 LSB
-        # on a handful of pixels, stubborn scenarios included (measured: all seven scenarios come out bit-identical)
-        close_u16(cc, ref['cc'])
-        close_u16(protus, ref['protus'])
+        # float stages (warp f64, transversalium f64 + device log, CLAHE f32) against the oracle on this host: all seven
+        # scenarios come out bit-identical, stubborn ones included -- held to that
+        flips('scenario %s shift %d cc' % (tag, shift), cc, ref['cc'])
+        flips('scenario %s shift %d protus' % (tag, shift), protus, ref['protus'])
         for product in ('clahe', 'protus'):
             key = '%s_s%d_%s' % (tag, shift, product)
             # The reference's own output for this product, captured under NumPy 1.26 / SciPy 1.7 (oracle/capture_goldens.py).
@@ -86,7 +92,10 @@ def test_solex_read_process_vs_oracle_and_reference(pkg, scan, tag):
             # 168 000 px in scenario F, 0 in G; every other scenario is exact.
             if key in g.files:
                 stretched = tag in 'FG' and product == 'clahe'
-                close_u16({'clahe': cc, 'protus': protus}[product], g[key], max_flips=2 if stretched else 4, lsb=4 if stretched else 1)
+                if stretched:
+                    close_to_capture(key, {'clahe': cc, 'protus': protus}[product], g[key], max_flips=2, lsb=4)
+                else:
+                    flips(key + ' vs the reference capture', {'clahe': cc, 'protus': protus}[product], g[key])
 
 
 def test_cli_writes_the_reference_file_layout(pkg, scan, tmp_path):
@@ -112,11 +121,11 @@ def test_cli_writes_the_reference_file_layout(pkg, scan, tmp_path):
     np.testing.assert_array_equal(raw, want['read']['disks'][1])
     mean, _ = fits_io.read_fits_u16(base + '_mean.fits')
     np.testing.assert_array_equal(mean, want['read']['mean'])
-    close_u16(png_io.read_png_gray(base + '_shift=0_clahe.png'), g['A_s0_clahe'])
-    close_u16(png_io.read_png_gray(base + '_shift=0_protus.png'), g['A_s0_protus'])
-    close_u16(png_io.read_png_gray(base + '_shift=0_uncontrasted.png'), g['A_s0_uncontrasted'])
-    close_u16(png_io.read_png_gray(base + '_shift=0_high_contrast.png'), g['A_s0_high_contrast'])
-    close_u16(fits_io.read_fits_u16(base + '_shift=0_clahe.fits')[0], want['results'][0]['cl1'])
+    flips('CLI clahe.png vs the reference capture', png_io.read_png_gray(base + '_shift=0_clahe.png'), g['A_s0_clahe'])
+    flips('CLI protus.png vs the reference capture', png_io.read_png_gray(base + '_shift=0_protus.png'), g['A_s0_protus'])
+    flips('CLI uncontrasted.png vs the reference capture', png_io.read_png_gray(base + '_shift=0_uncontrasted.png'), g['A_s0_uncontrasted'])
+    flips('CLI high_contrast.png vs the reference capture', png_io.read_png_gray(base + '_shift=0_high_contrast.png'), g['A_s0_high_contrast'])
+    flips('CLI clahe.fits vs the oracle', fits_io.read_fits_u16(base + '_shift=0_clahe.fits')[0], want['results'][0]['cl1'])
     log = open(base + '_log.txt').read()
     for needle in ('start time', 'Pixel shift : [0]', 'Width, Height : 400 32', 'Number of frames : 400',
                    'Vertical limits y1, y2 : 41 359', 'Spectral line polynomial fit', 'Transversalium correction : 301',
@@ -179,7 +188,7 @@ def test_folder_of_files_with_prefetch(pkg, scan, tmp_path):
     a = png_io.read_png_gray(files[0][:-4] + '_shift=0_clahe.png')
     b = png_io.read_png_gray(files[1][:-4] + '_shift=0_clahe.png')
     c = png_io.read_png_gray(files[2][:-4] + '_shift=0_clahe.png')
-    close_u16(a, g['A_s0_clahe'])
+    flips('clahe of scenario A vs the reference capture', a, g['A_s0_clahe'])
     np.testing.assert_array_equal(a, c)
     assert a.shape[0] == b.shape[0] and not np.array_equal(a, b)
     # a missing file in the middle stops the batch when its turn comes (README: "will halt if a file is unsuitable")
@@ -344,9 +353,9 @@ def test_two_ranks_sharded_scan_equals_one_rank(pkg, scan, tmp_path):
 
 
 def test_two_ranks_series_of_sharded_scans_overlaps_and_equals_one_rank(pkg, scan, tmp_path):
-    """SHG_DISTRIBUTE=frames with several files: every file's frames are sharded over the two ranks; rank 0 post-processes file k on
-    a second thread while both ranks already read file k + 1 (collectives in file order).  Three different files must come
-    out like the single-process run, written by rank 0 only."""
+    """SHG_DISTRIBUTE=frames with several files: every file's frames are sharded over the two ranks; file k's owner (rank k mod 2)
+    post-processes it on a thread of its own while both ranks already read files k + 1 and k + 2 (two reading threads, their
+    collectives in one order).  Three different files must come out like the single-process run, each written by its owner only."""
     import subprocess
     import sys
     g, frames, path = scan
@@ -372,6 +381,39 @@ def test_two_ranks_series_of_sharded_scans_overlaps_and_equals_one_rank(pkg, sca
     for name in names:
         if name.endswith('.png'):
             np.testing.assert_array_equal(png_io.read_png_gray(str(dirs['one'] / name)), png_io.read_png_gray(str(dirs['two'] / name)), err_msg=name)
+
+
+def test_two_ranks_series_returns_one_entry_per_scan_and_two_collectives_each(pkg, scan, tmp_path):
+    """solex_do_work(distribute='frames', return_results=True) over five different scans on two ranks (gloo, one GPU): the returned
+    list has one entry per task on every rank -- scan k's products on rank k mod 2, None on the other (round 5 dropped the Nones:
+    the entries could not be matched to files) -- the products are the one-process run's bit for bit, and the series took two
+    collectives per scan plus the one word at its end (two scans being read at a time, tests/series_worker.py)."""
+    import subprocess
+    import sys
+    SHG_MAIN, Solex_recon, outputs = pkg
+    g, frames, path = scan
+    files = []
+    for j in range(5):
+        f = str(tmp_path / ('scan%d.ser' % j))
+        synth.write_ser(f, np.roll(frames, 5 * j, axis=0) if j else frames)
+        files.append(f)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=repo, SHG_DIST_BACKEND='gloo', MPLBACKEND='Agg')
+    subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                    '--master-port', str(free_port()), os.path.join(repo, 'tests', 'series_worker.py'), str(tmp_path)] + files,
+                   check=True, env=env, cwd=repo, timeout=900)
+    ranks = [np.load(str(tmp_path / ('series_rank%d.npz' % r))) for r in range(2)]
+    for r, rep in enumerate(ranks):
+        assert int(rep['n_entries']) == 5
+        assert list(rep['held']) == [i for i in range(5) if i % 2 == r]
+        assert int(rep['collectives']) == 2 * 5 + 1
+    for i, f in enumerate(files):
+        opts = SHG_MAIN.default_options()
+        opts.update(_nolog=True)
+        (res,) = Solex_recon.solex_do_work([(f, opts)], True, return_results=True)
+        (cc, protus), = res
+        np.testing.assert_array_equal(ranks[i % 2]['cc_%d' % i], np.asarray(cc))
+        np.testing.assert_array_equal(ranks[i % 2]['protus_%d' % i], np.asarray(protus))
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='the RCCL (nccl) branch needs two GPUs; gloo covers the logic on one')
@@ -428,8 +470,8 @@ def test_whole_flow_other_shapes_vs_oracle(pkg, n, w, h, bits, extra):
         np.testing.assert_array_equal(np.asarray(got), ref)
     requested = [s for s in opts['shift'] if s in opts['shift_requested']]
     for shift, (cc, protus) in zip(requested, results):
-        close_u16(cc, want['results'][shift]['cc'])
-        close_u16(protus, want['results'][shift]['protus'])
+        flips('cc', cc, want['results'][shift]['cc'])
+        flips('protus', protus, want['results'][shift]['protus'])
 
 
 def test_bad_files_raise_like_the_reference(pkg, tmp_path):
@@ -528,7 +570,7 @@ def test_solex_read_from_avi_equals_ser(pkg, tmp_path, layout):
         results[path] = [np.asarray(x) for x in out[0]]
     for a, b in zip(results[ser], results[avi]):
         np.testing.assert_array_equal(a, b)
-    close_u16(results[avi][0], want['results'][0]['cc'])
+    flips('AVI scan cc', results[avi][0], want['results'][0]['cc'])
 
 
 VARIANTS = {
@@ -577,8 +619,8 @@ def test_scene_variants_vs_oracle(pkg, name):
     np.testing.assert_allclose(opts['ratio_fixe'], want['geometry']['ratio'], rtol=1e-9)
     requested = [s for s in opts['shift'] if s in opts['shift_requested']]
     for shift, (cc, protus) in zip(requested, results):
-        close_u16(cc, want['results'][shift]['cc'])
-        close_u16(protus, want['results'][shift]['protus'])
+        flips('cc', cc, want['results'][shift]['cc'])
+        flips('protus', protus, want['results'][shift]['protus'])
 
 
 @pytest.mark.parametrize('name', ['zeros', 'noise_only', 'ten_frames', 'half_scan', 'tiny_disk'])
@@ -610,7 +652,7 @@ def test_pathological_scans_fail_like_the_reference(pkg, name):
     else:
         (results,) = Solex_recon.solex_do_work(task, True, return_results=True)
         outputs.flush()
-        close_u16(results[0][0], want['results'][0]['cc'])
+        flips('cc', results[0][0], want['results'][0]['cc'])
     assert (expected is None) == (name == 'half_scan')
 
 
