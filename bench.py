@@ -324,7 +324,7 @@ def main():
                                        'how': 'the same XOR-only kernel with pass A\'s addresses (a lane walks the frame axis), best of 8 '
                                               '(splits x unroll) = %s' % (walk_shape,)},
                 'lane': lane,
-                'secondary': {'kernel': 'k_extract (pass B)', 'algorithmic_bytes_per_launch': bytes_b,
+                'secondary': {'kernel': 'k_extract_band (pass B)', 'algorithmic_bytes_per_launch': bytes_b,
                               'avg_launch_ms': round(ext_ms / ext_n, 5) if ext_n else None,
                               'achieved': round(bytes_b / (ext_ms / ext_n * 1e-3) / 1e9, 1) if ext_n else None,
                               'uncontended_avg_launch_ms': round(ext1_ms / ext1_n, 5) if ext1_n else None,
