@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SHG_ABI_VERSION 15
+#define SHG_ABI_VERSION 16
 
 #define SHG_E_ARG        (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SHG_E_WORKSPACE  (-2)   /* workspace too small                                 */
@@ -116,6 +116,13 @@ int shg_unpack_dib_frames(const uint8_t* raw, int64_t n_frames, int64_t raw_pitc
 int shg_finalize_mean_max(const uint64_t* sum, const uint16_t* max_raw, int64_t n_total,
                           int64_t height, int64_t width, int bytes_per_px,
                           uint16_t* mean_out, uint16_t* max_out, shg_stream_t stream);
+/* The frame statistics of a frame-sharded scan after their exchange (the reference has no such step: its compute_mean_max,
+ * solex_util.py:174-188, sees every frame): n_pieces records of piece_words 32-bit words, one per rank, each
+ * [npix partial sums as 32-bit words | npix partial maxima as 16-bit words, padded to a whole word | ...] -- what ONE all-gather of
+ * every rank's packed statistics brings (dist.exchange_frame_stats) -- folded into the 64-bit sums and the maxima
+ * shg_finalize_mean_max takes.  Integer: the result does not depend on the number of pieces. */
+int shg_reduce_frame_stats(const uint32_t* pieces, int n_pieces, int64_t piece_words, int64_t npix, uint64_t* sum_out,
+                           uint16_t* max_out, shg_stream_t stream);
 /* compute_mean_max (solex_util.py:174-188) for a scan that is whole on this GPU: pass A, then mean and max images straight
  * from its per-slab partials (shg_accumulate_sum_max + shg_finalize_mean_max without the 64-bit totals in between).
  * workspace: shg_accumulate_workspace_bytes. */

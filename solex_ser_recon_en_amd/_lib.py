@@ -77,6 +77,7 @@ SIGNATURES = {
     'shg_upload_frames': (c_int, [P, c_int64, P, c_int64, c_int64, P]),
     'shg_unpack_dib_frames': (c_int, [P, c_int64, c_int64, c_int64, c_int64, c_int, c_int64, c_int, P, P, c_int64, P]),
     'shg_finalize_mean_max': (c_int, [P, P, c_int64, c_int64, c_int64, c_int, P, P, P]),
+    'shg_reduce_frame_stats': (c_int, [P, c_int, c_int64, c_int64, P, P, P]),
     'shg_accumulate_mean_max': (c_int, [P, c_int64, c_int64, c_int64, c_int, c_int64, P, P, P, c_size_t, P]),
     'shg_box_blur_u16': (c_int, [P, c_int64, c_int64, c_int, c_int, P, P, P]),
     'shg_row_argmin_u16': (c_int, [P, c_int64, c_int64, c_int64, c_int64, P, P]),
@@ -201,7 +202,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 if lib.shg_abi_version() != ABI_VERSION:
     raise ImportError('libshg_hip.so ABI %d != expected %d: rebuild it' % (lib.shg_abi_version(), ABI_VERSION))
 

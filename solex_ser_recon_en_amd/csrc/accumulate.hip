@@ -568,6 +568,42 @@ extern "C" int shg_accumulate_mean_max(const void* stack, int64_t n_frames, int6
     return launch_finalize(FromPartials{a.psum, a.pmax, a.p.nsplit, a.p.npix}, n_frames, height, width, bytes_per_px, mean_out, max_out, shg::as_stream(stream));
 }
 
+// ---- the frame statistics of a sharded scan: the G ranks' pieces, as one all-gather brought them, folded in one launch -------------
+// pieces: n_pieces records of piece_words 32-bit words each: [npix partial sums as 32-bit words | npix partial maxima as 16-bit
+// words (padded to a whole word) | anything else] -- dist.exchange_frame_stats' message.  -> sum_out [npix] (64 bits), max_out [npix].
+namespace {
+struct ReducePiecesArgs {
+    const uint32_t* pieces;
+    int n_pieces;
+    int64_t piece_words, npix;
+    uint64_t* sum_out;
+    uint16_t* max_out;
+};
+__global__ __launch_bounds__(256) void k_reduce_frame_stats(const ReducePiecesArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.npix) return;
+    uint64_t s = 0;
+    uint32_t m = 0;
+    for (int j = 0; j < a.n_pieces; ++j) {
+        const uint32_t* piece = a.pieces + (int64_t)j * a.piece_words;
+        s += piece[i];
+        const uint32_t v = reinterpret_cast<const uint16_t*>(piece + a.npix)[i];
+        m = m > v ? m : v;
+    }
+    a.sum_out[i] = s;
+    a.max_out[i] = (uint16_t)m;
+}
+}  // namespace
+
+extern "C" int shg_reduce_frame_stats(const uint32_t* pieces, int n_pieces, int64_t piece_words, int64_t npix, uint64_t* sum_out,
+                                      uint16_t* max_out, shg_stream_t stream) {
+    SHG_REQUIRE(pieces && sum_out && max_out, SHG_E_ARG, "shg_reduce_frame_stats: null pointer");
+    SHG_REQUIRE(n_pieces > 0 && npix > 0 && piece_words >= npix + (npix + 1) / 2, SHG_E_ARG, "shg_reduce_frame_stats: %d pieces of %lld words for %lld pixels",
+                n_pieces, (long long)piece_words, (long long)npix);
+    return shg::launch(k_reduce_frame_stats, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, shg::as_stream(stream),
+                       ReducePiecesArgs{pieces, n_pieces, piece_words, npix, sum_out, max_out}, "k_reduce_frame_stats");
+}
+
 extern "C" int shg_finalize_mean_max(const uint64_t* sum, const uint16_t* max_raw, int64_t n_total,
                                      int64_t height, int64_t width, int bytes_per_px,
                                      uint16_t* mean_out, uint16_t* max_out, shg_stream_t stream) {

@@ -266,6 +266,10 @@ def exchange_frame_stats(total, mx, failed=False, n_frames=None):
     every = every.view(g, words)
     if staged:
         every = every.to(dev)
+    if every.is_cuda:
+        # the G pieces folded in one launch (shg_reduce_frame_stats)
+        from . import ops
+        return ops.reduce_frame_stats(every, p)
     sums = (every[:, :p].to(torch.int64) & 0xffffffff).sum(dim=0)
     maxima = (every[:, p:p + (p + 1) // 2].contiguous().view(torch.int16)[:, :p].to(torch.int32) & 0xffff).amax(dim=0)
     return sums, maxima.to(torch.int16).view(torch.uint16)

@@ -132,6 +132,19 @@ def finalize_mean_max(total, mx, n_total, height, width, bpp):
     return mean, mout
 
 
+def reduce_frame_stats(pieces, npix):
+    """pieces: int32 GPU tensor [G, words], every row one rank's [npix sums as 32-bit words | npix maxima as 16-bit words | ...]
+    (dist.exchange_frame_stats' all-gather) -> (int64 [npix] sums, uint16 [npix] maxima) over all ranks, one launch."""
+    _dev(pieces, 'pieces')
+    if pieces.dtype != torch.int32 or pieces.dim() != 2 or not pieces.is_contiguous():
+        raise TypeError('pieces must be a contiguous int32 [G, words] tensor')
+    total = torch.empty(int(npix), dtype=torch.int64, device=pieces.device)
+    mx = torch.empty(int(npix), dtype=torch.uint16, device=pieces.device)
+    _lib.check(lib.shg_reduce_frame_stats(pieces.data_ptr(), int(pieces.shape[0]), int(pieces.shape[1]), int(npix), total.data_ptr(),
+                                          mx.data_ptr(), _stream()), 'shg_reduce_frame_stats')
+    return total, mx
+
+
 # ---- line detection helpers -------------------------------------------------
 def box_blur_u16(img, kw, kh):
     ptr, h, w, pitch = _img(img, 'img', torch.uint16)

@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(_lib.lib, name), 'libshg_hip.so does not export %s' % name
         assert name in _lib.SIGNATURES, 'no ctypes signature for %s' % name
     assert sorted(_lib.SIGNATURES) == names
-    assert _lib.lib.shg_abi_version() == _lib.ABI_VERSION == 15
+    assert _lib.lib.shg_abi_version() == _lib.ABI_VERSION == 16
     assert isinstance(_lib.last_error(), str)
 
 

@@ -81,6 +81,23 @@ def test_mean_max_sharding_is_bit_identical(ops):
     np.testing.assert_array_equal(host(m_all), m_max)
 
 
+def test_frame_statistics_of_the_ranks_folded_in_one_launch(ops):
+    """shg_reduce_frame_stats: the pieces one all-gather brings -- per rank [sums as 32-bit words | maxima as 16-bit words | failure
+    word] -- against NumPy, sums beyond 2^31 per piece and an odd pixel count (the maxima's last word half used) included."""
+    rng = np.random.default_rng(77)
+    for g, p in ((8, 400001), (2, 64), (3, 1)):
+        sums = rng.integers(0, 2 ** 32, (g, p), dtype=np.uint64)
+        maxs = rng.integers(0, 65536, (g, p), dtype=np.uint64).astype(np.uint16)
+        words = p + (p + 1) // 2 + 1
+        pieces = np.zeros((g, words), dtype=np.uint32)
+        pieces[:, :p] = sums.astype(np.uint32)
+        pieces[:, p:p + (p + 1) // 2].view(np.uint16)[:, :p] = maxs
+        pieces[:, -1] = 0xdeadbeef
+        total, mx = ops.reduce_frame_stats(torch.from_numpy(pieces.view(np.int32)).cuda(), p)
+        np.testing.assert_array_equal(total.cpu().numpy().view(np.uint64), sums.sum(axis=0))
+        np.testing.assert_array_equal(host(mx), maxs.max(axis=0))
+
+
 # ---- line detection helpers ---------------------------------------------------
 @pytest.mark.parametrize('h,w,kw,kh', [(180, 48, 25, 1), (180, 48, 5, 5), (64, 203, 25, 7), (33, 31, 4, 6), (12, 9, 25, 3)])
 def test_box_blur_matches_oracle(ops, orc, h, w, kw, kh):
