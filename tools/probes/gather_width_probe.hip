@@ -83,6 +83,56 @@ void run(const uint16_t* stack, int n, int64_t fstride, int width, int ih, int S
            bytes / (best * 1e-3) / 1e12, distinct / (best * 1e-3) / 1e12, grid.x * grid.y * grid.z, 2 * R, 64.0 * 2 * R * SC * 2 * BATCH / 1024);
 }
 
+// Round 6: every file row of the band ONCE (what k_extract_band asks for): a lane owns R consecutive slit rows and loads its 2 R
+// bytes of each of the NR file rows of a frame; 8 waves a workgroup, FPW frames a wave, all FPW x NR loads in flight.
+// grid (frames / (8 FPW), slit rows / (64 R)); the band of NR = 8 rows (a group of seven shifts) or 22 (all of them at once)
+template <int R, int NR, int FPW>
+__global__ __launch_bounds__(512) void k_band_once(const uint16_t* __restrict__ stack, int n_frames, int64_t fstride, int width, int x0, uint32_t* out) {
+    using V = typename Vec<R>::type;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int y = (blockIdx.y * 64 + lane) * R;
+    const int g0 = blockIdx.z * (NR - 1);
+    uint32_t voff[NR];
+#pragma unroll
+    for (int d = 0; d < NR; ++d) voff[d] = (uint32_t)(((int64_t)(x0 + g0 + d) * width + y) * 2);
+    V v[FPW][NR];
+#pragma unroll
+    for (int i = 0; i < FPW; ++i) {
+        const int k = (blockIdx.x * 8 + wave) * FPW + i;
+        const char* f = reinterpret_cast<const char*>(stack + (int64_t)(k < n_frames ? k : 0) * fstride);
+#pragma unroll
+        for (int d = 0; d < NR; ++d) v[i][d] = *reinterpret_cast<const V*>(f + voff[d]);
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < FPW; ++i)
+#pragma unroll
+        for (int d = 0; d < NR; ++d) acc ^= fold(v[i][d]);
+    out[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 512 + threadIdx.x] = acc;
+}
+
+template <int R, int NR, int FPW>
+void run_once(const uint16_t* stack, int n, int64_t fstride, int width, int ih, int S, uint32_t* out, const char* what) {
+    dim3 grid((n + 8 * FPW - 1) / (8 * FPW), ih / (64 * R), (S + NR - 2) / (NR - 1));
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    float best = 1e9f;
+    for (int rep = 0; rep < 6; ++rep) {
+        CHECK(hipEventRecord(a, 0));
+        hipLaunchKernelGGL((k_band_once<R, NR, FPW>), grid, dim3(512), 0, 0, stack, n, fstride, width, 80, out);
+        CHECK(hipEventRecord(b, 0));
+        CHECK(hipEventSynchronize(b));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    const double distinct = (double)n * (S + 1) * ih * 2;
+    printf("%-52s %7.1f us  %5.2f TB/s of distinct bytes; %u workgroups, %d B a lane-load, %d loads in flight a wave\n", what, best * 1e3,
+           distinct / (best * 1e-3) / 1e12, grid.x * grid.y * grid.z, 2 * R, FPW * NR);
+}
+
 int main() {
     const int n = 2000, height = 200, width = 2000, S = 21;
     const int64_t fstride = 802816 / 2;
@@ -105,5 +155,14 @@ int main() {
     run<8, 2, 2>(stack, n, fstride, width, ih, S, out, "8 rows a lane, SC 2, batch 2");
     run<8, 1, 8>(stack, n, fstride, width, ih, S, out, "8 rows a lane, SC 1, batch 8");
     run<8, 11, 1>(stack, n, fstride, width, ih, S, out, "8 rows a lane, SC 11, batch 1");
+    // round 6: every row of a group of seven shifts once (8 rows; 24 loads per slit row and frame), lane width 2 .. 16 bytes
+    run_once<1, 8, 8>(stack, n, fstride, width, ih, S, out, "once: 1 row a lane (128 B a wave-load), 8 x 8");
+    run_once<2, 8, 8>(stack, n, fstride, width, ih, S, out, "once: 2 rows a lane (256 B), 8 x 8");
+    run_once<4, 8, 4>(stack, n, fstride, width, ih, S, out, "once: 4 rows a lane (512 B), 8 x 4");
+    run_once<4, 8, 8>(stack, n, fstride, width, ih, S, out, "once: 4 rows a lane (512 B), 8 x 8");
+    run_once<8, 8, 2>(stack, n, fstride, width, ih, S, out, "once: 8 rows a lane (1 KiB), 8 x 2");
+    run_once<8, 8, 4>(stack, n, fstride, width, ih, S, out, "once: 8 rows a lane (1 KiB), 8 x 4");
+    run_once<1, 22, 2>(stack, n, fstride, width, ih, S, out, "once: 1 row a lane, all 22 rows x 2 frames");
+    run_once<8, 22, 1>(stack, n, fstride, width, ih, S, out, "once: 8 rows a lane, all 22 rows x 1 frame");
     return 0;
 }
