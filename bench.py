@@ -123,13 +123,16 @@ def launch_ranks(n):
     and exits with the first non-zero code (the other ranks are then ended by their own PIDs)."""
     import socket
     import subprocess
-    with socket.socket() as sk:
+    import tempfile
+    with socket.socket() as sk:                              # (MASTER_PORT is still set, for code that reads it; the ranks meet through the file)
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
+    meet_dir = tempfile.mkdtemp(prefix='shg_bench_')
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), SHG_BENCH_SELF_LAUNCHED='1')
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), SHG_BENCH_SELF_LAUNCHED='1',
+                   SHG_BENCH_RENDEZVOUS=os.path.join(meet_dir, 'rendezvous'))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else sys.stderr))
@@ -150,6 +153,8 @@ def launch_ranks(n):
     finally:
         for pr in pending:                                   # (this process is being stopped: its ranks go with it, by their own PIDs)
             pr.terminate()
+        import shutil
+        shutil.rmtree(meet_dir, ignore_errors=True)
     return rc
 
 
@@ -172,10 +177,14 @@ def main():
     device_index = local_rank % max(torch.cuda.device_count(), 1) if backend != 'nccl' else local_rank
     torch.cuda.set_device(device_index)
     if world > 1:
+        # ranks this file started itself meet through a FILE (launch_ranks made it): no port that another process could take
+        # between its choice and the ranks' bind; under a launcher the environment's MASTER_ADDR / MASTER_PORT are the launcher's
+        meet = os.environ.get('SHG_BENCH_RENDEZVOUS')
+        kw = dict(init_method='file://' + meet, rank=rank, world_size=world) if meet else {}
         if backend == 'nccl':
-            td.init_process_group('nccl', device_id=torch.device('cuda', device_index))
+            td.init_process_group('nccl', device_id=torch.device('cuda', device_index), **kw)
         else:
-            td.init_process_group(backend)
+            td.init_process_group(backend, **kw)
 
     from solex_ser_recon_en_amd import SHG_MAIN, Solex_recon, _lib, synth, timing
     from solex_ser_recon_en_amd import ops as _ops
