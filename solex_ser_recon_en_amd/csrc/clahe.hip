@@ -1090,6 +1090,7 @@ struct InterpVmArgs {
 // T2: a 2 x 2 tile grid, known at compile time.  With `tiles` a run-time value the four-entry load sat inside a branch per pixel and
 // the compiler waited for each before issuing the next: a lane's PX gathers went one after the other, eight L2 round trips a row
 // (the kernel's 0.18 of the roofline; its instruction count never mattered).  With T2 all PX gathers are issued, then blended.
+constexpr int INTERP_ROUNDS = 4;                              // rounds of a workgroup in the tiled walk (launch_interp16)
 template <int PX, bool COUNT, bool T2> __global__ __launch_bounds__(256) void k_clahe_interp_vm(const InterpVmArgs kargs) {
     const shg::PtrBatch& imgs = kargs.imgs;
     const shg::PtrBatch& dsts = kargs.dsts;
@@ -1164,59 +1165,25 @@ template <int PX, bool COUNT, bool T2> __global__ __launch_bounds__(256) void k_
     }
     // (tiled walk, whole vectors: the NEXT round's pixels are asked for as soon as this round's have been unpacked, so that a round is
     // one round trip -- its gathers -- and not two)
-    const bool ahead = tiled && (PX == 8 || PX == 4) && x0 + PX <= w;
+    const bool ahead = tiled && (PX == 8 || PX == 4) && x0 + PX <= w && rows <= INTERP_ROUNDS;
     auto fetch = [&](uint32_t yy) {
         if (PX == 8) return *reinterpret_cast<const uint4*>(img + (int64_t)yy * pitch + x0);
         const uint2 t = *reinterpret_cast<const uint2*>(img + (int64_t)yy * pitch + x0);
         return make_uint4(t.x, t.y, 0u, 0u);
     };
-    uint4 qnext = make_uint4(0u, 0u, 0u, 0u);
-    if (ahead && (int64_t)row0 < h) qnext = fetch(row0);
-    for (int it = 0; it < rows; ++it) {
-        uint32_t yy;
-        if (tiled) {
-            yy = row0 + (uint32_t)it * row_step;
-            if (x0 >= w) break;
-        } else {
-            const uint32_t flat = (blockIdx.x * (uint32_t)rows + (uint32_t)it) * 256u + threadIdx.x;
-            yy = flat / nv;
-            x0 = (int64_t)(flat - yy * nv) * PX;
-            column_terms(x0);
-        }
-        const int64_t y = yy;
-        if (y >= h) break;
-        const int n = (int)min((int64_t)PX, w - x0);
-        const float tyf = (float)(int)y * inv_th - 0.5f;
-        int ty1 = (int)floorf(tyf);
-        int ty2 = ty1 + 1;
-        const float ya = tyf - (float)ty1;
-        const float ya1 = 1.0f - ya;
-        ty1 = max(ty1, 0);
-        ty2 = min(ty2, tiles - 1);
-        uint32_t px[PX];
-        if (ahead) {
-            const uint4 q = qnext;
-            px[0] = q.x & 0xffffu; px[1 % PX] = q.x >> 16; px[2 % PX] = q.y & 0xffffu; px[3 % PX] = q.y >> 16;
-            if (PX == 8) { px[4 % PX] = q.z & 0xffffu; px[5 % PX] = q.z >> 16; px[6 % PX] = q.w & 0xffffu; px[7 % PX] = q.w >> 16; }
-            const uint32_t yn = yy + row_step;
-            if (it + 1 < rows && (int64_t)yn < h) qnext = fetch(yn);
-        } else if (PX == 8 && n == 8) {
-            const uint4 q = *reinterpret_cast<const uint4*>(img + y * pitch + x0);
-            px[0] = q.x & 0xffffu; px[1 % PX] = q.x >> 16; px[2 % PX] = q.y & 0xffffu; px[3 % PX] = q.y >> 16;
-            px[4 % PX] = q.z & 0xffffu; px[5 % PX] = q.z >> 16; px[6 % PX] = q.w & 0xffffu; px[7 % PX] = q.w >> 16;
-        } else if (PX == 4 && n == 4) {
-            const uint2 q = *reinterpret_cast<const uint2*>(img + y * pitch + x0);
-            px[0] = q.x & 0xffffu; px[1 % PX] = q.x >> 16; px[2 % PX] = q.y & 0xffffu; px[3 % PX] = q.y >> 16;
-        } else {
+    // Round 6: ALL of the workgroup's rounds asked for up front (the launch hands a tiled workgroup at most INTERP_ROUNDS of them): with one
+    // round ahead a lane had one 16-byte load in flight -- 20 KB a CU, 2.6 TB/s at best: without its gathers, stores and arithmetic the
+    // kernel still took 63 us for 67 Mpx (tools/interp_harness.py, profiles/r06_sweeps.txt).
+    uint4 qs[INTERP_ROUNDS];
 #pragma unroll
-            for (int j = 0; j < PX; ++j) px[j] = j < n ? img[y * pitch + x0 + j] : 0;
-        }
+    for (int k = 0; k < INTERP_ROUNDS; ++k) {
+        const uint32_t yk = row0 + (uint32_t)k * row_step;
+        qs[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (ahead && k < rows && (int64_t)yk < h) qs[k] = fetch(yk);
+    }
+    // the rest of a round once the pixels' LUT entries are here: blend, store, the select's counts
+    auto finish = [&](int64_t y, int n, int ty1, int ty2, float ya, float ya1, const uint32_t (&px)[PX], const uint2 (&q4)[PX]) {
         uint32_t out[PX];
-        uint2 q4[PX];                                        // T2: the pixel's four entries are one 8-byte load: [tile row 0: columns 0, 1 | tile row 1: columns 0, 1]
-        if (T2) {
-#pragma unroll
-            for (int j = 0; j < PX; ++j) q4[j] = *reinterpret_cast<const uint2*>(lut + (int64_t)px[j] * 4);
-        }
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
             uint32_t l11, l12, l21, l22;
@@ -1284,6 +1251,94 @@ template <int PX, bool COUNT, bool T2> __global__ __launch_bounds__(256) void k_
                 }
             }
         }
+    };
+    auto row_terms = [&](int64_t y, int& ty1, int& ty2, float& ya, float& ya1) {
+        const float tyf = (float)(int)y * inv_th - 0.5f;
+        ty1 = (int)floorf(tyf);
+        ty2 = ty1 + 1;
+        ya = tyf - (float)ty1;
+        ya1 = 1.0f - ya;
+        ty1 = max(ty1, 0);
+        ty2 = min(ty2, tiles - 1);
+    };
+    if (T2 && ahead) {
+        // Round 6: the gathers of the NEXT round are in flight while this one is blended (two sets of entry registers): a round's chain was
+        // pixels -> 8 gathers -> wait -> blend, four times over; one round trip to L2 per round was the kernel (tools/interp_harness.py:
+        // without its gathers 87 us against 152 for 67 Mpx, the blend's arithmetic 2.5 of them).
+        int rounds_here = 0;
+        if ((int64_t)row0 < h) rounds_here = (int)min((int64_t)rows, (h - (int64_t)row0 + row_step - 1) / row_step);
+        auto issue = [&](int k, uint2 (&q)[PX]) {
+            uint4 v = qs[0];                                   // (picked by compares: an indexed register array would go to scratch)
+#pragma unroll
+            for (int kk = 1; kk < INTERP_ROUNDS; ++kk)
+                if (k == kk) v = qs[kk];
+            uint32_t p[PX];
+            p[0] = v.x & 0xffffu; p[1 % PX] = v.x >> 16; p[2 % PX] = v.y & 0xffffu; p[3 % PX] = v.y >> 16;
+            if (PX == 8) { p[4 % PX] = v.z & 0xffffu; p[5 % PX] = v.z >> 16; p[6 % PX] = v.w & 0xffffu; p[7 % PX] = v.w >> 16; }
+#pragma unroll
+            for (int j = 0; j < PX; ++j) q[j] = *reinterpret_cast<const uint2*>(lut + (int64_t)p[j] * 4);
+        };
+        auto round_of = [&](int k, const uint2 (&q)[PX]) {
+            const int64_t y = row0 + (uint32_t)k * row_step;
+            int ty1, ty2;
+            float ya, ya1;
+            row_terms(y, ty1, ty2, ya, ya1);
+            const uint32_t none[PX] = {};
+            finish(y, PX, ty1, ty2, ya, ya1, none, q);
+        };
+        uint2 qa[PX], qb[PX];
+        if (rounds_here > 0) issue(0, qa);
+        for (int it = 0; it < rounds_here; it += 2) {
+            if (it + 1 < rounds_here) issue(it + 1, qb);
+            round_of(it, qa);
+            if (it + 1 < rounds_here) {
+                if (it + 2 < rounds_here) issue(it + 2, qa);
+                round_of(it + 1, qb);
+            }
+        }
+    } else
+    for (int it = 0; it < rows; ++it) {
+        uint32_t yy;
+        if (tiled) {
+            yy = row0 + (uint32_t)it * row_step;
+            if (x0 >= w) break;
+        } else {
+            const uint32_t flat = (blockIdx.x * (uint32_t)rows + (uint32_t)it) * 256u + threadIdx.x;
+            yy = flat / nv;
+            x0 = (int64_t)(flat - yy * nv) * PX;
+            column_terms(x0);
+        }
+        const int64_t y = yy;
+        if (y >= h) break;
+        const int n = (int)min((int64_t)PX, w - x0);
+        int ty1, ty2;
+        float ya, ya1;
+        row_terms(y, ty1, ty2, ya, ya1);
+        uint32_t px[PX];
+        if (ahead) {
+            uint4 q = qs[0];                                   // (picked by compares: an indexed register array would go to scratch)
+#pragma unroll
+            for (int k = 1; k < INTERP_ROUNDS; ++k)
+                if (it == k) q = qs[k];
+            px[0] = q.x & 0xffffu; px[1 % PX] = q.x >> 16; px[2 % PX] = q.y & 0xffffu; px[3 % PX] = q.y >> 16;
+            if (PX == 8) { px[4 % PX] = q.z & 0xffffu; px[5 % PX] = q.z >> 16; px[6 % PX] = q.w & 0xffffu; px[7 % PX] = q.w >> 16; }
+        } else if (PX == 8 && n == 8) {
+            const uint4 q = *reinterpret_cast<const uint4*>(img + y * pitch + x0);
+            px[0] = q.x & 0xffffu; px[1 % PX] = q.x >> 16; px[2 % PX] = q.y & 0xffffu; px[3 % PX] = q.y >> 16;
+            px[4 % PX] = q.z & 0xffffu; px[5 % PX] = q.z >> 16; px[6 % PX] = q.w & 0xffffu; px[7 % PX] = q.w >> 16;
+        } else if (PX == 4 && n == 4) {
+            const uint2 q = *reinterpret_cast<const uint2*>(img + y * pitch + x0);
+            px[0] = q.x & 0xffffu; px[1 % PX] = q.x >> 16; px[2 % PX] = q.y & 0xffffu; px[3 % PX] = q.y >> 16;
+        } else {
+#pragma unroll
+            for (int j = 0; j < PX; ++j) px[j] = j < n ? img[y * pitch + x0 + j] : 0;
+        }
+        uint2 q4[PX] = {};                                   // T2: the pixel's four entries are one 8-byte load: [tile row 0: columns 0, 1 | tile row 1: columns 0, 1]
+        if (T2) {
+#pragma unroll
+            for (int j = 0; j < PX; ++j) q4[j] = *reinterpret_cast<const uint2*>(lut + (int64_t)px[j] * 4);
+        }
+        finish(y, n, ty1, ty2, ya, ya1, px, q4);
     }
     if (COUNT) {
         if (window) {
