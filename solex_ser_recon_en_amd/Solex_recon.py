@@ -437,6 +437,16 @@ def _sharded_series(tasks, decoder, collected):
                 pending.append(done)
             post.jobs.put(functools.partial(post_job, i, options, disk_list, bounds, hdr, ready, done))
 
+    def placeholder_second(i):
+        """Scan i failed on THIS rank between its two exchanges: the other ranks are on their way into the reduction of the mosaic --
+        join them with an empty one (the scan is lost: this rank's failure word travels in the next exchange after pass A)."""
+        file, options = tasks[i]
+        rdr = file if hasattr(file, 'device_stack') else video_reader(file)
+        n_total, ih = int(rdr.FrameCount), int(max(rdr.Width, rdr.Height))
+        shifts = list(dict.fromkeys([options['ellipse_fit_shift'], 0] + list(options.get('shift_requested', options['shift']))))
+        dist.gather_columns(lambda out, k0: None, len(shifts), ih, dist.frame_block(n_total), n_total, bool(options['flip_x']), device,
+                            dst=options.get('_mosaic_to'))
+
     @contextlib.contextmanager
     def second_thread():
         rctx = _worker_context(device, 'read1')
@@ -461,7 +471,7 @@ def _sharded_series(tasks, decoder, collected):
     previous = bind_thread('scan', device)
     try:
         read_errors = dist.run_series(len(tasks), read_scan, two_readers=two_readers, second_thread=second_thread, before_verdict=posts_done,
-                                      device=device, also_failed=post_failed)
+                                      device=device, also_failed=post_failed, placeholder_second=placeholder_second if plain else None)
     finally:
         posts_done()
         if previous is not None:

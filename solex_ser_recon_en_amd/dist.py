@@ -103,6 +103,10 @@ class Sequencer:
                 self.done.add(key)
                 self._advance()
 
+    def is_done(self, key):
+        with self.cv:
+            return key in self.done
+
     def skip(self, *keys):
         with self.cv:
             self.done.update(keys)
@@ -141,13 +145,17 @@ def reading(scan_index):
     _tls.scan = scan_index
 
 
-def run_series(n_scans, read_scan, two_readers=True, second_thread=None, before_verdict=None, device=None, also_failed=None):
+def run_series(n_scans, read_scan, two_readers=True, second_thread=None, before_verdict=None, device=None, also_failed=None,
+               placeholder_second=None):
     """Drive a series of frame-sharded scans on this rank: read_scan(i) does scan i -- decode, pass A, exchange_frame_stats, fit, pass
     B, gather_columns, hand-over of the mosaic -- on the calling thread and raises what goes wrong.  two_readers: this thread takes
     the even scans, a second one (run inside the context manager second_thread(), which gives it its device and stream) the odd ones;
     their collectives go out in one order on every rank (Sequencer).  A failure of this rank travels in the next exchange after
     pass A and stops every rank at that scan (SeriesAborted); a scan that fails on every rank alike gives up its places in the
-    order.  before_verdict(): waited for after the last scan (the owner's post-processing threads), also_failed(): their failures.
+    order.  placeholder_second(i): what a rank does when ITS scan i fails between the two exchanges (pass B ran out of memory, say):
+    it still takes part in exchange 2, with an empty mosaic -- the other ranks are on their way into it -- and reports in the next
+    exchange after pass A; without the callback the place is given up, which is only right for a failure every rank runs into alike.
+    before_verdict(): waited for after the last scan (the owner's post-processing threads), also_failed(): their failures.
     At the end one word goes round
     (any_failed): -> the list of (scan index, exception) of this rank, with a RuntimeError appended when only another rank failed."""
     import contextlib
@@ -177,6 +185,13 @@ def run_series(n_scans, read_scan, two_readers=True, second_thread=None, before_
                         note(i, RuntimeError('this rank set the failure word in the exchange of scan %d' % i))
                 except BaseException as e:      # noqa: BLE001 -- reported to the caller; the series goes on to the exchange that tells the others
                     note(i, e)
+                    if placeholder_second is not None and series.seq.is_done(2 * i) and not series.seq.is_done(2 * i + second):
+                        try:
+                            placeholder_second(i)
+                        except SeriesAborted:
+                            go_on = False
+                        except BaseException as e2:      # noqa: BLE001
+                            note(i, e2)
                 finally:
                     reading(None)
                 # (the places of collectives this scan did not get to -- it failed on every rank alike, or the series stopped -- are

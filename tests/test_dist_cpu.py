@@ -218,6 +218,8 @@ def _pipelined_worker(rank, world, port, stacks, fit, shifts, fail, two_readers,
             stats[str(i)] = (total.numpy().copy(), mx.view(torch.int16).numpy().view(np.uint16).copy())
             if fail == ('all', i):
                 raise ValueError('scan %d: a fit that fails on every rank alike' % i)
+            if fail == ('between', i) and rank == world - 1:
+                raise MemoryError('scan %d: pass B ran out of memory on this rank only' % i)
             flip = bool(i & 1)
             local_disks = np.stack(orc.extract_columns(orc.SerReader(frames, k0, k1), fit, shifts))[:, :, k0:k1]
 
@@ -230,8 +232,13 @@ def _pipelined_worker(rank, world, port, stacks, fit, shifts, fail, two_readers,
             if rank == owner:
                 owned[str(i)] = full.contiguous().view(torch.int16).numpy().view(np.uint16)
 
+        def placeholder_second(i):                           # this rank's scan i failed between the exchanges: an empty mosaic
+            n = stacks[i].shape[0]
+            ih = max(stacks[i].shape[1], stacks[i].shape[2])
+            dist.gather_columns(lambda out, k0: None, len(shifts), ih, dist.frame_block(n), n, bool(i & 1), torch.device('cpu'), dst=dist.scan_owner(i))
+
         before = dist.counters['collectives']
-        errors = dist.run_series(len(stacks), read_scan, two_readers=two_readers)
+        errors = dist.run_series(len(stacks), read_scan, two_readers=two_readers, placeholder_second=placeholder_second)
         np.savez(os.path.join(out_dir, 'owned%d.npz' % rank), **owned)
         np.savez(os.path.join(out_dir, 'sums%d.npz' % rank), **{k: v[0] for k, v in stats.items()})
         np.savez(os.path.join(out_dir, 'maxs%d.npz' % rank), **{k: v[1] for k, v in stats.items()})
@@ -284,12 +291,13 @@ def test_pipelined_series_two_collectives_per_scan_and_one_rank_products(tmp_pat
         np.testing.assert_array_equal(full, want[:, :, ::-1] if i & 1 else want)
 
 
-@pytest.mark.parametrize('world,fail', [(2, ('rank', 3)), (3, ('rank', 0)), (8, ('rank', 4)), (3, ('all', 2))])
+@pytest.mark.parametrize('world,fail', [(2, ('rank', 3)), (3, ('rank', 0)), (8, ('rank', 4)), (3, ('all', 2)), (3, ('between', 1)), (8, ('between', 3))])
 def test_pipelined_series_stops_on_every_rank_together(tmp_path, world, fail):
     """A rank that cannot read its share of scan j sets the failure word in that scan's exchange: EVERY rank leaves the series there
     (its own error on the failing rank, 'another rank failed' on the others), nobody is left waiting in a collective, and what was
     reduced before is intact.  A scan that fails on every rank alike (a fit on the all-reduced mean) gives up its mosaic's place in the
-    order; the word then travels in the next exchange."""
+    order; the word then travels in the next exchange.  A rank whose scan fails BETWEEN the two exchanges (pass B out of memory) joins
+    the reduction of the mosaic with an empty one instead of leaving the others waiting in it, then reports."""
     stacks, fit, shifts = _series_inputs(6)
     mp.spawn(_pipelined_worker, args=(world, _free_port(), stacks, fit, shifts, fail, True, str(tmp_path)), nprocs=world, join=True)
     verdicts = _verdicts(tmp_path, world)
@@ -299,13 +307,17 @@ def test_pipelined_series_stops_on_every_rank_together(tmp_path, world, fail):
             assert v['collectives'] <= 2 * len(stacks) + 1
             if r != world - 1:
                 assert any('another rank failed' in msg for _, _, msg in v['errors']), (r, v)
-        else:
+        elif fail[0] == 'all':
             assert any('fails on every rank alike' in msg for _, _, msg in v['errors']), (r, v)
+        else:       # one rank failed BETWEEN the exchanges: it took part in the mosaic's reduction with an empty one, then said so
+            assert any(('ran out of memory' if r == world - 1 else 'another rank failed') in msg for _, _, msg in v['errors']), (r, v)
     assert len({v['collectives'] for v in verdicts}) == 1                  # the same collectives on every rank: none waited alone
     for r in range(world):
         got = np.load(str(tmp_path / ('owned%d.npz' % r)))
         for key in got.files:                                              # mosaics reduced before the stop are the oracle's
             i = int(key)
             want = np.stack(orc.extract_columns(orc.SerReader(stacks[i]), fit, shifts))
+            if fail[0] == 'between' and i == fail[1]:
+                continue                                                   # the lost scan: its owner holds a mosaic with a hole
             np.testing.assert_array_equal(got[key], want[:, :, ::-1] if i & 1 else want)
-            assert fail[0] == 'all' or i < fail[1]
+            assert fail[0] != 'rank' or i < fail[1]
