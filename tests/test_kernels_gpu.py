@@ -214,6 +214,32 @@ def test_band_kernel_equals_the_general_kernel(ops, monkeypatch, n, h, w, bits, 
             assert [tuple(e) for e in mm.cpu().numpy().astype(np.int64)] == [(int(p.min()), int(p.max())) for p in want]
 
 
+@pytest.mark.parametrize('shifts', [[10, 0], list(range(-10, 11))])
+def test_band_kernel_into_rows_that_are_not_16_byte_aligned(ops, monkeypatch, shifts):
+    """The band kernel's 16-byte stores need rows on 16-byte boundaries; a caller's buffer whose row pitch is odd takes its pixel-by-pixel
+    write-out (and the extrema from there): same disks as k_extract, the buffer's padding columns untouched."""
+    from solex_ser_recon_en_amd import hostmath
+    rng = np.random.default_rng(len(shifts))
+    n, h, w = 150, 40, 700
+    frames = rng.integers(0, 65536, (n, h, w)).astype(np.uint16)
+    y = np.arange(w)
+    curve = h / 2 + 0.004 * (y - w / 2)
+    fit = np.stack([np.floor(curve), curve - np.floor(curve), y.astype(float), curve], axis=1)
+    ind_l, lw, rw = hostmath.column_plan(fit, shifts, w, h)
+    stack = dev(frames)
+    outs = []
+    for general in (True, False):
+        if general:
+            monkeypatch.setenv('SHG_EXT_GENERAL', '1')
+        else:
+            monkeypatch.delenv('SHG_EXT_GENERAL')
+        buf = torch.full((len(shifts), w, n + 3), 0x5a5a, dtype=torch.int32, device='cuda').to(torch.uint16)
+        ops.extract_columns(stack, ind_l, lw, rw, out=buf[:, :, :n])
+        outs.append(host(buf))
+    np.testing.assert_array_equal(outs[1], outs[0])
+    assert (outs[1][:, :, n:] == 0x5a5a).all()
+
+
 def test_pass_a_in_the_lane_waits_for_the_stack_its_caller_is_still_writing(ops):
     """With a frame-pass lane set, pass A runs on another stream than its caller's: it must still see a stack that the caller's
     stream has only queued the writing of (no synchronisation in between)."""
