@@ -60,16 +60,29 @@ __device__ __forceinline__ void hist_add(uint32_t* hist, bool valid, uint32_t di
     if (valid && digit != d0) atomicAdd(&hist[digit], 1u);
 }
 
-// Inclusive prefix sum across the wave.  The lane number is hidden from the optimiser (see block_sum): the six source-lane
-// addresses and their comparisons, hoisted out of this function as loop invariants, otherwise sit in registers from the first
-// select to the last.
-template <typename T>
-__device__ __forceinline__ T wave_inclusive_scan(T v) {
+// Inclusive prefix sum across the wave, without LDS (round 6: DPP row shifts inside each row of 16 lanes -- a lane without a source
+// adds 0 --, then the totals of the rows before a lane's own from scalar registers).  The ds_bpermute ladder it replaces was six
+// dependent LDS round trips.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    v += dpp_or_zero<0x111>(v);          // row_shr:1
+    v += dpp_or_zero<0x112>(v);          // row_shr:2
+    v += dpp_or_zero<0x114>(v);          // row_shr:4
+    v += dpp_or_zero<0x118>(v);          // row_shr:8
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), t1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31),
+                   t2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
+    const int lane = threadIdx.x & 63;
+    return v + (lane >= 16 ? t0 : 0u) + (lane >= 32 ? t1 : 0u) + (lane >= 48 ? t2 : 0u);
+}
+__device__ __forceinline__ int64_t wave_inclusive_scan(int64_t v) {          // (the radix select's counts: 64 bits, the rare path)
     int self = threadIdx.x & 63;
     asm volatile("" : "+v"(self));
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const T o = __shfl(v, self - d);
+        const int64_t o = __shfl(v, self - d);
         if (self >= d) v += o;
     }
     return v;
@@ -256,14 +269,28 @@ __device__ __forceinline__ bool select2_buckets(ValFn val, int n, int64_t rank_l
     return false;
 }
 
+// The sum of a double over the wave, in every lane, without LDS (round 6): four DPP steps inside each row of 16 lanes (quad
+// butterflies, then the mirrored half and the mirrored row: every lane ends with its row's sum), then the four rows' sums read into
+// scalar registers and added.  The ds_bpermute butterfly it replaces was six dependent LDS round trips per value (~1000 cycles a
+// call): k_rowpair_stats' two block sums were 38 of its 300 us at C4 (profiles/r06_sweeps.txt).  The tree's shape -- and with it the
+// last bits of a sum -- differs from the butterfly's; it is as fixed as that one was.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_f64<0xB1>(v);               // quad_perm [1, 0, 3, 2]
+    v += dpp_f64<0x4E>(v);               // quad_perm [2, 3, 0, 1]
+    v += dpp_f64<0x141>(v);              // row_half_mirror
+    v += dpp_f64<0x140>(v);              // row_mirror
+    auto row = [&](int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l)); };
+    return (row(0) + row(16)) + (row(32) + row(48));
+}
+
 __device__ __forceinline__ double block_sum(double v, double* red) {
-    // The butterflies' lane addresses are formed anew in every call: hoisted out as common subexpressions they stay live
-    // across the whole kernel, and under k_rowpair_stats' 64-register cap four of them were spilled to scratch (16 bytes
-    // written and read back per lane, 60 MB per 21-disk launch).  The empty asm hides the lane number from that hoisting.
-    int self = threadIdx.x & 63;
-    asm volatile("" : "+v"(self));
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl(v, self ^ d);
+    v = wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -272,13 +299,8 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 
 // two sums in one round of barriers (red: 8 doubles)
 __device__ __forceinline__ void block_sum2(double& a, double& b, double* red) {
-    int self = threadIdx.x & 63;
-    asm volatile("" : "+v"(self));
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        a += __shfl(a, self ^ d);
-        b += __shfl(b, self ^ d);
-    }
+    a = wave_sum(a);
+    b = wave_sum(b);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = b; }
     __syncthreads();
