@@ -427,13 +427,12 @@ __global__ __launch_bounds__(1024) void k_hist_reduce(const HistReduceArgs kargs
     }
     *reinterpret_cast<uint2*>(hist + (int64_t)tile * HIST16 + 2 * d) = make_uint2(c0, c1);
     uint32_t t = c0 + c1;
-#pragma unroll
-    for (int k = 16; k >= 1; k >>= 1) t += __shfl_xor(t, k);
+    t = shg::sum_of_32_lanes(t);
     if ((lane & 31) == 0) chunk_tile[tile * 1024 + (d >> 5)] = t;
     int kept = (int)min(c0, (uint32_t)clip) + (int)min(c1, (uint32_t)clip);
     int over = (int)(c0 + c1) - kept;
-#pragma unroll
-    for (int k = 32; k >= 1; k >>= 1) { kept += __shfl_xor(kept, k); over += __shfl_xor(over, k); }
+    kept = shg::wave_sum(kept);
+    over = shg::wave_sum(over);
     if (lane == 0) { wsum[0][wave] = kept; wsum[1][wave] = over; }
     __syncthreads();
     if (tid < 2) {
@@ -519,9 +518,7 @@ template <int BITS> __global__ __launch_bounds__(256) void k_hist_reduce_sat(con
         const int b0 = 8 * q + (HIST16 / KF) * k;
         *reinterpret_cast<uint2*>(hist8 + (int64_t)tile * HIST16 + b0) = make_uint2(o[0], o[1]);
         int t = kept;
-        t += __shfl_xor(t, 1);
-        t += __shfl_xor(t, 2);
-        t += __shfl_xor(t, 4);
+        t = shg::sum_of_8_lanes(t);
         if ((lane & 7) == 0) chunk_tile[tile * 1024 + (b0 >> 6)] = (uint32_t)t;
 #pragma unroll
         for (int d = 8; d <= 32; d <<= 1) t += __shfl_xor(t, d);
@@ -595,11 +592,7 @@ __device__ __forceinline__ void hist_rank_job(const uint32_t* __restrict__ hist,
         local -= border_n[tid];
     }
     int64_t incl = local;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int64_t o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
+    incl = shg::wave_scan(incl);
     if (lane == 63) wtot[wave] = incl;
     __syncthreads();
     for (int i = 0; i < wave; ++i) incl += wtot[i];
@@ -616,11 +609,7 @@ __device__ __forceinline__ void hist_rank_job(const uint32_t* __restrict__ hist,
     int64_t c = border ? -(int64_t)border_n[lane] : 0;
     for (int t = 0; t < ntiles; ++t) c += hist[(int64_t)t * HIST16 + chunk * 64 + lane];
     int64_t inc2 = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int64_t o = __shfl_up(inc2, d);
-        if (lane >= d) inc2 += o;
-    }
+    inc2 = shg::wave_scan(inc2);
     if (below + inc2 - c <= rank && rank < below + inc2) *out = (double)(chunk * 64 + lane);
 }
 
@@ -663,11 +652,8 @@ __device__ __forceinline__ void hist_rank_top_job(const uint8_t* __restrict__ hi
         local -= border_n[tid];
     }
     int incl = local, incl_with = with;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(incl, d), ow = __shfl_up(incl_with, d);
-        if (lane >= d) { incl += o; incl_with += ow; }
-    }
+    incl = shg::wave_scan(incl);
+    incl_with = shg::wave_scan(incl_with);
     if (lane == 63) { wtot[0][wave] = incl; wtot[1][wave] = incl_with; }
     __syncthreads();
     for (int i = 0; i < wave; ++i) { incl += wtot[0][i]; incl_with += wtot[1][i]; }
@@ -704,11 +690,8 @@ __device__ __forceinline__ void hist_rank_top_job(const uint8_t* __restrict__ hi
     }
     const int c = border ? cw - border_n[63 - lane] : cw;
     int inc2 = c, inc2_with = cw;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(inc2, d), ow = __shfl_up(inc2_with, d);
-        if (lane >= d) { inc2 += o; inc2_with += ow; }
-    }
+    inc2 = shg::wave_scan(inc2);
+    inc2_with = shg::wave_scan(inc2_with);
     const bool mine = above + inc2 - c < K && K <= above + inc2;
     if (!border) {
         if (mine) *out = (double)bin;
@@ -785,8 +768,8 @@ template <bool SAT, bool ALLT> __global__ __launch_bounds__(1024) void k_tile_lu
                 kept = lane < b ? se[(tile * 32 + lane) * 2] : 0;
                 over = se[(tile * 32 + lane) * 2 + 1];
             }
-#pragma unroll
-            for (int k = 32; k >= 1; k >>= 1) { kept += __shfl_xor(kept, k); over += __shfl_xor(over, k); }
+            kept = shg::wave_sum(kept);
+            over = shg::wave_sum(over);
             if (lane == 0) { s_before = kept; s_excess = SAT ? kargs.tile_area - over : over; }
         }
         uint2 hh;
@@ -809,11 +792,7 @@ template <bool SAT, bool ALLT> __global__ __launch_bounds__(1024) void k_tile_lu
         }
         const int local = c0 + c1;
         int incl = local;
-#pragma unroll
-        for (int k = 1; k < 64; k <<= 1) {
-            const int o = __shfl_up(incl, k);
-            if (lane >= k) incl += o;
-        }
+        incl = shg::wave_scan(incl);
         if (lane == 63) wsum[wave] = incl;
         __syncthreads();
         int base = 0;
@@ -884,8 +863,7 @@ __global__ __launch_bounds__(1024) void k_tile_lut(const uint32_t* __restrict__ 
     }
     // workgroup total of the clipped excess
     int v = clipped;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    v = shg::wave_sum(v);
     if (lane == 0) wsum[wave] = v;
     __syncthreads();
     if (tid == 0) {
@@ -919,11 +897,7 @@ __global__ __launch_bounds__(1024) void k_tile_lut(const uint32_t* __restrict__ 
     for (int j = 0; j < PER; ++j) local += bins[j];
     // exclusive scan of `local` across the workgroup
     int incl = local;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
+    incl = shg::wave_scan(incl);
     __syncthreads();
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
@@ -970,8 +944,7 @@ __global__ __launch_bounds__(1024) void k_tile_lut16_lds(const uint32_t* __restr
         }
     }
     int v = clipped;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    v = shg::wave_sum(v);
     if (lane == 0) wsum[wave] = v;
     __syncthreads();
     if (tid == 0) {
@@ -1003,11 +976,7 @@ __global__ __launch_bounds__(1024) void k_tile_lut16_lds(const uint32_t* __restr
         local += c;
     }
     int incl = local;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
+    incl = shg::wave_scan(incl);
     __syncthreads();
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
@@ -1342,8 +1311,7 @@ template <int PX, bool COUNT, bool T2> __global__ __launch_bounds__(256) void k_
     }
     if (COUNT) {
         if (window) {
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(vmax, d); vmax = o > vmax ? o : vmax; }
+            vmax = shg::wave_fold_u32(vmax, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
             if ((threadIdx.x & 63) == 0) wmax_s[threadIdx.x >> 6] = vmax;
         }
         __syncthreads();
@@ -1419,11 +1387,7 @@ __device__ __forceinline__ void pick_digit(const uint32_t* __restrict__ hist, in
         for (int k = 0; k < SLOTS; ++k) c += v[k];
     }
     int64_t incl = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int64_t o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
+    incl = shg::wave_scan(incl);
     if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
     for (int i = 0; i < wave; ++i) incl += wave_tot[i];
@@ -1484,11 +1448,7 @@ __global__ __launch_bounds__(1024) void k_select16_pass(const SelectPassArgs kar
             for (int k = 0; k < SEL_SLOTS; ++k) c += v[k];
         }
         int64_t incl = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int64_t o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
+        incl = shg::wave_scan(incl);
         if (lane == 63) wave_tot[wave] = incl;
         __syncthreads();
         for (int i = 0; i < wave; ++i) incl += wave_tot[i];
@@ -1655,8 +1615,7 @@ __global__ __launch_bounds__(1024) void k_chunk_sums(const uint32_t* __restrict_
     const int bin = blockIdx.x * 1024 + threadIdx.x;
     uint32_t t = 0;
     for (int k = 0; k < ntiles; ++k) t += hist[(int64_t)k * HIST16 + bin];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+    t = shg::wave_sum(t);
     if ((threadIdx.x & 63) == 0) chunk[bin >> 6] = t;
 }
 

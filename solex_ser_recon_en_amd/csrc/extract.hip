@@ -574,11 +574,8 @@ __global__ __launch_bounds__(64 * BAND_NW) void k_extract_band(const BandArgs a)
             }
         }
         if (a.mm) {
-#pragma unroll
-            for (int e = 32; e >= 1; e >>= 1) {
-                lo = pk_min_u16(lo, __shfl_xor(lo, e));
-                hi = pk_max_u16(hi, __shfl_xor(hi, e));
-            }
+            lo = shg::wave_fold_u32(lo, [](uint32_t x, uint32_t y) { return pk_min_u16(x, y); });
+            hi = shg::wave_fold_u32(hi, [](uint32_t x, uint32_t y) { return pk_max_u16(x, y); });
             const uint32_t l16 = min(lo & 0xffffu, lo >> 16), h16 = max(hi & 0xffffu, hi >> 16);
             if (lane == 0 && h16 >= l16) {                    // this workgroup stored at least one value of the plane
                 // one atomic pair per wave and plane into one of 64 slots (same-address atomics serialise chip-wide; k_fold_minmax folds them)

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <type_traits>
 #include "../../include/shg_hip.h"
 
 namespace shg {
@@ -135,6 +136,78 @@ constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kCUs = 256;          // MI355X
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+// A 32-bit value folded over the wave with an associative, commutative `op` (min, max, packed min / max, or, add of integers: the order
+// does not matter), the result in every lane -- without LDS: four DPP steps inside each row of 16 lanes (quad butterflies, the mirrored
+// half, the mirrored row), then the four rows' results through scalar registers.  A __shfl_xor ladder is six DEPENDENT ds_bpermute round
+// trips (~1000 cycles at the end of a workgroup's chain; round 6 found two of them to be 13 % of k_rowpair_stats).
+template <typename Op>
+__device__ __forceinline__ uint32_t wave_fold_u32(uint32_t v, Op op) {
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false));      // quad_perm [1, 0, 3, 2]
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false));      // quad_perm [2, 3, 0, 1]
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false));     // row_half_mirror
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false));     // row_mirror
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16),
+                   r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return op(op(r0, r1), op(r2, r3));
+}
+
+// Integer sums over the wave through the same DPP steps (exact whatever the order): the total in every lane; the total of a lane's
+// group of 8 lanes; the totals of the two 32-lane halves; and the inclusive prefix sum (row shifts inside a row of 16 -- a lane without a
+// source adds 0 --, then the totals of the rows before the lane's own from scalar registers).  Workgroups are one-dimensional: a wave
+// is 64 consecutive threads.
+template <int CTRL>
+__device__ __forceinline__ int dpp_get(int v, int fallback) {                 // lane's source under CTRL, `fallback` where it has none
+    return __builtin_amdgcn_update_dpp(fallback, v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int wave_sum(int v) {
+    v += dpp_get<0xB1>(v, v);
+    v += dpp_get<0x4E>(v, v);
+    v += dpp_get<0x141>(v, v);
+    v += dpp_get<0x140>(v, v);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return (uint32_t)wave_sum((int)v); }
+__device__ __forceinline__ int sum_of_8_lanes(int v) {                       // lanes 8 g .. 8 g + 7 all get their group's total
+    v += dpp_get<0xB1>(v, v);
+    v += dpp_get<0x4E>(v, v);
+    v += dpp_get<0x141>(v, v);
+    return v;
+}
+__device__ __forceinline__ uint32_t sum_of_32_lanes(uint32_t u) {            // lanes 0 .. 31 get their half's total, lanes 32 .. 63 theirs
+    int v = (int)u;
+    v += dpp_get<0xB1>(v, v);
+    v += dpp_get<0x4E>(v, v);
+    v += dpp_get<0x141>(v, v);
+    v += dpp_get<0x140>(v, v);
+    const int lo = __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16), hi = __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+    return (uint32_t)((threadIdx.x & 32) ? hi : lo);
+}
+__device__ __forceinline__ int wave_scan(int v) {
+    v += dpp_get<0x111>(v, 0);           // row_shr:1
+    v += dpp_get<0x112>(v, 0);           // row_shr:2
+    v += dpp_get<0x114>(v, 0);           // row_shr:4
+    v += dpp_get<0x118>(v, 0);           // row_shr:8
+    const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+    const int lane = threadIdx.x & 63;
+    return v + (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0);
+}
+__device__ __forceinline__ int64_t wave_scan(int64_t v) {
+    auto shifted = [&](auto ctrl) {
+        const int lo = dpp_get<decltype(ctrl)::value>((int)(uint32_t)v, 0), hi = dpp_get<decltype(ctrl)::value>((int)(v >> 32), 0);
+        return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+    };
+    v += shifted(std::integral_constant<int, 0x111>{});
+    v += shifted(std::integral_constant<int, 0x112>{});
+    v += shifted(std::integral_constant<int, 0x114>{});
+    v += shifted(std::integral_constant<int, 0x118>{});
+    auto at = [&](int l) {
+        return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l));
+    };
+    const int64_t t0 = at(15), t1 = at(31), t2 = at(47);
+    const int lane = threadIdx.x & 63;
+    return v + (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0);
+}
 
 // BORDER_REFLECT_101 index (gfedcb|abcdefgh|gfedcba), valid for any i
 __host__ __device__ __forceinline__ int64_t reflect101(int64_t i, int64_t n) {
