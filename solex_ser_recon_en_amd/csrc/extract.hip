@@ -639,12 +639,8 @@ __global__ __launch_bounds__(64) void k_fold_minmax(const FoldMinmaxArgs kargs) 
         return;
     }
     uint32_t a = slots[((int64_t)blockIdx.x * 64 + threadIdx.x) * 2], b = slots[((int64_t)blockIdx.x * 64 + threadIdx.x) * 2 + 1];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t oa = __shfl_xor(a, d), ob = __shfl_xor(b, d);
-        a = oa > a ? oa : a;
-        b = ob > b ? ob : b;
-    }
+    a = shg::wave_fold_u32(a, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
+    b = shg::wave_fold_u32(b, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
     if (threadIdx.x == 0) { out[blockIdx.x * 2] = 0xffffu - a; out[blockIdx.x * 2 + 1] = b; }
 }
 

@@ -203,8 +203,7 @@ __global__ __launch_bounds__(256) void k_limb_blur(const LimbBlurArgs kargs) {
         const int oy = y0 - hl + r, ox = x0 - hl + c;                    // the tile's own pixels: np.sum(image)
         if (r >= hl && r < hl + BT && c >= hl && c < hl + BT && oy < sh && ox < sw) own += s;
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) own += __shfl_xor(own, d);
+    own = shg::wave_sum((uint64_t)own);
     if ((tid & 63) == 0) wsum[tid >> 6] = own;
     const int n_arrays = k == 5 ? 1 : 2;
     for (int a = 0; a < n_arrays; ++a) {
@@ -228,11 +227,7 @@ __global__ __launch_bounds__(256) void k_limb_blur(const LimbBlurArgs kargs) {
             if (a == 0) my_min = s;
         }
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t o = __shfl_xor(my_min, d);
-        my_min = o < my_min ? o : my_min;
-    }
+    my_min = shg::wave_fold_u32(my_min, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
     if ((tid & 63) == 0) wmin[tid >> 6] = my_min;
     __syncthreads();
     if (tid == 0) {
@@ -260,12 +255,7 @@ __device__ __forceinline__ void wave_pick(const uint32_t* __restrict__ fine, con
         c[j] = __hip_atomic_load(&coarse[lane * 4 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         local += c[j];
     }
-    int64_t incl = local;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int64_t o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
+    int64_t incl = shg::wave_scan((int64_t)local);
     int64_t excl = incl - local;
     int chunk = -1;
     int64_t base = 0;
@@ -281,12 +271,7 @@ __device__ __forceinline__ void wave_pick(const uint32_t* __restrict__ fine, con
     chunk = __shfl(chunk, src);
     base = __shfl(base, src);
     const int64_t f = lane < per ? (int64_t)__hip_atomic_load(&fine[chunk * per + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    int64_t fi = f;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int64_t o = __shfl_up(fi, d);
-        if (lane >= d) fi += o;
-    }
+    int64_t fi = shg::wave_scan((int64_t)f);
     const int64_t fe = base + fi - f;
     const bool mine = lane < per && fe <= rank && rank < fe + f;
     const unsigned long long who = __ballot(mine);
@@ -423,8 +408,7 @@ __global__ __launch_bounds__(256) void k_limb_select1(const LimbSelect1Args karg
             const double bl = ((double)vk[i] * kUnit) * p.scale[2];
             if (bl < very_bright) { const unsigned long long kk = f64_key(bl); hi = kk > hi ? kk : hi; }
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(hi, d); hi = o > hi ? o : hi; }
+        hi = shg::wave_max((uint64_t)hi);
         if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = hi;
         __syncthreads();
     }
@@ -789,8 +773,7 @@ __global__ __launch_bounds__(256) void k_limb_emit(const LimbEmitArgs kargs) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int before = 0;
     for (int e = threadIdx.x; e < y * tiles_x; e += 256) before += row_counts[e];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
+    before = shg::wave_sum(before);
     if (lane == 0) part[wave] = before;
     __syncthreads();
     if (threadIdx.x == 0) base = part[0] + part[1] + part[2] + part[3];

@@ -54,12 +54,8 @@ __global__ __launch_bounds__(256) void k_row_argmin(const uint16_t* __restrict__
         const uint32_t v = row[x];
         if (v < best) { best = v; best_i = (int32_t)(x - x0); }
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t ov = __shfl_xor(best, d);
-        const int32_t oi = __shfl_xor(best_i, d);
-        if (ov < best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
-    }
+    // (the smallest value, the lowest index among equals: the minimum of value << 32 | index)
+    best_i = (int32_t)(uint32_t)shg::wave_min(((uint64_t)best << 32) | (uint32_t)best_i);
     if (lane == 0) out[y] = best_i;
 }
 
@@ -72,8 +68,7 @@ __global__ __launch_bounds__(256) void k_row_mean(const uint16_t* __restrict__ i
     const uint16_t* row = img + y * w;
     uint64_t s = 0;
     for (int64_t x = lane; x < w; x += 64) s += row[x];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    s = shg::wave_sum(s);
     if (lane == 0) out[y] = (double)s / (double)w;
 }
 
@@ -218,8 +213,7 @@ template <int MODE> __global__ __launch_bounds__(256) void k_blur_reduce(const B
         if (MODE == 0) {
             uint64_t acc = 0;
             for (int x = lane; x < w; x += 64) acc += (uint64_t)blurred(x);
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+            acc = shg::wave_sum(acc);
             if (lane == 0) means[y] = (double)acc / (double)w;
         } else {
             uint32_t best = 0xffffffffu, sbest = 0xffffffffu;
@@ -233,13 +227,9 @@ template <int MODE> __global__ __launch_bounds__(256) void k_blur_reduce(const B
                     if (v < best) { best = v; best_i = x - x0; }
                 }
             }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const uint32_t ov = __shfl_xor(best, d), osv = __shfl_xor(sbest, d);
-                const int32_t oi = __shfl_xor(best_i, d), osi = __shfl_xor(sbest_i, d);
-                if (ov < best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
-                if (osv < sbest || (osv == sbest && osi < sbest_i)) { sbest = osv; sbest_i = osi; }
-            }
+            // (the smallest value, the lowest index among equals: the minimum of value << 32 | index)
+            best_i = (int32_t)(uint32_t)shg::wave_min(((uint64_t)best << 32) | (uint32_t)best_i);
+            sbest_i = (int32_t)(uint32_t)shg::wave_min(((uint64_t)sbest << 32) | (uint32_t)sbest_i);
             if (lane == 0) { arg_blur[y] = best_i; arg_sharp[y] = sbest_i; }
         }
     }

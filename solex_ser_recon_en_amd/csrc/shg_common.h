@@ -152,6 +152,28 @@ __device__ __forceinline__ uint32_t wave_fold_u32(uint32_t v, Op op) {
     return op(op(r0, r1), op(r2, r3));
 }
 
+// The same for a 64-bit value (both halves travel together): sums of 64-bit integers, the minimum / maximum of order-preserving keys,
+// an arg-min as the minimum of (value << 32 | index).
+template <typename Op>
+__device__ __forceinline__ uint64_t wave_fold_u64(uint64_t v, Op op) {
+    auto step = [&](auto ctrl) {
+        const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, decltype(ctrl)::value, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp((int)(v >> 32), (int)(v >> 32), decltype(ctrl)::value, 0xf, 0xf, false);
+        v = op(v, ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+    };
+    step(std::integral_constant<int, 0xB1>{});
+    step(std::integral_constant<int, 0x4E>{});
+    step(std::integral_constant<int, 0x141>{});
+    step(std::integral_constant<int, 0x140>{});
+    auto at = [&](int l) {
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    };
+    return op(op(at(0), at(16)), op(at(32), at(48)));
+}
+__device__ __forceinline__ uint64_t wave_sum(uint64_t v) { return wave_fold_u64(v, [](uint64_t a, uint64_t b) { return a + b; }); }
+__device__ __forceinline__ uint64_t wave_min(uint64_t v) { return wave_fold_u64(v, [](uint64_t a, uint64_t b) { return a < b ? a : b; }); }
+__device__ __forceinline__ uint64_t wave_max(uint64_t v) { return wave_fold_u64(v, [](uint64_t a, uint64_t b) { return a > b ? a : b; }); }
+
 // Integer sums over the wave through the same DPP steps (exact whatever the order): the total in every lane; the total of a lane's
 // group of 8 lanes; the totals of the two 32-lane halves; and the inclusive prefix sum (row shifts inside a row of 16 -- a lane without a
 // source adds 0 --, then the totals of the rows before the lane's own from scalar registers).  Workgroups are one-dimensional: a wave
