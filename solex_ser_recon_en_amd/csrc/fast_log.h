@@ -83,8 +83,12 @@ SHG_FASTLOG_FN double log_normal(double x) {
 //     runs this text with a reciprocal that is wrong by up to 2^-22 and compares q's logarithm with that of the compiler's a / b.)
 //   * sqrt(2) / 2 <= q < sqrt(2) (neighbouring rows of a sunlit disk: always, but for a handful of pixels): k = 0, f = q - 1,
 //     d = fl(2 + f), and 1 / d ~ b / (a + b) = b (z b) to a few ulp -- one Newton step and the same quotient correction give
-//     s = f / d as div_normal does.  Any other q: log_normal(q).
-SHG_FASTLOG_FN double log_ratio_u16(unsigned a_px, unsigned b_px) {
+//     s = f / d as div_normal does.  Any other q: other(q) -- log_normal(q) for the two-argument form.
+//   * a zero pixel never takes the short way: a = 0 gives q = 0 exactly, b = 0 a NaN (the reciprocal of 0 is inf, and inf * 0),
+//     neither passes the range test -- a caller that may see zeros tells them apart inside other() (k_rowpair_stats does: round 6,
+//     the two compares with zero left the path every pair takes).
+template <typename Other>
+SHG_FASTLOG_FN double log_ratio_u16(unsigned a_px, unsigned b_px, Other other) {
     const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
                  Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
                  Lg7 = 1.479819860511658591e-01;
@@ -102,7 +106,7 @@ SHG_FASTLOG_FN double log_ratio_u16(unsigned a_px, unsigned b_px) {
     const double y = z * t;                              // ~ 1 / b
     const double q0 = a * y;
     const double q = fma(fma(-b, q0, a), y, q0);         // fl(a / b)
-    if (!(q >= 0.70710678118654752440 && q < 1.41421356237309504880)) return log_normal(q);
+    if (!(q >= 0.70710678118654752440 && q < 1.41421356237309504880)) return other(q);
     const double f = q - 1.0, d = 2.0 + f;
     double v = b * u;                                    // ~ 1 / (q + 1)
     v = fma(v, fma(-d, v, 1.0), v);
@@ -114,6 +118,10 @@ SHG_FASTLOG_FN double log_ratio_u16(unsigned a_px, unsigned b_px) {
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
     return f - (hfsq - s * (hfsq + R));                  // (log_normal's last line with k = 0: -(x - f) = f - x to the bit)
+}
+
+SHG_FASTLOG_FN double log_ratio_u16(unsigned a_px, unsigned b_px) {                    // both pixels >= 1
+    return log_ratio_u16(a_px, b_px, [](double q) { return log_normal(q); });
 }
 
 }  // namespace shg

@@ -36,7 +36,7 @@ __device__ __forceinline__ double key_f64(uint64_t k) {
 constexpr int NB = 512;          // buckets of the bucket select (= the radix select's two 256-bin histograms)
 constexpr int CAP = 128;         // candidates ranked directly
 
-struct Scratch {
+struct alignas(16) Scratch {
     uint32_t hist[2][256];       // radix select: one histogram per rank; bucket select: one of NB bins
     int64_t wave_tot[2][4];
     int64_t pick[2][3];          // [which rank][digit / bucket, count below, count in the bin]
@@ -47,6 +47,9 @@ struct Scratch {
     double red[8];
     double vfound[2];            // bucket select: the two values found
     int bad, nonfinite;
+    uint32_t pick32[8];          // bucket select: [bucket of rank_lo, values before it, values in it, -, bucket of rank_hi, values in it]
+    float redf[8];               // the sums that only steer the bucket select
+    uint32_t kept[4];            // the inliers each wave counted
 };
 
 // one histogram increment with wave-level aggregation of the most common digit
@@ -166,15 +169,23 @@ __device__ __forceinline__ void sweep(int n, F body) {
     if (last < n) body(last);
 }
 
-// The same two order statistics by bucketing, for keys that are all finite and lie in [kmin, kmax] (the extrema of the
-// set, found by the caller).  x -> min(NB-1, int((x - lo) * NB / (hi - lo))) never decreases with x, so every key of a
-// bucket is <= every key of the next one and the bucket holding a rank is found by a prefix sum; its keys (a few
-// dozen of ~2000 for real rows) are ranked against each other.  A crowded bucket is bucketed again between its own
-// extrema.  Returns false (block-uniform) when it gives up: the caller then runs select2.
+// The same two order statistics by bucketing, for keys that are all finite, and ADJACENT ranks (rank_hi - rank_lo is 0 or 1: a
+// median).  x -> min(NB-1, max(0, int(x * inv + off))) never decreases with x (a fused multiply-add rounds a rising function once),
+// so every key of a bucket is <= every key of the next one and the bucket holding a rank is found by a prefix sum; its keys (a dozen
+// of ~2000 for real rows) are ranked against each other.  A crowded bucket is bucketed again between its own extrema.  Returns false
+// (block-uniform) when it gives up: the caller then runs select2.
+//
+// Round 6: this kernel is bound by the vector instructions it issues (SQ_INSTS_VALU x 4 cycles = 90 % of its duration, profiles/
+// r06_sq_k_rowpair_stats.json) and a thread has only ~7 values, so what a select costs per WORKGROUP counts as much as what it costs
+// per value: (a) the buckets' prefix sum and the search for the two ranks are one wave's work (eight buckets a lane) instead of
+// every wave repeating them, in 32-bit counts; (b) 1 / (hi - lo) is the hardware's approximate reciprocal -- the map only has to
+// be monotone --, the bucket one multiply-add; (c) the candidates are the values whose position lies in [b0, b1 + 1): two compares
+// instead of convert / clamp / two compares (the buckets between two adjacent ranks' are empty).
 template <typename ValFn>
-__device__ __forceinline__ bool select2_buckets(ValFn val, int n, int64_t rank_lo, int64_t rank_hi, double lo, double hi,
+__device__ __forceinline__ bool select2_buckets(ValFn val, int n, int rank_lo, int rank_hi, double lo, double hi,
                                                 Scratch& sc, double& out_lo, double& out_hi) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint32_t* hist = &sc.hist[0][0];
     double* cand = reinterpret_cast<double*>(sc.cand);
     uint32_t below = 0;                                 // values smaller than wlo
@@ -189,10 +200,12 @@ __device__ __forceinline__ bool select2_buckets(ValFn val, int n, int64_t rank_l
         // The caller passes the bulk of the distribution (mean +- 3 sigma) rather than the extrema: with the range set by
         // a few outliers the bulk shares a dozen buckets and the LDS atomics below serialise (measured: 69 us instead of
         // 51 for the radix select; profiles/).
-        const double inv = (double)NB / (hi - lo);
-        if (!(inv > 0.0) || inv > 1.7e308) return false;
-        auto bucket = [&](double v) {                    // (the sweeps read the values as they are: no sort keys made and unmade)
-            int b = (int)((v - lo) * inv);               // toward zero, saturating (v_cvt_i32_f64): still monotone
+        const double inv = (double)NB * __builtin_amdgcn_rcp(hi - lo);
+        const double off = -lo * inv;
+        if (!(inv > 0.0) || inv > 1.7e308 || !(fabs(off) <= 1.7e308)) return false;
+        auto place = [&](double v) { return fma(v, inv, off); };      // (the sweeps read the values as they are: no sort keys made and unmade)
+        auto bucket = [&](double v) {
+            int b = (int)place(v);                       // toward zero, saturating (v_cvt_i32_f64): still monotone
             b = b < 0 ? 0 : b;
             return b > NB - 1 ? NB - 1 : b;
         };
@@ -206,32 +219,46 @@ __device__ __forceinline__ bool select2_buckets(ValFn val, int n, int64_t rank_l
             if (in_play(v)) atomicAdd(&hist[bucket(v)], 1u);
         });
         __syncthreads();
-        // prefix sum over the buckets, two per thread
-        const uint32_t c0 = hist[2 * tid], c1 = hist[2 * tid + 1];
-        uint32_t incl = wave_inclusive_scan(c0 + c1);
-        if (lane == 63) sc.wave_tot[0][wave] = incl;
-        __syncthreads();
-        for (int i = 0; i < wave; ++i) incl += (uint32_t)sc.wave_tot[0][i];
-        const uint32_t excl = below + incl - c0 - c1;
-        const int64_t rk[2] = {rank_lo, rank_hi};
+        if (wave == 0) {
+            // prefix sum over the buckets, eight per lane; p[k] = the values up to and including the lane's bucket k
+            const uint4 h0 = *reinterpret_cast<const uint4*>(&hist[8 * lane]), h1 = *reinterpret_cast<const uint4*>(&hist[8 * lane + 4]);
+            const uint32_t c[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+            const uint32_t tot = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
+            const uint32_t run = below + wave_inclusive_scan(tot) - tot;
+            uint32_t p[8];
+            p[0] = run + c[0];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            if (excl <= rk[r] && rk[r] < excl + c0) { sc.pick[r][0] = 2 * tid; sc.pick[r][1] = excl; sc.pick[r][2] = c0; }
-            else if (excl + c0 <= rk[r] && rk[r] < excl + c0 + c1) { sc.pick[r][0] = 2 * tid + 1; sc.pick[r][1] = excl + c0; sc.pick[r][2] = c1; }
+            for (int k = 1; k < 8; ++k) p[k] = p[k - 1] + c[k];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t rk = (uint32_t)(r ? rank_hi : rank_lo);
+                if (run <= rk && rk < p[7]) {            // this lane's buckets hold the rank: walk them
+                    uint32_t b = 0, before = run, in = c[0];
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) {
+                        const bool past = rk >= p[k];    // (true for every k before the bucket, false from it on)
+                        b += past ? 1u : 0u;
+                        before = past ? p[k] : before;
+                        in = past ? c[k + 1] : in;
+                    }
+                    sc.pick32[4 * r] = 8u * (uint32_t)lane + b;
+                    sc.pick32[4 * r + 1] = before;
+                    sc.pick32[4 * r + 2] = in;
+                }
+            }
         }
         __syncthreads();
-        const int b0 = (int)sc.pick[0][0], b1 = (int)sc.pick[1][0];
-        const uint32_t base = (uint32_t)sc.pick[0][1];
-        const uint32_t cnt = (uint32_t)sc.pick[0][2] + (b1 != b0 ? (uint32_t)sc.pick[1][2] : 0u);
-        __syncthreads();                                // pick[] is rewritten by the next level
+        const int b0 = (int)sc.pick32[0], b1 = (int)sc.pick32[4];
+        const uint32_t base = sc.pick32[1];
+        const uint32_t cnt = sc.pick32[2] + (b1 != b0 ? sc.pick32[6] : 0u);
         if (cnt <= (uint32_t)CAP) {
-            // adjacent ranks: the buckets between b0 and b1 are empty, so the candidates are consecutive in rank
+            // adjacent ranks: the buckets between b0 and b1 are empty, so the candidates -- every value of the buckets b0 ... b1 --
+            // are consecutive in rank.  bucket >= b0 <=> place >= b0 (or b0 = 0), bucket <= b1 <=> place < b1 + 1 (or b1 = NB - 1).
+            const double from = b0 == 0 ? -__builtin_huge_val() : (double)b0, to = b1 == NB - 1 ? __builtin_huge_val() : (double)(b1 + 1);
             sweep(n, [&](int i) {
                 const double v = val(i);
-                if (in_play(v)) {
-                    const int b = bucket(v);
-                    if (b == b0 || b == b1) cand[atomicAdd(&sc.n_cand, 1u)] = v;
-                }
+                const double t = place(v);
+                if (in_play(v) && t >= from && t < to) cand[atomicAdd(&sc.n_cand, 1u)] = v;
             });
             __syncthreads();
             const int m = (int)sc.n_cand;
@@ -308,6 +335,31 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* red) {
     b = (red[4] + red[5]) + (red[6] + red[7]);
 }
 
+// The same for two sums that only have to be roughly right (the bulk of a row's values, for the bucket select's range): rounded to
+// float first, where a DPP step is ONE instruction (v_add_f32_dpp) instead of two moves and an add -- 11 instructions a sum
+// instead of 26.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    v += dpp_f32<0x140>(v);
+    auto row = [&](int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+    return (row(0) + row(16)) + (row(32) + row(48));
+}
+__device__ __forceinline__ void block_sum2_rough(float& a, float& b, float* red) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = b; }
+    __syncthreads();
+    a = (red[0] + red[1]) + (red[2] + red[3]);
+    b = (red[4] + red[5]) + (red[6] + red[7]);
+}
+
 // grid (rows, 1, disks): blockIdx.z picks the image and its slice (out_stride doubles apart) of out / mirror
 struct RowpairArgs {
     shg::PtrBatch imgs;
@@ -360,17 +412,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8))) void k_
         // logarithm's own division -- for pixel pairs without a zero; four pairs' loads in flight before the first is used.
         bool odd = false;
         auto one = [&](uint32_t a, uint32_t b, int i) {
-            double x;
-            if (a != 0 && b != 0) {
-                x = shg::log_ratio_u16(a, b);
-            } else {                     // a zero pixel: 0, inf or NaN quotient -- the library's log knows what to return
-                x = log((double)a / (double)b);
-                if (x != x) sc.bad = 1;
-                odd = odd || !(fabs(x) <= 1.7976931348623157e308);
-            }
+            // (a pair with a zero pixel fails log_ratio_u16's range test like any quotient far from 1: fast_log.h)
+            const double x = shg::log_ratio_u16(a, b, [&](double q) {
+                if (a != 0 && b != 0) return shg::log_normal(q);
+                const double l = log((double)a / (double)b);      // 0, inf or NaN quotient -- the library's log knows what to return
+                if (l != l) sc.bad = 1;
+                odd = odd || !(fabs(l) <= 1.7976931348623157e308);
+                return l;
+            });
             vals[i] = x;
             sum1 += x;
-            sum2 += x * x;
+            sum2 = fma(x, x, sum2);
         };
         // whole groups of 4 x NT pairs first (a scalar trip count, no index clamps or per-lane bounds: see sweep()), then the rest
         const int groups = __builtin_amdgcn_readfirstlane(n / (4 * NT));
@@ -413,22 +465,26 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8))) void k_
             odd = odd || !(fabs(x) <= 1.7976931348623157e308);
             vals[i] = x;
             sum1 += x;
-            sum2 += x * x;
+            sum2 = fma(x, x, sum2);
         }
         if (odd) sc.nonfinite = 1;
     }
-    block_sum2(sum1, sum2, sc.red);
+    // Where the bulk of the row lies, roughly: single precision and the hardware's approximate reciprocal and square root will do
+    // (a range that spreads the values badly costs the bucket select a second level, never a wrong answer).
+    float rough1 = (float)sum1, rough2 = (float)sum2;
+    block_sum2_rough(rough1, rough2, sc.redf);
     __syncthreads();
     if (sc.bad) {
         emit(__builtin_nan(""));
         return;
     }
     const bool finite = !sc.nonfinite;
-    const double mean = sum1 / (double)n;
-    const double var = sum2 / (double)n - mean * mean;
-    const double sigma = var > 0.0 ? sqrt(var) : 0.0;
+    const float per_n = __builtin_amdgcn_rcpf((float)n);
+    const float meanf = rough1 * per_n, varf = rough2 * per_n - meanf * meanf;
+    const double mean = (double)meanf;
+    const double sigma = varf > 0.0f ? (double)__builtin_amdgcn_sqrtf(varf) : 0.0;
     // np.median: the middle order statistic, or the mean of the two middle ones
-    const int64_t lo = (n & 1) ? (n >> 1) : (n >> 1) - 1, hi = n >> 1;
+    const int lo = (n & 1) ? (n >> 1) : (n >> 1) - 1, hi = n >> 1;
     double va, vb;
     auto general = [&](auto key) {                 // the radix select, over sort keys made on the fly
         uint64_t ka, kb;
@@ -459,14 +515,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8))) void k_
     // double lies in [2 mdev (1 - 2^-54), 2 mdev) -- the two tests agree for every pair of doubles (infinities and NaN included),
     // and the sweep has no division.
     const double twice = 2.0 * mdev;
-    double s = 0.0, cnt = 0.0;
+    const bool all = !(mdev != 0.0);                                       // s = d/mdev if mdev else zeros; data[s < 2] (see above)
+    double s = 0.0;
+    uint32_t kept = 0;                                                     // (the wave's count, in a scalar register)
     sweep(n, [&](int i) {
         const double x = vals[i];
-        const double dev = fabs(x - med);
-        const bool keep = (mdev != 0.0) ? (dev < twice) : true;        // s = d/mdev if mdev else zeros; data[s < 2] (see above)
-        if (keep) { s += x; cnt += 1.0; }
+        const bool keep = all || fabs(x - med) < twice;
+        kept += (uint32_t)__popcll(__ballot(keep));
+        if (keep) s += x;
     });
-    block_sum2(s, cnt, sc.red);
+    s = wave_sum(s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sc.red[threadIdx.x >> 6] = s; sc.kept[threadIdx.x >> 6] = kept; }
+    __syncthreads();
+    s = (sc.red[0] + sc.red[1]) + (sc.red[2] + sc.red[3]);
+    const double cnt = (double)((sc.kept[0] + sc.kept[1]) + (sc.kept[2] + sc.kept[3]));
     emit(s / cnt);
 }
 
