@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include "shg_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -71,6 +72,7 @@ struct WarpArgs {
     WarpPtrs dsts;
     int64_t out_h, out_w, dst_pitch;
     WarpPtrs mms;
+    uint32_t nv_magic, nv_shift;                   // k_warp_rows8: flat / nv = __umulhi(flat, nv_magic) >> nv_shift
 };
 
 template <int WARP_ROWS>
@@ -135,19 +137,24 @@ __global__ __launch_bounds__(256) void k_warp_rows(const WarpArgs kargs) {
 // k_warp_rows above issues two 2-byte loads and one 2-byte store per output pixel: 24 vector-memory instructions for a wave's 8 rows,
 // each of them 128 bytes -- the kernel was bound by their issue, not by their bytes (0.37 of the HBM roofline at C4).  Here a lane owns 8
 // consecutive columns of one output row: its 16 source samples lie within 24 pixels of the first one (the transform's column step is at
-// most 1.75: the host checks), so it fetches three aligned 16-byte pieces of the source row, parks them in LDS ([word][lane]: the bank is the
-// lane, no conflict whatever word a lane asks for), and reads each pixel's pair of neighbours back with one ds_read2_b32 at an offset of
-// its own; one 16-byte store.  4 vector-memory instructions for 8 pixels a lane instead of 24.  Same float64 arithmetic, unfused --
-// but no more of it than the result needs: the column term as one fma, no test for whole positions, the clip on integers (34
-// instructions a pixel, 13 of them float64).  C4: 115 -> 104 us; without its loads 96, with nontemporal stores 103: what is left is
-// the float64 work itself (profiles/r06_sweeps.txt).
+// most 1.75: the host checks), so it fetches three aligned pieces of the source row (16, 16 and 12 bytes), parks every PAIR of
+// neighbours of the window in LDS ([pair][lane]: the bank is the lane, no conflict whatever pair a lane asks for), and reads each
+// pixel's pair back with one ds_read_b32 at an offset of its own; one 16-byte store.  4 vector-memory instructions for 8 pixels a lane
+// instead of 24.  Same float64 arithmetic, unfused -- but no more of it than the result needs: the column term as one fma, no test for
+// whole positions, the clip on integers.
+// The kernel is bound by the vector instructions it issues (SQ_INSTS_VALU x 4 cycles = 0.9 of its duration at 42 a pixel, profiles/
+// r06_sq_k_warp_rows8.json), so the second half of round 6 counted them: waves whose samples all lie inside their rows skip the
+// border tests (-6 a pixel), pairs instead of words in LDS (-3), flat / nv as a multiply-high (-2), 32-bit byte offsets off the
+// scalar image bases (-2), the first pixel's position from the placement (-1): ~29 a pixel, 18 in the blend itself.
+// C4: 115 (k_warp_rows) -> 104 -> 82 - 85 us (profiles/r06_sweeps.txt).
 // Lanes are dealt (row, 8-column vector) pairs in one flat sequence, ITER of them per thread, the next one's pieces asked for before
 // the current one is blended.
 typedef unsigned int __attribute__((ext_vector_type(4))) u32x4_t;
-constexpr int kWarpWords = 13;                     // LDS words per lane: one of margin (the pixel left of the window) + 12 of window
+typedef unsigned int __attribute__((ext_vector_type(3))) u32x3_t;
+constexpr int kWarpPairs = 22;                     // LDS words per lane: the pairs (pixel p, pixel p + 1) of the window, p = -1 ... 20
 template <int ITER>
-__global__ __launch_bounds__(256) void k_warp_rows8(const WarpArgs kargs) {
-    __shared__ uint32_t win[4][kWarpWords][64];
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void k_warp_rows8(const WarpArgs kargs) {
+    __shared__ uint32_t win[4][kWarpPairs][64];
     const int64_t h = kargs.h, w = kargs.w, pitch = kargs.pitch, out_h = kargs.out_h, out_w = kargs.out_w, dst_pitch = kargs.dst_pitch;
     const uint16_t* __restrict__ src = kargs.srcs.at<const uint16_t>(blockIdx.z);
     uint16_t* __restrict__ dst = kargs.dsts.at<uint16_t>(blockIdx.z);
@@ -163,68 +170,101 @@ __global__ __launch_bounds__(256) void k_warp_rows8(const WarpArgs kargs) {
     const int w_last = (int)w - 1, last_piece = (int)pitch - 8;
 
     // (row, first column, window start) of the it-th vector of this thread, and its three pieces
-    auto place = [&](int it, int& r, int& c, int& ws) {
+    auto place = [&](int it, int& r, int& c, int& ws, double& hr, double& x) {
         const uint32_t flat = ((uint32_t)blockIdx.x * ITER + (uint32_t)it) * 256u + threadIdx.x;
         const uint32_t f = flat < total ? flat : total - 1;
-        r = (int)(f / nv);
+        r = (int)(__umulhi(f, kargs.nv_magic) >> kargs.nv_shift);      // f / nv (exact below 2^31: the host's choice of the pair)
         c = (int)(f - (uint32_t)r * nv) * 8;
-        const double x = h00 * (double)c + h01 * (double)r + h02;
+        hr = h01 * (double)r;
+        x = h00 * (double)c + hr + h02;                         // (the first pixel's position: the blend below takes it from here)
         const int i0 = __double2int_rz(floor(x));               // saturates far outside
         ws = min(max(i0, 0), w_last) & ~7;
         return flat < total;
     };
-    auto fetch = [&](int r, int ws, u32x4_t (&q)[3]) {
-        const uint16_t* row = src + (int64_t)(r < h ? r : 0) * pitch;
+    // (the window's last two pixels are nobody's neighbours -- see the pairs below --: the third piece is 12 bytes.  A 16-byte load
+    // whose last word is never read lets the compiler reuse that register straight away, and wait for the whole prefetch to land first.)
+    // Byte offsets in 32 bits off the images' (scalar) bases -- the host checks that both images end below 4 GiB and that the pitches
+    // fit 24 bits --: one multiply and an add-and-shift per piece where 64-bit pointers took a dozen instructions a vector.
+    const char* const src_bytes = reinterpret_cast<const char*>(src);
+    const uint32_t pitch_u = (uint32_t)pitch, dst_pitch_u = (uint32_t)dst_pitch, hu = (uint32_t)h;
+    auto fetch = [&](int r, int ws, u32x4_t (&q)[2], u32x3_t& q2) {
+        const uint32_t row = __umul24((uint32_t)r < hu ? (uint32_t)r : 0u, pitch_u);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) q[t] = *reinterpret_cast<const u32x4_t*>(row + min(ws + 8 * t, last_piece));   // (a piece past the row: all of it outside the image)
+        for (int t = 0; t < 2; ++t) q[t] = *reinterpret_cast<const u32x4_t*>(src_bytes + ((row + (uint32_t)min(ws + 8 * t, last_piece)) << 1));   // (a piece past the row: all of it outside the image)
+        q2 = *reinterpret_cast<const u32x3_t*>(src_bytes + ((row + (uint32_t)min(ws + 16, last_piece)) << 1));
     };
     int r, c, ws;
-    bool live = place(0, r, c, ws);
-    u32x4_t q[3];
-    fetch(r, ws, q);
+    double hr_next, x_next;
+    bool live = place(0, r, c, ws, hr_next, x_next);
+    u32x4_t q[2];
+    u32x3_t q2;
+    fetch(r, ws, q, q2);
 #pragma unroll 1
     for (int it = 0; it < ITER; ++it) {
         if (!__any(live)) break;
+        {
+            // every pair of neighbours a pixel of this vector can ask for, one word each: pair p = (pixel p, pixel p + 1) of the window
+            // at row p + 1.  Even p: a word of the pieces as it is; odd p: the funnel shift of two (11 instructions a vector, where
+            // every PIXEL spent four on picking its pair out of two words).  p = -1 serves a position just left of the image; the
+            // window's last three pixels are never a left neighbour (a00 <= 1.75: p <= 7 + 13).
+            const uint32_t wd[11] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q2.x, q2.y, q2.z};
+            my[0][lane] = wd[0] << 16;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            my[1 + 4 * t][lane] = q[t].x;
-            my[2 + 4 * t][lane] = q[t].y;
-            my[3 + 4 * t][lane] = q[t].z;
-            my[4 + 4 * t][lane] = q[t].w;
+            for (int k = 0; k < 11; ++k) my[1 + 2 * k][lane] = wd[k];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) my[2 + 2 * k][lane] = __builtin_amdgcn_alignbit(wd[k + 1], wd[k], 16);
         }
         const int r_now = r, c_now = c, ws_now = ws;
+        const double hr = hr_next, x_first = x_next;
         const bool live_now = live;
         if (it + 1 < ITER) {
-            live = place(it + 1, r, c, ws);
-            fetch(r, ws, q);
+            live = place(it + 1, r, c, ws, hr_next, x_next);
+            fetch(r, ws, q, q2);
         }
         const uint32_t w_row = r_now < h ? wu : 0u;              // (a row the source does not have: every sample outside)
-        const double hr = h01 * (double)r_now;
-        const int ws2 = ws_now - 2;
+        const int ws1 = ws_now - 1;
+        const double col0 = __hiloint2double(0x43300000, c_now);    // 2^52 + c: + j is exact
         uint32_t out[8];
+        // INSIDE: every sample of the wave's 64 vectors lies in its row (all but the waves over the image's left and right edges):
+        // no tests against the row's width, no cval, no clamp of the window offset -- 6 of a pixel's ~36 vector instructions, and
+        // the kernel is bound by those (SQ_INSTS_VALU x 4 cycles = 0.9 of its duration, profiles/r06_sq_k_warp_rows8.json).
+        auto pixels = [&](auto inside_tag) {
+            constexpr bool INSIDE = decltype(inside_tag)::value;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            // h00 * (double)(c + j) with one instruction: 2^52 + (c + j) is the double whose low word is c + j, and (2^52 + n) h00 - 2^52 h00
-            // rounds once, to fl(n h00) (the column step is at most 1.75: 2^52 h00 is exact)
-            const double x = __builtin_fma(__hiloint2double(0x43300000, c_now + j), h00, -k00) + hr + h02;
-            const double x0 = floor(x);
-            const double dc = x - x0;
-            const int i0 = __double2int_rz(x0);                  // saturates far outside: stays outside
-            // the right neighbour is pixel i0 + 1 even where x is whole (the reference takes ceil(x) = i0 there): its weight dc is 0 then,
-            // and 0 x any sample is +0 -- no test for it
-            const bool in0 = (uint32_t)i0 < w_row, in1 = (uint32_t)i0 + 1u < w_row;
-            // the pair (pixel i0, pixel i0 + 1) out of the window: words k, k + 1 shifted by the pixel's parity (a position outside the
-            // window is outside the image: whatever it reads is replaced by cval)
-            const uint32_t off = min((uint32_t)(i0 - ws2), 23u);
-            const uint32_t d0 = my[off >> 1][lane], d1 = my[(off >> 1) + 1][lane];
-            const uint32_t pair = __builtin_amdgcn_alignbit(d1, d0, (off & 1u) * 16u);
-            const double left = (double)(in0 ? (pair & 0xffffu) : cval), right = (double)(in1 ? pair >> 16 : cval);
-            const double v = (1.0 - dc) * left + dc * right;
-            // np.clip(warped, image.min(), image.max()) and the truncation commute (both monotonic, the bounds whole numbers): on integers
-            out[j] = (uint32_t)min(max((int)v, lo_i), hi_i);
-        }
+            for (int j = 0; j < 8; ++j) {
+                // h00 * (double)(c + j) with one instruction: 2^52 + (c + j) is the double whose low word is c + j, and (2^52 + n) h00 - 2^52 h00
+                // rounds once, to fl(n h00) (the column step is at most 1.75: 2^52 h00 is exact)
+                const double x = j == 0 ? x_first : __builtin_fma(col0 + (double)j, h00, -k00) + hr + h02;
+                const double x0 = floor(x);
+                const double dc = x - x0;
+                const int i0 = __double2int_rz(x0);                  // saturates far outside: stays outside
+                // the pair (pixel i0, pixel i0 + 1) out of the window (a position outside the window is outside the image: whatever it
+                // reads is replaced by cval)
+                const int row = INSIDE ? i0 - ws1 : min(max(i0 - ws1, 0), kWarpPairs - 1);
+                const uint32_t pair = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(&my[0][lane]) + ((uint32_t)row << 8));
+                double left, right;
+                if constexpr (INSIDE) {
+                    left = (double)(pair & 0xffffu);
+                    right = (double)(pair >> 16);
+                } else {
+                    // the right neighbour is pixel i0 + 1 even where x is whole (the reference takes ceil(x) = i0 there): its weight dc is 0
+                    // then, and 0 x any sample is +0 -- no test for it
+                    const bool in0 = (uint32_t)i0 < w_row, in1 = (uint32_t)i0 + 1u < w_row;
+                    left = (double)(in0 ? (pair & 0xffffu) : cval);
+                    right = (double)(in1 ? pair >> 16 : cval);
+                }
+                const double v = (1.0 - dc) * left + dc * right;
+                // np.clip(warped, image.min(), image.max()) and the truncation commute (both monotonic, the bounds whole numbers): on integers
+                out[j] = (uint32_t)min(max((int)v, lo_i), hi_i);
+            }
+        };
+        // (a00 >= 0: the first and the last pixel's positions bound the others'; the window starts at most 7 pixels before the first)
+        const double x_last = __builtin_fma(col0 + 7.0, h00, -k00) + hr + h02;
+        const bool inside = x_first >= 0.0 && x_last < (double)w_last && r_now < h;
+        if (__all(inside)) pixels(std::true_type{});
+        else pixels(std::false_type{});
         if (live_now) {
-            uint16_t* o = dst + (int64_t)r_now * dst_pitch + c_now;
+            uint16_t* o = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(dst) + ((__umul24((uint32_t)r_now, dst_pitch_u) + (uint32_t)c_now) << 1));
             if (c_now + 8 <= out_w) {
                 const u32x4_t pk = {out[0] | (out[1] << 16), out[2] | (out[3] << 16), out[4] | (out[5] << 16), out[6] | (out[7] << 16)};
                 *reinterpret_cast<u32x4_t*>(o) = pk;
@@ -286,21 +326,35 @@ int shg::warp_rows_batch(const uint16_t* const* host_srcs, int64_t k, int64_t h,
         WarpRows rows = {};
         for (int d = 0; d < m; ++d)
             for (int j = 0; j < 3; ++j) rows.h[d][j] = host_h3[3 * (i0 + d) + j];
+        // vectors a row, as a multiply-high and a shift: with s = ceil(log2 nv) - 1 and M = ceil(2^(32 + s) / nv) <= 2^32 - 1 (nv >= 2),
+        // M nv - 2^(32 + s) < nv, so f M / 2^(32 + s) stays below the next whole number for every f < 2^(32 + s) / nv, which is > 2^31
+        const uint64_t nv = (uint64_t)((out_w + 7) / 8);
+        uint32_t nv_shift = 0;
+        while ((2ull << nv_shift) < nv) ++nv_shift;
+        const uint32_t nv_magic = nv >= 2 ? (uint32_t)(((1ull << (32 + nv_shift)) + nv - 1) / nv) : 0u;
         const WarpArgs args{shg::make_batch_n<kWarpBatch>(host_srcs, (int)i0, m), h, w, src_pitch, rows, shg::make_batch_n<kWarpBatch>(host_dsts, (int)i0, m),
-                            out_h, out_w, dst_pitch, shg::make_batch_n<kWarpBatch>(host_minmax2, (int)i0, m)};
+                            out_h, out_w, dst_pitch, shg::make_batch_n<kWarpBatch>(host_minmax2, (int)i0, m), nv_magic, nv_shift};
         // eight pixels a lane where the pieces can be 16-byte loads and stores and the window holds a lane's samples (SHG_WARP_WIDE=0: never)
         const bool wide_ok = [] { const char* e = getenv("SHG_WARP_WIDE"); return !e || atoi(e) != 0; }();     // (read per call: the parity test switches it)
-        bool wide = wide_ok && src_pitch % 8 == 0 && dst_pitch % 8 == 0 && w >= 8 && src_pitch >= 8 && out_h * ((out_w + 7) / 8) < (1ll << 31);
+        bool wide = wide_ok && src_pitch % 8 == 0 && dst_pitch % 8 == 0 && w >= 8 && src_pitch >= 8 && nv >= 2 && out_h * ((out_w + 7) / 8) < (1ll << 31) &&
+                    src_pitch < (1ll << 24) && dst_pitch < (1ll << 24) && h * src_pitch < (1ll << 31) && out_h * dst_pitch < (1ll << 31);
         for (int d = 0; d < m && wide; ++d) {
             const double a00 = rows.h[d][0], a01 = rows.h[d][1], a02 = rows.h[d][2];
             wide = a00 >= 0.0 && a00 <= 1.75 && std::fabs(a01) < 1e300 && std::fabs(a02) < 1e300 &&
                    (reinterpret_cast<uintptr_t>(host_srcs[i0 + d]) & 15) == 0 && (reinterpret_cast<uintptr_t>(host_dsts[i0 + d]) & 15) == 0;
         }
         if (wide) {
-            constexpr int ITER = 4;
+            // ITER vectors a thread (the next one's pieces asked for while the current one is blended) -- as long as that still
+            // leaves every CU a few workgroups: a single 2000 x 2096 disk is 512 workgroups of 4 vectors a thread
             const int64_t vecs = out_h * ((out_w + 7) / 8);
-            dim3 grid((unsigned)((vecs + 256 * ITER - 1) / (256 * ITER)), 1u, (unsigned)m);
-            if (int e = shg::launch(k_warp_rows8<ITER>, grid, dim3(256), 0, st, args, "k_warp_rows8")) return e;
+            // (measured on one box, C2 / C4: 1 vector a thread 11.3 - 12.9 / 82.3 us, 4 vectors 11.3 - 12.1 / 82.2 - 83.3: the resident waves hide
+            // the loads either way; profiles/r06_sweeps.txt)
+            const bool few = vecs * m < 4 * 256 * 2048;
+            auto go8 = [&](auto I) {
+                dim3 grid((unsigned)((vecs + 256 * I.value - 1) / (256 * I.value)), 1u, (unsigned)m);
+                return shg::launch(k_warp_rows8<I.value>, grid, dim3(256), 0, st, args, "k_warp_rows8");
+            };
+            if (int e = few ? go8(std::integral_constant<int, 1>{}) : go8(std::integral_constant<int, 4>{})) return e;
             continue;
         }
         const int64_t gx = (out_w + 255) / 256;
