@@ -230,10 +230,22 @@ __device__ __forceinline__ uint32_t rescale1_fast(double px, double lo, double s
 }
 
 // Eight pixels per lane: 16-byte loads of frame and cl1, 16-byte stores of the three products (rows 16-byte aligned,
-// pitches multiples of 8; a row's last, partial vector goes pixel by pixel).  A lane takes the same eight columns of PROD_ROWS
-// rows, their loads issued before the first use (what took k_warp_rows from 227 to 144 us over 21 disks did nothing here).
-// grid (ceil(vectors per row * row groups / 256), 1, disks)
-constexpr int PROD_ROWS = 1;            // (4 rows per lane, loads hoisted: 160 us per 16-disk launch against 140 -- the extra live registers cost more than the requests in flight bring)
+// pitches multiples of 8; a row's last, partial vector goes pixel by pixel).  Lanes are dealt (row, 8-column vector) pairs in one flat
+// sequence -- a width just past a multiple of 2048 pixels (2096 at C2) would leave every second workgroup of a (x, y) grid with half a
+// dozen lanes to do.
+// grid (ceil(vectors / 256), 1, disks)
+//
+// Round 6, second half: the kernel was bound by the vector instructions it issues (SQ_INSTS_VALU x 4 cycles = 0.96 of its duration at
+// 70 a pixel, profiles/r06_sq_k_products8.json), a third of them per THREAD, not per pixel: the bounds from the statistics, three IEEE
+// divisions for 1 / span, the disc's half width by a float64 square root and 64-bit fix-up loops, 64-bit addresses -- for eight
+// pixels.  Now: 1 / span is the hardware's reciprocal and two Newton steps (its error, 2^-52, moves q by 1e-11: the near-whole test
+// below allows 1e-7); the half width is a float square root and two 32-bit fix-ups (radii below 32768: the host checks); row and
+// column by a multiply-high; 32-bit byte offsets off the scalar image bases.  Per pixel: the three rescales without a branch each --
+// every pixel takes the short way, the lane notes whether any of its 24 quotients sat within 1e-7 of a whole number, and only such a
+// lane (one in ~10^5) goes over its eight pixels again with the exact division.  70 -> 45 instructions a pixel; a single disk (C2)
+// 12.8 -> 10.4 us.  A 21-disk stack stays at 162 - 167 us: with the instructions gone it is its five streams (two read, three
+// written, 718 MB at 4.4 TB/s) that set the pace -- a plain copy of that size runs at 5.4 TB/s on this part (tools/probes/
+// write_rate.py), four vectors a thread measured 163 and 189 us on two boxes (profiles/r06_sweeps.txt).
 struct ProductsArgs {
     ProdPtrs frames;
     int64_t frame_pitch;
@@ -243,66 +255,82 @@ struct ProductsArgs {
     ProdPtrs hcs, protuss, ccs;
     int64_t dst_pitch, x0, y0, r;
     StatsSource stats;
+    uint32_t nv_magic, nv_shift;         // flat / (vectors a row) = __umulhi(flat, nv_magic) >> nv_shift (see k_warp_rows8's host side)
 };
 
-__global__ __launch_bounds__(256) void k_products8(const ProductsArgs kargs) {
-    const ProdPtrs& frames = kargs.frames;
-    const ProdPtrs& cl1s = kargs.cl1s;
-    const ProdPtrs& hcs = kargs.hcs;
-    const ProdPtrs& protuss = kargs.protuss;
-    const ProdPtrs& ccs = kargs.ccs;
-    const int64_t frame_pitch = kargs.frame_pitch, cl1_pitch = kargs.cl1_pitch, h = kargs.h, w = kargs.w, dst_pitch = kargs.dst_pitch,
-                  x0 = kargs.x0, y0 = kargs.y0, r = kargs.r;
-    const BoundsBatch& bb = kargs.bb;
-    const StatsSource& stats = kargs.stats;
-    // lanes are dealt (row group, vector) pairs in one flat sequence: a width just past a multiple of 2048 pixels (2096 at C2)
-    // would leave every second workgroup of a (x, y) grid with half a dozen lanes to do
-    const uint32_t nv = (uint32_t)((w + 7) / 8);
-    const uint32_t flat = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t yg = flat / nv;
-    const int64_t x = (int64_t)(flat - yg * nv) * 8;
-    const int64_t ya = (int64_t)yg * PROD_ROWS;
-    if (ya >= h) return;
-    const uint16_t* __restrict__ frame = frames.at<const uint16_t>(blockIdx.z);
-    const uint16_t* __restrict__ cl1 = cl1s.at<const uint16_t>(blockIdx.z);
-    uint16_t* __restrict__ hc = hcs.at<uint16_t>(blockIdx.z);
-    uint16_t* __restrict__ protus = protuss.at<uint16_t>(blockIdx.z);
-    uint16_t* __restrict__ cc = ccs.at<uint16_t>(blockIdx.z);
-    const bool full = x + 8 <= w;
-    // the rows' pixels first (a row beyond the image re-reads the last one), then the bounds: both are waited for once
-    uint4 qf[PROD_ROWS], qc[PROD_ROWS];
-    if (full) {
+// The short way of rescale1_fast, and whether the exact division has to decide (rescale1_fast says why that is the only case): the
+// quotient's fraction is >= 0 here, "within 1e-7 of a whole number" is its high word outside [A, B) = [that of 1e-7, that of 1 - 1e-7)
+// (a shade wider: more pixels in doubt, none fewer), i.e. (hi - A) >= B - A unsigned -- and a lane only has to know whether ANY of
+// its 24 quotients is: the largest hi - A, one v_max_u32 a quotient instead of a compare and a scalar or (and 24 flags kept in
+// registers until the end: 134 of them, three waves a SIMD).  A quotient beyond int32 or infinite has a "fraction" >= 1: in doubt.
+constexpr uint32_t kFracA = 0x3E7AD7F3u, kFracB = 0x3FEFFFFFu;
+__device__ __forceinline__ uint32_t rescale1_quick(double px, double lo, double inv_span, uint32_t& worst) {
+    // (a quotient at or below 0 -- a black pixel under lo = 0, a pixel equal to an integral lo: every such one exactly 0, i.e. "whole" --
+    // gives 0 whichever way it is computed: lifted to 0.25 it does not send its lane the long way; a NaN -- 0 x inf -- likewise)
+    const double q = fmax((65535.0 * (px - lo)) * inv_span, 0.25);
+    const int r = (int)q;                                                  // saturating
+    const double fr = q - (double)r;
+    worst = max(worst, (uint32_t)__double2hiint(fr) - kFracA);
+    return (uint32_t)min(r, 65535);
+}
+__device__ __forceinline__ double recip_newton(double d) {                // 1 / d to an ulp or so (0, inf, NaN: a NaN -- every pixel in doubt)
+    double y = __builtin_amdgcn_rcp(d);
+    y = fma(y, fma(-d, y, 1.0), y);
+    return fma(y, fma(-d, y, 1.0), y);
+}
+// floor(sqrt(v)) for v < 2^31
+__device__ __forceinline__ uint32_t isqrt31(uint32_t v) {
+    uint32_t s = (uint32_t)__builtin_amdgcn_sqrtf((float)v);             // within 1 of the root (v < 2^31, the root < 46341: float's 2^-22 is 0.01)
+    s = s > 46340u ? 46340u : s;
 #pragma unroll
-        for (int rr = 0; rr < PROD_ROWS; ++rr) {
-            const int64_t y = ya + rr < h ? ya + rr : h - 1;
-            qf[rr] = *reinterpret_cast<const uint4*>(frame + y * frame_pitch + x);
-            qc[rr] = *reinterpret_cast<const uint4*>(cl1 + y * cl1_pitch + x);
-        }
-    }
-    Bounds6 b = bb.v[blockIdx.z];
+    for (int i = 0; i < 2; ++i) s -= (s * s > v) ? 1u : 0u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) s += ((s + 1u) * (s + 1u) <= v) ? 1u : 0u;
+    return s;
+}
+
+__global__ __launch_bounds__(256) void k_products8(const ProductsArgs kargs) {
+    const uint32_t h = (uint32_t)kargs.h, w = (uint32_t)kargs.w;
+    const uint32_t frame_pitch = (uint32_t)kargs.frame_pitch, cl1_pitch = (uint32_t)kargs.cl1_pitch, dst_pitch = (uint32_t)kargs.dst_pitch;
+    const int64_t x0 = kargs.x0, y0 = kargs.y0;
+    const int r = (int)kargs.r;
+    const StatsSource& stats = kargs.stats;
+    const char* __restrict__ frame = kargs.frames.at<const char>(blockIdx.z);
+    const char* __restrict__ cl1 = kargs.cl1s.at<const char>(blockIdx.z);
+    char* __restrict__ hc = kargs.hcs.at<char>(blockIdx.z);
+    char* __restrict__ protus = kargs.protuss.at<char>(blockIdx.z);
+    char* __restrict__ cc = kargs.ccs.at<char>(blockIdx.z);
+    Bounds6 b = kargs.bb.v[blockIdx.z];
     if (stats.stats5) {
         const bool ok = bounds_from_stats(stats, blockIdx.z, b);
         if (stats.mirror5 && blockIdx.x == 0 && threadIdx.x < 5) stats.mirror5[5 * blockIdx.z + threadIdx.x] = stats.stats5[5 * blockIdx.z + threadIdx.x];
         if (!ok) return;
     }
-    const double i0 = 1.0 / b.span[0], i1 = 1.0 / b.span[1], i2 = 1.0 / b.span[2];
-#pragma unroll
-    for (int rr = 0; rr < PROD_ROWS; ++rr) {
-        const int64_t y = ya + rr;
-        if (y >= h) break;
-        // the disc's span on this row: [x0 - half, x0 + half] (cv2.circle(frame_protus, (x0, y0), r, 80, -1))
-        int64_t d_lo = 1, d_hi = 0;
+    const double i0 = recip_newton(b.span[0]), i1 = recip_newton(b.span[1]), i2 = recip_newton(b.span[2]);
+    const uint32_t nv = (w + 7u) / 8u, total = nv * h;
+    typedef unsigned int __attribute__((ext_vector_type(4))) u32x4;
+    {
+        const uint32_t flat = (uint32_t)blockIdx.x * 256u + threadIdx.x;
+        if (flat >= total) return;
+        const uint32_t y = __umulhi(flat, kargs.nv_magic) >> kargs.nv_shift;
+        const uint32_t x = (flat - y * nv) * 8u;
+        // the disc's span on this row: [x0 - half, x0 + half] (cv2.circle(frame_protus, (x0, y0), r, 80, -1)), relative to x
+        int d_lo = 1, d_hi = 0;
         if (r > 0) {
-            const int64_t ady = y > y0 ? y - y0 : y0 - y;
-            if (ady <= r) {
-                const int64_t half = isqrt64(r * r - ady * ady);
-                d_lo = x0 - half;
-                d_hi = x0 + half;
+            const int64_t ady = (int64_t)y > y0 ? (int64_t)y - y0 : y0 - (int64_t)y;
+            if (ady <= (int64_t)r) {
+                const int64_t half = (int64_t)isqrt31((uint32_t)(r * r) - (uint32_t)((int)ady * (int)ady));
+                const int64_t lim = 1ll << 30;                             // (columns are below 2^30: clamping there keeps every compare)
+                d_lo = (int)(std::min(std::max(x0 - half, -lim), lim) - (int64_t)x);
+                d_hi = (int)(std::min(std::max(x0 + half, -lim), lim) - (int64_t)x);
             }
         }
-        if (full) {
-            const uint32_t fw[4] = {qf[rr].x, qf[rr].y, qf[rr].z, qf[rr].w}, cw[4] = {qc[rr].x, qc[rr].y, qc[rr].z, qc[rr].w};
+        if (x + 8u <= w) {
+            const u32x4 qf = *reinterpret_cast<const u32x4*>(frame + ((__umul24(y, frame_pitch) + x) << 1));
+            const u32x4 qc = *reinterpret_cast<const u32x4*>(cl1 + ((__umul24(y, cl1_pitch) + x) << 1));
+            const uint32_t fw[4] = {qf.x, qf.y, qf.z, qf.w}, cw[4] = {qc.x, qc.y, qc.z, qc.w};
             uint32_t oh[4], op[4], oc[4];
+            uint32_t worst = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 uint32_t h2[2], p2[2], c2[2];
@@ -310,27 +338,48 @@ __global__ __launch_bounds__(256) void k_products8(const ProductsArgs kargs) {
                 for (int e = 0; e < 2; ++e) {
                     const double f = (double)((fw[j] >> (16 * e)) & 0xffffu);
                     const double c = (double)((cw[j] >> (16 * e)) & 0xffffu);
-                    const int64_t xi = x + 2 * j + e;
-                    h2[e] = rescale1_fast(f, b.lo[0], b.span[0], i0);
-                    p2[e] = (xi >= d_lo && xi <= d_hi) ? 80u : rescale1_fast(f, b.lo[1], b.span[1], i1);
-                    c2[e] = rescale1_fast(c, b.lo[2], b.span[2], i2);
+                    const int k = 2 * j + e;
+                    h2[e] = rescale1_quick(f, b.lo[0], i0, worst);
+                    const uint32_t pq = rescale1_quick(f, b.lo[1], i1, worst);
+                    p2[e] = (k >= d_lo && k <= d_hi) ? 80u : pq;
+                    c2[e] = rescale1_quick(c, b.lo[2], i2, worst);
                 }
                 oh[j] = h2[0] | (h2[1] << 16);
                 op[j] = p2[0] | (p2[1] << 16);
                 oc[j] = c2[0] | (c2[1] << 16);
             }
+            if (worst >= kFracB - kFracA) {                                // rare: the reference's own arithmetic for the lane's eight pixels
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t h2[2], p2[2], c2[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const double f = (double)((fw[j] >> (16 * e)) & 0xffffu);
+                        const double c = (double)((cw[j] >> (16 * e)) & 0xffffu);
+                        const int k = 2 * j + e;
+                        h2[e] = rescale1(f, b.lo[0], b.span[0]);
+                        p2[e] = (k >= d_lo && k <= d_hi) ? 80u : (uint32_t)rescale1(f, b.lo[1], b.span[1]);
+                        c2[e] = rescale1(c, b.lo[2], b.span[2]);
+                    }
+                    oh[j] = h2[0] | (h2[1] << 16);
+                    op[j] = p2[0] | (p2[1] << 16);
+                    oc[j] = c2[0] | (c2[1] << 16);
+                }
+            }
             // the products are final: nobody on the GPU reads them again, so they bypass the caches (frame and cl1 stay)
-            typedef unsigned int __attribute__((ext_vector_type(4))) u32x4;
-            __builtin_nontemporal_store((u32x4){oh[0], oh[1], oh[2], oh[3]}, reinterpret_cast<u32x4*>(hc + y * dst_pitch + x));
-            __builtin_nontemporal_store((u32x4){op[0], op[1], op[2], op[3]}, reinterpret_cast<u32x4*>(protus + y * dst_pitch + x));
-            __builtin_nontemporal_store((u32x4){oc[0], oc[1], oc[2], oc[3]}, reinterpret_cast<u32x4*>(cc + y * dst_pitch + x));
+            const uint32_t o = (__umul24(y, dst_pitch) + x) << 1;
+            __builtin_nontemporal_store((u32x4){oh[0], oh[1], oh[2], oh[3]}, reinterpret_cast<u32x4*>(hc + o));
+            __builtin_nontemporal_store((u32x4){op[0], op[1], op[2], op[3]}, reinterpret_cast<u32x4*>(protus + o));
+            __builtin_nontemporal_store((u32x4){oc[0], oc[1], oc[2], oc[3]}, reinterpret_cast<u32x4*>(cc + o));
         } else {
-            for (int64_t xi = x; xi < w; ++xi) {
-                const double f = (double)frame[y * frame_pitch + xi];
-                const double c = (double)cl1[y * cl1_pitch + xi];
-                hc[y * dst_pitch + xi] = (uint16_t)rescale1_fast(f, b.lo[0], b.span[0], i0);
-                protus[y * dst_pitch + xi] = (xi >= d_lo && xi <= d_hi) ? (uint16_t)80 : (uint16_t)rescale1_fast(f, b.lo[1], b.span[1], i1);
-                cc[y * dst_pitch + xi] = (uint16_t)rescale1_fast(c, b.lo[2], b.span[2], i2);
+            for (uint32_t xi = x; xi < w; ++xi) {
+                const double f = (double)*reinterpret_cast<const uint16_t*>(frame + ((__umul24(y, frame_pitch) + xi) << 1));
+                const double c = (double)*reinterpret_cast<const uint16_t*>(cl1 + ((__umul24(y, cl1_pitch) + xi) << 1));
+                const uint32_t o = (__umul24(y, dst_pitch) + xi) << 1;
+                const int k = (int)(xi - x);
+                *reinterpret_cast<uint16_t*>(hc + o) = rescale1(f, b.lo[0], b.span[0]);
+                *reinterpret_cast<uint16_t*>(protus + o) = (k >= d_lo && k <= d_hi) ? (uint16_t)80 : rescale1(f, b.lo[1], b.span[1]);
+                *reinterpret_cast<uint16_t*>(cc + o) = rescale1(c, b.lo[2], b.span[2]);
             }
         }
     }
@@ -398,7 +447,10 @@ int shg::contrast_products_batch(const uint16_t* const* host_frames, int64_t fra
         }
     }
     hipStream_t st = shg::as_stream(stream);
-    const bool vec = (ptrs & 15) == 0 && frame_pitch % 8 == 0 && cl1_pitch % 8 == 0 && dst_pitch % 8 == 0;
+    // (the vector kernel's 32-bit offsets and multiply-high: every image below 4 GiB, pitches in 24 bits, at least two vectors a row)
+    const bool vec = (ptrs & 15) == 0 && frame_pitch % 8 == 0 && cl1_pitch % 8 == 0 && dst_pitch % 8 == 0 && w >= 9 && w < (1ll << 30) &&
+                     std::max(frame_pitch, std::max(cl1_pitch, dst_pitch)) < (1ll << 24) && h * std::max(frame_pitch, std::max(cl1_pitch, dst_pitch)) < (1ll << 31) &&
+                     ((w + 7) / 8) * h < (1ll << 31);
     SHG_PROF("products", st);
     for (int64_t i0 = 0; i0 < k; i0 += kProductsBatch) {
         const int m = (int)std::min<int64_t>(kProductsBatch, k - i0);
@@ -413,11 +465,13 @@ int shg::contrast_products_batch(const uint16_t* const* host_frames, int64_t fra
                        hc = shg::make_batch_n<kProductsBatch>(host_hc, (int)i0, m), pr = shg::make_batch_n<kProductsBatch>(host_protus, (int)i0, m),
                        cc = shg::make_batch_n<kProductsBatch>(host_cc, (int)i0, m);
         if (vec) {
-            const int64_t lanes = ((w + 7) / 8) * ((h + PROD_ROWS - 1) / PROD_ROWS);
+            const int64_t nv = (w + 7) / 8, lanes = nv * h;
+            uint32_t nv_shift = 0;
+            while ((2ull << nv_shift) < (uint64_t)nv) ++nv_shift;
+            const uint32_t nv_magic = (uint32_t)(((1ull << (32 + nv_shift)) + (uint64_t)nv - 1) / (uint64_t)nv);
+            const ProductsArgs args{f, frame_pitch, c, cl1_pitch, h, w, bb, hc, pr, cc, dst_pitch, disc_x0, disc_y0, disc_r > 0 ? disc_r : 0, src, nv_magic, nv_shift};
             dim3 grid((unsigned)((lanes + 255) / 256), 1u, (unsigned)m);
-            if (int e = shg::launch(k_products8, grid, dim3(256), 0, st,
-                                   ProductsArgs{f, frame_pitch, c, cl1_pitch, h, w, bb, hc, pr, cc, dst_pitch, disc_x0, disc_y0, disc_r > 0 ? disc_r : 0, src}, "k_products8"))
-                return e;
+            if (int e = shg::launch(k_products8, grid, dim3(256), 0, st, args, "k_products8")) return e;
         } else {
             dim3 grid((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)m);
             k_products<<<grid, 256, 0, st>>>(f, frame_pitch, c, cl1_pitch, w, bb, hc, pr, cc, dst_pitch, disc_x0, disc_y0, disc_r > 0 ? disc_r : 0, src);

@@ -806,6 +806,45 @@ def test_row_kernels_on_widths_around_their_vector_and_workgroup_sizes(ops, h, w
     np.testing.assert_array_equal(protus, want_p)
 
 
+@pytest.mark.parametrize('bounds', [
+    [0.0, 65535.0, 0.0, 65535.0, 0.0, 65535.0],              # q = px: every quotient whole -- every lane takes the exact division
+    [1000.0, 14107.0, 0.0, 13107.0, 2000.0, 15107.0],        # span 13107 = 65535 / 5: q = 5 (px - lo), whole again
+    [100.0, 103.0, 0.0, 3.0, 65000.0, 65535.0],              # tiny spans: quotients far beyond 65535, some beyond int32's reach of a fraction
+    [16383.75, 65535.0, 0.0, 11796.3, 12345.0, 65535.0],     # the shape image_process gives them (0.25 / 0.18 of the brightest, an integral dark level)
+    [0.5, 65534.5, 0.0, 1e-3, 7.0, 8.0],                     # a span of 1e-3: every quotient but 0 saturates the conversion
+])
+@pytest.mark.parametrize('disc', [None, (40, 30, 25), (-500, 20, 600), (90, 400, 380), (50, 30, 1), (50, 30, 32000)])
+def test_products_where_the_short_way_must_not_be_trusted(ops, bounds, disc):
+    """k_products8 computes 65535 (px - lo) / span as a product with 1 / span and lets the exact division decide for a lane any of whose
+    24 quotients lies within 1e-7 of a whole number (round 6: one decision per lane, not one branch per quotient).  Bounds that make
+    EVERY quotient whole, black pixels under lo = 0, pixels equal to lo, quotients beyond 65535 and beyond int32, and discs that
+    cover the image, miss it, start left of it or are a single pixel: the three products equal rescale_brightness
+    (solex_util.py:519-524) and cv2.circle's fill, pixel for pixel."""
+    h, w = 61, 104
+    rng = np.random.default_rng(int(bounds[0] * 7 + bounds[3]) & 0xffff)
+    img = rng.integers(0, 65536, (h, w)).astype(np.uint16)
+    img[::3, ::5] = 0
+    img[1::4, 2::7] = 65535
+    for k, v in enumerate(bounds):
+        img[5 + k, 10:40] = np.uint16(min(max(int(v), 0), 65535))
+    cl1 = np.ascontiguousarray(img[::-1, ::-1])
+
+    def rescale(a, lo, hi):
+        v = 65535.0 * (a.astype(np.float64) - lo) / (hi - lo)
+        return np.clip(v, 0, 65535).astype(np.uint16)
+    hc, protus, cc = (host(t) for t in ops.contrast_products_u16(dev(img), dev(cl1), bounds, disc))
+    np.testing.assert_array_equal(hc, rescale(img, bounds[0], bounds[1]))
+    np.testing.assert_array_equal(cc, rescale(cl1, bounds[4], bounds[5]))
+    want_p = rescale(img, bounds[2], bounds[3])
+    if disc is not None:
+        import math
+        yy, xx = np.mgrid[0:h, 0:w]
+        ady = np.abs(yy - disc[1])
+        half = np.vectorize(lambda d: math.isqrt(max(disc[2] ** 2 - int(d) ** 2, 0)))(ady)
+        want_p[(ady <= disc[2]) & (np.abs(xx - disc[0]) <= half)] = 80
+    np.testing.assert_array_equal(protus, want_p)
+
+
 @pytest.mark.parametrize('h,w,tiles', [(96, 104, 2), (130, 200, 2), (257, 2096, 2), (1000, 1048, 2), (90, 120, 3), (77, 50, 2)])
 def test_contrast_stats_is_clahe_plus_the_order_statistics(ops, orc, h, w, tiles):
     """shg_contrast_stats_u16 (the first half of image_process in one call): the blend that lays its lanes out in 16 x 16 tiles and counts the
