@@ -281,17 +281,28 @@ extern "C" int shg_host_line_fit(const int32_t* host_trace_blur, const int32_t* 
     // residual -- takes the sort (16 us of a scan's critical path for 2000 rows)
     bool counted = n > 0;
     double kmin = 0, kmax = 0;
+    std::vector<double> ks((size_t)n);
     for (int64_t i = 0; i < n && counted; ++i) {
-        const double k = rint(ds[i] * 10.0);
+        const double k = ks[i] = rint(ds[i] * 10.0);
         if (!(fabs(k) < 1e9)) { counted = false; break; }
         kmin = i == 0 || k < kmin ? k : kmin;
         kmax = i == 0 || k > kmax ? k : kmax;
     }
     if (counted && kmax - kmin <= 65536.0) {
+        // (-0.0 and 0.0 share a bin, as they share a run of the sort -- there the run's first element, whichever the sort left first,
+        // is the value reported; here +0.0 unless every zero of the bin is -0.0.  The value only ever enters |ds - shift| < 5 below.)
         std::vector<int64_t> bins((size_t)(kmax - kmin) + 1, 0);
-        for (int64_t i = 0; i < n; ++i) ++bins[(size_t)(rint(ds[i] * 10.0) - kmin)];      // (-0.0 and 0.0 share a bin, as they share a run of the sort)
+        bool plus_zero = false;
+        for (int64_t i = 0; i < n; ++i) {
+            ++bins[(size_t)(ks[i] - kmin)];
+            plus_zero = plus_zero || (ks[i] == 0.0 && !std::signbit(ks[i]));
+        }
         for (size_t b = 0; b < bins.size(); ++b)
-            if (bins[b]) { values.push_back(((double)b + kmin) / 10.0); counts.push_back(bins[b]); }
+            if (bins[b]) {
+                const double k = (double)b + kmin;
+                values.push_back(k == 0.0 && !plus_zero ? -0.0 : k / 10.0);
+                counts.push_back(bins[b]);
+            }
     } else {
         std::vector<double> sorted(rounded);
         std::sort(sorted.begin(), sorted.end());

@@ -235,8 +235,8 @@ __device__ __forceinline__ uint32_t rescale1_fast(double px, double lo, double s
 // dozen lanes to do.
 // grid (ceil(vectors / 256), 1, disks)
 //
-// Round 6, second half: the kernel was bound by the vector instructions it issues (SQ_INSTS_VALU x 4 cycles = 0.96 of its duration at
-// 70 a pixel, profiles/r06_sq_k_products8.json), a third of them per THREAD, not per pixel: the bounds from the statistics, three IEEE
+// Round 6, second half: the kernel issued 70 vector instructions a pixel (96 M wave instructions a C4 launch, profiles/
+// r06_sq_k_products8.json of the round's fourth collection), a third of them per THREAD, not per pixel: the bounds from the statistics, three IEEE
 // divisions for 1 / span, the disc's half width by a float64 square root and 64-bit fix-up loops, 64-bit addresses -- for eight
 // pixels.  Now: 1 / span is the hardware's reciprocal and two Newton steps (its error, 2^-52, moves q by 1e-11: the near-whole test
 // below allows 1e-7); the half width is a float square root and two 32-bit fix-ups (radii below 32768: the host checks); row and

@@ -160,11 +160,15 @@ __device__ __forceinline__ void select2(KeyFn key, int n, int64_t rank_lo, int64
 // per-lane index compare, no juggling of the exec mask: three of the eight to ten VALU instructions an element cost in the plain
 // `for (i = tid; i < n; i += NT)` form, and this kernel is bound by its VALU instructions -- and one last round for the lanes below n % NT.
 // (n must be uniform over the workgroup.)
-template <typename F>
+template <bool UNROLL = true, typename F>
 __device__ __forceinline__ void sweep(int n, F body) {
     const int rounds = __builtin_amdgcn_readfirstlane(n / NT);
+    if (UNROLL) {
 #pragma unroll 2
-    for (int r = 0; r < rounds; ++r) body((int)threadIdx.x + r * NT);
+        for (int r = 0; r < rounds; ++r) body((int)threadIdx.x + r * NT);
+    } else {                                 // (a body with a ballot: the compiler will not unroll it, and says so)
+        for (int r = 0; r < rounds; ++r) body((int)threadIdx.x + r * NT);
+    }
     const int last = (int)threadIdx.x + rounds * NT;
     if (last < n) body(last);
 }
@@ -175,8 +179,8 @@ __device__ __forceinline__ void sweep(int n, F body) {
 // of ~2000 for real rows) are ranked against each other.  A crowded bucket is bucketed again between its own extrema.  Returns false
 // (block-uniform) when it gives up: the caller then runs select2.
 //
-// Round 6: this kernel is bound by the vector instructions it issues (SQ_INSTS_VALU x 4 cycles = 90 % of its duration, profiles/
-// r06_sq_k_rowpair_stats.json) and a thread has only ~7 values, so what a select costs per WORKGROUP counts as much as what it costs
+// Round 6: this kernel's time follows the vector instructions it issues (150 M wave instructions a C4 launch, 135 a pixel pair,
+// profiles/r06_sq_k_rowpair_stats.json; 21 % fewer of them: 14 % less time) and a thread has only ~7 values, so what a select costs per WORKGROUP counts as much as what it costs
 // per value: (a) the buckets' prefix sum and the search for the two ranks are one wave's work (eight buckets a lane) instead of
 // every wave repeating them, in 32-bit counts; (b) 1 / (hi - lo) is the hardware's approximate reciprocal -- the map only has to
 // be monotone --, the bucket one multiply-add; (c) the candidates are the values whose position lies in [b0, b1 + 1): two compares
@@ -518,7 +522,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8))) void k_
     const bool all = !(mdev != 0.0);                                       // s = d/mdev if mdev else zeros; data[s < 2] (see above)
     double s = 0.0;
     uint32_t kept = 0;                                                     // (the wave's count, in a scalar register)
-    sweep(n, [&](int i) {
+    sweep<false>(n, [&](int i) {
         const double x = vals[i];
         const bool keep = all || fabs(x - med) < twice;
         kept += (uint32_t)__popcll(__ballot(keep));

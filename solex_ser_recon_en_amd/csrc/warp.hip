@@ -142,8 +142,8 @@ __global__ __launch_bounds__(256) void k_warp_rows(const WarpArgs kargs) {
 // pixel's pair back with one ds_read_b32 at an offset of its own; one 16-byte store.  4 vector-memory instructions for 8 pixels a lane
 // instead of 24.  Same float64 arithmetic, unfused -- but no more of it than the result needs: the column term as one fma, no test for
 // whole positions, the clip on integers.
-// The kernel is bound by the vector instructions it issues (SQ_INSTS_VALU x 4 cycles = 0.9 of its duration at 42 a pixel, profiles/
-// r06_sq_k_warp_rows8.json), so the second half of round 6 counted them: waves whose samples all lie inside their rows skip the
+// The kernel's time follows the vector instructions it issues (57.8 M wave instructions a C4 launch, 42 a pixel: profiles/
+// r06_sq_k_warp_rows8.json; 28 % fewer of them: 19 % less time), so the second half of round 6 counted them: waves whose samples all lie inside their rows skip the
 // border tests (-6 a pixel), pairs instead of words in LDS (-3), flat / nv as a multiply-high (-2), 32-bit byte offsets off the
 // scalar image bases (-2), the first pixel's position from the placement (-1): ~29 a pixel, 18 in the blend itself.
 // C4: 115 (k_warp_rows) -> 104 -> 82 - 85 us (profiles/r06_sweeps.txt).
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void k
         uint32_t out[8];
         // INSIDE: every sample of the wave's 64 vectors lies in its row (all but the waves over the image's left and right edges):
         // no tests against the row's width, no cval, no clamp of the window offset -- 6 of a pixel's ~36 vector instructions, and
-        // the kernel is bound by those (SQ_INSTS_VALU x 4 cycles = 0.9 of its duration, profiles/r06_sq_k_warp_rows8.json).
+        // the kernel's time follows those (see above).
         auto pixels = [&](auto inside_tag) {
             constexpr bool INSIDE = decltype(inside_tag)::value;
 #pragma unroll
