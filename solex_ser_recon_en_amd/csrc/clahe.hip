@@ -233,47 +233,48 @@ template <bool FUSED, int BITS> __global__ __launch_bounds__(1024) void k_tile_h
             const int64_t xa8 = (xa + 7) & ~(int64_t)7, xb8 = max(xb & ~(int64_t)7, xa8);
             const int nvr = (int)((xb8 - xa8) / 8);
             const int n_head = (int)(min(xa8, xb) - xa), n_tail = (int)(xb - max(xb8, xa + n_head)), n_edge = n_head + n_tail + (int)(xbase + tw - xb);
-            for (int yy = ca + wave; yy <= cb; yy += 32) {
-                const bool two = yy + 16 <= cb;
-                int64_t y0 = ty * th + yy, y1 = ty * th + (two ? yy + 16 : yy);
-                const bool border0 = y0 >= h, border1 = y1 >= h;             // rows of the reflected border: counted, not stored
-                if (border0) y0 = mirror101(y0, h);
-                if (border1) y1 = mirror101(y1, h);
-                const uint16_t* s0 = FUSED ? raw + y0 * fs.raw_pitch : img + y0 * pitch;
-                const uint16_t* s1 = FUSED ? raw + y1 * fs.raw_pitch : img + y1 * pitch;
-                const uint4* r0 = reinterpret_cast<const uint4*>(s0 + xa8);
-                const uint4* r1 = reinterpret_cast<const uint4*>(s1 + xa8);
-                const double c0 = FUSED ? cf[yy - ya] : 1.0, c1 = FUSED ? cf[(two ? yy + 16 : yy) - ya] : 1.0;
-                const double k0 = c0 * 0x1p+52, k1 = c1 * 0x1p+52;
-                for (int v0 = lane; v0 < nvr; v0 += 64 * 3) {
-                    uint4 q[2][3];
+            // Round 6: the chunk's whole vectors as ONE flat sequence, (row, vector) = (i / nvr, i % nvr), four of them per thread in
+            // flight.  Dealt row by row -- a wave two rows a round, three vector slots a lane -- a 1048-pixel tile (131 vectors) left the
+            // third slot to 3 lanes of 64 and half of the second's second row idle: 12 slots a lane for 8 vectors, a third of the
+            // count's instructions spent on masked-off lanes.
+            {
+                const uint32_t nvr_u = (uint32_t)nvr, total_v = (uint32_t)(cb - ca + 1) * nvr_u;
+                const float inv_nvr = nvr > 0 ? 1.0f / (float)nvr : 0.0f;
+                constexpr int U = 4;
+                for (uint32_t i0 = threadIdx.x; i0 < total_v; i0 += 1024u * U) {
+                    uint4 q[U];
+                    int64_t yv[U];
+                    uint32_t vv[U], rowv[U];
+                    bool borderv[U];
 #pragma unroll
-                    for (int u = 0; u < 3; ++u) {
-                        const int vi = v0 + 64 * u < nvr ? v0 + 64 * u : v0;
-                        q[0][u] = r0[vi];
-                        q[1][u] = r1[vi];
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t i = i0 + 1024u * u < total_v ? i0 + 1024u * u : i0;
+                        uint32_t r = (uint32_t)((float)i * inv_nvr);              // i / nvr, within one (i < 2^16): set right below
+                        r -= (r * nvr_u > i) ? 1u : 0u;
+                        r += ((r + 1u) * nvr_u <= i) ? 1u : 0u;
+                        rowv[u] = r;
+                        vv[u] = i - r * nvr_u;
+                        int64_t y = ty * th + ca + (int64_t)r;
+                        borderv[u] = y >= h;                                       // a row of the reflected border: counted, not stored
+                        if (borderv[u]) y = mirror101(y, h);
+                        yv[u] = y;
+                        const uint16_t* srow = FUSED ? raw + y * fs.raw_pitch : img + y * pitch;
+                        q[u] = reinterpret_cast<const uint4*>(srow + xa8)[vv[u]];
                     }
 #pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) {
-                        if (rr == 1 && !two) break;
+                    for (int u = 0; u < U; ++u) {
+                        if (i0 + 1024u * u >= total_v) break;
+                        uint32_t d[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+                        if (FUSED) {
+                            if (scaled) {
+                                const double cy = cf[ca - ya + (int)rowv[u]], kc = cy * 0x1p+52;
 #pragma unroll
-                        for (int u = 0; u < 3; ++u) {
-                            if (v0 + 64 * u >= nvr) break;
-                            uint32_t d[4] = {q[rr][u].x, q[rr][u].y, q[rr][u].z, q[rr][u].w};
-                            if (FUSED) {
-                                if (scaled) {
-                                    const double cy = rr ? c1 : c0, kc = rr ? k1 : k0;
-#pragma unroll
-                                    for (int j = 0; j < 4; ++j) d[j] = (scale_px_fma(d[j] & 0xffffu, cy, kc) & 0xffffu) | (scale_px_fma(d[j] >> 16, cy, kc) << 16);
-                                }
-                                if (!(rr ? border1 : border0)) {
-                                    uint4* dst = reinterpret_cast<uint4*>(fin + (rr ? y1 : y0) * pitch + xa8);
-                                    dst[v0 + 64 * u] = make_uint4(d[0], d[1], d[2], d[3]);
-                                }
+                                for (int j = 0; j < 4; ++j) d[j] = (scale_px_fma(d[j] & 0xffffu, cy, kc) & 0xffffu) | (scale_px_fma(d[j] >> 16, cy, kc) << 16);
                             }
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) { count(d[j] & 0xffffu); count(d[j] >> 16); }
+                            if (!borderv[u]) reinterpret_cast<uint4*>(fin + yv[u] * pitch + xa8)[vv[u]] = make_uint4(d[0], d[1], d[2], d[3]);
                         }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { count(d[j] & 0xffffu); count(d[j] >> 16); }
                     }
                 }
             }
