@@ -475,6 +475,11 @@ def test_warp_golden_bit_exact(ops, golden):
     (64, 200, 64, 131, 1.76, 0.0, 0.0),             # beyond it: the narrow kernel serves
     (64, 200, 64, 300, 0.31, 0.0, 190.0),           # neighbouring outputs share their samples; most of the row beyond the image
     (33, 9, 33, 40, 1.0, 0.5, -3.0),                # an image narrower than a piece's stride
+    (70, 4200, 70, 4200, 0.98, 0.004, 17.3),        # wide: most waves lie inside their rows (the copy of the blend without border tests)
+    (50, 300, 50, 300, 1.0, 0.0, -1e-13),           # a hair left of whole positions: weights 1e-13 and 1 - 1e-13, the first pixel at -1e-13
+    (40, 64, 40, 16, 1.0, 0.0, 3.0),                # two vectors a row: the smallest divisor of the multiply-high
+    (40, 5000, 40, 4096, 1.2, 0.0, -7.5),           # 512 vectors a row: a power of two
+    (2100, 8200, 2100, 8192, 0.999, 0.0001, 2.0),   # 2.15 M vectors: four of them a thread
 ])
 def test_warp_eight_pixels_a_lane_equals_one_pixel_a_lane(ops, monkeypatch, h, w, oh, ow, h00, h01, h02):
     """k_warp_rows8 (round 6: three 16-byte pieces of the source row per lane, LDS window, one 16-byte store) against k_warp_rows
@@ -1132,6 +1137,58 @@ def test_rowpair_stats_with_heavily_tied_ratios(ops, orc, levels):
         xa[y - y1], xb[y - y1] = a, max(a, b)
     got = host(ops.rowpair_logratio_stats(dev(img), y1, y2, dev(xa), dev(xb)))
     np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-15)
+
+
+def test_rowpair_stats_row_by_row_over_the_shapes_the_bucket_select_has_to_survive(ops, orc):
+    """One row pair per shape, every one against np.mean(reject_outliers(np.log(row / row_before))) (solex_util.py:81-86, 384-395):
+    chords of 1 to 2600 pixels on either side of a workgroup's 256 threads and of a wave's eight buckets a lane; rows whose ratios
+    are all equal (sigma 0: the radix select), nearly all equal (every value in one bucket: the bucket select's second level),
+    bimodal (the middle ranks' bucket far from the mean), with one wild pixel (sigma set by an outlier), with zero pixels (-inf, +inf
+    and NaN ratios) and all black; round 6's rough float sums and one-wave bucket scan must steer the select, never change it."""
+    rng = np.random.default_rng(66)
+    w = 2700
+    shapes = []
+    for n in (1, 2, 3, 7, 8, 9, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1023, 1025, 2047, 2049, 2600):
+        shapes.append(('noise', n))
+    for kind in ('flat', 'nearly_flat', 'bimodal', 'wild', 'zeros', 'black', 'ramp', 'two_values'):
+        for n in (5, 300, 1800):
+            shapes.append((kind, n))
+    h = len(shapes) + 1
+    img = np.empty((h, w), np.uint16)
+    img[0] = rng.integers(9000, 11000, w)
+    xa = np.zeros(h, np.int32)
+    xb = np.zeros(h, np.int32)
+    for t, (kind, n) in enumerate(shapes, start=1):
+        prev = img[t - 1].astype(np.int64)
+        prev = np.where(prev == 0, 10000, prev)
+        a = int(rng.integers(0, w - n + 1))
+        xa[t], xb[t] = a, a + n
+        row = (prev * (1 + 0.01 * rng.standard_normal(w))).clip(1, 65535)
+        if kind == 'flat':
+            row = prev * 2
+        elif kind == 'nearly_flat':
+            row = prev * 2
+            row[a + n // 2] += 1
+        elif kind == 'bimodal':
+            row = np.where(rng.random(w) < 0.5, prev * 0.5, prev * 1.9)
+        elif kind == 'wild':
+            row[a + n // 3] = 65535 if prev[a + n // 3] < 30000 else 1
+        elif kind == 'zeros':
+            row[a:a + n:4] = 0
+        elif kind == 'black':
+            row[:] = 0
+        elif kind == 'ramp':
+            row = prev + np.arange(w) % 7
+        elif kind == 'two_values':
+            row = np.where(np.arange(w) % 3 == 0, prev, prev + 1)
+        img[t] = np.clip(row, 0, 65535).astype(np.uint16)
+    with np.errstate(all='ignore'):
+        want = np.array([0.0] + [np.mean(orc.reject_outliers(np.log(img[t, xa[t]:xb[t]] / img[t - 1, xa[t]:xb[t]]))) for t in range(1, h)])
+    got = host(ops.rowpair_logratio_stats(dev(img), 0, h, xa, xb))
+    assert np.array_equal(np.isnan(got), np.isnan(want)), (np.flatnonzero(np.isnan(got) != np.isnan(want)), [shapes[i - 1] for i in np.flatnonzero(np.isnan(got) != np.isnan(want))])
+    ok = ~np.isnan(want)
+    bad = np.flatnonzero(ok & ~np.isclose(got, want, rtol=1e-12, atol=1e-15, equal_nan=True) & ~(np.isinf(want) & (got == want)))
+    assert bad.size == 0, [(shapes[i - 1], got[i], want[i]) for i in bad[:8]]
 
 
 # ---- the limb stage's fused kernels against the one-kernel-per-call chain (csrc/limb_fused.hip vs csrc/limb.hip) ----------
