@@ -204,31 +204,6 @@ __device__ __forceinline__ bool bounds_from_stats(const StatsSource& src, int di
            bright_clahe > dark_clahe;
 }
 
-// rescale1 without the division for all but a handful of pixels.  t = 65535 * (px - lo) is rounded as the reference
-// rounds it; q = t * (1 / span) is within 2^-50 * 65535 < 1e-10 of the correctly rounded t / span, so unless q sits that
-// close to a whole number both truncate to the same integer (and clamp alike beyond 0 / 65535).  The rare pixel near a
-// boundary takes the exact division.  Three float64 divisions per pixel made k_products ALU bound (20 us
-// for 40 MB of traffic, see profiles/).
-__device__ __forceinline__ uint32_t rescale1_fast(double px, double lo, double span, double inv_span) {
-    const double t = 65535.0 * (px - lo);
-    const double q = t * inv_span;
-    // Round 6: the same decision with 6 float64 instructions instead of 10 and no float64 compare (two of them, a floor and three
-    // branches a pixel made the kernel VALU bound at 0.66 of its bytes): r = trunc(q) (saturating), fr = q - r in (-1, 1), and
-    // "q within 1e-7 of a whole number" is read off the high word of |fr| -- below that of 1e-7 or from that of 1 - 1e-7 on (both a
-    // shade wider than the limits: more pixels take the exact division, none fewer).  Beyond [0, 65535] the clamps decide as before.
-    const int r = (int)q;
-    const double fr = q - (double)r;
-    const uint32_t hi = (uint32_t)__double2hiint(fr) & 0x7fffffffu;
-    const bool near_whole = hi < 0x3E7AD7F3u || hi >= 0x3FEFFFFFu;
-    if (near_whole && r >= -1 && r <= 65536) {
-        double v = t / span;
-        v = v < 0.0 ? 0.0 : v;
-        v = v > 65535.0 ? 65535.0 : v;
-        return (uint32_t)(int)v;
-    }
-    return (uint32_t)min(max(r, 0), 65535);
-}
-
 // Eight pixels per lane: 16-byte loads of frame and cl1, 16-byte stores of the three products (rows 16-byte aligned,
 // pitches multiples of 8; a row's last, partial vector goes pixel by pixel).  Lanes are dealt (row, 8-column vector) pairs in one flat
 // sequence -- a width just past a multiple of 2048 pixels (2096 at C2) would leave every second workgroup of a (x, y) grid with half a
@@ -258,11 +233,14 @@ struct ProductsArgs {
     uint32_t nv_magic, nv_shift;         // flat / (vectors a row) = __umulhi(flat, nv_magic) >> nv_shift (see k_warp_rows8's host side)
 };
 
-// The short way of rescale1_fast, and whether the exact division has to decide (rescale1_fast says why that is the only case): the
-// quotient's fraction is >= 0 here, "within 1e-7 of a whole number" is its high word outside [A, B) = [that of 1e-7, that of 1 - 1e-7)
-// (a shade wider: more pixels in doubt, none fewer), i.e. (hi - A) >= B - A unsigned -- and a lane only has to know whether ANY of
-// its 24 quotients is: the largest hi - A, one v_max_u32 a quotient instead of a compare and a scalar or (and 24 flags kept in
-// registers until the end: 134 of them, three waves a SIMD).  A quotient beyond int32 or infinite has a "fraction" >= 1: in doubt.
+// rescale1 without the division for all but a handful of pixels.  t = 65535 * (px - lo) is rounded as the reference rounds it;
+// q = t * (1 / span) is within 2^-50 * 65535 < 1e-10 of the correctly rounded t / span, so unless q sits that close to a whole number
+// both truncate to the same integer (and clamp alike beyond 0 / 65535); a pixel near a whole number takes the exact division (three
+// float64 divisions per pixel made the first k_products ALU bound).  This is the short way, and whether the exact division has to
+// decide: r = trunc(q), the fraction fr = q - r is >= 0 here, "within 1e-7 of a whole number" is fr's high word outside [A, B) = [that
+// of 1e-7, that of 1 - 1e-7) (a shade wider: more pixels in doubt, none fewer), i.e. (hi - A) >= B - A unsigned -- and a lane only has
+// to know whether ANY of its 24 quotients is: the largest hi - A, one v_max_u32 a quotient instead of a compare and a scalar or (and 24
+// flags kept in registers until the end: 134 of them, three waves a SIMD).  A quotient beyond int32 or infinite has a "fraction" >= 1: in doubt.
 constexpr uint32_t kFracA = 0x3E7AD7F3u, kFracB = 0x3FEFFFFFu;
 __device__ __forceinline__ uint32_t rescale1_quick(double px, double lo, double inv_span, uint32_t& worst) {
     // (a quotient at or below 0 -- a black pixel under lo = 0, a pixel equal to an integral lo: every such one exactly 0, i.e. "whole" --
