@@ -496,8 +496,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8))) void k_
         va = key_f64(ka);
         vb = key_f64(kb);
     };
+    // The buckets' range: mean +- 1 sigma for the median, [0, 1 sigma] for the MAD (0.67 sigma for clean data).  A row's sigma is set by the
+    // few pixel pairs at its limb ends (0.06 where the bulk's is 0.007: in-kernel clock + counts, profiles/r06_sweeps.txt), and with +- 3 /
+    // [0, 2] sigma such a row's middle bucket held 45 - 120 candidates -- whose ranking against each other (a loop of LDS reads per
+    // candidate) made its selects take twice a clean row's.  A median beyond 1 sigma of the mean lands in an end bucket: second level.
+    const double kMedSpan = 1.0, kMadSpan = 1.0;
     auto row_val = [&](int i) { return vals[i]; };
-    if (!(finite && select2_buckets(row_val, n, lo, hi, mean - 3.0 * sigma, mean + 3.0 * sigma, sc, va, vb)))
+    if (!(finite && select2_buckets(row_val, n, lo, hi, mean - kMedSpan * sigma, mean + kMedSpan * sigma, sc, va, vb)))
         general([&](int i) { return f64_key(vals[i]); });
     const double med = (n & 1) ? va : (va + vb) / 2.0;
     if (!finite) {                       // (finite values and a finite median cannot make a NaN)
@@ -512,7 +517,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8))) void k_
         }
     }
     auto dev_val = [&](int i) { return fabs(vals[i] - med); };
-    if (!(finite && select2_buckets(dev_val, n, lo, hi, 0.0, 2.0 * sigma, sc, va, vb)))
+    if (!(finite && select2_buckets(dev_val, n, lo, hi, 0.0, kMadSpan * sigma, sc, va, vb)))
         general([&](int i) { return f64_key(fabs(vals[i] - med)); });    // |x - med| >= 0: its bit pattern is already order preserving
     const double mdev = (n & 1) ? va : (va + vb) / 2.0;
     // `dev / mdev < 2` as `dev < 2 * mdev`: the rounded quotient is below 2 exactly when the true one is below 2 - 2^-53, and no
